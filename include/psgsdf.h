@@ -1,0 +1,232 @@
+/* psgsdf.h — C ABI of the MI355X-native Gradient-SDF photometric-stereo engine.
+ *
+ * This header is the drop-in boundary for the reference's photometric-stereo hot path.
+ * The reference (Sangluisme/PSgradientSDF) has no FFI of its own: the seam is the C++
+ * class interface that `main()` drives (cpp/voxel_ps/src/main_ps.cpp:193-202,323-330):
+ *
+ *     vOpt = new PsOptimizer|LedOptimizer(tSDF, voxel_size, K, output, opt_set_);
+ *     vOpt->setImages(..); vOpt->setKeyframes(..); vOpt->setKeytimestamps(..); vOpt->setPoses(..);
+ *     vOpt->init();  vOpt->alternatingOptimize(light, albedo, distance, pose);
+ *
+ * Every entry point below names the reference member it replaces (file:line under
+ * /root/reference/cpp/include/).  All pointers are plain host pointers unless a name ends
+ * in `_dev`; sizes are element counts; there are no C++/torch types in any signature.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative psgsdf_status otherwise and never throws;
+ *     psgsdf_last_error(ctx) gives the message of the last failure on that context.
+ *   - volume arrays are x-fastest (lin = i + j*Nx + k*Nx*Ny, VoxelGrid.h:79-82), SoA planes.
+ *   - images are float32 RGB (not OpenCV BGR), row-major H x W x 3, values in [0,1].
+ *   - poses are 4x4 row-major camera->world (Optimizer.h:52-60).
+ *   - a context is owned by one host thread; it is not thread-safe (the reference is
+ *     single-threaded and not re-entrant either).
+ */
+#ifndef PSGSDF_H_
+#define PSGSDF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct psgsdf_ctx psgsdf_ctx;
+
+enum psgsdf_status {
+    PSGSDF_OK = 0,
+    PSGSDF_ERR_ARG = -1,        /* bad argument / call order                               */
+    PSGSDF_ERR_DEVICE = -2,     /* HIP runtime error (no device, OOM, launch failure)       */
+    PSGSDF_ERR_UNSUPPORTED = -3,/* a setting the engine does not implement (e.g. reg albedo) */
+    PSGSDF_ERR_STATE = -4,      /* called before the required earlier call                  */
+    PSGSDF_ERR_COMM = -5        /* RCCL failure                                             */
+};
+
+/* ModelType, OptimizerSettings.h:18-22 */
+enum psgsdf_model { PSGSDF_SH1 = 0, PSGSDF_SH2 = 1, PSGSDF_LED = 2 };
+/* LossFunction, OptimizerSettings.h:9-16 (same numeric values) */
+enum psgsdf_loss { PSGSDF_L2 = 0, PSGSDF_CAUCHY = 1, PSGSDF_HUBER = 2, PSGSDF_TUKEY = 3, PSGSDF_TRUNC_L2 = 4 };
+/* the four blocks of alternatingOptimize(light, albedo, distance, pose), Optimizer.h:178 */
+enum psgsdf_block { PSGSDF_ALBEDO = 1, PSGSDF_LIGHT = 2, PSGSDF_DIST = 4, PSGSDF_POSE = 8, PSGSDF_ALL = 15 };
+
+/* VoxelGrid(grid_dim, voxel_size, shift) + Sdf(T): VoxelGrid.h:127-133, Sdf.h:81-85.
+ * origin = shift - 0.5*voxel_size*dim is derived inside (VoxelGrid.h:130). */
+typedef struct psgsdf_grid_desc {
+    int32_t dim[3];
+    float voxel_size;
+    float shift[3];      /* grid centre (the depth centroid in main_ps.cpp:178-183) */
+    float truncation;    /* T = truncation_factor * voxel_size (main_ps.cpp:86)      */
+} psgsdf_grid_desc;
+
+/* OptimizerSettings (OptimizerSettings.h:24-51) + the engine-only knobs at the end. */
+typedef struct psgsdf_settings {
+    int32_t model;          /* psgsdf_model                                                   */
+    int32_t loss;           /* psgsdf_loss                                                    */
+    float lambda;           /* robust-loss scale                                              */
+    float damping;          /* LM damping: H_ii *= (1+damping)                                */
+    float reg_weight_rho;   /* "reg albedo"   (must be 0: PSGSDF_ERR_UNSUPPORTED otherwise)   */
+    float reg_weight_n;     /* "reg norm"     Eikonal weight                                  */
+    float reg_weight_l;     /* "reg laplacian"                                                */
+    int32_t max_it;         /* "max iter"                                                     */
+    float conv_threshold;   /* "converge threshold"                                           */
+    int32_t upsample;       /* "upsample": 2x refine at iteration 5                           */
+    /* engine-only */
+    int32_t ref_quirks;     /* 1 = replicate reference quirks (B6 LED sign,
+                               B8 CG-gated updates); 0 = corrected variants                  */
+    int32_t cg_max_it;      /* cap for the distance PCG; <=0 = Eigen's default 2*n            */
+} psgsdf_settings;
+
+/* per-sub-step statistics returned by psgsdf_step */
+typedef struct psgsdf_step_stats {
+    int32_t block;          /* psgsdf_block that ran                                          */
+    int32_t cg_iters;       /* PCG iterations of the distance solve (0 for direct solves)     */
+    int32_t cg_converged;   /* Eigen's info()==Success                                        */
+    int32_t applied;        /* 1 if the update was applied (B8 gating)                        */
+    double  e_in;           /* PS energy of the state the sweep started from                  */
+    double  cg_error;       /* final ||r||/||b||                                              */
+    int64_t n_accepted;     /* accepted per-voxel updates (OptimizerAux.cpp:149,183)          */
+    int64_t n_obs;          /* visible, in-image observations seen by the sweep               */
+} psgsdf_step_stats;
+
+/* one record per Gauss-Newton iteration (the body of the while loop, PsOptimizer.cpp:303-425) */
+typedef struct psgsdf_iter_stats {
+    double e_after[4];      /* PS energy after albedo / light / dist / pose (NaN if block off) */
+    double e_n, e_l;        /* un-weighted Eikonal / Laplacian energies after the dist step    */
+    double e_total;         /* getTotalEnergy at the end of the iteration                      */
+    double rel_diff;        /* |E_prev - E_total| / E_prev                                     */
+    float  reg_weight_n;    /* effective (normalised) weights in force, PsOptimizer.cpp:277,283 */
+    float  reg_weight_l;
+    int32_t cg_iters;
+    int32_t converged;      /* rel_diff < conv_threshold                                       */
+    int32_t diverged;       /* E_total > E_prev                                                */
+    int32_t upsampled;      /* this iteration ended with the 2x refine                         */
+} psgsdf_iter_stats;
+
+/* sizes the caller needs for downloads */
+typedef struct psgsdf_info {
+    int32_t dim[3];
+    float voxel_size;
+    float origin[3];
+    int32_t n_frames;
+    int32_t n_band;         /* |surface_points_|                                               */
+    int32_t light_stride;   /* 4 (SH1), 9 (SH2), 3 (LED: one global RGB vector, n=1)           */
+    int32_t vis_words;      /* 64-bit words of keyframe visibility per voxel                   */
+    float reg_weight_n, reg_weight_l;   /* current effective weights                          */
+} psgsdf_info;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+
+/* Replaces the PsOptimizer / LedOptimizer constructor (PsOptimizer.cpp:15-23,
+ * LedOptimizer.cpp:15-23, Optimizer.cpp:16-27).  K is the 3x3 row-major intrinsic matrix
+ * (only fx,fy,cx,cy are read, like OptimizerAux.cpp:209-212).  `device` is the HIP device
+ * ordinal this context lives on. */
+int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_settings* settings,
+                  int device, psgsdf_ctx** out);
+void psgsdf_destroy(psgsdf_ctx* ctx);
+const char* psgsdf_last_error(const psgsdf_ctx* ctx);
+/* version string "psgsdf-hip gfx950 <build tag>" */
+const char* psgsdf_version(void);
+
+/* ---- inputs ---------------------------------------------------------------------------- */
+
+/* Replaces the friend access to VolumetricGradSdf::tsdf_ / vis_ (VolumetricGradSdf.h:25-42):
+ * hands the fused voxel state to the engine.  dist/weight: N^3; grad_xyz, rgb: 3 planes of N^3
+ * (x|y|z, r|g|b); vis_words: N^3 * words_per_voxel 64-bit words, bit c of a voxel = "seen by
+ * integrated frame c" (the per-voxel std::vector<bool>, VolumetricGradSdf.cpp:129-130). */
+int psgsdf_upload_volume(psgsdf_ctx* ctx, const float* dist, const float* grad_xyz,
+                         const float* weight, const float* rgb,
+                         const uint64_t* vis_words, int words_per_voxel);
+
+/* Replaces setImages + setKeyframes + setPoses (Optimizer.h:137-154).  frame_idx[f] is the
+ * integration counter of keyframe f (selects the visibility bit, Optimizer.cpp:30-47). */
+int psgsdf_set_keyframes(psgsdf_ctx* ctx, int n_frames, const int32_t* frame_idx,
+                         const float* rgb_images, int width, int height, const float* poses);
+
+/* Replaces PsOptimizer::init / LedOptimizer::init (PsOptimizer.cpp:25-42,
+ * LedOptimizer.cpp:25-36): select_vis, getSurfaceVoxel, light initialisation. */
+int psgsdf_init(psgsdf_ctx* ctx);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* Optimizer::initAlbedo (Optimizer.cpp:50-81). */
+int psgsdf_init_albedo(psgsdf_ctx* ctx);
+
+/* getPSEnergy / getNormalEnergy / getLaplacianEnergy / getTotalEnergy
+ * (PsOptimizer.cpp:47-78, Optimizer.cpp:86-119, OptimizerAux.cpp:259-269):
+ * out = { E_ps, E_n, E_l, E_total } with the current effective weights. */
+int psgsdf_energy(psgsdf_ctx* ctx, double out[4]);
+
+/* The weight normalisation that opens alternatingOptimize (PsOptimizer.cpp:274-285):
+ * reg_weight_n *= E/E_n, reg_weight_l *= E/E_l.  Returns E_total in *e_total. */
+int psgsdf_normalize_weights(psgsdf_ctx* ctx, double* e_total);
+
+/* One sub-step: optimize{Albedo,Light,Dist,Poses}All (PsOptimizer.cpp:85-234,
+ * LedOptimizer.cpp:134-275).  `block` is one psgsdf_block value. */
+int psgsdf_step(psgsdf_ctx* ctx, int block, psgsdf_step_stats* stats);
+
+/* n_iters bodies of the alternation loop (PsOptimizer.cpp:303-366 / LedOptimizer.cpp:343-409)
+ * with the blocks in `flags` enabled, energies and the convergence / divergence tests
+ * evaluated for every iteration but never acted upon (no early exit, no file dumps, no
+ * upsampling).  stats may be NULL, else n_iters records. */
+int psgsdf_iterate(psgsdf_ctx* ctx, int flags, int n_iters, psgsdf_iter_stats* stats);
+
+/* The full alternatingOptimize control flow (PsOptimizer.cpp:239-428,
+ * LedOptimizer.cpp:279-478) minus file output: initAlbedo, weight normalisation, loop with
+ * convergence / divergence exit, upsample at iteration 5, Laplacian schedule.
+ * `on_iter` (may be NULL) is called after every iteration with the record and the number of
+ * completed iterations so the host can write the reference's periodic dumps
+ * (PsOptimizer.cpp:419-423); a non-zero return from it aborts the loop.
+ * Returns in *n_done the iterations run, in *result 1 = converged (reference returns true),
+ * 0 = diverged or max_it reached (reference returns false). */
+typedef int (*psgsdf_iter_cb)(void* user, int iter_done, const psgsdf_iter_stats* rec);
+int psgsdf_optimize(psgsdf_ctx* ctx, int flags, psgsdf_iter_stats* stats, int stats_cap,
+                    int* n_done, int* result, psgsdf_iter_cb on_iter, void* user);
+
+/* Optimizer::subsampling (OptimizerAux.cpp:622-684): 2x refine of grid + band rebuild. */
+int psgsdf_upsample2x(psgsdf_ctx* ctx);
+
+/* ---- outputs --------------------------------------------------------------------------- */
+
+int psgsdf_get_info(psgsdf_ctx* ctx, psgsdf_info* info);
+/* Dense state back to the host (what the reference's writers read through tSDF_->tsdf_,
+ * OptimizerAux.cpp:278-577).  Any pointer may be NULL. vis_words: N^3 * info.vis_words. */
+int psgsdf_download_volume(psgsdf_ctx* ctx, float* dist, float* grad_xyz, float* weight,
+                           float* rgb, uint64_t* vis_words);
+/* surface_points_ (ascending linear indices), n_band entries */
+int psgsdf_download_band(psgsdf_ctx* ctx, int32_t* lin_idx);
+/* poses_: n_frames * 16 row-major */
+int psgsdf_download_poses(psgsdf_ctx* ctx, float* poses);
+/* light_: n_frames * light_stride (SH) or 3 floats (LED) */
+int psgsdf_download_light(psgsdf_ctx* ctx, float* light);
+int psgsdf_upload_light(psgsdf_ctx* ctx, const float* light);
+
+/* ---- multi-GPU (z-slab partition, one context per rank) -------------------------------- */
+
+/* 128-byte RCCL unique id, generated on rank 0 and broadcast by the host program. */
+int psgsdf_comm_unique_id(uint8_t id[128]);
+/* Attach this context to rank `rank` of `n_ranks`; must be called before psgsdf_init.
+ * The band is then cut into n_ranks z-slabs of (almost) equal band count; this context owns
+ * slab `rank` and keeps one halo plane either side. */
+int psgsdf_comm_init(psgsdf_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
+
+/* ---- measurement / test hooks (not part of the reference seam) -------------------------- */
+
+/* last measured kernel durations in ms keyed by name; names[i] are static strings.
+ * Returns the number of entries written (<= cap). */
+int psgsdf_kernel_times(psgsdf_ctx* ctx, const char** names, double* ms, int64_t* launches, int cap);
+int psgsdf_reset_kernel_times(psgsdf_ctx* ctx);
+/* enable per-kernel hipEvent timing (adds a sync per launch: measurement mode only) */
+int psgsdf_set_profiling(psgsdf_ctx* ctx, int enabled);
+/* Builds the distance normal equations at the current state and returns, for the n_band rows:
+ * diag (H_ii before damping), rhs b, and y = H*x for the supplied x (may be NULL). */
+int psgsdf_debug_dist_system(psgsdf_ctx* ctx, float* diag, float* rhs, const float* x, float* y);
+/* per-frame light / pose normal equations at the current state: H (n*n row-major) and b (n)
+ * per frame, n = light_stride or 6.  `block` = PSGSDF_LIGHT or PSGSDF_POSE. */
+int psgsdf_debug_frame_system(psgsdf_ctx* ctx, int block, double* H, double* b);
+/* albedo diagonal system: H (3*n_band), b (3*n_band), channel-interleaved per row */
+int psgsdf_debug_albedo_system(psgsdf_ctx* ctx, float* H, float* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSGSDF_H_ */

@@ -1,0 +1,1292 @@
+/* psgsdf_oracle.c — CPU restatement of the reference's photometric-stereo hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under psgradientsdf_amd/ may include, link or call this
+ * file; it is the checker used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg.  The shipped product is the HIP engine (psgradientsdf_amd/csrc).
+ *
+ * PARITY UNPINNED: the reference (Sangluisme/PSgradientSDF) has no tests, golden vectors or
+ * fixtures for this path, and it cannot be built in this image (Eigen, Sophus, OpenCV,
+ * CLI11, nlohmann/json are absent).  This restatement is pinned instead by
+ * analytic known-answer tests and by the enabled form of the reference's own disabled
+ * numeric-vs-analytic Jacobian diagnostic (PsOptimizerJa.cpp:293-318,514-517) in tests/.
+ *
+ * Arithmetic follows the reference: float32 per observation, evaluated in the reference's
+ * operation order (no FMA contraction: build with -ffp-contract=off), double only where the
+ * reference's C++ promotes to double (bilinear weights Auxilary.h:47, 1./z OptimizerAux.cpp:219,
+ * std::pow in Optimizer.cpp:278).  One deliberate deviation: sums over many observations
+ * (energies, normal-equation entries, CG dot products) are accumulated in double and rounded
+ * to float once, because the reference's float summation order (Eigen sparse products) cannot
+ * be reproduced and control flow must not depend on it (SURVEY.md §7 hard part 2).
+ *
+ * Every function cites the reference lines it follows, relative to
+ * /root/reference/cpp/include/.  The exported orc_* functions mirror include/psgsdf.h
+ * one-to-one so the same test driver runs the engine and the oracle.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/psgsdf.h"
+
+#define MAXB 9 /* max SH basis */
+
+typedef struct orc_ctx {
+    /* grid (VoxelGrid.h:27-34) */
+    int dim[3];
+    size_t nvox;
+    float vs, vs_inv;
+    float shift[3], origin[3];
+    float T;
+    float fx, fy, cx, cy;
+    psgsdf_settings set;
+    float reg_n, reg_l; /* effective weights (settings_->reg_weight_n/l are mutated, B9) */
+    /* dense voxel state (SdfVoxel, Sdfvoxel.h:6-13) in SoA */
+    float *dist, *gx, *gy, *gz, *weight, *r, *g, *b;
+    uint64_t* vis_seq; int wpv_seq;  /* per integrated frame */
+    uint64_t* vis;     int wpv;      /* per keyframe, after select_vis */
+    /* keyframes */
+    int F, W, H;
+    int* frame_idx;
+    float* img;    /* F*H*W*3 RGB */
+    float* poses;  /* F*16 row-major */
+    float* light;  /* F*MAXB (SH) or 3 (LED) */
+    int basis;
+    /* band (surface_points_) */
+    int S;
+    int* band;
+    int* row_of;
+    int inited;
+    int solver_mode; /* 0 = direct per-block solves, 1 = Eigen-style global Jacobi-PCG */
+    int threads;
+    char err[256];
+    /* last dist system (debug) */
+} orc_ctx;
+
+/* ------------------------------------------------------------------ small helpers */
+
+static inline float dot3(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline float norm3(const float a[3]) { return sqrtf(dot3(a, a)); }
+/* Eigen normalized(): z = squaredNorm; z>0 ? v/sqrt(z) : v  */
+static inline void normalized3(const float v[3], float o[3]) {
+    float z = dot3(v, v);
+    if (z > 0.f) { float s = sqrtf(z); o[0] = v[0] / s; o[1] = v[1] / s; o[2] = v[2] / s; }
+    else { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; }
+}
+/* o = M^T v for row-major 3x3 M (R.transpose() * v) */
+static inline void mulT3(const float* M, const float v[3], float o[3]) {
+    for (int i = 0; i < 3; ++i) o[i] = (M[0 * 3 + i] * v[0] + M[1 * 3 + i] * v[1]) + M[2 * 3 + i] * v[2];
+}
+static inline void mul3(const float* M, const float v[3], float o[3]) {
+    for (int i = 0; i < 3; ++i) o[i] = (M[i * 3 + 0] * v[0] + M[i * 3 + 1] * v[1]) + M[i * 3 + 2] * v[2];
+}
+static inline void pose_Rt(const orc_ctx* c, int f, float R[9], float t[3]) {
+    const float* P = c->poses + 16 * f; /* Optimizer.h:52-60 */
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i * 3 + j] = P[i * 4 + j]; t[i] = P[i * 4 + 3]; }
+}
+static inline void line2idx(const orc_ctx* c, int lin, int idx[3]) { /* VoxelGrid.h:88-97 */
+    int nxy = c->dim[0] * c->dim[1];
+    int k = lin / nxy; int rest = lin - k * nxy; int j = rest / c->dim[0]; int i = rest - j * c->dim[0];
+    idx[0] = i; idx[1] = j; idx[2] = k;
+}
+static inline void voxel2world(const orc_ctx* c, const int idx[3], float x[3]) { /* VoxelGrid.h:38-40 */
+    for (int a = 0; a < 3; ++a) x[a] = c->origin[a] + c->vs * (float)idx[a];
+}
+static inline int vis_bit(const orc_ctx* c, int lin, int f) {
+    return (int)((c->vis[(size_t)lin * c->wpv + (f >> 6)] >> (f & 63)) & 1ull);
+}
+static inline const float* pix(const orc_ctx* c, int f, int row, int col) {
+    /* clamp: only reachable through the reference's one-past reads at the image corner (B16) */
+    if (row < 0) row = 0; if (row >= c->H) row = c->H - 1;
+    if (col < 0) col = 0; if (col >= c->W) col = c->W - 1;
+    return c->img + (((size_t)f * c->H + row) * c->W + col) * 3;
+}
+
+/* Auxilary.h:41-61 interpolateImage(m=row coordinate, n=column coordinate) */
+static void interpolate_image(const orc_ctx* c, int f, float m, float n, float out[3]) {
+    int x = (int)floorf(m), y = (int)floorf(n);
+    if ((x + 1) < c->H && (y + 1) < c->W) {
+        const float* p10 = pix(c, f, x + 1, y);
+        const float* p00 = pix(c, f, x, y);
+        const float* p11 = pix(c, f, x + 1, y + 1);
+        const float* p01 = pix(c, f, x, y + 1);
+        double w1 = ((double)y + 1.0 - (double)n) * (double)(m - (float)x);          /* double * float */
+        double w2 = ((double)y + 1.0 - (double)n) * ((double)x + 1.0 - (double)m);  /* double * double */
+        float  w3 = (n - (float)y) * (m - (float)x);                                  /* float * float */
+        double w4 = (double)(n - (float)y) * ((double)x + 1.0 - (double)m);           /* float * double */
+        for (int ch = 0; ch < 3; ++ch) {
+            float t1 = (float)((double)p10[ch] * w1);
+            float t2 = (float)((double)p00[ch] * w2);
+            float t3 = p11[ch] * w3;
+            float t4 = (float)((double)p01[ch] * w4);
+            out[ch] = ((t1 + t2) + t3) + t4;
+        }
+    } else { /* the two middle branches are unreachable after the bounds test */
+        const float* p = pix(c, f, x, y);
+        out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+    }
+}
+
+/* Auxilary.h:64-123 computeImageGradient(m=row, n=col, direction) */
+static void image_gradient(const orc_ctx* c, int f, float m, float n, int direction, float out[3]) {
+    int x = (int)floorf(m), y = (int)floorf(n);
+    float w01 = m - (float)x, w11 = n - (float)y;
+    float w00 = (float)(1.0 - (double)w01), w10 = (float)(1.0 - (double)w11);
+    int rows = c->H, cols = c->W;
+    float v0[3] = {0, 0, 0}, v1[3] = {0, 0, 0};
+    int two = 0; float wa = 0, wb = 0;
+    if (direction == 0) {
+        if ((x + 1) < rows && (y + 1) < cols) {
+            for (int ch = 0; ch < 3; ++ch) { v0[ch] = pix(c, f, x, y + 1)[ch] - pix(c, f, x, y)[ch]; v1[ch] = pix(c, f, x + 1, y + 1)[ch] - pix(c, f, x + 1, y)[ch]; }
+            two = 1; wa = w00; wb = w01;
+        } else if ((x + 1) >= rows) {
+            for (int ch = 0; ch < 3; ++ch) v0[ch] = pix(c, f, x, y + 1)[ch] - pix(c, f, x, y)[ch];
+        } else { /* x+1<rows && y+1>=cols */
+            for (int ch = 0; ch < 3; ++ch) { v0[ch] = -pix(c, f, x, y - 1)[ch] + pix(c, f, x, y)[ch]; v1[ch] = -pix(c, f, x + 1, y - 1)[ch] + pix(c, f, x + 1, y)[ch]; }
+            two = 1; wa = w00; wb = w01;
+        }
+    } else {
+        if ((x + 1) < rows && (y + 1) < cols) {
+            for (int ch = 0; ch < 3; ++ch) { v0[ch] = pix(c, f, x + 1, y)[ch] - pix(c, f, x, y)[ch]; v1[ch] = pix(c, f, x + 1, y + 1)[ch] - pix(c, f, x, y + 1)[ch]; }
+            two = 1; wa = w10; wb = w11;
+        } else if ((x + 1) >= rows && (y + 1) < cols) {
+            for (int ch = 0; ch < 3; ++ch) { v0[ch] = -pix(c, f, x - 1, y)[ch] + pix(c, f, x, y)[ch]; v1[ch] = -pix(c, f, x - 1, y + 1)[ch] + pix(c, f, x, y + 1)[ch]; }
+            two = 1; wa = w10; wb = w11;
+        } else { /* y+1>=cols */
+            for (int ch = 0; ch < 3; ++ch) v0[ch] = pix(c, f, x + 1, y)[ch] - pix(c, f, x, y)[ch];
+        }
+    }
+    for (int ch = 0; ch < 3; ++ch) out[ch] = two ? (wa * v0[ch] + wb * v1[ch]) : v0[ch];
+}
+
+/* per-observation geometry shared by getIntensity and the Jacobians */
+typedef struct obs_geom {
+    float point[3]; /* camera-frame surface point */
+    float m, n;     /* column, row */
+    float gn[3];    /* v.grad.normalized() */
+} obs_geom;
+
+/* OptimizerAux.cpp:207-231 getIntensity (use_div=0) and the projection inside the Jacobians
+ * (PsOptimizerJa.cpp:70-76, use_div=1: fx*px/pz instead of fx*px*z_inv). */
+static int project(const orc_ctx* c, int lin, const float R[9], const float t[3], int use_div, obs_geom* o) {
+    int idx[3]; line2idx(c, lin, idx);
+    float xv[3]; voxel2world(c, idx, xv);
+    float gr[3] = {c->gx[lin], c->gy[lin], c->gz[lin]};
+    normalized3(gr, o->gn);
+    float d = c->dist[lin];
+    float tmp[3];
+    for (int a = 0; a < 3; ++a) tmp[a] = (xv[a] - d * o->gn[a]) - t[a];
+    mulT3(R, tmp, o->point);
+    if (use_div) {
+        o->m = c->fx * o->point[0] / o->point[2] + c->cx;
+        o->n = c->fy * o->point[1] / o->point[2] + c->cy;
+    } else {
+        float z_inv = (float)(1.0 / (double)o->point[2]);
+        o->m = c->fx * o->point[0] * z_inv + c->cx;
+        o->n = c->fy * o->point[1] * z_inv + c->cy;
+    }
+    /* reference: if (m<0 || m>=cols || n<0 || n>=rows) return false; NaN treated as outside */
+    if (!(o->m >= 0.f && o->m < (float)c->W && o->n >= 0.f && o->n < (float)c->H)) return 0;
+    return 1;
+}
+static int get_intensity(const orc_ctx* c, int lin, int f, const float R[9], const float t[3], float I[3], obs_geom* og) {
+    obs_geom o;
+    if (!project(c, lin, R, t, 0, &o)) return 0;
+    interpolate_image(c, f, o.n, o.m, I); /* OptimizerAux.cpp:228 */
+    if (og) *og = o;
+    return 1;
+}
+
+/* Optimizer.cpp:462-474 ifValidDirection(idx, +1, pos): bound test is `>` (B2), membership by
+ * linear index (std::find over surface_points_ == row_of lookup). */
+static inline int valid_forward(const orc_ctx* c, int lin, const int idx[3], int pos) {
+    if (idx[pos] + 1 > c->dim[pos]) return 0;
+    size_t stride = pos == 0 ? 1 : (pos == 1 ? (size_t)c->dim[0] : (size_t)c->dim[0] * c->dim[1]);
+    size_t ln = (size_t)lin + stride;
+    if (ln >= c->nvox) return 0;
+    return c->row_of[ln] >= 0;
+}
+static inline float dist_at(const orc_ctx* c, long lin, float fallback) {
+    if (lin < 0 || (size_t)lin >= c->nvox) return fallback; /* reference reads out of bounds here (UB) */
+    return c->dist[lin];
+}
+/* Optimizer.cpp:287-364 computeDistGrad: (n, dir) */
+static void dist_grad(const orc_ctx* c, int lin, float n[3], float dir[3]) {
+    int idx[3]; line2idx(c, lin, idx);
+    long stride[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
+    float d = c->dist[lin];
+    for (int a = 0; a < 3; ++a) {
+        dir[a] = valid_forward(c, lin, idx, a) ? 1.0f : -1.0f;
+        float dn = dist_at(c, (long)lin + (long)dir[a] * stride[a], d);
+        n[a] = dir[a] * (dn - d);
+    }
+    for (int a = 0; a < 3; ++a) n[a] = n[a] * c->vs_inv;
+}
+/* Optimizer.cpp:368-393 computeDistLaplacian */
+static float dist_laplacian(const orc_ctx* c, int lin) {
+    long stride[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
+    float d = c->dist[lin];
+    float dd[3];
+    for (int a = 0; a < 3; ++a) {
+        float p1 = dist_at(c, (long)lin + stride[a], d), p0 = dist_at(c, (long)lin - stride[a], d);
+        dd[a] = p1 + p0 - 2 * d;
+    }
+    return (dd[0] + dd[1] + dd[2]) * c->vs_inv * c->vs_inv;
+}
+/* Optimizer.cpp:269-284 normalJacobian(grad, direction, lag=false) */
+static void normal_jacobian(const orc_ctx* c, const float grad[3], const float direction[3], float J[3]) {
+    float n_d[3] = {-c->vs_inv * direction[0], -c->vs_inv * direction[1], -c->vs_inv * direction[2]};
+    float N_inv = (float)(1.0 / (double)fmaxf(norm3(grad), 0.001f));
+    float dN = (float)(pow((double)N_inv, 3) * (double)dot3(n_d, grad));
+    for (int a = 0; a < 3; ++a) J[a] = N_inv * n_d[a] - dN * grad[a];
+}
+/* PsOptimizerJa.cpp:17-28 */
+static void SH(const float n[3], int order, float* sh) {
+    sh[0] = 1.0f; sh[1] = n[0]; sh[2] = n[1]; sh[3] = n[2];
+    if (order == 2) { sh[4] = n[0] * n[1]; sh[5] = n[0] * n[2]; sh[6] = n[1] * n[2]; sh[7] = n[0] * n[0] - n[1] * n[1]; sh[8] = n[0] * n[0] - n[2] * n[2]; }
+}
+static inline float dotn(const float* a, const float* b, int n) { float s = 0.f; for (int i = 0; i < n; ++i) s += a[i] * b[i]; return s; }
+static inline int sh_order(const orc_ctx* c) { return c->set.model == PSGSDF_SH2 ? 2 : 1; }
+
+/* PsOptimizerJa.cpp:30-40 / LedOptimizerJa.cpp:15-29 renderedIntensity; og is the geometry
+ * of the same observation (LED needs `point`). */
+static void rendered_intensity(const orc_ctx* c, int lin, int f, const float R[9], const obs_geom* og, float out[3]) {
+    float n[3], dir[3]; dist_grad(c, lin, n, dir);
+    float nn[3]; normalized3(n, nn);
+    float irr;
+    if (c->set.model == PSGSDF_LED) {
+        float Rp[3]; mul3(R, og->point, Rp);
+        irr = -dot3(nn, Rp);
+        float ld = (float)pow((double)norm3(og->point), 3);
+        irr /= ld;
+        out[0] = c->r[lin] * c->light[0] * irr; out[1] = c->g[lin] * c->light[1] * irr; out[2] = c->b[lin] * c->light[2] * irr;
+    } else {
+        float sh[MAXB]; SH(nn, sh_order(c), sh);
+        irr = dotn(c->light + (size_t)f * MAXB, sh, c->basis);
+        out[0] = c->r[lin] * irr; out[1] = c->g[lin] * irr; out[2] = c->b[lin] * irr;
+    }
+}
+
+/* Optimizer.cpp:140-161 computeWeight (per channel) */
+static inline float robust_weight(const orc_ctx* c, float r) {
+    float lam = c->set.lambda, lam_sq = lam * lam;
+    switch (c->set.loss) {
+        case PSGSDF_CAUCHY: { float x = r / lam; return 1.0f / (1.0f + x * x); }
+        case PSGSDF_TUKEY: { float x = r / lam; float w = (1.0f - x * x); w = w * w; return (r * r < lam_sq) ? w : 0.0f; }
+        case PSGSDF_HUBER: { float w = lam * fabsf(1.0f / r); return (r * r < lam_sq) ? 1.0f : w; }
+        case PSGSDF_TRUNC_L2: return (r * r < lam_sq) ? 1.0f : 0.0f;
+        default: return 1.0f;
+    }
+}
+/* Optimizer.cpp:164-186 computeLoss (per channel; the reference sums the 3 channels) */
+static inline float robust_loss(const orc_ctx* c, float r) {
+    float lam = c->set.lambda, lam_sq = lam * lam;
+    switch (c->set.loss) {
+        case PSGSDF_CAUCHY: { float x = r / lam; return logf(1.0f + x * x); }
+        case PSGSDF_TUKEY: { float x = r / lam; float u = 1.0f - x * x; float v = 1.0f - u * u * u; return (r * r < lam_sq) ? v : 1.0f; }
+        case PSGSDF_HUBER: { return (r * r < lam_sq) ? 0.5f * (r * r) : lam * (fabsf(r) - 0.5f * lam * 1.0f); }
+        case PSGSDF_TRUNC_L2: { float x = fminf(fmaxf(r, -lam), lam); return x * x; }
+        default: return r * r;
+    }
+}
+
+/* ------------------------------------------------------------------ band */
+
+/* OptimizerAux.cpp:237-257 getSurfaceVoxel */
+static void build_band(orc_ctx* c) {
+    free(c->band); free(c->row_of);
+    c->row_of = (int*)malloc(sizeof(int) * c->nvox);
+    int cnt = 0;
+    for (size_t lin = 0; lin < c->nvox; ++lin) {
+        int seen = 0;
+        for (int w = 0; w < c->wpv; ++w) seen |= (c->vis[lin * c->wpv + w] != 0);
+        if ((double)fabsf(c->dist[lin]) <= sqrt(3.0) * (double)c->vs && seen) c->row_of[lin] = cnt++;
+        else c->row_of[lin] = -1;
+    }
+    c->S = cnt;
+    c->band = (int*)malloc(sizeof(int) * (cnt > 0 ? cnt : 1));
+    for (size_t lin = 0; lin < c->nvox; ++lin) if (c->row_of[lin] >= 0) c->band[c->row_of[lin]] = (int)lin;
+}
+
+/* Optimizer.cpp:30-47 select_vis: keyframe bit f := sequence bit frame_idx[f] */
+static void select_vis(orc_ctx* c) {
+    free(c->vis);
+    c->wpv = (c->F + 63) / 64; if (c->wpv < 1) c->wpv = 1;
+    c->vis = (uint64_t*)calloc(c->nvox * c->wpv, sizeof(uint64_t));
+    for (size_t lin = 0; lin < c->nvox; ++lin)
+        for (int f = 0; f < c->F; ++f) {
+            int s = c->frame_idx[f];
+            if (s < 0 || s >= 64 * c->wpv_seq) continue;
+            if ((c->vis_seq[lin * c->wpv_seq + (s >> 6)] >> (s & 63)) & 1ull) c->vis[lin * c->wpv + (f >> 6)] |= 1ull << (f & 63);
+        }
+}
+
+/* ------------------------------------------------------------------ energies */
+
+/* PsOptimizer.cpp:47-78 / LedOptimizer.cpp:40-71 getPSEnergy */
+static double ps_energy(const orc_ctx* c, long long* n_obs_out) {
+    double E = 0.0; long long nobs = 0;
+#pragma omp parallel for reduction(+ : E, nobs) schedule(static) num_threads(c->threads)
+    for (int j = 0; j < c->S; ++j) {
+        int lin = c->band[j];
+        for (int f = 0; f < c->F; ++f) {
+            if (!vis_bit(c, lin, f)) continue;
+            float R[9], t[3]; pose_Rt(c, f, R, t);
+            float I[3]; obs_geom og;
+            if (!get_intensity(c, lin, f, R, t, I, &og)) continue;
+            float ren[3]; rendered_intensity(c, lin, f, R, &og, ren);
+            float l = 0.f;
+            for (int ch = 0; ch < 3; ++ch) l += robust_loss(c, I[ch] - ren[ch]);
+            E += (double)l; nobs++;
+        }
+    }
+    if (n_obs_out) *n_obs_out = nobs;
+    return c->S ? E / (double)c->S : 0.0;
+}
+/* Optimizer.cpp:86-103 getNormalEnergy */
+static double normal_energy(const orc_ctx* c) {
+    double E = 0.0;
+    for (int j = 0; j < c->S; ++j) { float n[3], d[3]; dist_grad(c, c->band[j], n, d); float e = norm3(n) - 1; E += (double)(e * e); }
+    return c->S ? E / (double)c->S : 0.0;
+}
+/* Optimizer.cpp:106-119 getLaplacianEnergy */
+static double laplacian_energy(const orc_ctx* c) {
+    double E = 0.0;
+    for (int j = 0; j < c->S; ++j) { float e = dist_laplacian(c, c->band[j]); E += (double)(e * e); }
+    return c->S ? E / (double)c->S : 0.0;
+}
+
+/* ------------------------------------------------------------------ linear algebra */
+
+/* Eigen::ConjugateGradient<SparseMatrix<float>> with the default DiagonalPreconditioner
+ * (SURVEY B18): float vectors, x0 = 0, threshold = max(tol^2*|b|^2, FLT_MIN), tol = eps_f32,
+ * maxIters = 2n unless capped; dots accumulated in double.  matvec(user, p, out). */
+typedef void (*matvec_fn)(void* user, const float* p, float* out);
+typedef struct cg_result { int iters; double error; int success; } cg_result;
+static double ddot(const float* a, const float* b, int n) { double s = 0; for (int i = 0; i < n; ++i) s += (double)a[i] * (double)b[i]; return s; }
+static cg_result eigen_cg(int n, matvec_fn mv, void* user, const float* diag, const float* rhs, float* x, int max_it) {
+    cg_result res = {0, 0.0, 1};
+    const float tol = FLT_EPSILON;
+    int maxIters = max_it > 0 ? max_it : 2 * n;
+    memset(x, 0, sizeof(float) * n);
+    float rhsNorm2 = (float)ddot(rhs, rhs, n);
+    if (rhsNorm2 == 0) { res.iters = 0; res.error = 0; return res; }
+    float* r = (float*)malloc(sizeof(float) * n); float* p = (float*)malloc(sizeof(float) * n);
+    float* z = (float*)malloc(sizeof(float) * n); float* tmp = (float*)malloc(sizeof(float) * n);
+    float* inv = (float*)malloc(sizeof(float) * n);
+    for (int i = 0; i < n; ++i) inv[i] = diag[i] != 0.f ? 1.0f / diag[i] : 1.0f;
+    memcpy(r, rhs, sizeof(float) * n); /* residual = rhs - A*0 */
+    float threshold = fmaxf(tol * tol * rhsNorm2, FLT_MIN);
+    float residualNorm2 = (float)ddot(r, r, n);
+    int i = 0;
+    if (residualNorm2 >= threshold) {
+        for (int k = 0; k < n; ++k) p[k] = inv[k] * r[k];
+        float absNew = (float)ddot(r, p, n);
+        while (i < maxIters) {
+            mv(user, p, tmp);
+            float alpha = absNew / (float)ddot(p, tmp, n);
+            for (int k = 0; k < n; ++k) { x[k] += alpha * p[k]; r[k] -= alpha * tmp[k]; }
+            residualNorm2 = (float)ddot(r, r, n);
+            if (residualNorm2 < threshold) break;
+            for (int k = 0; k < n; ++k) z[k] = inv[k] * r[k];
+            float absOld = absNew;
+            absNew = (float)ddot(r, z, n);
+            float beta = absNew / absOld;
+            for (int k = 0; k < n; ++k) p[k] = z[k] + beta * p[k];
+            i++;
+        }
+    }
+    res.iters = i;
+    res.error = sqrt((double)residualNorm2 / (double)rhsNorm2);
+    res.success = res.error <= (double)tol;
+    free(r); free(p); free(z); free(tmp); free(inv);
+    return res;
+}
+
+/* dense symmetric solve in double with LDL^T, zero for non-positive pivots */
+static void solve_spd(int n, const double* Hin, const double* bin, double* x) {
+    double L[MAXB * MAXB]; double D[MAXB]; double y[MAXB];
+    double scale = 0; for (int i = 0; i < n; ++i) if (fabs(Hin[i * n + i]) > scale) scale = fabs(Hin[i * n + i]);
+    double tiny = scale * 1e-12;
+    memset(L, 0, sizeof(L));
+    for (int j = 0; j < n; ++j) {
+        double d = Hin[j * n + j];
+        for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k] * D[k];
+        D[j] = d;
+        L[j * n + j] = 1.0;
+        for (int i = j + 1; i < n; ++i) {
+            double s = Hin[i * n + j];
+            for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k] * D[k];
+            L[i * n + j] = (d > tiny) ? s / d : 0.0;
+        }
+    }
+    for (int i = 0; i < n; ++i) { double s = bin[i]; for (int k = 0; k < i; ++k) s -= L[i * n + k] * y[k]; y[i] = s; }
+    for (int i = 0; i < n; ++i) y[i] = (D[i] > tiny) ? y[i] / D[i] : 0.0;
+    for (int i = n - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k]; x[i] = s; }
+}
+
+/* block-diagonal system of nb blocks of size n: float H (damped), b; solved either per block
+ * (solver_mode 0) or as one global Eigen CG (solver_mode 1, what the reference does). */
+typedef struct blockdiag { int nb, n; const float* H; } blockdiag;
+static void blockdiag_mv(void* user, const float* p, float* out) {
+    blockdiag* B = (blockdiag*)user;
+    for (int k = 0; k < B->nb; ++k) for (int i = 0; i < B->n; ++i) {
+        double s = 0; for (int j = 0; j < B->n; ++j) s += (double)B->H[(size_t)k * B->n * B->n + i * B->n + j] * (double)p[k * B->n + j];
+        out[k * B->n + i] = (float)s;
+    }
+}
+static cg_result solve_blockdiag(const orc_ctx* c, int nb, int n, const float* H, const float* b, float* x) {
+    cg_result res = {0, 0.0, 1};
+    if (c->solver_mode == 1) {
+        blockdiag B = {nb, n, H};
+        float* diag = (float*)malloc(sizeof(float) * nb * n);
+        for (int k = 0; k < nb; ++k) for (int i = 0; i < n; ++i) diag[k * n + i] = H[(size_t)k * n * n + i * n + i];
+        res = eigen_cg(nb * n, blockdiag_mv, &B, diag, b, x, 0);
+        free(diag);
+        return res;
+    }
+    for (int k = 0; k < nb; ++k) {
+        double Hd[MAXB * MAXB], bd[MAXB], xd[MAXB];
+        for (int i = 0; i < n * n; ++i) Hd[i] = (double)H[(size_t)k * n * n + i];
+        for (int i = 0; i < n; ++i) bd[i] = (double)b[k * n + i];
+        solve_spd(n, Hd, bd, xd);
+        for (int i = 0; i < n; ++i) x[k * n + i] = (float)xd[i];
+    }
+    return res;
+}
+
+/* Sophus SO3::exp(omega).matrix(): quaternion exponential then Eigen toRotationMatrix */
+static void so3_exp(const float w[3], float R[9]) {
+    float theta_sq = dot3(w, w);
+    float imag, real;
+    if (theta_sq < 1e-10f /* Sophus Constants<float>::epsilon()^2 ~ (1e-5)^2 */) {
+        float theta_po4 = theta_sq * theta_sq;
+        imag = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_po4;
+        real = 1.0f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_po4;
+    } else {
+        float theta = sqrtf(theta_sq), half = 0.5f * theta;
+        imag = sinf(half) / theta; real = cosf(half);
+    }
+    float qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+    /* Eigen QuaternionBase::toRotationMatrix */
+    float tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
+/* ------------------------------------------------------------------ sub-steps */
+
+/* the residual/weight pair of one observation (computeResidual body, PsOptimizerJa.cpp:586-619) */
+static int residual_obs(const orc_ctx* c, int lin, int f, const float R[9], const float t[3], float r[3], float w[3], obs_geom* og) {
+    float I[3];
+    if (!get_intensity(c, lin, f, R, t, I, og)) return 0;
+    float ren[3]; rendered_intensity(c, lin, f, R, og, ren);
+    for (int ch = 0; ch < 3; ++ch) { r[ch] = I[ch] - ren[ch]; w[ch] = robust_weight(c, r[ch]); }
+    return 1;
+}
+
+/* rhoJacobian: PsOptimizerJa.cpp:118-122 (scalar) / LedOptimizerJa.cpp:85-99 (3-vector) */
+static void rho_jacobian(const orc_ctx* c, int lin, int f, const float R[9], const float t[3], float J[3]) {
+    float gr[3] = {c->gx[lin], c->gy[lin], c->gz[lin]}, n[3]; normalized3(gr, n);
+    if (c->set.model == PSGSDF_LED) {
+        int idx[3]; line2idx(c, lin, idx); float xv[3]; voxel2world(c, idx, xv);
+        float tmp[3], point[3]; float d = c->dist[lin];
+        for (int a = 0; a < 3; ++a) tmp[a] = (xv[a] - d * n[a]) - t[a];
+        mulT3(R, tmp, point);
+        float Rp[3]; mul3(R, point, Rp);
+        float refl = dot3(n, Rp);
+        refl /= (float)pow((double)norm3(point), 3);
+        for (int ch = 0; ch < 3; ++ch) J[ch] = refl * c->light[ch];
+    } else {
+        float sh[MAXB]; SH(n, sh_order(c), sh);
+        float j = -dotn(c->light + (size_t)f * MAXB, sh, c->basis);
+        J[0] = J[1] = J[2] = j;
+    }
+}
+
+/* albedo normal equations: H (3S), b (3S) float, from double sums.
+ * optimizeAlbedoAll, PsOptimizer.cpp:85-121 / LedOptimizer.cpp:162-196 */
+static void albedo_system(const orc_ctx* c, float* H, float* b, double* e_in, long long* nobs_out) {
+    double E = 0; long long nobs = 0;
+#pragma omp parallel for reduction(+ : E, nobs) schedule(static) num_threads(c->threads)
+    for (int j = 0; j < c->S; ++j) {
+        int lin = c->band[j];
+        double Hd[3] = {0, 0, 0}, bd[3] = {0, 0, 0};
+        for (int f = 0; f < c->F; ++f) {
+            if (!vis_bit(c, lin, f)) continue;
+            float R[9], t[3]; pose_Rt(c, f, R, t);
+            float r[3], w[3]; obs_geom og;
+            if (!residual_obs(c, lin, f, R, t, r, w, &og)) continue;
+            float J[3]; rho_jacobian(c, lin, f, R, t, J);
+            float l = 0;
+            for (int ch = 0; ch < 3; ++ch) {
+                float jw = J[ch] * w[ch];
+                Hd[ch] += (double)(jw * J[ch]); bd[ch] += (double)(jw * r[ch]);
+                l += robust_loss(c, r[ch]);
+            }
+            E += (double)l; nobs++;
+        }
+        for (int ch = 0; ch < 3; ++ch) { H[3 * j + ch] = (float)Hd[ch]; b[3 * j + ch] = (float)bd[ch]; }
+    }
+    if (e_in) *e_in = c->S ? E / c->S : 0.0;
+    if (nobs_out) *nobs_out = nobs;
+}
+
+static int step_albedo(orc_ctx* c, psgsdf_step_stats* st) {
+    int n = 3 * c->S;
+    float* H = (float*)malloc(sizeof(float) * (n > 0 ? n : 1)); float* b = (float*)malloc(sizeof(float) * (n > 0 ? n : 1));
+    double e_in; long long nobs;
+    albedo_system(c, H, b, &e_in, &nobs);
+    float damping = c->set.damping;
+    long long count = 0;
+    /* diagonal system: Jacobi-PCG is exact after one step: delta = b / H */
+    for (int j = 0; j < c->S; ++j) {
+        int lin = c->band[j];
+        float* rho[3] = {&c->r[lin], &c->g[lin], &c->b[lin]};
+        for (int ch = 0; ch < 3; ++ch) {
+            float h = H[3 * j + ch];
+            if (damping != 0.0f) h += damping * h; /* PsOptimizer.cpp:103-105 */
+            float delta = (h != 0.f) ? b[3 * j + ch] / h : 0.f;
+            float v = *rho[ch] - delta; /* updateAlbedo, OptimizerAux.cpp:120-150 */
+            if (v > 0.0f && v < 1.0f) { *rho[ch] = v; count++; }
+        }
+    }
+    if (st) { st->block = PSGSDF_ALBEDO; st->cg_iters = 1; st->cg_converged = 1; st->applied = 1; st->e_in = e_in; st->cg_error = 0; st->n_accepted = count; st->n_obs = nobs; }
+    free(H); free(b);
+    return 0;
+}
+
+/* light normal equations per frame (PS: basis x basis per frame, lightJacobian
+ * PsOptimizerJa.cpp:132-143,323-371; LED: one 3-vector, LedOptimizerJa.cpp:101-115,299-346). */
+static void light_system(const orc_ctx* c, double* H, double* b, double* e_in, long long* nobs_out) {
+    int nb = c->set.model == PSGSDF_LED ? 1 : c->F, n = c->basis;
+    memset(H, 0, sizeof(double) * nb * n * n); memset(b, 0, sizeof(double) * nb * n);
+    double E = 0; long long nobs = 0;
+    for (int f = 0; f < c->F; ++f) {
+        float R[9], t[3]; pose_Rt(c, f, R, t);
+        double* Hf = H + (c->set.model == PSGSDF_LED ? 0 : (size_t)f * n * n);
+        double* bf = b + (c->set.model == PSGSDF_LED ? 0 : (size_t)f * n);
+        for (int j = 0; j < c->S; ++j) {
+            int lin = c->band[j];
+            if (!vis_bit(c, lin, f)) continue;
+            float r[3], w[3]; obs_geom og;
+            if (!residual_obs(c, lin, f, R, t, r, w, &og)) continue;
+            float rho[3] = {c->r[lin], c->g[lin], c->b[lin]};
+            float l = 0;
+            if (c->set.model == PSGSDF_LED) {
+                /* LightJacobian: reflectance * rho, column = channel */
+                float gr[3] = {c->gx[lin], c->gy[lin], c->gz[lin]}, nn[3]; normalized3(gr, nn);
+                float Rp[3]; mul3(R, og.point, Rp);
+                float refl = dot3(nn, Rp); refl /= (float)pow((double)norm3(og.point), 3);
+                for (int ch = 0; ch < 3; ++ch) {
+                    float J = refl * rho[ch]; float jw = J * w[ch];
+                    Hf[ch * 3 + ch] += (double)(jw * J); bf[ch] += (double)(jw * r[ch]);
+                    l += robust_loss(c, r[ch]);
+                }
+            } else {
+                float gr[3] = {c->gx[lin], c->gy[lin], c->gz[lin]}, nn[3]; normalized3(gr, nn);
+                float sh[MAXB]; SH(nn, sh_order(c), sh);
+                for (int ch = 0; ch < 3; ++ch) {
+                    float J[MAXB]; for (int i = 0; i < n; ++i) J[i] = -rho[ch] * sh[i];
+                    for (int i = 0; i < n; ++i) {
+                        float jw = J[i] * w[ch];
+                        for (int k = 0; k < n; ++k) Hf[i * n + k] += (double)(jw * J[k]);
+                        bf[i] += (double)(jw * r[ch]);
+                    }
+                    l += robust_loss(c, r[ch]);
+                }
+            }
+            E += (double)l; nobs++;
+        }
+    }
+    if (e_in) *e_in = c->S ? E / c->S : 0.0;
+    if (nobs_out) *nobs_out = nobs;
+}
+
+static int step_light(orc_ctx* c, psgsdf_step_stats* st) {
+    int led = c->set.model == PSGSDF_LED;
+    int nb = led ? 1 : c->F, n = c->basis;
+    double* H = (double*)malloc(sizeof(double) * nb * n * n); double* b = (double*)malloc(sizeof(double) * nb * n);
+    double e_in; long long nobs;
+    light_system(c, H, b, &e_in, &nobs);
+    float* Hf = (float*)malloc(sizeof(float) * nb * n * n); float* bf = (float*)malloc(sizeof(float) * nb * n); float* x = (float*)malloc(sizeof(float) * nb * n);
+    for (int i = 0; i < nb * n * n; ++i) Hf[i] = (float)H[i];
+    for (int i = 0; i < nb * n; ++i) bf[i] = (float)b[i];
+    if (led && c->set.damping != 0.0f) /* LedOptimizer.cpp:144-146; PS light has no damping */
+        for (int i = 0; i < n; ++i) Hf[i * n + i] += c->set.damping * Hf[i * n + i];
+    cg_result cr = solve_blockdiag(c, nb, n, Hf, bf, x);
+    if (led) for (int ch = 0; ch < 3; ++ch) c->light[ch] -= x[ch]; /* LedOptimizer.cpp:159 */
+    else for (int f = 0; f < c->F; ++f) for (int i = 0; i < n; ++i) c->light[(size_t)f * MAXB + i] -= x[f * n + i]; /* PsOptimizer.cpp:199-201 */
+    if (st) { st->block = PSGSDF_LIGHT; st->cg_iters = cr.iters; st->cg_converged = cr.success; st->applied = 1; st->e_in = e_in; st->cg_error = cr.error; st->n_accepted = nb; st->n_obs = nobs; }
+    free(H); free(b); free(Hf); free(bf); free(x);
+    return 0;
+}
+
+/* G = image_grad(3x2) * pi_grad(2x3), PsOptimizerJa.cpp:78-90 */
+static void image_pi_grad(const orc_ctx* c, int f, const obs_geom* og, float G[9]) {
+    float gu[3], gv[3];
+    image_gradient(c, f, og->n, og->m, 0, gu);
+    image_gradient(c, f, og->n, og->m, 1, gv);
+    float z_inv = (float)(1.0 / (double)og->point[2]);
+    float z_inv_sq = z_inv * z_inv;
+    float p00 = c->fx * z_inv, p02 = -c->fx * og->point[0] * z_inv_sq, p11 = c->fy * z_inv, p12 = -c->fy * og->point[1] * z_inv_sq;
+    for (int ch = 0; ch < 3; ++ch) {
+        G[ch * 3 + 0] = gu[ch] * p00 + gv[ch] * 0.0f;
+        G[ch * 3 + 1] = gu[ch] * 0.0f + gv[ch] * p11;
+        G[ch * 3 + 2] = gu[ch] * p02 + gv[ch] * p12;
+    }
+}
+
+/* poseJacobian: PsOptimizerJa.cpp:61-115 / LedOptimizerJa.cpp:32-81.  J is 3x6 row-major. */
+static int pose_jacobian(const orc_ctx* c, int lin, int f, const float R[9], const float t[3], float J[18]) {
+    obs_geom og;
+    if (!project(c, lin, R, t, 1, &og)) return 0;
+    float G[9]; image_pi_grad(c, f, &og, G);
+    /* -G * R^T */
+    for (int ch = 0; ch < 3; ++ch) for (int k = 0; k < 3; ++k) {
+        float s = (G[ch * 3 + 0] * R[k * 3 + 0] + G[ch * 3 + 1] * R[k * 3 + 1]) + G[ch * 3 + 2] * R[k * 3 + 2];
+        J[ch * 6 + k] = -s;
+    }
+    /* G * skew(point) */
+    const float* p = og.point;
+    float sk[9] = {0, -p[2], p[1], p[2], 0, -p[0], -p[1], p[0], 0};
+    for (int ch = 0; ch < 3; ++ch) for (int k = 0; k < 3; ++k)
+        J[ch * 6 + 3 + k] = (G[ch * 3 + 0] * sk[0 * 3 + k] + G[ch * 3 + 1] * sk[1 * 3 + k]) + G[ch * 3 + 2] * sk[2 * 3 + k];
+    if (c->set.model == PSGSDF_LED) {
+        float l = (float)pow((double)norm3(p), 3);
+        float rho[3] = {c->r[lin], c->g[lin], c->b[lin]};
+        for (int ch = 0; ch < 3; ++ch) {
+            float s = -(rho[ch] * c->light[ch] / l);
+            for (int k = 0; k < 3; ++k) J[ch * 6 + k] += s * og.gn[k]; /* LED_t_grad */
+            /* LED_R_grad is identically zero: skew(p)*p = 0 (LedOptimizerJa.cpp:71) */
+        }
+    }
+    return 1;
+}
+
+static void pose_system(const orc_ctx* c, double* H, double* b, double* e_in, long long* nobs_out) {
+    memset(H, 0, sizeof(double) * c->F * 36); memset(b, 0, sizeof(double) * c->F * 6);
+    double E = 0; long long nobs = 0;
+#pragma omp parallel for reduction(+ : E, nobs) schedule(static) num_threads(c->threads)
+    for (int f = 0; f < c->F; ++f) {
+        float R[9], t[3]; pose_Rt(c, f, R, t);
+        double* Hf = H + (size_t)f * 36; double* bf = b + (size_t)f * 6;
+        for (int j = 0; j < c->S; ++j) {
+            int lin = c->band[j];
+            if (!vis_bit(c, lin, f)) continue;
+            float r[3], w[3]; obs_geom og;
+            int ok_r = residual_obs(c, lin, f, R, t, r, w, &og);
+            float J[18];
+            int ok_j = pose_jacobian(c, lin, f, R, t, J);
+            if (ok_r) { float l = 0; for (int ch = 0; ch < 3; ++ch) l += robust_loss(c, r[ch]); E += (double)l; nobs++; }
+            if (!ok_r || !ok_j) continue; /* W = 0 or J row empty */
+            for (int ch = 0; ch < 3; ++ch) for (int i = 0; i < 6; ++i) {
+                float jw = J[ch * 6 + i] * w[ch];
+                for (int k = 0; k < 6; ++k) Hf[i * 6 + k] += (double)(jw * J[ch * 6 + k]);
+                bf[i] += (double)(jw * r[ch]);
+            }
+        }
+    }
+    if (e_in) *e_in = c->S ? E / c->S : 0.0;
+    if (nobs_out) *nobs_out = nobs;
+}
+
+static int step_pose(orc_ctx* c, psgsdf_step_stats* st) {
+    int nb = c->F, n = 6;
+    double* H = (double*)malloc(sizeof(double) * nb * 36); double* b = (double*)malloc(sizeof(double) * nb * 6);
+    double e_in; long long nobs;
+    pose_system(c, H, b, &e_in, &nobs);
+    float* Hf = (float*)malloc(sizeof(float) * nb * 36); float* bf = (float*)malloc(sizeof(float) * nb * 6); float* x = (float*)malloc(sizeof(float) * nb * 6);
+    for (int i = 0; i < nb * 36; ++i) Hf[i] = (float)H[i];
+    for (int i = 0; i < nb * 6; ++i) bf[i] = (float)b[i];
+    if (c->set.damping != 0.0f) for (int k = 0; k < nb; ++k) for (int i = 0; i < 6; ++i) Hf[k * 36 + i * 6 + i] += c->set.damping * Hf[k * 36 + i * 6 + i];
+    cg_result cr = solve_blockdiag(c, nb, n, Hf, bf, x);
+    int apply = 1;
+    if (c->set.model == PSGSDF_LED && c->set.ref_quirks && !cr.success) apply = 0; /* LedOptimizer.cpp:271-273 */
+    if (apply) for (int f = 0; f < c->F; ++f) { /* updatePose, OptimizerAux.cpp:190-205 */
+        float* P = c->poses + 16 * f; const float* xi = x + 6 * f;
+        float R[9], t[3]; pose_Rt(c, f, R, t);
+        float mw[3] = {-xi[3], -xi[4], -xi[5]}, E3[9]; so3_exp(mw, E3);
+        for (int i = 0; i < 3; ++i) {
+            P[i * 4 + 3] = t[i] - xi[i];
+            for (int k = 0; k < 3; ++k) P[i * 4 + k] = (R[i * 3 + 0] * E3[0 * 3 + k] + R[i * 3 + 1] * E3[1 * 3 + k]) + R[i * 3 + 2] * E3[2 * 3 + k];
+        }
+    }
+    if (st) { st->block = PSGSDF_POSE; st->cg_iters = cr.iters; st->cg_converged = cr.success; st->applied = apply; st->e_in = e_in; st->cg_error = cr.error; st->n_accepted = apply ? nb : 0; st->n_obs = nobs; }
+    free(H); free(b); free(Hf); free(bf); free(x);
+    return 0;
+}
+
+/* distJacobian per observation: PsOptimizerJa.cpp:160-289 / LedOptimizerJa.cpp:117-218.
+ * J[k][ch], k = 0..3 (self, x-, y-, z-stencil neighbour); dir returned. */
+static int dist_jacobian(const orc_ctx* c, int lin, int f, const float R[9], const float t[3], float J[4][3], float dir[3]) {
+    obs_geom og;
+    if (!project(c, lin, R, t, 1, &og)) return 0;
+    float G[9]; image_pi_grad(c, f, &og, G);
+    float grad[3]; dist_grad(c, lin, grad, dir);
+    float dn[4][3];
+    normal_jacobian(c, grad, dir, dn[0]);
+    int led = c->set.model == PSGSDF_LED;
+    for (int a = 0; a < 3; ++a) {
+        float nd[3] = {0, 0, 0};
+        /* SH: n_d1[a] -= dir[a] (PsOptimizerJa.cpp:200-210); LED: += (LedOptimizerJa.cpp:157-167, B6) */
+        if (led && c->set.ref_quirks) nd[a] += dir[a]; else nd[a] -= dir[a];
+        normal_jacobian(c, grad, nd, dn[a + 1]);
+    }
+    float d = c->dist[lin];
+    float dx[4][3];
+    for (int a = 0; a < 3; ++a) dx[0][a] = -og.gn[a] - d * dn[0][a];
+    for (int k = 1; k < 4; ++k) for (int a = 0; a < 3; ++a) dx[k][a] = -d * dn[k][a];
+    /* dI_k = G * R^T * dx_k  (Eigen evaluates (G*R^T) first, then * vector) */
+    float GRt[9];
+    for (int ch = 0; ch < 3; ++ch) for (int k = 0; k < 3; ++k)
+        GRt[ch * 3 + k] = (G[ch * 3 + 0] * R[k * 3 + 0] + G[ch * 3 + 1] * R[k * 3 + 1]) + G[ch * 3 + 2] * R[k * 3 + 2];
+    float dI[4][3];
+    for (int k = 0; k < 4; ++k) mul3(GRt, dx[k], dI[k]);
+    float rho[3] = {c->r[lin], c->g[lin], c->b[lin]};
+    if (!led) {
+        const float* l = c->light + (size_t)f * MAXB;
+        if (sh_order(c) == 1) {
+            for (int k = 0; k < 4; ++k) for (int ch = 0; ch < 3; ++ch) {
+                float dr[3] = {rho[ch] * l[1], rho[ch] * l[2], rho[ch] * l[3]};
+                J[k][ch] = dI[k][ch] - dot3(dr, dn[k]);
+            }
+        } else {
+            float nh[3]; normalized3(grad, nh);
+            float D[3][9] = {{0, 1, 0, 0, nh[1], nh[2], 0, 2 * nh[0], 2 * nh[0]},
+                             {0, 0, 1, 0, nh[0], 0, nh[2], -2 * nh[1], 0},
+                             {0, 0, 0, 1, 0, nh[0], nh[1], 0, -2 * nh[2]}};
+            for (int k = 0; k < 4; ++k) {
+                float dsh[9];
+                for (int i = 0; i < 9; ++i) dsh[i] = (D[0][i] * dn[k][0] + D[1][i] * dn[k][1]) + D[2][i] * dn[k][2];
+                for (int ch = 0; ch < 3; ++ch) {
+                    float s = 0; for (int i = 0; i < 9; ++i) s += (rho[ch] * l[i]) * dsh[i];
+                    J[k][ch] = dI[k][ch] - s;
+                }
+            }
+        }
+    } else {
+        float Rp[3]; mul3(R, og.point, Rp);
+        float nh[3]; normalized3(grad, nh);
+        float pn = norm3(og.point);
+        float radius = (float)pow((double)pn, 3);
+        float p5 = (float)pow((double)pn, 5);
+        float nRp = dot3(nh, Rp);
+        for (int k = 0; k < 4; ++k) {
+            float dm = dot3(dn[k], Rp) + dot3(nh, dx[k]);
+            /* point^T * R^T * dx = (R*point) . dx */
+            float tmp[3]; mulT3(R, dx[k], tmp); /* R^T dx */
+            float dm2 = -3 * dot3(og.point, tmp) / p5;
+            dm = dm / radius + dm2 * nRp;
+            for (int ch = 0; ch < 3; ++ch) J[k][ch] = dI[k][ch] + (rho[ch] * c->light[ch]) * dm;
+        }
+    }
+    return 1;
+}
+
+/* Optimizer.cpp:196-218 distRegJacobian(v, idx, Jr_d) + residual (477-537) */
+static void eikonal_row(const orc_ctx* c, int lin, float Jr[4], float* res, float dir[3]) {
+    float grad[3]; dist_grad(c, lin, grad, dir);
+    float n_d[3] = {-c->vs_inv * dir[0], -c->vs_inv * dir[1], -c->vs_inv * dir[2]};
+    Jr[0] = dot3(grad, n_d);
+    for (int a = 0; a < 3; ++a) Jr[a + 1] = grad[a] * (c->vs_inv * dir[a]);
+    float gn = norm3(grad);
+    if (gn > 0.0f) for (int k = 0; k < 4; ++k) Jr[k] /= gn;
+    *res = gn - 1;
+}
+
+/* The assembled distance system: per band voxel a 4x4 block over {self, 3 stencil neighbours};
+ * H = sum_j P_j^T B_j P_j.  Stored explicitly as sorted COO -> CSR in float. */
+typedef struct dist_sys {
+    int S;
+    int* cols;     /* S*4 row indices of the stencil slots (-1 = column dropped) */
+    double* B;     /* S*16 */
+    double* g;     /* S*4  */
+    /* CSR */
+    int* rowptr; int* colidx; float* val; float* diag; float* rhs;
+} dist_sys;
+
+typedef struct { long long key; double v; } coo_t;
+static int coo_cmp(const void* a, const void* b) { long long x = ((const coo_t*)a)->key, y = ((const coo_t*)b)->key; return x < y ? -1 : (x > y ? 1 : 0); }
+
+static void dist_sys_free(dist_sys* s) { free(s->cols); free(s->B); free(s->g); free(s->rowptr); free(s->colidx); free(s->val); free(s->diag); free(s->rhs); memset(s, 0, sizeof(*s)); }
+
+/* optimizeDistAll assembly, PsOptimizer.cpp:124-154 / LedOptimizer.cpp:198-228 */
+static void dist_system(const orc_ctx* c, int normal_reg, int laplacian_reg, dist_sys* s, double* e_in, long long* nobs_out) {
+    int S = c->S;
+    memset(s, 0, sizeof(*s));
+    s->S = S;
+    s->cols = (int*)malloc(sizeof(int) * 4 * (S + 1)); s->B = (double*)calloc((size_t)16 * (S + 1), sizeof(double)); s->g = (double*)calloc((size_t)4 * (S + 1), sizeof(double));
+    long stride[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
+    double E = 0; long long nobs = 0;
+#pragma omp parallel for reduction(+ : E, nobs) schedule(static) num_threads(c->threads)
+    for (int j = 0; j < S; ++j) {
+        int lin = c->band[j];
+        float gtmp[3], dir[3]; dist_grad(c, lin, gtmp, dir);
+        int* cols = s->cols + 4 * j; double* B = s->B + 16 * j; double* g = s->g + 4 * j;
+        cols[0] = j;
+        for (int a = 0; a < 3; ++a) {
+            long ln = (long)lin + (long)dir[a] * stride[a];
+            cols[a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? c->row_of[ln] : -1;
+        }
+        for (int f = 0; f < c->F; ++f) {
+            if (!vis_bit(c, lin, f)) continue;
+            float R[9], t[3]; pose_Rt(c, f, R, t);
+            float r[3], w[3]; obs_geom og;
+            int ok_r = residual_obs(c, lin, f, R, t, r, w, &og);
+            float J[4][3], d2[3];
+            int ok_j = dist_jacobian(c, lin, f, R, t, J, d2);
+            if (ok_r) { float l = 0; for (int ch = 0; ch < 3; ++ch) l += robust_loss(c, r[ch]); E += (double)l; nobs++; }
+            if (!ok_r || !ok_j) continue;
+            for (int ch = 0; ch < 3; ++ch) for (int a = 0; a < 4; ++a) {
+                float jw = J[a][ch] * w[ch];
+                for (int bq = 0; bq < 4; ++bq) B[a * 4 + bq] += (double)(jw * J[bq][ch]);
+                g[a] += (double)(jw * r[ch]);
+            }
+        }
+        if (normal_reg) {
+            float Jr[4], res, d3[3]; eikonal_row(c, lin, Jr, &res, d3);
+            for (int a = 0; a < 4; ++a) {
+                for (int bq = 0; bq < 4; ++bq) B[a * 4 + bq] += (double)(c->reg_n * (Jr[a] * Jr[bq]));
+                g[a] += (double)(c->reg_n * (Jr[a] * res));
+            }
+        }
+        if (laplacian_reg) { /* diagonal only (B3), Optimizer.cpp:540-590 */
+            float vs2 = c->vs_inv * c->vs_inv; float Jl = -6 * vs2; float res = dist_laplacian(c, lin);
+            B[0] += (double)(c->reg_l * (Jl * Jl)); g[0] += (double)(c->reg_l * (Jl * res));
+        }
+    }
+    if (e_in) *e_in = S ? E / S : 0.0;
+    if (nobs_out) *nobs_out = nobs;
+    /* assemble: drop absent columns */
+    size_t ncoo = 0; coo_t* coo = (coo_t*)malloc(sizeof(coo_t) * 16 * (size_t)(S + 1));
+    double* rhs = (double*)calloc(S + 1, sizeof(double));
+    for (int j = 0; j < S; ++j) for (int a = 0; a < 4; ++a) {
+        int ra = s->cols[4 * j + a]; if (ra < 0) continue;
+        rhs[ra] += s->g[4 * j + a];
+        for (int bq = 0; bq < 4; ++bq) { int cb = s->cols[4 * j + bq]; if (cb < 0) continue; coo[ncoo].key = (long long)ra * S + cb; coo[ncoo].v = s->B[16 * j + a * 4 + bq]; ncoo++; }
+    }
+    qsort(coo, ncoo, sizeof(coo_t), coo_cmp);
+    s->rowptr = (int*)calloc(S + 2, sizeof(int)); s->colidx = (int*)malloc(sizeof(int) * (ncoo + 1)); s->val = (float*)malloc(sizeof(float) * (ncoo + 1));
+    s->diag = (float*)calloc(S + 1, sizeof(float)); s->rhs = (float*)malloc(sizeof(float) * (S + 1));
+    size_t nnz = 0;
+    for (size_t i = 0; i < ncoo;) {
+        size_t k = i; double v = 0;
+        while (k < ncoo && coo[k].key == coo[i].key) { v += coo[k].v; ++k; }
+        int row = (int)(coo[i].key / S), col = (int)(coo[i].key % S);
+        s->colidx[nnz] = col; s->val[nnz] = (float)v; s->rowptr[row + 1]++;
+        if (row == col) s->diag[row] = (float)v;
+        nnz++; i = k;
+    }
+    for (int i = 0; i < S; ++i) s->rowptr[i + 1] += s->rowptr[i];
+    for (int i = 0; i < S; ++i) s->rhs[i] = (float)rhs[i];
+    free(coo); free(rhs);
+}
+typedef struct { const dist_sys* s; float damping; } dist_mv_ctx;
+static void dist_mv(void* user, const float* p, float* out) {
+    const dist_mv_ctx* m = (const dist_mv_ctx*)user; const dist_sys* s = m->s;
+    for (int i = 0; i < s->S; ++i) {
+        double acc = 0;
+        for (int k = s->rowptr[i]; k < s->rowptr[i + 1]; ++k) {
+            float v = s->val[k];
+            if (s->colidx[k] == i && m->damping != 0.f) v += m->damping * v; /* H.diagonal() += damping*H.diagonal() */
+            acc += (double)v * (double)p[s->colidx[k]];
+        }
+        out[i] = (float)acc;
+    }
+}
+
+/* updateGrad, OptimizerAux.cpp:152-160 */
+static void update_grad(orc_ctx* c) {
+    float* ng = (float*)malloc(sizeof(float) * 3 * (c->S + 1));
+    for (int j = 0; j < c->S; ++j) { float d[3]; dist_grad(c, c->band[j], ng + 3 * j, d); }
+    for (int j = 0; j < c->S; ++j) { int lin = c->band[j]; c->gx[lin] = ng[3 * j]; c->gy[lin] = ng[3 * j + 1]; c->gz[lin] = ng[3 * j + 2]; }
+    free(ng);
+}
+
+static int step_dist(orc_ctx* c, int laplacian_reg, psgsdf_step_stats* st) {
+    int normal_reg = c->reg_n != 0.0f;
+    dist_sys s; double e_in; long long nobs;
+    dist_system(c, normal_reg, laplacian_reg, &s, &e_in, &nobs);
+    int S = c->S;
+    float* x = (float*)calloc(S + 1, sizeof(float));
+    float* dd = (float*)malloc(sizeof(float) * (S + 1));
+    for (int i = 0; i < S; ++i) { dd[i] = s.diag[i]; if (c->set.damping != 0.f) dd[i] += c->set.damping * dd[i]; }
+    dist_mv_ctx m = {&s, c->set.damping};
+    cg_result cr = eigen_cg(S, dist_mv, &m, dd, s.rhs, x, c->set.cg_max_it);
+    int apply = 1;
+    if (c->set.model != PSGSDF_LED && c->set.ref_quirks && !cr.success) apply = 0; /* PsOptimizer.cpp:168-170 (B8) */
+    long long count = 0;
+    if (apply) { /* updateDist, OptimizerAux.cpp:162-188 */
+        for (int j = 0; j < S; ++j) {
+            float d = x[j];
+            if ((double)fabsf(d) < sqrt(3.0) * (double)c->vs) { c->dist[c->band[j]] -= d; count++; }
+        }
+        update_grad(c);
+    }
+    if (st) { st->block = PSGSDF_DIST; st->cg_iters = cr.iters; st->cg_converged = cr.success; st->applied = apply; st->e_in = e_in; st->cg_error = cr.error; st->n_accepted = count; st->n_obs = nobs; }
+    free(x); free(dd); dist_sys_free(&s);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ init */
+
+/* Optimizer.cpp:50-81 initAlbedo */
+static void init_albedo(orc_ctx* c) {
+    for (int j = 0; j < c->S; ++j) {
+        int lin = c->band[j]; int count = 0; float rho[3] = {0, 0, 0};
+        for (int f = 0; f < c->F; ++f) {
+            if (!vis_bit(c, lin, f)) continue;
+            float R[9], t[3]; pose_Rt(c, f, R, t); float I[3];
+            if (!get_intensity(c, lin, f, R, t, I, NULL)) continue;
+            rho[0] += I[0]; rho[1] += I[1]; rho[2] += I[2]; count++;
+        }
+        if (count) { c->r[lin] = rho[0] / (float)count; c->g[lin] = rho[1] / (float)count; c->b[lin] = rho[2] / (float)count; }
+    }
+}
+/* PsOptimizer.cpp:25-42 / LedOptimizer.cpp:25-36,76-112 */
+static void init_light(orc_ctx* c) {
+    free(c->light);
+    if (c->set.model == PSGSDF_LED) {
+        c->basis = 3; c->light = (float*)malloc(sizeof(float) * MAXB);
+        c->light[0] = c->light[1] = c->light[2] = 1.0f;
+        double I[3] = {0, 0, 0}, Rr[3] = {0, 0, 0};
+        for (int j = 0; j < c->S; ++j) { int lin = c->band[j];
+            for (int f = 0; f < c->F; ++f) {
+                if (!vis_bit(c, lin, f)) continue;
+                float R[9], t[3]; pose_Rt(c, f, R, t); float in[3]; obs_geom og;
+                if (!get_intensity(c, lin, f, R, t, in, &og)) continue;
+                float ren[3]; rendered_intensity(c, lin, f, R, &og, ren);
+                for (int ch = 0; ch < 3; ++ch) { I[ch] += in[ch]; Rr[ch] += ren[ch]; }
+            } }
+        for (int ch = 0; ch < 3; ++ch) c->light[ch] = (float)I[ch] / (float)Rr[ch];
+    } else {
+        c->basis = c->set.model == PSGSDF_SH2 ? 9 : 4;
+        c->light = (float*)calloc((size_t)(c->F > 0 ? c->F : 1) * MAXB, sizeof(float));
+        for (int f = 0; f < c->F; ++f) {
+            float R[9], t[3]; pose_Rt(c, f, R, t);
+            float s[3] = {0.0f, 0.0f, -1.0f}, Rs[3]; mul3(R, s, Rs);
+            SH(Rs, sh_order(c), c->light + (size_t)f * MAXB);
+            c->light[(size_t)f * MAXB] = 0.02f;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ upsample */
+
+/* Optimizer::subsampling OptimizerAux.cpp:622-684 + VolumetricGradSdf::subsample
+ * VolumetricGradSdf.cpp:469-494 + grid_subsample VoxelGrid.h:143-149 */
+static void upsample2x(orc_ctx* c) {
+    int nd[3] = {2 * c->dim[0], 2 * c->dim[1], 2 * c->dim[2]};
+    size_t nn = 8 * c->nvox;
+    float* dist = (float*)malloc(sizeof(float) * nn); float* gx = (float*)calloc(nn, sizeof(float)); float* gy = (float*)calloc(nn, sizeof(float)); float* gz = (float*)calloc(nn, sizeof(float));
+    float* w = (float*)calloc(nn, sizeof(float)); float* r = (float*)malloc(sizeof(float) * nn); float* g = (float*)malloc(sizeof(float) * nn); float* b = (float*)malloc(sizeof(float) * nn);
+    uint64_t* vis = (uint64_t*)calloc(nn * c->wpv, sizeof(uint64_t));
+    for (size_t i = 0; i < nn; ++i) { dist[i] = c->T; r[i] = g[i] = b[i] = 0.5f; }
+    float vs4 = (float)(0.25 * (double)c->vs);
+    for (int k = 0; k < c->dim[2]; ++k) for (int j = 0; j < c->dim[1]; ++j) for (int i = 0; i < c->dim[0]; ++i) {
+        size_t lin = (size_t)i + (size_t)j * c->dim[0] + (size_t)k * c->dim[0] * c->dim[1];
+        if (c->dist[lin] == c->T) continue;
+        float gr[3] = {c->gx[lin], c->gy[lin], c->gz[lin]}, gn[3]; normalized3(gr, gn);
+        for (int sub = 0; sub < 8; ++sub) {
+            int sx = sub & 1, sy = (sub >> 1) & 1, sz = (sub >> 2) & 1;
+            float ax = sx ? gn[0] : -gn[0], ay = sy ? gn[1] : -gn[1], az = sz ? gn[2] : -gn[2];
+            float d = c->dist[lin] + vs4 * (ax + ay + az);
+            size_t ls = (size_t)(2 * i + sx) + (size_t)(2 * j + sy) * nd[0] + (size_t)(2 * k + sz) * nd[0] * nd[1];
+            dist[ls] = d; gx[ls] = gr[0]; gy[ls] = gr[1]; gz[ls] = gr[2]; w[ls] = c->weight[lin]; r[ls] = c->r[lin]; g[ls] = c->g[lin]; b[ls] = c->b[lin];
+            for (int q = 0; q < c->wpv; ++q) vis[ls * c->wpv + q] = c->vis[lin * c->wpv + q];
+        }
+    }
+    free(c->dist); free(c->gx); free(c->gy); free(c->gz); free(c->weight); free(c->r); free(c->g); free(c->b); free(c->vis);
+    c->dist = dist; c->gx = gx; c->gy = gy; c->gz = gz; c->weight = w; c->r = r; c->g = g; c->b = b; c->vis = vis;
+    c->vs *= 0.5f; /* grid_subsample and Optimizer::voxel_size_ both halve */
+    for (int a = 0; a < 3; ++a) c->dim[a] = nd[a];
+    for (int a = 0; a < 3; ++a) c->origin[a] = c->shift[a] - (float)(0.5 * (double)c->vs) * (float)c->dim[a] - (float)(0.5 * (double)c->vs) * 1.0f;
+    c->nvox = nn;
+    c->vs_inv = (float)(1.0 / (double)c->vs);
+    build_band(c);
+}
+
+/* ------------------------------------------------------------------ exported API (mirrors psgsdf.h) */
+
+#define ORC_FAIL(c, code, msg) do { if (c) snprintf((c)->err, sizeof((c)->err), "%s", msg); return code; } while (0)
+
+int orc_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_settings* settings, int device, orc_ctx** out) {
+    (void)device;
+    if (!grid || !K || !settings || !out) return PSGSDF_ERR_ARG;
+    if (settings->reg_weight_rho != 0.0f) return PSGSDF_ERR_UNSUPPORTED;
+    orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
+    for (int a = 0; a < 3; ++a) { c->dim[a] = grid->dim[a]; c->shift[a] = grid->shift[a]; }
+    c->nvox = (size_t)c->dim[0] * c->dim[1] * c->dim[2];
+    c->vs = grid->voxel_size; c->vs_inv = 1.f / c->vs; c->T = grid->truncation;
+    /* VoxelGrid.h:130: origin_ = shift_ - 0.5*voxel_size*grid_dim_.cast<float>() */
+    for (int a = 0; a < 3; ++a) c->origin[a] = c->shift[a] - (float)(0.5 * (double)c->vs) * (float)c->dim[a];
+    c->fx = K[0]; c->fy = K[4]; c->cx = K[2]; c->cy = K[5];
+    c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l;
+    c->threads = 1;
+    *out = c;
+    return 0;
+}
+void orc_destroy(orc_ctx* c) {
+    if (!c) return;
+    free(c->dist); free(c->gx); free(c->gy); free(c->gz); free(c->weight); free(c->r); free(c->g); free(c->b);
+    free(c->vis_seq); free(c->vis); free(c->frame_idx); free(c->img); free(c->poses); free(c->light); free(c->band); free(c->row_of);
+    free(c);
+}
+const char* orc_last_error(const orc_ctx* c) { return c ? c->err : "null context"; }
+const char* orc_version(void) { return "psgsdf-oracle cpu (test infrastructure)"; }
+int orc_set_solver_mode(orc_ctx* c, int mode) { c->solver_mode = mode; return 0; }
+int orc_set_threads(orc_ctx* c, int n) { c->threads = n > 0 ? n : 1; return 0; }
+
+static float* dupf(const float* p, size_t n) { float* q = (float*)malloc(sizeof(float) * n); memcpy(q, p, sizeof(float) * n); return q; }
+
+int orc_upload_volume(orc_ctx* c, const float* dist, const float* grad_xyz, const float* weight, const float* rgb, const uint64_t* vis_words, int words_per_voxel) {
+    if (!c || !dist || !grad_xyz || !weight || !rgb || !vis_words || words_per_voxel < 1) return PSGSDF_ERR_ARG;
+    size_t n = c->nvox;
+    free(c->dist); free(c->gx); free(c->gy); free(c->gz); free(c->weight); free(c->r); free(c->g); free(c->b); free(c->vis_seq);
+    c->dist = dupf(dist, n); c->gx = dupf(grad_xyz, n); c->gy = dupf(grad_xyz + n, n); c->gz = dupf(grad_xyz + 2 * n, n);
+    c->weight = dupf(weight, n); c->r = dupf(rgb, n); c->g = dupf(rgb + n, n); c->b = dupf(rgb + 2 * n, n);
+    c->vis_seq = (uint64_t*)malloc(sizeof(uint64_t) * n * words_per_voxel); memcpy(c->vis_seq, vis_words, sizeof(uint64_t) * n * words_per_voxel);
+    c->wpv_seq = words_per_voxel;
+    c->inited = 0;
+    return 0;
+}
+int orc_set_keyframes(orc_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_images, int width, int height, const float* poses) {
+    if (!c || n_frames < 0 || (n_frames > 0 && (!frame_idx || !rgb_images || !poses))) return PSGSDF_ERR_ARG;
+    free(c->frame_idx); free(c->img); free(c->poses);
+    c->F = n_frames; c->W = width; c->H = height;
+    c->frame_idx = (int*)malloc(sizeof(int) * (n_frames + 1)); memcpy(c->frame_idx, frame_idx, sizeof(int) * n_frames);
+    c->img = dupf(rgb_images, (size_t)n_frames * width * height * 3);
+    c->poses = dupf(poses, (size_t)n_frames * 16);
+    c->inited = 0;
+    return 0;
+}
+int orc_init(orc_ctx* c) {
+    if (!c || !c->dist || !c->frame_idx) ORC_FAIL(c, PSGSDF_ERR_STATE, "upload_volume and set_keyframes first");
+    select_vis(c);
+    build_band(c);
+    init_light(c);
+    c->inited = 1;
+    return 0;
+}
+int orc_init_albedo(orc_ctx* c) { if (!c || !c->inited) return PSGSDF_ERR_STATE; init_albedo(c); return 0; }
+
+static float total_energy(const orc_ctx* c, float E, float E_n, float E_l) { return E + c->reg_n * E_n + c->reg_l * E_l; /* OptimizerAux.cpp:261 (reg_rho term is 0) */ }
+
+int orc_energy(orc_ctx* c, double out[4]) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    out[0] = ps_energy(c, NULL); out[1] = normal_energy(c); out[2] = laplacian_energy(c);
+    out[3] = (double)total_energy(c, (float)out[0], c->reg_n != 0.f ? (float)out[1] : 0.f, c->reg_l != 0.f ? (float)out[2] : 0.f);
+    return 0;
+}
+int orc_normalize_weights(orc_ctx* c, double* e_total) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    float E = (float)ps_energy(c, NULL), E_n = 0, E_l = 0;
+    if (c->reg_n != 0.f) { E_n = (float)normal_energy(c); c->reg_n *= E / E_n; }
+    if (c->reg_l != 0.f) { E_l = (float)laplacian_energy(c); c->reg_l *= E / E_l; }
+    if (e_total) *e_total = (double)total_energy(c, E, E_n, E_l);
+    return 0;
+}
+int orc_step_ex(orc_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    switch (block) {
+        case PSGSDF_ALBEDO: return step_albedo(c, st);
+        case PSGSDF_LIGHT: return step_light(c, st);
+        case PSGSDF_DIST: return step_dist(c, laplacian_reg, st);
+        case PSGSDF_POSE: return step_pose(c, st);
+        default: return PSGSDF_ERR_ARG;
+    }
+}
+int orc_step(orc_ctx* c, int block, psgsdf_step_stats* st) { return orc_step_ex(c, block, c && c->reg_l != 0.f, st); }
+
+/* one body of the alternation loop; order SH: albedo,light,dist,pose (PsOptimizer.cpp:304-360),
+ * LED: light,albedo,dist,pose (LedOptimizer.cpp:345-403) */
+static void iterate_once(orc_ctx* c, int flags, int laplacian_reg, float* E, float* E_n, float* E_l, psgsdf_iter_stats* rec) {
+    int led = c->set.model == PSGSDF_LED;
+    int order[4] = {led ? PSGSDF_LIGHT : PSGSDF_ALBEDO, led ? PSGSDF_ALBEDO : PSGSDF_LIGHT, PSGSDF_DIST, PSGSDF_POSE};
+    for (int q = 0; q < 4; ++q) rec->e_after[q] = NAN;
+    rec->cg_iters = 0;
+    for (int q = 0; q < 4; ++q) {
+        int blk = order[q];
+        if (!(flags & blk)) continue;
+        psgsdf_step_stats st; memset(&st, 0, sizeof(st));
+        orc_step_ex(c, blk, laplacian_reg, &st);
+        *E = (float)ps_energy(c, NULL);
+        if (blk == PSGSDF_DIST) {
+            rec->cg_iters = st.cg_iters;
+            if (c->reg_n != 0.f) *E_n = (float)normal_energy(c);
+            if (laplacian_reg) *E_l = (float)laplacian_energy(c);
+        }
+        int slot = blk == PSGSDF_ALBEDO ? 0 : blk == PSGSDF_LIGHT ? 1 : blk == PSGSDF_DIST ? 2 : 3;
+        rec->e_after[slot] = (double)*E;
+    }
+    rec->e_n = *E_n; rec->e_l = *E_l;
+    rec->e_total = (double)total_energy(c, *E, *E_n, *E_l);
+    rec->reg_weight_n = c->reg_n; rec->reg_weight_l = c->reg_l;
+}
+
+int orc_iterate(orc_ctx* c, int flags, int n_iters, psgsdf_iter_stats* stats) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    float E = (float)ps_energy(c, NULL), E_n = c->reg_n != 0.f ? (float)normal_energy(c) : 0.f, E_l = c->reg_l != 0.f ? (float)laplacian_energy(c) : 0.f;
+    float E_prev = total_energy(c, E, E_n, E_l);
+    for (int it = 0; it < n_iters; ++it) {
+        psgsdf_iter_stats rec; memset(&rec, 0, sizeof(rec));
+        iterate_once(c, flags, c->reg_l != 0.f, &E, &E_n, &E_l, &rec);
+        float Et = (float)rec.e_total;
+        rec.rel_diff = (double)(fabsf(E_prev - Et) / E_prev);
+        rec.converged = rec.rel_diff < (double)c->set.conv_threshold; rec.diverged = E_prev < Et;
+        E_prev = Et;
+        if (stats) stats[it] = rec;
+    }
+    return 0;
+}
+
+/* alternatingOptimize, PsOptimizer.cpp:239-428 / LedOptimizer.cpp:279-478 (no file output) */
+int orc_optimize(orc_ctx* c, int flags, psgsdf_iter_stats* stats, int stats_cap, int* n_done, int* result, psgsdf_iter_cb on_iter, void* user) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    int led = c->set.model == PSGSDF_LED;
+    int laplacian_reg = c->reg_l != 0.f;
+    init_albedo(c);
+    float E = (float)ps_energy(c, NULL), E_n = 0, E_l = 0;
+    if (c->reg_n != 0.f) { E_n = (float)normal_energy(c); c->reg_n *= E / E_n; }
+    if (laplacian_reg) { E_l = (float)laplacian_energy(c); c->reg_l *= E / E_l; if (c->set.upsample) laplacian_reg = 0; }
+    float E_prev = total_energy(c, E, E_n, E_l);
+    int iter = 0, done = 0; if (result) *result = 0;
+    while (iter < c->set.max_it) {
+        psgsdf_iter_stats rec; memset(&rec, 0, sizeof(rec));
+        iterate_once(c, flags, laplacian_reg, &E, &E_n, &E_l, &rec);
+        float Et = (float)rec.e_total;
+        rec.rel_diff = (double)(fabsf(E_prev - Et) / E_prev);
+        rec.converged = rec.rel_diff < (double)c->set.conv_threshold;
+        rec.diverged = !rec.converged && (E_prev < Et);
+        int stop = rec.converged || rec.diverged;
+        float E_last = Et;
+        if (!stop && iter == 5 && c->set.upsample) {
+            if (c->reg_l == 0.0f) c->reg_l = 1.0f;
+            laplacian_reg = 1;
+            upsample2x(c);
+            E_l = (float)laplacian_energy(c);
+            c->reg_l *= E / E_l;
+            E_last = total_energy(c, E, E_n, E_l);
+            rec.upsampled = 1;
+        }
+        if (!stop && c->set.upsample && (led ? iter == 15 : iter > 15)) c->reg_l = 0.0f;
+        E_prev = E_last;
+        if (stats && done < stats_cap) stats[done] = rec;
+        done++;
+        if (rec.converged) { if (result) *result = 1; break; }
+        if (rec.diverged) break;
+        ++iter;
+        if (on_iter && on_iter(user, iter, &rec)) break;
+    }
+    if (n_done) *n_done = done;
+    return 0;
+}
+
+int orc_upsample2x(orc_ctx* c) { if (!c || !c->inited) return PSGSDF_ERR_STATE; upsample2x(c); return 0; }
+
+int orc_get_info(orc_ctx* c, psgsdf_info* info) {
+    if (!c || !info) return PSGSDF_ERR_ARG;
+    for (int a = 0; a < 3; ++a) { info->dim[a] = c->dim[a]; info->origin[a] = c->origin[a]; }
+    info->voxel_size = c->vs; info->n_frames = c->F; info->n_band = c->S;
+    info->light_stride = c->set.model == PSGSDF_LED ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4);
+    info->vis_words = c->wpv; info->reg_weight_n = c->reg_n; info->reg_weight_l = c->reg_l;
+    return 0;
+}
+int orc_download_volume(orc_ctx* c, float* dist, float* grad_xyz, float* weight, float* rgb, uint64_t* vis_words) {
+    if (!c || !c->dist) return PSGSDF_ERR_STATE;
+    size_t n = c->nvox;
+    if (dist) memcpy(dist, c->dist, sizeof(float) * n);
+    if (grad_xyz) { memcpy(grad_xyz, c->gx, sizeof(float) * n); memcpy(grad_xyz + n, c->gy, sizeof(float) * n); memcpy(grad_xyz + 2 * n, c->gz, sizeof(float) * n); }
+    if (weight) memcpy(weight, c->weight, sizeof(float) * n);
+    if (rgb) { memcpy(rgb, c->r, sizeof(float) * n); memcpy(rgb + n, c->g, sizeof(float) * n); memcpy(rgb + 2 * n, c->b, sizeof(float) * n); }
+    if (vis_words) { if (!c->vis) return PSGSDF_ERR_STATE; memcpy(vis_words, c->vis, sizeof(uint64_t) * n * c->wpv); }
+    return 0;
+}
+int orc_download_band(orc_ctx* c, int32_t* lin_idx) { if (!c || !c->inited) return PSGSDF_ERR_STATE; memcpy(lin_idx, c->band, sizeof(int) * c->S); return 0; }
+int orc_download_poses(orc_ctx* c, float* poses) { if (!c || !c->poses) return PSGSDF_ERR_STATE; memcpy(poses, c->poses, sizeof(float) * 16 * c->F); return 0; }
+int orc_download_light(orc_ctx* c, float* light) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    if (c->set.model == PSGSDF_LED) { memcpy(light, c->light, sizeof(float) * 3); return 0; }
+    for (int f = 0; f < c->F; ++f) memcpy(light + (size_t)f * c->basis, c->light + (size_t)f * MAXB, sizeof(float) * c->basis);
+    return 0;
+}
+int orc_upload_light(orc_ctx* c, const float* light) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    if (c->set.model == PSGSDF_LED) { memcpy(c->light, light, sizeof(float) * 3); return 0; }
+    for (int f = 0; f < c->F; ++f) memcpy(c->light + (size_t)f * MAXB, light + (size_t)f * c->basis, sizeof(float) * c->basis);
+    return 0;
+}
+
+/* ---- test hooks mirroring psgsdf_debug_* */
+int orc_debug_dist_system(orc_ctx* c, float* diag, float* rhs, const float* x, float* y) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    dist_sys s; dist_system(c, c->reg_n != 0.f, c->reg_l != 0.f, &s, NULL, NULL);
+    if (diag) memcpy(diag, s.diag, sizeof(float) * c->S);
+    if (rhs) memcpy(rhs, s.rhs, sizeof(float) * c->S);
+    if (x && y) { dist_mv_ctx m = {&s, 0.0f}; dist_mv(&m, x, y); }
+    dist_sys_free(&s);
+    return 0;
+}
+int orc_debug_frame_system(orc_ctx* c, int block, double* H, double* b) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    if (block == PSGSDF_LIGHT) light_system(c, H, b, NULL, NULL);
+    else if (block == PSGSDF_POSE) pose_system(c, H, b, NULL, NULL);
+    else return PSGSDF_ERR_ARG;
+    return 0;
+}
+int orc_debug_albedo_system(orc_ctx* c, float* H, float* b) { if (!c || !c->inited) return PSGSDF_ERR_STATE; albedo_system(c, H, b, NULL, NULL); return 0; }
+
+/* ---- oracle-only probes used by the known-answer tests */
+
+/* residual (3) of observation (band row j, frame f); returns 1 if visible & in image */
+int orc_probe_residual(orc_ctx* c, int j, int f, float r[3], float w[3]) {
+    int lin = c->band[j]; if (!vis_bit(c, lin, f)) return 0;
+    float R[9], t[3]; pose_Rt(c, f, R, t); obs_geom og;
+    return residual_obs(c, lin, f, R, t, r, w, &og);
+}
+/* analytic distance Jacobian block (4x3) + stencil rows of observation (j,f) */
+int orc_probe_dist_jacobian(orc_ctx* c, int j, int f, float J[12], int rows[4]) {
+    int lin = c->band[j]; if (!vis_bit(c, lin, f)) return 0;
+    float R[9], t[3]; pose_Rt(c, f, R, t);
+    float Jb[4][3], dir[3];
+    if (!dist_jacobian(c, lin, f, R, t, Jb, dir)) return 0;
+    long stride[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
+    rows[0] = j;
+    for (int a = 0; a < 3; ++a) { long ln = (long)lin + (long)dir[a] * stride[a]; rows[a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? c->row_of[ln] : -1; }
+    for (int k = 0; k < 4; ++k) for (int ch = 0; ch < 3; ++ch) J[k * 3 + ch] = Jb[k][ch];
+    return 1;
+}
+int orc_probe_pose_jacobian(orc_ctx* c, int j, int f, float J[18]) {
+    int lin = c->band[j]; if (!vis_bit(c, lin, f)) return 0;
+    float R[9], t[3]; pose_Rt(c, f, R, t);
+    return pose_jacobian(c, lin, f, R, t, J);
+}
+int orc_probe_rho_jacobian(orc_ctx* c, int j, int f, float J[3]) {
+    int lin = c->band[j]; float R[9], t[3]; pose_Rt(c, f, R, t); rho_jacobian(c, lin, f, R, t, J); return 1;
+}
+/* direct state pokes for finite-difference tests */
+int orc_poke_dist(orc_ctx* c, int lin, float v) { c->dist[lin] = v; return 0; }
+float orc_peek_dist(orc_ctx* c, int lin) { return c->dist[lin]; }
+int orc_poke_grad(orc_ctx* c, int lin, const float g[3]) { c->gx[lin] = g[0]; c->gy[lin] = g[1]; c->gz[lin] = g[2]; return 0; }
+int orc_peek_grad(orc_ctx* c, int lin, float g[3]) { g[0] = c->gx[lin]; g[1] = c->gy[lin]; g[2] = c->gz[lin]; return 0; }
+int orc_poke_rgb(orc_ctx* c, int lin, const float v[3]) { c->r[lin] = v[0]; c->g[lin] = v[1]; c->b[lin] = v[2]; return 0; }
+int orc_peek_rgb(orc_ctx* c, int lin, float v[3]) { v[0] = c->r[lin]; v[1] = c->g[lin]; v[2] = c->b[lin]; return 0; }
+int orc_poke_pose(orc_ctx* c, int f, const float P[16]) { memcpy(c->poses + 16 * f, P, sizeof(float) * 16); return 0; }
+int orc_update_grad(orc_ctx* c) { update_grad(c); return 0; }
+int orc_so3_exp(const float w[3], float R[9]) { so3_exp(w, R); return 0; }
+/* Eigen-CG on a dense SPD matrix (n x n row-major) for the solver known-answer test */
+typedef struct { int n; const float* A; } dense_mv_ctx;
+static void dense_mv(void* u, const float* p, float* out) { dense_mv_ctx* d = (dense_mv_ctx*)u; for (int i = 0; i < d->n; ++i) { double s = 0; for (int j = 0; j < d->n; ++j) s += (double)d->A[i * d->n + j] * p[j]; out[i] = (float)s; } }
+int orc_eigen_cg_dense(int n, const float* A, const float* b, float* x, int* iters, double* err) {
+    float* diag = (float*)malloc(sizeof(float) * n); for (int i = 0; i < n; ++i) diag[i] = A[i * n + i];
+    dense_mv_ctx d = {n, A}; cg_result r = eigen_cg(n, dense_mv, &d, diag, b, x, 0);
+    if (iters) *iters = r.iters; if (err) *err = r.error; free(diag); return r.success;
+}

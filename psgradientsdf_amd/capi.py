@@ -1,0 +1,263 @@
+"""ctypes binding of the C ABI declared in include/psgsdf.h.
+
+This is host-side plumbing for tests and bench.py (the reference is C++; the C++ mirror of its
+PsOptimizer/LedOptimizer interface lives in psgradientsdf_amd/host/).  `Api` is generic over
+(shared library, symbol prefix) because the test oracle exports the same functions under `orc_`;
+the product only ever instantiates it through `load_engine()`, which binds `libpsgsdf.so` and
+raises if the HIP library is missing — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+ALBEDO, LIGHT, DIST, POSE, ALL = 1, 2, 4, 8, 15
+SH1, SH2, LED = 0, 1, 2
+L2, CAUCHY, HUBER, TUKEY, TRUNC_L2 = 0, 1, 2, 3, 4
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ENGINE_LIB = os.path.join(_HERE, "csrc", "libpsgsdf.so")
+
+
+class GridDesc(C.Structure):
+    _fields_ = [("dim", C.c_int32 * 3), ("voxel_size", C.c_float), ("shift", C.c_float * 3), ("truncation", C.c_float)]
+
+
+class Settings(C.Structure):
+    _fields_ = [("model", C.c_int32), ("loss", C.c_int32), ("lambda_", C.c_float), ("damping", C.c_float),
+                ("reg_weight_rho", C.c_float), ("reg_weight_n", C.c_float), ("reg_weight_l", C.c_float),
+                ("max_it", C.c_int32), ("conv_threshold", C.c_float), ("upsample", C.c_int32),
+                ("ref_quirks", C.c_int32), ("cg_max_it", C.c_int32)]
+
+
+class StepStats(C.Structure):
+    _fields_ = [("block", C.c_int32), ("cg_iters", C.c_int32), ("cg_converged", C.c_int32), ("applied", C.c_int32),
+                ("e_in", C.c_double), ("cg_error", C.c_double), ("n_accepted", C.c_int64), ("n_obs", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class IterStats(C.Structure):
+    _fields_ = [("e_after", C.c_double * 4), ("e_n", C.c_double), ("e_l", C.c_double), ("e_total", C.c_double),
+                ("rel_diff", C.c_double), ("reg_weight_n", C.c_float), ("reg_weight_l", C.c_float),
+                ("cg_iters", C.c_int32), ("converged", C.c_int32), ("diverged", C.c_int32), ("upsampled", C.c_int32)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["e_after"] = list(self.e_after)
+        return d
+
+
+class Info(C.Structure):
+    _fields_ = [("dim", C.c_int32 * 3), ("voxel_size", C.c_float), ("origin", C.c_float * 3), ("n_frames", C.c_int32),
+                ("n_band", C.c_int32), ("light_stride", C.c_int32), ("vis_words", C.c_int32),
+                ("reg_weight_n", C.c_float), ("reg_weight_l", C.c_float)]
+
+
+def default_settings(model=SH1, **kw):
+    """config_skorates.json values (cauchy, lambda 0.2, damping 1, reg_n 10, reg_l 0, conv 5e-3)."""
+    s = Settings(model=model, loss=CAUCHY, lambda_=0.2, damping=1.0, reg_weight_rho=0.0, reg_weight_n=10.0,
+                 reg_weight_l=0.0, max_it=100, conv_threshold=5e-3, upsample=0, ref_quirks=1, cg_max_it=0)
+    for k, v in kw.items():
+        if k == "lambda":
+            k = "lambda_"
+        setattr(s, k, v)
+    return s
+
+
+def _fp(a, dtype=np.float32):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class PsgsdfError(RuntimeError):
+    pass
+
+
+class Api:
+    """One context of either the HIP engine (prefix psgsdf_) or the test oracle (prefix orc_)."""
+
+    def __init__(self, lib: C.CDLL, prefix: str, grid: GridDesc, K, settings: Settings, device: int = 0):
+        self._lib, self._p = lib, prefix
+        self.ctx = C.c_void_p()
+        Karr, Kp = _fp(K)
+        self._grid, self._settings = grid, settings
+        self._check(self._fn("create")(C.byref(grid), Kp, C.byref(settings), C.c_int(device), C.byref(self.ctx)), "create")
+
+    # -- plumbing
+    def _fn(self, name):
+        f = getattr(self._lib, self._p + name)
+        f.restype = C.c_int
+        return f
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = ""
+            try:
+                g = getattr(self._lib, self._p + "last_error")
+                g.restype = C.c_char_p
+                msg = (g(self.ctx) or b"").decode()
+            except Exception:
+                pass
+            raise PsgsdfError(f"{self._p}{what} failed rc={rc} {msg}")
+
+    def close(self):
+        if self.ctx:
+            d = getattr(self._lib, self._p + "destroy")
+            d.restype = None
+            d(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- inputs
+    def upload_volume(self, dist, grad, weight, rgb, vis, words):
+        a = [_fp(dist), _fp(grad), _fp(weight), _fp(rgb), _fp(vis, np.uint64)]
+        self._check(self._fn("upload_volume")(self.ctx, a[0][1], a[1][1], a[2][1], a[3][1], a[4][1], C.c_int(words)), "upload_volume")
+
+    def set_keyframes(self, frame_idx, images, poses):
+        F, H, W, _ = images.shape
+        a = [_fp(frame_idx, np.int32), _fp(images), _fp(poses)]
+        self._check(self._fn("set_keyframes")(self.ctx, C.c_int(F), a[0][1], a[1][1], C.c_int(W), C.c_int(H), a[2][1]), "set_keyframes")
+
+    def load_scene(self, sc):
+        self.upload_volume(sc.dist, sc.grad, sc.weight, sc.rgb, sc.vis, sc.vis_words)
+        self.set_keyframes(sc.frame_idx, sc.images, sc.poses)
+        self.init()
+
+    def init(self):
+        self._check(self._fn("init")(self.ctx), "init")
+
+    # -- hot path
+    def init_albedo(self):
+        self._check(self._fn("init_albedo")(self.ctx), "init_albedo")
+
+    def energy(self):
+        out = (C.c_double * 4)()
+        self._check(self._fn("energy")(self.ctx, out), "energy")
+        return list(out)
+
+    def normalize_weights(self):
+        e = C.c_double()
+        self._check(self._fn("normalize_weights")(self.ctx, C.byref(e)), "normalize_weights")
+        return e.value
+
+    def step(self, block):
+        st = StepStats()
+        self._check(self._fn("step")(self.ctx, C.c_int(block), C.byref(st)), "step")
+        return st.as_dict()
+
+    def iterate(self, flags, n):
+        arr = (IterStats * n)()
+        self._check(self._fn("iterate")(self.ctx, C.c_int(flags), C.c_int(n), arr), "iterate")
+        return [a.as_dict() for a in arr]
+
+    def optimize(self, flags, cap=256):
+        arr = (IterStats * cap)()
+        n, res = C.c_int(), C.c_int()
+        self._check(self._fn("optimize")(self.ctx, C.c_int(flags), arr, C.c_int(cap), C.byref(n), C.byref(res), None, None), "optimize")
+        return [arr[i].as_dict() for i in range(min(n.value, cap))], bool(res.value)
+
+    def upsample2x(self):
+        self._check(self._fn("upsample2x")(self.ctx), "upsample2x")
+
+    # -- outputs
+    def info(self):
+        i = Info()
+        self._check(self._fn("get_info")(self.ctx, C.byref(i)), "get_info")
+        return i
+
+    def download_volume(self, want_vis=False):
+        i = self.info()
+        n = int(i.dim[0]) * int(i.dim[1]) * int(i.dim[2])
+        dist = np.empty(n, np.float32); grad = np.empty((3, n), np.float32)
+        weight = np.empty(n, np.float32); rgb = np.empty((3, n), np.float32)
+        vis = np.empty((n, i.vis_words), np.uint64) if want_vis else None
+        self._check(self._fn("download_volume")(self.ctx, dist.ctypes.data_as(C.c_void_p), grad.ctypes.data_as(C.c_void_p),
+                                                 weight.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p),
+                                                 vis.ctypes.data_as(C.c_void_p) if want_vis else None), "download_volume")
+        return dict(dist=dist, grad=grad, weight=weight, rgb=rgb, vis=vis)
+
+    def download_band(self):
+        i = self.info()
+        b = np.empty(max(i.n_band, 1), np.int32)
+        self._check(self._fn("download_band")(self.ctx, b.ctypes.data_as(C.c_void_p)), "download_band")
+        return b[: i.n_band]
+
+    def download_poses(self):
+        i = self.info()
+        p = np.empty((i.n_frames, 16), np.float32)
+        self._check(self._fn("download_poses")(self.ctx, p.ctypes.data_as(C.c_void_p)), "download_poses")
+        return p
+
+    def download_light(self):
+        i = self.info()
+        shape = (3,) if self._settings.model == LED else (i.n_frames, i.light_stride)
+        l = np.empty(shape, np.float32)
+        self._check(self._fn("download_light")(self.ctx, l.ctypes.data_as(C.c_void_p)), "download_light")
+        return l
+
+    def upload_light(self, light):
+        a, p = _fp(light)
+        self._check(self._fn("upload_light")(self.ctx, p), "upload_light")
+
+    # -- test hooks
+    def debug_dist_system(self, x=None):
+        S = self.info().n_band
+        diag = np.empty(S, np.float32); rhs = np.empty(S, np.float32)
+        y = np.empty(S, np.float32) if x is not None else None
+        xa = np.ascontiguousarray(x, np.float32) if x is not None else None
+        self._check(self._fn("debug_dist_system")(self.ctx, diag.ctypes.data_as(C.c_void_p), rhs.ctypes.data_as(C.c_void_p),
+                                                   xa.ctypes.data_as(C.c_void_p) if x is not None else None,
+                                                   y.ctypes.data_as(C.c_void_p) if x is not None else None), "debug_dist_system")
+        return diag, rhs, y
+
+    def debug_frame_system(self, block):
+        i = self.info()
+        if block == LIGHT:
+            n = i.light_stride; nb = 1 if self._settings.model == LED else i.n_frames
+        else:
+            n = 6; nb = i.n_frames
+        H = np.empty((nb, n, n), np.float64); b = np.empty((nb, n), np.float64)
+        self._check(self._fn("debug_frame_system")(self.ctx, C.c_int(block), H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)), "debug_frame_system")
+        return H, b
+
+    def debug_albedo_system(self):
+        S = self.info().n_band
+        H = np.empty((S, 3), np.float32); b = np.empty((S, 3), np.float32)
+        self._check(self._fn("debug_albedo_system")(self.ctx, H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)), "debug_albedo_system")
+        return H, b
+
+
+def grid_of(sc) -> GridDesc:
+    g = GridDesc()
+    g.dim[:] = [int(x) for x in sc.dim]
+    g.voxel_size = float(sc.voxel_size)
+    g.shift[:] = [float(x) for x in sc.shift]
+    g.truncation = float(sc.truncation)
+    return g
+
+
+_engine_lib = None
+
+
+def engine_lib() -> C.CDLL:
+    """dlopen the HIP engine; raises (no fallback) if it has not been built."""
+    global _engine_lib
+    if _engine_lib is None:
+        if not os.path.exists(ENGINE_LIB):
+            raise PsgsdfError(f"HIP engine {ENGINE_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _engine_lib = C.CDLL(ENGINE_LIB)
+    return _engine_lib
+
+
+def load_engine(sc_or_grid, K, settings: Settings, device: int = 0) -> Api:
+    grid = sc_or_grid if isinstance(sc_or_grid, GridDesc) else grid_of(sc_or_grid)
+    return Api(engine_lib(), "psgsdf_", grid, K, settings, device)

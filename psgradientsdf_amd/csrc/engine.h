@@ -1,0 +1,120 @@
+// engine.h — data layout shared by the host orchestration (engine.hip) and the gfx950 kernels
+// (kernels.hip).  Internal: the public boundary is include/psgsdf.h.
+//
+// Layout in HBM:
+//   dense grid  : SoA planes dist | gx | gy | gz | weight | r | g | b (float, x-fastest) + packed
+//                 visibility words + row_of[lin] (int32, -1 = not in band).  Source of truth for
+//                 band construction, 2x refinement and download.
+//   band        : the surface band (|d| <= sqrt(3) vs, seen >= 1; OptimizerAux.cpp:237-257)
+//                 compacted in ascending linear index, every per-voxel quantity as its own
+//                 padded plane so that lane i of a wavefront touches element i of each plane.
+//   frames      : float32 RGB images, interleaved, resident for the whole optimisation;
+//                 per-frame pose / light in a 96-byte record staged through LDS by every sweep.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psg {
+
+constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts of 64)
+constexpr int kMaxFramesLds = 128;   // frame records staged in LDS (12 KiB)
+constexpr int kNQ = 19;              // columns of one assembled distance-system row (ELL)
+constexpr int kMaxBasis = 9;
+
+struct FrameP {       // 24 floats = 96 B
+    float R[9];       // camera->world rotation, row-major (Optimizer.h:52-55)
+    float t[3];       // camera centre                      (Optimizer.h:57-60)
+    float l[9];       // SH light of this frame; LED: global RGB intensity in l[0..2]
+    float pad[3];
+};
+
+struct Cam { float fx, fy, cx, cy; int W, H; };
+
+struct GridP {
+    int dim[3];
+    long long nvox;
+    float vs, vs_inv;
+    float origin[3];
+    float T;
+};
+
+struct Robust { int loss; float lambda, lambda_sq; };
+
+// Band view: plain pointers into one big allocation; Spad = S rounded up to kBlock.
+struct Band {
+    int S, Spad, KW;
+    int* lin;                 // [Spad] linear voxel index
+    float* dist;              // [Spad]
+    float* g[3];              // stored gradient (un-normalised), SdfVoxel::grad
+    float* rho[3];            // albedo r,g,b
+    uint64_t* vis;            // [KW][Spad] keyframe visibility words
+    int* nb;                  // [6][Spad] band row of +x,-x,+y,-y,+z,-z neighbour or -1
+    float* nbd;               // [6][Spad] distance of that neighbour when it is NOT in the band (static)
+    int* col;                 // [kNQ][Spad] band row of each ELL column offset or -1
+    // derived per voxel, refreshed whenever dist / grad change (k_derive)
+    float* xs[3];             // surface point x_v - d*normalized(grad)      (OptimizerAux.cpp:215)
+    float* gn[3];             // normalized(stored grad)
+    float* gfd[3];            // finite-difference gradient (Optimizer.cpp:287-364), un-normalised
+    // albedo diagonal system
+    float* aH; float* ab;     // [3][Spad]
+    // distance system: per-voxel 4x4 block (10 sym) + 4 rhs, then assembled ELL rows
+    float* blk;               // [14][Spad]
+    float* H;                 // [kNQ][Spad]
+    float* rhs; float* x; float* r; float* z; float* t; float* p[2]; float* inv;
+};
+
+// accumulators for the per-frame normal equations and the scalar reductions (double)
+struct Accum {
+    double* frame;            // [F][stride] light: n(n+1)/2 + n, pose: 21 + 6
+    double* scal;             // [8]: 0 energy sum, 1 n_obs, 2 E_n sum, 3 E_l sum, 4 accepted, 5 aux0.. 7 aux2
+};
+
+enum { SC_ENERGY = 0, SC_NOBS = 1, SC_EN = 2, SC_EL = 3, SC_ACCEPT = 4, SC_AUX0 = 5, SC_AUX1 = 6, SC_AUX2 = 7, SC_COUNT = 8 };
+
+struct SweepArgs {
+    Band b;
+    const FrameP* frames;     // [F]
+    const float* img;         // [F][H][W][3]
+    int F;
+    Cam cam;
+    GridP grid;
+    Robust rob;
+    Accum acc;
+    int model;                // 0 SH1, 1 SH2, 2 LED
+    int quirks;
+    float reg_n, reg_l;
+    int normal_reg, laplacian_reg;
+    float damping;
+};
+
+// ---- launchers implemented in kernels.hip (all asynchronous on `s`) ----------------------
+void launch_select_vis(const uint64_t* vis_seq, int wpv_seq, uint64_t* vis_key, int KW, const int* frame_idx, int F, long long nvox, hipStream_t s);
+void launch_band_flags(const float* dist, const uint64_t* vis_key, int KW, float vs, long long nvox, int* flags, hipStream_t s);
+// exclusive scan of flags -> row_of (-1 where flag==0); returns total through d_total (device int)
+void launch_band_scan(int* flags_inout_rowof, long long nvox, int* block_sums, int* d_total, hipStream_t s);
+struct DenseView { float* dist; float* g[3]; float* weight; float* rho[3]; uint64_t* vis; int KW; int* row_of; };
+void launch_band_fill(const DenseView& d, const GridP& grid, Band b, hipStream_t s);
+void launch_band_scatter(const DenseView& d, Band b, hipStream_t s);
+void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s);
+void launch_init_albedo(const SweepArgs& a, hipStream_t s);
+void launch_led_light_init(const SweepArgs& a, hipStream_t s);
+void launch_energy(const SweepArgs& a, hipStream_t s);
+void launch_sweep_albedo(const SweepArgs& a, hipStream_t s);
+void launch_apply_albedo(const SweepArgs& a, hipStream_t s);
+void launch_sweep_light(const SweepArgs& a, hipStream_t s);
+void launch_sweep_pose(const SweepArgs& a, hipStream_t s);
+void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, hipStream_t s);
+void launch_solve_pose(const SweepArgs& a, FrameP* frames, hipStream_t s);
+void launch_sweep_dist(const SweepArgs& a, hipStream_t s);
+void launch_assemble(const SweepArgs& a, hipStream_t s);
+void launch_pcg_init(const SweepArgs& a, double* sc, hipStream_t s);
+void launch_pcg_mv(const SweepArgs& a, double* sc, int k, int with_damping, hipStream_t s);
+void launch_pcg_upd(const SweepArgs& a, double* sc, int k, hipStream_t s);
+void launch_matvec(const SweepArgs& a, const float* x, float* y, hipStream_t s);   // debug: y = H x (no damping)
+void launch_apply_dist(const SweepArgs& a, hipStream_t s);
+void launch_upsample(const DenseView& src, const DenseView& dst, const GridP& g_old, hipStream_t s);
+void launch_fill_f32(float* p, float v, long long n, hipStream_t s);
+
+constexpr int kPcgScalHead = 4;   // sc[0]=|b|^2, sc[1]=r0.z0, then 3 doubles per iteration: p.t, |r|^2, r.z
+
+}  // namespace psg

@@ -1,0 +1,717 @@
+// engine.hip — host orchestration of the HIP engine and the C ABI of include/psgsdf.h.
+// One context = one HIP device + one stream.  All kernels live in kernels.hip.
+#include "engine.h"
+#include "../../include/psgsdf.h"
+
+#include <math.h>
+#include <float.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace psg;
+
+namespace {
+
+struct KTime { double ms = 0; int64_t n = 0; };
+
+}  // namespace
+
+struct psgsdf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    psgsdf_settings set{};
+    float reg_n = 0, reg_l = 0;
+    GridP grid{};
+    float shift[3]{};
+    Cam cam{};
+    // dense
+    DenseView dense{};
+    uint64_t* vis_seq = nullptr; int wpv_seq = 0;
+    int* block_sums = nullptr; int* d_total = nullptr;
+    bool have_volume = false;
+    // frames
+    int F = 0;
+    int* frame_idx = nullptr;
+    float* img = nullptr;
+    FrameP* frames = nullptr;            // device
+    std::vector<FrameP> frames_h;        // host mirror of the initial records
+    float* led_light = nullptr;          // device [3]
+    bool have_frames = false;
+    // band
+    void* band_mem = nullptr; size_t band_bytes = 0;
+    Band band{};
+    bool inited = false;
+    // accumulators
+    double* acc_frame = nullptr; size_t acc_frame_n = 0;
+    double* scal = nullptr;
+    double* pcg_sc = nullptr; int pcg_cap = 4096;
+    double* host_buf = nullptr;          // pinned readback
+    // cached energies
+    double en_sum = 0, el_sum = 0;       // sums over the band from the last k_derive
+    // comm
+    int rank = 0, n_ranks = 1;
+    // profiling
+    bool profiling = false;
+    std::map<std::string, KTime> ktimes;
+    std::vector<const char*> kt_names;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    char err[512] = {0};
+};
+
+namespace {
+
+int fail(psgsdf_ctx* c, int code, const char* fmt, ...) {
+    if (c) { va_list ap; va_start(ap, fmt); vsnprintf(c->err, sizeof(c->err), fmt, ap); va_end(ap); }
+    return code;
+}
+#define HIPCHK(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(c, PSGSDF_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+
+template <class Fn> void timed(psgsdf_ctx* c, const char* name, Fn&& fn) {
+    if (!c->profiling) { fn(); return; }
+    hipEventRecord(c->ev0, c->stream);
+    fn();
+    hipEventRecord(c->ev1, c->stream);
+    hipEventSynchronize(c->ev1);
+    float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    KTime& k = c->ktimes[name]; k.ms += ms; k.n += 1;
+}
+
+SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
+    SweepArgs a{};
+    a.b = c->band; a.frames = c->frames; a.img = c->img; a.F = c->F; a.cam = c->cam; a.grid = c->grid;
+    a.rob.loss = c->set.loss; a.rob.lambda = c->set.lambda; a.rob.lambda_sq = c->set.lambda * c->set.lambda;
+    a.acc.frame = c->acc_frame; a.acc.scal = c->scal;
+    a.model = c->set.model; a.quirks = c->set.ref_quirks;
+    a.reg_n = c->reg_n; a.reg_l = c->reg_l;
+    a.normal_reg = c->reg_n != 0.0f; a.laplacian_reg = laplacian_reg;
+    a.damping = c->set.damping;
+    return a;
+}
+
+int zero_scal(psgsdf_ctx* c) { HIPCHK(c, hipMemsetAsync(c->scal, 0, sizeof(double) * SC_COUNT, c->stream)); return 0; }
+int read_scal(psgsdf_ctx* c, double* out) {
+    HIPCHK(c, hipMemcpyAsync(c->host_buf, c->scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(out, c->host_buf, sizeof(double) * SC_COUNT);
+    return 0;
+}
+
+void free_dense(psgsdf_ctx* c) {
+    hipFree(c->dense.dist); for (int a = 0; a < 3; ++a) { hipFree(c->dense.g[a]); hipFree(c->dense.rho[a]); }
+    hipFree(c->dense.weight); hipFree(c->dense.vis); hipFree(c->dense.row_of); hipFree(c->block_sums);
+    c->dense = DenseView{}; c->block_sums = nullptr;
+}
+int alloc_dense(psgsdf_ctx* c, DenseView& d, long long nvox, int KW, bool with_rowof) {
+    HIPCHK(c, hipMalloc(&d.dist, sizeof(float) * nvox));
+    for (int a = 0; a < 3; ++a) { HIPCHK(c, hipMalloc(&d.g[a], sizeof(float) * nvox)); HIPCHK(c, hipMalloc(&d.rho[a], sizeof(float) * nvox)); }
+    HIPCHK(c, hipMalloc(&d.weight, sizeof(float) * nvox));
+    d.KW = KW;
+    if (KW > 0) HIPCHK(c, hipMalloc(&d.vis, sizeof(uint64_t) * nvox * KW));
+    if (with_rowof) HIPCHK(c, hipMalloc(&d.row_of, sizeof(int) * nvox));
+    return 0;
+}
+
+// (re)build the band from the dense grid: flags -> scan -> compact planes -> neighbour tables
+int build_band(psgsdf_ctx* c) {
+    const long long nvox = c->grid.nvox;
+    const int KW = c->dense.KW;
+    if (!c->block_sums) HIPCHK(c, hipMalloc(&c->block_sums, sizeof(int) * ((nvox + 1023) / 1024 + 1)));
+    timed(c, "band_flags", [&] { launch_band_flags(c->dense.dist, c->dense.vis, KW, c->grid.vs, nvox, c->dense.row_of, c->stream); });
+    timed(c, "band_scan", [&] { launch_band_scan(c->dense.row_of, nvox, c->block_sums, c->d_total, c->stream); });
+    int S = 0;
+    HIPCHK(c, hipMemcpyAsync(&S, c->d_total, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int Spad = ((S + kBlock - 1) / kBlock) * kBlock + kBlock;
+    // planes (4-byte units per row): see Band
+    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 9 + 6 + 14 + kNQ + 9;
+    const size_t bytes = (n4 * 4 + (size_t)KW * 8) * Spad + 256;
+    if (c->band_mem) { hipFree(c->band_mem); c->band_mem = nullptr; }
+    HIPCHK(c, hipMalloc(&c->band_mem, bytes));
+    HIPCHK(c, hipMemsetAsync(c->band_mem, 0, bytes, c->stream));
+    c->band_bytes = bytes;
+    char* p = (char*)c->band_mem;
+    auto take = [&](size_t elems, size_t esz) { void* r = p; p += elems * esz * Spad; return r; };
+    Band& b = c->band;
+    b.S = S; b.Spad = Spad; b.KW = KW;
+    b.vis = (uint64_t*)take(KW, 8);
+    b.lin = (int*)take(1, 4);
+    b.dist = (float*)take(1, 4);
+    for (int a = 0; a < 3; ++a) b.g[a] = (float*)take(1, 4);
+    for (int a = 0; a < 3; ++a) b.rho[a] = (float*)take(1, 4);
+    b.nb = (int*)take(6, 4); b.nbd = (float*)take(6, 4); b.col = (int*)take(kNQ, 4);
+    for (int a = 0; a < 3; ++a) b.xs[a] = (float*)take(1, 4);
+    for (int a = 0; a < 3; ++a) b.gn[a] = (float*)take(1, 4);
+    for (int a = 0; a < 3; ++a) b.gfd[a] = (float*)take(1, 4);
+    b.aH = (float*)take(3, 4); b.ab = (float*)take(3, 4);
+    b.blk = (float*)take(14, 4); b.H = (float*)take(kNQ, 4);
+    b.rhs = (float*)take(1, 4); b.x = (float*)take(1, 4); b.r = (float*)take(1, 4); b.z = (float*)take(1, 4); b.t = (float*)take(1, 4);
+    b.p[0] = (float*)take(1, 4); b.p[1] = (float*)take(1, 4); b.inv = (float*)take(1, 4);
+    timed(c, "band_fill", [&] { launch_band_fill(c->dense, c->grid, b, c->stream); });
+    return 0;
+}
+
+int derive(psgsdf_ctx* c, int update_grad) {
+    int rc = zero_scal(c); if (rc) return rc;
+    SweepArgs a = make_args(c, 0);
+    timed(c, "derive", [&] { launch_derive(a, update_grad, c->stream); });
+    double s[SC_COUNT]; rc = read_scal(c, s); if (rc) return rc;
+    c->en_sum = s[SC_EN]; c->el_sum = s[SC_EL];
+    return 0;
+}
+
+inline double band_mean(const psgsdf_ctx* c, double sum) { return c->band.S ? sum / (double)c->band.S : 0.0; }
+inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l) { return E + c->reg_n * E_n + c->reg_l * E_l; }
+
+int ps_energy(psgsdf_ctx* c, double* E, int64_t* nobs) {
+    int rc = zero_scal(c); if (rc) return rc;
+    SweepArgs a = make_args(c, 0);
+    timed(c, "energy", [&] { launch_energy(a, c->stream); });
+    double s[SC_COUNT]; rc = read_scal(c, s); if (rc) return rc;
+    *E = band_mean(c, s[SC_ENERGY]); if (nobs) *nobs = (int64_t)s[SC_NOBS];
+    return 0;
+}
+
+int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_out, double* err_out) {
+    const int S = c->band.S;
+    int cap = c->set.cg_max_it > 0 ? c->set.cg_max_it : 2 * S;
+    if (cap > c->pcg_cap) cap = c->pcg_cap;
+    HIPCHK(c, hipMemsetAsync(c->pcg_sc, 0, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap), c->stream));
+    timed(c, "pcg_init", [&] { launch_pcg_init(a, c->pcg_sc, c->stream); });
+    const int chunk = 16;
+    int k = 0, iters = -1;
+    double rhsNorm2 = 0;
+    float rn2_last = 0;
+    while (true) {
+        int n = chunk; if (k + n > cap) n = cap - k;
+        for (int q = 0; q < n; ++q) {
+            timed(c, "pcg_mv", [&] { launch_pcg_mv(a, c->pcg_sc, k + q, 1, c->stream); });
+            timed(c, "pcg_upd", [&] { launch_pcg_upd(a, c->pcg_sc, k + q, c->stream); });
+        }
+        // read head + this chunk's scalars
+        HIPCHK(c, hipMemcpyAsync(c->host_buf, c->pcg_sc, sizeof(double) * kPcgScalHead, hipMemcpyDeviceToHost, c->stream));
+        if (n > 0) HIPCHK(c, hipMemcpyAsync(c->host_buf + kPcgScalHead, c->pcg_sc + kPcgScalHead + 3 * (size_t)k, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        rhsNorm2 = c->host_buf[0];
+        float rhsN = (float)rhsNorm2;
+        if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; return 0; }
+        float threshold = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
+        for (int q = 0; q < n; ++q) {
+            rn2_last = (float)c->host_buf[kPcgScalHead + 3 * q + 1];
+            if (rn2_last < threshold) { iters = k + q; break; }
+        }
+        if (iters >= 0) break;
+        k += n;
+        if (k >= cap || n == 0) { iters = cap; break; }
+    }
+    double err = sqrt((double)rn2_last / (double)(float)rhsNorm2);
+    *iters_out = iters; *err_out = err; *success_out = err <= (double)FLT_EPSILON;
+    return 0;
+}
+
+int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) {
+    psgsdf_step_stats tmp; if (!st) st = &tmp;
+    memset(st, 0, sizeof(*st));
+    st->block = block;
+    SweepArgs a = make_args(c, laplacian_reg);
+    const bool led = c->set.model == PSGSDF_LED;
+    double s[SC_COUNT];
+    int rc;
+    switch (block) {
+        case PSGSDF_ALBEDO: {
+            if ((rc = zero_scal(c))) return rc;
+            timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); });
+            timed(c, "apply_albedo", [&] { launch_apply_albedo(a, c->stream); });
+            if ((rc = read_scal(c, s))) return rc;
+            st->cg_iters = 1; st->cg_converged = 1; st->applied = 1; st->n_accepted = (int64_t)s[SC_ACCEPT];
+            break;
+        }
+        case PSGSDF_LIGHT: {
+            if ((rc = zero_scal(c))) return rc;
+            HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
+            timed(c, "sweep_light", [&] { launch_sweep_light(a, c->stream); });
+            timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->stream); });
+            if ((rc = read_scal(c, s))) return rc;
+            st->cg_converged = 1; st->applied = 1; st->n_accepted = led ? 1 : c->F;
+            break;
+        }
+        case PSGSDF_POSE: {
+            if ((rc = zero_scal(c))) return rc;
+            HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
+            timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); });
+            timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->stream); });
+            if ((rc = read_scal(c, s))) return rc;
+            st->cg_converged = 1; st->applied = 1; st->n_accepted = c->F;
+            break;
+        }
+        case PSGSDF_DIST: {
+            if ((rc = zero_scal(c))) return rc;
+            timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); });
+            timed(c, "assemble", [&] { launch_assemble(a, c->stream); });
+            int iters = 0, ok = 1; double err = 0;
+            if ((rc = pcg_solve(c, a, &iters, &ok, &err))) return rc;
+            int apply = 1;
+            if (!led && c->set.ref_quirks && !ok) apply = 0;   // PsOptimizer.cpp:168-170 (B8)
+            if (apply) timed(c, "apply_dist", [&] { launch_apply_dist(a, c->stream); });
+            if ((rc = read_scal(c, s))) return rc;
+            if (apply) { if ((rc = derive(c, 1))) return rc; }
+            st->cg_iters = iters; st->cg_converged = ok; st->cg_error = err; st->applied = apply; st->n_accepted = (int64_t)s[SC_ACCEPT];
+            break;
+        }
+        default: return fail(c, PSGSDF_ERR_ARG, "unknown block %d", block);
+    }
+    st->e_in = band_mean(c, s[SC_ENERGY]);
+    st->n_obs = (int64_t)s[SC_NOBS];
+    return 0;
+}
+
+// one body of the alternation loop; E/E_n/E_l carry the reference's float energies
+int iterate_once(psgsdf_ctx* c, int flags, int laplacian_reg, float* E, float* E_n, float* E_l, psgsdf_iter_stats* rec) {
+    const bool led = c->set.model == PSGSDF_LED;
+    const int order[4] = {led ? PSGSDF_LIGHT : PSGSDF_ALBEDO, led ? PSGSDF_ALBEDO : PSGSDF_LIGHT, PSGSDF_DIST, PSGSDF_POSE};
+    for (int q = 0; q < 4; ++q) rec->e_after[q] = NAN;
+    rec->cg_iters = 0;
+    int pending = -1;   // slot whose "energy after" is delivered by the next sweep's e_in
+    for (int q = 0; q < 4; ++q) {
+        const int blk = order[q];
+        if (!(flags & blk)) continue;
+        psgsdf_step_stats st;
+        int rc = do_step(c, blk, laplacian_reg, &st); if (rc) return rc;
+        if (pending >= 0) { *E = (float)st.e_in; rec->e_after[pending] = (double)*E; }
+        if (blk == PSGSDF_DIST) {
+            rec->cg_iters = st.cg_iters;
+            if (c->reg_n != 0.f) *E_n = (float)band_mean(c, c->en_sum);
+            if (laplacian_reg) *E_l = (float)band_mean(c, c->el_sum);
+        }
+        pending = blk == PSGSDF_ALBEDO ? 0 : blk == PSGSDF_LIGHT ? 1 : blk == PSGSDF_DIST ? 2 : 3;
+    }
+    if (pending >= 0) {
+        double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;
+        *E = (float)e; rec->e_after[pending] = (double)*E;
+    }
+    rec->e_n = *E_n; rec->e_l = *E_l;
+    rec->e_total = (double)total_energy(c, *E, *E_n, *E_l);
+    rec->reg_weight_n = c->reg_n; rec->reg_weight_l = c->reg_l;
+    return 0;
+}
+
+int do_upsample(psgsdf_ctx* c) {
+    // bring the dense grid up to date, refine, rebuild the band
+    timed(c, "band_scatter", [&] { launch_band_scatter(c->dense, c->band, c->stream); });
+    DenseView nd{};
+    const long long nn = 8 * c->grid.nvox;
+    int rc = alloc_dense(c, nd, nn, c->dense.KW, true); if (rc) return rc;
+    timed(c, "upsample", [&] { launch_upsample(c->dense, nd, c->grid, c->stream); });
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_dense(c);
+    c->dense = nd;
+    if (c->vis_seq) { hipFree(c->vis_seq); c->vis_seq = nullptr; }
+    GridP& g = c->grid;
+    g.vs *= 0.5f;
+    for (int a = 0; a < 3; ++a) g.dim[a] *= 2;
+    for (int a = 0; a < 3; ++a) g.origin[a] = c->shift[a] - (float)(0.5 * (double)g.vs) * (float)g.dim[a] - (float)(0.5 * (double)g.vs) * 1.0f;   // VoxelGrid.h:143-149
+    g.nvox = nn;
+    g.vs_inv = (float)(1.0 / (double)g.vs);
+    if ((rc = build_band(c))) return rc;
+    return derive(c, 0);
+}
+
+}  // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+extern "C" {
+
+const char* psgsdf_version(void) { return "psgsdf-hip gfx950 r1"; }
+const char* psgsdf_last_error(const psgsdf_ctx* c) { return c ? c->err : "null context"; }
+
+int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_settings* settings, int device, psgsdf_ctx** out) {
+    if (!grid || !K || !settings || !out) return PSGSDF_ERR_ARG;
+    if (settings->reg_weight_rho != 0.0f) return PSGSDF_ERR_UNSUPPORTED;
+    if (settings->model < 0 || settings->model > 2) return PSGSDF_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PSGSDF_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return PSGSDF_ERR_DEVICE;
+    psgsdf_ctx* c = new psgsdf_ctx();
+    c->device = device;
+    c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l;
+    GridP& g = c->grid;
+    for (int a = 0; a < 3; ++a) { g.dim[a] = grid->dim[a]; c->shift[a] = grid->shift[a]; }
+    g.nvox = (long long)g.dim[0] * g.dim[1] * g.dim[2];
+    g.vs = grid->voxel_size; g.vs_inv = 1.f / g.vs; g.T = grid->truncation;
+    for (int a = 0; a < 3; ++a) g.origin[a] = c->shift[a] - (float)(0.5 * (double)g.vs) * (float)g.dim[a];   // VoxelGrid.h:130
+    c->cam.fx = K[0]; c->cam.fy = K[4]; c->cam.cx = K[2]; c->cam.cy = K[5];
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess
+        && hipMalloc(&c->scal, sizeof(double) * SC_COUNT) == hipSuccess
+        && hipMalloc(&c->pcg_sc, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap)) == hipSuccess
+        && hipHostMalloc(&c->host_buf, sizeof(double) * (kPcgScalHead + 3 * 64 + SC_COUNT + 64)) == hipSuccess
+        && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess
+        && hipMalloc(&c->led_light, sizeof(float) * 3) == hipSuccess
+        && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    if (!ok) { delete c; return PSGSDF_ERR_DEVICE; }
+    *out = c;
+    return PSGSDF_OK;
+}
+
+void psgsdf_destroy(psgsdf_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    free_dense(c);
+    hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->frames); hipFree(c->led_light);
+    hipFree(c->band_mem); hipFree(c->acc_frame); hipFree(c->scal); hipFree(c->pcg_sc); hipFree(c->d_total);
+    if (c->host_buf) hipHostFree(c->host_buf);
+    if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int psgsdf_upload_volume(psgsdf_ctx* c, const float* dist, const float* grad_xyz, const float* weight, const float* rgb, const uint64_t* vis_words, int words_per_voxel) {
+    if (!c || !dist || !grad_xyz || !weight || !rgb || !vis_words || words_per_voxel < 1) return fail(c, PSGSDF_ERR_ARG, "upload_volume: null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long n = c->grid.nvox;
+    free_dense(c);
+    if (c->vis_seq) { hipFree(c->vis_seq); c->vis_seq = nullptr; }
+    int rc = alloc_dense(c, c->dense, n, 0, true); if (rc) return rc;
+    HIPCHK(c, hipMalloc(&c->vis_seq, sizeof(uint64_t) * n * words_per_voxel));
+    c->wpv_seq = words_per_voxel;
+    HIPCHK(c, hipMemcpyAsync(c->dense.dist, dist, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    for (int a = 0; a < 3; ++a) {
+        HIPCHK(c, hipMemcpyAsync(c->dense.g[a], grad_xyz + (size_t)a * n, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dense.rho[a], rgb + (size_t)a * n, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->dense.weight, weight, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->vis_seq, vis_words, sizeof(uint64_t) * n * words_per_voxel, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_volume = true; c->inited = false;
+    return PSGSDF_OK;
+}
+
+int psgsdf_set_keyframes(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_images, int width, int height, const float* poses) {
+    if (!c || n_frames <= 0 || !frame_idx || !rgb_images || !poses || width <= 1 || height <= 1) return fail(c, PSGSDF_ERR_ARG, "set_keyframes: bad argument");
+    if (n_frames > kMaxFramesLds) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d keyframes", kMaxFramesLds);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipFree(c->frame_idx); hipFree(c->img); hipFree(c->frames); hipFree(c->acc_frame);
+    c->frame_idx = nullptr; c->img = nullptr; c->frames = nullptr; c->acc_frame = nullptr;
+    c->F = n_frames; c->cam.W = width; c->cam.H = height;
+    const size_t npx = (size_t)n_frames * width * height * 3;
+    HIPCHK(c, hipMalloc(&c->frame_idx, sizeof(int) * n_frames));
+    HIPCHK(c, hipMalloc(&c->img, sizeof(float) * npx));
+    HIPCHK(c, hipMalloc(&c->frames, sizeof(FrameP) * n_frames));
+    c->acc_frame_n = (size_t)n_frames * 64;
+    HIPCHK(c, hipMalloc(&c->acc_frame, sizeof(double) * c->acc_frame_n));
+    HIPCHK(c, hipMemcpyAsync(c->frame_idx, frame_idx, sizeof(int) * n_frames, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->img, rgb_images, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
+    c->frames_h.assign(n_frames, FrameP{});
+    for (int f = 0; f < n_frames; ++f) {
+        const float* P = poses + 16 * f;
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) c->frames_h[f].R[i * 3 + j] = P[i * 4 + j]; c->frames_h[f].t[i] = P[i * 4 + 3]; }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->frames, c->frames_h.data(), sizeof(FrameP) * n_frames, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_frames = true; c->inited = false;
+    return PSGSDF_OK;
+}
+
+int psgsdf_init(psgsdf_ctx* c) {
+    if (!c || !c->have_volume || !c->have_frames) return fail(c, PSGSDF_ERR_STATE, "init: upload_volume and set_keyframes first");
+    if (!c->vis_seq) return fail(c, PSGSDF_ERR_STATE, "init: volume was refined; upload it again");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int KW = (c->F + 63) / 64;
+    if (c->dense.vis) { hipFree(c->dense.vis); c->dense.vis = nullptr; }
+    HIPCHK(c, hipMalloc(&c->dense.vis, sizeof(uint64_t) * c->grid.nvox * KW));
+    c->dense.KW = KW;
+    timed(c, "select_vis", [&] { launch_select_vis(c->vis_seq, c->wpv_seq, c->dense.vis, KW, c->frame_idx, c->F, c->grid.nvox, c->stream); });
+    int rc = build_band(c); if (rc) return rc;
+    // light initialisation: PsOptimizer.cpp:30-37 l = SH(R*(0,0,-1)), l[0] = 0.02 ; LED: ones, then intensity ratio
+    const bool led = c->set.model == PSGSDF_LED;
+    for (int f = 0; f < c->F; ++f) {
+        FrameP& fp = c->frames_h[f];
+        for (int i = 0; i < 9; ++i) fp.l[i] = 0.f;
+        if (led) { fp.l[0] = fp.l[1] = fp.l[2] = 1.0f; continue; }
+        float n[3];
+        for (int i = 0; i < 3; ++i) n[i] = (fp.R[i * 3 + 0] * 0.0f + fp.R[i * 3 + 1] * 0.0f) + fp.R[i * 3 + 2] * -1.0f;
+        fp.l[0] = 0.02f; fp.l[1] = n[0]; fp.l[2] = n[1]; fp.l[3] = n[2];
+        if (c->set.model == PSGSDF_SH2) { fp.l[4] = n[0] * n[1]; fp.l[5] = n[0] * n[2]; fp.l[6] = n[1] * n[2]; fp.l[7] = n[0] * n[0] - n[1] * n[1]; fp.l[8] = n[0] * n[0] - n[2] * n[2]; }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->frames, c->frames_h.data(), sizeof(FrameP) * c->F, hipMemcpyHostToDevice, c->stream));
+    if ((rc = derive(c, 0))) return rc;
+    if (led) {   // computeLightIntensive, LedOptimizer.cpp:76-112
+        if ((rc = zero_scal(c))) return rc;
+        SweepArgs a = make_args(c, 0);
+        timed(c, "led_light_init", [&] { launch_led_light_init(a, c->stream); });
+        double s[SC_COUNT]; if ((rc = read_scal(c, s))) return rc;
+        float L[3] = {(float)s[SC_AUX0] / (float)s[SC_EN], (float)s[SC_AUX1] / (float)s[SC_EL], (float)s[SC_AUX2] / (float)s[SC_ACCEPT]};
+        std::vector<FrameP> fr(c->F);
+        HIPCHK(c, hipMemcpy(fr.data(), c->frames, sizeof(FrameP) * c->F, hipMemcpyDeviceToHost));
+        for (int f = 0; f < c->F; ++f) for (int ch = 0; ch < 3; ++ch) fr[f].l[ch] = L[ch];
+        HIPCHK(c, hipMemcpy(c->frames, fr.data(), sizeof(FrameP) * c->F, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->led_light, L, sizeof(L), hipMemcpyHostToDevice));
+        if ((rc = derive(c, 0))) return rc;   // restores the cached Eikonal / Laplacian sums
+    }
+    c->inited = true;
+    return PSGSDF_OK;
+}
+
+int psgsdf_init_albedo(psgsdf_ctx* c) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SweepArgs a = make_args(c, 0);
+    timed(c, "init_albedo", [&] { launch_init_albedo(a, c->stream); });
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSGSDF_OK;
+}
+
+int psgsdf_energy(psgsdf_ctx* c, double out[4]) {
+    if (!c || !c->inited || !out) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    double E; int rc = ps_energy(c, &E, nullptr); if (rc) return rc;
+    out[0] = E; out[1] = band_mean(c, c->en_sum); out[2] = band_mean(c, c->el_sum);
+    out[3] = (double)total_energy(c, (float)out[0], c->reg_n != 0.f ? (float)out[1] : 0.f, c->reg_l != 0.f ? (float)out[2] : 0.f);
+    return PSGSDF_OK;
+}
+
+int psgsdf_normalize_weights(psgsdf_ctx* c, double* e_total) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;
+    float E = (float)e, E_n = 0, E_l = 0;
+    if (c->reg_n != 0.f) { E_n = (float)band_mean(c, c->en_sum); c->reg_n *= E / E_n; }   // PsOptimizer.cpp:275-278
+    if (c->reg_l != 0.f) { E_l = (float)band_mean(c, c->el_sum); c->reg_l *= E / E_l; }   // PsOptimizer.cpp:281-284
+    if (e_total) *e_total = (double)total_energy(c, E, E_n, E_l);
+    return PSGSDF_OK;
+}
+
+int psgsdf_step(psgsdf_ctx* c, int block, psgsdf_step_stats* stats) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    return do_step(c, block, c->reg_l != 0.f, stats);
+}
+
+int psgsdf_iterate(psgsdf_ctx* c, int flags, int n_iters, psgsdf_iter_stats* stats) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;
+    float E = (float)e;
+    float E_n = c->reg_n != 0.f ? (float)band_mean(c, c->en_sum) : 0.f, E_l = c->reg_l != 0.f ? (float)band_mean(c, c->el_sum) : 0.f;
+    float E_prev = total_energy(c, E, E_n, E_l);
+    for (int it = 0; it < n_iters; ++it) {
+        psgsdf_iter_stats rec; memset(&rec, 0, sizeof(rec));
+        if ((rc = iterate_once(c, flags, c->reg_l != 0.f, &E, &E_n, &E_l, &rec))) return rc;
+        float Et = (float)rec.e_total;
+        rec.rel_diff = (double)(fabsf(E_prev - Et) / E_prev);
+        rec.converged = rec.rel_diff < (double)c->set.conv_threshold; rec.diverged = E_prev < Et;
+        E_prev = Et;
+        if (stats) stats[it] = rec;
+    }
+    return PSGSDF_OK;
+}
+
+int psgsdf_optimize(psgsdf_ctx* c, int flags, psgsdf_iter_stats* stats, int stats_cap, int* n_done, int* result, psgsdf_iter_cb on_iter, void* user) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool led = c->set.model == PSGSDF_LED;
+    int laplacian_reg = c->reg_l != 0.f;
+    int rc = psgsdf_init_albedo(c); if (rc) return rc;
+    double e; if ((rc = ps_energy(c, &e, nullptr))) return rc;
+    float E = (float)e, E_n = 0, E_l = 0;
+    if (c->reg_n != 0.f) { E_n = (float)band_mean(c, c->en_sum); c->reg_n *= E / E_n; }
+    if (laplacian_reg) { E_l = (float)band_mean(c, c->el_sum); c->reg_l *= E / E_l; if (c->set.upsample) laplacian_reg = 0; }
+    float E_prev = total_energy(c, E, E_n, E_l);
+    int iter = 0, done = 0; if (result) *result = 0;
+    while (iter < c->set.max_it) {
+        psgsdf_iter_stats rec; memset(&rec, 0, sizeof(rec));
+        if ((rc = iterate_once(c, flags, laplacian_reg, &E, &E_n, &E_l, &rec))) return rc;
+        float Et = (float)rec.e_total;
+        rec.rel_diff = (double)(fabsf(E_prev - Et) / E_prev);
+        rec.converged = rec.rel_diff < (double)c->set.conv_threshold;
+        rec.diverged = !rec.converged && (E_prev < Et);
+        const bool stop = rec.converged || rec.diverged;
+        float E_last = Et;
+        if (!stop && iter == 5 && c->set.upsample) {   // PsOptimizer.cpp:386-409
+            if (c->reg_l == 0.0f) c->reg_l = 1.0f;
+            laplacian_reg = 1;
+            if ((rc = do_upsample(c))) return rc;
+            E_l = (float)band_mean(c, c->el_sum);
+            c->reg_l *= E / E_l;
+            E_last = total_energy(c, E, E_n, E_l);
+            rec.upsampled = 1;
+        }
+        if (!stop && c->set.upsample && (led ? iter == 15 : iter > 15)) c->reg_l = 0.0f;   // PsOptimizer.cpp:411-413 / LedOptimizer.cpp:461-463
+        E_prev = E_last;
+        if (stats && done < stats_cap) stats[done] = rec;
+        done++;
+        if (rec.converged) { if (result) *result = 1; break; }
+        if (rec.diverged) break;
+        ++iter;
+        if (on_iter && on_iter(user, iter, &rec)) break;
+    }
+    if (n_done) *n_done = done;
+    return PSGSDF_OK;
+}
+
+int psgsdf_upsample2x(psgsdf_ctx* c) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    return do_upsample(c);
+}
+
+int psgsdf_get_info(psgsdf_ctx* c, psgsdf_info* info) {
+    if (!c || !info) return PSGSDF_ERR_ARG;
+    for (int a = 0; a < 3; ++a) { info->dim[a] = c->grid.dim[a]; info->origin[a] = c->grid.origin[a]; }
+    info->voxel_size = c->grid.vs; info->n_frames = c->F; info->n_band = c->inited ? c->band.S : 0;
+    info->light_stride = c->set.model == PSGSDF_LED ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4);
+    info->vis_words = c->dense.KW; info->reg_weight_n = c->reg_n; info->reg_weight_l = c->reg_l;
+    return PSGSDF_OK;
+}
+
+int psgsdf_download_volume(psgsdf_ctx* c, float* dist, float* grad_xyz, float* weight, float* rgb, uint64_t* vis_words) {
+    if (!c || !c->have_volume) return fail(c, PSGSDF_ERR_STATE, "no volume");
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long n = c->grid.nvox;
+    if (c->inited) launch_band_scatter(c->dense, c->band, c->stream);
+    if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->dense.dist, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    for (int a = 0; a < 3; ++a) {
+        if (grad_xyz) HIPCHK(c, hipMemcpyAsync(grad_xyz + (size_t)a * n, c->dense.g[a], sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+        if (rgb) HIPCHK(c, hipMemcpyAsync(rgb + (size_t)a * n, c->dense.rho[a], sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (weight) HIPCHK(c, hipMemcpyAsync(weight, c->dense.weight, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    if (vis_words) {
+        if (!c->dense.vis) return fail(c, PSGSDF_ERR_STATE, "visibility not selected yet");
+        HIPCHK(c, hipMemcpyAsync(vis_words, c->dense.vis, sizeof(uint64_t) * n * c->dense.KW, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSGSDF_OK;
+}
+
+int psgsdf_download_band(psgsdf_ctx* c, int32_t* lin_idx) {
+    if (!c || !c->inited || !lin_idx) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(lin_idx, c->band.lin, sizeof(int) * c->band.S, hipMemcpyDeviceToHost));
+    return PSGSDF_OK;
+}
+
+int psgsdf_download_poses(psgsdf_ctx* c, float* poses) {
+    if (!c || !c->have_frames || !poses) return fail(c, PSGSDF_ERR_STATE, "no keyframes");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<FrameP> fr(c->F);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(fr.data(), c->frames, sizeof(FrameP) * c->F, hipMemcpyDeviceToHost));
+    for (int f = 0; f < c->F; ++f) {
+        float* P = poses + 16 * f;
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) P[i * 4 + j] = fr[f].R[i * 3 + j]; P[i * 4 + 3] = fr[f].t[i]; }
+        P[12] = P[13] = P[14] = 0.f; P[15] = 1.f;
+    }
+    return PSGSDF_OK;
+}
+
+int psgsdf_download_light(psgsdf_ctx* c, float* light) {
+    if (!c || !c->inited || !light) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<FrameP> fr(c->F);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(fr.data(), c->frames, sizeof(FrameP) * c->F, hipMemcpyDeviceToHost));
+    if (c->set.model == PSGSDF_LED) { for (int ch = 0; ch < 3; ++ch) light[ch] = fr[0].l[ch]; return PSGSDF_OK; }
+    const int nb = c->set.model == PSGSDF_SH2 ? 9 : 4;
+    for (int f = 0; f < c->F; ++f) for (int i = 0; i < nb; ++i) light[(size_t)f * nb + i] = fr[f].l[i];
+    return PSGSDF_OK;
+}
+
+int psgsdf_upload_light(psgsdf_ctx* c, const float* light) {
+    if (!c || !c->inited || !light) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<FrameP> fr(c->F);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(fr.data(), c->frames, sizeof(FrameP) * c->F, hipMemcpyDeviceToHost));
+    const bool led = c->set.model == PSGSDF_LED;
+    const int nb = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4);
+    for (int f = 0; f < c->F; ++f) for (int i = 0; i < nb; ++i) fr[f].l[i] = led ? light[i] : light[(size_t)f * nb + i];
+    HIPCHK(c, hipMemcpy(c->frames, fr.data(), sizeof(FrameP) * c->F, hipMemcpyHostToDevice));
+    if (led) HIPCHK(c, hipMemcpy(c->led_light, light, sizeof(float) * 3, hipMemcpyHostToDevice));
+    return PSGSDF_OK;
+}
+
+// ---- multi-GPU: implemented in a later step of round 1 ---------------------
+int psgsdf_comm_unique_id(uint8_t id[128]) { (void)id; return PSGSDF_ERR_UNSUPPORTED; }
+int psgsdf_comm_init(psgsdf_ctx* c, const uint8_t id[128], int rank, int n_ranks) {
+    (void)id;
+    if (!c) return PSGSDF_ERR_ARG;
+    if (n_ranks == 1 && rank == 0) return PSGSDF_OK;
+    return fail(c, PSGSDF_ERR_UNSUPPORTED, "multi-rank contexts are not built yet");
+}
+
+// ---- measurement / test hooks -------------------------------------------------------------
+int psgsdf_set_profiling(psgsdf_ctx* c, int enabled) { if (!c) return PSGSDF_ERR_ARG; c->profiling = enabled != 0; return PSGSDF_OK; }
+int psgsdf_reset_kernel_times(psgsdf_ctx* c) { if (!c) return PSGSDF_ERR_ARG; c->ktimes.clear(); return PSGSDF_OK; }
+int psgsdf_kernel_times(psgsdf_ctx* c, const char** names, double* ms, int64_t* launches, int cap) {
+    if (!c) return 0;
+    int n = 0;
+    for (auto& kv : c->ktimes) { if (n >= cap) break; names[n] = kv.first.c_str(); ms[n] = kv.second.ms; launches[n] = kv.second.n; ++n; }
+    return n;
+}
+
+int psgsdf_debug_dist_system(psgsdf_ctx* c, float* diag, float* rhs, const float* x, float* y) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = zero_scal(c); if (rc) return rc;
+    SweepArgs a = make_args(c, c->reg_l != 0.f);
+    launch_sweep_dist(a, c->stream);
+    launch_assemble(a, c->stream);
+    const int S = c->band.S;
+    if (diag) HIPCHK(c, hipMemcpyAsync(diag, c->band.H, sizeof(float) * S, hipMemcpyDeviceToHost, c->stream));
+    if (rhs) HIPCHK(c, hipMemcpyAsync(rhs, c->band.rhs, sizeof(float) * S, hipMemcpyDeviceToHost, c->stream));
+    if (x && y) {
+        HIPCHK(c, hipMemcpyAsync(c->band.x, x, sizeof(float) * S, hipMemcpyHostToDevice, c->stream));
+        launch_matvec(a, c->band.x, c->band.t, c->stream);
+        HIPCHK(c, hipMemcpyAsync(y, c->band.t, sizeof(float) * S, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSGSDF_OK;
+}
+
+int psgsdf_debug_frame_system(psgsdf_ctx* c, int block, double* H, double* b) {
+    if (!c || !c->inited || !H || !b) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = zero_scal(c); if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
+    SweepArgs a = make_args(c, 0);
+    const bool led = c->set.model == PSGSDF_LED;
+    int n, nb, nh;
+    if (block == PSGSDF_LIGHT) { launch_sweep_light(a, c->stream); n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4); nb = led ? 1 : c->F; nh = led ? 3 : n * (n + 1) / 2; }
+    else if (block == PSGSDF_POSE) { launch_sweep_pose(a, c->stream); n = 6; nb = c->F; nh = 21; }
+    else return fail(c, PSGSDF_ERR_ARG, "block must be LIGHT or POSE");
+    std::vector<double> acc(c->acc_frame_n);
+    HIPCHK(c, hipMemcpyAsync(acc.data(), c->acc_frame, sizeof(double) * c->acc_frame_n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < nb; ++k) {
+        const double* A = acc.data() + (size_t)k * (nh + n);
+        double* Hk = H + (size_t)k * n * n; double* bk = b + (size_t)k * n;
+        for (int i = 0; i < n * n; ++i) Hk[i] = 0;
+        if (led && block == PSGSDF_LIGHT) { for (int i = 0; i < 3; ++i) { Hk[i * 3 + i] = A[i]; bk[i] = A[3 + i]; } continue; }
+        int q = 0;
+        for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) { Hk[i * n + j] = A[q]; Hk[j * n + i] = A[q]; ++q; }
+        for (int i = 0; i < n; ++i) bk[i] = A[nh + i];
+    }
+    return PSGSDF_OK;
+}
+
+int psgsdf_debug_albedo_system(psgsdf_ctx* c, float* H, float* b) {
+    if (!c || !c->inited || !H || !b) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = zero_scal(c); if (rc) return rc;
+    SweepArgs a = make_args(c, 0);
+    launch_sweep_albedo(a, c->stream);
+    const int S = c->band.S, Sp = c->band.Spad;
+    std::vector<float> h(3 * (size_t)Sp), bb(3 * (size_t)Sp);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->band.aH, sizeof(float) * 3 * Sp, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(bb.data(), c->band.ab, sizeof(float) * 3 * Sp, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int j = 0; j < S; ++j) for (int ch = 0; ch < 3; ++ch) { H[3 * j + ch] = h[(size_t)ch * Sp + j]; b[3 * j + ch] = bb[(size_t)ch * Sp + j]; }
+    return PSGSDF_OK;
+}
+
+}  // extern "C"

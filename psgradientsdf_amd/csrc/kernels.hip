@@ -1,0 +1,1312 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the Gradient-SDF photometric-stereo
+// hot path.  No CUDA compatibility layer, no other back end.
+//
+// Reference arithmetic is cited per function (paths relative to /root/reference/cpp/include/).
+// Per-observation arithmetic is float32 in the reference's operation order; FMA contraction is
+// off in this file so projections / bilinear weights are bit-compatible with the CPU reference
+// build (baseline x86-64, no FMA).  Sums over many observations are accumulated in double.
+//
+// Kernel map:
+//   dense grid : k_select_vis, k_band_flags, k_scan_*, k_band_fill, k_band_nb, k_band_scatter, k_upsample
+//   per voxel  : k_derive (FD gradient / surface point / Eikonal+Laplacian energies), k_init_albedo,
+//                k_energy, k_sweep_albedo, k_sweep_dist            (voxel-major, set-bit iteration)
+//   per frame  : k_sweep_light, k_sweep_pose                        (frame-major, wave+LDS reduction)
+//   solves     : k_solve_light, k_solve_pose (LDL^T per frame), k_assemble, k_pcg_init/mv/upd
+#include "engine.h"
+#include <float.h>
+
+#pragma clang fp contract(off)
+
+namespace psg {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+__device__ __forceinline__ float norm3(const float* a) { return sqrtf(dot3(a, a)); }
+// Eigen normalized(): z>0 ? v/sqrt(z) : v
+__device__ __forceinline__ void normalized3(const float* v, float* o) {
+    float z = dot3(v, v);
+    if (z > 0.f) { float s = sqrtf(z); o[0] = v[0] / s; o[1] = v[1] / s; o[2] = v[2] / s; }
+    else { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; }
+}
+__device__ __forceinline__ void mulT3(const float* M, const float* v, float* o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = (M[0 * 3 + i] * v[0] + M[1 * 3 + i] * v[1]) + M[2 * 3 + i] * v[2];
+}
+__device__ __forceinline__ void mul3(const float* M, const float* v, float* o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = (M[i * 3 + 0] * v[0] + M[i * 3 + 1] * v[1]) + M[i * 3 + 2] * v[2];
+}
+template <int NB> __device__ __forceinline__ float dotn(const float* a, const float* b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) s += a[i] * b[i];
+    return s;
+}
+// PsOptimizerJa.cpp:17-28
+template <int NB> __device__ __forceinline__ void SH(const float* n, float* sh) {
+    sh[0] = 1.0f; sh[1] = n[0]; sh[2] = n[1]; sh[3] = n[2];
+    if (NB == 9) { sh[4] = n[0] * n[1]; sh[5] = n[0] * n[2]; sh[6] = n[1] * n[2]; sh[7] = n[0] * n[0] - n[1] * n[1]; sh[8] = n[0] * n[0] - n[2] * n[2]; }
+}
+template <int MODEL> struct ModelTraits { static constexpr int NB = MODEL == 1 ? 9 : (MODEL == 0 ? 4 : 3); static constexpr bool LED = MODEL == 2; };
+
+// Optimizer.cpp:140-161 / 164-186
+__device__ __forceinline__ float robust_weight(const Robust& rb, float r) {
+    switch (rb.loss) {
+        case 1: { float x = r / rb.lambda; return 1.0f / (1.0f + x * x); }
+        case 3: { float x = r / rb.lambda; float w = (1.0f - x * x); w = w * w; return (r * r < rb.lambda_sq) ? w : 0.0f; }
+        case 2: { float w = rb.lambda * fabsf(1.0f / r); return (r * r < rb.lambda_sq) ? 1.0f : w; }
+        case 4: return (r * r < rb.lambda_sq) ? 1.0f : 0.0f;
+        default: return 1.0f;
+    }
+}
+__device__ __forceinline__ float robust_loss(const Robust& rb, float r) {
+    switch (rb.loss) {
+        case 1: { float x = r / rb.lambda; return logf(1.0f + x * x); }
+        case 3: { float x = r / rb.lambda; float u = 1.0f - x * x; float v = 1.0f - u * u * u; return (r * r < rb.lambda_sq) ? v : 1.0f; }
+        case 2: return (r * r < rb.lambda_sq) ? 0.5f * (r * r) : rb.lambda * (fabsf(r) - 0.5f * rb.lambda * 1.0f);
+        case 4: { float x = fminf(fmaxf(r, -rb.lambda), rb.lambda); return x * x; }
+        default: return r * r;
+    }
+}
+
+// wavefront (64 lanes) and workgroup reductions; one device-scope atomic per workgroup
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sumf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// all threads of the block must call; red is __shared__ double[kBlock/64]
+__device__ __forceinline__ void block_atomic_add(double v, double* dst, double* red) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+        if (s != 0.0) atomicAdd(dst, s);
+    }
+}
+
+__device__ __forceinline__ void load_frames(FrameP* sf, const FrameP* frames, int F) {
+    const float* src = (const float*)frames; float* dst = (float*)sf;
+    for (int i = threadIdx.x; i < F * (int)(sizeof(FrameP) / 4); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// projection + image sampling
+// ------------------------------------------------------------------------------------------
+struct Proj { float p[3]; float m, n; bool ok; };
+
+// OptimizerAux.cpp:207-226 (surface point precomputed in xs = x_v - d*normalized(grad))
+__device__ __forceinline__ Proj project(const float* xs, const FrameP& fp, const Cam& cam) {
+    Proj o;
+    float tmp[3] = {xs[0] - fp.t[0], xs[1] - fp.t[1], xs[2] - fp.t[2]};
+    mulT3(fp.R, tmp, o.p);
+    float z_inv = (float)(1.0 / (double)o.p[2]);
+    o.m = cam.fx * o.p[0] * z_inv + cam.cx;
+    o.n = cam.fy * o.p[1] * z_inv + cam.cy;
+    o.ok = (o.m >= 0.f && o.m < (float)cam.W && o.n >= 0.f && o.n < (float)cam.H);
+    return o;
+}
+
+__device__ __forceinline__ const float* pix(const float* img, const Cam& cam, int row, int col) {
+    row = row < 0 ? 0 : (row >= cam.H ? cam.H - 1 : row);
+    col = col < 0 ? 0 : (col >= cam.W ? cam.W - 1 : col);
+    return img + ((size_t)row * cam.W + col) * 3;
+}
+
+// Auxilary.h:41-61 interpolateImage + Auxilary.h:64-123 computeImageGradient from one set of taps.
+// (row coordinate n_row, column coordinate m_col); gu = d/d(col), gv = d/d(row).
+template <bool GRAD>
+__device__ __forceinline__ void sample(const float* img, const Cam& cam, float m_col, float n_row, float* I, float* gu, float* gv) {
+    const float m = n_row, n = m_col;  // names of Auxilary.h: m = row, n = column
+    int x = (int)floorf(m), y = (int)floorf(n);
+    if ((x + 1) < cam.H && (y + 1) < cam.W) {
+        const float* p00 = img + ((size_t)x * cam.W + y) * 3;
+        const float* p10 = p00 + (size_t)cam.W * 3;
+        float a00[3] = {p00[0], p00[1], p00[2]}, a01[3] = {p00[3], p00[4], p00[5]};
+        float a10[3] = {p10[0], p10[1], p10[2]}, a11[3] = {p10[3], p10[4], p10[5]};
+        double w1 = ((double)y + 1.0 - (double)n) * (double)(m - (float)x);
+        double w2 = ((double)y + 1.0 - (double)n) * ((double)x + 1.0 - (double)m);
+        float w3 = (n - (float)y) * (m - (float)x);
+        double w4 = (double)(n - (float)y) * ((double)x + 1.0 - (double)m);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float t1 = (float)((double)a10[ch] * w1);
+            float t2 = (float)((double)a00[ch] * w2);
+            float t3 = a11[ch] * w3;
+            float t4 = (float)((double)a01[ch] * w4);
+            I[ch] = ((t1 + t2) + t3) + t4;
+        }
+        if (GRAD) {
+            float w01 = m - (float)x, w11 = n - (float)y;
+            float w00 = (float)(1.0 - (double)w01), w10 = (float)(1.0 - (double)w11);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                gu[ch] = w00 * (a01[ch] - a00[ch]) + w01 * (a11[ch] - a10[ch]);
+                gv[ch] = w10 * (a10[ch] - a00[ch]) + w11 * (a11[ch] - a01[ch]);
+            }
+        }
+    } else {  // last row / column: nearest sample, one-sided differences (Auxilary.h:55-57,90-121)
+        const float* p = pix(img, cam, x, y);
+        I[0] = p[0]; I[1] = p[1]; I[2] = p[2];
+        if (GRAD) {
+            float w01 = m - (float)x, w11 = n - (float)y;
+            float w00 = (float)(1.0 - (double)w01), w10 = (float)(1.0 - (double)w11);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                if ((x + 1) >= cam.H) gu[ch] = pix(img, cam, x, y + 1)[ch] - pix(img, cam, x, y)[ch];
+                else { float v0 = -pix(img, cam, x, y - 1)[ch] + pix(img, cam, x, y)[ch]; float v1 = -pix(img, cam, x + 1, y - 1)[ch] + pix(img, cam, x + 1, y)[ch]; gu[ch] = w00 * v0 + w01 * v1; }
+                if ((x + 1) >= cam.H && (y + 1) < cam.W) { float v0 = -pix(img, cam, x - 1, y)[ch] + pix(img, cam, x, y)[ch]; float v1 = -pix(img, cam, x - 1, y + 1)[ch] + pix(img, cam, x, y + 1)[ch]; gv[ch] = w10 * v0 + w11 * v1; }
+                else gv[ch] = pix(img, cam, x + 1, y)[ch] - pix(img, cam, x, y)[ch];
+            }
+        }
+    }
+}
+
+// rendered intensity: PsOptimizerJa.cpp:30-40 (SH) / LedOptimizerJa.cpp:15-29 (LED).
+// nfd = normalized FD gradient, shfd = SH(nfd) (SH models only)
+template <int MODEL>
+__device__ __forceinline__ void rendered(const FrameP& fp, const Proj& pr, const float* nfd, const float* shfd, const float* rho, float* out) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    float irr;
+    if (ModelTraits<MODEL>::LED) {
+        float Rp[3]; mul3(fp.R, pr.p, Rp);
+        irr = -dot3(nfd, Rp);
+        float pn = norm3(pr.p); double pd = (double)pn;
+        float ld = (float)(pd * pd * pd);
+        irr /= ld;
+        out[0] = rho[0] * fp.l[0] * irr; out[1] = rho[1] * fp.l[1] * irr; out[2] = rho[2] * fp.l[2] * irr;
+    } else {
+        irr = dotn<NB>(fp.l, shfd);
+        out[0] = rho[0] * irr; out[1] = rho[1] * irr; out[2] = rho[2] * irr;
+    }
+}
+
+// rhoJacobian: PsOptimizerJa.cpp:118-122 / LedOptimizerJa.cpp:85-99 (stored normal gn)
+template <int MODEL>
+__device__ __forceinline__ void rho_jac(const FrameP& fp, const Proj& pr, const float* gn, const float* shg, float* J) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    if (ModelTraits<MODEL>::LED) {
+        float Rp[3]; mul3(fp.R, pr.p, Rp);
+        float refl = dot3(gn, Rp);
+        float pn = norm3(pr.p); double pd = (double)pn;
+        refl /= (float)(pd * pd * pd);
+        J[0] = refl * fp.l[0]; J[1] = refl * fp.l[1]; J[2] = refl * fp.l[2];
+    } else {
+        float j = -dotn<NB>(fp.l, shg);
+        J[0] = J[1] = J[2] = j;
+    }
+}
+
+// per-voxel state in registers
+struct Vox { float xs[3], gn[3], nfd[3], rho[3]; };
+__device__ __forceinline__ void load_vox(const Band& b, int j, Vox& v) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { v.xs[a] = b.xs[a][j]; v.gn[a] = b.gn[a][j]; v.rho[a] = b.rho[a][j]; }
+    float g[3] = {b.gfd[0][j], b.gfd[1][j], b.gfd[2][j]};
+    normalized3(g, v.nfd);
+}
+
+// ------------------------------------------------------------------------------------------
+// dense-grid kernels: visibility selection, band construction, scatter, 2x refinement
+// ------------------------------------------------------------------------------------------
+
+// Optimizer.cpp:30-47 select_vis
+__global__ void __launch_bounds__(kBlock) k_select_vis(const uint64_t* __restrict__ vis_seq, int wpv_seq, uint64_t* __restrict__ vis_key, int KW, const int* __restrict__ frame_idx, int F, long long nvox) {
+    for (long long lin = blockIdx.x * (long long)blockDim.x + threadIdx.x; lin < nvox; lin += (long long)gridDim.x * blockDim.x) {
+        for (int w = 0; w < KW; ++w) {
+            uint64_t out = 0;
+            int f1 = min(F, 64 * (w + 1));
+            for (int f = 64 * w; f < f1; ++f) {
+                int s = frame_idx[f];
+                if (s >= 0 && s < 64 * wpv_seq && ((vis_seq[lin * wpv_seq + (s >> 6)] >> (s & 63)) & 1ull)) out |= 1ull << (f & 63);
+            }
+            vis_key[lin * KW + w] = out;
+        }
+    }
+}
+void launch_select_vis(const uint64_t* vis_seq, int wpv_seq, uint64_t* vis_key, int KW, const int* frame_idx, int F, long long nvox, hipStream_t s) {
+    int grid = (int)min((nvox + kBlock - 1) / kBlock, (long long)256 * 16);
+    hipLaunchKernelGGL(k_select_vis, dim3(grid), dim3(kBlock), 0, s, vis_seq, wpv_seq, vis_key, KW, frame_idx, F, nvox);
+}
+
+// OptimizerAux.cpp:237-257 getSurfaceVoxel membership test
+__global__ void __launch_bounds__(kBlock) k_band_flags(const float* __restrict__ dist, const uint64_t* __restrict__ vis_key, int KW, float vs, long long nvox, int* __restrict__ flags) {
+    const double thr = sqrt(3.0) * (double)vs;
+    for (long long lin = blockIdx.x * (long long)blockDim.x + threadIdx.x; lin < nvox; lin += (long long)gridDim.x * blockDim.x) {
+        bool seen = false;
+        for (int w = 0; w < KW; ++w) seen |= vis_key[lin * KW + w] != 0;
+        flags[lin] = ((double)fabsf(dist[lin]) <= thr && seen) ? 1 : 0;
+    }
+}
+void launch_band_flags(const float* dist, const uint64_t* vis_key, int KW, float vs, long long nvox, int* flags, hipStream_t s) {
+    int grid = (int)min((nvox + kBlock - 1) / kBlock, (long long)256 * 16);
+    hipLaunchKernelGGL(k_band_flags, dim3(grid), dim3(kBlock), 0, s, dist, vis_key, KW, vs, nvox, flags);
+}
+
+// three-phase exclusive scan over 1024-element tiles: flag -> band row (or -1)
+constexpr int kScanTile = 1024;
+__global__ void __launch_bounds__(kBlock) k_scan_tile(int* __restrict__ v, long long n, int* __restrict__ sums) {
+    __shared__ int wsum[kBlock / 64];
+    long long base = (long long)blockIdx.x * kScanTile + threadIdx.x * 4;
+    int f[4]; int loc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = (base + i < n) ? v[base + i] : 0; loc += f[i]; }
+    // inclusive scan of loc across the block: wave scan + wave offsets
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < w; ++i) woff += wsum[i];
+    int excl = woff + inc - loc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { if (base + i < n) v[base + i] = f[i] ? excl : -1; excl += f[i]; }
+    if (threadIdx.x == kBlock - 1) sums[blockIdx.x] = woff + inc;
+}
+__global__ void __launch_bounds__(1024) k_scan_sums(int* __restrict__ sums, int nb, int* __restrict__ total) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < nb; base += 1024) {
+        int i = base + threadIdx.x;
+        int val = i < nb ? sums[i] : 0;
+        int inc = val;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < w; ++k) woff += wsum[k];
+        int carry = carry_s;
+        if (i < nb) sums[i] = carry + woff + inc - val;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+__global__ void __launch_bounds__(kBlock) k_scan_add(int* __restrict__ v, long long n, const int* __restrict__ sums) {
+    long long base = (long long)blockIdx.x * kScanTile + threadIdx.x * 4;
+    int off = sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (base + i < n) { int x = v[base + i]; if (x >= 0) v[base + i] = x + off; }
+}
+void launch_band_scan(int* v, long long nvox, int* block_sums, int* d_total, hipStream_t s) {
+    int nb = (int)((nvox + kScanTile - 1) / kScanTile);
+    hipLaunchKernelGGL(k_scan_tile, dim3(nb), dim3(kBlock), 0, s, v, nvox, block_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, block_sums, nb, d_total);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kBlock), 0, s, v, nvox, (const int*)block_sums);
+}
+
+// ELL column offsets of one assembled distance row: self, 6 axis neighbours, 12 axis pairs
+__host__ __device__ inline void q_offset(int q, int* o) {
+    o[0] = o[1] = o[2] = 0;
+    if (q == 0) return;
+    if (q <= 6) { int a = (q - 1) >> 1; o[a] = ((q - 1) & 1) ? -1 : 1; return; }
+    int pi = (q - 7) >> 2, si = (q - 7) & 3;
+    int a = pi == 2 ? 1 : 0, b = pi == 0 ? 1 : 2;
+    o[a] = (si & 2) ? -1 : 1; o[b] = (si & 1) ? -1 : 1;
+}
+__device__ __forceinline__ int q_of(const int* o) {
+    int nz = (o[0] != 0) + (o[1] != 0) + (o[2] != 0);
+    if (nz == 0) return 0;
+    if (nz == 1) { int a = o[0] ? 0 : (o[1] ? 1 : 2); return 1 + 2 * a + (o[a] < 0 ? 1 : 0); }
+    int a = o[0] ? 0 : 1, b = o[2] ? 2 : 1;
+    int pi = (a == 0 && b == 1) ? 0 : ((a == 0) ? 1 : 2);
+    return 7 + 4 * pi + ((o[a] < 0 ? 2 : 0) | (o[b] < 0 ? 1 : 0));
+}
+
+// gather the compact band planes from the dense grid (one thread per dense voxel, coalesced reads)
+__global__ void __launch_bounds__(kBlock) k_band_fill(DenseView d, GridP grid, Band b) {
+    for (long long lin = blockIdx.x * (long long)blockDim.x + threadIdx.x; lin < grid.nvox; lin += (long long)gridDim.x * blockDim.x) {
+        int j = d.row_of[lin];
+        if (j < 0) continue;
+        b.lin[j] = (int)lin;
+        b.dist[j] = d.dist[lin];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { b.g[a][j] = d.g[a][lin]; b.rho[a][j] = d.rho[a][lin]; }
+        for (int w = 0; w < b.KW; ++w) b.vis[(size_t)w * b.Spad + j] = d.vis[lin * b.KW + w];
+    }
+}
+// neighbour tables: membership by linear index exactly as Optimizer.cpp:462-474 does it
+__global__ void __launch_bounds__(kBlock) k_band_nb(DenseView d, GridP grid, Band b) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= b.S) return;
+    long long lin = b.lin[j];
+    long long stride[3] = {1, grid.dim[0], (long long)grid.dim[0] * grid.dim[1]};
+    float dj = d.dist[lin];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        long long ln = lin + ((q & 1) ? -stride[q >> 1] : stride[q >> 1]);
+        bool in = ln >= 0 && ln < grid.nvox;
+        b.nb[(size_t)q * b.Spad + j] = in ? d.row_of[ln] : -1;
+        b.nbd[(size_t)q * b.Spad + j] = in ? d.dist[ln] : dj;   // reference reads out of bounds here (UB): use own value
+    }
+    for (int q = 0; q < kNQ; ++q) {
+        int o[3]; q_offset(q, o);
+        long long ln = lin + o[0] * stride[0] + o[1] * stride[1] + o[2] * stride[2];
+        b.col[(size_t)q * b.Spad + j] = (ln >= 0 && ln < grid.nvox) ? d.row_of[ln] : -1;
+    }
+}
+void launch_band_fill(const DenseView& d, const GridP& grid, Band b, hipStream_t s) {
+    int g1 = (int)min((grid.nvox + kBlock - 1) / kBlock, (long long)256 * 16);
+    hipLaunchKernelGGL(k_band_fill, dim3(g1), dim3(kBlock), 0, s, d, grid, b);
+    if (b.S > 0) hipLaunchKernelGGL(k_band_nb, dim3((b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d, grid, b);
+}
+__global__ void __launch_bounds__(kBlock) k_band_scatter(DenseView d, Band b) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= b.S) return;
+    long long lin = b.lin[j];
+    d.dist[lin] = b.dist[j];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { d.g[a][lin] = b.g[a][j]; d.rho[a][lin] = b.rho[a][j]; }
+}
+void launch_band_scatter(const DenseView& d, Band b, hipStream_t s) {
+    if (b.S > 0) hipLaunchKernelGGL(k_band_scatter, dim3((b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d, b);
+}
+
+// Optimizer::subsampling, OptimizerAux.cpp:622-684 + VolumetricGradSdf.cpp:469-494; one thread per CHILD
+// voxel so that the 8x larger output is written fully coalesced.
+__global__ void __launch_bounds__(kBlock) k_upsample(DenseView src, DenseView dst, GridP g) {
+    const long long nx = 2LL * g.dim[0], ny = 2LL * g.dim[1], nn = 8 * g.nvox;
+    const float vs4 = (float)(0.25 * (double)g.vs);
+    for (long long ls = blockIdx.x * (long long)blockDim.x + threadIdx.x; ls < nn; ls += (long long)gridDim.x * blockDim.x) {
+        long long kz = ls / (nx * ny); long long rest = ls - kz * nx * ny; long long jy = rest / nx; long long ix = rest - jy * nx;
+        long long lin = (ix >> 1) + (jy >> 1) * g.dim[0] + (kz >> 1) * (long long)g.dim[0] * g.dim[1];
+        float d = src.dist[lin];
+        if (d == g.T) {  // untouched children keep the defaults (OptimizerAux.cpp:625-631,652)
+            dst.dist[ls] = g.T; dst.weight[ls] = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { dst.g[a][ls] = 0.f; dst.rho[a][ls] = 0.5f; }
+            for (int w = 0; w < src.KW; ++w) dst.vis[ls * src.KW + w] = 0;
+            continue;
+        }
+        float gr[3] = {src.g[0][lin], src.g[1][lin], src.g[2][lin]}, gn[3];
+        normalized3(gr, gn);
+        float ax = (ix & 1) ? gn[0] : -gn[0], ay = (jy & 1) ? gn[1] : -gn[1], az = (kz & 1) ? gn[2] : -gn[2];
+        dst.dist[ls] = d + vs4 * (ax + ay + az);
+        dst.weight[ls] = src.weight[lin];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { dst.g[a][ls] = gr[a]; dst.rho[a][ls] = src.rho[a][lin]; }
+        for (int w = 0; w < src.KW; ++w) dst.vis[ls * src.KW + w] = src.vis[lin * src.KW + w];
+    }
+}
+void launch_upsample(const DenseView& src, const DenseView& dst, const GridP& g_old, hipStream_t s) {
+    int grid = (int)min((8 * g_old.nvox + kBlock - 1) / kBlock, (long long)256 * 32);
+    hipLaunchKernelGGL(k_upsample, dim3(grid), dim3(kBlock), 0, s, src, dst, g_old);
+}
+__global__ void k_fill_f32(float* p, float v, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill_f32(float* p, float v, long long n, hipStream_t s) {
+    int grid = (int)min((n + kBlock - 1) / kBlock, (long long)256 * 16);
+    if (n > 0) hipLaunchKernelGGL(k_fill_f32, dim3(grid), dim3(kBlock), 0, s, p, v, n);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-voxel derived quantities
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nb_dist(const Band& b, int q, int j) {
+    int r = b.nb[(size_t)q * b.Spad + j];
+    return r >= 0 ? b.dist[r] : b.nbd[(size_t)q * b.Spad + j];
+}
+// Optimizer.cpp:287-364 computeDistGrad -> (n, dir)
+__device__ __forceinline__ void fd_grad(const Band& b, int j, float vs_inv, float* n, float* dir) {
+    float d = b.dist[j];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        bool fwd = b.nb[(size_t)(2 * a) * b.Spad + j] >= 0;
+        dir[a] = fwd ? 1.0f : -1.0f;
+        float dn = fwd ? b.dist[b.nb[(size_t)(2 * a) * b.Spad + j]] : nb_dist(b, 2 * a + 1, j);
+        n[a] = dir[a] * (dn - d);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) n[a] = n[a] * vs_inv;
+}
+// Optimizer.cpp:368-393 computeDistLaplacian
+__device__ __forceinline__ float laplacian(const Band& b, int j, float vs_inv) {
+    float d = b.dist[j];
+    float dd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { float p1 = nb_dist(b, 2 * a, j), p0 = nb_dist(b, 2 * a + 1, j); dd[a] = p1 + p0 - 2 * d; }
+    return (dd[0] + dd[1] + dd[2]) * vs_inv * vs_inv;
+}
+
+// FD gradient, optional updateGrad (OptimizerAux.cpp:152-160), surface point, and the Eikonal /
+// Laplacian energies (Optimizer.cpp:86-119) in one pass over the band.
+__global__ void __launch_bounds__(kBlock) k_derive(SweepArgs a, int update_grad) {
+    __shared__ double red[kBlock / 64];
+    const Band& b = a.b;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double en = 0, el = 0;
+    if (j < b.S) {
+        float n[3], dir[3];
+        fd_grad(b, j, a.grid.vs_inv, n, dir);
+        float g[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { b.gfd[k][j] = n[k]; if (update_grad) b.g[k][j] = n[k]; g[k] = update_grad ? n[k] : b.g[k][j]; }
+        float gn[3]; normalized3(g, gn);
+        long long lin = b.lin[j];
+        int nxy = a.grid.dim[0] * a.grid.dim[1];
+        int kz = (int)(lin / nxy); int rest = (int)(lin - (long long)kz * nxy); int jy = rest / a.grid.dim[0]; int ix = rest - jy * a.grid.dim[0];
+        int idx[3] = {ix, jy, kz};
+        float d = b.dist[j];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float xv = a.grid.origin[k] + a.grid.vs * (float)idx[k];   // VoxelGrid.h:38-40
+            b.gn[k][j] = gn[k];
+            b.xs[k][j] = xv - d * gn[k];
+        }
+        float e = norm3(n) - 1; en = (double)(e * e);
+        float l = laplacian(b, j, a.grid.vs_inv); el = (double)(l * l);
+    }
+    block_atomic_add(en, a.acc.scal + SC_EN, red);
+    block_atomic_add(el, a.acc.scal + SC_EL, red);
+}
+void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_derive, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, update_grad);
+}
+
+// ------------------------------------------------------------------------------------------
+// voxel-major sweeps: one thread per band voxel, iterating the set bits of its visibility mask
+// ------------------------------------------------------------------------------------------
+#define FOR_EACH_VISIBLE_FRAME(b, j, F, f)                                                   \
+    for (int _w = 0; _w < (b).KW; ++_w)                                                      \
+        for (uint64_t _m = (b).vis[(size_t)_w * (b).Spad + (j)]; _m; _m &= _m - 1)            \
+            if (int f = 64 * _w + __builtin_ctzll(_m); f < (F))
+
+// Optimizer.cpp:50-81 initAlbedo
+__global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
+    __shared__ FrameP sf[kMaxFramesLds];
+    load_frames(sf, a.frames, a.F);
+    const Band& b = a.b;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= b.S) return;
+    float xs[3] = {b.xs[0][j], b.xs[1][j], b.xs[2][j]};
+    int count = 0; float rho[3] = {0, 0, 0};
+    FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
+        Proj pr = project(xs, sf[f], a.cam);
+        if (!pr.ok) continue;
+        float I[3];
+        sample<false>(a.img + (size_t)f * a.cam.H * a.cam.W * 3, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        rho[0] += I[0]; rho[1] += I[1]; rho[2] += I[2]; count++;
+    }
+    if (count) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) b.rho[k][j] = rho[k] / (float)count;
+    }
+}
+void launch_init_albedo(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_init_albedo, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+}
+
+// getPSEnergy PsOptimizer.cpp:47-78 / LedOptimizer.cpp:40-71; LED_INIT: computeLightIntensive
+// LedOptimizer.cpp:76-112 (sums of observed and rendered intensity)
+template <int MODEL, bool LED_INIT>
+__global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    __shared__ FrameP sf[kMaxFramesLds];
+    __shared__ double red[kBlock / 64];
+    load_frames(sf, a.frames, a.F);
+    const Band& b = a.b;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double E = 0, nobs = 0, sI[3] = {0, 0, 0}, sR[3] = {0, 0, 0};
+    if (j < b.S) {
+        Vox v; load_vox(b, j, v);
+        float shfd[kMaxBasis];
+        if (!ModelTraits<MODEL>::LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
+        FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
+            const FrameP& fp = sf[f];
+            Proj pr = project(v.xs, fp, a.cam);
+            if (!pr.ok) continue;
+            float I[3], ren[3];
+            sample<false>(a.img + (size_t)f * a.cam.H * a.cam.W * 3, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+            rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
+            if (LED_INIT) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) { sI[ch] += (double)I[ch]; sR[ch] += (double)ren[ch]; }
+            } else {
+                float l = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) l += robust_loss(a.rob, I[ch] - ren[ch]);
+                E += (double)l; nobs += 1.0;
+            }
+        }
+    }
+    if (LED_INIT) {
+        // 6 sums: observed rgb into SC_AUX0.., rendered into SC_EN/SC_EL/SC_ACCEPT slots (scratch use at init only)
+        block_atomic_add(sI[0], a.acc.scal + SC_AUX0, red); block_atomic_add(sI[1], a.acc.scal + SC_AUX1, red); block_atomic_add(sI[2], a.acc.scal + SC_AUX2, red);
+        block_atomic_add(sR[0], a.acc.scal + SC_EN, red); block_atomic_add(sR[1], a.acc.scal + SC_EL, red); block_atomic_add(sR[2], a.acc.scal + SC_ACCEPT, red);
+    } else {
+        block_atomic_add(E, a.acc.scal + SC_ENERGY, red);
+        block_atomic_add(nobs, a.acc.scal + SC_NOBS, red);
+    }
+}
+void launch_energy(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S <= 0) return;
+    dim3 g((a.b.S + kBlock - 1) / kBlock), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_energy<0, false>), g, bl, 0, s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_energy<1, false>), g, bl, 0, s, a);
+    else hipLaunchKernelGGL((k_energy<2, false>), g, bl, 0, s, a);
+}
+void launch_led_light_init(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL((k_energy<2, true>), dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+}
+
+// albedo normal equations (diagonal): optimizeAlbedoAll PsOptimizer.cpp:85-121 / LedOptimizer.cpp:162-196,
+// albedoJacobian PsOptimizerJa.cpp:375-422, computeResidual :567-626.  Also yields the PS energy of the input state.
+template <int MODEL>
+__global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    __shared__ FrameP sf[kMaxFramesLds];
+    __shared__ double red[kBlock / 64];
+    load_frames(sf, a.frames, a.F);
+    const Band& b = a.b;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double E = 0, nobs = 0;
+    if (j < b.S) {
+        Vox v; load_vox(b, j, v);
+        float shfd[kMaxBasis], shg[kMaxBasis];
+        if (!ModelTraits<MODEL>::LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
+        double Hd[3] = {0, 0, 0}, bd[3] = {0, 0, 0};
+        FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
+            const FrameP& fp = sf[f];
+            Proj pr = project(v.xs, fp, a.cam);
+            if (!pr.ok) continue;
+            float I[3], ren[3], J[3];
+            sample<false>(a.img + (size_t)f * a.cam.H * a.cam.W * 3, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+            rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
+            rho_jac<MODEL>(fp, pr, v.gn, shg, J);
+            float l = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
+                float jw = J[ch] * w;
+                Hd[ch] += (double)(jw * J[ch]); bd[ch] += (double)(jw * r);
+                l += robust_loss(a.rob, r);
+            }
+            E += (double)l; nobs += 1.0;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { b.aH[(size_t)ch * b.Spad + j] = (float)Hd[ch]; b.ab[(size_t)ch * b.Spad + j] = (float)bd[ch]; }
+    }
+    block_atomic_add(E, a.acc.scal + SC_ENERGY, red);
+    block_atomic_add(nobs, a.acc.scal + SC_NOBS, red);
+}
+void launch_sweep_albedo(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S <= 0) return;
+    dim3 g((a.b.S + kBlock - 1) / kBlock), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_albedo<0>), g, bl, 0, s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_albedo<1>), g, bl, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_albedo<2>), g, bl, 0, s, a);
+}
+// delta = b / ((1+damping) H), updateAlbedo accept rule OptimizerAux.cpp:120-150
+__global__ void __launch_bounds__(kBlock) k_apply_albedo(SweepArgs a) {
+    __shared__ double red[kBlock / 64];
+    const Band& b = a.b;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double cnt = 0;
+    if (j < b.S) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float h = b.aH[(size_t)ch * b.Spad + j];
+            if (a.damping != 0.0f) h += a.damping * h;
+            float delta = (h != 0.f) ? b.ab[(size_t)ch * b.Spad + j] / h : 0.f;
+            float v = b.rho[ch][j] - delta;
+            if (v > 0.0f && v < 1.0f) { b.rho[ch][j] = v; cnt += 1.0; }
+        }
+    }
+    block_atomic_add(cnt, a.acc.scal + SC_ACCEPT, red);
+}
+void launch_apply_albedo(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_apply_albedo, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// frame-major sweeps: grid = (row chunks, F); per-thread accumulation over several voxels of ONE
+// frame, then wavefront shuffle reduction -> LDS -> one double atomic per value per workgroup
+// ------------------------------------------------------------------------------------------
+constexpr int kRowsPerThread = 8;
+constexpr int kChunk = kBlock * kRowsPerThread;
+
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(const float* acc, double* dst, double* lds /*[4][NV]*/) {
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double v = wave_sum((double)acc[k]);
+        if (lane == 0) lds[w * NV + k] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NV; k += blockDim.x) {
+        double s = 0;
+        for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + k];
+        if (s != 0.0) atomicAdd(dst + k, s);
+    }
+}
+
+// light normal equations: lightJacobian PsOptimizerJa.cpp:132-143,323-371 (per frame NBxNB),
+// LED LightJacobian LedOptimizerJa.cpp:101-115,299-346 (one global diagonal 3x3)
+template <int MODEL>
+__global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    constexpr bool LED = ModelTraits<MODEL>::LED;
+    constexpr int NH = LED ? 3 : NB * (NB + 1) / 2;
+    constexpr int NV = NH + NB + 2;   // + energy, n_obs
+    __shared__ FrameP sfp;
+    __shared__ double lds[(kBlock / 64) * NV];
+    const int f = blockIdx.y;
+    if (threadIdx.x < (int)(sizeof(FrameP) / 4)) ((float*)&sfp)[threadIdx.x] = ((const float*)(a.frames + f))[threadIdx.x];
+    __syncthreads();
+    const Band& b = a.b;
+    const FrameP& fp = sfp;
+    const float* img = a.img + (size_t)f * a.cam.H * a.cam.W * 3;
+    float acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+    const int base = blockIdx.x * kChunk;
+    for (int it = 0; it < kRowsPerThread; ++it) {
+        int j = base + it * kBlock + threadIdx.x;
+        if (j >= b.S) break;
+        if (!((b.vis[(size_t)(f >> 6) * b.Spad + j] >> (f & 63)) & 1ull)) continue;
+        Vox v; load_vox(b, j, v);
+        Proj pr = project(v.xs, fp, a.cam);
+        if (!pr.ok) continue;
+        float shfd[kMaxBasis], shg[kMaxBasis];
+        if (!LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
+        float I[3], ren[3];
+        sample<false>(img, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
+        float refl = 0.f;
+        if (LED) { float Rp[3]; mul3(fp.R, pr.p, Rp); refl = dot3(v.gn, Rp); float pn = norm3(pr.p); double pd = (double)pn; refl /= (float)(pd * pd * pd); }
+        float l = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
+            l += robust_loss(a.rob, r);
+            if (LED) {
+                float J = refl * v.rho[ch]; float jw = J * w;
+                acc[ch] += jw * J; acc[NH + ch] += jw * r;
+            } else {
+                float J[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) J[i] = -v.rho[ch] * shg[i];
+                int q = 0;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    float jw = J[i] * w;
+#pragma unroll
+                    for (int k = i; k < NB; ++k) acc[q++] += jw * J[k];
+                    acc[NH + i] += jw * r;
+                }
+            }
+        }
+        acc[NH + NB] += l; acc[NH + NB + 1] += 1.0f;
+    }
+    // energy / n_obs go to the scalar block, the rest to this frame's accumulator row
+    double* dst = a.acc.frame + (size_t)(LED ? 0 : f) * (NH + NB);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NV; k += blockDim.x) {
+        double s = 0;
+        for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + k];
+        if (s != 0.0) atomicAdd(k < NH + NB ? dst + k : a.acc.scal + (k == NH + NB ? SC_ENERGY : SC_NOBS), s);
+    }
+}
+void launch_sweep_light(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S <= 0 || a.F <= 0) return;
+    dim3 g((a.b.S + kChunk - 1) / kChunk, a.F), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_light<0>), g, bl, 0, s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_light<1>), g, bl, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_light<2>), g, bl, 0, s, a);
+}
+
+// G = image_grad(3x2) * pi_grad(2x3), PsOptimizerJa.cpp:78-90
+__device__ __forceinline__ void image_pi_grad(const Cam& cam, const Proj& pr, const float* gu, const float* gv, float* G) {
+    float z_inv = (float)(1.0 / (double)pr.p[2]);
+    float z_inv_sq = z_inv * z_inv;
+    float p00 = cam.fx * z_inv, p02 = -cam.fx * pr.p[0] * z_inv_sq, p11 = cam.fy * z_inv, p12 = -cam.fy * pr.p[1] * z_inv_sq;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        G[ch * 3 + 0] = gu[ch] * p00 + gv[ch] * 0.0f;
+        G[ch * 3 + 1] = gu[ch] * 0.0f + gv[ch] * p11;
+        G[ch * 3 + 2] = gu[ch] * p02 + gv[ch] * p12;
+    }
+}
+
+// pose normal equations: poseJacobian PsOptimizerJa.cpp:61-115,427-475 / LedOptimizerJa.cpp:32-81,351-399
+template <int MODEL>
+__global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    constexpr bool LED = ModelTraits<MODEL>::LED;
+    constexpr int NV = 21 + 6 + 2;
+    __shared__ FrameP sfp;
+    __shared__ double lds[(kBlock / 64) * NV];
+    const int f = blockIdx.y;
+    if (threadIdx.x < (int)(sizeof(FrameP) / 4)) ((float*)&sfp)[threadIdx.x] = ((const float*)(a.frames + f))[threadIdx.x];
+    __syncthreads();
+    const Band& b = a.b;
+    const FrameP& fp = sfp;
+    const float* img = a.img + (size_t)f * a.cam.H * a.cam.W * 3;
+    float acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+    const int base = blockIdx.x * kChunk;
+    for (int it = 0; it < kRowsPerThread; ++it) {
+        int j = base + it * kBlock + threadIdx.x;
+        if (j >= b.S) break;
+        if (!((b.vis[(size_t)(f >> 6) * b.Spad + j] >> (f & 63)) & 1ull)) continue;
+        Vox v; load_vox(b, j, v);
+        Proj pr = project(v.xs, fp, a.cam);
+        if (!pr.ok) continue;
+        float shfd[kMaxBasis];
+        if (!LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
+        float I[3], gu[3], gv[3], ren[3];
+        sample<true>(img, a.cam, pr.m, pr.n, I, gu, gv);
+        rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
+        float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
+        float J[18];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float s = (G[ch * 3 + 0] * fp.R[k * 3 + 0] + G[ch * 3 + 1] * fp.R[k * 3 + 1]) + G[ch * 3 + 2] * fp.R[k * 3 + 2];
+                J[ch * 6 + k] = -s;
+            }
+        const float* p = pr.p;
+        float sk[9] = {0, -p[2], p[1], p[2], 0, -p[0], -p[1], p[0], 0};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) J[ch * 6 + 3 + k] = (G[ch * 3 + 0] * sk[0 * 3 + k] + G[ch * 3 + 1] * sk[1 * 3 + k]) + G[ch * 3 + 2] * sk[2 * 3 + k];
+        if (LED) {
+            float pn = norm3(p); double pd = (double)pn; float l3 = (float)(pd * pd * pd);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float s = -(v.rho[ch] * fp.l[ch] / l3);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) J[ch * 6 + k] += s * v.gn[k];
+            }
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
+            l += robust_loss(a.rob, r);
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float jw = J[ch * 6 + i] * w;
+#pragma unroll
+                for (int k = i; k < 6; ++k) acc[q++] += jw * J[ch * 6 + k];
+                acc[21 + i] += jw * r;
+            }
+        }
+        acc[27] += l; acc[28] += 1.0f;
+    }
+    double* dst = a.acc.frame + (size_t)f * 27;
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NV; k += blockDim.x) {
+        double s = 0;
+        for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + k];
+        if (s != 0.0) atomicAdd(k < 27 ? dst + k : a.acc.scal + (k == 27 ? SC_ENERGY : SC_NOBS), s);
+    }
+}
+void launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S <= 0 || a.F <= 0) return;
+    dim3 g((a.b.S + kChunk - 1) / kChunk, a.F), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_pose<0>), g, bl, 0, s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_pose<1>), g, bl, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_pose<2>), g, bl, 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// small dense solves (one thread per frame): LDL^T in double, zero step on non-positive pivots
+// ------------------------------------------------------------------------------------------
+template <int N>
+__device__ void solve_spd(const double* Hin, const double* bin, double* x) {
+    double L[N * N], D[N], y[N];
+    double scale = 0;
+    for (int i = 0; i < N; ++i) scale = fmax(scale, fabs(Hin[i * N + i]));
+    const double tiny = scale * 1e-12;
+    for (int i = 0; i < N * N; ++i) L[i] = 0;
+    for (int j = 0; j < N; ++j) {
+        double d = Hin[j * N + j];
+        for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k] * D[k];
+        D[j] = d; L[j * N + j] = 1.0;
+        for (int i = j + 1; i < N; ++i) {
+            double s = Hin[i * N + j];
+            for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k] * D[k];
+            L[i * N + j] = (d > tiny) ? s / d : 0.0;
+        }
+    }
+    for (int i = 0; i < N; ++i) { double s = bin[i]; for (int k = 0; k < i; ++k) s -= L[i * N + k] * y[k]; y[i] = s; }
+    for (int i = 0; i < N; ++i) y[i] = (D[i] > tiny) ? y[i] / D[i] : 0.0;
+    for (int i = N - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k]; x[i] = s; }
+}
+
+// optimizeLightAll: PsOptimizer.cpp:175-203 (no damping) / LedOptimizer.cpp:134-160 (damped, one RGB vector)
+template <int MODEL>
+__global__ void k_solve_light(SweepArgs a, FrameP* frames, float* led_light) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    constexpr bool LED = ModelTraits<MODEL>::LED;
+    constexpr int NH = LED ? 3 : NB * (NB + 1) / 2;
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (LED) {
+        if (f >= a.F) return;
+        // every thread solves the same 3 scalar equations and updates its own frame record
+        const double* acc = a.acc.frame;
+        float nl[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float h = (float)acc[ch], bb = (float)acc[NH + ch];
+            if (a.damping != 0.0f) h += a.damping * h;
+            double Hd[1] = {(double)h}, bd[1] = {(double)bb}, xd[1];
+            solve_spd<1>(Hd, bd, xd);
+            nl[ch] = frames[f].l[ch] - (float)xd[0];
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { frames[f].l[ch] = nl[ch]; if (f == 0) led_light[ch] = nl[ch]; }
+        return;
+    } else {
+        if (f >= a.F) return;
+        const double* acc = a.acc.frame + (size_t)f * (NH + NB);
+        double Hd[NB * NB], bd[NB], xd[NB];
+        int q = 0;
+        for (int i = 0; i < NB; ++i) for (int k = i; k < NB; ++k) { double v = (double)(float)acc[q++]; Hd[i * NB + k] = v; Hd[k * NB + i] = v; }
+        for (int i = 0; i < NB; ++i) bd[i] = (double)(float)acc[NH + i];
+        solve_spd<NB>(Hd, bd, xd);
+        for (int i = 0; i < NB; ++i) frames[f].l[i] -= (float)xd[i];
+    }
+}
+void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, hipStream_t s) {
+    if (a.F <= 0) return;
+    dim3 g((a.F + 63) / 64), bl(64);
+    if (a.model == 0) hipLaunchKernelGGL((k_solve_light<0>), g, bl, 0, s, a, frames, led_light);
+    else if (a.model == 1) hipLaunchKernelGGL((k_solve_light<1>), g, bl, 0, s, a, frames, led_light);
+    else hipLaunchKernelGGL((k_solve_light<2>), g, bl, 0, s, a, frames, led_light);
+}
+
+// Sophus SO3::exp(w).matrix() (quaternion exponential + Eigen toRotationMatrix)
+__device__ void so3_exp(const float* w, float* R) {
+    float theta_sq = dot3(w, w);
+    float imag, real;
+    if (theta_sq < 1e-10f) {
+        float theta_po4 = theta_sq * theta_sq;
+        imag = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_po4;
+        real = 1.0f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_po4;
+    } else {
+        float theta = sqrtf(theta_sq), half = 0.5f * theta;
+        imag = sinf(half) / theta; real = cosf(half);
+    }
+    float qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+    float tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+// optimizePosesAll PsOptimizer.cpp:207-234 + updatePose OptimizerAux.cpp:190-205
+__global__ void k_solve_pose(SweepArgs a, FrameP* frames) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.F) return;
+    const double* acc = a.acc.frame + (size_t)f * 27;
+    double Hd[36], bd[6], xd[6];
+    int q = 0;
+    for (int i = 0; i < 6; ++i) for (int k = i; k < 6; ++k) {
+        float v = (float)acc[q++];
+        if (i == k && a.damping != 0.0f) v += a.damping * v;
+        Hd[i * 6 + k] = (double)v; Hd[k * 6 + i] = (double)v;
+    }
+    for (int i = 0; i < 6; ++i) bd[i] = (double)(float)acc[21 + i];
+    solve_spd<6>(Hd, bd, xd);
+    float xi[6];
+    for (int i = 0; i < 6; ++i) xi[i] = (float)xd[i];
+    float R[9], t[3];
+    for (int i = 0; i < 9; ++i) R[i] = frames[f].R[i];
+    for (int i = 0; i < 3; ++i) t[i] = frames[f].t[i];
+    float mw[3] = {-xi[3], -xi[4], -xi[5]}, E3[9];
+    so3_exp(mw, E3);
+    for (int i = 0; i < 3; ++i) {
+        frames[f].t[i] = t[i] - xi[i];
+        for (int k = 0; k < 3; ++k) frames[f].R[i * 3 + k] = (R[i * 3 + 0] * E3[0 * 3 + k] + R[i * 3 + 1] * E3[1 * 3 + k]) + R[i * 3 + 2] * E3[2 * 3 + k];
+    }
+}
+void launch_solve_pose(const SweepArgs& a, FrameP* frames, hipStream_t s) {
+    if (a.F > 0) hipLaunchKernelGGL(k_solve_pose, dim3((a.F + 63) / 64), dim3(64), 0, s, a, frames);
+}
+
+// ------------------------------------------------------------------------------------------
+// distance block: per-voxel 4x4 normal-equation blocks, ELL assembly, Jacobi-PCG
+// ------------------------------------------------------------------------------------------
+// Optimizer.cpp:269-284 normalJacobian(grad, direction, lag=false)
+__device__ __forceinline__ void normal_jacobian(float vs_inv, const float* grad, const float* direction, float* J) {
+    float n_d[3] = {-vs_inv * direction[0], -vs_inv * direction[1], -vs_inv * direction[2]};
+    float N_inv = (float)(1.0 / (double)fmaxf(norm3(grad), 0.001f));
+    double Nd = (double)N_inv;
+    float dN = (float)((Nd * Nd * Nd) * (double)dot3(n_d, grad));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) J[k] = N_inv * n_d[k] - dN * grad[k];
+}
+__device__ __forceinline__ int sym4(int a, int b) {   // index into the 10 upper-triangular entries
+    if (a > b) { int t = a; a = b; b = t; }
+    return a * 4 - (a * (a - 1)) / 2 + (b - a);
+}
+
+// distJacobian per observation PsOptimizerJa.cpp:160-289 / LedOptimizerJa.cpp:117-218, accumulated directly
+// into the per-voxel block over {self, x-, y-, z-stencil neighbour}; regularisers Optimizer.cpp:196-218,477-590.
+template <int MODEL>
+__global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    constexpr bool LED = ModelTraits<MODEL>::LED;
+    __shared__ FrameP sf[kMaxFramesLds];
+    __shared__ double red[kBlock / 64];
+    load_frames(sf, a.frames, a.F);
+    const Band& b = a.b;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double E = 0, nobs = 0;
+    if (j < b.S) {
+        Vox v; load_vox(b, j, v);
+        const float vs_inv = a.grid.vs_inv;
+        float grad[3] = {b.gfd[0][j], b.gfd[1][j], b.gfd[2][j]};
+        float dir[3]; bool exists[4]; exists[0] = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bool fwd = b.nb[(size_t)(2 * k) * b.Spad + j] >= 0;
+            dir[k] = fwd ? 1.0f : -1.0f;
+            exists[k + 1] = fwd ? true : (b.nb[(size_t)(2 * k + 1) * b.Spad + j] >= 0);
+        }
+        float dn[4][3];
+        normal_jacobian(vs_inv, grad, dir, dn[0]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float nd[3] = {0.f, 0.f, 0.f};
+            if (LED && a.quirks) nd[k] += dir[k]; else nd[k] -= dir[k];   // B6: LedOptimizerJa.cpp:157-167 vs PsOptimizerJa.cpp:200-210
+            normal_jacobian(vs_inv, grad, nd, dn[k + 1]);
+        }
+        const float d = b.dist[j];
+        float dx[4][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dx[0][k] = -v.gn[k] - d * dn[0][k];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dx[q][k] = -d * dn[q][k];
+        float shfd[kMaxBasis];
+        if (!LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
+        float Dm[3][9];
+        if (NB == 9) {
+            const float* nh = v.nfd;
+            float D0[9] = {0, 1, 0, 0, nh[1], nh[2], 0, 2 * nh[0], 2 * nh[0]};
+            float D1[9] = {0, 0, 1, 0, nh[0], 0, nh[2], -2 * nh[1], 0};
+            float D2[9] = {0, 0, 0, 1, 0, nh[0], nh[1], 0, -2 * nh[2]};
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { Dm[0][i] = D0[i]; Dm[1][i] = D1[i]; Dm[2][i] = D2[i]; }
+        }
+        double B[10], g[4];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) B[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = 0;
+        FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
+            const FrameP& fp = sf[f];
+            Proj pr = project(v.xs, fp, a.cam);
+            if (!pr.ok) continue;
+            float I[3], gu[3], gv[3], ren[3];
+            sample<true>(a.img + (size_t)f * a.cam.H * a.cam.W * 3, a.cam, pr.m, pr.n, I, gu, gv);
+            rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
+            float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
+            float GRt[9];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) GRt[ch * 3 + k] = (G[ch * 3 + 0] * fp.R[k * 3 + 0] + G[ch * 3 + 1] * fp.R[k * 3 + 1]) + G[ch * 3 + 2] * fp.R[k * 3 + 2];
+            float J[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mul3(GRt, dx[q], J[q]);   // dI_q
+            if (!LED) {
+                if (NB == 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            float dr[3] = {v.rho[ch] * fp.l[1], v.rho[ch] * fp.l[2], v.rho[ch] * fp.l[3]};
+                            J[q][ch] = J[q][ch] - dot3(dr, dn[q]);
+                        }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float dsh[9];
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) dsh[i] = (Dm[0][i] * dn[q][0] + Dm[1][i] * dn[q][1]) + Dm[2][i] * dn[q][2];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            float s = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) s += (v.rho[ch] * fp.l[i]) * dsh[i];
+                            J[q][ch] = J[q][ch] - s;
+                        }
+                    }
+                }
+            } else {
+                float Rp[3]; mul3(fp.R, pr.p, Rp);
+                float pn = norm3(pr.p); double pd = (double)pn;
+                float radius = (float)(pd * pd * pd);
+                float p5 = (float)(pd * pd * pd * pd * pd);
+                float nRp = dot3(v.nfd, Rp);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float dm = dot3(dn[q], Rp) + dot3(v.nfd, dx[q]);
+                    float tmp[3]; mulT3(fp.R, dx[q], tmp);
+                    float dm2 = -3 * dot3(pr.p, tmp) / p5;
+                    dm = dm / radius + dm2 * nRp;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) J[q][ch] = J[q][ch] + (v.rho[ch] * fp.l[ch]) * dm;
+                }
+            }
+            float l = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
+                l += robust_loss(a.rob, r);
+                int q = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float jw = J[p][ch] * w;
+#pragma unroll
+                    for (int k = p; k < 4; ++k) B[q++] += (double)(jw * J[k][ch]);
+                    g[p] += (double)(jw * r);
+                }
+            }
+            E += (double)l; nobs += 1.0;
+        }
+        if (a.normal_reg) {   // Eikonal row, Optimizer.cpp:196-218 + residual :509
+            float n_d[3] = {-vs_inv * dir[0], -vs_inv * dir[1], -vs_inv * dir[2]};
+            float Jr[4];
+            Jr[0] = dot3(grad, n_d);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Jr[k + 1] = grad[k] * (vs_inv * dir[k]);
+            float gnrm = norm3(grad);
+            if (gnrm > 0.0f) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Jr[k] /= gnrm;
+            }
+            float res = gnrm - 1;
+            int q = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int k = p; k < 4; ++k) B[q++] += (double)(a.reg_n * (Jr[p] * Jr[k]));
+                g[p] += (double)(a.reg_n * (Jr[p] * res));
+            }
+        }
+        if (a.laplacian_reg) {   // diagonal only (reference drops the off-diagonals), Optimizer.cpp:540-590
+            float vs2 = vs_inv * vs_inv; float Jl = -6 * vs2; float res = laplacian(b, j, vs_inv);
+            B[0] += (double)(a.reg_l * (Jl * Jl)); g[0] += (double)(a.reg_l * (Jl * res));
+        }
+        // columns whose stencil neighbour is outside the band are dropped (PsOptimizerJa.cpp:536-552)
+        int q = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int k = p; k < 4; ++k) { b.blk[(size_t)q * b.Spad + j] = (exists[p] && exists[k]) ? (float)B[q] : 0.f; ++q; }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) b.blk[(size_t)(10 + p) * b.Spad + j] = exists[p] ? (float)g[p] : 0.f;
+    }
+    block_atomic_add(E, a.acc.scal + SC_ENERGY, red);
+    block_atomic_add(nobs, a.acc.scal + SC_NOBS, red);
+}
+void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S <= 0) return;
+    dim3 g((a.b.S + kBlock - 1) / kBlock), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_dist<0>), g, bl, 0, s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_dist<1>), g, bl, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_dist<2>), g, bl, 0, s, a);
+}
+
+// H = sum_j P_j^T B_j P_j assembled row-wise into 19 fixed column offsets (ELL); a row receives
+// slices from itself, from each lower neighbour (whose forward stencil points at it) and from each
+// upper neighbour whose stencil was forced backward.  Accumulation in LDS (dynamic column index).
+__global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
+    __shared__ double acc[kNQ][kBlock];
+    const Band& b = a.b;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < kNQ; ++q) acc[q][tid] = 0.0;
+    if (i >= b.S) return;
+    double rhs = 0.0;
+    for (int c = 0; c < 7; ++c) {
+        int jrow, s; int coff[3] = {0, 0, 0};
+        if (c == 0) { jrow = i; s = 0; }
+        else {
+            int ax = (c - 1) >> 1; bool upper = (c - 1) & 1;
+            jrow = b.nb[(size_t)(2 * ax + (upper ? 0 : 1)) * b.Spad + i];
+            if (jrow < 0) continue;
+            if (upper && b.nb[(size_t)(2 * ax) * b.Spad + jrow] >= 0) continue;   // its stencil is forward: does not touch row i
+            s = ax + 1; coff[ax] = upper ? 1 : -1;
+        }
+        int dirj[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dirj[k] = b.nb[(size_t)(2 * k) * b.Spad + jrow] >= 0 ? 1 : -1;
+        rhs += (double)b.blk[(size_t)(10 + s) * b.Spad + jrow];
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {
+            int o[3] = {coff[0], coff[1], coff[2]};
+            if (bq > 0) o[bq - 1] += dirj[bq - 1];
+            float val = b.blk[(size_t)sym4(s, bq) * b.Spad + jrow];
+            if (val != 0.f) acc[q_of(o)][tid] += (double)val;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kNQ; ++q) b.H[(size_t)q * b.Spad + i] = (float)acc[q][tid];
+    b.rhs[i] = (float)rhs;
+}
+void launch_assemble(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_assemble, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+}
+
+// Jacobi-PCG with Eigen::ConjugateGradient semantics: x0 = 0, threshold = max(eps^2 |b|^2, FLT_MIN),
+// scalar recurrences in float, dot products accumulated in double.  Two kernels per iteration.
+__global__ void __launch_bounds__(kBlock) k_pcg_init(SweepArgs a, double* sc) {
+    __shared__ double red[kBlock / 64];
+    const Band& b = a.b;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double bb = 0, rz = 0;
+    if (i < b.S) {
+        float dg = b.H[i];
+        if (a.damping != 0.0f) dg += a.damping * dg;
+        float inv = dg != 0.f ? 1.0f / dg : 1.0f;
+        float r = b.rhs[i];
+        float z = inv * r;
+        b.inv[i] = inv; b.x[i] = 0.f; b.r[i] = r; b.z[i] = z; b.p[0][i] = 0.f; b.p[1][i] = 0.f;
+        bb = (double)r * (double)r; rz = (double)r * (double)z;
+    }
+    block_atomic_add(bb, sc + 0, red);
+    block_atomic_add(rz, sc + 1, red);
+}
+void launch_pcg_init(const SweepArgs& a, double* sc, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_init, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, sc);
+}
+__device__ __forceinline__ bool pcg_done(const double* sc, int k) {
+    float rhsNorm2 = (float)sc[0];
+    if (rhsNorm2 == 0.f) return true;
+    if (k == 0) return false;
+    float threshold = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsNorm2, FLT_MIN);
+    return (float)sc[kPcgScalHead + 3 * (k - 1) + 1] < threshold;
+}
+// p_k = z + beta p_{k-1} (recomputed for every gathered column), t = A p_k, p.t partial
+__global__ void __launch_bounds__(kBlock) k_pcg_mv(SweepArgs a, double* sc, int k, int with_damping) {
+    __shared__ double red[kBlock / 64];
+    if (pcg_done(sc, k)) return;
+    const Band& b = a.b;
+    float beta = 0.f;
+    if (k > 0) {
+        float absNew = (float)sc[kPcgScalHead + 3 * (k - 1) + 2];
+        float absOld = (float)(k == 1 ? sc[1] : sc[kPcgScalHead + 3 * (k - 2) + 2]);
+        beta = absNew / absOld;
+    }
+    const float* pold = b.p[(k + 1) & 1];
+    float* pnew = b.p[k & 1];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double pt = 0;
+    if (i < b.S) {
+        double acc = 0;
+        float pi = 0.f;
+#pragma unroll
+        for (int q = 0; q < kNQ; ++q) {
+            float h = b.H[(size_t)q * b.Spad + i];
+            int c = q == 0 ? i : b.col[(size_t)q * b.Spad + i];
+            if (q == 0 && with_damping && a.damping != 0.0f) h += a.damping * h;
+            if (c < 0) continue;
+            float pc = b.z[c] + beta * pold[c];
+            if (q == 0) pi = pc;
+            acc += (double)h * (double)pc;
+        }
+        float t = (float)acc;
+        pnew[i] = pi; b.t[i] = t;
+        pt = (double)pi * (double)t;
+    }
+    block_atomic_add(pt, sc + kPcgScalHead + 3 * k + 0, red);
+}
+void launch_pcg_mv(const SweepArgs& a, double* sc, int k, int with_damping, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_mv, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, sc, k, with_damping);
+}
+// x += alpha p ; r -= alpha t ; z = M^-1 r ; partial |r|^2 and r.z
+__global__ void __launch_bounds__(kBlock) k_pcg_upd(SweepArgs a, double* sc, int k) {
+    __shared__ double red[kBlock / 64];
+    if (pcg_done(sc, k)) return;
+    const Band& b = a.b;
+    float absNew = (float)(k == 0 ? sc[1] : sc[kPcgScalHead + 3 * (k - 1) + 2]);
+    float alpha = absNew / (float)sc[kPcgScalHead + 3 * k + 0];
+    const float* p = b.p[k & 1];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double rr = 0, rz = 0;
+    if (i < b.S) {
+        float x = b.x[i] + alpha * p[i];
+        float r = b.r[i] - alpha * b.t[i];
+        float z = b.inv[i] * r;
+        b.x[i] = x; b.r[i] = r; b.z[i] = z;
+        rr = (double)r * (double)r; rz = (double)r * (double)z;
+    }
+    block_atomic_add(rr, sc + kPcgScalHead + 3 * k + 1, red);
+    block_atomic_add(rz, sc + kPcgScalHead + 3 * k + 2, red);
+}
+void launch_pcg_upd(const SweepArgs& a, double* sc, int k, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_upd, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, sc, k);
+}
+// debug: y = H x without damping
+__global__ void __launch_bounds__(kBlock) k_matvec(SweepArgs a, const float* x, float* y) {
+    const Band& b = a.b;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.S) return;
+    double acc = 0;
+    for (int q = 0; q < kNQ; ++q) {
+        int c = q == 0 ? i : b.col[(size_t)q * b.Spad + i];
+        if (c < 0) continue;
+        acc += (double)b.H[(size_t)q * b.Spad + i] * (double)x[c];
+    }
+    y[i] = (float)acc;
+}
+void launch_matvec(const SweepArgs& a, const float* x, float* y, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_matvec, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, x, y);
+}
+// updateDist accept rule OptimizerAux.cpp:162-188
+__global__ void __launch_bounds__(kBlock) k_apply_dist(SweepArgs a) {
+    __shared__ double red[kBlock / 64];
+    const Band& b = a.b;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double cnt = 0;
+    if (j < b.S) {
+        float d = b.x[j];
+        if ((double)fabsf(d) < sqrt(3.0) * (double)a.grid.vs) { b.dist[j] -= d; cnt = 1.0; }
+    }
+    block_atomic_add(cnt, a.acc.scal + SC_ACCEPT, red);
+}
+void launch_apply_dist(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_apply_dist, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+}
+
+}  // namespace psg

@@ -1,0 +1,268 @@
+"""Deterministic synthetic RGB-D photometric-stereo scenes.
+
+Test / benchmark input generator only: a bumpy sphere with a smooth albedo pattern, observed by
+F cameras on an orbit, rendered with the same forward model the optimiser inverts
+(reference: PsOptimizerJa.cpp:30-40 for SH, LedOptimizerJa.cpp:15-29 for LED), plus the
+"analytic" fused voxel state the reference would obtain from VolumetricGradSdf::update
+(VolumetricGradSdf.cpp:51-138): dist, outward gradient, weight, colour, per-frame visibility.
+
+Everything is numpy (no GPU, no oracle): the same arrays feed the HIP engine and the CPU oracle.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+MODELS = {"SH1": 0, "SH2": 1, "LED": 2}
+
+
+def _unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+class Scene:
+    """Plain container; see make_scene."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _shape_f(x, c, R0, A):
+    """f(x)=|x-c|-(R0+A sin(8 theta) sin(8 phi)) and its gradient (float64)."""
+    p = x - c
+    r = np.linalg.norm(p, axis=-1)
+    r = np.maximum(r, 1e-12)
+    ct = np.clip(p[..., 2] / r, -1.0, 1.0)
+    theta = np.arccos(ct)
+    phi = np.arctan2(p[..., 1], p[..., 0])
+    s8t, c8t = np.sin(8 * theta), np.cos(8 * theta)
+    s8p, c8p = np.sin(8 * phi), np.cos(8 * phi)
+    f = r - (R0 + A * s8t * s8p)
+    # gradient: e_r - A*(8 c8t s8p e_theta/r + 8 s8t c8p e_phi/(r sin theta))
+    st = np.sqrt(np.maximum(1.0 - ct * ct, 1e-12))
+    er = p / r[..., None]
+    rho = np.maximum(np.hypot(p[..., 0], p[..., 1]), 1e-12)
+    eth = np.stack([ct * p[..., 0] / rho, ct * p[..., 1] / rho, -st], -1)
+    eph = np.stack([-p[..., 1] / rho, p[..., 0] / rho, np.zeros_like(rho)], -1)
+    g = er - A * (8 * c8t * s8p / r)[..., None] * eth - A * (8 * s8t * c8p / (r * st))[..., None] * eph
+    return f, g
+
+
+def _albedo(x, c, L):
+    """smooth 3-colour pattern in [0.2, 0.9]"""
+    q = (x - c) / L
+    k = 2 * np.pi * 1.5
+    a = np.stack([
+        np.sin(k * q[..., 0] + 0.3) * np.cos(k * q[..., 1]),
+        np.sin(k * q[..., 1] + 1.1) * np.cos(k * q[..., 2]),
+        np.sin(k * q[..., 2] + 2.3) * np.cos(k * q[..., 0]),
+    ], -1)
+    return 0.55 + 0.35 * a
+
+
+def _sh(n, order):
+    one = np.ones_like(n[..., 0])
+    b = [one, n[..., 0], n[..., 1], n[..., 2]]
+    if order == 2:
+        b += [n[..., 0] * n[..., 1], n[..., 0] * n[..., 2], n[..., 1] * n[..., 2],
+              n[..., 0] ** 2 - n[..., 1] ** 2, n[..., 0] ** 2 - n[..., 2] ** 2]
+    return np.stack(b, -1)
+
+
+def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, noise=True,
+               perturb=True, z_mult=1, dtype=np.float32):
+    """Build a scene.  N: grid edge (z edge = N*z_mult, z_mult bumpy spheres stacked along z for the
+    weak-scaling bench), F keyframes of W x H pixels.
+
+    Intrinsics scale with the image so the object always fills the same fraction of the frame:
+    fx = fy = 525 * W/640 (TUM-like 640x480 -> 525)."""
+    rng_l = np.random.default_rng(seed)
+    vs = extent / N
+    dim = np.array([N, N, N * z_mult], np.int32)
+    shift = np.array([0.013, -0.021, 0.007], np.float64)
+    T = 5.0 * vs
+    R0 = 0.34 * N * vs
+    A = 0.01 * N * vs
+    centres = [shift + np.array([0, 0, (s - 0.5 * (z_mult - 1)) * N * vs]) for s in range(z_mult)]
+    fx = fy = 525.0 * W / 640.0
+    cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+    K = np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], np.float32)
+    order = 2 if model == "SH2" else 1
+    nb = 9 if model == "SH2" else 4
+
+    # ---- cameras: orbit of radius 1.5*N*vs around the z axis of the (whole) object, +-15 deg zig-zag
+    orbit = 1.5 * N * vs
+    poses = np.zeros((F, 4, 4), np.float64)
+    zspan = 0.5 * (z_mult - 1) * N * vs
+    for f in range(F):
+        az = 2 * np.pi * f / F
+        el = np.deg2rad(15.0) * (1 if f % 2 == 0 else -1)
+        zc = 0.0 if z_mult == 1 else -zspan + 2 * zspan * ((f * 7) % F) / max(F - 1, 1)
+        target = shift + np.array([0, 0, zc])
+        pos = target + orbit * np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+        zax = _unit(target - pos)
+        up = np.array([0.0, 0.0, 1.0])
+        xax = _unit(np.cross(zax, up))
+        yax = np.cross(zax, xax)
+        poses[f, :3, 0], poses[f, :3, 1], poses[f, :3, 2], poses[f, :3, 3] = xax, yax, zax, pos
+        poses[f, 3, 3] = 1.0
+
+    # ---- lights
+    light = None
+    if model == "LED":
+        light = np.array([1.2, 1.0, 0.8]) * orbit ** 2
+    else:
+        light = np.zeros((F, nb))
+        for f in range(F):
+            d = _unit(-poses[f, :3, 2] + 0.5 * rng_l.standard_normal(3))
+            light[f, 0] = 0.3
+            light[f, 1:4] = 0.6 * d
+            if order == 2:
+                light[f, 4:] = rng_l.uniform(-0.1, 0.1, 5)
+
+    def shade(x, n, f):
+        """rendered intensity of surface point x with outward unit normal n in frame f"""
+        rho = _albedo(x, shift, extent)
+        if model == "LED":
+            R, t = poses[f, :3, :3], poses[f, :3, 3]
+            v = x - t
+            irr = -(n * v).sum(-1) / np.linalg.norm(v, axis=-1) ** 3
+            return rho * light[None, :] * irr[..., None]
+        irr = (_sh(n, order) * light[f]).sum(-1)
+        return rho * irr[..., None]
+
+    def fmin(x):
+        """distance-like value to the union of the stacked blobs + gradient of the active one"""
+        best_f, best_g = None, None
+        for c in centres:
+            f_, g_ = _shape_f(x, c, R0, A)
+            if best_f is None:
+                best_f, best_g = f_, g_
+            else:
+                m = f_ < best_f
+                best_f = np.where(m, f_, best_f)
+                best_g = np.where(m[..., None], g_, best_g)
+        return best_f, best_g
+
+    # ---- images by sphere tracing
+    images = np.zeros((F, H, W, 3), np.float64)
+    uu, vv = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    dirs_c = _unit(np.stack([(uu - cx) / fx, (vv - cy) / fy, np.ones_like(uu)], -1))
+    for f in range(F):
+        R, t = poses[f, :3, :3], poses[f, :3, 3]
+        d = dirs_c @ R.T
+        # cull by the bounding spheres
+        hit_any = np.zeros((H, W), bool)
+        t0 = np.full((H, W), np.inf)
+        for c in centres:
+            oc = t - c
+            bq = (d * oc).sum(-1)
+            cq = (oc * oc).sum() - (R0 + 1.2 * A) ** 2
+            disc = bq * bq - cq
+            ok = disc > 0
+            tt = -bq - np.sqrt(np.where(ok, disc, 0))
+            ok &= tt > 0
+            t0 = np.where(ok & (tt < t0), tt, t0)
+            hit_any |= ok
+        idx = np.nonzero(hit_any)
+        if len(idx[0]) == 0:
+            continue
+        dd = d[idx]
+        s = t0[idx].copy()
+        alive = np.ones(len(s), bool)
+        for _ in range(60):
+            x = t + dd * s[:, None]
+            fv, gv = fmin(x)
+            step = fv / np.linalg.norm(gv, axis=-1)
+            s = s + np.where(alive, 0.9 * step, 0)
+            alive &= s < t0[idx] + 4 * (R0 + 2 * A)
+        x = t + dd * s[:, None]
+        fv, gv = fmin(x)
+        good = np.abs(fv) < 1e-6 * extent + 1e-9
+        n = _unit(gv)
+        col = shade(x, n, f)
+        col = np.where(good[:, None], col, 0.0)
+        images[f][idx] = col
+    if noise:
+        images = images + 0.005 * np.random.default_rng(1).standard_normal(images.shape)
+    images = np.clip(images, 0.0, 1.0)
+
+    # ---- analytic voxel state
+    ii = np.arange(N, dtype=np.float64)
+    kk = np.arange(N * z_mult, dtype=np.float64)
+    origin = shift - 0.5 * vs * dim.astype(np.float64)
+    nvox = int(dim.prod())
+    dist = np.empty(nvox, np.float32)
+    grad = np.zeros((3, nvox), np.float32)
+    weight = np.zeros(nvox, np.float32)
+    rgb = np.zeros((3, nvox), np.float32)
+    wpv = (F + 63) // 64
+    vis = np.zeros((nvox, wpv), np.uint64)
+    # process z-planes in chunks to bound memory
+    plane = N * N
+    chunk = max(1, (1 << 22) // plane)
+    rng_d = np.random.default_rng(3)
+    for k0 in range(0, N * z_mult, chunk):
+        k1 = min(N * z_mult, k0 + chunk)
+        Z, Y, X = np.meshgrid(kk[k0:k1], ii, ii, indexing="ij")
+        x = origin + vs * np.stack([X, Y, Z], -1).reshape(-1, 3)
+        fv, gv = fmin(x)
+        gn = np.linalg.norm(gv, axis=-1)
+        d = fv / gn
+        nrm = gv / gn[:, None]
+        sl = slice(k0 * plane, k1 * plane)
+        near = np.abs(d) < T
+        dn = np.clip(d, -T, T)
+        if perturb:
+            pert = 0.3 * vs * np.sin(40.0 * x[:, 0] / extent * 2 + 1.0) * np.cos(34.0 * x[:, 1] / extent * 2) * np.sin(28.0 * x[:, 2] / extent * 2 + 0.5)
+            pert = pert + 0.03 * vs * rng_d.standard_normal(len(d))
+            dn = np.where(near, np.clip(d + pert, -T, T), dn)
+        dist[sl] = dn
+        nidx = np.nonzero(near)[0]
+        if len(nidx) == 0:
+            continue
+        xs = x[nidx] - d[nidx, None] * nrm[nidx]
+        cnt = np.zeros(len(nidx))
+        colsum = np.zeros((len(nidx), 3))
+        vbits = np.zeros((len(nidx), wpv), np.uint64)
+        for f in range(F):
+            R, t = poses[f, :3, :3], poses[f, :3, 3]
+            view = _unit(t - xs)
+            cosang = (view * nrm[nidx]).sum(-1)
+            pc = (xs - t) @ R
+            with np.errstate(divide="ignore", invalid="ignore"):
+                m = fx * pc[:, 0] / pc[:, 2] + cx
+                n_ = fy * pc[:, 1] / pc[:, 2] + cy
+            ok = (cosang > 0.25) & (pc[:, 2] > 0) & (m >= 1) & (m < W - 2) & (n_ >= 1) & (n_ < H - 2)
+            cnt += ok
+            vbits[ok, f >> 6] |= np.uint64(1) << np.uint64(f & 63)
+            if ok.any():
+                colsum[ok] += np.clip(shade(xs[ok], nrm[nidx][ok], f), 0, 1)
+        g = sl.start + nidx
+        weight[g] = cnt
+        grad[:, g] = (nrm[nidx] * np.maximum(cnt, 1)[:, None]).T
+        rgb[:, g] = (colsum / np.maximum(cnt, 1)[:, None]).T
+        vis[g] = vbits
+
+    poses_used = poses.copy()
+    if perturb:
+        rng_p = np.random.default_rng(4)
+        for f in range(F):
+            xi_t = 0.002 * rng_p.standard_normal(3)
+            w = np.deg2rad(0.2) * rng_p.standard_normal(3)
+            th = np.linalg.norm(w)
+            Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            Rw = np.eye(3) + np.sin(th) / th * Kx + (1 - np.cos(th)) / th ** 2 * Kx @ Kx
+            poses_used[f, :3, :3] = poses[f, :3, :3] @ Rw
+            poses_used[f, :3, 3] = poses[f, :3, 3] + xi_t
+
+    return Scene(
+        N=N, F=F, W=W, H=H, model=model, model_id=MODELS[model], dim=dim, voxel_size=np.float32(vs),
+        shift=shift.astype(np.float32), truncation=np.float32(T), K=K,
+        dist=dist, grad=np.ascontiguousarray(grad), weight=weight, rgb=np.ascontiguousarray(rgb),
+        vis=np.ascontiguousarray(vis), vis_words=wpv,
+        images=np.ascontiguousarray(images.astype(np.float32)),
+        poses=np.ascontiguousarray(poses_used.reshape(F, 16).astype(np.float32)),
+        poses_gt=poses.reshape(F, 16).astype(np.float32),
+        light_gt=np.asarray(light, np.float32), frame_idx=np.arange(F, dtype=np.int32),
+        R0=R0, A=A, extent=extent,
+    )
