@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py — Gauss-Newton iterations/sec of the full photometric-stereo sweep (BASELINE.json metric).
+
+One "step" = one body of the alternation loop (albedo, light, distance, pose blocks, the four PS-energy
+evaluations and the convergence test; PsOptimizer.cpp:303-366) on the synthetic 256^3 x 50-keyframe
+scene, inputs resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 256] [--frames 50] [--model SH1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1 (round 1): every rank runs its own replica of the workload on its own GPU ("replicas"; the
+z-slab partition with RCCL halo exchange is DESIGN.md §7 work in progress), value = N * it/s.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from psgradientsdf_amd import capi, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(kernel, S, n_obs, W, H, F, laplacian=False):
+    """Algorithmic HBM bytes of ONE launch: per band voxel B_v = 60 B of state
+    (dist 4, grad 12, rgb 12, vis 8, 3 stencil-neighbour dists 12, 3 row lookups 12; +12 with the Laplacian),
+    image taps U_img = min(48 B * n_obs, 12 B * W*H*F) and the kernel's per-voxel output."""
+    B_v = 60 + (12 if laplacian else 0) + (8 if F > 64 else 0)
+    U = min(48 * n_obs, 12 * W * H * F)
+    table = {
+        "sweep_albedo": S * B_v + U + 24 * S,
+        "sweep_light": S * B_v + U,
+        "sweep_pose": S * B_v + U,
+        "sweep_dist": S * B_v + U + 56 * S,
+        "energy": S * B_v + U,
+        "pcg_mv": 124 * S,
+        "pcg_upd": 40 * S,
+        "assemble": (56 + 80 + 12) * S,
+        "derive": (4 + 12 + 24 + 36 + 12) * S,
+    }
+    return table.get(kernel)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=50)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--model", default="SH1", choices=["SH1", "SH2", "LED"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    device = local_rank if world > 1 else 0
+
+    t_gen = time.time()
+    sc = synth.make_scene(N=args.grid, F=args.frames, W=args.width, H=args.height, model=args.model)
+    t_gen = time.time() - t_gen
+    model_id = synth.MODELS[args.model]
+    st = capi.default_settings(model_id)
+    if args.model == "LED":   # config_basket_LED.json
+        st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0
+    eng = capi.load_engine(sc, sc.K, st, device)
+    eng.load_scene(sc)
+    eng.init_albedo()
+    eng.normalize_weights()
+    S = eng.info().n_band
+    n_obs = eng.step(capi.ALBEDO)["n_obs"]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    eng.iterate(capi.ALL, args.warmup)
+    eng.reset_kernel_times()
+    eng.watch_kernel("sweep_dist")       # HIP events on the launch stream, no host sync
+    barrier()
+    t0 = time.perf_counter()
+    recs = eng.iterate(capi.ALL, args.steps)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    watched = eng.kernel_times().get("sweep_dist", (0.0, 0))
+    eng.watch_kernel("")
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed
+    cg_iters = float(np.mean([r["cg_iters"] for r in recs]))
+
+    out = {
+        "metric": "Gauss-Newton iterations/sec (full PS sweep), 256^3 grid x 50 frames" if (args.grid, args.frames) == (256, 50)
+        else f"Gauss-Newton iterations/sec (full PS sweep), {args.grid}^3 grid x {args.frames} frames",
+        "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic {args.width}x{args.height} RGB-D bumpy sphere, {args.grid}^3 grid, {args.model}, {args.frames} keyframes, "
+                               "albedo+light+distance+pose blocks, Cauchy IRLS, Eikonal reg (config_skorates.json settings)",
+                   "band_voxels": int(S), "observations": int(n_obs), "pcg_iters_per_step": cg_iters,
+                   "parallelism": "single GPU" if world == 1 else f"{world} replicas (one per GPU)"},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, timed live with HIP events inside the timed region
+        lap = st.reg_weight_l != 0.0
+        kernels = {}
+        if not args.no_breakdown:
+            eng.set_profiling(True)
+            eng.reset_kernel_times()
+            nprof = 3
+            eng.iterate(capi.ALL, nprof)
+            kt = eng.kernel_times()
+            eng.set_profiling(False)
+            kernels = {k: {"ms_per_iter": v[0] / nprof, "launches_per_iter": v[1] / nprof, "avg_us": 1e3 * v[0] / max(v[1], 1)} for k, v in kt.items()}
+        dom = "sweep_dist"
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["ms_per_iter"] if algorithmic_bytes(k, 1, 1, 1, 1, 1) else -1)
+        if dom == "sweep_dist" and watched[1] > 0:
+            avg_ms = watched[0] / watched[1]
+        else:
+            avg_ms = kernels[dom]["avg_us"] / 1e3
+        nbytes = algorithmic_bytes(dom, S, n_obs, args.width, args.height, args.frames, lap)
+        achieved = nbytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms}
+        # whole-iteration algorithmic bytes (SURVEY.md §8d formula) for reference
+        U = min(48 * n_obs, 12 * args.width * args.height * args.frames)
+        B_iter = 4 * (S * 60 + U) + 120 * S + 124 * cg_iters * S
+        out["iteration"] = {"algorithmic_bytes": B_iter, "achieved_GBs": B_iter * (value / world) / 1e9,
+                            "frac_of_hbm_peak": B_iter * (value / world) / 1e9 / HBM_PEAK_GBS}
+        if kernels:
+            out["kernels"] = {k: round(v["ms_per_iter"], 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_iter"])}
+        out["setup_s"] = {"scene_generation": round(t_gen, 1)}
+
+        # ---- CPU baseline: the oracle (a port of the reference's arithmetic) on the host cores, bounded sample
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle
+            orc = oracle.Oracle(sc, sc.K, st, threads=1)
+            orc.load_scene(sc)
+            orc.init_albedo()
+            orc.normalize_weights()
+            tc = time.perf_counter()
+            orc.iterate(capi.ALL, 1)
+            tc = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "it/s", "cores": 1, "kind": "port",
+                                   "sample": f"1 full Gauss-Newton iteration of the same {args.grid}^3 x {args.frames} scene "
+                                             f"(4 blocks + 4 energy evaluations), single-threaded C oracle with indexed band lookup, {tc:.1f} s"}
+            orc.close()
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -217,6 +217,9 @@ int psgsdf_kernel_times(psgsdf_ctx* ctx, const char** names, double* ms, int64_t
 int psgsdf_reset_kernel_times(psgsdf_ctx* ctx);
 /* enable per-kernel hipEvent timing (adds a sync per launch: measurement mode only) */
 int psgsdf_set_profiling(psgsdf_ctx* ctx, int enabled);
+/* time ONE kernel (by its name in psgsdf_kernel_times) with hipEvent pairs recorded on the launch
+ * stream and no host synchronisation; resolved by the next psgsdf_kernel_times call.  NULL/"" = off. */
+int psgsdf_watch_kernel(psgsdf_ctx* ctx, const char* name);
 /* Builds the distance normal equations at the current state and returns, for the n_band rows:
  * diag (H_ii before damping), rhs b, and y = H*x for the supplied x (may be NULL). */
 int psgsdf_debug_dist_system(psgsdf_ctx* ctx, float* diag, float* rhs, const float* x, float* y);

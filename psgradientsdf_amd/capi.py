@@ -208,6 +208,23 @@ class Api:
         a, p = _fp(light)
         self._check(self._fn("upload_light")(self.ctx, p), "upload_light")
 
+    # -- measurement
+    def set_profiling(self, on):
+        self._check(self._fn("set_profiling")(self.ctx, C.c_int(1 if on else 0)), "set_profiling")
+
+    def watch_kernel(self, name):
+        self._check(self._fn("watch_kernel")(self.ctx, name.encode() if name else None), "watch_kernel")
+
+    def reset_kernel_times(self):
+        self._check(self._fn("reset_kernel_times")(self.ctx), "reset_kernel_times")
+
+    def kernel_times(self):
+        cap = 64
+        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); n = (C.c_int64 * cap)()
+        f = getattr(self._lib, self._p + "kernel_times"); f.restype = C.c_int
+        k = f(self.ctx, names, ms, n, C.c_int(cap))
+        return {names[i].decode(): (ms[i], n[i]) for i in range(k)}
+
     # -- test hooks
     def debug_dist_system(self, x=None):
         S = self.info().n_band

@@ -59,6 +59,10 @@ struct psgsdf_ctx {
     std::map<std::string, KTime> ktimes;
     std::vector<const char*> kt_names;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // asynchronous watch of ONE kernel name: event pairs recorded on the launch stream, resolved on query
+    std::string watch;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> watch_pool;
+    size_t watch_used = 0;
     char err[512] = {0};
 };
 
@@ -71,7 +75,19 @@ int fail(psgsdf_ctx* c, int code, const char* fmt, ...) {
 #define HIPCHK(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(c, PSGSDF_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
 
 template <class Fn> void timed(psgsdf_ctx* c, const char* name, Fn&& fn) {
-    if (!c->profiling) { fn(); return; }
+    if (!c->profiling) {
+        if (!c->watch.empty() && c->watch == name) {
+            if (c->watch_used == c->watch_pool.size()) {
+                hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); c->watch_pool.emplace_back(a, b);
+            }
+            auto& pr = c->watch_pool[c->watch_used++];
+            hipEventRecord(pr.first, c->stream);
+            fn();
+            hipEventRecord(pr.second, c->stream);
+            return;
+        }
+        fn(); return;
+    }
     hipEventRecord(c->ev0, c->stream);
     fn();
     hipEventRecord(c->ev1, c->stream);
@@ -366,6 +382,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     hipFree(c->band_mem); hipFree(c->acc_frame); hipFree(c->scal); hipFree(c->pcg_sc); hipFree(c->d_total);
     if (c->host_buf) hipHostFree(c->host_buf);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
+    for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -646,9 +663,21 @@ int psgsdf_comm_init(psgsdf_ctx* c, const uint8_t id[128], int rank, int n_ranks
 
 // ---- measurement / test hooks -------------------------------------------------------------
 int psgsdf_set_profiling(psgsdf_ctx* c, int enabled) { if (!c) return PSGSDF_ERR_ARG; c->profiling = enabled != 0; return PSGSDF_OK; }
-int psgsdf_reset_kernel_times(psgsdf_ctx* c) { if (!c) return PSGSDF_ERR_ARG; c->ktimes.clear(); return PSGSDF_OK; }
+int psgsdf_reset_kernel_times(psgsdf_ctx* c) { if (!c) return PSGSDF_ERR_ARG; c->ktimes.clear(); c->watch_used = 0; return PSGSDF_OK; }
+int psgsdf_watch_kernel(psgsdf_ctx* c, const char* name) {
+    if (!c) return PSGSDF_ERR_ARG;
+    hipStreamSynchronize(c->stream);
+    c->watch = name ? name : ""; c->watch_used = 0;
+    return PSGSDF_OK;
+}
 int psgsdf_kernel_times(psgsdf_ctx* c, const char** names, double* ms, int64_t* launches, int cap) {
     if (!c) return 0;
+    if (c->watch_used) {   // resolve the asynchronous event pairs of the watched kernel
+        hipStreamSynchronize(c->stream);
+        KTime& k = c->ktimes[c->watch];
+        for (size_t i = 0; i < c->watch_used; ++i) { float t = 0; if (hipEventElapsedTime(&t, c->watch_pool[i].first, c->watch_pool[i].second) == hipSuccess) { k.ms += t; k.n += 1; } }
+        c->watch_used = 0;
+    }
     int n = 0;
     for (auto& kv : c->ktimes) { if (n >= cap) break; names[n] = kv.first.c_str(); ms[n] = kv.second.ms; launches[n] = kv.second.n; ++n; }
     return n;
