@@ -19,6 +19,7 @@ namespace psg {
 constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts of 64)
 constexpr int kMaxFramesLds = 128;   // frame records staged in LDS (12 KiB)
 constexpr int kNQ = 19;              // columns of one assembled distance-system row (ELL)
+constexpr int kNQCommon = 13;        // self + 6 axis neighbours + 6 mixed-sign pairs: all a forward-only stencil touches
 constexpr int kMaxBasis = 9;
 
 struct FrameP {       // 24 floats = 96 B
@@ -55,19 +56,29 @@ struct Band {
     float* xs[3];             // surface point x_v - d*normalized(grad)      (OptimizerAux.cpp:215)
     float* gn[3];             // normalized(stored grad)
     float* gfd[3];            // finite-difference gradient (Optimizer.cpp:287-364), un-normalised
+    float* nfd[3];            // normalized(gfd): the normal every residual is rendered with
     // albedo diagonal system
     float* aH; float* ab;     // [3][Spad]
     // distance system: per-voxel 4x4 block (10 sym) + 4 rhs, then assembled ELL rows
     float* blk;               // [14][Spad]
     float* H;                 // [kNQ][Spad]
-    float* rhs; float* x; float* r; float* z; float* t; float* p[2]; float* inv;
+    int* hx;                  // [Spad] 1 if any of the 6 rare columns of this row is non-zero
+    float* rhs; float* x; float* r; float* t; float* p; float* inv;
+    float2* zp;               // [Spad] {z_i, p_i of the previous PCG pass}: ONE 8-byte gather per matrix column
+    // per-frame observation lists (static per band): rows visible in frame f, ascending
+    int* obs_ptr;             // [F+1]
+    int* obs_rows;            // [obs_ptr[F]]
+    int obs_max;              // longest list
 };
 
 // accumulators for the per-frame normal equations and the scalar reductions (double)
 struct Accum {
-    double* frame;            // [F][stride] light: n(n+1)/2 + n, pose: 21 + 6
-    double* scal;             // [8]: 0 energy sum, 1 n_obs, 2 E_n sum, 3 E_l sum, 4 accepted, 5 aux0.. 7 aux2
+    double* frame;            // [F][kFrameRow] per-frame rows: H (upper triangle) | rhs | energy | n_obs
+    double* part;             // [SC_COUNT][PB] per-workgroup partials of the scalar reductions
+    int PB;                   // capacity (workgroups) of one partial slot
 };
+constexpr int kFrameRow = 64;        // doubles per frame accumulator row (SH2: 45 + 9 + 2 = 56)
+constexpr int kPcgMaxBlocks = 2048;  // workgroups of one PCG pass (grid-stride)
 
 enum { SC_ENERGY = 0, SC_NOBS = 1, SC_EN = 2, SC_EL = 3, SC_ACCEPT = 4, SC_AUX0 = 5, SC_AUX1 = 6, SC_AUX2 = 7, SC_COUNT = 8 };
 
@@ -96,6 +107,9 @@ struct DenseView { float* dist; float* g[3]; float* weight; float* rho[3]; uint6
 void launch_band_fill(const DenseView& d, const GridP& grid, Band b, hipStream_t s);
 void launch_band_scatter(const DenseView& d, Band b, hipStream_t s);
 void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s);
+constexpr int kObsChunk = 2048;      // rows per workgroup of the observation-list builders
+void launch_obs_count(const Band& b, int F, int* counts, hipStream_t s);                 // counts[F][nch]
+void launch_obs_fill(const Band& b, int F, const int* offsets, hipStream_t s);           // offsets[F][nch] -> b.obs_rows
 void launch_init_albedo(const SweepArgs& a, hipStream_t s);
 void launch_led_light_init(const SweepArgs& a, hipStream_t s);
 void launch_energy(const SweepArgs& a, hipStream_t s);
@@ -107,9 +121,10 @@ void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, hi
 void launch_solve_pose(const SweepArgs& a, FrameP* frames, hipStream_t s);
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s);
 void launch_assemble(const SweepArgs& a, hipStream_t s);
-void launch_pcg_init(const SweepArgs& a, double* sc, hipStream_t s);
-void launch_pcg_mv(const SweepArgs& a, double* sc, int k, int with_damping, hipStream_t s);
-void launch_pcg_upd(const SweepArgs& a, double* sc, int k, hipStream_t s);
+void launch_pcg_init(const SweepArgs& a, double* sc, double* part, int G, hipStream_t s);
+void launch_pcg_mv(const SweepArgs& a, double* sc, double* part, int G, int k, int with_damping, hipStream_t s);
+void launch_pcg_upd(const SweepArgs& a, double* sc, double* part, int G, int k, hipStream_t s);
+void launch_pcg_final(double* sc, double* part, int G, int k, hipStream_t s);
 void launch_matvec(const SweepArgs& a, const float* x, float* y, hipStream_t s);   // debug: y = H x (no damping)
 void launch_apply_dist(const SweepArgs& a, hipStream_t s);
 void launch_upsample(const DenseView& src, const DenseView& dst, const GridP& g_old, hipStream_t s);

@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -43,13 +44,16 @@ struct psgsdf_ctx {
     bool have_frames = false;
     // band
     void* band_mem = nullptr; size_t band_bytes = 0;
+    void* obs_mem = nullptr;
     Band band{};
     bool inited = false;
     // accumulators
     double* acc_frame = nullptr; size_t acc_frame_n = 0;
-    double* scal = nullptr;
+    double* part = nullptr; int PB = 0;  // [SC_COUNT][PB] per-workgroup partials
     double* pcg_sc = nullptr; int pcg_cap = 4096;
-    double* host_buf = nullptr;          // pinned readback
+    double* pcg_part = nullptr;          // [2][3][kPcgMaxBlocks]
+    int last_cg_iters = 0;
+    double* host_buf = nullptr; size_t host_buf_n = 0;   // pinned readback
     // cached energies
     double en_sum = 0, el_sum = 0;       // sums over the band from the last k_derive
     // comm
@@ -100,7 +104,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     SweepArgs a{};
     a.b = c->band; a.frames = c->frames; a.img = c->img; a.F = c->F; a.cam = c->cam; a.grid = c->grid;
     a.rob.loss = c->set.loss; a.rob.lambda = c->set.lambda; a.rob.lambda_sq = c->set.lambda * c->set.lambda;
-    a.acc.frame = c->acc_frame; a.acc.scal = c->scal;
+    a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
     a.model = c->set.model; a.quirks = c->set.ref_quirks;
     a.reg_n = c->reg_n; a.reg_l = c->reg_l;
     a.normal_reg = c->reg_n != 0.0f; a.laplacian_reg = laplacian_reg;
@@ -108,11 +112,31 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     return a;
 }
 
-int zero_scal(psgsdf_ctx* c) { HIPCHK(c, hipMemsetAsync(c->scal, 0, sizeof(double) * SC_COUNT, c->stream)); return 0; }
-int read_scal(psgsdf_ctx* c, double* out) {
-    HIPCHK(c, hipMemcpyAsync(c->host_buf, c->scal, sizeof(double) * SC_COUNT, hipMemcpyDeviceToHost, c->stream));
+inline int band_blocks(const psgsdf_ctx* c) { return (c->band.S + kBlock - 1) / kBlock; }
+// sum the per-workgroup partials of the given slots (written by a voxel-major kernel of band_blocks() workgroups)
+int read_parts(psgsdf_ctx* c, const int* slots, int n, double* out) {
+    const int nb = band_blocks(c);
+    for (int i = 0; i < n; ++i)
+        if (nb > 0) HIPCHK(c, hipMemcpyAsync(c->host_buf + (size_t)i * nb, c->part + (size_t)slots[i] * c->PB, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    memcpy(out, c->host_buf, sizeof(double) * SC_COUNT);
+    for (int i = 0; i < n; ++i) { double s = 0; for (int k = 0; k < nb; ++k) s += c->host_buf[(size_t)i * nb + k]; out[i] = s; }
+    return 0;
+}
+// frame-major sweeps: energy and n_obs live in columns (col_e, col_e+1) of every frame row
+int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs) {
+    HIPCHK(c, hipMemcpyAsync(c->host_buf, c->acc_frame, sizeof(double) * c->acc_frame_n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double e = 0, n = 0;
+    for (int f = 0; f < c->F; ++f) { e += c->host_buf[(size_t)f * kFrameRow + col_e]; n += c->host_buf[(size_t)f * kFrameRow + col_e + 1]; }
+    *E = e; *nobs = n;
+    return 0;
+}
+int ensure_host_buf(psgsdf_ctx* c, size_t n) {
+    if (n <= c->host_buf_n) return 0;
+    if (c->host_buf) hipHostFree(c->host_buf);
+    c->host_buf = nullptr; c->host_buf_n = 0;
+    HIPCHK(c, hipHostMalloc(&c->host_buf, sizeof(double) * n));
+    c->host_buf_n = n;
     return 0;
 }
 
@@ -143,7 +167,7 @@ int build_band(psgsdf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int Spad = ((S + kBlock - 1) / kBlock) * kBlock + kBlock;
     // planes (4-byte units per row): see Band
-    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 9 + 6 + 14 + kNQ + 9;
+    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 11;
     const size_t bytes = (n4 * 4 + (size_t)KW * 8) * Spad + 256;
     if (c->band_mem) { hipFree(c->band_mem); c->band_mem = nullptr; }
     HIPCHK(c, hipMalloc(&c->band_mem, bytes));
@@ -162,20 +186,51 @@ int build_band(psgsdf_ctx* c) {
     for (int a = 0; a < 3; ++a) b.xs[a] = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.gn[a] = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.gfd[a] = (float*)take(1, 4);
+    for (int a = 0; a < 3; ++a) b.nfd[a] = (float*)take(1, 4);
     b.aH = (float*)take(3, 4); b.ab = (float*)take(3, 4);
     b.blk = (float*)take(14, 4); b.H = (float*)take(kNQ, 4);
-    b.rhs = (float*)take(1, 4); b.x = (float*)take(1, 4); b.r = (float*)take(1, 4); b.z = (float*)take(1, 4); b.t = (float*)take(1, 4);
-    b.p[0] = (float*)take(1, 4); b.p[1] = (float*)take(1, 4); b.inv = (float*)take(1, 4);
+    b.zp = (float2*)take(2, 4);
+    b.hx = (int*)take(1, 4);
+    b.rhs = (float*)take(1, 4); b.x = (float*)take(1, 4); b.r = (float*)take(1, 4); b.t = (float*)take(1, 4);
+    b.p = (float*)take(1, 4); b.inv = (float*)take(1, 4);
     timed(c, "band_fill", [&] { launch_band_fill(c->dense, c->grid, b, c->stream); });
-    return 0;
+    // per-frame observation lists (counts -> host prefix -> fill)
+    {
+        const int nch = (S + kObsChunk - 1) / kObsChunk, F = c->F;
+        if (c->obs_mem) { hipFree(c->obs_mem); c->obs_mem = nullptr; }
+        b.obs_ptr = nullptr; b.obs_rows = nullptr; b.obs_max = 0;
+        if (nch > 0 && F > 0) {
+            int* d_counts = nullptr;
+            HIPCHK(c, hipMalloc(&d_counts, sizeof(int) * (size_t)nch * F));
+            launch_obs_count(b, F, d_counts, c->stream);
+            std::vector<int> cnt((size_t)nch * F), off((size_t)nch * F), ptr(F + 1);
+            HIPCHK(c, hipMemcpyAsync(cnt.data(), d_counts, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            int run = 0, mx = 0;
+            for (int f = 0; f < F; ++f) { ptr[f] = run; for (int k = 0; k < nch; ++k) { off[(size_t)f * nch + k] = run; run += cnt[(size_t)f * nch + k]; } mx = std::max(mx, run - ptr[f]); }
+            ptr[F] = run;
+            HIPCHK(c, hipMalloc(&c->obs_mem, sizeof(int) * ((size_t)run + F + 2)));
+            b.obs_ptr = (int*)c->obs_mem; b.obs_rows = b.obs_ptr + (F + 1); b.obs_max = mx;
+            HIPCHK(c, hipMemcpyAsync(b.obs_ptr, ptr.data(), sizeof(int) * (F + 1), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_counts, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice, c->stream));
+            launch_obs_fill(b, F, d_counts, c->stream);
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(d_counts);
+        }
+    }
+    if (c->part) { hipFree(c->part); c->part = nullptr; }
+    c->PB = Spad / kBlock + 1;
+    HIPCHK(c, hipMalloc(&c->part, sizeof(double) * SC_COUNT * c->PB));
+    HIPCHK(c, hipMemsetAsync(c->part, 0, sizeof(double) * SC_COUNT * c->PB, c->stream));
+    return ensure_host_buf(c, (size_t)SC_COUNT * c->PB + (size_t)c->F * kFrameRow + kPcgScalHead + 3 * 4096 + 64);
 }
 
 int derive(psgsdf_ctx* c, int update_grad) {
-    int rc = zero_scal(c); if (rc) return rc;
     SweepArgs a = make_args(c, 0);
     timed(c, "derive", [&] { launch_derive(a, update_grad, c->stream); });
-    double s[SC_COUNT]; rc = read_scal(c, s); if (rc) return rc;
-    c->en_sum = s[SC_EN]; c->el_sum = s[SC_EL];
+    const int slots[2] = {SC_EN, SC_EL}; double s[2];
+    int rc = read_parts(c, slots, 2, s); if (rc) return rc;
+    c->en_sum = s[0]; c->el_sum = s[1];
     return 0;
 }
 
@@ -183,11 +238,11 @@ inline double band_mean(const psgsdf_ctx* c, double sum) { return c->band.S ? su
 inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l) { return E + c->reg_n * E_n + c->reg_l * E_l; }
 
 int ps_energy(psgsdf_ctx* c, double* E, int64_t* nobs) {
-    int rc = zero_scal(c); if (rc) return rc;
     SweepArgs a = make_args(c, 0);
     timed(c, "energy", [&] { launch_energy(a, c->stream); });
-    double s[SC_COUNT]; rc = read_scal(c, s); if (rc) return rc;
-    *E = band_mean(c, s[SC_ENERGY]); if (nobs) *nobs = (int64_t)s[SC_NOBS];
+    const int slots[2] = {SC_ENERGY, SC_NOBS}; double s[2];
+    int rc = read_parts(c, slots, 2, s); if (rc) return rc;
+    *E = band_mean(c, s[0]); if (nobs) *nobs = (int64_t)s[1];
     return 0;
 }
 
@@ -195,19 +250,24 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
     const int S = c->band.S;
     int cap = c->set.cg_max_it > 0 ? c->set.cg_max_it : 2 * S;
     if (cap > c->pcg_cap) cap = c->pcg_cap;
+    // balanced grid-stride: the fewest equal passes that fit kPcgMaxBlocks workgroups
+    const int nblk = std::max(1, band_blocks(c));
+    const int passes = (nblk + kPcgMaxBlocks - 1) / kPcgMaxBlocks;
+    const int G = (nblk + passes - 1) / passes;
     HIPCHK(c, hipMemsetAsync(c->pcg_sc, 0, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap), c->stream));
-    timed(c, "pcg_init", [&] { launch_pcg_init(a, c->pcg_sc, c->stream); });
-    const int chunk = 16;
+    timed(c, "pcg_init", [&] { launch_pcg_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
+    // first chunk sized from the previous solve (the count is stable between Gauss-Newton iterations)
+    int chunk = std::max(4, c->last_cg_iters + 1);
     int k = 0, iters = -1;
     double rhsNorm2 = 0;
     float rn2_last = 0;
     while (true) {
         int n = chunk; if (k + n > cap) n = cap - k;
         for (int q = 0; q < n; ++q) {
-            timed(c, "pcg_mv", [&] { launch_pcg_mv(a, c->pcg_sc, k + q, 1, c->stream); });
-            timed(c, "pcg_upd", [&] { launch_pcg_upd(a, c->pcg_sc, k + q, c->stream); });
+            timed(c, "pcg_mv", [&] { launch_pcg_mv(a, c->pcg_sc, c->pcg_part, G, k + q, 1, c->stream); });
+            timed(c, "pcg_upd", [&] { launch_pcg_upd(a, c->pcg_sc, c->pcg_part, G, k + q, c->stream); });
         }
-        // read head + this chunk's scalars
+        if (n > 0) launch_pcg_final(c->pcg_sc, c->pcg_part, G, k + n - 1, c->stream);
         HIPCHK(c, hipMemcpyAsync(c->host_buf, c->pcg_sc, sizeof(double) * kPcgScalHead, hipMemcpyDeviceToHost, c->stream));
         if (n > 0) HIPCHK(c, hipMemcpyAsync(c->host_buf + kPcgScalHead, c->pcg_sc + kPcgScalHead + 3 * (size_t)k, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -222,9 +282,11 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         if (iters >= 0) break;
         k += n;
         if (k >= cap || n == 0) { iters = cap; break; }
+        chunk = 4;
     }
     double err = sqrt((double)rn2_last / (double)(float)rhsNorm2);
     *iters_out = iters; *err_out = err; *success_out = err <= (double)FLT_EPSILON;
+    c->last_cg_iters = iters;
     return 0;
 }
 
@@ -234,37 +296,36 @@ int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) 
     st->block = block;
     SweepArgs a = make_args(c, laplacian_reg);
     const bool led = c->set.model == PSGSDF_LED;
-    double s[SC_COUNT];
+    double e_sum = 0, nobs = 0;
     int rc;
     switch (block) {
         case PSGSDF_ALBEDO: {
-            if ((rc = zero_scal(c))) return rc;
             timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); });
             timed(c, "apply_albedo", [&] { launch_apply_albedo(a, c->stream); });
-            if ((rc = read_scal(c, s))) return rc;
-            st->cg_iters = 1; st->cg_converged = 1; st->applied = 1; st->n_accepted = (int64_t)s[SC_ACCEPT];
+            const int slots[3] = {SC_ENERGY, SC_NOBS, SC_ACCEPT}; double s[3];
+            if ((rc = read_parts(c, slots, 3, s))) return rc;
+            e_sum = s[0]; nobs = s[1];
+            st->cg_iters = 1; st->cg_converged = 1; st->applied = 1; st->n_accepted = (int64_t)s[2];
             break;
         }
         case PSGSDF_LIGHT: {
-            if ((rc = zero_scal(c))) return rc;
             HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
             timed(c, "sweep_light", [&] { launch_sweep_light(a, c->stream); });
             timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->stream); });
-            if ((rc = read_scal(c, s))) return rc;
+            const int n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4), nh = led ? 3 : n * (n + 1) / 2;
+            if ((rc = read_frame_energy(c, nh + n, &e_sum, &nobs))) return rc;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = led ? 1 : c->F;
             break;
         }
         case PSGSDF_POSE: {
-            if ((rc = zero_scal(c))) return rc;
             HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
             timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); });
             timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->stream); });
-            if ((rc = read_scal(c, s))) return rc;
+            if ((rc = read_frame_energy(c, 27, &e_sum, &nobs))) return rc;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = c->F;
             break;
         }
         case PSGSDF_DIST: {
-            if ((rc = zero_scal(c))) return rc;
             timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); });
             timed(c, "assemble", [&] { launch_assemble(a, c->stream); });
             int iters = 0, ok = 1; double err = 0;
@@ -272,15 +333,17 @@ int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) 
             int apply = 1;
             if (!led && c->set.ref_quirks && !ok) apply = 0;   // PsOptimizer.cpp:168-170 (B8)
             if (apply) timed(c, "apply_dist", [&] { launch_apply_dist(a, c->stream); });
-            if ((rc = read_scal(c, s))) return rc;
+            const int slots[3] = {SC_ENERGY, SC_NOBS, SC_ACCEPT}; double s[3];
+            if ((rc = read_parts(c, slots, 3, s))) return rc;
+            e_sum = s[0]; nobs = s[1];
             if (apply) { if ((rc = derive(c, 1))) return rc; }
-            st->cg_iters = iters; st->cg_converged = ok; st->cg_error = err; st->applied = apply; st->n_accepted = (int64_t)s[SC_ACCEPT];
+            st->cg_iters = iters; st->cg_converged = ok; st->cg_error = err; st->applied = apply; st->n_accepted = apply ? (int64_t)s[2] : 0;
             break;
         }
         default: return fail(c, PSGSDF_ERR_ARG, "unknown block %d", block);
     }
-    st->e_in = band_mean(c, s[SC_ENERGY]);
-    st->n_obs = (int64_t)s[SC_NOBS];
+    st->e_in = band_mean(c, e_sum);
+    st->n_obs = (int64_t)nobs;
     return 0;
 }
 
@@ -362,9 +425,8 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     for (int a = 0; a < 3; ++a) g.origin[a] = c->shift[a] - (float)(0.5 * (double)g.vs) * (float)g.dim[a];   // VoxelGrid.h:130
     c->cam.fx = K[0]; c->cam.fy = K[4]; c->cam.cx = K[2]; c->cam.cy = K[5];
     bool ok = hipStreamCreate(&c->stream) == hipSuccess
-        && hipMalloc(&c->scal, sizeof(double) * SC_COUNT) == hipSuccess
         && hipMalloc(&c->pcg_sc, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap)) == hipSuccess
-        && hipHostMalloc(&c->host_buf, sizeof(double) * (kPcgScalHead + 3 * 64 + SC_COUNT + 64)) == hipSuccess
+        && hipMalloc(&c->pcg_part, sizeof(double) * 6 * kPcgMaxBlocks) == hipSuccess
         && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess
         && hipMalloc(&c->led_light, sizeof(float) * 3) == hipSuccess
         && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
@@ -379,7 +441,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     free_dense(c);
     hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->frames); hipFree(c->led_light);
-    hipFree(c->band_mem); hipFree(c->acc_frame); hipFree(c->scal); hipFree(c->pcg_sc); hipFree(c->d_total);
+    hipFree(c->band_mem); hipFree(c->obs_mem); hipFree(c->acc_frame); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->d_total);
     if (c->host_buf) hipHostFree(c->host_buf);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -458,11 +520,11 @@ int psgsdf_init(psgsdf_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->frames, c->frames_h.data(), sizeof(FrameP) * c->F, hipMemcpyHostToDevice, c->stream));
     if ((rc = derive(c, 0))) return rc;
     if (led) {   // computeLightIntensive, LedOptimizer.cpp:76-112
-        if ((rc = zero_scal(c))) return rc;
         SweepArgs a = make_args(c, 0);
         timed(c, "led_light_init", [&] { launch_led_light_init(a, c->stream); });
-        double s[SC_COUNT]; if ((rc = read_scal(c, s))) return rc;
-        float L[3] = {(float)s[SC_AUX0] / (float)s[SC_EN], (float)s[SC_AUX1] / (float)s[SC_EL], (float)s[SC_AUX2] / (float)s[SC_ACCEPT]};
+        const int slots[6] = {SC_AUX0, SC_AUX1, SC_AUX2, SC_EN, SC_EL, SC_ACCEPT}; double s[6];
+        if ((rc = read_parts(c, slots, 6, s))) return rc;
+        float L[3] = {(float)s[0] / (float)s[3], (float)s[1] / (float)s[4], (float)s[2] / (float)s[5]};
         std::vector<FrameP> fr(c->F);
         HIPCHK(c, hipMemcpy(fr.data(), c->frames, sizeof(FrameP) * c->F, hipMemcpyDeviceToHost));
         for (int f = 0; f < c->F; ++f) for (int ch = 0; ch < 3; ++ch) fr[f].l[ch] = L[ch];
@@ -686,7 +748,6 @@ int psgsdf_kernel_times(psgsdf_ctx* c, const char** names, double* ms, int64_t* 
 int psgsdf_debug_dist_system(psgsdf_ctx* c, float* diag, float* rhs, const float* x, float* y) {
     if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = zero_scal(c); if (rc) return rc;
     SweepArgs a = make_args(c, c->reg_l != 0.f);
     launch_sweep_dist(a, c->stream);
     launch_assemble(a, c->stream);
@@ -705,7 +766,6 @@ int psgsdf_debug_dist_system(psgsdf_ctx* c, float* diag, float* rhs, const float
 int psgsdf_debug_frame_system(psgsdf_ctx* c, int block, double* H, double* b) {
     if (!c || !c->inited || !H || !b) return fail(c, PSGSDF_ERR_STATE, "init first");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = zero_scal(c); if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
     SweepArgs a = make_args(c, 0);
     const bool led = c->set.model == PSGSDF_LED;
@@ -716,11 +776,15 @@ int psgsdf_debug_frame_system(psgsdf_ctx* c, int block, double* H, double* b) {
     std::vector<double> acc(c->acc_frame_n);
     HIPCHK(c, hipMemcpyAsync(acc.data(), c->acc_frame, sizeof(double) * c->acc_frame_n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (led && block == PSGSDF_LIGHT) {   // one global system: sum the per-frame rows
+        for (int i = 0; i < 9; ++i) H[i] = 0;
+        for (int i = 0; i < 3; ++i) { b[i] = 0; for (int f = 0; f < c->F; ++f) { H[i * 3 + i] += acc[(size_t)f * kFrameRow + i]; b[i] += acc[(size_t)f * kFrameRow + 3 + i]; } }
+        return PSGSDF_OK;
+    }
     for (int k = 0; k < nb; ++k) {
-        const double* A = acc.data() + (size_t)k * (nh + n);
+        const double* A = acc.data() + (size_t)k * kFrameRow;
         double* Hk = H + (size_t)k * n * n; double* bk = b + (size_t)k * n;
         for (int i = 0; i < n * n; ++i) Hk[i] = 0;
-        if (led && block == PSGSDF_LIGHT) { for (int i = 0; i < 3; ++i) { Hk[i * 3 + i] = A[i]; bk[i] = A[3 + i]; } continue; }
         int q = 0;
         for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) { Hk[i * n + j] = A[q]; Hk[j * n + i] = A[q]; ++q; }
         for (int i = 0; i < n; ++i) bk[i] = A[nh + i];
@@ -731,7 +795,6 @@ int psgsdf_debug_frame_system(psgsdf_ctx* c, int block, double* H, double* b) {
 int psgsdf_debug_albedo_system(psgsdf_ctx* c, float* H, float* b) {
     if (!c || !c->inited || !H || !b) return fail(c, PSGSDF_ERR_STATE, "init first");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = zero_scal(c); if (rc) return rc;
     SweepArgs a = make_args(c, 0);
     launch_sweep_albedo(a, c->stream);
     const int S = c->band.S, Sp = c->band.Spad;

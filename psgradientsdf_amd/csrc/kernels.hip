@@ -82,8 +82,11 @@ __device__ __forceinline__ float wave_sumf(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
-// all threads of the block must call; red is __shared__ double[kBlock/64]
-__device__ __forceinline__ void block_atomic_add(double v, double* dst, double* red) {
+// Workgroup reduction -> ONE plain store per workgroup into a per-block partial slot (no atomics: 1300+
+// workgroups hitting one address serialise at ~12 ns each, which made trivial kernels take 30 us).
+// All threads of the block must call; red is __shared__ double[kBlock/64].  The partials are summed by the
+// consumer (host, or the next PCG kernel) in a fixed order, so results are run-to-run deterministic.
+__device__ __forceinline__ void block_part_store(double v, double* part_slot, double* red) {
     v = wave_sum(v);
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
@@ -92,9 +95,23 @@ __device__ __forceinline__ void block_atomic_add(double v, double* dst, double* 
     if (threadIdx.x == 0) {
         double s = 0;
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
-        if (s != 0.0) atomicAdd(dst, s);
+        part_slot[blockIdx.x] = s;
     }
 }
+// sum of n partials, identical in every thread of every block (fixed order)
+__device__ __forceinline__ double block_total(const double* part, int n, double* red) {
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += part[i];
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;
+}
+#define PART(a, slot) ((a).acc.part + (size_t)(slot) * (a).acc.PB)
 
 __device__ __forceinline__ void load_frames(FrameP* sf, const FrameP* frames, int F) {
     const float* src = (const float*)frames; float* dst = (float*)sf;
@@ -105,14 +122,17 @@ __device__ __forceinline__ void load_frames(FrameP* sf, const FrameP* frames, in
 // ------------------------------------------------------------------------------------------
 // projection + image sampling
 // ------------------------------------------------------------------------------------------
-struct Proj { float p[3]; float m, n; bool ok; };
+struct Proj { float p[3]; float m, n, z_inv; bool ok; };
 
 // OptimizerAux.cpp:207-226 (surface point precomputed in xs = x_v - d*normalized(grad))
 __device__ __forceinline__ Proj project(const float* xs, const FrameP& fp, const Cam& cam) {
     Proj o;
     float tmp[3] = {xs[0] - fp.t[0], xs[1] - fp.t[1], xs[2] - fp.t[2]};
     mulT3(fp.R, tmp, o.p);
-    float z_inv = (float)(1.0 / (double)o.p[2]);
+    // reference: (float)(1. / point[2]) evaluated in double (OptimizerAux.cpp:219); the correctly rounded float
+    // reciprocal differs from that only in double-rounding corner cases (~1e-8 of all inputs)
+    const float z_inv = 1.0f / o.p[2];
+    o.z_inv = z_inv;
     o.m = cam.fx * o.p[0] * z_inv + cam.cx;
     o.n = cam.fy * o.p[1] * z_inv + cam.cy;
     o.ok = (o.m >= 0.f && o.m < (float)cam.W && o.n >= 0.f && o.n < (float)cam.H);
@@ -213,9 +233,7 @@ __device__ __forceinline__ void rho_jac(const FrameP& fp, const Proj& pr, const 
 struct Vox { float xs[3], gn[3], nfd[3], rho[3]; };
 __device__ __forceinline__ void load_vox(const Band& b, int j, Vox& v) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { v.xs[a] = b.xs[a][j]; v.gn[a] = b.gn[a][j]; v.rho[a] = b.rho[a][j]; }
-    float g[3] = {b.gfd[0][j], b.gfd[1][j], b.gfd[2][j]};
-    normalized3(g, v.nfd);
+    for (int a = 0; a < 3; ++a) { v.xs[a] = b.xs[a][j]; v.gn[a] = b.gn[a][j]; v.rho[a] = b.rho[a][j]; v.nfd[a] = b.nfd[a][j]; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -319,9 +337,12 @@ __host__ __device__ inline void q_offset(int q, int* o) {
     o[0] = o[1] = o[2] = 0;
     if (q == 0) return;
     if (q <= 6) { int a = (q - 1) >> 1; o[a] = ((q - 1) & 1) ? -1 : 1; return; }
-    int pi = (q - 7) >> 2, si = (q - 7) & 3;
+    // q 7..12: mixed-sign axis pairs (the only pair columns a forward-only stencil produces), q 13..18: (+,+) / (-,-)
+    int pi, sa, sb;
+    if (q < kNQCommon) { pi = (q - 7) >> 1; sa = ((q - 7) & 1) ? -1 : 1; sb = -sa; }
+    else { pi = (q - kNQCommon) >> 1; sa = ((q - kNQCommon) & 1) ? -1 : 1; sb = sa; }
     int a = pi == 2 ? 1 : 0, b = pi == 0 ? 1 : 2;
-    o[a] = (si & 2) ? -1 : 1; o[b] = (si & 1) ? -1 : 1;
+    o[a] = sa; o[b] = sb;
 }
 __device__ __forceinline__ int q_of(const int* o) {
     int nz = (o[0] != 0) + (o[1] != 0) + (o[2] != 0);
@@ -329,7 +350,8 @@ __device__ __forceinline__ int q_of(const int* o) {
     if (nz == 1) { int a = o[0] ? 0 : (o[1] ? 1 : 2); return 1 + 2 * a + (o[a] < 0 ? 1 : 0); }
     int a = o[0] ? 0 : 1, b = o[2] ? 2 : 1;
     int pi = (a == 0 && b == 1) ? 0 : ((a == 0) ? 1 : 2);
-    return 7 + 4 * pi + ((o[a] < 0 ? 2 : 0) | (o[b] < 0 ? 1 : 0));
+    if (o[a] != o[b]) return 7 + 2 * pi + (o[a] < 0 ? 1 : 0);
+    return kNQCommon + 2 * pi + (o[a] < 0 ? 1 : 0);
 }
 
 // gather the compact band planes from the dense grid (one thread per dense voxel, coalesced reads)
@@ -361,7 +383,8 @@ __global__ void __launch_bounds__(kBlock) k_band_nb(DenseView d, GridP grid, Ban
     for (int q = 0; q < kNQ; ++q) {
         int o[3]; q_offset(q, o);
         long long ln = lin + o[0] * stride[0] + o[1] * stride[1] + o[2] * stride[2];
-        b.col[(size_t)q * b.Spad + j] = (ln >= 0 && ln < grid.nvox) ? d.row_of[ln] : -1;
+        int r = (ln >= 0 && ln < grid.nvox) ? d.row_of[ln] : -1;
+        b.col[(size_t)q * b.Spad + j] = r >= 0 ? r : j;   // absent column: coefficient is 0, point at self so gathers stay in range
     }
 }
 void launch_band_fill(const DenseView& d, const GridP& grid, Band b, hipStream_t s) {
@@ -462,6 +485,9 @@ __global__ void __launch_bounds__(kBlock) k_derive(SweepArgs a, int update_grad)
 #pragma unroll
         for (int k = 0; k < 3; ++k) { b.gfd[k][j] = n[k]; if (update_grad) b.g[k][j] = n[k]; g[k] = update_grad ? n[k] : b.g[k][j]; }
         float gn[3]; normalized3(g, gn);
+        float nn[3]; normalized3(n, nn);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) b.nfd[k][j] = nn[k];
         long long lin = b.lin[j];
         int nxy = a.grid.dim[0] * a.grid.dim[1];
         int kz = (int)(lin / nxy); int rest = (int)(lin - (long long)kz * nxy); int jy = rest / a.grid.dim[0]; int ix = rest - jy * a.grid.dim[0];
@@ -476,11 +502,62 @@ __global__ void __launch_bounds__(kBlock) k_derive(SweepArgs a, int update_grad)
         float e = norm3(n) - 1; en = (double)(e * e);
         float l = laplacian(b, j, a.grid.vs_inv); el = (double)(l * l);
     }
-    block_atomic_add(en, a.acc.scal + SC_EN, red);
-    block_atomic_add(el, a.acc.scal + SC_EL, red);
+    block_part_store(en, PART(a, SC_EN), red);
+    block_part_store(el, PART(a, SC_EL), red);
 }
 void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s) {
     if (a.b.S > 0) hipLaunchKernelGGL(k_derive, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, update_grad);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-frame observation lists: band rows whose visibility bit f is set, ascending.  Visibility is static
+// between band rebuilds, so the frame-major sweeps run over fully populated wavefronts instead of testing
+// (and mostly rejecting) every (voxel, frame) pair.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_obs_count(Band b, int F, int* __restrict__ counts) {
+    __shared__ int red[kBlock / 64];
+    const int f = blockIdx.y, nch = gridDim.x;
+    int cnt = 0;
+    for (int it = 0; it < kObsChunk / kBlock; ++it) {
+        int j = blockIdx.x * kObsChunk + it * kBlock + threadIdx.x;
+        if (j < b.S) cnt += (int)((b.vis[(size_t)(f >> 6) * b.Spad + j] >> (f & 63)) & 1ull);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) { int s = 0; for (int i = 0; i < kBlock / 64; ++i) s += red[i]; counts[f * nch + blockIdx.x] = s; }
+}
+void launch_obs_count(const Band& b, int F, int* counts, hipStream_t s) {
+    int nch = (b.S + kObsChunk - 1) / kObsChunk;
+    if (nch > 0 && F > 0) hipLaunchKernelGGL(k_obs_count, dim3(nch, F), dim3(kBlock), 0, s, b, F, counts);
+}
+__global__ void __launch_bounds__(kBlock) k_obs_fill(Band b, int F, const int* __restrict__ offsets) {
+    __shared__ int wsum[kBlock / 64];
+    __shared__ int run_s;
+    const int f = blockIdx.y, nch = gridDim.x;
+    if (threadIdx.x == 0) run_s = offsets[f * nch + blockIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int it = 0; it < kObsChunk / kBlock; ++it) {
+        int j = blockIdx.x * kObsChunk + it * kBlock + threadIdx.x;
+        bool flag = j < b.S && ((b.vis[(size_t)(f >> 6) * b.Spad + j] >> (f & 63)) & 1ull);
+        unsigned long long m = __ballot(flag);
+        int pre = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int i = 0; i < kBlock / 64; ++i) { if (i < w) woff += wsum[i]; tot += wsum[i]; }
+        int run = run_s;
+        if (flag) b.obs_rows[run + woff + pre] = j;
+        __syncthreads();
+        if (threadIdx.x == 0) run_s = run + tot;
+        __syncthreads();
+    }
+}
+void launch_obs_fill(const Band& b, int F, const int* offsets, hipStream_t s) {
+    int nch = (b.S + kObsChunk - 1) / kObsChunk;
+    if (nch > 0 && F > 0) hipLaunchKernelGGL(k_obs_fill, dim3(nch, F), dim3(kBlock), 0, s, b, F, offsets);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -551,11 +628,11 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
     }
     if (LED_INIT) {
         // 6 sums: observed rgb into SC_AUX0.., rendered into SC_EN/SC_EL/SC_ACCEPT slots (scratch use at init only)
-        block_atomic_add(sI[0], a.acc.scal + SC_AUX0, red); block_atomic_add(sI[1], a.acc.scal + SC_AUX1, red); block_atomic_add(sI[2], a.acc.scal + SC_AUX2, red);
-        block_atomic_add(sR[0], a.acc.scal + SC_EN, red); block_atomic_add(sR[1], a.acc.scal + SC_EL, red); block_atomic_add(sR[2], a.acc.scal + SC_ACCEPT, red);
+        block_part_store(sI[0], PART(a, SC_AUX0), red); block_part_store(sI[1], PART(a, SC_AUX1), red); block_part_store(sI[2], PART(a, SC_AUX2), red);
+        block_part_store(sR[0], PART(a, SC_EN), red); block_part_store(sR[1], PART(a, SC_EL), red); block_part_store(sR[2], PART(a, SC_ACCEPT), red);
     } else {
-        block_atomic_add(E, a.acc.scal + SC_ENERGY, red);
-        block_atomic_add(nobs, a.acc.scal + SC_NOBS, red);
+        block_part_store(E, PART(a, SC_ENERGY), red);
+        block_part_store(nobs, PART(a, SC_NOBS), red);
     }
 }
 void launch_energy(const SweepArgs& a, hipStream_t s) {
@@ -606,8 +683,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) { b.aH[(size_t)ch * b.Spad + j] = (float)Hd[ch]; b.ab[(size_t)ch * b.Spad + j] = (float)bd[ch]; }
     }
-    block_atomic_add(E, a.acc.scal + SC_ENERGY, red);
-    block_atomic_add(nobs, a.acc.scal + SC_NOBS, red);
+    block_part_store(E, PART(a, SC_ENERGY), red);
+    block_part_store(nobs, PART(a, SC_NOBS), red);
 }
 void launch_sweep_albedo(const SweepArgs& a, hipStream_t s) {
     if (a.b.S <= 0) return;
@@ -632,7 +709,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_albedo(SweepArgs a) {
             if (v > 0.0f && v < 1.0f) { b.rho[ch][j] = v; cnt += 1.0; }
         }
     }
-    block_atomic_add(cnt, a.acc.scal + SC_ACCEPT, red);
+    block_part_store(cnt, PART(a, SC_ACCEPT), red);
 }
 void launch_apply_albedo(const SweepArgs& a, hipStream_t s) {
     if (a.b.S > 0) hipLaunchKernelGGL(k_apply_albedo, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
@@ -644,22 +721,6 @@ void launch_apply_albedo(const SweepArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 constexpr int kRowsPerThread = 8;
 constexpr int kChunk = kBlock * kRowsPerThread;
-
-template <int NV>
-__device__ __forceinline__ void block_reduce_store(const float* acc, double* dst, double* lds /*[4][NV]*/) {
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double v = wave_sum((double)acc[k]);
-        if (lane == 0) lds[w * NV + k] = v;
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < NV; k += blockDim.x) {
-        double s = 0;
-        for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + k];
-        if (s != 0.0) atomicAdd(dst + k, s);
-    }
-}
 
 // light normal equations: lightJacobian PsOptimizerJa.cpp:132-143,323-371 (per frame NBxNB),
 // LED LightJacobian LedOptimizerJa.cpp:101-115,299-346 (one global diagonal 3x3)
@@ -680,11 +741,11 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
     float acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.f;
-    const int base = blockIdx.x * kChunk;
+    const int beg = b.obs_ptr[f], end = b.obs_ptr[f + 1];
     for (int it = 0; it < kRowsPerThread; ++it) {
-        int j = base + it * kBlock + threadIdx.x;
-        if (j >= b.S) break;
-        if (!((b.vis[(size_t)(f >> 6) * b.Spad + j] >> (f & 63)) & 1ull)) continue;
+        int e = beg + blockIdx.x * kChunk + it * kBlock + threadIdx.x;
+        if (e >= end) break;
+        const int j = b.obs_rows[e];
         Vox v; load_vox(b, j, v);
         Proj pr = project(v.xs, fp, a.cam);
         if (!pr.ok) continue;
@@ -719,8 +780,9 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
         }
         acc[NH + NB] += l; acc[NH + NB + 1] += 1.0f;
     }
-    // energy / n_obs go to the scalar block, the rest to this frame's accumulator row
-    double* dst = a.acc.frame + (size_t)(LED ? 0 : f) * (NH + NB);
+    // one atomic per value per workgroup into THIS frame's row (<= S/2048 workgroups contend per address);
+    // row layout: [NH H entries | NB rhs | energy | n_obs]
+    double* dst = a.acc.frame + (size_t)f * kFrameRow;
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }
@@ -728,12 +790,12 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
     for (int k = threadIdx.x; k < NV; k += blockDim.x) {
         double s = 0;
         for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + k];
-        if (s != 0.0) atomicAdd(k < NH + NB ? dst + k : a.acc.scal + (k == NH + NB ? SC_ENERGY : SC_NOBS), s);
+        if (s != 0.0) atomicAdd(dst + k, s);
     }
 }
 void launch_sweep_light(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S <= 0 || a.F <= 0) return;
-    dim3 g((a.b.S + kChunk - 1) / kChunk, a.F), bl(kBlock);
+    if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return;
+    dim3 g((a.b.obs_max + kChunk - 1) / kChunk, a.F), bl(kBlock);
     if (a.model == 0) hipLaunchKernelGGL((k_sweep_light<0>), g, bl, 0, s, a);
     else if (a.model == 1) hipLaunchKernelGGL((k_sweep_light<1>), g, bl, 0, s, a);
     else hipLaunchKernelGGL((k_sweep_light<2>), g, bl, 0, s, a);
@@ -741,7 +803,7 @@ void launch_sweep_light(const SweepArgs& a, hipStream_t s) {
 
 // G = image_grad(3x2) * pi_grad(2x3), PsOptimizerJa.cpp:78-90
 __device__ __forceinline__ void image_pi_grad(const Cam& cam, const Proj& pr, const float* gu, const float* gv, float* G) {
-    float z_inv = (float)(1.0 / (double)pr.p[2]);
+    const float z_inv = pr.z_inv;
     float z_inv_sq = z_inv * z_inv;
     float p00 = cam.fx * z_inv, p02 = -cam.fx * pr.p[0] * z_inv_sq, p11 = cam.fy * z_inv, p12 = -cam.fy * pr.p[1] * z_inv_sq;
 #pragma unroll
@@ -769,11 +831,11 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
     float acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.f;
-    const int base = blockIdx.x * kChunk;
+    const int beg = b.obs_ptr[f], end = b.obs_ptr[f + 1];
     for (int it = 0; it < kRowsPerThread; ++it) {
-        int j = base + it * kBlock + threadIdx.x;
-        if (j >= b.S) break;
-        if (!((b.vis[(size_t)(f >> 6) * b.Spad + j] >> (f & 63)) & 1ull)) continue;
+        int e = beg + blockIdx.x * kChunk + it * kBlock + threadIdx.x;
+        if (e >= end) break;
+        const int j = b.obs_rows[e];
         Vox v; load_vox(b, j, v);
         Proj pr = project(v.xs, fp, a.cam);
         if (!pr.ok) continue;
@@ -822,7 +884,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
         }
         acc[27] += l; acc[28] += 1.0f;
     }
-    double* dst = a.acc.frame + (size_t)f * 27;
+    double* dst = a.acc.frame + (size_t)f * kFrameRow;   // [21 H | 6 rhs | energy | n_obs]
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }
@@ -830,12 +892,12 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
     for (int k = threadIdx.x; k < NV; k += blockDim.x) {
         double s = 0;
         for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + k];
-        if (s != 0.0) atomicAdd(k < 27 ? dst + k : a.acc.scal + (k == 27 ? SC_ENERGY : SC_NOBS), s);
+        if (s != 0.0) atomicAdd(dst + k, s);
     }
 }
 void launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S <= 0 || a.F <= 0) return;
-    dim3 g((a.b.S + kChunk - 1) / kChunk, a.F), bl(kBlock);
+    if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return;
+    dim3 g((a.b.obs_max + kChunk - 1) / kChunk, a.F), bl(kBlock);
     if (a.model == 0) hipLaunchKernelGGL((k_sweep_pose<0>), g, bl, 0, s, a);
     else if (a.model == 1) hipLaunchKernelGGL((k_sweep_pose<1>), g, bl, 0, s, a);
     else hipLaunchKernelGGL((k_sweep_pose<2>), g, bl, 0, s, a);
@@ -875,12 +937,13 @@ __global__ void k_solve_light(SweepArgs a, FrameP* frames, float* led_light) {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (LED) {
         if (f >= a.F) return;
-        // every thread solves the same 3 scalar equations and updates its own frame record
-        const double* acc = a.acc.frame;
+        // every thread sums the per-frame rows, solves the same 3 scalar equations and updates its own record
         float nl[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            float h = (float)acc[ch], bb = (float)acc[NH + ch];
+            double hs = 0, bs = 0;
+            for (int ff = 0; ff < a.F; ++ff) { hs += a.acc.frame[(size_t)ff * kFrameRow + ch]; bs += a.acc.frame[(size_t)ff * kFrameRow + NH + ch]; }
+            float h = (float)hs, bb = (float)bs;
             if (a.damping != 0.0f) h += a.damping * h;
             double Hd[1] = {(double)h}, bd[1] = {(double)bb}, xd[1];
             solve_spd<1>(Hd, bd, xd);
@@ -891,7 +954,7 @@ __global__ void k_solve_light(SweepArgs a, FrameP* frames, float* led_light) {
         return;
     } else {
         if (f >= a.F) return;
-        const double* acc = a.acc.frame + (size_t)f * (NH + NB);
+        const double* acc = a.acc.frame + (size_t)f * kFrameRow;
         double Hd[NB * NB], bd[NB], xd[NB];
         int q = 0;
         for (int i = 0; i < NB; ++i) for (int k = i; k < NB; ++k) { double v = (double)(float)acc[q++]; Hd[i * NB + k] = v; Hd[k * NB + i] = v; }
@@ -931,7 +994,7 @@ __device__ void so3_exp(const float* w, float* R) {
 __global__ void k_solve_pose(SweepArgs a, FrameP* frames) {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= a.F) return;
-    const double* acc = a.acc.frame + (size_t)f * 27;
+    const double* acc = a.acc.frame + (size_t)f * kFrameRow;
     double Hd[36], bd[6], xd[6];
     int q = 0;
     for (int i = 0; i < 6; ++i) for (int k = i; k < 6; ++k) {
@@ -1135,8 +1198,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) b.blk[(size_t)(10 + p) * b.Spad + j] = exists[p] ? (float)g[p] : 0.f;
     }
-    block_atomic_add(E, a.acc.scal + SC_ENERGY, red);
-    block_atomic_add(nobs, a.acc.scal + SC_NOBS, red);
+    block_part_store(E, PART(a, SC_ENERGY), red);
+    block_part_store(nobs, PART(a, SC_NOBS), red);
 }
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
     if (a.b.S <= 0) return;
@@ -1180,8 +1243,10 @@ __global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
             if (val != 0.f) acc[q_of(o)][tid] += (double)val;
         }
     }
+    int extra = 0;
 #pragma unroll
-    for (int q = 0; q < kNQ; ++q) b.H[(size_t)q * b.Spad + i] = (float)acc[q][tid];
+    for (int q = 0; q < kNQ; ++q) { float h = (float)acc[q][tid]; b.H[(size_t)q * b.Spad + i] = h; if (q >= kNQCommon && h != 0.f) extra = 1; }
+    b.hx[i] = extra;
     b.rhs[i] = (float)rhs;
 }
 void launch_assemble(const SweepArgs& a, hipStream_t s) {
@@ -1189,93 +1254,145 @@ void launch_assemble(const SweepArgs& a, hipStream_t s) {
 }
 
 // Jacobi-PCG with Eigen::ConjugateGradient semantics: x0 = 0, threshold = max(eps^2 |b|^2, FLT_MIN),
-// scalar recurrences in float, dot products accumulated in double.  Two kernels per iteration.
-__global__ void __launch_bounds__(kBlock) k_pcg_init(SweepArgs a, double* sc) {
+// scalar recurrences in float, dot products accumulated in double.  Two kernels per iteration, each a grid-stride
+// pass of G <= kPcgMaxBlocks workgroups.  Dot products: every workgroup stores ONE partial; the consumer kernel sums
+// the G partials in a fixed order in every workgroup (deterministic, no atomics) and workgroup 0 publishes the
+// scalar to `sc` for the host and for later kernels.
+//   sc[0] = |b|^2, sc[1] = r0.z0, then per iteration k: sc[4+3k] = p.t, sc[5+3k] = |r|^2, sc[6+3k] = r.z
+//   part layout: [parity 2][kind 3: p.t, |r|^2, r.z][kPcgMaxBlocks]; the init partials use parity 1 kinds 1,2 (= "iteration -1")
+__device__ __forceinline__ double* pcg_part(double* part, int k, int kind) { return part + ((size_t)((k & 1) * 3 + kind)) * kPcgMaxBlocks; }
+
+__global__ void __launch_bounds__(kBlock) k_pcg_init(SweepArgs a, double* sc, double* part) {
     __shared__ double red[kBlock / 64];
     const Band& b = a.b;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
     double bb = 0, rz = 0;
-    if (i < b.S) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b.S; i += gridDim.x * blockDim.x) {
         float dg = b.H[i];
         if (a.damping != 0.0f) dg += a.damping * dg;
         float inv = dg != 0.f ? 1.0f / dg : 1.0f;
         float r = b.rhs[i];
         float z = inv * r;
-        b.inv[i] = inv; b.x[i] = 0.f; b.r[i] = r; b.z[i] = z; b.p[0][i] = 0.f; b.p[1][i] = 0.f;
-        bb = (double)r * (double)r; rz = (double)r * (double)z;
+        b.inv[i] = inv; b.x[i] = 0.f; b.r[i] = r; b.zp[i] = make_float2(z, 0.f); b.p[i] = 0.f;
+        bb += (double)r * (double)r; rz += (double)r * (double)z;
     }
-    block_atomic_add(bb, sc + 0, red);
-    block_atomic_add(rz, sc + 1, red);
+    block_part_store(bb, pcg_part(part, -1, 1), red);
+    block_part_store(rz, pcg_part(part, -1, 2), red);
 }
-void launch_pcg_init(const SweepArgs& a, double* sc, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_init, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, sc);
+void launch_pcg_init(const SweepArgs& a, double* sc, double* part, int G, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_init, dim3(G), dim3(kBlock), 0, s, a, sc, part);
 }
-__device__ __forceinline__ bool pcg_done(const double* sc, int k) {
-    float rhsNorm2 = (float)sc[0];
-    if (rhsNorm2 == 0.f) return true;
-    if (k == 0) return false;
-    float threshold = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsNorm2, FLT_MIN);
-    return (float)sc[kPcgScalHead + 3 * (k - 1) + 1] < threshold;
+__device__ __forceinline__ float pcg_threshold(float rhsNorm2) { return fmaxf(FLT_EPSILON * FLT_EPSILON * rhsNorm2, FLT_MIN); }
+
+// sum of two partial arrays at once (one pair of barriers), identical in every thread of every block
+__device__ __forceinline__ void block_total2(const double* p1, const double* p2, int n, double* red /*[2*kBlock/64]*/, double& s1, double& s2) {
+    double v1 = 0, v2 = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { v1 += p1[i]; v2 += p2[i]; }
+    v1 = wave_sum(v1); v2 = wave_sum(v2);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * w] = v1; red[2 * w + 1] = v2; }
+    __syncthreads();
+    s1 = 0; s2 = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { s1 += red[2 * i]; s2 += red[2 * i + 1]; }
 }
-// p_k = z + beta p_{k-1} (recomputed for every gathered column), t = A p_k, p.t partial
-__global__ void __launch_bounds__(kBlock) k_pcg_mv(SweepArgs a, double* sc, int k, int with_damping) {
-    __shared__ double red[kBlock / 64];
-    if (pcg_done(sc, k)) return;
+// p_k = z + beta p_{k-1} (recomputed for every gathered column from the {z,p} pair), t = A p_k, partial p.t
+__global__ void __launch_bounds__(kBlock) k_pcg_mv(SweepArgs a, double* sc, double* part, int k, int with_damping) {
+    __shared__ double red[2 * kBlock / 64];
     const Band& b = a.b;
+    // reduce what the previous kernel produced: |r|^2 and r.z of iteration k-1 (k = 0: |b|^2 and r0.z0)
+    double s1, s2;
+    block_total2(pcg_part(part, k - 1, 1), pcg_part(part, k - 1, 2), gridDim.x, red, s1, s2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (k == 0) { sc[0] = s1; sc[1] = s2; } else { sc[kPcgScalHead + 3 * (k - 1) + 1] = s1; sc[kPcgScalHead + 3 * (k - 1) + 2] = s2; }
+    }
+    const float rhsNorm2 = (float)(k == 0 ? s1 : sc[0]);
+    if (rhsNorm2 == 0.f) return;
+    if (k > 0 && (float)s1 < pcg_threshold(rhsNorm2)) return;   // converged in pass k-1
     float beta = 0.f;
     if (k > 0) {
-        float absNew = (float)sc[kPcgScalHead + 3 * (k - 1) + 2];
+        float absNew = (float)s2;
         float absOld = (float)(k == 1 ? sc[1] : sc[kPcgScalHead + 3 * (k - 2) + 2]);
         beta = absNew / absOld;
     }
-    const float* pold = b.p[(k + 1) & 1];
-    float* pnew = b.p[k & 1];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
     double pt = 0;
-    if (i < b.S) {
-        double acc = 0;
-        float pi = 0.f;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < b.S; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        const bool live = i < b.S;
+        const int ii = live ? i : b.S - 1;
+        // 13 common columns: coefficient, column and gather loads are all independent of each other
+        float h[kNQCommon]; int c[kNQCommon];
 #pragma unroll
-        for (int q = 0; q < kNQ; ++q) {
-            float h = b.H[(size_t)q * b.Spad + i];
-            int c = q == 0 ? i : b.col[(size_t)q * b.Spad + i];
-            if (q == 0 && with_damping && a.damping != 0.0f) h += a.damping * h;
-            if (c < 0) continue;
-            float pc = b.z[c] + beta * pold[c];
+        for (int q = 0; q < kNQCommon; ++q) { h[q] = b.H[(size_t)q * b.Spad + ii]; c[q] = q == 0 ? ii : b.col[(size_t)q * b.Spad + ii]; }
+        if (with_damping && a.damping != 0.0f) h[0] += a.damping * h[0];
+        double acc = 0; float pi = 0.f;
+#pragma unroll
+        for (int q = 0; q < kNQCommon; ++q) {
+            const float2 zpc = b.zp[c[q]];
+            const float pc = zpc.x + beta * zpc.y;
             if (q == 0) pi = pc;
-            acc += (double)h * (double)pc;
+            acc += (double)h[q] * (double)pc;
         }
-        float t = (float)acc;
-        pnew[i] = pi; b.t[i] = t;
-        pt = (double)pi * (double)t;
+        // the 6 rare columns exist only next to backward-forced stencils: wave-uniform skip
+        if (__any(live && b.hx[ii])) {
+#pragma unroll
+            for (int q = kNQCommon; q < kNQ; ++q) {
+                const float hq = b.H[(size_t)q * b.Spad + ii];
+                const float2 zpc = b.zp[b.col[(size_t)q * b.Spad + ii]];
+                acc += (double)hq * (double)(zpc.x + beta * zpc.y);
+            }
+        }
+        if (live) {
+            float t = (float)acc;
+            b.p[i] = pi; b.t[i] = t;
+            pt += (double)pi * (double)t;
+        }
     }
-    block_atomic_add(pt, sc + kPcgScalHead + 3 * k + 0, red);
+    block_part_store(pt, pcg_part(part, k, 0), red);
 }
-void launch_pcg_mv(const SweepArgs& a, double* sc, int k, int with_damping, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_mv, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, sc, k, with_damping);
+void launch_pcg_mv(const SweepArgs& a, double* sc, double* part, int G, int k, int with_damping, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_mv, dim3(G), dim3(kBlock), 0, s, a, sc, part, k, with_damping);
 }
 // x += alpha p ; r -= alpha t ; z = M^-1 r ; partial |r|^2 and r.z
-__global__ void __launch_bounds__(kBlock) k_pcg_upd(SweepArgs a, double* sc, int k) {
+__global__ void __launch_bounds__(kBlock) k_pcg_upd(SweepArgs a, double* sc, double* part, int k) {
     __shared__ double red[kBlock / 64];
-    if (pcg_done(sc, k)) return;
     const Band& b = a.b;
+    const float rhsNorm2 = (float)sc[0];
+    bool done = rhsNorm2 == 0.f || (k > 0 && (float)sc[kPcgScalHead + 3 * (k - 1) + 1] < pcg_threshold(rhsNorm2));
+    if (done) {   // keep the partials of this (skipped) pass at zero so that later passes stay skipped
+        if (threadIdx.x == 0) { pcg_part(part, k, 1)[blockIdx.x] = 0.0; pcg_part(part, k, 2)[blockIdx.x] = 0.0; }
+        return;
+    }
+    const double ptot = block_total(pcg_part(part, k, 0), gridDim.x, red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[kPcgScalHead + 3 * k + 0] = ptot;
     float absNew = (float)(k == 0 ? sc[1] : sc[kPcgScalHead + 3 * (k - 1) + 2]);
-    float alpha = absNew / (float)sc[kPcgScalHead + 3 * k + 0];
-    const float* p = b.p[k & 1];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float alpha = absNew / (float)ptot;
     double rr = 0, rz = 0;
-    if (i < b.S) {
-        float x = b.x[i] + alpha * p[i];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b.S; i += gridDim.x * blockDim.x) {
+        const float pi = b.p[i];
+        float x = b.x[i] + alpha * pi;
         float r = b.r[i] - alpha * b.t[i];
         float z = b.inv[i] * r;
-        b.x[i] = x; b.r[i] = r; b.z[i] = z;
-        rr = (double)r * (double)r; rz = (double)r * (double)z;
+        b.x[i] = x; b.r[i] = r; b.zp[i] = make_float2(z, pi);
+        rr += (double)r * (double)r; rz += (double)r * (double)z;
     }
-    block_atomic_add(rr, sc + kPcgScalHead + 3 * k + 1, red);
-    block_atomic_add(rz, sc + kPcgScalHead + 3 * k + 2, red);
+    block_part_store(rr, pcg_part(part, k, 1), red);
+    block_part_store(rz, pcg_part(part, k, 2), red);
 }
-void launch_pcg_upd(const SweepArgs& a, double* sc, int k, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_upd, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, sc, k);
+void launch_pcg_upd(const SweepArgs& a, double* sc, double* part, int G, int k, hipStream_t s) {
+    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_upd, dim3(G), dim3(kBlock), 0, s, a, sc, part, k);
+}
+// publish |r|^2 and r.z of pass k (end of a chunk: the host has to see them)
+__global__ void __launch_bounds__(kBlock) k_pcg_final(double* sc, double* part, int G, int k) {
+    __shared__ double red[kBlock / 64];
+    const double s1 = block_total(pcg_part(part, k, 1), G, red);
+    const double s2 = block_total(pcg_part(part, k, 2), G, red);
+    if (threadIdx.x == 0) {
+        float rhsNorm2 = (float)sc[0];
+        bool prev_done = rhsNorm2 == 0.f || (k > 0 && (float)sc[kPcgScalHead + 3 * (k - 1) + 1] < pcg_threshold(rhsNorm2));
+        if (!prev_done) { sc[kPcgScalHead + 3 * k + 1] = s1; sc[kPcgScalHead + 3 * k + 2] = s2; }
+    }
+}
+void launch_pcg_final(double* sc, double* part, int G, int k, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_final, dim3(1), dim3(kBlock), 0, s, sc, part, G, k);
 }
 // debug: y = H x without damping
 __global__ void __launch_bounds__(kBlock) k_matvec(SweepArgs a, const float* x, float* y) {
@@ -1303,7 +1420,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_dist(SweepArgs a) {
         float d = b.x[j];
         if ((double)fabsf(d) < sqrt(3.0) * (double)a.grid.vs) { b.dist[j] -= d; cnt = 1.0; }
     }
-    block_atomic_add(cnt, a.acc.scal + SC_ACCEPT, red);
+    block_part_store(cnt, PART(a, SC_ACCEPT), red);
 }
 void launch_apply_dist(const SweepArgs& a, hipStream_t s) {
     if (a.b.S > 0) hipLaunchKernelGGL(k_apply_dist, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
