@@ -7,6 +7,7 @@
 #include <float.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -252,7 +253,9 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
     if (cap > c->pcg_cap) cap = c->pcg_cap;
     // balanced grid-stride: the fewest equal passes that fit kPcgMaxBlocks workgroups
     const int nblk = std::max(1, band_blocks(c));
-    const int passes = (nblk + kPcgMaxBlocks - 1) / kPcgMaxBlocks;
+    int maxb = 704;   // ~2 rows per thread at the 256^3 band size measured best (profiles/r01_notes.md)
+    if (const char* e = getenv("PSGSDF_PCG_BLOCKS")) { int v = atoi(e); if (v > 0 && v <= kPcgMaxBlocks) maxb = v; }   // tuning knob
+    const int passes = (nblk + maxb - 1) / maxb;
     const int G = (nblk + passes - 1) / passes;
     HIPCHK(c, hipMemsetAsync(c->pcg_sc, 0, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap), c->stream));
     timed(c, "pcg_init", [&] { launch_pcg_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });

@@ -604,6 +604,7 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
     const Band& b = a.b;
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     double E = 0, nobs = 0, sI[3] = {0, 0, 0}, sR[3] = {0, 0, 0};
+    float Ef = 0.f;
     if (j < b.S) {
         Vox v; load_vox(b, j, v);
         float shfd[kMaxBasis];
@@ -622,10 +623,11 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
                 float l = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) l += robust_loss(a.rob, I[ch] - ren[ch]);
-                E += (double)l; nobs += 1.0;
+                Ef += l; nobs += 1.0;
             }
         }
     }
+    E = (double)Ef;
     if (LED_INIT) {
         // 6 sums: observed rgb into SC_AUX0.., rendered into SC_EN/SC_EL/SC_ACCEPT slots (scratch use at init only)
         block_part_store(sI[0], PART(a, SC_AUX0), red); block_part_store(sI[1], PART(a, SC_AUX1), red); block_part_store(sI[2], PART(a, SC_AUX2), red);
@@ -661,7 +663,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
         Vox v; load_vox(b, j, v);
         float shfd[kMaxBasis], shg[kMaxBasis];
         if (!ModelTraits<MODEL>::LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
-        double Hd[3] = {0, 0, 0}, bd[3] = {0, 0, 0};
+        float Hd[3] = {0, 0, 0}, bd[3] = {0, 0, 0};
+        float Ef = 0.f; int nobs_i = 0;
         FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
             const FrameP& fp = sf[f];
             Proj pr = project(v.xs, fp, a.cam);
@@ -675,13 +678,14 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
             for (int ch = 0; ch < 3; ++ch) {
                 float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
                 float jw = J[ch] * w;
-                Hd[ch] += (double)(jw * J[ch]); bd[ch] += (double)(jw * r);
+                Hd[ch] += jw * J[ch]; bd[ch] += jw * r;
                 l += robust_loss(a.rob, r);
             }
-            E += (double)l; nobs += 1.0;
+            Ef += l; nobs_i += 1;
         }
+        E = (double)Ef; nobs = (double)nobs_i;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) { b.aH[(size_t)ch * b.Spad + j] = (float)Hd[ch]; b.ab[(size_t)ch * b.Spad + j] = (float)bd[ch]; }
+        for (int ch = 0; ch < 3; ++ch) { b.aH[(size_t)ch * b.Spad + j] = Hd[ch]; b.ab[(size_t)ch * b.Spad + j] = bd[ch]; }
     }
     block_part_store(E, PART(a, SC_ENERGY), red);
     block_part_store(nobs, PART(a, SC_NOBS), red);
@@ -719,7 +723,7 @@ void launch_apply_albedo(const SweepArgs& a, hipStream_t s) {
 // frame-major sweeps: grid = (row chunks, F); per-thread accumulation over several voxels of ONE
 // frame, then wavefront shuffle reduction -> LDS -> one double atomic per value per workgroup
 // ------------------------------------------------------------------------------------------
-constexpr int kRowsPerThread = 8;
+constexpr int kRowsPerThread = 16;
 constexpr int kChunk = kBlock * kRowsPerThread;
 
 // light normal equations: lightJacobian PsOptimizerJa.cpp:132-143,323-371 (per frame NBxNB),
@@ -785,7 +789,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
     double* dst = a.acc.frame + (size_t)f * kFrameRow;
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }
+    for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }   // double: SH2 light blocks are ill-conditioned
     __syncthreads();
     for (int k = threadIdx.x; k < NV; k += blockDim.x) {
         double s = 0;
@@ -887,7 +891,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
     double* dst = a.acc.frame + (size_t)f * kFrameRow;   // [21 H | 6 rhs | energy | n_obs]
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }
+    for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }   // double: SH2 light blocks are ill-conditioned
     __syncthreads();
     for (int k = threadIdx.x; k < NV; k += blockDim.x) {
         double s = 0;
@@ -1087,7 +1091,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) { Dm[0][i] = D0[i]; Dm[1][i] = D1[i]; Dm[2][i] = D2[i]; }
         }
-        double B[10], g[4];
+        float B[10], g[4];   // <= F terms each: float accumulation (oracle: double) differs ~1e-7 relative
+        float Ef = 0.f; int nobs_i = 0;
 #pragma unroll
         for (int i = 0; i < 10; ++i) B[i] = 0;
 #pragma unroll
@@ -1158,12 +1163,13 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
                 for (int p = 0; p < 4; ++p) {
                     float jw = J[p][ch] * w;
 #pragma unroll
-                    for (int k = p; k < 4; ++k) B[q++] += (double)(jw * J[k][ch]);
-                    g[p] += (double)(jw * r);
+                    for (int k = p; k < 4; ++k) B[q++] += jw * J[k][ch];
+                    g[p] += jw * r;
                 }
             }
-            E += (double)l; nobs += 1.0;
+            Ef += l; nobs_i += 1;
         }
+        E = (double)Ef; nobs = (double)nobs_i;
         if (a.normal_reg) {   // Eikonal row, Optimizer.cpp:196-218 + residual :509
             float n_d[3] = {-vs_inv * dir[0], -vs_inv * dir[1], -vs_inv * dir[2]};
             float Jr[4];
@@ -1180,23 +1186,23 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
 #pragma unroll
-                for (int k = p; k < 4; ++k) B[q++] += (double)(a.reg_n * (Jr[p] * Jr[k]));
-                g[p] += (double)(a.reg_n * (Jr[p] * res));
+                for (int k = p; k < 4; ++k) B[q++] += a.reg_n * (Jr[p] * Jr[k]);
+                g[p] += a.reg_n * (Jr[p] * res);
             }
         }
         if (a.laplacian_reg) {   // diagonal only (reference drops the off-diagonals), Optimizer.cpp:540-590
             float vs2 = vs_inv * vs_inv; float Jl = -6 * vs2; float res = laplacian(b, j, vs_inv);
-            B[0] += (double)(a.reg_l * (Jl * Jl)); g[0] += (double)(a.reg_l * (Jl * res));
+            B[0] += a.reg_l * (Jl * Jl); g[0] += a.reg_l * (Jl * res);
         }
         // columns whose stencil neighbour is outside the band are dropped (PsOptimizerJa.cpp:536-552)
         int q = 0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
 #pragma unroll
-            for (int k = p; k < 4; ++k) { b.blk[(size_t)q * b.Spad + j] = (exists[p] && exists[k]) ? (float)B[q] : 0.f; ++q; }
+            for (int k = p; k < 4; ++k) { b.blk[(size_t)q * b.Spad + j] = (exists[p] && exists[k]) ? B[q] : 0.f; ++q; }
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) b.blk[(size_t)(10 + p) * b.Spad + j] = exists[p] ? (float)g[p] : 0.f;
+        for (int p = 0; p < 4; ++p) b.blk[(size_t)(10 + p) * b.Spad + j] = exists[p] ? g[p] : 0.f;
     }
     block_part_store(E, PART(a, SC_ENERGY), red);
     block_part_store(nobs, PART(a, SC_NOBS), red);

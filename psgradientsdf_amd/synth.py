@@ -195,6 +195,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
     grad = np.zeros((3, nvox), np.float32)
     weight = np.zeros(nvox, np.float32)
     rgb = np.zeros((3, nvox), np.float32)
+    albedo_gt = np.zeros((3, nvox), np.float32)   # true albedo at the surface point of every near-surface voxel
     wpv = (F + 63) // 64
     vis = np.zeros((nvox, wpv), np.uint64)
     # process z-planes in chunks to bound memory
@@ -241,6 +242,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         weight[g] = cnt
         grad[:, g] = (nrm[nidx] * np.maximum(cnt, 1)[:, None]).T
         rgb[:, g] = (colsum / np.maximum(cnt, 1)[:, None]).T
+        albedo_gt[:, g] = _albedo(xs, shift, extent).T
         vis[g] = vbits
 
     poses_used = poses.copy()
@@ -259,7 +261,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         N=N, F=F, W=W, H=H, model=model, model_id=MODELS[model], dim=dim, voxel_size=np.float32(vs),
         shift=shift.astype(np.float32), truncation=np.float32(T), K=K,
         dist=dist, grad=np.ascontiguousarray(grad), weight=weight, rgb=np.ascontiguousarray(rgb),
-        vis=np.ascontiguousarray(vis), vis_words=wpv,
+        vis=np.ascontiguousarray(vis), vis_words=wpv, albedo_gt=albedo_gt,
         images=np.ascontiguousarray(images.astype(np.float32)),
         poses=np.ascontiguousarray(poses_used.reshape(F, 16).astype(np.float32)),
         poses_gt=poses.reshape(F, 16).astype(np.float32),

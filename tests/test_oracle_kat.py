@@ -61,7 +61,7 @@ def test_dist_jacobian_numeric(model, quirks):
     o.update_grad()
     band = o.download_band()
     vs = float(sc.voxel_size)
-    h = 0.02 * vs
+    h = 0.003 * vs   # small enough that the bilinear sample stays inside one pixel cell
     checked = 0
     for j, f in visible_obs(o, 30):
         ok, J, rows = o.probe_dist_jacobian(j, f)
@@ -82,7 +82,7 @@ def test_dist_jacobian_numeric(model, quirks):
                 continue
             num = (res[0] - res[1]) / (2 * h)
             scale = max(np.abs(J).max(), 1e-3)
-            assert np.abs(num - J[k]).max() <= 0.05 * scale + 2e-2, (model, j, f, k, num, J[k])
+            assert np.abs(num - J[k]).max() <= 0.02 * scale + 1e-2, (model, j, f, k, num, J[k])
             checked += 1
     assert checked >= 20
 
@@ -175,20 +175,27 @@ def test_so3_exp():
         assert np.allclose(oracle.so3_exp(w), Rotation.from_rotvec(w).as_matrix(), atol=2e-6)
 
 
+def _gt_energy(model, N, W, H):
+    sc = synth.make_scene(N=N, F=5, W=W, H=H, model=model, noise=False, perturb=False)
+    o = oracle.Oracle(sc, sc.K, capi.default_settings(synth.MODELS[model]))
+    # ground truth everywhere: analytic distances, true albedo, true light, FD normals of the analytic field
+    o.upload_volume(sc.dist, sc.grad, sc.weight, sc.albedo_gt, sc.vis, sc.vis_words)
+    o.set_keyframes(sc.frame_idx, sc.images, sc.poses)
+    o.init()
+    o.update_grad()
+    o.upload_light(sc.light_gt)
+    return o.energy()[0]
+
+
 @pytest.mark.parametrize("model", ["SH1", "SH2", "LED"])
 def test_ground_truth_has_small_residual_and_blocks_descend(model):
-    sc = synth.make_scene(N=32, F=5, W=128, H=96, model=model, noise=False, perturb=False)
-    st = capi.default_settings(synth.MODELS[model])
-    o = oracle.Oracle(sc, sc.K, st); o.load_scene(sc)
-    o.update_grad()                      # FD normals of the analytic distance field
-    o.upload_light(sc.light_gt)
-    o.init_albedo()
-    e_gt = o.energy()[0]
-    # perturbed scene, default light: every block must lower (or keep) the PS energy, and GT must be far better
+    """Forward-model KAT: images rendered with the model the optimiser inverts, so at ground truth the PS energy
+    is only discretisation error -- far below the perturbed start and shrinking with resolution."""
+    e32, e64 = _gt_energy(model, 32, 128, 96), _gt_energy(model, 64, 256, 192)
     sc2, o2 = make(model)
     o2.init_albedo(); o2.normalize_weights()
     e0 = o2.energy()[0]
-    assert e_gt < 0.2 * e0, (e_gt, e0)
+    assert e64 < e32 < (0.3 if model == "LED" else 0.2) * e0, (e32, e64, e0)
     prev = e0
     order = [capi.LIGHT, capi.ALBEDO, capi.POSE] if model == "LED" else [capi.ALBEDO, capi.LIGHT, capi.POSE]
     for blk in order:

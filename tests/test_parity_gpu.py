@@ -12,6 +12,10 @@ from psgradientsdf_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 MODELS = [("SH1", capi.SH1), ("SH2", capi.SH2), ("LED", capi.LED)]
+# The reference stores the per-frame light normal equations in float32 (Eigen::SparseMatrix<float>), so the light
+# step is only determined to cond(H_f) * eps_f32.  SH1 blocks have cond ~1e2, SH2 9x9 blocks ~2e4 on these scenes
+# (printed by the diagnosis in profiles/r01_notes.md): 2e4 * 6e-8 * a small factor.
+LIGHT_RTOL = {"SH1": 1e-4, "SH2": 5e-3, "LED": 1e-4}
 
 
 def make_pair(model_name, model_id, N=48, F=6, **kw):
@@ -76,7 +80,7 @@ def test_substeps(built, name, mid):
         assert np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max() <= 1e-4, blk
         assert np.abs(ve["grad"][:, band] - vo["grad"][:, band]).max() <= 2e-4, blk
         assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 1e-5, blk
-        assert relmax(eng.download_light(), orc.download_light()) <= 1e-4, blk
+        assert relmax(eng.download_light(), orc.download_light()) <= LIGHT_RTOL[name], blk
 
 
 @pytest.mark.parametrize("name,mid", MODELS)
