@@ -1,0 +1,259 @@
+// ps_optimizer.hpp — C++ mirror of the reference's optimiser interface over the C ABI (include/psgsdf.h).
+//
+// Same class / member names, argument meaning and return conventions as
+//   ps_optimizer/Optimizer.h:24-182, PsOptimizer.h, LedOptimizer.h, OptimizerSettings.h:24-51
+// so that main_ps.cpp:193-202,323-330 reads the same against this header.  The reference's Eigen / OpenCV
+// types are replaced by plain structs (none of those libraries is a dependency of this project):
+//   Eigen::Matrix4f  -> Mat4f   (row-major 16 floats)        cv::Mat (CV_32FC3, BGR) -> ImageRGB (float RGB)
+//   VolumetricGradSdf -> VolumetricGradSdf below: the SoA form of its private tsdf_/vis_ arrays, which the
+//   reference's optimisers reach through `friend` access (VolumetricGradSdf.h:25-42).
+// All numerical work happens in libpsgsdf.so on the GPU; this header only marshals and writes the text files
+// the reference writes from inside alternatingOptimize (optimizer_doc.txt, after_poses_opt_<k>.txt,
+// *_pointcloud.ply).  Mesh extraction (marching cubes) is a SURVEY §8f "next" row and not part of it.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/psgsdf.h"
+
+namespace psgsdf_host {
+
+using Mat4f = std::array<float, 16>;                 // row-major camera->world
+struct Mat3f { float v[9]; };                        // row-major intrinsics
+struct ImageRGB { int rows = 0, cols = 0; std::vector<float> data; };   // rows*cols*3, RGB in [0,1]
+
+enum LossFunction { L2 = 0, CAUCHY = 1, HUBER = 2, TUKEY = 3, TRUNC_L2 = 4 };   // OptimizerSettings.h:9-16
+enum ModelType { SH1, SH2, LED };                                               // OptimizerSettings.h:18-22
+
+struct OptimizerSettings {                           // OptimizerSettings.h:24-51 (same defaults)
+    int max_it = 100;
+    float conv_threshold = 1e-4f;
+    float damping = 1.0f;
+    float lambda = 0.5f;
+    float lambda_sq = 0.25f;
+    float reg_weight_rho = 0.0f, reg_weight_n = 0.0f, reg_weight_l = 0.0f;
+    int order = 1;
+    bool upsample = false;
+    ModelType model = SH1;
+    LossFunction loss = CAUCHY;
+};
+
+// SoA image of VolumetricGradSdf's state (x-fastest, VoxelGrid.h:79-82)
+struct VolumetricGradSdf {
+    int grid_dim_[3] = {0, 0, 0};
+    float voxel_size_ = 0, T_ = 0;
+    float shift_[3] = {0, 0, 0};
+    std::vector<float> dist, grad, weight, rgb;      // N, 3N (x|y|z), N, 3N (r|g|b)
+    std::vector<uint64_t> vis; int vis_words = 1;    // N*vis_words, bit c = seen by integrated frame c
+    size_t num_voxels() const { return (size_t)grid_dim_[0] * grid_dim_[1] * grid_dim_[2]; }
+};
+
+class Optimizer {
+protected:
+    VolumetricGradSdf* tSDF_;
+    float voxel_size_;
+    Mat3f K_;
+    std::string save_path_;
+    OptimizerSettings* settings_;
+    std::vector<int> frame_idx_;
+    std::vector<std::shared_ptr<ImageRGB>> images_;
+    std::vector<Mat4f> poses_;
+    std::vector<std::string> key_stamps_;
+    psgsdf_ctx* ctx_ = nullptr;
+    size_t num_frames_ = 0, num_voxels_ = 0;
+    std::ofstream doc_;
+
+    bool fail(const char* what, int rc) {
+        std::cerr << what << " failed (" << rc << "): " << (ctx_ ? psgsdf_last_error(ctx_) : "") << std::endl;
+        return false;
+    }
+    static int on_iter_trampoline(void* user, int iter_done, const psgsdf_iter_stats* rec) { return static_cast<Optimizer*>(user)->on_iter(iter_done, rec); }
+
+    // getTotalEnergy's log line, OptimizerAux.cpp:259-269
+    void log_energy(double E, const psgsdf_iter_stats* r) {
+        double en = r->reg_weight_n * r->e_n, el = r->reg_weight_l * r->e_l;
+        for (std::ostream* o : {static_cast<std::ostream*>(&std::cout), static_cast<std::ostream*>(&doc_)})
+            if (o == &std::cout || doc_.is_open())
+                *o << "PS energy: " << E << "\t normal reg energy: " << en << "\t laplacian reg energy: " << el << "\t rho reg energy: " << 0
+                   << "\t total energy: " << (float)(E + en + el) << std::endl;
+    }
+    // the per-iteration narration of PsOptimizer.cpp:304-366 and the periodic dumps of :419-423
+    int on_iter(int iter_done, const psgsdf_iter_stats* r) {
+        const int iter = iter_done - 1;
+        const bool led = settings_->model == LED;
+        const char* names[4] = {"albedo", "light", "distance", "pose"};
+        const int order_sh[4] = {0, 1, 2, 3}, order_led[4] = {1, 0, 2, 3};
+        for (int q = 0; q < 4; ++q) {
+            int s = led ? order_led[q] : order_sh[q];
+            if (std::isnan(r->e_after[s])) continue;
+            std::cout << "===> [" << iter << "]: after " << names[s] << " optimization: ";
+            if (doc_.is_open()) doc_ << "===> [" << iter << "]: after " << names[s] << " optimization: \n";
+            log_energy(r->e_after[s], r);
+        }
+        std::cout << "===> [" << iter << "]: relative diff " << r->rel_diff << std::endl;
+        if (doc_.is_open()) doc_ << "===> [" << iter << "]: relative diff " << r->rel_diff << "\n";
+        if (iter_done % 3 == 0) {
+            savePoses("after_poses_opt_" + std::to_string(iter_done));
+            save_pointcloud("after_iter_" + std::to_string(iter_done));
+        }
+        return 0;
+    }
+
+public:
+    Optimizer(VolumetricGradSdf* tSDF, const float voxel_size, const Mat3f& K, std::string save_path, OptimizerSettings* settings)
+        : tSDF_(tSDF), voxel_size_(voxel_size), K_(K), save_path_(save_path), settings_(settings) {}
+    virtual ~Optimizer() { if (ctx_) psgsdf_destroy(ctx_); }
+
+    void setImages(std::vector<std::shared_ptr<ImageRGB>> images) { images_ = images; }          // Optimizer.h:137-140
+    void setPoses(std::vector<Mat4f>& pose) { poses_ = pose; }                                    // Optimizer.h:142-145
+    void setKeyframes(std::vector<int>& keyframes) { frame_idx_ = keyframes; }                    // Optimizer.h:147-150
+    void setKeytimestamps(std::vector<std::string>& keystamps) { key_stamps_ = keystamps; }      // Optimizer.h:151-154
+
+    // PsOptimizer::init / LedOptimizer::init (PsOptimizer.cpp:25-42): with zero keyframes (the constructor-time
+    // call of the reference) this is a no-op; with keyframes it creates the device context and uploads everything.
+    virtual void init() {
+        num_frames_ = frame_idx_.size();
+        num_voxels_ = tSDF_->num_voxels();
+        if (num_frames_ == 0) return;
+        if (ctx_) { psgsdf_destroy(ctx_); ctx_ = nullptr; }
+        psgsdf_grid_desc g{};
+        for (int a = 0; a < 3; ++a) { g.dim[a] = tSDF_->grid_dim_[a]; g.shift[a] = tSDF_->shift_[a]; }
+        g.voxel_size = voxel_size_; g.truncation = tSDF_->T_;
+        psgsdf_settings s{};
+        s.model = settings_->model == LED ? PSGSDF_LED : (settings_->model == SH2 ? PSGSDF_SH2 : PSGSDF_SH1);
+        s.loss = (int)settings_->loss; s.lambda = settings_->lambda; s.damping = settings_->damping;
+        s.reg_weight_rho = settings_->reg_weight_rho; s.reg_weight_n = settings_->reg_weight_n; s.reg_weight_l = settings_->reg_weight_l;
+        s.max_it = settings_->max_it; s.conv_threshold = settings_->conv_threshold; s.upsample = settings_->upsample ? 1 : 0;
+        s.ref_quirks = 1; s.cg_max_it = 0;
+        int rc = psgsdf_create(&g, K_.v, &s, 0, &ctx_);
+        if (rc) { fail("psgsdf_create", rc); ctx_ = nullptr; return; }
+        rc = psgsdf_upload_volume(ctx_, tSDF_->dist.data(), tSDF_->grad.data(), tSDF_->weight.data(), tSDF_->rgb.data(), tSDF_->vis.data(), tSDF_->vis_words);
+        if (rc) { fail("psgsdf_upload_volume", rc); return; }
+        const int W = images_[0]->cols, H = images_[0]->rows;
+        std::vector<float> img((size_t)num_frames_ * W * H * 3), P(num_frames_ * 16);
+        for (size_t f = 0; f < num_frames_; ++f) {
+            std::copy(images_[f]->data.begin(), images_[f]->data.end(), img.begin() + f * (size_t)W * H * 3);
+            std::copy(poses_[f].begin(), poses_[f].end(), P.begin() + f * 16);
+        }
+        rc = psgsdf_set_keyframes(ctx_, (int)num_frames_, frame_idx_.data(), img.data(), W, H, P.data());
+        if (rc) { fail("psgsdf_set_keyframes", rc); return; }
+        rc = psgsdf_init(ctx_);
+        if (rc) fail("psgsdf_init", rc);
+    }
+
+    // alternatingOptimize (PsOptimizer.cpp:239-428 / LedOptimizer.cpp:279-478): true = converged
+    virtual bool alternatingOptimize(bool light, bool albedo, bool distance, bool pose) {
+        if (!ctx_) return false;
+        doc_.open((save_path_ + "optimizer_doc.txt").c_str());
+        std::cout << "albation study settings: \n" << "light: " << light << "\n" << "albedo: " << albedo << "\n" << "distance: " << distance << "\n" << "pose: " << pose << std::endl;
+        doc_ << "albation study settings: \t" << "light: " << light << "\t" << "albedo: " << albedo << "\t" << "distance: " << distance << "\t" << "pose: " << pose
+             << "\n" << "num of key frame: " << num_frames_ << " \n total voxels: " << num_voxels_ << "\n";
+        int flags = (albedo ? PSGSDF_ALBEDO : 0) | (light ? PSGSDF_LIGHT : 0) | (distance ? PSGSDF_DIST : 0) | (pose ? PSGSDF_POSE : 0);
+        std::vector<psgsdf_iter_stats> recs(settings_->max_it + 1);
+        int n_done = 0, result = 0;
+        int rc = psgsdf_optimize(ctx_, flags, recs.data(), (int)recs.size(), &n_done, &result, &Optimizer::on_iter_trampoline, this);
+        if (rc) return fail("psgsdf_optimize", rc);
+        if (n_done > 0 && (recs[n_done - 1].converged || recs[n_done - 1].diverged)) {
+            const int iter = n_done - 1;
+            on_iter(n_done, &recs[n_done - 1]);   // the callback is not invoked for the terminating iteration
+            std::cout << "===> [" << iter << "]: " << (result ? "converged!" : "diverged!") << std::endl;
+            doc_ << "===> [" << iter << "]: " << (result ? "converged! \n" : "diverged!\n");
+            save_pointcloud("final_refined");                      // PsOptimizer.cpp:372,379
+        }
+        // the reference mutates the shared settings (B9): report the effective weights back the same way
+        psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
+        settings_->reg_weight_n = info.reg_weight_n; settings_->reg_weight_l = info.reg_weight_l;
+        sync_back();
+        doc_.close();
+        return result != 0;
+    }
+
+    // copy the refined state back into tSDF_ / poses_ (the reference mutates them in place)
+    bool sync_back() {
+        psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
+        size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
+        for (int a = 0; a < 3; ++a) tSDF_->grid_dim_[a] = info.dim[a];
+        tSDF_->voxel_size_ = info.voxel_size; voxel_size_ = info.voxel_size;
+        tSDF_->dist.resize(n); tSDF_->grad.resize(3 * n); tSDF_->weight.resize(n); tSDF_->rgb.resize(3 * n);
+        tSDF_->vis.resize(n * info.vis_words); tSDF_->vis_words = info.vis_words;
+        int rc = psgsdf_download_volume(ctx_, tSDF_->dist.data(), tSDF_->grad.data(), tSDF_->weight.data(), tSDF_->rgb.data(), tSDF_->vis.data());
+        if (rc) return fail("psgsdf_download_volume", rc);
+        std::vector<float> P(num_frames_ * 16);
+        rc = psgsdf_download_poses(ctx_, P.data());
+        if (rc) return fail("psgsdf_download_poses", rc);
+        for (size_t f = 0; f < num_frames_; ++f) std::copy(P.begin() + 16 * f, P.begin() + 16 * f + 16, poses_[f].begin());
+        return true;
+    }
+
+    // savePoses, OptimizerAux.cpp:580-599: "stamp tx ty tz qx qy qz qw" with Eigen's matrix->quaternion conversion
+    bool savePoses(std::string filename) {
+        std::vector<float> P(num_frames_ * 16);
+        if (psgsdf_download_poses(ctx_, P.data())) return false;
+        std::ofstream posefile((save_path_ + filename + ".txt").c_str());
+        if (!posefile.is_open()) { std::cout << "couldn't save optimized poses! " << std::endl; return false; }
+        for (size_t i = 0; i < num_frames_; ++i) {
+            const float* M = &P[16 * i];
+            float q[4];   // x y z w, Eigen::QuaternionBase::operator=(Matrix3)
+            float t = M[0] + M[5] + M[10];
+            if (t > 0) { t = std::sqrt(t + 1.0f); q[3] = 0.5f * t; t = 0.5f / t; q[0] = (M[9] - M[6]) * t; q[1] = (M[2] - M[8]) * t; q[2] = (M[4] - M[1]) * t; }
+            else {
+                int a = 0; if (M[5] > M[0]) a = 1; if (M[10] > M[a * 5]) a = 2;
+                int b = (a + 1) % 3, c = (b + 1) % 3;
+                t = std::sqrt(M[a * 5] - M[b * 5] - M[c * 5] + 1.0f);
+                q[a] = 0.5f * t; t = 0.5f / t;
+                q[3] = (M[c * 4 + b] - M[b * 4 + c]) * t; q[b] = (M[b * 4 + a] + M[a * 4 + b]) * t; q[c] = (M[c * 4 + a] + M[a * 4 + c]) * t;
+            }
+            posefile << (i < key_stamps_.size() ? key_stamps_[i] : std::to_string(i)) << " " << M[3] << " " << M[7] << " " << M[11] << " "
+                     << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << "\n";
+        }
+        return true;
+    }
+
+    // save_pointcloud, OptimizerAux.cpp:456-511 (grid-local coordinates: vox2float, origin not added)
+    bool save_pointcloud(std::string filename) {
+        psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
+        size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
+        std::vector<float> d(n), g(3 * n), rgb(3 * n); std::vector<int32_t> band(info.n_band);
+        if (psgsdf_download_volume(ctx_, d.data(), g.data(), nullptr, rgb.data(), nullptr) || psgsdf_download_band(ctx_, band.data())) return false;
+        std::ofstream ply((save_path_ + filename + "_pointcloud.ply").c_str());
+        if (!ply.is_open()) { std::cout << " can't save point cloud!" << std::endl; return false; }
+        size_t cnt = 0;
+        for (int lin : band) if (std::abs(d[lin]) < std::sqrt(3.0) * info.voxel_size) ++cnt;
+        ply << "ply\nformat ascii 1.0\nelement vertex " << cnt << "\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+            << "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header" << std::endl;
+        const int nx = info.dim[0], nxy = info.dim[0] * info.dim[1];
+        for (int lin : band) {
+            if (!(std::abs(d[lin]) < std::sqrt(3.0) * info.voxel_size)) continue;
+            int k = lin / nxy, rest = lin - k * nxy, j = rest / nx, i = rest - j * nx;
+            float gv[3] = {g[lin], g[n + lin], g[2 * n + lin]};
+            float z = gv[0] * gv[0] + gv[1] * gv[1] + gv[2] * gv[2];
+            if (z > 0) { float s = std::sqrt(z); gv[0] /= s; gv[1] /= s; gv[2] /= s; }
+            float p[3] = {info.voxel_size * i - d[lin] * gv[0], info.voxel_size * j - d[lin] * gv[1], info.voxel_size * k - d[lin] * gv[2]};
+            ply << p[0] << " " << p[1] << " " << p[2] << " " << gv[0] << " " << gv[1] << " " << gv[2] << " "
+                << int(255 * rgb[lin]) << " " << int(255 * rgb[n + lin]) << " " << int(255 * rgb[2 * n + lin]) << std::endl;
+        }
+        return true;
+    }
+
+    psgsdf_ctx* context() { return ctx_; }
+};
+
+// PsOptimizer.h / LedOptimizer.h: the constructor runs init() like the reference (PsOptimizer.cpp:15-23)
+class PsOptimizer : public Optimizer {
+public:
+    PsOptimizer(VolumetricGradSdf* tSDF, const float voxel_size, const Mat3f& K, std::string save_path, OptimizerSettings* settings)
+        : Optimizer(tSDF, voxel_size, K, save_path, settings) { init(); }
+};
+class LedOptimizer : public Optimizer {
+public:
+    LedOptimizer(VolumetricGradSdf* tSDF, const float voxel_size, const Mat3f& K, std::string save_path, OptimizerSettings* settings)
+        : Optimizer(tSDF, voxel_size, K, save_path, settings) { settings_->model = LED; init(); }
+};
+
+}  // namespace psgsdf_host
