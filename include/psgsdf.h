@@ -200,14 +200,37 @@ int psgsdf_download_poses(psgsdf_ctx* ctx, float* poses);
 int psgsdf_download_light(psgsdf_ctx* ctx, float* light);
 int psgsdf_upload_light(psgsdf_ctx* ctx, const float* light);
 
-/* ---- multi-GPU (z-slab partition, one context per rank) -------------------------------- */
+/* ---- multi-GPU (z-slab partition, one context per rank, one process per GPU) -------------- */
 
-/* 128-byte RCCL unique id, generated on rank 0 and broadcast by the host program. */
+/* Attach this context to rank `rank` of `n_ranks` (before psgsdf_init).  The band, sorted by linear index (z
+ * slowest), is cut into n_ranks contiguous row ranges of equal band count, i.e. z-slabs; this context owns one
+ * and computes only there.  `id` is reserved (the collectives run in the host program, see below) and may be NULL. */
 int psgsdf_comm_unique_id(uint8_t id[128]);
-/* Attach this context to rank `rank` of `n_ranks`; must be called before psgsdf_init.
- * The band is then cut into n_ranks z-slabs of (almost) equal band count; this context owns
- * slab `rank` and keeps one halo plane either side. */
 int psgsdf_comm_init(psgsdf_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
+/* run every launch of this context on a caller-owned HIP stream (e.g. torch's current stream) */
+int psgsdf_set_stream(psgsdf_ctx* ctx, void* hip_stream);
+/* out = { S, Spad, row0, row1, halo, F, rank, n_ranks }: owned rows [row0,row1), halo = widest stencil reach in rows;
+ * a rank's halo is the contiguous ranges [row0-halo,row0) and [row1,row1+halo) clipped to [0,S) */
+int psgsdf_mg_info(psgsdf_ctx* ctx, int32_t out[8]);
+/* device pointers of the arrays the host program exchanges between phases */
+enum psgsdf_mg_buf { PSGSDF_MG_BUF_FRAME_ACC = 0, PSGSDF_MG_BUF_SCAL = 1, PSGSDF_MG_BUF_PCG = 2, PSGSDF_MG_BUF_DIST = 3,
+                     PSGSDF_MG_BUF_BLK = 4, PSGSDF_MG_BUF_ZP = 5, PSGSDF_MG_BUF_RHO = 6, PSGSDF_MG_BUF_GRAD = 7 };
+int psgsdf_mg_buffer(psgsdf_ctx* ctx, int which, void** ptr, int64_t* count);
+/* the phases of one Gauss-Newton iteration on the owned rows; what must be exchanged after each is listed in
+ * psgradientsdf_amd/distributed.py, which is the reference host program for them */
+enum psgsdf_mg_phase_id {
+    PSGSDF_MG_ENERGY = 0, PSGSDF_MG_INIT_ALBEDO = 1, PSGSDF_MG_LED_SUMS = 2, PSGSDF_MG_LED_SET = 3,
+    PSGSDF_MG_SWEEP_ALBEDO = 4, PSGSDF_MG_APPLY_ALBEDO = 5, PSGSDF_MG_SWEEP_LIGHT = 6, PSGSDF_MG_SOLVE_LIGHT = 7,
+    PSGSDF_MG_SWEEP_POSE = 8, PSGSDF_MG_SOLVE_POSE = 9, PSGSDF_MG_SWEEP_DIST = 10, PSGSDF_MG_ASSEMBLE = 11,
+    PSGSDF_MG_PCG_INIT = 12, PSGSDF_MG_PCG_MV = 13, PSGSDF_MG_PCG_UPD = 14, PSGSDF_MG_APPLY_DIST = 15,
+    PSGSDF_MG_DERIVE = 16, PSGSDF_MG_SET_REG_SUMS = 17
+};
+int psgsdf_mg_phase(psgsdf_ctx* ctx, int phase, int arg);
+int psgsdf_mg_pcg_status(psgsdf_ctx* ctx, int k0, int n, int32_t* iters, double* err);
+int psgsdf_mg_set_weights(psgsdf_ctx* ctx, float reg_weight_n, float reg_weight_l);
+/* before / after the final all-gather of dist, rho and grad planes (no-ops for the engine) */
+int psgsdf_mg_pack_state(psgsdf_ctx* ctx);
+int psgsdf_mg_unpack_state(psgsdf_ctx* ctx);
 
 /* ---- measurement / test hooks (not part of the reference seam) -------------------------- */
 

@@ -62,6 +62,12 @@ typedef struct orc_ctx {
     int* band;
     int* row_of;
     int inited;
+    /* multi-rank (slab) mode: owned band rows [row0,row1); exchange buffers mirror the engine's layout */
+    int rank, n_ranks, row0, row1, halo, Spad;
+    double* mg_frame; double mg_scal[16]; double mg_ext[4];
+    float *mg_dist, *mg_blk, *mg_zp, *mg_rho, *mg_grad;
+    float *cg_x, *cg_r, *cg_t, *cg_p, *cg_inv; double* cg_sc;
+    void* mg_sys; /* dist_sys* of the current solve */
     int solver_mode; /* 0 = direct per-block solves, 1 = Eigen-style global Jacobi-PCG */
     int threads;
     char err[256];
@@ -297,6 +303,7 @@ static inline float robust_loss(const orc_ctx* c, float r) {
 
 /* ------------------------------------------------------------------ band */
 
+static void mg_setup(orc_ctx* c);
 /* OptimizerAux.cpp:237-257 getSurfaceVoxel */
 static void build_band(orc_ctx* c) {
     free(c->band); free(c->row_of);
@@ -311,6 +318,7 @@ static void build_band(orc_ctx* c) {
     c->S = cnt;
     c->band = (int*)malloc(sizeof(int) * (cnt > 0 ? cnt : 1));
     for (size_t lin = 0; lin < c->nvox; ++lin) if (c->row_of[lin] >= 0) c->band[c->row_of[lin]] = (int)lin;
+    mg_setup(c);
 }
 
 /* Optimizer.cpp:30-47 select_vis: keyframe bit f := sequence bit frame_idx[f] */
@@ -332,7 +340,7 @@ static void select_vis(orc_ctx* c) {
 static double ps_energy(const orc_ctx* c, long long* n_obs_out) {
     double E = 0.0; long long nobs = 0;
 #pragma omp parallel for reduction(+ : E, nobs) schedule(static) num_threads(c->threads)
-    for (int j = 0; j < c->S; ++j) {
+    for (int j = c->row0; j < c->row1; ++j) {
         int lin = c->band[j];
         for (int f = 0; f < c->F; ++f) {
             if (!vis_bit(c, lin, f)) continue;
@@ -351,13 +359,13 @@ static double ps_energy(const orc_ctx* c, long long* n_obs_out) {
 /* Optimizer.cpp:86-103 getNormalEnergy */
 static double normal_energy(const orc_ctx* c) {
     double E = 0.0;
-    for (int j = 0; j < c->S; ++j) { float n[3], d[3]; dist_grad(c, c->band[j], n, d); float e = norm3(n) - 1; E += (double)(e * e); }
+    for (int j = c->row0; j < c->row1; ++j) { float n[3], d[3]; dist_grad(c, c->band[j], n, d); float e = norm3(n) - 1; E += (double)(e * e); }
     return c->S ? E / (double)c->S : 0.0;
 }
 /* Optimizer.cpp:106-119 getLaplacianEnergy */
 static double laplacian_energy(const orc_ctx* c) {
     double E = 0.0;
-    for (int j = 0; j < c->S; ++j) { float e = dist_laplacian(c, c->band[j]); E += (double)(e * e); }
+    for (int j = c->row0; j < c->row1; ++j) { float e = dist_laplacian(c, c->band[j]); E += (double)(e * e); }
     return c->S ? E / (double)c->S : 0.0;
 }
 
@@ -516,7 +524,7 @@ static void rho_jacobian(const orc_ctx* c, int lin, int f, const float R[9], con
 static void albedo_system(const orc_ctx* c, float* H, float* b, double* e_in, long long* nobs_out) {
     double E = 0; long long nobs = 0;
 #pragma omp parallel for reduction(+ : E, nobs) schedule(static) num_threads(c->threads)
-    for (int j = 0; j < c->S; ++j) {
+    for (int j = c->row0; j < c->row1; ++j) {
         int lin = c->band[j];
         double Hd[3] = {0, 0, 0}, bd[3] = {0, 0, 0};
         for (int f = 0; f < c->F; ++f) {
@@ -547,7 +555,7 @@ static int step_albedo(orc_ctx* c, psgsdf_step_stats* st) {
     float damping = c->set.damping;
     long long count = 0;
     /* diagonal system: Jacobi-PCG is exact after one step: delta = b / H */
-    for (int j = 0; j < c->S; ++j) {
+    for (int j = c->row0; j < c->row1; ++j) {
         int lin = c->band[j];
         float* rho[3] = {&c->r[lin], &c->g[lin], &c->b[lin]};
         for (int ch = 0; ch < 3; ++ch) {
@@ -573,7 +581,7 @@ static void light_system(const orc_ctx* c, double* H, double* b, double* e_in, l
         float R[9], t[3]; pose_Rt(c, f, R, t);
         double* Hf = H + (c->set.model == PSGSDF_LED ? 0 : (size_t)f * n * n);
         double* bf = b + (c->set.model == PSGSDF_LED ? 0 : (size_t)f * n);
-        for (int j = 0; j < c->S; ++j) {
+        for (int j = c->row0; j < c->row1; ++j) {
             int lin = c->band[j];
             if (!vis_bit(c, lin, f)) continue;
             float r[3], w[3]; obs_geom og;
@@ -610,12 +618,18 @@ static void light_system(const orc_ctx* c, double* H, double* b, double* e_in, l
     if (nobs_out) *nobs_out = nobs;
 }
 
+static int light_finish(orc_ctx* c, double* H, double* b, double e_in, long long nobs, psgsdf_step_stats* st);
 static int step_light(orc_ctx* c, psgsdf_step_stats* st) {
     int led = c->set.model == PSGSDF_LED;
     int nb = led ? 1 : c->F, n = c->basis;
     double* H = (double*)malloc(sizeof(double) * nb * n * n); double* b = (double*)malloc(sizeof(double) * nb * n);
     double e_in; long long nobs;
     light_system(c, H, b, &e_in, &nobs);
+    return light_finish(c, H, b, e_in, nobs, st);
+}
+static int light_finish(orc_ctx* c, double* H, double* b, double e_in, long long nobs, psgsdf_step_stats* st) {
+    int led = c->set.model == PSGSDF_LED;
+    int nb = led ? 1 : c->F, n = c->basis;
     float* Hf = (float*)malloc(sizeof(float) * nb * n * n); float* bf = (float*)malloc(sizeof(float) * nb * n); float* x = (float*)malloc(sizeof(float) * nb * n);
     for (int i = 0; i < nb * n * n; ++i) Hf[i] = (float)H[i];
     for (int i = 0; i < nb * n; ++i) bf[i] = (float)b[i];
@@ -678,7 +692,7 @@ static void pose_system(const orc_ctx* c, double* H, double* b, double* e_in, lo
     for (int f = 0; f < c->F; ++f) {
         float R[9], t[3]; pose_Rt(c, f, R, t);
         double* Hf = H + (size_t)f * 36; double* bf = b + (size_t)f * 6;
-        for (int j = 0; j < c->S; ++j) {
+        for (int j = c->row0; j < c->row1; ++j) {
             int lin = c->band[j];
             if (!vis_bit(c, lin, f)) continue;
             float r[3], w[3]; obs_geom og;
@@ -698,11 +712,16 @@ static void pose_system(const orc_ctx* c, double* H, double* b, double* e_in, lo
     if (nobs_out) *nobs_out = nobs;
 }
 
+static int pose_finish(orc_ctx* c, double* H, double* b, double e_in, long long nobs, psgsdf_step_stats* st);
 static int step_pose(orc_ctx* c, psgsdf_step_stats* st) {
-    int nb = c->F, n = 6;
+    int nb = c->F;
     double* H = (double*)malloc(sizeof(double) * nb * 36); double* b = (double*)malloc(sizeof(double) * nb * 6);
     double e_in; long long nobs;
     pose_system(c, H, b, &e_in, &nobs);
+    return pose_finish(c, H, b, e_in, nobs, st);
+}
+static int pose_finish(orc_ctx* c, double* H, double* b, double e_in, long long nobs, psgsdf_step_stats* st) {
+    int nb = c->F, n = 6;
     float* Hf = (float*)malloc(sizeof(float) * nb * 36); float* bf = (float*)malloc(sizeof(float) * nb * 6); float* x = (float*)malloc(sizeof(float) * nb * 6);
     for (int i = 0; i < nb * 36; ++i) Hf[i] = (float)H[i];
     for (int i = 0; i < nb * 6; ++i) bf[i] = (float)b[i];
@@ -814,6 +833,7 @@ typedef struct dist_sys {
 } dist_sys;
 
 typedef struct { long long key; double v; } coo_t;
+static void dist_assemble(const orc_ctx* c, dist_sys* s);
 static int coo_cmp(const void* a, const void* b) { long long x = ((const coo_t*)a)->key, y = ((const coo_t*)b)->key; return x < y ? -1 : (x > y ? 1 : 0); }
 
 static void dist_sys_free(dist_sys* s) { free(s->cols); free(s->B); free(s->g); free(s->rowptr); free(s->colidx); free(s->val); free(s->diag); free(s->rhs); memset(s, 0, sizeof(*s)); }
@@ -827,7 +847,7 @@ static void dist_system(const orc_ctx* c, int normal_reg, int laplacian_reg, dis
     long stride[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
     double E = 0; long long nobs = 0;
 #pragma omp parallel for reduction(+ : E, nobs) schedule(static) num_threads(c->threads)
-    for (int j = 0; j < S; ++j) {
+    for (int j = c->row0; j < c->row1; ++j) {
         int lin = c->band[j];
         float gtmp[3], dir[3]; dist_grad(c, lin, gtmp, dir);
         int* cols = s->cols + 4 * j; double* B = s->B + 16 * j; double* g = s->g + 4 * j;
@@ -865,11 +885,31 @@ static void dist_system(const orc_ctx* c, int normal_reg, int laplacian_reg, dis
     }
     if (e_in) *e_in = S ? E / S : 0.0;
     if (nobs_out) *nobs_out = nobs;
-    /* assemble: drop absent columns */
+    /* the engine keeps the per-voxel blocks in float32 planes (and exchanges them between ranks in that form):
+     * round here too, absent columns zeroed, so that 1-rank and n-rank runs assemble from identical numbers */
+    for (int j = c->row0; j < c->row1; ++j) for (int a = 0; a < 4; ++a) {
+        int ea = s->cols[4 * j + a] >= 0;
+        s->g[4 * j + a] = ea ? (double)(float)s->g[4 * j + a] : 0.0;
+        for (int bq = 0; bq < 4; ++bq) { int eb = s->cols[4 * j + bq] >= 0; s->B[16 * j + a * 4 + bq] = (ea && eb) ? (double)(float)s->B[16 * j + a * 4 + bq] : 0.0; }
+    }
+    if (c->n_ranks > 1) return;   /* slab mode: blocks are exchanged, then dist_assemble() */
+    dist_assemble(c, s);
+}
+/* assemble H rows [row0,row1) from the blocks of every contributing voxel (own + halo): drop absent columns */
+static void dist_assemble(const orc_ctx* c, dist_sys* s) {
+    int S = c->S;
+    long stride[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
+    int jlo = c->row0 - c->halo < 0 ? 0 : c->row0 - c->halo, jhi = c->row1 + c->halo > S ? S : c->row1 + c->halo;
+    if (c->n_ranks > 1) for (int j = jlo; j < jhi; ++j) {   /* stencil columns of halo voxels are static: recompute */
+        if (j >= c->row0 && j < c->row1) continue;
+        int lin = c->band[j]; int idx[3]; line2idx(c, lin, idx);
+        s->cols[4 * j] = j;
+        for (int a = 0; a < 3; ++a) { float dir = valid_forward(c, lin, idx, a) ? 1.0f : -1.0f; long ln = (long)lin + (long)dir * stride[a]; s->cols[4 * j + a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? c->row_of[ln] : -1; }
+    }
     size_t ncoo = 0; coo_t* coo = (coo_t*)malloc(sizeof(coo_t) * 16 * (size_t)(S + 1));
     double* rhs = (double*)calloc(S + 1, sizeof(double));
-    for (int j = 0; j < S; ++j) for (int a = 0; a < 4; ++a) {
-        int ra = s->cols[4 * j + a]; if (ra < 0) continue;
+    for (int j = jlo; j < jhi; ++j) for (int a = 0; a < 4; ++a) {
+        int ra = s->cols[4 * j + a]; if (ra < c->row0 || ra >= c->row1) continue;
         rhs[ra] += s->g[4 * j + a];
         for (int bq = 0; bq < 4; ++bq) { int cb = s->cols[4 * j + bq]; if (cb < 0) continue; coo[ncoo].key = (long long)ra * S + cb; coo[ncoo].v = s->B[16 * j + a * 4 + bq]; ncoo++; }
     }
@@ -894,6 +934,7 @@ static void dist_mv(void* user, const float* p, float* out) {
     const dist_mv_ctx* m = (const dist_mv_ctx*)user; const dist_sys* s = m->s;
     for (int i = 0; i < s->S; ++i) {
         double acc = 0;
+        if (s->rowptr[i + 1] == s->rowptr[i]) { out[i] = 0.f; continue; }
         for (int k = s->rowptr[i]; k < s->rowptr[i + 1]; ++k) {
             float v = s->val[k];
             if (s->colidx[k] == i && m->damping != 0.f) v += m->damping * v; /* H.diagonal() += damping*H.diagonal() */
@@ -906,8 +947,8 @@ static void dist_mv(void* user, const float* p, float* out) {
 /* updateGrad, OptimizerAux.cpp:152-160 */
 static void update_grad(orc_ctx* c) {
     float* ng = (float*)malloc(sizeof(float) * 3 * (c->S + 1));
-    for (int j = 0; j < c->S; ++j) { float d[3]; dist_grad(c, c->band[j], ng + 3 * j, d); }
-    for (int j = 0; j < c->S; ++j) { int lin = c->band[j]; c->gx[lin] = ng[3 * j]; c->gy[lin] = ng[3 * j + 1]; c->gz[lin] = ng[3 * j + 2]; }
+    for (int j = c->row0; j < c->row1; ++j) { float d[3]; dist_grad(c, c->band[j], ng + 3 * j, d); }
+    for (int j = c->row0; j < c->row1; ++j) { int lin = c->band[j]; c->gx[lin] = ng[3 * j]; c->gy[lin] = ng[3 * j + 1]; c->gz[lin] = ng[3 * j + 2]; }
     free(ng);
 }
 
@@ -925,7 +966,7 @@ static int step_dist(orc_ctx* c, int laplacian_reg, psgsdf_step_stats* st) {
     if (c->set.model != PSGSDF_LED && c->set.ref_quirks && !cr.success) apply = 0; /* PsOptimizer.cpp:168-170 (B8) */
     long long count = 0;
     if (apply) { /* updateDist, OptimizerAux.cpp:162-188 */
-        for (int j = 0; j < S; ++j) {
+        for (int j = c->row0; j < c->row1; ++j) {
             float d = x[j];
             if ((double)fabsf(d) < sqrt(3.0) * (double)c->vs) { c->dist[c->band[j]] -= d; count++; }
         }
@@ -940,7 +981,7 @@ static int step_dist(orc_ctx* c, int laplacian_reg, psgsdf_step_stats* st) {
 
 /* Optimizer.cpp:50-81 initAlbedo */
 static void init_albedo(orc_ctx* c) {
-    for (int j = 0; j < c->S; ++j) {
+    for (int j = c->row0; j < c->row1; ++j) {
         int lin = c->band[j]; int count = 0; float rho[3] = {0, 0, 0};
         for (int f = 0; f < c->F; ++f) {
             if (!vis_bit(c, lin, f)) continue;
@@ -958,7 +999,7 @@ static void init_light(orc_ctx* c) {
         c->basis = 3; c->light = (float*)malloc(sizeof(float) * MAXB);
         c->light[0] = c->light[1] = c->light[2] = 1.0f;
         double I[3] = {0, 0, 0}, Rr[3] = {0, 0, 0};
-        for (int j = 0; j < c->S; ++j) { int lin = c->band[j];
+        for (int j = c->row0; j < c->row1; ++j) { int lin = c->band[j];
             for (int f = 0; f < c->F; ++f) {
                 if (!vis_bit(c, lin, f)) continue;
                 float R[9], t[3]; pose_Rt(c, f, R, t); float in[3]; obs_geom og;
@@ -966,7 +1007,8 @@ static void init_light(orc_ctx* c) {
                 float ren[3]; rendered_intensity(c, lin, f, R, &og, ren);
                 for (int ch = 0; ch < 3; ++ch) { I[ch] += in[ch]; Rr[ch] += ren[ch]; }
             } }
-        for (int ch = 0; ch < 3; ++ch) c->light[ch] = (float)I[ch] / (float)Rr[ch];
+        for (int ch = 0; ch < 3; ++ch) { c->mg_scal[ch] = I[ch]; c->mg_scal[3 + ch] = Rr[ch]; }
+        if (c->n_ranks == 1) for (int ch = 0; ch < 3; ++ch) c->light[ch] = (float)I[ch] / (float)Rr[ch];
     } else {
         c->basis = c->set.model == PSGSDF_SH2 ? 9 : 4;
         c->light = (float*)calloc((size_t)(c->F > 0 ? c->F : 1) * MAXB, sizeof(float));
@@ -1014,6 +1056,213 @@ static void upsample2x(orc_ctx* c) {
     build_band(c);
 }
 
+
+/* ------------------------------------------------------------------ multi-rank (slab) phases
+ * Mirror of psgsdf_mg_* (include/psgsdf.h): same buffers, same layouts, same phase ids, so the host program
+ * psgradientsdf_amd/distributed.py can be exercised on CPU (gloo, world_size 2) against this oracle. */
+#define FROW 64
+static void mg_setup(orc_ctx* c) {
+    int S = c->S;
+    int C = (S + c->n_ranks - 1) / c->n_ranks;
+    c->row0 = c->rank * C < S ? c->rank * C : S; c->row1 = c->row0 + C < S ? c->row0 + C : S;
+    c->Spad = ((S + 255) / 256) * 256 + 256;
+    /* halo = widest reach of any ELL column of the distance rows (self, 6 axis, 12 pair offsets) */
+    c->halo = 0;
+    if (c->n_ranks > 1) {
+        long st[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
+        for (int i = 0; i < S; ++i) for (int ox = -1; ox <= 1; ++ox) for (int oy = -1; oy <= 1; ++oy) for (int oz = -1; oz <= 1; ++oz) {
+            if ((ox != 0) + (oy != 0) + (oz != 0) > 2) continue;
+            long ln = (long)c->band[i] + ox * st[0] + oy * st[1] + oz * st[2];
+            if (ln < 0 || (size_t)ln >= c->nvox) continue;
+            int r = c->row_of[ln]; if (r < 0) continue;
+            int d = r > i ? r - i : i - r; if (d > c->halo) c->halo = d;
+        }
+    }
+    free(c->mg_frame); free(c->mg_dist); free(c->mg_blk); free(c->mg_zp); free(c->mg_rho); free(c->mg_grad);
+    free(c->cg_x); free(c->cg_r); free(c->cg_t); free(c->cg_p); free(c->cg_inv); free(c->cg_sc);
+    c->mg_frame = (double*)calloc((size_t)(c->F > 0 ? c->F : 1) * FROW, sizeof(double));
+    c->mg_dist = (float*)calloc(c->Spad, sizeof(float)); c->mg_blk = (float*)calloc((size_t)14 * c->Spad, sizeof(float));
+    c->mg_zp = (float*)calloc((size_t)2 * c->Spad, sizeof(float)); c->mg_rho = (float*)calloc((size_t)3 * c->Spad, sizeof(float)); c->mg_grad = (float*)calloc((size_t)3 * c->Spad, sizeof(float));
+    c->cg_x = (float*)calloc(c->Spad, sizeof(float)); c->cg_r = (float*)calloc(c->Spad, sizeof(float)); c->cg_t = (float*)calloc(c->Spad, sizeof(float));
+    c->cg_p = (float*)calloc(c->Spad, sizeof(float)); c->cg_inv = (float*)calloc(c->Spad, sizeof(float));
+    c->cg_sc = (double*)calloc(4 + 3 * 4096, sizeof(double));
+}
+static int sym4(int a, int b) { if (a > b) { int t = a; a = b; b = t; } return a * 4 - (a * (a - 1)) / 2 + (b - a); }
+
+int orc_comm_init(orc_ctx* c, const uint8_t* id, int rank, int n_ranks) { (void)id; if (!c || rank < 0 || rank >= n_ranks) return PSGSDF_ERR_ARG; c->rank = rank; c->n_ranks = n_ranks; c->inited = 0; return 0; }
+int orc_set_stream(orc_ctx* c, void* s) { (void)c; (void)s; return 0; }
+int orc_mg_info(orc_ctx* c, int32_t out[8]) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    out[0] = c->S; out[1] = c->Spad; out[2] = c->row0; out[3] = c->row1; out[4] = c->halo; out[5] = c->F; out[6] = c->rank; out[7] = c->n_ranks;
+    return 0;
+}
+int orc_mg_buffer(orc_ctx* c, int which, void** ptr, int64_t* count) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    int64_t Sp = c->Spad;
+    switch (which) {
+        case PSGSDF_MG_BUF_FRAME_ACC: *ptr = c->mg_frame; *count = (int64_t)c->F * FROW; break;
+        case PSGSDF_MG_BUF_SCAL: *ptr = c->mg_scal; *count = 16; break;
+        case PSGSDF_MG_BUF_PCG: *ptr = c->mg_ext; *count = 3; break;
+        case PSGSDF_MG_BUF_DIST: *ptr = c->mg_dist; *count = Sp; break;
+        case PSGSDF_MG_BUF_BLK: *ptr = c->mg_blk; *count = 14 * Sp; break;
+        case PSGSDF_MG_BUF_ZP: *ptr = c->mg_zp; *count = 2 * Sp; break;
+        case PSGSDF_MG_BUF_RHO: *ptr = c->mg_rho; *count = 3 * Sp; break;
+        case PSGSDF_MG_BUF_GRAD: *ptr = c->mg_grad; *count = 3 * Sp; break;
+        default: return PSGSDF_ERR_ARG;
+    }
+    return 0;
+}
+/* dense <-> band-compact exchange planes */
+static void pack_state(orc_ctx* c) {
+    int Sp = c->Spad;
+    for (int j = c->row0; j < c->row1; ++j) { int lin = c->band[j];
+        c->mg_dist[j] = c->dist[lin];
+        c->mg_rho[j] = c->r[lin]; c->mg_rho[Sp + j] = c->g[lin]; c->mg_rho[2 * Sp + j] = c->b[lin];
+        c->mg_grad[j] = c->gx[lin]; c->mg_grad[Sp + j] = c->gy[lin]; c->mg_grad[2 * Sp + j] = c->gz[lin]; }
+}
+static void unpack_state(orc_ctx* c, int lo, int hi, int with_rho_grad) {
+    int Sp = c->Spad;
+    for (int j = lo; j < hi; ++j) { if (j >= c->row0 && j < c->row1) continue; int lin = c->band[j];
+        c->dist[lin] = c->mg_dist[j];
+        if (with_rho_grad) { c->r[lin] = c->mg_rho[j]; c->g[lin] = c->mg_rho[Sp + j]; c->b[lin] = c->mg_rho[2 * Sp + j];
+                             c->gx[lin] = c->mg_grad[j]; c->gy[lin] = c->mg_grad[Sp + j]; c->gz[lin] = c->mg_grad[2 * Sp + j]; } }
+}
+static float pcg_thr(float rhsN) { return fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN); }
+
+int orc_mg_phase(orc_ctx* c, int phase, int arg) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    int S = c->S, Sp = c->Spad, F = c->F;
+    int led = c->set.model == PSGSDF_LED;
+    switch (phase) {
+        case PSGSDF_MG_ENERGY: { long long n; double e = ps_energy(c, &n); c->mg_scal[0] = e * S; c->mg_scal[1] = (double)n; return 0; }
+        case PSGSDF_MG_INIT_ALBEDO: init_albedo(c); return 0;
+        case PSGSDF_MG_LED_SUMS: { float keep[3] = {c->light[0], c->light[1], c->light[2]}; init_light(c); (void)keep; return 0; }   /* leaves sums in mg_scal[0..5] */
+        case PSGSDF_MG_LED_SET: for (int ch = 0; ch < 3; ++ch) c->light[ch] = (float)c->mg_scal[ch] / (float)c->mg_scal[3 + ch]; return 0;
+        case PSGSDF_MG_SWEEP_ALBEDO: {
+            float* H = (float*)malloc(sizeof(float) * 3 * (S + 1)); float* b = (float*)malloc(sizeof(float) * 3 * (S + 1));
+            double e; long long n; albedo_system(c, H, b, &e, &n);
+            for (int j = c->row0; j < c->row1; ++j) for (int ch = 0; ch < 3; ++ch) { c->mg_blk[(size_t)ch * Sp + j] = H[3 * j + ch]; c->mg_blk[(size_t)(3 + ch) * Sp + j] = b[3 * j + ch]; }
+            c->mg_scal[0] = e * S; c->mg_scal[1] = (double)n; free(H); free(b); return 0; }
+        case PSGSDF_MG_APPLY_ALBEDO: {
+            long long count = 0; float damping = c->set.damping;
+            for (int j = c->row0; j < c->row1; ++j) { int lin = c->band[j]; float* rho[3] = {&c->r[lin], &c->g[lin], &c->b[lin]};
+                for (int ch = 0; ch < 3; ++ch) { float h = c->mg_blk[(size_t)ch * Sp + j]; if (damping != 0.0f) h += damping * h;
+                    float delta = (h != 0.f) ? c->mg_blk[(size_t)(3 + ch) * Sp + j] / h : 0.f; float v = *rho[ch] - delta;
+                    if (v > 0.0f && v < 1.0f) { *rho[ch] = v; count++; } } }
+            c->mg_scal[0] = (double)count; return 0; }
+        case PSGSDF_MG_SWEEP_LIGHT: {
+            int nb = led ? 1 : F, n = c->basis, nh = led ? 3 : n * (n + 1) / 2;
+            double* H = (double*)malloc(sizeof(double) * nb * n * n); double* b = (double*)malloc(sizeof(double) * nb * n); double e; long long no;
+            light_system(c, H, b, &e, &no);
+            memset(c->mg_frame, 0, sizeof(double) * (size_t)F * FROW);
+            for (int k = 0; k < nb; ++k) { double* row = c->mg_frame + (size_t)k * FROW; int q = 0;
+                if (led) { for (int i = 0; i < 3; ++i) { row[i] = H[i * 3 + i]; row[3 + i] = b[i]; } }
+                else { for (int i = 0; i < n; ++i) for (int kk = i; kk < n; ++kk) row[q++] = H[(size_t)k * n * n + i * n + kk]; for (int i = 0; i < n; ++i) row[nh + i] = b[(size_t)k * n + i]; } }
+            c->mg_frame[nh + n] = e * S; c->mg_frame[nh + n + 1] = (double)no;   /* energy / n_obs ride in row 0 */
+            free(H); free(b); return 0; }
+        case PSGSDF_MG_SOLVE_LIGHT: {
+            int nb = led ? 1 : F, n = c->basis, nh = led ? 3 : n * (n + 1) / 2;
+            double* H = (double*)calloc((size_t)nb * n * n, sizeof(double)); double* b = (double*)calloc((size_t)nb * n, sizeof(double));
+            if (led) { for (int f = 0; f < F; ++f) for (int i = 0; i < 3; ++i) { H[i * 3 + i] += c->mg_frame[(size_t)f * FROW + i]; b[i] += c->mg_frame[(size_t)f * FROW + 3 + i]; } }
+            else for (int k = 0; k < nb; ++k) { const double* row = c->mg_frame + (size_t)k * FROW; int q = 0;
+                for (int i = 0; i < n; ++i) for (int kk = i; kk < n; ++kk) { H[(size_t)k * n * n + i * n + kk] = row[q]; H[(size_t)k * n * n + kk * n + i] = row[q]; ++q; }
+                for (int i = 0; i < n; ++i) b[(size_t)k * n + i] = row[nh + i]; }
+            return light_finish(c, H, b, 0, 0, NULL); }
+        case PSGSDF_MG_SWEEP_POSE: {
+            double* H = (double*)malloc(sizeof(double) * F * 36); double* b = (double*)malloc(sizeof(double) * F * 6); double e; long long no;
+            pose_system(c, H, b, &e, &no);
+            memset(c->mg_frame, 0, sizeof(double) * (size_t)F * FROW);
+            for (int k = 0; k < F; ++k) { double* row = c->mg_frame + (size_t)k * FROW; int q = 0;
+                for (int i = 0; i < 6; ++i) for (int kk = i; kk < 6; ++kk) row[q++] = H[(size_t)k * 36 + i * 6 + kk]; for (int i = 0; i < 6; ++i) row[21 + i] = b[(size_t)k * 6 + i]; }
+            c->mg_frame[27] = e * S; c->mg_frame[28] = (double)no; free(H); free(b); return 0; }
+        case PSGSDF_MG_SOLVE_POSE: {
+            double* H = (double*)calloc((size_t)F * 36, sizeof(double)); double* b = (double*)calloc((size_t)F * 6, sizeof(double));
+            for (int k = 0; k < F; ++k) { const double* row = c->mg_frame + (size_t)k * FROW; int q = 0;
+                for (int i = 0; i < 6; ++i) for (int kk = i; kk < 6; ++kk) { H[(size_t)k * 36 + i * 6 + kk] = row[q]; H[(size_t)k * 36 + kk * 6 + i] = row[q]; ++q; }
+                for (int i = 0; i < 6; ++i) b[(size_t)k * 6 + i] = row[21 + i]; }
+            return pose_finish(c, H, b, 0, 0, NULL); }
+        case PSGSDF_MG_SWEEP_DIST: {
+            dist_sys* sy = (dist_sys*)c->mg_sys; if (sy) { dist_sys_free(sy); free(sy); }
+            sy = (dist_sys*)calloc(1, sizeof(dist_sys)); c->mg_sys = sy;
+            double e; long long no; dist_system(c, c->reg_n != 0.f, arg, sy, &e, &no);
+            for (int j = c->row0; j < c->row1; ++j) { int q = 0;
+                for (int a = 0; a < 4; ++a) for (int bq = a; bq < 4; ++bq) c->mg_blk[(size_t)(q++) * Sp + j] = (float)sy->B[16 * j + a * 4 + bq];
+                for (int a = 0; a < 4; ++a) c->mg_blk[(size_t)(10 + a) * Sp + j] = (float)sy->g[4 * j + a]; }
+            c->mg_scal[0] = e * S; c->mg_scal[1] = (double)no; return 0; }
+        case PSGSDF_MG_ASSEMBLE: {
+            dist_sys* sy = (dist_sys*)c->mg_sys; if (!sy) return PSGSDF_ERR_STATE;
+            if (c->n_ranks > 1) {
+                int jlo = c->row0 - c->halo < 0 ? 0 : c->row0 - c->halo, jhi = c->row1 + c->halo > S ? S : c->row1 + c->halo;
+                for (int j = jlo; j < jhi; ++j) { if (j >= c->row0 && j < c->row1) continue;
+                    for (int a = 0; a < 4; ++a) { for (int bq = 0; bq < 4; ++bq) sy->B[16 * j + a * 4 + bq] = (double)c->mg_blk[(size_t)sym4(a, bq) * Sp + j]; sy->g[4 * j + a] = (double)c->mg_blk[(size_t)(10 + a) * Sp + j]; } }
+                dist_assemble(c, sy);
+            }
+            return 0; }
+        case PSGSDF_MG_PCG_INIT: {
+            dist_sys* sy = (dist_sys*)c->mg_sys; if (!sy || !sy->rowptr) return PSGSDF_ERR_STATE;
+            memset(c->cg_sc, 0, sizeof(double) * (4 + 3 * 4096));
+            double bb = 0, rz = 0;
+            for (int i = c->row0; i < c->row1; ++i) { float dg = sy->diag[i]; if (c->set.damping != 0.f) dg += c->set.damping * dg;
+                float inv = dg != 0.f ? 1.0f / dg : 1.0f; float r = sy->rhs[i]; float z = inv * r;
+                c->cg_inv[i] = inv; c->cg_x[i] = 0.f; c->cg_r[i] = r; c->mg_zp[2 * i] = z; c->mg_zp[2 * i + 1] = 0.f; c->cg_p[i] = 0.f;
+                bb += (double)r * r; rz += (double)r * z; }
+            c->mg_ext[0] = bb; c->mg_ext[1] = rz; return 0; }
+        case PSGSDF_MG_PCG_MV: {
+            dist_sys* sy = (dist_sys*)c->mg_sys; int k = arg; double* sc = c->cg_sc;
+            double s1 = c->mg_ext[0], s2 = c->mg_ext[1];
+            if (k == 0) { sc[0] = s1; sc[1] = s2; } else { sc[4 + 3 * (k - 1) + 1] = s1; sc[4 + 3 * (k - 1) + 2] = s2; }
+            float rhsN = (float)(k == 0 ? s1 : sc[0]);
+            c->mg_ext[2] = 0;
+            if (rhsN == 0.f) return 0;
+            if (k > 0 && (float)s1 < pcg_thr(rhsN)) return 0;
+            float beta = 0.f;
+            if (k > 0) { float absNew = (float)s2; float absOld = (float)(k == 1 ? sc[1] : sc[4 + 3 * (k - 2) + 2]); beta = absNew / absOld; }
+            double pt = 0;
+            for (int i = c->row0; i < c->row1; ++i) {
+                double acc = 0;
+                for (int q = sy->rowptr[i]; q < sy->rowptr[i + 1]; ++q) { int cc = sy->colidx[q]; float v = sy->val[q];
+                    if (cc == i && c->set.damping != 0.f) v += c->set.damping * v;
+                    acc += (double)v * (double)(c->mg_zp[2 * cc] + beta * c->mg_zp[2 * cc + 1]); }
+                float pi = c->mg_zp[2 * i] + beta * c->mg_zp[2 * i + 1]; float t = (float)acc;
+                c->cg_p[i] = pi; c->cg_t[i] = t; pt += (double)pi * (double)t; }
+            c->mg_ext[2] = pt; return 0; }
+        case PSGSDF_MG_PCG_UPD: {
+            int k = arg; double* sc = c->cg_sc; float rhsN = (float)sc[0];
+            int done = rhsN == 0.f || (k > 0 && (float)sc[4 + 3 * (k - 1) + 1] < pcg_thr(rhsN));
+            if (done) { c->mg_ext[0] = 0; c->mg_ext[1] = 0; return 0; }
+            double ptot = c->mg_ext[2]; sc[4 + 3 * k] = ptot;
+            float absNew = (float)(k == 0 ? sc[1] : sc[4 + 3 * (k - 1) + 2]); float alpha = absNew / (float)ptot;
+            double rr = 0, rz = 0;
+            for (int i = c->row0; i < c->row1; ++i) { float pi = c->cg_p[i]; float x = c->cg_x[i] + alpha * pi; float r = c->cg_r[i] - alpha * c->cg_t[i]; float z = c->cg_inv[i] * r;
+                c->cg_x[i] = x; c->cg_r[i] = r; c->mg_zp[2 * i] = z; c->mg_zp[2 * i + 1] = pi; rr += (double)r * r; rz += (double)r * z; }
+            c->mg_ext[0] = rr; c->mg_ext[1] = rz; return 0; }
+        case PSGSDF_MG_APPLY_DIST: {
+            long long count = 0;
+            for (int j = c->row0; j < c->row1; ++j) { float d = c->cg_x[j]; if ((double)fabsf(d) < sqrt(3.0) * (double)c->vs) { c->dist[c->band[j]] -= d; count++; } }
+            pack_state(c); c->mg_scal[0] = (double)count; return 0; }
+        case PSGSDF_MG_DERIVE: {
+            int lo = c->row0 - c->halo < 0 ? 0 : c->row0 - c->halo, hi = c->row1 + c->halo > S ? S : c->row1 + c->halo;
+            if (c->n_ranks > 1) unpack_state(c, lo, hi, 0);
+            if (arg) update_grad(c);
+            c->mg_scal[0] = normal_energy(c) * S; c->mg_scal[1] = laplacian_energy(c) * S; return 0; }
+        case PSGSDF_MG_SET_REG_SUMS: return 0;   /* the oracle recomputes regulariser energies on demand */
+        default: return PSGSDF_ERR_ARG;
+    }
+}
+int orc_mg_pcg_status(orc_ctx* c, int k0, int n, int32_t* iters, double* err) {
+    double* sc = c->cg_sc; float rhsN = (float)sc[0];
+    *iters = -1; *err = 0;
+    if (rhsN == 0.f) { *iters = 0; return 0; }
+    float thr = pcg_thr(rhsN), rn2 = 0;
+    for (int q = 0; q < n; ++q) { rn2 = (float)(q == n - 1 ? c->mg_ext[0] : sc[4 + 3 * (k0 + q) + 1]); if (rn2 < thr) { *iters = k0 + q; break; } }
+    *err = sqrt((double)rn2 / (double)rhsN);
+    return 0;
+}
+int orc_mg_set_weights(orc_ctx* c, float reg_n, float reg_l) { c->reg_n = reg_n; c->reg_l = reg_l; return 0; }
+/* final state gather support: owned rows -> exchange planes, all rows <- exchange planes */
+int orc_mg_pack_state(orc_ctx* c) { pack_state(c); return 0; }
+int orc_mg_unpack_state(orc_ctx* c) { unpack_state(c, 0, c->S, 1); return 0; }
+
 /* ------------------------------------------------------------------ exported API (mirrors psgsdf.h) */
 
 #define ORC_FAIL(c, code, msg) do { if (c) snprintf((c)->err, sizeof((c)->err), "%s", msg); return code; } while (0)
@@ -1030,7 +1279,7 @@ int orc_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_sett
     for (int a = 0; a < 3; ++a) c->origin[a] = c->shift[a] - (float)(0.5 * (double)c->vs) * (float)c->dim[a];
     c->fx = K[0]; c->fy = K[4]; c->cx = K[2]; c->cy = K[5];
     c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l;
-    c->threads = 1;
+    c->threads = 1; c->rank = 0; c->n_ranks = 1;
     *out = c;
     return 0;
 }

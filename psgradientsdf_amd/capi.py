@@ -208,6 +208,40 @@ class Api:
         a, p = _fp(light)
         self._check(self._fn("upload_light")(self.ctx, p), "upload_light")
 
+    # -- multi-rank phase API (driven by psgradientsdf_amd/distributed.py)
+    def comm_init(self, rank, n_ranks):
+        self._check(self._fn("comm_init")(self.ctx, None, C.c_int(rank), C.c_int(n_ranks)), "comm_init")
+
+    def set_stream(self, stream_ptr):
+        self._check(self._fn("set_stream")(self.ctx, C.c_void_p(stream_ptr)), "set_stream")
+
+    def mg_info(self):
+        out = (C.c_int32 * 8)()
+        self._check(self._fn("mg_info")(self.ctx, out), "mg_info")
+        return dict(zip(["S", "Spad", "row0", "row1", "halo", "F", "rank", "n_ranks"], list(out)))
+
+    def mg_buffer(self, which):
+        ptr = C.c_void_p(); n = C.c_int64()
+        self._check(self._fn("mg_buffer")(self.ctx, C.c_int(which), C.byref(ptr), C.byref(n)), "mg_buffer")
+        return ptr.value, n.value
+
+    def mg_phase(self, phase, arg=0):
+        self._check(self._fn("mg_phase")(self.ctx, C.c_int(phase), C.c_int(arg)), f"mg_phase({phase})")
+
+    def mg_pcg_status(self, k0, n):
+        it = C.c_int32(); err = C.c_double()
+        self._check(self._fn("mg_pcg_status")(self.ctx, C.c_int(k0), C.c_int(n), C.byref(it), C.byref(err)), "mg_pcg_status")
+        return it.value, err.value
+
+    def mg_set_weights(self, reg_n, reg_l):
+        self._check(self._fn("mg_set_weights")(self.ctx, C.c_float(reg_n), C.c_float(reg_l)), "mg_set_weights")
+
+    def mg_pack_state(self):
+        self._check(self._fn("mg_pack_state")(self.ctx), "mg_pack_state")
+
+    def mg_unpack_state(self):
+        self._check(self._fn("mg_unpack_state")(self.ctx), "mg_unpack_state")
+
     # -- measurement
     def set_profiling(self, on):
         self._check(self._fn("set_profiling")(self.ctx, C.c_int(1 if on else 0)), "set_profiling")

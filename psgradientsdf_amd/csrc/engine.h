@@ -96,6 +96,8 @@ struct SweepArgs {
     float reg_n, reg_l;
     int normal_reg, laplacian_reg;
     float damping;
+    int row0, row1;           // band rows this context owns: [row0, row1) (whole band on one GPU; a z-slab per rank otherwise)
+    const double* ext;        // multi-rank PCG: globally reduced scalars {|b|^2 or |r|^2, r.z, p.t} supplied by the host program, else nullptr
 };
 
 // ---- launchers implemented in kernels.hip (all asynchronous on `s`) ----------------------
@@ -108,8 +110,11 @@ void launch_band_fill(const DenseView& d, const GridP& grid, Band b, hipStream_t
 void launch_band_scatter(const DenseView& d, Band b, hipStream_t s);
 void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s);
 constexpr int kObsChunk = 2048;      // rows per workgroup of the observation-list builders
-void launch_obs_count(const Band& b, int F, int* counts, hipStream_t s);                 // counts[F][nch]
-void launch_obs_fill(const Band& b, int F, const int* offsets, hipStream_t s);           // offsets[F][nch] -> b.obs_rows
+void launch_obs_count(const Band& b, int F, int row0, int row1, int* counts, hipStream_t s);       // counts[F][nch]
+void launch_obs_fill(const Band& b, int F, int row0, int row1, const int* offsets, hipStream_t s); // offsets[F][nch] -> b.obs_rows
+void launch_reach(const Band& b, int* d_reach, hipStream_t s);                                     // max |col - row| over the band
+void launch_sum_parts(const double* part, int PB, int nblk, const int* slots, int nslots, double* out, hipStream_t s);
+void launch_pcg_sum(const double* part, int G, int k, int which, double* out, hipStream_t s);      // which 0: p.t of pass k; 1: |r|^2, r.z of pass k (-1 = init)
 void launch_init_albedo(const SweepArgs& a, hipStream_t s);
 void launch_led_light_init(const SweepArgs& a, hipStream_t s);
 void launch_energy(const SweepArgs& a, hipStream_t s);

@@ -57,8 +57,13 @@ struct psgsdf_ctx {
     double* host_buf = nullptr; size_t host_buf_n = 0;   // pinned readback
     // cached energies
     double en_sum = 0, el_sum = 0;       // sums over the band from the last k_derive
-    // comm
+    // row partition (multi-rank): this context owns band rows [row0, row1); halo = widest column reach
     int rank = 0, n_ranks = 1;
+    int row0 = 0, row1 = 0, halo = 0;
+    double* mg_scal = nullptr;           // [16] folded local sums the host program all-reduces
+    double* mg_ext = nullptr;            // [3] globally reduced PCG scalars {|r|^2, r.z, p.t}
+    int* mg_slots = nullptr;             // [8] device copy of slot ids for k_sum_parts
+    bool own_stream = true;
     // profiling
     bool profiling = false;
     std::map<std::string, KTime> ktimes;
@@ -110,10 +115,12 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.reg_n = c->reg_n; a.reg_l = c->reg_l;
     a.normal_reg = c->reg_n != 0.0f; a.laplacian_reg = laplacian_reg;
     a.damping = c->set.damping;
+    a.row0 = c->row0; a.row1 = c->row1;
+    a.ext = nullptr;
     return a;
 }
 
-inline int band_blocks(const psgsdf_ctx* c) { return (c->band.S + kBlock - 1) / kBlock; }
+inline int band_blocks(const psgsdf_ctx* c) { return (c->row1 - c->row0 + kBlock - 1) / kBlock; }
 // sum the per-workgroup partials of the given slots (written by a voxel-major kernel of band_blocks() workgroups)
 int read_parts(psgsdf_ctx* c, const int* slots, int n, double* out) {
     const int nb = band_blocks(c);
@@ -195,15 +202,28 @@ int build_band(psgsdf_ctx* c) {
     b.rhs = (float*)take(1, 4); b.x = (float*)take(1, 4); b.r = (float*)take(1, 4); b.t = (float*)take(1, 4);
     b.p = (float*)take(1, 4); b.inv = (float*)take(1, 4);
     timed(c, "band_fill", [&] { launch_band_fill(c->dense, c->grid, b, c->stream); });
-    // per-frame observation lists (counts -> host prefix -> fill)
+    // row partition: equal band count per rank = z-slabs (the band is sorted by linear index, z slowest)
     {
-        const int nch = (S + kObsChunk - 1) / kObsChunk, F = c->F;
+        const int C = (S + c->n_ranks - 1) / c->n_ranks;
+        c->row0 = std::min(S, c->rank * C); c->row1 = std::min(S, c->row0 + C);
+        c->halo = 0;
+        if (c->n_ranks > 1 && S > 0) {
+            HIPCHK(c, hipMemsetAsync(c->d_total, 0, sizeof(int), c->stream));
+            launch_reach(b, c->d_total, c->stream);
+            HIPCHK(c, hipMemcpyAsync(&c->halo, c->d_total, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->halo > C) return fail(c, PSGSDF_ERR_UNSUPPORTED, "slab of %d rows is thinner than the stencil reach %d: use fewer ranks", C, c->halo);
+        }
+    }
+    // per-frame observation lists of the owned rows (counts -> host prefix -> fill)
+    {
+        const int nch = (c->row1 - c->row0 + kObsChunk - 1) / kObsChunk, F = c->F;
         if (c->obs_mem) { hipFree(c->obs_mem); c->obs_mem = nullptr; }
         b.obs_ptr = nullptr; b.obs_rows = nullptr; b.obs_max = 0;
         if (nch > 0 && F > 0) {
             int* d_counts = nullptr;
             HIPCHK(c, hipMalloc(&d_counts, sizeof(int) * (size_t)nch * F));
-            launch_obs_count(b, F, d_counts, c->stream);
+            launch_obs_count(b, F, c->row0, c->row1, d_counts, c->stream);
             std::vector<int> cnt((size_t)nch * F), off((size_t)nch * F), ptr(F + 1);
             HIPCHK(c, hipMemcpyAsync(cnt.data(), d_counts, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -214,7 +234,7 @@ int build_band(psgsdf_ctx* c) {
             b.obs_ptr = (int*)c->obs_mem; b.obs_rows = b.obs_ptr + (F + 1); b.obs_max = mx;
             HIPCHK(c, hipMemcpyAsync(b.obs_ptr, ptr.data(), sizeof(int) * (F + 1), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(d_counts, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice, c->stream));
-            launch_obs_fill(b, F, d_counts, c->stream);
+            launch_obs_fill(b, F, c->row0, c->row1, d_counts, c->stream);
             HIPCHK(c, hipStreamSynchronize(c->stream));
             hipFree(d_counts);
         }
@@ -430,6 +450,8 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     bool ok = hipStreamCreate(&c->stream) == hipSuccess
         && hipMalloc(&c->pcg_sc, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap)) == hipSuccess
         && hipMalloc(&c->pcg_part, sizeof(double) * 6 * kPcgMaxBlocks) == hipSuccess
+        && hipMalloc(&c->mg_scal, sizeof(double) * 16) == hipSuccess && hipMalloc(&c->mg_ext, sizeof(double) * 4) == hipSuccess
+        && hipMalloc(&c->mg_slots, sizeof(int) * 8) == hipSuccess
         && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess
         && hipMalloc(&c->led_light, sizeof(float) * 3) == hipSuccess
         && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
@@ -448,7 +470,8 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (c->host_buf) hipHostFree(c->host_buf);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    if (c->stream) hipStreamDestroy(c->stream);
+    hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mg_slots);
+    if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -522,7 +545,7 @@ int psgsdf_init(psgsdf_ctx* c) {
     }
     HIPCHK(c, hipMemcpyAsync(c->frames, c->frames_h.data(), sizeof(FrameP) * c->F, hipMemcpyHostToDevice, c->stream));
     if ((rc = derive(c, 0))) return rc;
-    if (led) {   // computeLightIntensive, LedOptimizer.cpp:76-112
+    if (led && c->n_ranks == 1) {   // computeLightIntensive, LedOptimizer.cpp:76-112 (multi-rank: phases MG_LED_SUMS / MG_LED_SET)
         SweepArgs a = make_args(c, 0);
         timed(c, "led_light_init", [&] { launch_led_light_init(a, c->stream); });
         const int slots[6] = {SC_AUX0, SC_AUX1, SC_AUX2, SC_EN, SC_EL, SC_ACCEPT}; double s[6];
@@ -717,14 +740,131 @@ int psgsdf_upload_light(psgsdf_ctx* c, const float* light) {
     return PSGSDF_OK;
 }
 
-// ---- multi-GPU: implemented in a later step of round 1 ---------------------
-int psgsdf_comm_unique_id(uint8_t id[128]) { (void)id; return PSGSDF_ERR_UNSUPPORTED; }
+// ---- multi-rank (z-slab) phase API ---------------------------------------------------------
+// One process per GPU.  Every rank holds the whole band but owns rows [row0,row1) (equal band count = z-slabs);
+// the host program (psgradientsdf_amd/distributed.py) runs the phases below and performs the exchanges between them
+// with torch.distributed (RCCL on the GPUs): all-reduce of the frame accumulators / folded scalars / PCG scalars,
+// halo exchange of contiguous row ranges of `blk`, `{z,p}` and `dist`.  DESIGN.md §7.
+int psgsdf_comm_unique_id(uint8_t id[128]) { (void)id; return PSGSDF_ERR_UNSUPPORTED; }   // collectives live in the host program
 int psgsdf_comm_init(psgsdf_ctx* c, const uint8_t id[128], int rank, int n_ranks) {
     (void)id;
-    if (!c) return PSGSDF_ERR_ARG;
-    if (n_ranks == 1 && rank == 0) return PSGSDF_OK;
-    return fail(c, PSGSDF_ERR_UNSUPPORTED, "multi-rank contexts are not built yet");
+    if (!c || rank < 0 || n_ranks < 1 || rank >= n_ranks) return PSGSDF_ERR_ARG;
+    c->rank = rank; c->n_ranks = n_ranks; c->inited = false;
+    return PSGSDF_OK;
 }
+int psgsdf_set_stream(psgsdf_ctx* c, void* hip_stream) {
+    if (!c) return PSGSDF_ERR_ARG;
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream; c->own_stream = false;
+    return PSGSDF_OK;
+}
+int psgsdf_mg_info(psgsdf_ctx* c, int32_t out[8]) {
+    if (!c || !c->inited) return PSGSDF_ERR_STATE;
+    out[0] = c->band.S; out[1] = c->band.Spad; out[2] = c->row0; out[3] = c->row1; out[4] = c->halo; out[5] = c->F; out[6] = c->rank; out[7] = c->n_ranks;
+    return PSGSDF_OK;
+}
+int psgsdf_mg_buffer(psgsdf_ctx* c, int which, void** ptr, int64_t* count) {
+    if (!c || !c->inited || !ptr || !count) return PSGSDF_ERR_STATE;
+    const int64_t Sp = c->band.Spad;
+    switch (which) {
+        case PSGSDF_MG_BUF_FRAME_ACC: *ptr = c->acc_frame; *count = (int64_t)c->F * kFrameRow; break;   /* f64 */
+        case PSGSDF_MG_BUF_SCAL: *ptr = c->mg_scal; *count = 16; break;                                 /* f64 */
+        case PSGSDF_MG_BUF_PCG: *ptr = c->mg_ext; *count = 3; break;                                    /* f64 */
+        case PSGSDF_MG_BUF_DIST: *ptr = c->band.dist; *count = Sp; break;                               /* f32 */
+        case PSGSDF_MG_BUF_BLK: *ptr = c->band.blk; *count = 14 * Sp; break;                            /* f32, 14 planes */
+        case PSGSDF_MG_BUF_ZP: *ptr = c->band.zp; *count = 2 * Sp; break;                               /* f32 pairs */
+        case PSGSDF_MG_BUF_RHO: *ptr = c->band.rho[0]; *count = 3 * Sp; break;                          /* f32, 3 planes */
+        case PSGSDF_MG_BUF_GRAD: *ptr = c->band.g[0]; *count = 3 * Sp; break;                           /* f32, 3 planes */
+        default: return PSGSDF_ERR_ARG;
+    }
+    return PSGSDF_OK;
+}
+static int mg_fold(psgsdf_ctx* c, std::initializer_list<int> slots) {
+    int h[8]; int n = 0; for (int s_ : slots) h[n++] = s_;
+    HIPCHK(c, hipMemcpyAsync(c->mg_slots, h, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    launch_sum_parts(c->part, c->PB, band_blocks(c), c->mg_slots, n, c->mg_scal, c->stream);
+    return 0;
+}
+static int mg_pcg_grid(psgsdf_ctx* c) {
+    const int nblk = std::max(1, band_blocks(c));
+    const int passes = (nblk + 704 - 1) / 704;
+    return (nblk + passes - 1) / passes;
+}
+int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SweepArgs a = make_args(c, arg);
+    int rc = 0;
+    switch (phase) {
+        case PSGSDF_MG_ENERGY: launch_energy(a, c->stream); return mg_fold(c, {SC_ENERGY, SC_NOBS});
+        case PSGSDF_MG_INIT_ALBEDO: launch_init_albedo(a, c->stream); return 0;
+        case PSGSDF_MG_LED_SUMS: launch_led_light_init(a, c->stream); return mg_fold(c, {SC_AUX0, SC_AUX1, SC_AUX2, SC_EN, SC_EL, SC_ACCEPT});
+        case PSGSDF_MG_LED_SET: {   // mg_scal holds the all-reduced sums
+            double s_[6]; HIPCHK(c, hipMemcpyAsync(s_, c->mg_scal, sizeof(s_), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+            float L[3] = {(float)s_[0] / (float)s_[3], (float)s_[1] / (float)s_[4], (float)s_[2] / (float)s_[5]};
+            return psgsdf_upload_light(c, L);
+        }
+        case PSGSDF_MG_SWEEP_ALBEDO: launch_sweep_albedo(a, c->stream); return mg_fold(c, {SC_ENERGY, SC_NOBS});
+        case PSGSDF_MG_APPLY_ALBEDO: launch_apply_albedo(a, c->stream); return mg_fold(c, {SC_ACCEPT});
+        case PSGSDF_MG_SWEEP_LIGHT: HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream)); launch_sweep_light(a, c->stream); return 0;
+        case PSGSDF_MG_SOLVE_LIGHT: launch_solve_light(a, c->frames, c->led_light, c->stream); return 0;
+        case PSGSDF_MG_SWEEP_POSE: HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream)); launch_sweep_pose(a, c->stream); return 0;
+        case PSGSDF_MG_SOLVE_POSE: launch_solve_pose(a, c->frames, c->stream); return 0;
+        case PSGSDF_MG_SWEEP_DIST: launch_sweep_dist(a, c->stream); return mg_fold(c, {SC_ENERGY, SC_NOBS});
+        case PSGSDF_MG_ASSEMBLE: launch_assemble(a, c->stream); return 0;
+        case PSGSDF_MG_PCG_INIT:
+            HIPCHK(c, hipMemsetAsync(c->pcg_sc, 0, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap), c->stream));
+            launch_pcg_init(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), c->stream);
+            launch_pcg_sum(c->pcg_part, mg_pcg_grid(c), -1, 1, c->mg_ext, c->stream);
+            return 0;
+        case PSGSDF_MG_PCG_MV:
+            a.ext = c->mg_ext; a.laplacian_reg = 0;
+            launch_pcg_mv(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), arg, 1, c->stream);
+            launch_pcg_sum(c->pcg_part, mg_pcg_grid(c), arg, 0, c->mg_ext, c->stream);
+            return 0;
+        case PSGSDF_MG_PCG_UPD:
+            a.ext = c->mg_ext; a.laplacian_reg = 0;
+            launch_pcg_upd(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), arg, c->stream);
+            launch_pcg_sum(c->pcg_part, mg_pcg_grid(c), arg, 1, c->mg_ext, c->stream);
+            return 0;
+        case PSGSDF_MG_APPLY_DIST: launch_apply_dist(a, c->stream); return mg_fold(c, {SC_ACCEPT});
+        case PSGSDF_MG_DERIVE: a.laplacian_reg = 0; launch_derive(a, arg, c->stream); return mg_fold(c, {SC_EN, SC_EL});
+        case PSGSDF_MG_SET_REG_SUMS: {   // mg_scal[0..1] = all-reduced Eikonal / Laplacian sums -> energy cache
+            double s_[2]; HIPCHK(c, hipMemcpyAsync(s_, c->mg_scal, sizeof(s_), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->en_sum = s_[0]; c->el_sum = s_[1];
+            return 0;
+        }
+        default: return fail(c, PSGSDF_ERR_ARG, "unknown phase %d", phase);
+    }
+    return rc;
+}
+// after a chunk of PCG passes [k0, k0+n): did it converge?  (mg_ext holds the reduced |r|^2, r.z of the last pass)
+int psgsdf_mg_pcg_status(psgsdf_ctx* c, int k0, int n, int32_t* iters, double* err) {
+    if (!c || !c->inited || n < 1 || n > 60) return PSGSDF_ERR_ARG;
+    HIPCHK(c, hipMemcpyAsync(c->host_buf, c->pcg_sc, sizeof(double) * kPcgScalHead, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->host_buf + kPcgScalHead, c->pcg_sc + kPcgScalHead + 3 * (size_t)k0, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->host_buf + kPcgScalHead + 3 * n, c->mg_ext, sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float rhsN = (float)c->host_buf[0];
+    *iters = -1; *err = 0;
+    if (rhsN == 0.f) { *iters = 0; return PSGSDF_OK; }
+    float thr = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
+    float rn2 = 0;
+    for (int q = 0; q < n; ++q) {
+        // |r|^2 of pass k0+q is published by the NEXT mv; for the last pass of the chunk it is still in mg_ext
+        rn2 = (float)(q == n - 1 ? c->host_buf[kPcgScalHead + 3 * n + 0] : c->host_buf[kPcgScalHead + 3 * q + 1]);
+        if (rn2 < thr) { *iters = k0 + q; break; }
+    }
+    *err = sqrt((double)rn2 / (double)rhsN);
+    if (*iters >= 0) c->last_cg_iters = *iters;
+    return PSGSDF_OK;
+}
+// the engine's band planes ARE the exchange planes: nothing to pack (the CPU oracle keeps a dense grid and needs these)
+int psgsdf_mg_pack_state(psgsdf_ctx* c) { return c ? PSGSDF_OK : PSGSDF_ERR_ARG; }
+int psgsdf_mg_unpack_state(psgsdf_ctx* c) { return c ? PSGSDF_OK : PSGSDF_ERR_ARG; }
+// effective regulariser weights are host state: the host program sets them after the global normalisation
+int psgsdf_mg_set_weights(psgsdf_ctx* c, float reg_n, float reg_l) { if (!c) return PSGSDF_ERR_ARG; c->reg_n = reg_n; c->reg_l = reg_l; return PSGSDF_OK; }
 
 // ---- measurement / test hooks -------------------------------------------------------------
 int psgsdf_set_profiling(psgsdf_ctx* c, int enabled) { if (!c) return PSGSDF_ERR_ARG; c->profiling = enabled != 0; return PSGSDF_OK; }

@@ -476,9 +476,9 @@ __device__ __forceinline__ float laplacian(const Band& b, int j, float vs_inv) {
 __global__ void __launch_bounds__(kBlock) k_derive(SweepArgs a, int update_grad) {
     __shared__ double red[kBlock / 64];
     const Band& b = a.b;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double en = 0, el = 0;
-    if (j < b.S) {
+    if (j < a.row1) {
         float n[3], dir[3];
         fd_grad(b, j, a.grid.vs_inv, n, dir);
         float g[3];
@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(kBlock) k_derive(SweepArgs a, int update_grad)
     block_part_store(el, PART(a, SC_EL), red);
 }
 void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_derive, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, update_grad);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_derive, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, update_grad);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -514,13 +514,13 @@ void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s) {
 // between band rebuilds, so the frame-major sweeps run over fully populated wavefronts instead of testing
 // (and mostly rejecting) every (voxel, frame) pair.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_obs_count(Band b, int F, int* __restrict__ counts) {
+__global__ void __launch_bounds__(kBlock) k_obs_count(Band b, int F, int row0, int row1, int* __restrict__ counts) {
     __shared__ int red[kBlock / 64];
     const int f = blockIdx.y, nch = gridDim.x;
     int cnt = 0;
     for (int it = 0; it < kObsChunk / kBlock; ++it) {
-        int j = blockIdx.x * kObsChunk + it * kBlock + threadIdx.x;
-        if (j < b.S) cnt += (int)((b.vis[(size_t)(f >> 6) * b.Spad + j] >> (f & 63)) & 1ull);
+        int j = row0 + blockIdx.x * kObsChunk + it * kBlock + threadIdx.x;
+        if (j < row1) cnt += (int)((b.vis[(size_t)(f >> 6) * b.Spad + j] >> (f & 63)) & 1ull);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
@@ -528,11 +528,11 @@ __global__ void __launch_bounds__(kBlock) k_obs_count(Band b, int F, int* __rest
     __syncthreads();
     if (threadIdx.x == 0) { int s = 0; for (int i = 0; i < kBlock / 64; ++i) s += red[i]; counts[f * nch + blockIdx.x] = s; }
 }
-void launch_obs_count(const Band& b, int F, int* counts, hipStream_t s) {
-    int nch = (b.S + kObsChunk - 1) / kObsChunk;
-    if (nch > 0 && F > 0) hipLaunchKernelGGL(k_obs_count, dim3(nch, F), dim3(kBlock), 0, s, b, F, counts);
+void launch_obs_count(const Band& b, int F, int row0, int row1, int* counts, hipStream_t s) {
+    int nch = (row1 - row0 + kObsChunk - 1) / kObsChunk;
+    if (nch > 0 && F > 0) hipLaunchKernelGGL(k_obs_count, dim3(nch, F), dim3(kBlock), 0, s, b, F, row0, row1, counts);
 }
-__global__ void __launch_bounds__(kBlock) k_obs_fill(Band b, int F, const int* __restrict__ offsets) {
+__global__ void __launch_bounds__(kBlock) k_obs_fill(Band b, int F, int row0, int row1, const int* __restrict__ offsets) {
     __shared__ int wsum[kBlock / 64];
     __shared__ int run_s;
     const int f = blockIdx.y, nch = gridDim.x;
@@ -540,8 +540,8 @@ __global__ void __launch_bounds__(kBlock) k_obs_fill(Band b, int F, const int* _
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int it = 0; it < kObsChunk / kBlock; ++it) {
-        int j = blockIdx.x * kObsChunk + it * kBlock + threadIdx.x;
-        bool flag = j < b.S && ((b.vis[(size_t)(f >> 6) * b.Spad + j] >> (f & 63)) & 1ull);
+        int j = row0 + blockIdx.x * kObsChunk + it * kBlock + threadIdx.x;
+        bool flag = j < row1 && ((b.vis[(size_t)(f >> 6) * b.Spad + j] >> (f & 63)) & 1ull);
         unsigned long long m = __ballot(flag);
         int pre = __popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0) wsum[w] = __popcll(m);
@@ -555,9 +555,34 @@ __global__ void __launch_bounds__(kBlock) k_obs_fill(Band b, int F, const int* _
         __syncthreads();
     }
 }
-void launch_obs_fill(const Band& b, int F, const int* offsets, hipStream_t s) {
-    int nch = (b.S + kObsChunk - 1) / kObsChunk;
-    if (nch > 0 && F > 0) hipLaunchKernelGGL(k_obs_fill, dim3(nch, F), dim3(kBlock), 0, s, b, F, offsets);
+void launch_obs_fill(const Band& b, int F, int row0, int row1, const int* offsets, hipStream_t s) {
+    int nch = (row1 - row0 + kObsChunk - 1) / kObsChunk;
+    if (nch > 0 && F > 0) hipLaunchKernelGGL(k_obs_fill, dim3(nch, F), dim3(kBlock), 0, s, b, F, row0, row1, offsets);
+}
+// halo width of a row partition: the largest |column row - row| over all ELL columns (contiguous halo ranges suffice
+// because the band is sorted by linear index)
+__global__ void __launch_bounds__(kBlock) k_reach(Band b, int* __restrict__ reach) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = 0;
+    if (i < b.S) for (int q = 1; q < kNQ; ++q) { int c = b.col[(size_t)q * b.Spad + i]; int d = c > i ? c - i : i - c; r = d > r ? d : r; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) r = max(r, __shfl_down(r, o, 64));
+    if ((threadIdx.x & 63) == 0 && r > 0) atomicMax(reach, r);
+}
+void launch_reach(const Band& b, int* d_reach, hipStream_t s) {
+    if (b.S > 0) hipLaunchKernelGGL(k_reach, dim3((b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, b, d_reach);
+}
+// multi-rank helpers: fold per-workgroup partials into a few doubles that the host program all-reduces
+__global__ void __launch_bounds__(kBlock) k_sum_parts(const double* __restrict__ part, int PB, int nblk, const int* __restrict__ slots, int nslots, double* __restrict__ out) {
+    __shared__ double red[kBlock / 64];
+    for (int s = 0; s < nslots; ++s) {
+        double t = block_total(part + (size_t)slots[s] * PB, nblk, red);
+        if (threadIdx.x == 0) out[s] = t;
+        __syncthreads();
+    }
+}
+void launch_sum_parts(const double* part, int PB, int nblk, const int* slots, int nslots, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(kBlock), 0, s, part, PB, nblk, slots, nslots, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -573,8 +598,8 @@ __global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
     __shared__ FrameP sf[kMaxFramesLds];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= b.S) return;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.row1) return;
     float xs[3] = {b.xs[0][j], b.xs[1][j], b.xs[2][j]};
     int count = 0; float rho[3] = {0, 0, 0};
     FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
@@ -590,7 +615,7 @@ __global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
     }
 }
 void launch_init_albedo(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_init_albedo, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_init_albedo, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 
 // getPSEnergy PsOptimizer.cpp:47-78 / LedOptimizer.cpp:40-71; LED_INIT: computeLightIntensive
@@ -602,10 +627,10 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
     __shared__ double red[kBlock / 64];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double E = 0, nobs = 0, sI[3] = {0, 0, 0}, sR[3] = {0, 0, 0};
     float Ef = 0.f;
-    if (j < b.S) {
+    if (j < a.row1) {
         Vox v; load_vox(b, j, v);
         float shfd[kMaxBasis];
         if (!ModelTraits<MODEL>::LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
@@ -638,14 +663,14 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
     }
 }
 void launch_energy(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S <= 0) return;
-    dim3 g((a.b.S + kBlock - 1) / kBlock), bl(kBlock);
+    if (a.row1 <= a.row0) return;
+    dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
     if (a.model == 0) hipLaunchKernelGGL((k_energy<0, false>), g, bl, 0, s, a);
     else if (a.model == 1) hipLaunchKernelGGL((k_energy<1, false>), g, bl, 0, s, a);
     else hipLaunchKernelGGL((k_energy<2, false>), g, bl, 0, s, a);
 }
 void launch_led_light_init(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL((k_energy<2, true>), dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL((k_energy<2, true>), dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 
 // albedo normal equations (diagonal): optimizeAlbedoAll PsOptimizer.cpp:85-121 / LedOptimizer.cpp:162-196,
@@ -657,9 +682,9 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
     __shared__ double red[kBlock / 64];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double E = 0, nobs = 0;
-    if (j < b.S) {
+    if (j < a.row1) {
         Vox v; load_vox(b, j, v);
         float shfd[kMaxBasis], shg[kMaxBasis];
         if (!ModelTraits<MODEL>::LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
@@ -691,8 +716,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
     block_part_store(nobs, PART(a, SC_NOBS), red);
 }
 void launch_sweep_albedo(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S <= 0) return;
-    dim3 g((a.b.S + kBlock - 1) / kBlock), bl(kBlock);
+    if (a.row1 <= a.row0) return;
+    dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
     if (a.model == 0) hipLaunchKernelGGL((k_sweep_albedo<0>), g, bl, 0, s, a);
     else if (a.model == 1) hipLaunchKernelGGL((k_sweep_albedo<1>), g, bl, 0, s, a);
     else hipLaunchKernelGGL((k_sweep_albedo<2>), g, bl, 0, s, a);
@@ -701,9 +726,9 @@ void launch_sweep_albedo(const SweepArgs& a, hipStream_t s) {
 __global__ void __launch_bounds__(kBlock) k_apply_albedo(SweepArgs a) {
     __shared__ double red[kBlock / 64];
     const Band& b = a.b;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double cnt = 0;
-    if (j < b.S) {
+    if (j < a.row1) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             float h = b.aH[(size_t)ch * b.Spad + j];
@@ -716,7 +741,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_albedo(SweepArgs a) {
     block_part_store(cnt, PART(a, SC_ACCEPT), red);
 }
 void launch_apply_albedo(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_apply_albedo, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_apply_albedo, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1051,9 +1076,9 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
     __shared__ double red[kBlock / 64];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double E = 0, nobs = 0;
-    if (j < b.S) {
+    if (j < a.row1) {
         Vox v; load_vox(b, j, v);
         const float vs_inv = a.grid.vs_inv;
         float grad[3] = {b.gfd[0][j], b.gfd[1][j], b.gfd[2][j]};
@@ -1208,8 +1233,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
     block_part_store(nobs, PART(a, SC_NOBS), red);
 }
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S <= 0) return;
-    dim3 g((a.b.S + kBlock - 1) / kBlock), bl(kBlock);
+    if (a.row1 <= a.row0) return;
+    dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
     if (a.model == 0) hipLaunchKernelGGL((k_sweep_dist<0>), g, bl, 0, s, a);
     else if (a.model == 1) hipLaunchKernelGGL((k_sweep_dist<1>), g, bl, 0, s, a);
     else hipLaunchKernelGGL((k_sweep_dist<2>), g, bl, 0, s, a);
@@ -1221,11 +1246,11 @@ void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
 __global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
     __shared__ double acc[kNQ][kBlock];
     const Band& b = a.b;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < kNQ; ++q) acc[q][tid] = 0.0;
-    if (i >= b.S) return;
+    if (i >= a.row1) return;
     double rhs = 0.0;
     for (int c = 0; c < 7; ++c) {
         int jrow, s; int coff[3] = {0, 0, 0};
@@ -1256,7 +1281,7 @@ __global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
     b.rhs[i] = (float)rhs;
 }
 void launch_assemble(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_assemble, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_assemble, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 
 // Jacobi-PCG with Eigen::ConjugateGradient semantics: x0 = 0, threshold = max(eps^2 |b|^2, FLT_MIN),
@@ -1272,7 +1297,7 @@ __global__ void __launch_bounds__(kBlock) k_pcg_init(SweepArgs a, double* sc, do
     __shared__ double red[kBlock / 64];
     const Band& b = a.b;
     double bb = 0, rz = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b.S; i += gridDim.x * blockDim.x) {
+    for (int i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x; i < a.row1; i += gridDim.x * blockDim.x) {
         float dg = b.H[i];
         if (a.damping != 0.0f) dg += a.damping * dg;
         float inv = dg != 0.f ? 1.0f / dg : 1.0f;
@@ -1285,7 +1310,7 @@ __global__ void __launch_bounds__(kBlock) k_pcg_init(SweepArgs a, double* sc, do
     block_part_store(rz, pcg_part(part, -1, 2), red);
 }
 void launch_pcg_init(const SweepArgs& a, double* sc, double* part, int G, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_init, dim3(G), dim3(kBlock), 0, s, a, sc, part);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_pcg_init, dim3(G), dim3(kBlock), 0, s, a, sc, part);
 }
 __device__ __forceinline__ float pcg_threshold(float rhsNorm2) { return fmaxf(FLT_EPSILON * FLT_EPSILON * rhsNorm2, FLT_MIN); }
 
@@ -1306,7 +1331,8 @@ __global__ void __launch_bounds__(kBlock) k_pcg_mv(SweepArgs a, double* sc, doub
     const Band& b = a.b;
     // reduce what the previous kernel produced: |r|^2 and r.z of iteration k-1 (k = 0: |b|^2 and r0.z0)
     double s1, s2;
-    block_total2(pcg_part(part, k - 1, 1), pcg_part(part, k - 1, 2), gridDim.x, red, s1, s2);
+    if (a.ext) { s1 = a.ext[0]; s2 = a.ext[1]; }   // multi-rank: already reduced over workgroups and ranks
+    else block_total2(pcg_part(part, k - 1, 1), pcg_part(part, k - 1, 2), gridDim.x, red, s1, s2);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (k == 0) { sc[0] = s1; sc[1] = s2; } else { sc[kPcgScalHead + 3 * (k - 1) + 1] = s1; sc[kPcgScalHead + 3 * (k - 1) + 2] = s2; }
     }
@@ -1320,10 +1346,10 @@ __global__ void __launch_bounds__(kBlock) k_pcg_mv(SweepArgs a, double* sc, doub
         beta = absNew / absOld;
     }
     double pt = 0;
-    for (int i0 = blockIdx.x * blockDim.x; i0 < b.S; i0 += gridDim.x * blockDim.x) {
+    for (int i0 = a.row0 + blockIdx.x * blockDim.x; i0 < a.row1; i0 += gridDim.x * blockDim.x) {
         const int i = i0 + threadIdx.x;
-        const bool live = i < b.S;
-        const int ii = live ? i : b.S - 1;
+        const bool live = i < a.row1;
+        const int ii = live ? i : a.row1 - 1;
         // 13 common columns: coefficient, column and gather loads are all independent of each other
         float h[kNQCommon]; int c[kNQCommon];
 #pragma unroll
@@ -1355,7 +1381,7 @@ __global__ void __launch_bounds__(kBlock) k_pcg_mv(SweepArgs a, double* sc, doub
     block_part_store(pt, pcg_part(part, k, 0), red);
 }
 void launch_pcg_mv(const SweepArgs& a, double* sc, double* part, int G, int k, int with_damping, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_mv, dim3(G), dim3(kBlock), 0, s, a, sc, part, k, with_damping);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_pcg_mv, dim3(G), dim3(kBlock), 0, s, a, sc, part, k, with_damping);
 }
 // x += alpha p ; r -= alpha t ; z = M^-1 r ; partial |r|^2 and r.z
 __global__ void __launch_bounds__(kBlock) k_pcg_upd(SweepArgs a, double* sc, double* part, int k) {
@@ -1367,12 +1393,12 @@ __global__ void __launch_bounds__(kBlock) k_pcg_upd(SweepArgs a, double* sc, dou
         if (threadIdx.x == 0) { pcg_part(part, k, 1)[blockIdx.x] = 0.0; pcg_part(part, k, 2)[blockIdx.x] = 0.0; }
         return;
     }
-    const double ptot = block_total(pcg_part(part, k, 0), gridDim.x, red);
+    const double ptot = a.ext ? a.ext[2] : block_total(pcg_part(part, k, 0), gridDim.x, red);
     if (blockIdx.x == 0 && threadIdx.x == 0) sc[kPcgScalHead + 3 * k + 0] = ptot;
     float absNew = (float)(k == 0 ? sc[1] : sc[kPcgScalHead + 3 * (k - 1) + 2]);
     float alpha = absNew / (float)ptot;
     double rr = 0, rz = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b.S; i += gridDim.x * blockDim.x) {
+    for (int i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x; i < a.row1; i += gridDim.x * blockDim.x) {
         const float pi = b.p[i];
         float x = b.x[i] + alpha * pi;
         float r = b.r[i] - alpha * b.t[i];
@@ -1384,7 +1410,7 @@ __global__ void __launch_bounds__(kBlock) k_pcg_upd(SweepArgs a, double* sc, dou
     block_part_store(rz, pcg_part(part, k, 2), red);
 }
 void launch_pcg_upd(const SweepArgs& a, double* sc, double* part, int G, int k, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_pcg_upd, dim3(G), dim3(kBlock), 0, s, a, sc, part, k);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_pcg_upd, dim3(G), dim3(kBlock), 0, s, a, sc, part, k);
 }
 // publish |r|^2 and r.z of pass k (end of a chunk: the host has to see them)
 __global__ void __launch_bounds__(kBlock) k_pcg_final(double* sc, double* part, int G, int k) {
@@ -1400,6 +1426,20 @@ __global__ void __launch_bounds__(kBlock) k_pcg_final(double* sc, double* part, 
 void launch_pcg_final(double* sc, double* part, int G, int k, hipStream_t s) {
     hipLaunchKernelGGL(k_pcg_final, dim3(1), dim3(kBlock), 0, s, sc, part, G, k);
 }
+__global__ void __launch_bounds__(kBlock) k_pcg_sum(const double* __restrict__ part_c, int G, int k, int which, double* __restrict__ out) {
+    __shared__ double red[kBlock / 64];
+    double* part = const_cast<double*>(part_c);
+    if (which == 0) { double t = block_total(pcg_part(part, k, 0), G, red); if (threadIdx.x == 0) out[2] = t; }
+    else {
+        double t1 = block_total(pcg_part(part, k, 1), G, red);
+        __syncthreads();
+        double t2 = block_total(pcg_part(part, k, 2), G, red);
+        if (threadIdx.x == 0) { out[0] = t1; out[1] = t2; }
+    }
+}
+void launch_pcg_sum(const double* part, int G, int k, int which, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_sum, dim3(1), dim3(kBlock), 0, s, part, G, k, which, out);
+}
 // debug: y = H x without damping
 __global__ void __launch_bounds__(kBlock) k_matvec(SweepArgs a, const float* x, float* y) {
     const Band& b = a.b;
@@ -1414,22 +1454,22 @@ __global__ void __launch_bounds__(kBlock) k_matvec(SweepArgs a, const float* x, 
     y[i] = (float)acc;
 }
 void launch_matvec(const SweepArgs& a, const float* x, float* y, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_matvec, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, x, y);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_matvec, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, x, y);
 }
 // updateDist accept rule OptimizerAux.cpp:162-188
 __global__ void __launch_bounds__(kBlock) k_apply_dist(SweepArgs a) {
     __shared__ double red[kBlock / 64];
     const Band& b = a.b;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double cnt = 0;
-    if (j < b.S) {
+    if (j < a.row1) {
         float d = b.x[j];
         if ((double)fabsf(d) < sqrt(3.0) * (double)a.grid.vs) { b.dist[j] -= d; cnt = 1.0; }
     }
     block_part_store(cnt, PART(a, SC_ACCEPT), red);
 }
 void launch_apply_dist(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_apply_dist, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_apply_dist, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 
 }  // namespace psg
