@@ -8,8 +8,10 @@ scene, inputs resident in HBM before the timed region.  Prints ONE JSON line on 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 256] [--frames 50] [--model SH1]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (round 1): every rank runs its own replica of the workload on its own GPU ("replicas"; the
-z-slab partition with RCCL halo exchange is DESIGN.md §7 work in progress), value = N * it/s.
+N > 1: weak scaling over z-slabs.  The grid grows to 256 x 256 x (256*N) -- N copies of the scene stacked
+along z, each with its own 50 keyframes -- one process per GPU owns one slab; the host program
+psgradientsdf_amd/distributed.py runs the phases and exchanges halos / all-reduces over RCCL.  value = N * it/s of the
+whole job (256^3 x 50-frame equivalents per second).
 """
 from __future__ import annotations
 
@@ -61,6 +63,7 @@ def main():
     ap.add_argument("--model", default="SH1", choices=["SH1", "SH2", "LED"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--force-slab", action="store_true", help="run the multi-rank host program even with one rank (overhead measurement)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -68,9 +71,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     import torch
-    if world > 1:
+    slab = world > 1 or args.force_slab
+    if slab:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     device = local_rank if world > 1 else 0
@@ -82,12 +87,28 @@ def main():
     st = capi.default_settings(model_id)
     if args.model == "LED":   # config_basket_LED.json
         st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0
+    if world > 1:
+        sc = synth.tile_scene(sc, world)
     eng = capi.load_engine(sc, sc.K, st, device)
-    eng.load_scene(sc)
-    eng.init_albedo()
-    eng.normalize_weights()
-    S = eng.info().n_band
-    n_obs = eng.step(capi.ALBEDO)["n_obs"]
+    run = None
+    if slab:
+        from psgradientsdf_amd.distributed import SlabRunner
+        eng.comm_init(rank, world)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        eng.load_scene(sc)
+        run = SlabRunner(eng, dist, cuda=True)
+        run.init_albedo()
+        run.normalize_weights()
+        S = run.S // world                      # per-slab band size
+        n_obs = run.step(capi.ALBEDO)["n_obs"] // world
+        iterate = lambda k: run.iterate(capi.ALL, k)
+    else:
+        eng.load_scene(sc)
+        eng.init_albedo()
+        eng.normalize_weights()
+        S = eng.info().n_band
+        n_obs = eng.step(capi.ALBEDO)["n_obs"]
+        iterate = lambda k: eng.iterate(capi.ALL, k)
 
     def barrier():
         torch.cuda.synchronize()
@@ -95,12 +116,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    eng.iterate(capi.ALL, args.warmup)
+    iterate(args.warmup)
+    # pick the dominant kernel (largest total time per iteration) from a short synchronous-event pass, then time THAT
+    # kernel inside the timed region with HIP events recorded on the launch stream (no host sync)
+    kernels, dom = {}, "sweep_dist"
+    if not args.no_breakdown:
+        eng.set_profiling(True)
+        eng.reset_kernel_times()
+        nprof = 3
+        iterate(nprof)
+        kt = eng.kernel_times()
+        eng.set_profiling(False)
+        kernels = {k: {"ms_per_iter": v[0] / nprof, "launches_per_iter": v[1] / nprof} for k, v in kt.items()}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_iter"] if algorithmic_bytes(k, 1, 1, 1, 1, 1) else -1)
     eng.reset_kernel_times()
-    eng.watch_kernel("sweep_dist")       # HIP events on the launch stream, no host sync
+    eng.watch_kernel(dom)
     barrier()
     t0 = time.perf_counter()
-    recs = eng.iterate(capi.ALL, args.steps)
+    recs = iterate(args.steps)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -109,7 +142,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    watched = eng.kernel_times().get("sweep_dist", (0.0, 0))
+    watched = eng.kernel_times().get(dom, (0.0, 0))
     eng.watch_kernel("")
 
     ms_per_step = 1e3 * elapsed / args.steps
@@ -125,29 +158,14 @@ def main():
         "config": {"workload": f"synthetic {args.width}x{args.height} RGB-D bumpy sphere, {args.grid}^3 grid, {args.model}, {args.frames} keyframes, "
                                "albedo+light+distance+pose blocks, Cauchy IRLS, Eikonal reg (config_skorates.json settings)",
                    "band_voxels": int(S), "observations": int(n_obs), "pcg_iters_per_step": cg_iters,
-                   "parallelism": "single GPU" if world == 1 else f"{world} replicas (one per GPU)"},
+                   "parallelism": "single GPU" if world == 1 else f"{world} z-slabs (one per GPU), grid 256x256x{256 * world}, {args.frames * world} keyframes, RCCL halo exchange + all-reduce"},
     }
 
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live with HIP events inside the timed region
         lap = st.reg_weight_l != 0.0
-        kernels = {}
-        if not args.no_breakdown:
-            eng.set_profiling(True)
-            eng.reset_kernel_times()
-            nprof = 3
-            eng.iterate(capi.ALL, nprof)
-            kt = eng.kernel_times()
-            eng.set_profiling(False)
-            kernels = {k: {"ms_per_iter": v[0] / nprof, "launches_per_iter": v[1] / nprof, "avg_us": 1e3 * v[0] / max(v[1], 1)} for k, v in kt.items()}
-        dom = "sweep_dist"
-        if kernels:
-            dom = max(kernels, key=lambda k: kernels[k]["ms_per_iter"] if algorithmic_bytes(k, 1, 1, 1, 1, 1) else -1)
-        if dom == "sweep_dist" and watched[1] > 0:
-            avg_ms = watched[0] / watched[1]
-        else:
-            avg_ms = kernels[dom]["avg_us"] / 1e3
-        nbytes = algorithmic_bytes(dom, S, n_obs, args.width, args.height, args.frames, lap)
+        avg_ms = watched[0] / max(watched[1], 1)
+        nbytes = algorithmic_bytes(dom, S, n_obs, args.width, args.height, args.frames, lap)   # per GPU (one slab)
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -157,10 +175,13 @@ def main():
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms}
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms,
+                           "launches_timed": int(watched[1])}
         # whole-iteration algorithmic bytes (SURVEY.md §8d formula) for reference
         U = min(48 * n_obs, 12 * args.width * args.height * args.frames)
         B_iter = 4 * (S * 60 + U) + 120 * S + 124 * cg_iters * S
+        if run is not None:
+            out["config"]["collectives_per_step"] = run.n_collectives / max(args.steps + args.warmup, 1)
         out["iteration"] = {"algorithmic_bytes": B_iter, "achieved_GBs": B_iter * (value / world) / 1e9,
                             "frac_of_hbm_peak": B_iter * (value / world) / 1e9 / HBM_PEAK_GBS}
         if kernels:
@@ -168,7 +189,7 @@ def main():
         out["setup_s"] = {"scene_generation": round(t_gen, 1)}
 
         # ---- CPU baseline: the oracle (a port of the reference's arithmetic) on the host cores, bounded sample
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not slab and not args.no_cpu_baseline:
             from oracle import oracle
             orc = oracle.Oracle(sc, sc.K, st, threads=1)
             orc.load_scene(sc)

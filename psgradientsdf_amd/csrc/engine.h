@@ -17,7 +17,7 @@
 namespace psg {
 
 constexpr int kBlock = 256;          // threads per workgroup (4 wavefronts of 64)
-constexpr int kMaxFramesLds = 128;   // frame records staged in LDS (12 KiB)
+constexpr int kMaxFramesLds = 640;   // frame records staged in dynamic LDS: 96 B each, 60 KiB at the limit
 constexpr int kNQ = 19;              // columns of one assembled distance-system row (ELL)
 constexpr int kNQCommon = 13;        // self + 6 axis neighbours + 6 mixed-sign pairs: all a forward-only stencil touches
 constexpr int kMaxBasis = 9;

@@ -113,6 +113,8 @@ __device__ __forceinline__ double block_total(const double* part, int n, double*
 }
 #define PART(a, slot) ((a).acc.part + (size_t)(slot) * (a).acc.PB)
 
+// frame records (pose, light) of all keyframes staged in dynamic LDS: F * 96 B (<= 60 KiB, F <= kMaxFramesLds)
+extern __shared__ __align__(16) unsigned char psg_dyn_smem[];
 __device__ __forceinline__ void load_frames(FrameP* sf, const FrameP* frames, int F) {
     const float* src = (const float*)frames; float* dst = (float*)sf;
     for (int i = threadIdx.x; i < F * (int)(sizeof(FrameP) / 4); i += blockDim.x) dst[i] = src[i];
@@ -595,7 +597,7 @@ void launch_sum_parts(const double* part, int PB, int nblk, const int* slots, in
 
 // Optimizer.cpp:50-81 initAlbedo
 __global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
-    __shared__ FrameP sf[kMaxFramesLds];
+    FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
     int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -615,7 +617,7 @@ __global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
     }
 }
 void launch_init_albedo(const SweepArgs& a, hipStream_t s) {
-    if (a.row1 > a.row0) hipLaunchKernelGGL(k_init_albedo, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_init_albedo, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), a.F * sizeof(FrameP), s, a);
 }
 
 // getPSEnergy PsOptimizer.cpp:47-78 / LedOptimizer.cpp:40-71; LED_INIT: computeLightIntensive
@@ -623,7 +625,7 @@ void launch_init_albedo(const SweepArgs& a, hipStream_t s) {
 template <int MODEL, bool LED_INIT>
 __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
     constexpr int NB = ModelTraits<MODEL>::NB;
-    __shared__ FrameP sf[kMaxFramesLds];
+    FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
     __shared__ double red[kBlock / 64];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
@@ -665,12 +667,12 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
 void launch_energy(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;
     dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_energy<0, false>), g, bl, 0, s, a);
-    else if (a.model == 1) hipLaunchKernelGGL((k_energy<1, false>), g, bl, 0, s, a);
-    else hipLaunchKernelGGL((k_energy<2, false>), g, bl, 0, s, a);
+    if (a.model == 0) hipLaunchKernelGGL((k_energy<0, false>), g, bl, a.F * sizeof(FrameP), s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_energy<1, false>), g, bl, a.F * sizeof(FrameP), s, a);
+    else hipLaunchKernelGGL((k_energy<2, false>), g, bl, a.F * sizeof(FrameP), s, a);
 }
 void launch_led_light_init(const SweepArgs& a, hipStream_t s) {
-    if (a.row1 > a.row0) hipLaunchKernelGGL((k_energy<2, true>), dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL((k_energy<2, true>), dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), a.F * sizeof(FrameP), s, a);
 }
 
 // albedo normal equations (diagonal): optimizeAlbedoAll PsOptimizer.cpp:85-121 / LedOptimizer.cpp:162-196,
@@ -678,7 +680,7 @@ void launch_led_light_init(const SweepArgs& a, hipStream_t s) {
 template <int MODEL>
 __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
     constexpr int NB = ModelTraits<MODEL>::NB;
-    __shared__ FrameP sf[kMaxFramesLds];
+    FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
     __shared__ double red[kBlock / 64];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
@@ -718,9 +720,9 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
 void launch_sweep_albedo(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;
     dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_sweep_albedo<0>), g, bl, 0, s, a);
-    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_albedo<1>), g, bl, 0, s, a);
-    else hipLaunchKernelGGL((k_sweep_albedo<2>), g, bl, 0, s, a);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_albedo<0>), g, bl, a.F * sizeof(FrameP), s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_albedo<1>), g, bl, a.F * sizeof(FrameP), s, a);
+    else hipLaunchKernelGGL((k_sweep_albedo<2>), g, bl, a.F * sizeof(FrameP), s, a);
 }
 // delta = b / ((1+damping) H), updateAlbedo accept rule OptimizerAux.cpp:120-150
 __global__ void __launch_bounds__(kBlock) k_apply_albedo(SweepArgs a) {
@@ -1072,7 +1074,7 @@ template <int MODEL>
 __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
-    __shared__ FrameP sf[kMaxFramesLds];
+    FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
     __shared__ double red[kBlock / 64];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
@@ -1235,9 +1237,9 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;
     dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_sweep_dist<0>), g, bl, 0, s, a);
-    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_dist<1>), g, bl, 0, s, a);
-    else hipLaunchKernelGGL((k_sweep_dist<2>), g, bl, 0, s, a);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_dist<0>), g, bl, a.F * sizeof(FrameP), s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_dist<1>), g, bl, a.F * sizeof(FrameP), s, a);
+    else hipLaunchKernelGGL((k_sweep_dist<2>), g, bl, a.F * sizeof(FrameP), s, a);
 }
 
 // H = sum_j P_j^T B_j P_j assembled row-wise into 19 fixed column offsets (ELL); a row receives

@@ -268,3 +268,42 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         light_gt=np.asarray(light, np.float32), frame_idx=np.arange(F, dtype=np.int32),
         R0=R0, A=A, extent=extent,
     )
+
+
+def tile_scene(sc, n):
+    """Weak-scaling scene: n copies of `sc` stacked along z (grid N x N x n*N), each copy observed by its own copy of
+    the F keyframes (poses translated with it), so per-slab work is exactly that of the single scene.  O(size) numpy
+    copies only -- no re-rendering."""
+    if n == 1:
+        return sc
+    N, F = int(sc.dim[0]), sc.F
+    nz = int(sc.dim[2])
+    plane = int(sc.dim[0]) * int(sc.dim[1])
+    nvox = plane * nz
+
+    def tz(a):          # [..., nvox] -> [..., n*nvox], copies consecutive along z (slowest index)
+        return np.ascontiguousarray(np.concatenate([a] * n, axis=-1))
+
+    wpv = (F * n + 63) // 64
+    vis = np.zeros((n * nvox, wpv), np.uint64)
+    near = np.nonzero((sc.vis != 0).any(axis=1))[0]
+    bits = [((sc.vis[near, f >> 6] >> np.uint64(f & 63)) & np.uint64(1)).astype(bool) for f in range(F)]
+    for c in range(n):
+        for f in range(F):
+            g = c * F + f
+            rows = near[bits[f]] + c * nvox
+            vis[rows, g >> 6] |= np.uint64(1) << np.uint64(g & 63)
+    poses = np.tile(sc.poses.reshape(1, F, 16), (n, 1, 1)).astype(np.float32)
+    poses_gt = np.tile(sc.poses_gt.reshape(1, F, 16), (n, 1, 1)).astype(np.float32)
+    vs = float(sc.voxel_size)
+    for c in range(n):
+        dz = np.float32(vs * nz * (c - 0.5 * (n - 1)))
+        poses[c, :, 11] += dz
+        poses_gt[c, :, 11] += dz
+    light = sc.light_gt if sc.model == "LED" else np.tile(sc.light_gt, (n, 1))
+    d = dict(sc.__dict__)
+    d.update(F=F * n, dim=np.array([sc.dim[0], sc.dim[1], nz * n], np.int32), dist=tz(sc.dist), grad=tz(sc.grad), weight=tz(sc.weight),
+             rgb=tz(sc.rgb), albedo_gt=tz(sc.albedo_gt), vis=vis, vis_words=wpv,
+             images=np.ascontiguousarray(np.tile(sc.images, (n, 1, 1, 1))), poses=poses.reshape(n * F, 16), poses_gt=poses_gt.reshape(n * F, 16),
+             light_gt=np.asarray(light, np.float32), frame_idx=np.arange(F * n, dtype=np.int32))
+    return Scene(**d)
