@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--force-slab", action="store_true", help="run the multi-rank host program even with one rank (overhead measurement)")
     args = ap.parse_args()
 
+    # RCCL / HIP runtime banners go to the C-level stdout: keep the real stdout for the ONE JSON line only
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -77,7 +80,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     device = local_rank if world > 1 else 0
 
     t_gen = time.time()
@@ -164,7 +167,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live with HIP events inside the timed region
         lap = st.reg_weight_l != 0.0
-        avg_ms = watched[0] / max(watched[1], 1)
+        avg_ms = watched[0] / max(watched[1], 1) if watched[1] else float("nan")
         nbytes = algorithmic_bytes(dom, S, n_obs, args.width, args.height, args.frames, lap)   # per GPU (one slab)
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         traffic = None
@@ -202,7 +205,7 @@ def main():
                                    "sample": f"1 full Gauss-Newton iteration of the same {args.grid}^3 x {args.frames} scene "
                                              f"(4 blocks + 4 energy evaluations), single-threaded C oracle with indexed band lookup, {tc:.1f} s"}
             orc.close()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -797,7 +797,7 @@ int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
     SweepArgs a = make_args(c, arg);
     int rc = 0;
     switch (phase) {
-        case PSGSDF_MG_ENERGY: launch_energy(a, c->stream); return mg_fold(c, {SC_ENERGY, SC_NOBS});
+        case PSGSDF_MG_ENERGY: timed(c, "energy", [&] { launch_energy(a, c->stream); }); return mg_fold(c, {SC_ENERGY, SC_NOBS});
         case PSGSDF_MG_INIT_ALBEDO: launch_init_albedo(a, c->stream); return 0;
         case PSGSDF_MG_LED_SUMS: launch_led_light_init(a, c->stream); return mg_fold(c, {SC_AUX0, SC_AUX1, SC_AUX2, SC_EN, SC_EL, SC_ACCEPT});
         case PSGSDF_MG_LED_SET: {   // mg_scal holds the all-reduced sums
@@ -805,14 +805,14 @@ int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
             float L[3] = {(float)s_[0] / (float)s_[3], (float)s_[1] / (float)s_[4], (float)s_[2] / (float)s_[5]};
             return psgsdf_upload_light(c, L);
         }
-        case PSGSDF_MG_SWEEP_ALBEDO: launch_sweep_albedo(a, c->stream); return mg_fold(c, {SC_ENERGY, SC_NOBS});
-        case PSGSDF_MG_APPLY_ALBEDO: launch_apply_albedo(a, c->stream); return mg_fold(c, {SC_ACCEPT});
-        case PSGSDF_MG_SWEEP_LIGHT: HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream)); launch_sweep_light(a, c->stream); return 0;
-        case PSGSDF_MG_SOLVE_LIGHT: launch_solve_light(a, c->frames, c->led_light, c->stream); return 0;
-        case PSGSDF_MG_SWEEP_POSE: HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream)); launch_sweep_pose(a, c->stream); return 0;
-        case PSGSDF_MG_SOLVE_POSE: launch_solve_pose(a, c->frames, c->stream); return 0;
-        case PSGSDF_MG_SWEEP_DIST: launch_sweep_dist(a, c->stream); return mg_fold(c, {SC_ENERGY, SC_NOBS});
-        case PSGSDF_MG_ASSEMBLE: launch_assemble(a, c->stream); return 0;
+        case PSGSDF_MG_SWEEP_ALBEDO: timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); }); return mg_fold(c, {SC_ENERGY, SC_NOBS});
+        case PSGSDF_MG_APPLY_ALBEDO: timed(c, "apply_albedo", [&] { launch_apply_albedo(a, c->stream); }); return mg_fold(c, {SC_ACCEPT});
+        case PSGSDF_MG_SWEEP_LIGHT: HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream)); timed(c, "sweep_light", [&] { launch_sweep_light(a, c->stream); }); return 0;
+        case PSGSDF_MG_SOLVE_LIGHT: timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->stream); }); return 0;
+        case PSGSDF_MG_SWEEP_POSE: HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream)); timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); }); return 0;
+        case PSGSDF_MG_SOLVE_POSE: timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->stream); }); return 0;
+        case PSGSDF_MG_SWEEP_DIST: timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); }); return mg_fold(c, {SC_ENERGY, SC_NOBS});
+        case PSGSDF_MG_ASSEMBLE: timed(c, "assemble", [&] { launch_assemble(a, c->stream); }); return 0;
         case PSGSDF_MG_PCG_INIT:
             HIPCHK(c, hipMemsetAsync(c->pcg_sc, 0, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap), c->stream));
             launch_pcg_init(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), c->stream);
@@ -820,16 +820,16 @@ int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
             return 0;
         case PSGSDF_MG_PCG_MV:
             a.ext = c->mg_ext; a.laplacian_reg = 0;
-            launch_pcg_mv(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), arg, 1, c->stream);
+            timed(c, "pcg_mv", [&] { launch_pcg_mv(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), arg, 1, c->stream); });
             launch_pcg_sum(c->pcg_part, mg_pcg_grid(c), arg, 0, c->mg_ext, c->stream);
             return 0;
         case PSGSDF_MG_PCG_UPD:
             a.ext = c->mg_ext; a.laplacian_reg = 0;
-            launch_pcg_upd(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), arg, c->stream);
+            timed(c, "pcg_upd", [&] { launch_pcg_upd(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), arg, c->stream); });
             launch_pcg_sum(c->pcg_part, mg_pcg_grid(c), arg, 1, c->mg_ext, c->stream);
             return 0;
-        case PSGSDF_MG_APPLY_DIST: launch_apply_dist(a, c->stream); return mg_fold(c, {SC_ACCEPT});
-        case PSGSDF_MG_DERIVE: a.laplacian_reg = 0; launch_derive(a, arg, c->stream); return mg_fold(c, {SC_EN, SC_EL});
+        case PSGSDF_MG_APPLY_DIST: timed(c, "apply_dist", [&] { launch_apply_dist(a, c->stream); }); return mg_fold(c, {SC_ACCEPT});
+        case PSGSDF_MG_DERIVE: a.laplacian_reg = 0; timed(c, "derive", [&] { launch_derive(a, arg, c->stream); }); return mg_fold(c, {SC_EN, SC_EL});
         case PSGSDF_MG_SET_REG_SUMS: {   // mg_scal[0..1] = all-reduced Eikonal / Laplacian sums -> energy cache
             double s_[2]; HIPCHK(c, hipMemcpyAsync(s_, c->mg_scal, sizeof(s_), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
             c->en_sum = s_[0]; c->el_sum = s_[1];
