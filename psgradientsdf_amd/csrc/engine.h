@@ -39,7 +39,7 @@ struct GridP {
     float T;
 };
 
-struct Robust { int loss; float lambda, lambda_sq; };
+struct Robust { int loss; float lambda, lambda_sq, inv_lambda; };
 
 // Band view: plain pointers into one big allocation; Spad = S rounded up to kBlock.
 struct Band {

@@ -54,6 +54,7 @@ struct psgsdf_ctx {
     double* pcg_sc = nullptr; int pcg_cap = 4096;
     double* pcg_part = nullptr;          // [2][3][kPcgMaxBlocks]
     int last_cg_iters = 0;
+    bool want_counts = true;             // read back the accepted-update counts (debug statistic of the reference)
     double* host_buf = nullptr; size_t host_buf_n = 0;   // pinned readback
     // cached energies
     double en_sum = 0, el_sum = 0;       // sums over the band from the last k_derive
@@ -109,7 +110,7 @@ template <class Fn> void timed(psgsdf_ctx* c, const char* name, Fn&& fn) {
 SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     SweepArgs a{};
     a.b = c->band; a.frames = c->frames; a.img = c->img; a.F = c->F; a.cam = c->cam; a.grid = c->grid;
-    a.rob.loss = c->set.loss; a.rob.lambda = c->set.lambda; a.rob.lambda_sq = c->set.lambda * c->set.lambda;
+    a.rob.loss = c->set.loss; a.rob.lambda = c->set.lambda; a.rob.lambda_sq = c->set.lambda * c->set.lambda; a.rob.inv_lambda = 1.0f / c->set.lambda;
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
     a.model = c->set.model; a.quirks = c->set.ref_quirks;
     a.reg_n = c->reg_n; a.reg_l = c->reg_l;
@@ -313,8 +314,11 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
     return 0;
 }
 
-int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) {
-    psgsdf_step_stats tmp; if (!st) st = &tmp;
+// A sub-step in two halves so that the alternation loop can look at the energy of the state a sweep started from
+// (= the energy AFTER the previous block, PsOptimizer.cpp:311,323,338,354) before anything is modified:
+//   step_begin : the sweep (normal equations + PS energy of the input state)          -> st->e_in, st->n_obs
+//   step_finish: solve + update (albedo apply / light, pose solves / distance PCG + apply + regrad)
+int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) {
     memset(st, 0, sizeof(*st));
     st->block = block;
     SweepArgs a = make_args(c, laplacian_reg);
@@ -322,45 +326,23 @@ int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) 
     double e_sum = 0, nobs = 0;
     int rc;
     switch (block) {
-        case PSGSDF_ALBEDO: {
-            timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); });
-            timed(c, "apply_albedo", [&] { launch_apply_albedo(a, c->stream); });
-            const int slots[3] = {SC_ENERGY, SC_NOBS, SC_ACCEPT}; double s[3];
-            if ((rc = read_parts(c, slots, 3, s))) return rc;
+        case PSGSDF_ALBEDO: case PSGSDF_DIST: {
+            if (block == PSGSDF_ALBEDO) timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); });
+            else timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); });
+            const int slots[2] = {SC_ENERGY, SC_NOBS}; double s[2];
+            if ((rc = read_parts(c, slots, 2, s))) return rc;
             e_sum = s[0]; nobs = s[1];
-            st->cg_iters = 1; st->cg_converged = 1; st->applied = 1; st->n_accepted = (int64_t)s[2];
             break;
         }
-        case PSGSDF_LIGHT: {
+        case PSGSDF_LIGHT: case PSGSDF_POSE: {
             HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
-            timed(c, "sweep_light", [&] { launch_sweep_light(a, c->stream); });
-            timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->stream); });
-            const int n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4), nh = led ? 3 : n * (n + 1) / 2;
-            if ((rc = read_frame_energy(c, nh + n, &e_sum, &nobs))) return rc;
-            st->cg_converged = 1; st->applied = 1; st->n_accepted = led ? 1 : c->F;
-            break;
-        }
-        case PSGSDF_POSE: {
-            HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
-            timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); });
-            timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->stream); });
-            if ((rc = read_frame_energy(c, 27, &e_sum, &nobs))) return rc;
-            st->cg_converged = 1; st->applied = 1; st->n_accepted = c->F;
-            break;
-        }
-        case PSGSDF_DIST: {
-            timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); });
-            timed(c, "assemble", [&] { launch_assemble(a, c->stream); });
-            int iters = 0, ok = 1; double err = 0;
-            if ((rc = pcg_solve(c, a, &iters, &ok, &err))) return rc;
-            int apply = 1;
-            if (!led && c->set.ref_quirks && !ok) apply = 0;   // PsOptimizer.cpp:168-170 (B8)
-            if (apply) timed(c, "apply_dist", [&] { launch_apply_dist(a, c->stream); });
-            const int slots[3] = {SC_ENERGY, SC_NOBS, SC_ACCEPT}; double s[3];
-            if ((rc = read_parts(c, slots, 3, s))) return rc;
-            e_sum = s[0]; nobs = s[1];
-            if (apply) { if ((rc = derive(c, 1))) return rc; }
-            st->cg_iters = iters; st->cg_converged = ok; st->cg_error = err; st->applied = apply; st->n_accepted = apply ? (int64_t)s[2] : 0;
+            int col;
+            if (block == PSGSDF_LIGHT) {
+                timed(c, "sweep_light", [&] { launch_sweep_light(a, c->stream); });
+                const int n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4), nh = led ? 3 : n * (n + 1) / 2;
+                col = nh + n;
+            } else { timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); }); col = 27; }
+            if ((rc = read_frame_energy(c, col, &e_sum, &nobs))) return rc;
             break;
         }
         default: return fail(c, PSGSDF_ERR_ARG, "unknown block %d", block);
@@ -369,34 +351,148 @@ int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) 
     st->n_obs = (int64_t)nobs;
     return 0;
 }
+int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) {
+    SweepArgs a = make_args(c, laplacian_reg);
+    const bool led = c->set.model == PSGSDF_LED;
+    int rc;
+    switch (block) {
+        case PSGSDF_ALBEDO: {
+            timed(c, "apply_albedo", [&] { launch_apply_albedo(a, c->stream); });
+            const int slots[1] = {SC_ACCEPT}; double s[1];
+            if (c->want_counts) { if ((rc = read_parts(c, slots, 1, s))) return rc; st->n_accepted = (int64_t)s[0]; }
+            st->cg_iters = 1; st->cg_converged = 1; st->applied = 1;
+            break;
+        }
+        case PSGSDF_LIGHT:
+            timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->stream); });
+            st->cg_converged = 1; st->applied = 1; st->n_accepted = led ? 1 : c->F;
+            break;
+        case PSGSDF_POSE:
+            timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->stream); });
+            st->cg_converged = 1; st->applied = 1; st->n_accepted = c->F;
+            break;
+        case PSGSDF_DIST: {
+            timed(c, "assemble", [&] { launch_assemble(a, c->stream); });
+            int iters = 0, ok = 1; double err = 0;
+            if ((rc = pcg_solve(c, a, &iters, &ok, &err))) return rc;
+            int apply = 1;
+            if (!led && c->set.ref_quirks && !ok) apply = 0;   // PsOptimizer.cpp:168-170 (B8)
+            if (apply) {
+                timed(c, "apply_dist", [&] { launch_apply_dist(a, c->stream); });
+                // regrad + Eikonal / Laplacian sums; one read-back for the accepted count and the two sums
+                SweepArgs a2 = make_args(c, 0);
+                timed(c, "derive", [&] { launch_derive(a2, 1, c->stream); });
+                const int slots[3] = {SC_ACCEPT, SC_EN, SC_EL}; double s[3];
+                if ((rc = read_parts(c, slots, 3, s))) return rc;
+                st->n_accepted = (int64_t)s[0]; c->en_sum = s[1]; c->el_sum = s[2];
+            }
+            st->cg_iters = iters; st->cg_converged = ok; st->cg_error = err; st->applied = apply;
+            break;
+        }
+        default: return fail(c, PSGSDF_ERR_ARG, "unknown block %d", block);
+    }
+    return 0;
+}
+int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) {
+    psgsdf_step_stats tmp; if (!st) st = &tmp;
+    int rc = step_begin(c, block, laplacian_reg, st); if (rc) return rc;
+    return step_finish(c, block, laplacian_reg, st);
+}
 
-// one body of the alternation loop; E/E_n/E_l carry the reference's float energies
-int iterate_once(psgsdf_ctx* c, int flags, int laplacian_reg, float* E, float* E_n, float* E_l, psgsdf_iter_stats* rec) {
+// The alternation loop (PsOptimizer.cpp:303-425 / LedOptimizer.cpp:343-475).  The reference evaluates getPSEnergy after
+// every block; here the energy after block k is the `e_in` of block k+1's sweep, and the energy that closes iteration i
+// is the `e_in` of the FIRST sweep of iteration i+1, which runs before anything of iteration i+1 is applied -- so the
+// convergence / divergence exit still leaves exactly the state the reference would leave.  Only the last iteration
+// (and the one that triggers the 2x refinement) needs a stand-alone energy sweep.
+int do_upsample(psgsdf_ctx* c);
+struct LoopState { float E, E_n, E_l, E_prev; int laplacian_reg; };
+
+// closes record `rec` of an iteration with the PS energy E that followed its last block
+void close_iteration(psgsdf_ctx* c, LoopState& L, psgsdf_iter_stats* rec, int pending_slot, float E, bool early_exit_semantics) {
+    L.E = E;
+    if (pending_slot >= 0) rec->e_after[pending_slot] = (double)E;
+    rec->e_n = L.E_n; rec->e_l = L.E_l;
+    rec->e_total = (double)total_energy(c, L.E, L.E_n, L.E_l);
+    rec->reg_weight_n = c->reg_n; rec->reg_weight_l = c->reg_l;
+    float Et = (float)rec->e_total;
+    rec->rel_diff = (double)(fabsf(L.E_prev - Et) / L.E_prev);
+    rec->converged = rec->rel_diff < (double)c->set.conv_threshold;
+    rec->diverged = early_exit_semantics ? (!rec->converged && (L.E_prev < Et)) : (L.E_prev < Et);
+}
+
+// Runs iterations [first, ...) until max_iters or (if stop_early) convergence / divergence.  `on_iter`, upsampling and
+// the Laplacian schedule only apply when `full` (psgsdf_optimize).
+int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, psgsdf_iter_stats* stats, int stats_cap, int* n_done, int* result,
+             psgsdf_iter_cb on_iter, void* user) {
     const bool led = c->set.model == PSGSDF_LED;
     const int order[4] = {led ? PSGSDF_LIGHT : PSGSDF_ALBEDO, led ? PSGSDF_ALBEDO : PSGSDF_LIGHT, PSGSDF_DIST, PSGSDF_POSE};
-    for (int q = 0; q < 4; ++q) rec->e_after[q] = NAN;
-    rec->cg_iters = 0;
-    int pending = -1;   // slot whose "energy after" is delivered by the next sweep's e_in
-    for (int q = 0; q < 4; ++q) {
-        const int blk = order[q];
-        if (!(flags & blk)) continue;
-        psgsdf_step_stats st;
-        int rc = do_step(c, blk, laplacian_reg, &st); if (rc) return rc;
-        if (pending >= 0) { *E = (float)st.e_in; rec->e_after[pending] = (double)*E; }
-        if (blk == PSGSDF_DIST) {
-            rec->cg_iters = st.cg_iters;
-            if (c->reg_n != 0.f) *E_n = (float)band_mean(c, c->en_sum);
-            if (laplacian_reg) *E_l = (float)band_mean(c, c->el_sum);
+    psgsdf_iter_stats rec; memset(&rec, 0, sizeof(rec));
+    psgsdf_iter_stats prev; int prev_slot = -1; bool have_prev = false;   // iteration waiting for its closing energy
+    struct CountsOff { psgsdf_ctx* c; bool old; CountsOff(psgsdf_ctx* c_) : c(c_), old(c_->want_counts) { c->want_counts = false; } ~CountsOff() { c->want_counts = old; } } counts_off(c);
+    int done = 0, iter = 0; if (result) *result = 0;
+    bool stop = false;
+    auto finalize = [&](psgsdf_iter_stats& r, int it) -> int {   // everything that happens after E_total(it) is known
+        const bool term = full && (r.converged || r.diverged);
+        float E_last = (float)r.e_total;
+        if (full && !term && it == 5 && c->set.upsample) {   // PsOptimizer.cpp:386-409
+            if (c->reg_l == 0.0f) c->reg_l = 1.0f;
+            L.laplacian_reg = 1;
+            int rc = do_upsample(c); if (rc) return rc;
+            L.E_l = (float)band_mean(c, c->el_sum);
+            c->reg_l *= L.E / L.E_l;
+            E_last = total_energy(c, L.E, L.E_n, L.E_l);
+            r.upsampled = 1;
         }
-        pending = blk == PSGSDF_ALBEDO ? 0 : blk == PSGSDF_LIGHT ? 1 : blk == PSGSDF_DIST ? 2 : 3;
+        if (full && !term && c->set.upsample && (led ? it == 15 : it > 15)) c->reg_l = 0.0f;   // PsOptimizer.cpp:411-413 / LedOptimizer.cpp:461-463
+        L.E_prev = E_last;
+        if (stats && done < stats_cap) stats[done] = r;
+        done++;
+        if (term) { if (result && r.converged) *result = 1; stop = true; return 0; }
+        if (full && on_iter && on_iter(user, it + 1, &r)) stop = true;
+        return 0;
+    };
+    while (iter < max_iters && !stop) {
+        memset(&rec, 0, sizeof(rec));
+        for (int q = 0; q < 4; ++q) rec.e_after[q] = NAN;
+        int pending = -1;
+        for (int q = 0; q < 4 && !stop; ++q) {
+            const int blk = order[q];
+            if (!(flags & blk)) continue;
+            psgsdf_step_stats st;
+            int rc = step_begin(c, blk, L.laplacian_reg, &st); if (rc) return rc;
+            if (have_prev) {   // this sweep's input energy closes the previous iteration
+                close_iteration(c, L, &prev, prev_slot, (float)st.e_in, full);
+                have_prev = false;
+                if ((rc = finalize(prev, iter - 1))) return rc;
+                if (stop) break;   // converged / diverged / aborted: nothing of this iteration has been applied
+            } else if (pending >= 0) { L.E = (float)st.e_in; rec.e_after[pending] = (double)L.E; }
+            if ((rc = step_finish(c, blk, L.laplacian_reg, &st))) return rc;
+            if (blk == PSGSDF_DIST) {
+                rec.cg_iters = st.cg_iters;
+                if (c->reg_n != 0.f) L.E_n = (float)band_mean(c, c->en_sum);
+                if (L.laplacian_reg) L.E_l = (float)band_mean(c, c->el_sum);
+            }
+            pending = blk == PSGSDF_ALBEDO ? 0 : blk == PSGSDF_LIGHT ? 1 : blk == PSGSDF_DIST ? 2 : 3;
+        }
+        if (stop) break;
+        // defer the closing energy to the next iteration's first sweep unless this is the last iteration, no block is
+        // enabled, or the refinement (which changes the state in between) is due
+        const bool last = iter + 1 >= max_iters;
+        const bool refine_next = full && c->set.upsample && iter == 5;
+        if (pending >= 0 && !last && !refine_next) { prev = rec; prev_slot = pending; have_prev = true; }
+        else {
+            double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;
+            close_iteration(c, L, &rec, pending, (float)e, full);
+            if ((rc = finalize(rec, iter))) return rc;
+        }
+        ++iter;
     }
-    if (pending >= 0) {
+    if (have_prev && !stop) {   // loop ended by max_iters while an iteration was still open (cannot happen: `last` closes it)
         double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;
-        *E = (float)e; rec->e_after[pending] = (double)*E;
+        close_iteration(c, L, &prev, prev_slot, (float)e, full);
+        if ((rc = finalize(prev, iter - 1))) return rc;
     }
-    rec->e_n = *E_n; rec->e_l = *E_l;
-    rec->e_total = (double)total_energy(c, *E, *E_n, *E_l);
-    rec->reg_weight_n = c->reg_n; rec->reg_weight_l = c->reg_l;
+    if (n_done) *n_done = done;
     return 0;
 }
 
@@ -601,62 +697,27 @@ int psgsdf_iterate(psgsdf_ctx* c, int flags, int n_iters, psgsdf_iter_stats* sta
     if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
     HIPCHK(c, hipSetDevice(c->device));
     double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;
-    float E = (float)e;
-    float E_n = c->reg_n != 0.f ? (float)band_mean(c, c->en_sum) : 0.f, E_l = c->reg_l != 0.f ? (float)band_mean(c, c->el_sum) : 0.f;
-    float E_prev = total_energy(c, E, E_n, E_l);
-    for (int it = 0; it < n_iters; ++it) {
-        psgsdf_iter_stats rec; memset(&rec, 0, sizeof(rec));
-        if ((rc = iterate_once(c, flags, c->reg_l != 0.f, &E, &E_n, &E_l, &rec))) return rc;
-        float Et = (float)rec.e_total;
-        rec.rel_diff = (double)(fabsf(E_prev - Et) / E_prev);
-        rec.converged = rec.rel_diff < (double)c->set.conv_threshold; rec.diverged = E_prev < Et;
-        E_prev = Et;
-        if (stats) stats[it] = rec;
-    }
-    return PSGSDF_OK;
+    LoopState L{};
+    L.E = (float)e;
+    L.E_n = c->reg_n != 0.f ? (float)band_mean(c, c->en_sum) : 0.f; L.E_l = c->reg_l != 0.f ? (float)band_mean(c, c->el_sum) : 0.f;
+    L.E_prev = total_energy(c, L.E, L.E_n, L.E_l);
+    L.laplacian_reg = c->reg_l != 0.f;
+    int done = 0;
+    return run_loop(c, flags, L, n_iters, false, stats, stats ? n_iters : 0, &done, nullptr, nullptr, nullptr);
 }
 
 int psgsdf_optimize(psgsdf_ctx* c, int flags, psgsdf_iter_stats* stats, int stats_cap, int* n_done, int* result, psgsdf_iter_cb on_iter, void* user) {
     if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
     HIPCHK(c, hipSetDevice(c->device));
-    const bool led = c->set.model == PSGSDF_LED;
-    int laplacian_reg = c->reg_l != 0.f;
+    LoopState L{};
+    L.laplacian_reg = c->reg_l != 0.f;
     int rc = psgsdf_init_albedo(c); if (rc) return rc;
     double e; if ((rc = ps_energy(c, &e, nullptr))) return rc;
-    float E = (float)e, E_n = 0, E_l = 0;
-    if (c->reg_n != 0.f) { E_n = (float)band_mean(c, c->en_sum); c->reg_n *= E / E_n; }
-    if (laplacian_reg) { E_l = (float)band_mean(c, c->el_sum); c->reg_l *= E / E_l; if (c->set.upsample) laplacian_reg = 0; }
-    float E_prev = total_energy(c, E, E_n, E_l);
-    int iter = 0, done = 0; if (result) *result = 0;
-    while (iter < c->set.max_it) {
-        psgsdf_iter_stats rec; memset(&rec, 0, sizeof(rec));
-        if ((rc = iterate_once(c, flags, laplacian_reg, &E, &E_n, &E_l, &rec))) return rc;
-        float Et = (float)rec.e_total;
-        rec.rel_diff = (double)(fabsf(E_prev - Et) / E_prev);
-        rec.converged = rec.rel_diff < (double)c->set.conv_threshold;
-        rec.diverged = !rec.converged && (E_prev < Et);
-        const bool stop = rec.converged || rec.diverged;
-        float E_last = Et;
-        if (!stop && iter == 5 && c->set.upsample) {   // PsOptimizer.cpp:386-409
-            if (c->reg_l == 0.0f) c->reg_l = 1.0f;
-            laplacian_reg = 1;
-            if ((rc = do_upsample(c))) return rc;
-            E_l = (float)band_mean(c, c->el_sum);
-            c->reg_l *= E / E_l;
-            E_last = total_energy(c, E, E_n, E_l);
-            rec.upsampled = 1;
-        }
-        if (!stop && c->set.upsample && (led ? iter == 15 : iter > 15)) c->reg_l = 0.0f;   // PsOptimizer.cpp:411-413 / LedOptimizer.cpp:461-463
-        E_prev = E_last;
-        if (stats && done < stats_cap) stats[done] = rec;
-        done++;
-        if (rec.converged) { if (result) *result = 1; break; }
-        if (rec.diverged) break;
-        ++iter;
-        if (on_iter && on_iter(user, iter, &rec)) break;
-    }
-    if (n_done) *n_done = done;
-    return PSGSDF_OK;
+    L.E = (float)e;
+    if (c->reg_n != 0.f) { L.E_n = (float)band_mean(c, c->en_sum); c->reg_n *= L.E / L.E_n; }                                             // PsOptimizer.cpp:275-278
+    if (L.laplacian_reg) { L.E_l = (float)band_mean(c, c->el_sum); c->reg_l *= L.E / L.E_l; if (c->set.upsample) L.laplacian_reg = 0; }   // :281-285
+    L.E_prev = total_energy(c, L.E, L.E_n, L.E_l);
+    return run_loop(c, flags, L, c->set.max_it, true, stats, stats_cap, n_done, result, on_iter, user);
 }
 
 int psgsdf_upsample2x(psgsdf_ctx* c) {

@@ -15,7 +15,10 @@
 #include "engine.h"
 #include <float.h>
 
-#pragma clang fp contract(off)
+// Floating-point contraction: ON for the Jacobian / normal-equation algebra (FMA: fewer instructions, one rounding
+// less), OFF inside the functions whose results feed discrete decisions or must match the CPU reference build bit for
+// bit (baseline x86-64, no FMA): normalisation, the surface point, the projection (floor / in-image test), FD gradient.
+#pragma clang fp contract(fast)
 
 namespace psg {
 
@@ -26,7 +29,8 @@ __device__ __forceinline__ float dot3(const float* a, const float* b) { return (
 __device__ __forceinline__ float norm3(const float* a) { return sqrtf(dot3(a, a)); }
 // Eigen normalized(): z>0 ? v/sqrt(z) : v
 __device__ __forceinline__ void normalized3(const float* v, float* o) {
-    float z = dot3(v, v);
+#pragma clang fp contract(off)
+    float z = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
     if (z > 0.f) { float s = sqrtf(z); o[0] = v[0] / s; o[1] = v[1] / s; o[2] = v[2] / s; }
     else { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; }
 }
@@ -54,17 +58,17 @@ template <int MODEL> struct ModelTraits { static constexpr int NB = MODEL == 1 ?
 // Optimizer.cpp:140-161 / 164-186
 __device__ __forceinline__ float robust_weight(const Robust& rb, float r) {
     switch (rb.loss) {
-        case 1: { float x = r / rb.lambda; return 1.0f / (1.0f + x * x); }
-        case 3: { float x = r / rb.lambda; float w = (1.0f - x * x); w = w * w; return (r * r < rb.lambda_sq) ? w : 0.0f; }
-        case 2: { float w = rb.lambda * fabsf(1.0f / r); return (r * r < rb.lambda_sq) ? 1.0f : w; }
+        case 1: { float x = r * rb.inv_lambda; return __builtin_amdgcn_rcpf(1.0f + x * x); }   // v_rcp_f32: 1 ulp
+        case 3: { float x = r * rb.inv_lambda; float w = (1.0f - x * x); w = w * w; return (r * r < rb.lambda_sq) ? w : 0.0f; }
+        case 2: { float w = rb.lambda * fabsf(__builtin_amdgcn_rcpf(r)); return (r * r < rb.lambda_sq) ? 1.0f : w; }
         case 4: return (r * r < rb.lambda_sq) ? 1.0f : 0.0f;
         default: return 1.0f;
     }
 }
 __device__ __forceinline__ float robust_loss(const Robust& rb, float r) {
     switch (rb.loss) {
-        case 1: { float x = r / rb.lambda; return logf(1.0f + x * x); }
-        case 3: { float x = r / rb.lambda; float u = 1.0f - x * x; float v = 1.0f - u * u * u; return (r * r < rb.lambda_sq) ? v : 1.0f; }
+        case 1: { float x = r * rb.inv_lambda; return __logf(1.0f + x * x); }
+        case 3: { float x = r * rb.inv_lambda; float u = 1.0f - x * x; float v = 1.0f - u * u * u; return (r * r < rb.lambda_sq) ? v : 1.0f; }
         case 2: return (r * r < rb.lambda_sq) ? 0.5f * (r * r) : rb.lambda * (fabsf(r) - 0.5f * rb.lambda * 1.0f);
         case 4: { float x = fminf(fmaxf(r, -rb.lambda), rb.lambda); return x * x; }
         default: return r * r;
@@ -128,9 +132,11 @@ struct Proj { float p[3]; float m, n, z_inv; bool ok; };
 
 // OptimizerAux.cpp:207-226 (surface point precomputed in xs = x_v - d*normalized(grad))
 __device__ __forceinline__ Proj project(const float* xs, const FrameP& fp, const Cam& cam) {
+#pragma clang fp contract(off)
     Proj o;
     float tmp[3] = {xs[0] - fp.t[0], xs[1] - fp.t[1], xs[2] - fp.t[2]};
-    mulT3(fp.R, tmp, o.p);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.p[i] = (fp.R[0 * 3 + i] * tmp[0] + fp.R[1 * 3 + i] * tmp[1]) + fp.R[2 * 3 + i] * tmp[2];
     // reference: (float)(1. / point[2]) evaluated in double (OptimizerAux.cpp:219); the correctly rounded float
     // reciprocal differs from that only in double-rounding corner cases (~1e-8 of all inputs)
     const float z_inv = 1.0f / o.p[2];
@@ -158,21 +164,13 @@ __device__ __forceinline__ void sample(const float* img, const Cam& cam, float m
         const float* p10 = p00 + (size_t)cam.W * 3;
         float a00[3] = {p00[0], p00[1], p00[2]}, a01[3] = {p00[3], p00[4], p00[5]};
         float a10[3] = {p10[0], p10[1], p10[2]}, a11[3] = {p10[3], p10[4], p10[5]};
-        double w1 = ((double)y + 1.0 - (double)n) * (double)(m - (float)x);
-        double w2 = ((double)y + 1.0 - (double)n) * ((double)x + 1.0 - (double)m);
-        float w3 = (n - (float)y) * (m - (float)x);
-        double w4 = (double)(n - (float)y) * ((double)x + 1.0 - (double)m);
+        // reference: weights partly in double (Auxilary.h:47); float weights agree to ~1e-7 relative
+        const float fm = m - (float)x, fn = n - (float)y;
+        const float w1 = (1.0f - fn) * fm, w2 = (1.0f - fn) * (1.0f - fm), w3 = fn * fm, w4 = fn * (1.0f - fm);
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            float t1 = (float)((double)a10[ch] * w1);
-            float t2 = (float)((double)a00[ch] * w2);
-            float t3 = a11[ch] * w3;
-            float t4 = (float)((double)a01[ch] * w4);
-            I[ch] = ((t1 + t2) + t3) + t4;
-        }
+        for (int ch = 0; ch < 3; ++ch) I[ch] = ((a10[ch] * w1 + a00[ch] * w2) + a11[ch] * w3) + a01[ch] * w4;
         if (GRAD) {
-            float w01 = m - (float)x, w11 = n - (float)y;
-            float w00 = (float)(1.0 - (double)w01), w10 = (float)(1.0 - (double)w11);
+            const float w01 = fm, w11 = fn, w00 = 1.0f - fm, w10 = 1.0f - fn;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 gu[ch] = w00 * (a01[ch] - a00[ch]) + w01 * (a11[ch] - a10[ch]);
@@ -453,6 +451,7 @@ __device__ __forceinline__ float nb_dist(const Band& b, int q, int j) {
 }
 // Optimizer.cpp:287-364 computeDistGrad -> (n, dir)
 __device__ __forceinline__ void fd_grad(const Band& b, int j, float vs_inv, float* n, float* dir) {
+#pragma clang fp contract(off)
     float d = b.dist[j];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -476,6 +475,7 @@ __device__ __forceinline__ float laplacian(const Band& b, int j, float vs_inv) {
 // FD gradient, optional updateGrad (OptimizerAux.cpp:152-160), surface point, and the Eikonal /
 // Laplacian energies (Optimizer.cpp:86-119) in one pass over the band.
 __global__ void __launch_bounds__(kBlock) k_derive(SweepArgs a, int update_grad) {
+#pragma clang fp contract(off)
     __shared__ double red[kBlock / 64];
     const Band& b = a.b;
     int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -597,6 +597,7 @@ void launch_sum_parts(const double* part, int PB, int nblk, const int* slots, in
 
 // Optimizer.cpp:50-81 initAlbedo
 __global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
+#pragma clang fp contract(off)
     FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
