@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -56,6 +57,9 @@ struct psgsdf_ctx {
     int last_cg_iters = 0;
     bool want_counts = true;             // read back the accepted-update counts (debug statistic of the reference)
     double* host_buf = nullptr; size_t host_buf_n = 0;   // pinned readback
+    // deferred read-backs: D2H copies enqueued on the stream into a pinned mailbox, consumed at the next host sync
+    double* mbox = nullptr; size_t mbox_n = 0, mbox_used = 0;
+    std::vector<std::function<void()>> deferred;
     // cached energies
     double en_sum = 0, el_sum = 0;       // sums over the band from the last k_derive
     // row partition (multi-rank): this context owns band rows [row0, row1); halo = widest column reach
@@ -79,6 +83,7 @@ struct psgsdf_ctx {
 
 namespace {
 
+int flush(psgsdf_ctx* c);
 int fail(psgsdf_ctx* c, int code, const char* fmt, ...) {
     if (c) { va_list ap; va_start(ap, fmt); vsnprintf(c->err, sizeof(c->err), fmt, ap); va_end(ap); }
     return code;
@@ -127,17 +132,51 @@ int read_parts(psgsdf_ctx* c, const int* slots, int n, double* out) {
     const int nb = band_blocks(c);
     for (int i = 0; i < n; ++i)
         if (nb > 0) HIPCHK(c, hipMemcpyAsync(c->host_buf + (size_t)i * nb, c->part + (size_t)slots[i] * c->PB, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc = flush(c); if (rc) return rc; }
     for (int i = 0; i < n; ++i) { double s = 0; for (int k = 0; k < nb; ++k) s += c->host_buf[(size_t)i * nb + k]; out[i] = s; }
     return 0;
 }
 // frame-major sweeps: energy and n_obs live in columns (col_e, col_e+1) of every frame row
 int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs) {
     HIPCHK(c, hipMemcpyAsync(c->host_buf, c->acc_frame, sizeof(double) * c->acc_frame_n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc = flush(c); if (rc) return rc; }
     double e = 0, n = 0;
     for (int f = 0; f < c->F; ++f) { e += c->host_buf[(size_t)f * kFrameRow + col_e]; n += c->host_buf[(size_t)f * kFrameRow + col_e + 1]; }
     *E = e; *nobs = n;
+    return 0;
+}
+// synchronise the stream once and run every deferred consumer in submission order
+int flush(psgsdf_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& f : c->deferred) f();
+    c->deferred.clear(); c->mbox_used = 0;
+    return 0;
+}
+// sum of per-workgroup partials of `slots`, delivered to `consume(sums)` at the next flush (no host sync here)
+int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<void(const double*)> consume) {
+    const int nb = band_blocks(c);
+    if (c->mbox_used + (size_t)n * nb > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+    double* dst = c->mbox + c->mbox_used; c->mbox_used += (size_t)n * nb;
+    for (int i = 0; i < n; ++i)
+        if (nb > 0) HIPCHK(c, hipMemcpyAsync(dst + (size_t)i * nb, c->part + (size_t)slots[i] * c->PB, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
+    c->deferred.push_back([dst, n, nb, consume] {
+        double sums[8];
+        for (int i = 0; i < n; ++i) { double s_ = 0; for (int k = 0; k < nb; ++k) s_ += dst[(size_t)i * nb + k]; sums[i] = s_; }
+        consume(sums);
+    });
+    return 0;
+}
+int read_frame_energy_deferred(psgsdf_ctx* c, int col_e, std::function<void(double, double)> consume) {
+    const size_t n = c->acc_frame_n;
+    if (c->mbox_used + n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+    double* dst = c->mbox + c->mbox_used; c->mbox_used += n;
+    HIPCHK(c, hipMemcpyAsync(dst, c->acc_frame, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    const int F = c->F;
+    c->deferred.push_back([dst, F, col_e, consume] {
+        double e = 0, nn = 0;
+        for (int f = 0; f < F; ++f) { e += dst[(size_t)f * kFrameRow + col_e]; nn += dst[(size_t)f * kFrameRow + col_e + 1]; }
+        consume(e, nn);
+    });
     return 0;
 }
 int ensure_host_buf(psgsdf_ctx* c, size_t n) {
@@ -244,6 +283,16 @@ int build_band(psgsdf_ctx* c) {
     c->PB = Spad / kBlock + 1;
     HIPCHK(c, hipMalloc(&c->part, sizeof(double) * SC_COUNT * c->PB));
     HIPCHK(c, hipMemsetAsync(c->part, 0, sizeof(double) * SC_COUNT * c->PB, c->stream));
+    {
+        const size_t need = 16 * ((size_t)3 * c->PB + (size_t)c->F * kFrameRow);
+        if (need > c->mbox_n) {
+            if (c->mbox) hipHostFree(c->mbox);
+            c->mbox = nullptr; c->mbox_n = 0;
+            HIPCHK(c, hipHostMalloc(&c->mbox, sizeof(double) * need));
+            c->mbox_n = need;
+        }
+        c->mbox_used = 0; c->deferred.clear();
+    }
     return ensure_host_buf(c, (size_t)SC_COUNT * c->PB + (size_t)c->F * kFrameRow + kPcgScalHead + 3 * 4096 + 64);
 }
 
@@ -281,7 +330,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
     HIPCHK(c, hipMemsetAsync(c->pcg_sc, 0, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap), c->stream));
     timed(c, "pcg_init", [&] { launch_pcg_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
     // first chunk sized from the previous solve (the count is stable between Gauss-Newton iterations)
-    int chunk = std::max(4, c->last_cg_iters + 1);
+    int chunk = std::max(4, c->last_cg_iters + 2);
     int k = 0, iters = -1;
     double rhsNorm2 = 0;
     float rn2_last = 0;
@@ -294,7 +343,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         if (n > 0) launch_pcg_final(c->pcg_sc, c->pcg_part, G, k + n - 1, c->stream);
         HIPCHK(c, hipMemcpyAsync(c->host_buf, c->pcg_sc, sizeof(double) * kPcgScalHead, hipMemcpyDeviceToHost, c->stream));
         if (n > 0) HIPCHK(c, hipMemcpyAsync(c->host_buf + kPcgScalHead, c->pcg_sc + kPcgScalHead + 3 * (size_t)k, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        { int rc = flush(c); if (rc) return rc; }
         rhsNorm2 = c->host_buf[0];
         float rhsN = (float)rhsNorm2;
         if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; return 0; }
@@ -318,7 +367,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
 // (= the energy AFTER the previous block, PsOptimizer.cpp:311,323,338,354) before anything is modified:
 //   step_begin : the sweep (normal equations + PS energy of the input state)          -> st->e_in, st->n_obs
 //   step_finish: solve + update (albedo apply / light, pose solves / distance PCG + apply + regrad)
-int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) {
+int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, std::function<void(double, double)> deferred_consumer = nullptr) {
     memset(st, 0, sizeof(*st));
     st->block = block;
     SweepArgs a = make_args(c, laplacian_reg);
@@ -330,6 +379,7 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
             if (block == PSGSDF_ALBEDO) timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); });
             else timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); });
             const int slots[2] = {SC_ENERGY, SC_NOBS}; double s[2];
+            if (deferred_consumer) return read_parts_deferred(c, slots, 2, [deferred_consumer](const double* v) { deferred_consumer(v[0], v[1]); });
             if ((rc = read_parts(c, slots, 2, s))) return rc;
             e_sum = s[0]; nobs = s[1];
             break;
@@ -342,6 +392,7 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
                 const int n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4), nh = led ? 3 : n * (n + 1) / 2;
                 col = nh + n;
             } else { timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); }); col = 27; }
+            if (deferred_consumer) return read_frame_energy_deferred(c, col, deferred_consumer);
             if ((rc = read_frame_energy(c, col, &e_sum, &nobs))) return rc;
             break;
         }
@@ -351,7 +402,7 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
     st->n_obs = (int64_t)nobs;
     return 0;
 }
-int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) {
+int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, bool defer_reg_sums = false) {
     SweepArgs a = make_args(c, laplacian_reg);
     const bool led = c->set.model == PSGSDF_LED;
     int rc;
@@ -383,8 +434,8 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
                 SweepArgs a2 = make_args(c, 0);
                 timed(c, "derive", [&] { launch_derive(a2, 1, c->stream); });
                 const int slots[3] = {SC_ACCEPT, SC_EN, SC_EL}; double s[3];
-                if ((rc = read_parts(c, slots, 3, s))) return rc;
-                st->n_accepted = (int64_t)s[0]; c->en_sum = s[1]; c->el_sum = s[2];
+                if (defer_reg_sums) { if ((rc = read_parts_deferred(c, slots, 3, [c](const double* v) { c->en_sum = v[1]; c->el_sum = v[2]; }))) return rc; }
+                else { if ((rc = read_parts(c, slots, 3, s))) return rc; st->n_accepted = (int64_t)s[0]; c->en_sum = s[1]; c->el_sum = s[2]; }
             }
             st->cg_iters = iters; st->cg_converged = ok; st->cg_error = err; st->applied = apply;
             break;
@@ -451,37 +502,58 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
         if (full && on_iter && on_iter(user, it + 1, &r)) stop = true;
         return 0;
     };
+    // per-iteration values that arrive through deferred read-backs (stable addresses: two alternating slots)
+    struct Late { double e_in[4]; int blk_of[4]; int n; bool dist_ran; int cg_iters; } late[2];
+    int li = 0;
+    auto apply_late = [&](psgsdf_iter_stats& r, const Late& lt, int first_slot_pending) {
+        // e_in of sweep q is the energy AFTER the block that ran before it in the same iteration
+        int pend = first_slot_pending;
+        for (int q = 0; q < lt.n; ++q) {
+            if (pend >= 0 && q > 0) { r.e_after[pend] = (double)(float)band_mean(c, lt.e_in[q]); }   // deferred values are raw sums
+            pend = lt.blk_of[q] == PSGSDF_ALBEDO ? 0 : lt.blk_of[q] == PSGSDF_LIGHT ? 1 : lt.blk_of[q] == PSGSDF_DIST ? 2 : 3;
+        }
+        if (lt.dist_ran) {
+            r.cg_iters = lt.cg_iters;
+            if (c->reg_n != 0.f) L.E_n = (float)band_mean(c, c->en_sum);
+            if (L.laplacian_reg) L.E_l = (float)band_mean(c, c->el_sum);
+        }
+    };
+    Late* prev_late = nullptr;
     while (iter < max_iters && !stop) {
         memset(&rec, 0, sizeof(rec));
         for (int q = 0; q < 4; ++q) rec.e_after[q] = NAN;
+        Late& lt = late[li]; lt.n = 0; lt.dist_ran = false; lt.cg_iters = 0;
         int pending = -1;
         for (int q = 0; q < 4 && !stop; ++q) {
             const int blk = order[q];
             if (!(flags & blk)) continue;
             psgsdf_step_stats st;
-            int rc = step_begin(c, blk, L.laplacian_reg, &st); if (rc) return rc;
-            if (have_prev) {   // this sweep's input energy closes the previous iteration
+            const int qi = lt.n;
+            lt.blk_of[qi] = blk; lt.e_in[qi] = NAN; lt.n++;
+            if (have_prev) {   // synchronous: this sweep's input energy closes the previous iteration (stop decision)
+                int rc = step_begin(c, blk, L.laplacian_reg, &st); if (rc) return rc;   // (flushes every deferred read of the previous iteration)
+                lt.e_in[qi] = st.e_in;
+                apply_late(prev, *prev_late, -1);
                 close_iteration(c, L, &prev, prev_slot, (float)st.e_in, full);
                 have_prev = false;
                 if ((rc = finalize(prev, iter - 1))) return rc;
                 if (stop) break;   // converged / diverged / aborted: nothing of this iteration has been applied
-            } else if (pending >= 0) { L.E = (float)st.e_in; rec.e_after[pending] = (double)L.E; }
-            if ((rc = step_finish(c, blk, L.laplacian_reg, &st))) return rc;
-            if (blk == PSGSDF_DIST) {
-                rec.cg_iters = st.cg_iters;
-                if (c->reg_n != 0.f) L.E_n = (float)band_mean(c, c->en_sum);
-                if (L.laplacian_reg) L.E_l = (float)band_mean(c, c->el_sum);
+            } else {
+                double* slot_e = &lt.e_in[qi];
+                int rc = step_begin(c, blk, L.laplacian_reg, &st, [slot_e](double e_sum, double) { *slot_e = e_sum; }); if (rc) return rc;
             }
+            int rc = step_finish(c, blk, L.laplacian_reg, &st, true); if (rc) return rc;
+            if (blk == PSGSDF_DIST) { lt.dist_ran = true; lt.cg_iters = st.cg_iters; }
             pending = blk == PSGSDF_ALBEDO ? 0 : blk == PSGSDF_LIGHT ? 1 : blk == PSGSDF_DIST ? 2 : 3;
         }
         if (stop) break;
-        // defer the closing energy to the next iteration's first sweep unless this is the last iteration, no block is
-        // enabled, or the refinement (which changes the state in between) is due
+        // deferred e_in values are raw sums (not yet divided by S) except the synchronous first one: normalise on use
         const bool last = iter + 1 >= max_iters;
         const bool refine_next = full && c->set.upsample && iter == 5;
-        if (pending >= 0 && !last && !refine_next) { prev = rec; prev_slot = pending; have_prev = true; }
+        if (pending >= 0 && !last && !refine_next) { prev = rec; prev_slot = pending; have_prev = true; prev_late = &lt; li ^= 1; }
         else {
-            double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;
+            double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;   // flushes the deferred reads of this iteration
+            apply_late(rec, lt, -1);
             close_iteration(c, L, &rec, pending, (float)e, full);
             if ((rc = finalize(rec, iter))) return rc;
         }
@@ -489,6 +561,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
     }
     if (have_prev && !stop) {   // loop ended by max_iters while an iteration was still open (cannot happen: `last` closes it)
         double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;
+        apply_late(prev, *prev_late, -1);
         close_iteration(c, L, &prev, prev_slot, (float)e, full);
         if ((rc = finalize(prev, iter - 1))) return rc;
     }
@@ -564,6 +637,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->frames); hipFree(c->led_light);
     hipFree(c->band_mem); hipFree(c->obs_mem); hipFree(c->acc_frame); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->d_total);
     if (c->host_buf) hipHostFree(c->host_buf);
+    if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mg_slots);
