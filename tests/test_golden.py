@@ -1,0 +1,51 @@
+"""Committed golden vectors (tests/golden/make_golden.py): the oracle must keep reproducing them (CPU), and the HIP
+engine must reproduce them through the C ABI (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from psgradientsdf_amd import capi, synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASE = dict(N=24, F=4, W=96, H=72)
+
+
+def _run(api):
+    api.init_albedo()
+    e_tot0 = api.normalize_weights()
+    recs = api.iterate(capi.ALL, 2)
+    return e_tot0, recs
+
+
+def _check(model, api, sc, tol_d, tol_e):
+    g = np.load(os.path.join(GOLD, f"oracle_small_{model}.npz"))
+    chk = np.array([float(np.abs(sc.dist).sum()), float(sc.images.sum()), float(sc.poses.sum())])
+    assert np.allclose(chk, g["scene_checksum"], rtol=1e-6), "the synthetic scene generator changed: regenerate the fixtures"
+    e_tot0, recs = _run(api)
+    band = api.download_band()
+    assert np.array_equal(band, g["band"])
+    assert abs(e_tot0 - float(g["e_total0"])) <= tol_e * abs(float(g["e_total0"]))
+    assert np.allclose([r["e_total"] for r in recs], g["e_total"], rtol=tol_e)
+    assert np.all(np.abs(np.array([r["cg_iters"] for r in recs]) - g["cg_iters"]) <= 1)
+    v = api.download_volume()
+    vs = float(sc.voxel_size)
+    assert np.abs(v["dist"][band] - g["dist"]).max() <= tol_d * vs
+    assert np.abs(v["rgb"][:, band] - g["rgb"]).max() <= max(tol_d, 1e-6)
+    assert np.abs(api.download_poses() - g["poses"]).max() <= max(tol_d * 0.1, 1e-6)
+
+
+@pytest.mark.parametrize("model", ["SH1", "SH2", "LED"])
+def test_oracle_reproduces_golden(built, model):
+    from oracle import oracle
+    sc = synth.make_scene(model=model, **CASE)
+    o = oracle.Oracle(sc, sc.K, capi.default_settings(sc.model_id, reg_weight_l=1.0)); o.load_scene(sc)
+    _check(model, o, sc, 1e-6, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["SH1", "SH2", "LED"])
+def test_engine_reproduces_golden(built, model):
+    sc = synth.make_scene(model=model, **CASE)
+    e = capi.load_engine(sc, sc.K, capi.default_settings(sc.model_id, reg_weight_l=1.0), 0); e.load_scene(sc)
+    _check(model, e, sc, 1e-3 if model == "SH2" else 1e-4, 2e-3 if model == "SH2" else 2e-4)
