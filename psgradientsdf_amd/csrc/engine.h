@@ -113,7 +113,10 @@ constexpr int kObsChunk = 2048;      // rows per workgroup of the observation-li
 void launch_obs_count(const Band& b, int F, int row0, int row1, int* counts, hipStream_t s);       // counts[F][nch]
 void launch_obs_fill(const Band& b, int F, int row0, int row1, const int* offsets, hipStream_t s); // offsets[F][nch] -> b.obs_rows
 void launch_reach(const Band& b, int* d_reach, hipStream_t s);                                     // max |col - row| over the band
-void launch_sum_parts(const double* part, int PB, int nblk, const int* slots, int nslots, double* out, hipStream_t s);
+struct SlotList { int n; int id[8]; };
+void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, hipStream_t s);
+void launch_frame_cols(const double* frame, int F, int col, double* out, hipStream_t s);
+void launch_zero_f64(double* p, int n, hipStream_t s);
 void launch_pcg_sum(const double* part, int G, int k, int which, double* out, hipStream_t s);      // which 0: p.t of pass k; 1: |r|^2, r.z of pass k (-1 = init)
 void launch_init_albedo(const SweepArgs& a, hipStream_t s);
 void launch_led_light_init(const SweepArgs& a, hipStream_t s);
@@ -129,7 +132,7 @@ void launch_assemble(const SweepArgs& a, hipStream_t s);
 void launch_pcg_init(const SweepArgs& a, double* sc, double* part, int G, hipStream_t s);
 void launch_pcg_mv(const SweepArgs& a, double* sc, double* part, int G, int k, int with_damping, hipStream_t s);
 void launch_pcg_upd(const SweepArgs& a, double* sc, double* part, int G, int k, hipStream_t s);
-void launch_pcg_final(double* sc, double* part, int G, int k, hipStream_t s);
+void launch_pcg_final(double* sc, double* part, int G, int k0, int k, double* host_out, hipStream_t s);
 void launch_matvec(const SweepArgs& a, const float* x, float* y, hipStream_t s);   // debug: y = H x (no damping)
 void launch_apply_dist(const SweepArgs& a, hipStream_t s);
 void launch_upsample(const DenseView& src, const DenseView& dst, const GridP& g_old, hipStream_t s);

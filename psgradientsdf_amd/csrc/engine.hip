@@ -57,8 +57,9 @@ struct psgsdf_ctx {
     int last_cg_iters = 0;
     bool want_counts = true;             // read back the accepted-update counts (debug statistic of the reference)
     double* host_buf = nullptr; size_t host_buf_n = 0;   // pinned readback
-    // deferred read-backs: D2H copies enqueued on the stream into a pinned mailbox, consumed at the next host sync
-    double* mbox = nullptr; size_t mbox_n = 0, mbox_used = 0;
+    // deferred read-backs: small fold kernels write into a host-mapped pinned mailbox (no D2H copies), consumed at the
+    // next host sync
+    double* mbox = nullptr; double* mbox_dev = nullptr; size_t mbox_n = 0, mbox_used = 0;
     std::vector<std::function<void()>> deferred;
     // cached energies
     double en_sum = 0, el_sum = 0;       // sums over the band from the last k_derive
@@ -127,23 +128,16 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
 }
 
 inline int band_blocks(const psgsdf_ctx* c) { return (c->row1 - c->row0 + kBlock - 1) / kBlock; }
-// sum the per-workgroup partials of the given slots (written by a voxel-major kernel of band_blocks() workgroups)
+int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<void(const double*)> consume);
+int read_frame_energy_deferred(psgsdf_ctx* c, int col_e, std::function<void(double, double)> consume);
+// blocking variants
 int read_parts(psgsdf_ctx* c, const int* slots, int n, double* out) {
-    const int nb = band_blocks(c);
-    for (int i = 0; i < n; ++i)
-        if (nb > 0) HIPCHK(c, hipMemcpyAsync(c->host_buf + (size_t)i * nb, c->part + (size_t)slots[i] * c->PB, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
-    { int rc = flush(c); if (rc) return rc; }
-    for (int i = 0; i < n; ++i) { double s = 0; for (int k = 0; k < nb; ++k) s += c->host_buf[(size_t)i * nb + k]; out[i] = s; }
-    return 0;
+    int rc = read_parts_deferred(c, slots, n, [out, n](const double* v) { for (int i = 0; i < n; ++i) out[i] = v[i]; });
+    return rc ? rc : flush(c);
 }
-// frame-major sweeps: energy and n_obs live in columns (col_e, col_e+1) of every frame row
 int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs) {
-    HIPCHK(c, hipMemcpyAsync(c->host_buf, c->acc_frame, sizeof(double) * c->acc_frame_n, hipMemcpyDeviceToHost, c->stream));
-    { int rc = flush(c); if (rc) return rc; }
-    double e = 0, n = 0;
-    for (int f = 0; f < c->F; ++f) { e += c->host_buf[(size_t)f * kFrameRow + col_e]; n += c->host_buf[(size_t)f * kFrameRow + col_e + 1]; }
-    *E = e; *nobs = n;
-    return 0;
+    int rc = read_frame_energy_deferred(c, col_e, [E, nobs](double e, double n) { *E = e; *nobs = n; });
+    return rc ? rc : flush(c);
 }
 // synchronise the stream once and run every deferred consumer in submission order
 int flush(psgsdf_ctx* c) {
@@ -154,29 +148,20 @@ int flush(psgsdf_ctx* c) {
 }
 // sum of per-workgroup partials of `slots`, delivered to `consume(sums)` at the next flush (no host sync here)
 int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<void(const double*)> consume) {
-    const int nb = band_blocks(c);
-    if (c->mbox_used + (size_t)n * nb > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
-    double* dst = c->mbox + c->mbox_used; c->mbox_used += (size_t)n * nb;
-    for (int i = 0; i < n; ++i)
-        if (nb > 0) HIPCHK(c, hipMemcpyAsync(dst + (size_t)i * nb, c->part + (size_t)slots[i] * c->PB, sizeof(double) * nb, hipMemcpyDeviceToHost, c->stream));
-    c->deferred.push_back([dst, n, nb, consume] {
-        double sums[8];
-        for (int i = 0; i < n; ++i) { double s_ = 0; for (int k = 0; k < nb; ++k) s_ += dst[(size_t)i * nb + k]; sums[i] = s_; }
-        consume(sums);
-    });
+    if (c->mbox_used + (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+    const size_t off = c->mbox_used; c->mbox_used += n;
+    SlotList sl; sl.n = n; for (int i = 0; i < n; ++i) sl.id[i] = slots[i];
+    launch_sum_parts(c->part, c->PB, band_blocks(c), sl, c->mbox_dev + off, c->stream);
+    const double* src = c->mbox + off;
+    c->deferred.push_back([src, consume] { consume(src); });
     return 0;
 }
 int read_frame_energy_deferred(psgsdf_ctx* c, int col_e, std::function<void(double, double)> consume) {
-    const size_t n = c->acc_frame_n;
-    if (c->mbox_used + n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
-    double* dst = c->mbox + c->mbox_used; c->mbox_used += n;
-    HIPCHK(c, hipMemcpyAsync(dst, c->acc_frame, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    const int F = c->F;
-    c->deferred.push_back([dst, F, col_e, consume] {
-        double e = 0, nn = 0;
-        for (int f = 0; f < F; ++f) { e += dst[(size_t)f * kFrameRow + col_e]; nn += dst[(size_t)f * kFrameRow + col_e + 1]; }
-        consume(e, nn);
-    });
+    if (c->mbox_used + 2 > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+    const size_t off = c->mbox_used; c->mbox_used += 2;
+    launch_frame_cols(c->acc_frame, c->F, col_e, c->mbox_dev + off, c->stream);
+    const double* src = c->mbox + off;
+    c->deferred.push_back([src, consume] { consume(src[0], src[1]); });
     return 0;
 }
 int ensure_host_buf(psgsdf_ctx* c, size_t n) {
@@ -284,11 +269,12 @@ int build_band(psgsdf_ctx* c) {
     HIPCHK(c, hipMalloc(&c->part, sizeof(double) * SC_COUNT * c->PB));
     HIPCHK(c, hipMemsetAsync(c->part, 0, sizeof(double) * SC_COUNT * c->PB, c->stream));
     {
-        const size_t need = 16 * ((size_t)3 * c->PB + (size_t)c->F * kFrameRow);
+        const size_t need = 4096;
         if (need > c->mbox_n) {
             if (c->mbox) hipHostFree(c->mbox);
             c->mbox = nullptr; c->mbox_n = 0;
-            HIPCHK(c, hipHostMalloc(&c->mbox, sizeof(double) * need));
+            HIPCHK(c, hipHostMalloc(&c->mbox, sizeof(double) * need, hipHostMallocMapped));
+            HIPCHK(c, hipHostGetDevicePointer((void**)&c->mbox_dev, c->mbox, 0));
             c->mbox_n = need;
         }
         c->mbox_used = 0; c->deferred.clear();
@@ -321,40 +307,42 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
     const int S = c->band.S;
     int cap = c->set.cg_max_it > 0 ? c->set.cg_max_it : 2 * S;
     if (cap > c->pcg_cap) cap = c->pcg_cap;
-    // balanced grid-stride: the fewest equal passes that fit kPcgMaxBlocks workgroups
+    // balanced grid-stride: the fewest equal passes that fit the workgroup budget
     const int nblk = std::max(1, band_blocks(c));
     int maxb = 704;   // ~2 rows per thread at the 256^3 band size measured best (profiles/r01_notes.md)
     if (const char* e = getenv("PSGSDF_PCG_BLOCKS")) { int v = atoi(e); if (v > 0 && v <= kPcgMaxBlocks) maxb = v; }   // tuning knob
     const int passes = (nblk + maxb - 1) / maxb;
     const int G = (nblk + passes - 1) / passes;
-    HIPCHK(c, hipMemsetAsync(c->pcg_sc, 0, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap), c->stream));
+    // every scalar the kernels or the host read is written by an earlier kernel of this solve: no memset needed
     timed(c, "pcg_init", [&] { launch_pcg_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
     // first chunk sized from the previous solve (the count is stable between Gauss-Newton iterations)
-    int chunk = std::max(4, c->last_cg_iters + 2);
+    int chunk = std::min(60, std::max(4, c->last_cg_iters + 2));
     int k = 0, iters = -1;
     double rhsNorm2 = 0;
     float rn2_last = 0;
     while (true) {
         int n = chunk; if (k + n > cap) n = cap - k;
+        if (n <= 0) { iters = cap; break; }
         for (int q = 0; q < n; ++q) {
             timed(c, "pcg_mv", [&] { launch_pcg_mv(a, c->pcg_sc, c->pcg_part, G, k + q, 1, c->stream); });
             timed(c, "pcg_upd", [&] { launch_pcg_upd(a, c->pcg_sc, c->pcg_part, G, k + q, c->stream); });
         }
-        if (n > 0) launch_pcg_final(c->pcg_sc, c->pcg_part, G, k + n - 1, c->stream);
-        HIPCHK(c, hipMemcpyAsync(c->host_buf, c->pcg_sc, sizeof(double) * kPcgScalHead, hipMemcpyDeviceToHost, c->stream));
-        if (n > 0) HIPCHK(c, hipMemcpyAsync(c->host_buf + kPcgScalHead, c->pcg_sc + kPcgScalHead + 3 * (size_t)k, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+        if (c->mbox_used + 64 > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+        const size_t off = c->mbox_used; c->mbox_used += 64;
+        launch_pcg_final(c->pcg_sc, c->pcg_part, G, k, k + n - 1, c->mbox_dev + off, c->stream);
         { int rc = flush(c); if (rc) return rc; }
-        rhsNorm2 = c->host_buf[0];
+        const double* st = c->mbox + off;
+        rhsNorm2 = st[0];
         float rhsN = (float)rhsNorm2;
-        if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; return 0; }
+        if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }
         float threshold = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
         for (int q = 0; q < n; ++q) {
-            rn2_last = (float)c->host_buf[kPcgScalHead + 3 * q + 1];
+            rn2_last = (float)st[1 + q];
             if (rn2_last < threshold) { iters = k + q; break; }
         }
         if (iters >= 0) break;
         k += n;
-        if (k >= cap || n == 0) { iters = cap; break; }
+        if (k >= cap) { iters = cap; break; }
         chunk = 4;
     }
     double err = sqrt((double)rn2_last / (double)(float)rhsNorm2);
@@ -385,7 +373,7 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
             break;
         }
         case PSGSDF_LIGHT: case PSGSDF_POSE: {
-            HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
+            launch_zero_f64(c->acc_frame, (int)c->acc_frame_n, c->stream);
             int col;
             if (block == PSGSDF_LIGHT) {
                 timed(c, "sweep_light", [&] { launch_sweep_light(a, c->stream); });
@@ -519,6 +507,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
         }
     };
     Late* prev_late = nullptr;
+    double* prev_close = nullptr;   // where the lazily delivered closing energy of `prev` will appear
     while (iter < max_iters && !stop) {
         memset(&rec, 0, sizeof(rec));
         for (int q = 0; q < 4; ++q) rec.e_after[q] = NAN;
@@ -530,7 +519,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
             psgsdf_step_stats st;
             const int qi = lt.n;
             lt.blk_of[qi] = blk; lt.e_in[qi] = NAN; lt.n++;
-            if (have_prev) {   // synchronous: this sweep's input energy closes the previous iteration (stop decision)
+            if (have_prev && full) {   // synchronous: this sweep's input energy closes the previous iteration (stop decision)
                 int rc = step_begin(c, blk, L.laplacian_reg, &st); if (rc) return rc;   // (flushes every deferred read of the previous iteration)
                 lt.e_in[qi] = st.e_in;
                 apply_late(prev, *prev_late, -1);
@@ -539,14 +528,30 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
                 if ((rc = finalize(prev, iter - 1))) return rc;
                 if (stop) break;   // converged / diverged / aborted: nothing of this iteration has been applied
             } else {
+                // no stop decision pending (psgsdf_iterate never exits early): even the closing energy of the previous
+                // iteration is delivered lazily, at the next host sync (the PCG status read of this iteration)
                 double* slot_e = &lt.e_in[qi];
                 int rc = step_begin(c, blk, L.laplacian_reg, &st, [slot_e](double e_sum, double) { *slot_e = e_sum; }); if (rc) return rc;
+                if (have_prev && prev_close == nullptr) prev_close = slot_e;
             }
             int rc = step_finish(c, blk, L.laplacian_reg, &st, true); if (rc) return rc;
             if (blk == PSGSDF_DIST) { lt.dist_ran = true; lt.cg_iters = st.cg_iters; }
+            if (have_prev && prev_close && !std::isnan(*prev_close)) {   // the lazy closing energy has arrived
+                apply_late(prev, *prev_late, -1);
+                close_iteration(c, L, &prev, prev_slot, (float)band_mean(c, *prev_close), full);
+                have_prev = false; prev_close = nullptr;
+                if ((rc = finalize(prev, iter - 1))) return rc;
+            }
             pending = blk == PSGSDF_ALBEDO ? 0 : blk == PSGSDF_LIGHT ? 1 : blk == PSGSDF_DIST ? 2 : 3;
         }
         if (stop) break;
+        if (have_prev && prev_close) {   // still open (no host sync happened during this iteration): force one
+            int rc = flush(c); if (rc) return rc;
+            apply_late(prev, *prev_late, -1);
+            close_iteration(c, L, &prev, prev_slot, (float)band_mean(c, *prev_close), full);
+            have_prev = false; prev_close = nullptr;
+            if ((rc = finalize(prev, iter - 1))) return rc;
+        }
         // deferred e_in values are raw sums (not yet divided by S) except the synchronous first one: normalise on use
         const bool last = iter + 1 >= max_iters;
         const bool refine_next = full && c->set.upsample && iter == 5;
@@ -916,9 +921,8 @@ int psgsdf_mg_buffer(psgsdf_ctx* c, int which, void** ptr, int64_t* count) {
     return PSGSDF_OK;
 }
 static int mg_fold(psgsdf_ctx* c, std::initializer_list<int> slots) {
-    int h[8]; int n = 0; for (int s_ : slots) h[n++] = s_;
-    HIPCHK(c, hipMemcpyAsync(c->mg_slots, h, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
-    launch_sum_parts(c->part, c->PB, band_blocks(c), c->mg_slots, n, c->mg_scal, c->stream);
+    SlotList sl; sl.n = 0; for (int s_ : slots) sl.id[sl.n++] = s_;
+    launch_sum_parts(c->part, c->PB, band_blocks(c), sl, c->mg_scal, c->stream);
     return 0;
 }
 static int mg_pcg_grid(psgsdf_ctx* c) {
@@ -949,7 +953,6 @@ int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
         case PSGSDF_MG_SWEEP_DIST: timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); }); return mg_fold(c, {SC_ENERGY, SC_NOBS});
         case PSGSDF_MG_ASSEMBLE: timed(c, "assemble", [&] { launch_assemble(a, c->stream); }); return 0;
         case PSGSDF_MG_PCG_INIT:
-            HIPCHK(c, hipMemsetAsync(c->pcg_sc, 0, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap), c->stream));
             launch_pcg_init(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), c->stream);
             launch_pcg_sum(c->pcg_part, mg_pcg_grid(c), -1, 1, c->mg_ext, c->stream);
             return 0;

@@ -574,18 +574,39 @@ __global__ void __launch_bounds__(kBlock) k_reach(Band b, int* __restrict__ reac
 void launch_reach(const Band& b, int* d_reach, hipStream_t s) {
     if (b.S > 0) hipLaunchKernelGGL(k_reach, dim3((b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, b, d_reach);
 }
-// multi-rank helpers: fold per-workgroup partials into a few doubles that the host program all-reduces
-__global__ void __launch_bounds__(kBlock) k_sum_parts(const double* __restrict__ part, int PB, int nblk, const int* __restrict__ slots, int nslots, double* __restrict__ out) {
+// fold per-workgroup partials into a few doubles.  `out` may be host-mapped pinned memory: the host then needs no
+// D2H copy (each hipMemcpyAsync costs ~10 us of GPU idle around it), only the stream synchronisation it does anyway.
+__global__ void __launch_bounds__(kBlock) k_sum_parts(const double* __restrict__ part, int PB, int nblk, SlotList slots, double* __restrict__ out) {
     __shared__ double red[kBlock / 64];
-    for (int s = 0; s < nslots; ++s) {
-        double t = block_total(part + (size_t)slots[s] * PB, nblk, red);
+    for (int s = 0; s < slots.n; ++s) {
+        double t = block_total(part + (size_t)slots.id[s] * PB, nblk, red);
         if (threadIdx.x == 0) out[s] = t;
         __syncthreads();
     }
 }
-void launch_sum_parts(const double* part, int PB, int nblk, const int* slots, int nslots, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(kBlock), 0, s, part, PB, nblk, slots, nslots, out);
+void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(kBlock), 0, s, part, PB, nblk, slots, out);
 }
+// sum of columns (col, col+1) over the F frame-accumulator rows -> out[0..1]
+__global__ void __launch_bounds__(kBlock) k_frame_cols(const double* __restrict__ frame, int F, int col, double* __restrict__ out) {
+    __shared__ double red[kBlock / 64];
+    double a = 0, b = 0;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) { a += frame[(size_t)f * kFrameRow + col]; b += frame[(size_t)f * kFrameRow + col + 1]; }
+    a = wave_sum(a); b = wave_sum(b);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; out[0] = t; }
+    __syncthreads();
+    if (lane == 0) red[w] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; out[1] = t; }
+}
+void launch_frame_cols(const double* frame, int F, int col, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_frame_cols, dim3(1), dim3(kBlock), 0, s, frame, F, col, out);
+}
+__global__ void k_zero_f64(double* p, int n) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.0; }
+void launch_zero_f64(double* p, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_zero_f64, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), dim3(256), 0, s, p, n); }
 
 // ------------------------------------------------------------------------------------------
 // voxel-major sweeps: one thread per band voxel, iterating the set bits of its visibility mask
@@ -995,6 +1016,8 @@ __global__ void k_solve_light(SweepArgs a, FrameP* frames, float* led_light) {
         for (int i = 0; i < NB; ++i) frames[f].l[i] -= (float)xd[i];
     }
 }
+// the frame accumulator rows are consumed: clear them for the next frame-major sweep (replaces a memset node)
+__global__ void k_clear_frame_rows(double* frame, int n) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) frame[i] = 0.0; }
 void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, hipStream_t s) {
     if (a.F <= 0) return;
     dim3 g((a.F + 63) / 64), bl(64);
@@ -1416,18 +1439,24 @@ void launch_pcg_upd(const SweepArgs& a, double* sc, double* part, int G, int k, 
     if (a.row1 > a.row0) hipLaunchKernelGGL(k_pcg_upd, dim3(G), dim3(kBlock), 0, s, a, sc, part, k);
 }
 // publish |r|^2 and r.z of pass k (end of a chunk: the host has to see them)
-__global__ void __launch_bounds__(kBlock) k_pcg_final(double* sc, double* part, int G, int k) {
+__global__ void __launch_bounds__(kBlock) k_pcg_final(double* sc, double* part, int G, int k0, int k, double* host_out) {
     __shared__ double red[kBlock / 64];
     const double s1 = block_total(pcg_part(part, k, 1), G, red);
     const double s2 = block_total(pcg_part(part, k, 2), G, red);
     if (threadIdx.x == 0) {
         float rhsNorm2 = (float)sc[0];
         bool prev_done = rhsNorm2 == 0.f || (k > 0 && (float)sc[kPcgScalHead + 3 * (k - 1) + 1] < pcg_threshold(rhsNorm2));
-        if (!prev_done) { sc[kPcgScalHead + 3 * k + 1] = s1; sc[kPcgScalHead + 3 * k + 2] = s2; }
+        double rn2_k = 0.0;
+        if (!prev_done) { sc[kPcgScalHead + 3 * k + 1] = s1; sc[kPcgScalHead + 3 * k + 2] = s2; rn2_k = s1; }
+        if (host_out) {   // {|b|^2, |r|^2 of passes k0..k}: everything the host needs to decide, no D2H copy
+            host_out[0] = sc[0];
+            for (int q = k0; q < k; ++q) host_out[1 + q - k0] = sc[kPcgScalHead + 3 * q + 1];
+            host_out[1 + k - k0] = rn2_k;
+        }
     }
 }
-void launch_pcg_final(double* sc, double* part, int G, int k, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_final, dim3(1), dim3(kBlock), 0, s, sc, part, G, k);
+void launch_pcg_final(double* sc, double* part, int G, int k0, int k, double* host_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_final, dim3(1), dim3(kBlock), 0, s, sc, part, G, k0, k, host_out);
 }
 __global__ void __launch_bounds__(kBlock) k_pcg_sum(const double* __restrict__ part_c, int G, int k, int which, double* __restrict__ out) {
     __shared__ double red[kBlock / 64];
