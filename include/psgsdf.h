@@ -185,6 +185,22 @@ int psgsdf_optimize(psgsdf_ctx* ctx, int flags, psgsdf_iter_stats* stats, int st
 /* Optimizer::subsampling (OptimizerAux.cpp:622-684): 2x refine of grid + band rebuild. */
 int psgsdf_upsample2x(psgsdf_ctx* ctx);
 
+/* ---- state producer (SURVEY §8f "next" row 1) ------------------------------------------ */
+
+/* VolumetricGradSdf::init (VolumetricGradSdf.cpp:14-38): an empty volume on the device — dist = T, grad = 0,
+ * weight = 0, rgb = 0, no visibility — with room for `max_frames` integrated frames.  Alternative to
+ * psgsdf_upload_volume. */
+int psgsdf_volume_init(psgsdf_ctx* ctx, int max_frames);
+/* VolumetricGradSdf::update (VolumetricGradSdf.cpp:51-138): fuse one RGB-D frame into the volume.
+ * rgb: H*W*3 float RGB; depth: H*W metres (0 = invalid); normals_xyz: 3 planes of H*W, camera-frame, inward
+ * pointing unit normals (what NormalEstimator::compute returns, NormalEstimator.h:150-176); pose: 4x4 row-major
+ * camera->world; counter: index of this frame in the sequence (the visibility bit it sets, Sdf.h increase_counter). */
+int psgsdf_integrate_frame(psgsdf_ctx* ctx, const float* rgb, const float* depth, const float* normals_xyz,
+                           int width, int height, const float pose[16], int counter, float z_min, float z_max);
+
+/* the per-integrated-frame visibility words (N^3 * words); returns words per voxel (>0) or a negative status */
+int psgsdf_download_vis_seq(psgsdf_ctx* ctx, uint64_t* out);
+
 /* ---- outputs --------------------------------------------------------------------------- */
 
 int psgsdf_get_info(psgsdf_ctx* ctx, psgsdf_info* info);

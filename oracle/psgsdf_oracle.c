@@ -1307,6 +1307,66 @@ int orc_upload_volume(orc_ctx* c, const float* dist, const float* grad_xyz, cons
     c->inited = 0;
     return 0;
 }
+/* VolumetricGradSdf::init, VolumetricGradSdf.cpp:14-38 */
+int orc_volume_init(orc_ctx* c, int max_frames) {
+    if (!c || max_frames < 1) return PSGSDF_ERR_ARG;
+    size_t n = c->nvox;
+    free(c->dist); free(c->gx); free(c->gy); free(c->gz); free(c->weight); free(c->r); free(c->g); free(c->b); free(c->vis_seq);
+    c->dist = (float*)malloc(sizeof(float) * n); for (size_t i = 0; i < n; ++i) c->dist[i] = c->T;
+    c->gx = (float*)calloc(n, sizeof(float)); c->gy = (float*)calloc(n, sizeof(float)); c->gz = (float*)calloc(n, sizeof(float));
+    c->weight = (float*)calloc(n, sizeof(float)); c->r = (float*)calloc(n, sizeof(float)); c->g = (float*)calloc(n, sizeof(float)); c->b = (float*)calloc(n, sizeof(float));
+    c->wpv_seq = (max_frames + 63) / 64; c->vis_seq = (uint64_t*)calloc(n * c->wpv_seq, sizeof(uint64_t));
+    c->inited = 0;
+    return 0;
+}
+/* VolumetricGradSdf::update, VolumetricGradSdf.cpp:51-138 (+ truncate / weight, Sdf.h:44-66) */
+int orc_integrate_frame(orc_ctx* c, const float* rgb, const float* depth, const float* normals_xyz, int W, int H, const float pose[16], int counter, float z_min, float z_max) {
+    if (!c || !c->dist || !c->vis_seq || !rgb || !depth || !normals_xyz || counter < 0 || counter >= 64 * c->wpv_seq) return PSGSDF_ERR_ARG;
+    const float fx = c->fx, fy = c->fy, cx = c->cx, cy = c->cy;
+    float R[9], t[3];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i * 3 + j] = pose[i * 4 + j]; t[i] = pose[i * 4 + 3]; }
+    const float T = c->T, inv_T = (float)(1.0 / (double)c->T);
+    const float* nxp = normals_xyz; const float* nyp = normals_xyz + (size_t)W * H; const float* nzp = normals_xyz + 2 * (size_t)W * H;
+    const double fx_inv = 1.0 / (double)fx, fy_inv = 1.0 / (double)fy;
+    for (int k = 0; k < c->dim[2]; ++k) for (int j = 0; j < c->dim[1]; ++j) for (int i = 0; i < c->dim[0]; ++i) {
+        size_t lin = (size_t)i + (size_t)c->dim[0] * j + (size_t)c->dim[0] * c->dim[1] * k;
+        int idx[3] = {i, j, k}; float xv[3]; voxel2world(c, idx, xv);
+        float tmp[3] = {xv[0] - t[0], xv[1] - t[1], xv[2] - t[2]}, point[3];
+        mulT3(R, tmp, point);
+        if (point[2] < 0.f) continue;
+        const int n = (int)((double)(cx + fx * point[0] / point[2]) + 0.5);   /* +0.5 is a double literal in the reference */
+        const int m = (int)((double)(cy + fy * point[1] / point[2]) + 0.5);
+        if (n < 0 || n >= W || m < 0 || m >= H) continue;
+        const float z = depth[(size_t)m * W + n];
+        if (z <= z_min || z >= z_max) continue;
+        const float sdf = z - point[2];
+        float w = 0.f;
+        if (sdf >= 0.) w = 1.f; else if (sdf >= -T) w = 1.f + sdf * inv_T;
+        if (w == 0) continue;
+        float normal[3] = {nxp[(size_t)m * W + n], nyp[(size_t)m * W + n], nzp[(size_t)m * W + n]};
+        if (dot3(normal, normal) < .1) continue;
+        float zi = (float)(1. / (double)point[2]);
+        float xy_hom[3] = {zi * point[0], zi * point[1], zi * point[2]};
+        /* n_sq_inv = 1/(1+x0^2+y0^2) evaluated in double and stored as float (NormalEstimator.h:66-77,100) */
+        double x0 = fx_inv * ((double)n - (double)cx), y0 = fy_inv * ((double)m - (double)cy);
+        float n_sq_inv = (float)(1.0 / (1.0 + x0 * x0 + y0 * y0));
+        float dn = dot3(normal, xy_hom);
+        if (dn * dn * n_sq_inv < .25 * .25) continue;
+        c->weight[lin] += w;
+        float ts = fmaxf(-T, fminf(T, sdf));
+        c->dist[lin] += (ts - c->dist[lin]) * w / c->weight[lin];
+        float Rn[3]; mul3(R, normal, Rn);
+        c->gx[lin] -= w * Rn[0]; c->gy[lin] -= w * Rn[1]; c->gz[lin] -= w * Rn[2];
+        const float* col = rgb + ((size_t)m * W + n) * 3;
+        c->r[lin] += (col[0] - c->r[lin]) * w / c->weight[lin];
+        c->g[lin] += (col[1] - c->g[lin]) * w / c->weight[lin];
+        c->b[lin] += (col[2] - c->b[lin]) * w / c->weight[lin];
+        c->vis_seq[lin * c->wpv_seq + (counter >> 6)] |= 1ull << (counter & 63);
+    }
+    return 0;
+}
+int orc_download_vis_seq(orc_ctx* c, uint64_t* out) { memcpy(out, c->vis_seq, sizeof(uint64_t) * c->nvox * c->wpv_seq); return c->wpv_seq; }
+
 int orc_set_keyframes(orc_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_images, int width, int height, const float* poses) {
     if (!c || n_frames < 0 || (n_frames > 0 && (!frame_idx || !rgb_images || !poses))) return PSGSDF_ERR_ARG;
     free(c->frame_idx); free(c->img); free(c->poses);

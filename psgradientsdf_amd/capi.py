@@ -135,6 +135,26 @@ class Api:
     def init(self):
         self._check(self._fn("init")(self.ctx), "init")
 
+    # -- state producer (VolumetricGradSdf::init / update)
+    def volume_init(self, max_frames):
+        self._check(self._fn("volume_init")(self.ctx, C.c_int(max_frames)), "volume_init")
+
+    def integrate_frame(self, rgb, depth, normals, pose, counter, z_min=0.05, z_max=10.0):
+        H, W = depth.shape
+        a = [_fp(rgb), _fp(depth), _fp(normals), _fp(pose)]
+        self._check(self._fn("integrate_frame")(self.ctx, a[0][1], a[1][1], a[2][1], C.c_int(W), C.c_int(H), a[3][1], C.c_int(counter),
+                                                 C.c_float(z_min), C.c_float(z_max)), "integrate_frame")
+
+    def download_vis_seq(self, words):
+        i = self.info()
+        n = int(i.dim[0]) * int(i.dim[1]) * int(i.dim[2])
+        out = np.empty((n, words), np.uint64)
+        f = self._fn("download_vis_seq")
+        rc = f(self.ctx, out.ctypes.data_as(C.c_void_p))
+        if rc < 0:
+            self._check(rc, "download_vis_seq")
+        return out
+
     # -- hot path
     def init_albedo(self):
         self._check(self._fn("init_albedo")(self.ctx), "init_albedo")

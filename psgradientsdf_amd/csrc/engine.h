@@ -137,6 +137,8 @@ void launch_matvec(const SweepArgs& a, const float* x, float* y, hipStream_t s);
 void launch_apply_dist(const SweepArgs& a, hipStream_t s);
 void launch_upsample(const DenseView& src, const DenseView& dst, const GridP& g_old, hipStream_t s);
 void launch_fill_f32(float* p, float v, long long n, hipStream_t s);
+void launch_integrate(const DenseView& d, uint64_t* vis_seq, int wpv_seq, const GridP& g, const Cam& cam, const FrameP& fp,
+                      const float* rgb, const float* depth, const float* normals, int counter, float z_min, float z_max, hipStream_t s);
 
 constexpr int kPcgScalHead = 4;   // sc[0]=|b|^2, sc[1]=r0.z0, then 3 doubles per iteration: p.t, |r|^2, r.z
 

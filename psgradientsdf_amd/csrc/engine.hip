@@ -47,6 +47,7 @@ struct psgsdf_ctx {
     // band
     void* band_mem = nullptr; size_t band_bytes = 0;
     void* obs_mem = nullptr;
+    float* stage = nullptr; size_t stage_px = 0;   // device staging of one RGB-D frame (integrate_frame)
     Band band{};
     bool inited = false;
     // accumulators
@@ -640,7 +641,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     free_dense(c);
     hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->frames); hipFree(c->led_light);
-    hipFree(c->band_mem); hipFree(c->obs_mem); hipFree(c->acc_frame); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->d_total);
+    hipFree(c->band_mem); hipFree(c->obs_mem); hipFree(c->stage); hipFree(c->acc_frame); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->d_total);
     if (c->host_buf) hipHostFree(c->host_buf);
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
@@ -668,6 +669,47 @@ int psgsdf_upload_volume(psgsdf_ctx* c, const float* dist, const float* grad_xyz
     HIPCHK(c, hipMemcpyAsync(c->vis_seq, vis_words, sizeof(uint64_t) * n * words_per_voxel, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_volume = true; c->inited = false;
+    return PSGSDF_OK;
+}
+
+int psgsdf_volume_init(psgsdf_ctx* c, int max_frames) {
+    if (!c || max_frames < 1) return fail(c, PSGSDF_ERR_ARG, "volume_init: max_frames");
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long n = c->grid.nvox;
+    free_dense(c);
+    if (c->vis_seq) { hipFree(c->vis_seq); c->vis_seq = nullptr; }
+    int rc = alloc_dense(c, c->dense, n, 0, true); if (rc) return rc;
+    c->wpv_seq = (max_frames + 63) / 64;
+    HIPCHK(c, hipMalloc(&c->vis_seq, sizeof(uint64_t) * n * c->wpv_seq));
+    launch_fill_f32(c->dense.dist, c->grid.T, n, c->stream);
+    for (int a = 0; a < 3; ++a) { HIPCHK(c, hipMemsetAsync(c->dense.g[a], 0, sizeof(float) * n, c->stream)); HIPCHK(c, hipMemsetAsync(c->dense.rho[a], 0, sizeof(float) * n, c->stream)); }
+    HIPCHK(c, hipMemsetAsync(c->dense.weight, 0, sizeof(float) * n, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->vis_seq, 0, sizeof(uint64_t) * n * c->wpv_seq, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_volume = true; c->inited = false;
+    return PSGSDF_OK;
+}
+
+int psgsdf_integrate_frame(psgsdf_ctx* c, const float* rgb, const float* depth, const float* normals_xyz, int width, int height, const float pose[16], int counter, float z_min, float z_max) {
+    if (!c || !c->have_volume || !c->vis_seq) return fail(c, PSGSDF_ERR_STATE, "integrate_frame: volume_init or upload_volume first");
+    if (!rgb || !depth || !normals_xyz || !pose || width < 2 || height < 2 || counter < 0 || counter >= 64 * c->wpv_seq) return fail(c, PSGSDF_ERR_ARG, "integrate_frame: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npx = (size_t)width * height;
+    if (c->stage_px < npx) {
+        hipFree(c->stage); c->stage = nullptr; c->stage_px = 0;
+        HIPCHK(c, hipMalloc(&c->stage, sizeof(float) * npx * 7));
+        c->stage_px = npx;
+    }
+    float* d_rgb = c->stage; float* d_depth = c->stage + 3 * npx; float* d_nrm = c->stage + 4 * npx;
+    HIPCHK(c, hipMemcpyAsync(d_rgb, rgb, sizeof(float) * 3 * npx, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_depth, depth, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_nrm, normals_xyz, sizeof(float) * 3 * npx, hipMemcpyHostToDevice, c->stream));
+    Cam cam = c->cam; cam.W = width; cam.H = height;
+    FrameP fp{};
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) fp.R[i * 3 + j] = pose[i * 4 + j]; fp.t[i] = pose[i * 4 + 3]; }
+    timed(c, "integrate_frame", [&] { launch_integrate(c->dense, c->vis_seq, c->wpv_seq, c->grid, cam, fp, d_rgb, d_depth, d_nrm, counter, z_min, z_max, c->stream); });
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->inited = false;
     return PSGSDF_OK;
 }
 
@@ -831,6 +873,13 @@ int psgsdf_download_volume(psgsdf_ctx* c, float* dist, float* grad_xyz, float* w
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PSGSDF_OK;
+}
+
+int psgsdf_download_vis_seq(psgsdf_ctx* c, uint64_t* out) {
+    if (!c || !c->vis_seq || !out) return PSGSDF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(out, c->vis_seq, sizeof(uint64_t) * c->grid.nvox * c->wpv_seq, hipMemcpyDeviceToHost));
+    return c->wpv_seq;
 }
 
 int psgsdf_download_band(psgsdf_ctx* c, int32_t* lin_idx) {

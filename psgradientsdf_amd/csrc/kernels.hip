@@ -434,6 +434,62 @@ void launch_upsample(const DenseView& src, const DenseView& dst, const GridP& g_
     int grid = (int)min((8 * g_old.nvox + kBlock - 1) / kBlock, (long long)256 * 32);
     hipLaunchKernelGGL(k_upsample, dim3(grid), dim3(kBlock), 0, s, src, dst, g_old);
 }
+// VolumetricGradSdf::update, VolumetricGradSdf.cpp:51-138 (+ truncate / weight, Sdf.h:44-66): fuse one RGB-D frame.
+// One thread per voxel of the dense grid, x fastest: 8 coalesced float planes + one visibility word are read and,
+// for the voxels the frame sees, written back.  HBM-bound: 36 B read + up to 40 B written per voxel.
+__global__ void __launch_bounds__(kBlock) k_integrate(DenseView d, uint64_t* __restrict__ vis_seq, int wpv_seq, GridP g, Cam cam, FrameP fp,
+                                                      const float* __restrict__ rgb, const float* __restrict__ depth, const float* __restrict__ normals,
+                                                      int counter, float z_min, float z_max) {
+#pragma clang fp contract(off)
+    const float T = g.T, inv_T = (float)(1.0 / (double)g.T);
+    const double fx_inv = 1.0 / (double)cam.fx, fy_inv = 1.0 / (double)cam.fy;
+    const size_t npx = (size_t)cam.W * cam.H;
+    const long long nxy = (long long)g.dim[0] * g.dim[1];
+    for (long long lin = blockIdx.x * (long long)blockDim.x + threadIdx.x; lin < g.nvox; lin += (long long)gridDim.x * blockDim.x) {
+        int k = (int)(lin / nxy); int rest = (int)(lin - (long long)k * nxy); int j = rest / g.dim[0]; int i = rest - j * g.dim[0];
+        float xv[3] = {g.origin[0] + g.vs * (float)i, g.origin[1] + g.vs * (float)j, g.origin[2] + g.vs * (float)k};
+        float tmp[3] = {xv[0] - fp.t[0], xv[1] - fp.t[1], xv[2] - fp.t[2]}, p[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) p[a] = (fp.R[0 * 3 + a] * tmp[0] + fp.R[1 * 3 + a] * tmp[1]) + fp.R[2 * 3 + a] * tmp[2];
+        if (p[2] < 0.f) continue;
+        const int n = (int)((double)(cam.cx + cam.fx * p[0] / p[2]) + 0.5);
+        const int m = (int)((double)(cam.cy + cam.fy * p[1] / p[2]) + 0.5);
+        if (n < 0 || n >= cam.W || m < 0 || m >= cam.H) continue;
+        const size_t px = (size_t)m * cam.W + n;
+        const float z = depth[px];
+        if (z <= z_min || z >= z_max) continue;
+        const float sdf = z - p[2];
+        float w = 0.f;
+        if (sdf >= 0.) w = 1.f; else if (sdf >= -T) w = 1.f + sdf * inv_T;
+        if (w == 0) continue;
+        float nrm[3] = {normals[px], normals[npx + px], normals[2 * npx + px]};
+        if ((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2] < .1) continue;
+        const float zi = (float)(1. / (double)p[2]);
+        const float xy[3] = {zi * p[0], zi * p[1], zi * p[2]};
+        const double x0 = fx_inv * ((double)n - (double)cam.cx), y0 = fy_inv * ((double)m - (double)cam.cy);
+        const float n_sq_inv = (float)(1.0 / (1.0 + x0 * x0 + y0 * y0));
+        const float dn = (nrm[0] * xy[0] + nrm[1] * xy[1]) + nrm[2] * xy[2];
+        if (dn * dn * n_sq_inv < .25 * .25) continue;   // normal more than 75.5 deg off the viewing ray
+        const float wsum = d.weight[lin] + w;
+        d.weight[lin] = wsum;
+        const float ts = fmaxf(-T, fminf(T, sdf));
+        const float dv = d.dist[lin];
+        d.dist[lin] = dv + (ts - dv) * w / wsum;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float Rn = (fp.R[a * 3 + 0] * nrm[0] + fp.R[a * 3 + 1] * nrm[1]) + fp.R[a * 3 + 2] * nrm[2];
+            d.g[a][lin] -= w * Rn;
+            float cv = d.rho[a][lin];
+            d.rho[a][lin] = cv + (rgb[px * 3 + a] - cv) * w / wsum;
+        }
+        vis_seq[lin * wpv_seq + (counter >> 6)] |= 1ull << (counter & 63);
+    }
+}
+void launch_integrate(const DenseView& d, uint64_t* vis_seq, int wpv_seq, const GridP& g, const Cam& cam, const FrameP& fp,
+                      const float* rgb, const float* depth, const float* normals, int counter, float z_min, float z_max, hipStream_t s) {
+    int grid = (int)min((g.nvox + kBlock - 1) / kBlock, (long long)256 * 32);
+    hipLaunchKernelGGL(k_integrate, dim3(grid), dim3(kBlock), 0, s, d, vis_seq, wpv_seq, g, cam, fp, rgb, depth, normals, counter, z_min, z_max);
+}
 __global__ void k_fill_f32(float* p, float v, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }

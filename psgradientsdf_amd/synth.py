@@ -145,6 +145,8 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
 
     # ---- images by sphere tracing
     images = np.zeros((F, H, W, 3), np.float64)
+    depth = np.zeros((F, H, W), np.float32)              # metres along the optical axis, 0 = no measurement
+    normals_cam = np.zeros((F, 3, H, W), np.float32)     # camera-frame, inward-pointing (VolumetricGradSdf.cpp:123)
     uu, vv = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
     dirs_c = _unit(np.stack([(uu - cx) / fx, (vv - cy) / fy, np.ones_like(uu)], -1))
     for f in range(F):
@@ -182,6 +184,11 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         col = shade(x, n, f)
         col = np.where(good[:, None], col, 0.0)
         images[f][idx] = col
+        zc = (s * dirs_c[idx][:, 2])
+        depth[f][idx] = np.where(good, zc, 0.0).astype(np.float32)
+        ncam = -(n @ R)                                   # R^T n_world, flipped to point into the surface
+        for a in range(3):
+            normals_cam[f, a][idx] = np.where(good, ncam[:, a], 0.0).astype(np.float32)
     if noise:
         images = images + 0.005 * np.random.default_rng(1).standard_normal(images.shape)
     images = np.clip(images, 0.0, 1.0)
@@ -266,7 +273,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         poses=np.ascontiguousarray(poses_used.reshape(F, 16).astype(np.float32)),
         poses_gt=poses.reshape(F, 16).astype(np.float32),
         light_gt=np.asarray(light, np.float32), frame_idx=np.arange(F, dtype=np.int32),
-        R0=R0, A=A, extent=extent,
+        depth=depth, normals_cam=normals_cam, R0=R0, A=A, extent=extent,
     )
 
 
