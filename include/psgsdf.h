@@ -198,6 +198,14 @@ int psgsdf_volume_init(psgsdf_ctx* ctx, int max_frames);
 int psgsdf_integrate_frame(psgsdf_ctx* ctx, const float* rgb, const float* depth, const float* normals_xyz,
                            int width, int height, const float pose[16], int counter, float z_min, float z_max);
 
+/* NormalEstimator::compute (normals/NormalEstimator.h:150-176): FALS normals of a depth map (11x11 window),
+ * 3 planes of H*W, camera frame. */
+int psgsdf_estimate_normals(psgsdf_ctx* ctx, const float* depth, int width, int height, float* normals_xyz);
+/* RigidPointOptimizer::optimize (sdf_tracker/RigidPointOptimizer.cpp:12-79): frame-to-model depth tracking against the
+ * volume on the device; `pose` (4x4 row-major camera->world) is the start value and receives the result.
+ * Reference defaults: num_iterations 50, conv_threshold 1e-3, damping 1 (RigidOptimizer.h:41-47). */
+int psgsdf_track(psgsdf_ctx* ctx, const float* depth, int width, int height, float pose[16], float z_min, float z_max,
+                 int num_iterations, float conv_threshold, float damping, int* iters_out, int* converged);
 /* the per-integrated-frame visibility words (N^3 * words); returns words per voxel (>0) or a negative status */
 int psgsdf_download_vis_seq(psgsdf_ctx* ctx, uint64_t* out);
 

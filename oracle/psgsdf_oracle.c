@@ -1367,6 +1367,136 @@ int orc_integrate_frame(orc_ctx* c, const float* rgb, const float* depth, const 
 }
 int orc_download_vis_seq(orc_ctx* c, uint64_t* out) { memcpy(out, c->vis_seq, sizeof(uint64_t) * c->nvox * c->wpv_seq); return c->wpv_seq; }
 
+
+/* ------------------------------------------------------------------ front-end "next" rows
+ * FALS normal estimation, normals/NormalEstimator.h:52-176 (cache in double, per-frame part in float with OpenCV's
+ * double-accumulating, un-normalised 11x11 box filter and BORDER_REFLECT_101), and the depth tracker
+ * RigidPointOptimizer::optimize_sampled, sdf_tracker/RigidPointOptimizer.cpp:12-79. */
+static inline int reflect101(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * n - 2 - i; } return i; }
+static void box_filter_d(const double* src, double* dst, int W, int H, int r) {   /* (2r+1)^2 window, un-normalised */
+    double* tmp = (double*)malloc(sizeof(double) * (size_t)W * H);
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) { double s = 0; for (int k = -r; k <= r; ++k) s += src[(size_t)y * W + reflect101(x + k, W)]; tmp[(size_t)y * W + x] = s; }
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) { double s = 0; for (int k = -r; k <= r; ++k) s += tmp[(size_t)reflect101(y + k, H) * W + x]; dst[(size_t)y * W + x] = s; }
+    free(tmp);
+}
+/* cache(): fills float planes {x0_n_sq_inv, y0_n_sq_inv, n_sq_inv, Q11, Q12, Q13, Q22, Q23, Q33} (9 * W*H) */
+int orc_normals_cache(const float K[9], int W, int H, int radius, float* out9) {
+    size_t n = (size_t)W * H;
+    double fx_inv = 1. / (double)K[0], fy_inv = 1. / (double)K[4], cx = (double)K[2], cy = (double)K[5];
+    double* a[6]; double* M[6];
+    for (int i = 0; i < 6; ++i) { a[i] = (double*)malloc(sizeof(double) * n); M[i] = (double*)malloc(sizeof(double) * n); }
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+        size_t p = (size_t)y * W + x;
+        double x0 = fx_inv * ((double)x - cx), y0 = fy_inv * ((double)y - cy);
+        double nsi = 1. / (1. + x0 * x0 + y0 * y0);
+        a[0][p] = x0 * x0 * nsi; a[1][p] = x0 * y0 * nsi; a[2][p] = x0 * nsi; a[3][p] = y0 * y0 * nsi; a[4][p] = y0 * nsi; a[5][p] = nsi;
+        out9[p] = (float)(x0 * nsi); out9[n + p] = (float)(y0 * nsi); out9[2 * n + p] = (float)nsi;
+    }
+    for (int i = 0; i < 6; ++i) box_filter_d(a[i], M[i], W, H, radius);
+    for (size_t p = 0; p < n; ++p) {
+        double M11 = M[0][p], M12 = M[1][p], M13 = M[2][p], M22 = M[3][p], M23 = M[4][p], M33 = M[5][p];
+        double det = M11 * (M22 * M33) + 2 * M12 * (M23 * M13) - (M13 * (M13 * M22) + M12 * (M12 * M33) + M23 * (M23 * M11));
+        double di = 1. / det;
+        out9[3 * n + p] = (float)(di * (M22 * M33 - M23 * M23)); out9[4 * n + p] = (float)(di * (M13 * M23 - M12 * M33));
+        out9[5 * n + p] = (float)(di * (M12 * M23 - M13 * M22)); out9[6 * n + p] = (float)(di * (M11 * M33 - M13 * M13));
+        out9[7 * n + p] = (float)(di * (M12 * M13 - M11 * M23)); out9[8 * n + p] = (float)(di * (M11 * M22 - M12 * M12));
+    }
+    for (int i = 0; i < 6; ++i) { free(a[i]); free(M[i]); }
+    return 0;
+}
+/* compute(): normals (3 planes) from a depth map, NormalEstimator.h:150-176 */
+int orc_estimate_normals(orc_ctx* c, const float* depth, int W, int H, float* normals_xyz) {
+    (void)0;
+    size_t n = (size_t)W * H;
+    float K[9] = {c->fx, 0, c->cx, 0, c->fy, c->cy, 0, 0, 1};
+    float* cache = (float*)malloc(sizeof(float) * 9 * n);
+    orc_normals_cache(K, W, H, 5, cache);
+    double* src = (double*)malloc(sizeof(double) * n); double* b[3];
+    for (int q = 0; q < 3; ++q) {
+        b[q] = (double*)malloc(sizeof(double) * n);
+        for (size_t p = 0; p < n; ++p) { float zi = depth[p] != 0.f ? 1.0f / depth[p] : 0.f; src[p] = (double)(cache[(size_t)q * n + p] * zi); }
+        box_filter_d(src, b[q], W, H, 5);
+    }
+    for (size_t p = 0; p < n; ++p) {
+        float b1 = (float)b[0][p], b2 = (float)b[1][p], b3 = (float)b[2][p];
+        const float Q11 = cache[3 * n + p], Q12 = cache[4 * n + p], Q13 = cache[5 * n + p], Q22 = cache[6 * n + p], Q23 = cache[7 * n + p], Q33 = cache[8 * n + p];
+        float nx = b1 * Q11 + b2 * Q12 + b3 * Q13, ny = b1 * Q12 + b2 * Q22 + b3 * Q23, nz = b1 * Q13 + b2 * Q23 + b3 * Q33;
+        float nn = sqrtf(nx * nx + ny * ny + nz * nz);
+        normals_xyz[p] = nx / nn; normals_xyz[n + p] = ny / nn; normals_xyz[2 * n + p] = nz / nn;
+    }
+    free(cache); free(src); for (int q = 0; q < 3; ++q) free(b[q]);
+    return 0;
+}
+
+/* VoxelGrid::nearest_index (VoxelGrid.cpp:57-72) */
+static long nearest_index(const orc_ctx* c, const float p[3]) {
+    float fi[3];
+    for (int a = 0; a < 3; ++a) fi[a] = (p[a] - c->origin[a]) / c->vs;
+    if (fi[0] <= 0 || fi[1] <= 0 || fi[2] <= 0 || fi[0] >= (c->dim[0] - 1) || fi[1] >= (c->dim[1] - 1) || fi[2] >= (c->dim[2] - 1)) return -1;
+    int im = (int)(fi[0] + 0.5), jm = (int)(fi[1] + 0.5), km = (int)(fi[2] + 0.5);
+    return (long)im + (long)jm * c->dim[0] + (long)km * c->dim[0] * c->dim[1];
+}
+/* SE3::exp (Sophus): R = exp(omega), t = V upsilon */
+static void se3_exp(const float xi[6], float T[16]) {
+    float R[9]; so3_exp(xi + 3, R);
+    const float* w = xi + 3; float th2 = dot3(w, w);
+    float V[9];
+    float Om[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}, Om2[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Om2[i * 3 + j] = (Om[i * 3] * Om[j] + Om[i * 3 + 1] * Om[3 + j]) + Om[i * 3 + 2] * Om[6 + j];
+    if (th2 < 1e-10f) { for (int i = 0; i < 9; ++i) V[i] = R[i]; }
+    else { float th = sqrtf(th2); float a = (1.f - cosf(th)) / th2, b = (th - sinf(th)) / (th2 * th);
+        for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0 ? 1.f : 0.f) + a * Om[i] + b * Om2[i]; }
+    float t[3]; mul3(V, xi, t);
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j]; T[i * 4 + 3] = t[i]; }
+    T[12] = T[13] = T[14] = 0; T[15] = 1;
+}
+/* one Gauss-Newton pass of the tracker: fills H (21 upper), g (6), E, count for the given pose */
+static void track_accumulate(const orc_ctx* c, const float* depth, int W, int H, const float pose[16], float z_min, float z_max, double acc[29]) {
+    float R[9], t[3];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R[i * 3 + j] = pose[i * 4 + j]; t[i] = pose[i * 4 + 3]; }
+    const float fx_inv = 1.f / c->fx, fy_inv = 1.f / c->fy;
+    memset(acc, 0, sizeof(double) * 29);
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+        const float z = depth[(size_t)y * W + x];
+        if (z <= z_min || z >= z_max) continue;
+        const float x0 = ((float)x - c->cx) * fx_inv, y0 = ((float)y - c->cy) * fy_inv;
+        float pc[3] = {x0 * z, y0 * z, z}, p[3]; mul3(R, pc, p);
+        for (int a = 0; a < 3; ++a) p[a] += t[a];
+        long I = nearest_index(c, p);
+        if (I < 0 || !(c->weight[I] > 0)) continue;
+        /* tsdf(point, &grad): VolumetricGradSdf.h:76-88 */
+        float gr[3] = {c->gx[I], c->gy[I], c->gz[I]}, gn[3]; normalized3(gr, gn);
+        int idx[3]; for (int a = 0; a < 3; ++a) idx[a] = (int)((p[a] - c->origin[a]) / c->vs + 0.5f);
+        float xv[3]; voxel2world(c, idx, xv);
+        float dv[3] = {xv[0] - p[0], xv[1] - p[1], xv[2] - p[2]};
+        float phi = c->dist[I] + dot3(gn, dv);
+        float gxi[6] = {gn[0], gn[1], gn[2], p[1] * gn[2] - p[2] * gn[1], p[2] * gn[0] - p[0] * gn[2], p[0] * gn[1] - p[1] * gn[0]};
+        int q = 0;
+        for (int i = 0; i < 6; ++i) { for (int k = i; k < 6; ++k) acc[q++] += (double)(gxi[i] * gxi[k]); acc[21 + i] += (double)(phi * gxi[i]); }
+        acc[27] += (double)(phi * phi); acc[28] += 1.0;
+    }
+}
+/* RigidPointOptimizer::optimize_sampled with sampling 1: pose (4x4 row-major) updated in place; returns 1 on convergence */
+int orc_track(orc_ctx* c, const float* depth, int W, int H, float pose[16], float z_min, float z_max, int num_iterations, float conv_threshold, float damping, int* iters_out, int* converged) {
+    if (converged) *converged = 0;
+    for (int k = 0; k < num_iterations; ++k) {
+        double acc[29]; track_accumulate(c, depth, W, H, pose, z_min, z_max, acc);
+        if (acc[28] == 0) { if (iters_out) *iters_out = k; return 0; }
+        double Hd[36], gd[6], xd[6]; int q = 0;
+        for (int i = 0; i < 6; ++i) { for (int j = i; j < 6; ++j) { Hd[i * 6 + j] = (double)(float)acc[q]; Hd[j * 6 + i] = (double)(float)acc[q]; ++q; } gd[i] = (double)(float)acc[21 + i]; }
+        solve_spd(6, Hd, gd, xd);
+        float xi[6], n2 = 0; for (int i = 0; i < 6; ++i) { xi[i] = damping * (float)xd[i]; n2 += xi[i] * xi[i]; }
+        if (n2 < conv_threshold * conv_threshold) { if (iters_out) *iters_out = k; if (converged) *converged = 1; return 0; }
+        float mxi[6]; for (int i = 0; i < 6; ++i) mxi[i] = -xi[i];
+        float E[16], P[16]; se3_exp(mxi, E);
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float s_ = 0; for (int m = 0; m < 4; ++m) s_ += E[i * 4 + m] * pose[m * 4 + j]; P[i * 4 + j] = s_; }
+        memcpy(pose, P, sizeof(P));
+    }
+    if (iters_out) *iters_out = num_iterations;
+    return 0;
+}
+int orc_track_system(orc_ctx* c, const float* depth, int W, int H, const float pose[16], float z_min, float z_max, double acc[29]) { track_accumulate(c, depth, W, H, pose, z_min, z_max, acc); return 0; }
+
 int orc_set_keyframes(orc_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_images, int width, int height, const float* poses) {
     if (!c || n_frames < 0 || (n_frames > 0 && (!frame_idx || !rgb_images || !poses))) return PSGSDF_ERR_ARG;
     free(c->frame_idx); free(c->img); free(c->poses);

@@ -145,6 +145,22 @@ class Api:
         self._check(self._fn("integrate_frame")(self.ctx, a[0][1], a[1][1], a[2][1], C.c_int(W), C.c_int(H), a[3][1], C.c_int(counter),
                                                  C.c_float(z_min), C.c_float(z_max)), "integrate_frame")
 
+    def estimate_normals(self, depth):
+        H, W = depth.shape
+        a = _fp(depth)
+        out = np.empty((3, H, W), np.float32)
+        self._check(self._fn("estimate_normals")(self.ctx, a[1], C.c_int(W), C.c_int(H), out.ctypes.data_as(C.c_void_p)), "estimate_normals")
+        return out
+
+    def track(self, depth, pose, z_min=0.05, z_max=10.0, num_iterations=50, conv_threshold=1e-3, damping=1.0):
+        H, W = depth.shape
+        a = _fp(depth)
+        P = np.ascontiguousarray(pose, np.float32).reshape(16).copy()
+        it = C.c_int(); conv = C.c_int()
+        self._check(self._fn("track")(self.ctx, a[1], C.c_int(W), C.c_int(H), P.ctypes.data_as(C.c_void_p), C.c_float(z_min), C.c_float(z_max),
+                                      C.c_int(num_iterations), C.c_float(conv_threshold), C.c_float(damping), C.byref(it), C.byref(conv)), "track")
+        return P.reshape(4, 4), it.value, bool(conv.value)
+
     def download_vis_seq(self, words):
         i = self.info()
         n = int(i.dim[0]) * int(i.dim[1]) * int(i.dim[2])

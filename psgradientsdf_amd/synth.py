@@ -69,7 +69,7 @@ def _sh(n, order):
 
 
 def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, noise=True,
-               perturb=True, z_mult=1, dtype=np.float32):
+               perturb=True, z_mult=1, dtype=np.float32, bump=1.0, arc=360.0):
     """Build a scene.  N: grid edge (z edge = N*z_mult, z_mult bumpy spheres stacked along z for the
     weak-scaling bench), F keyframes of W x H pixels.
 
@@ -81,7 +81,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
     shift = np.array([0.013, -0.021, 0.007], np.float64)
     T = 5.0 * vs
     R0 = 0.34 * N * vs
-    A = 0.01 * N * vs
+    A = 0.01 * N * vs * bump      # bump > 1: stronger relief (pose tracking needs shape that is not rotation-symmetric)
     centres = [shift + np.array([0, 0, (s - 0.5 * (z_mult - 1)) * N * vs]) for s in range(z_mult)]
     fx = fy = 525.0 * W / 640.0
     cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
@@ -94,7 +94,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
     poses = np.zeros((F, 4, 4), np.float64)
     zspan = 0.5 * (z_mult - 1) * N * vs
     for f in range(F):
-        az = 2 * np.pi * f / F
+        az = np.deg2rad(arc) * f / F      # arc < 360: a short video-like sweep (frame-to-model tracking tests)
         el = np.deg2rad(15.0) * (1 if f % 2 == 0 else -1)
         zc = 0.0 if z_mult == 1 else -zspan + 2 * zspan * ((f * 7) % F) / max(F - 1, 1)
         target = shift + np.array([0, 0, zc])
