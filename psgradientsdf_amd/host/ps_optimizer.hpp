@@ -11,6 +11,7 @@
 // the reference writes from inside alternatingOptimize (optimizer_doc.txt, after_poses_opt_<k>.txt,
 // *_pointcloud.ply).  Mesh extraction (marching cubes) is a SURVEY §8f "next" row and not part of it.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -21,6 +22,7 @@
 #include <vector>
 
 #include "../../include/psgsdf.h"
+#include "marching_cubes.hpp"
 
 namespace psgsdf_host {
 
@@ -44,14 +46,123 @@ struct OptimizerSettings {                           // OptimizerSettings.h:24-5
     LossFunction loss = CAUCHY;
 };
 
-// SoA image of VolumetricGradSdf's state (x-fastest, VoxelGrid.h:79-82)
+struct DepthImage;
+// writers shared by VolumetricGradSdf (init_* files) and Optimizer (refined files): cropped box of |d| <= sqrt(3) vs,
+// -dist, grid-local coordinates (VolumetricGradSdf.cpp:234-318,379-442, OptimizerAux.cpp:278-363,513-577)
+struct CropBox { int lo[3], hi[3]; bool any; };
+inline CropBox crop_box(const int dim[3], const std::vector<float>& dist, float vs) {
+    CropBox b{{1 << 30, 1 << 30, 1 << 30}, {-(1 << 30), -(1 << 30), -(1 << 30)}, false};
+    size_t lin = 0;
+    for (int k = 0; k < dim[2]; ++k) for (int j = 0; j < dim[1]; ++j) for (int i = 0; i < dim[0]; ++i, ++lin) {
+        if (std::fabs(dist[lin]) > std::sqrt(3) * vs) continue;
+        int idx[3] = {i, j, k};
+        for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], idx[a]); b.hi[a] = std::max(b.hi[a], idx[a]); }
+        b.any = true;
+    }
+    return b;
+}
+inline bool write_mesh(const std::string& file, const int dim[3], float vs, const std::vector<float>& dist, const std::vector<float>& weight, const std::vector<float>& rgb) {
+    CropBox b = crop_box(dim, dist, vs); if (!b.any) return false;
+    const size_t n = (size_t)dim[0] * dim[1] * dim[2];
+    int d[3] = {b.hi[0] - b.lo[0] + 1, b.hi[1] - b.lo[1] + 1, b.hi[2] - b.lo[2] + 1};
+    const size_t nv = (size_t)d[0] * d[1] * d[2];
+    std::vector<float> t(nv), w(nv); std::vector<unsigned char> r(nv), g(nv), bl(nv);
+    size_t pos = 0;
+    for (int k = b.lo[2]; k <= b.hi[2]; ++k) for (int j = b.lo[1]; j <= b.hi[1]; ++j) for (int i = b.lo[0]; i <= b.hi[0]; ++i, ++pos) {
+        size_t lin = (size_t)i + (size_t)j * dim[0] + (size_t)k * dim[0] * dim[1];
+        t[pos] = -dist[lin]; w[pos] = weight[lin];
+        r[pos] = (unsigned char)int(255 * rgb[lin]); g[pos] = (unsigned char)int(255 * rgb[n + lin]); bl[pos] = (unsigned char)int(255 * rgb[2 * n + lin]);
+    }
+    float size[3] = {vs * d[0], vs * d[1], vs * d[2]}, org[3] = {-vs * b.lo[0], -vs * b.lo[1], -vs * b.lo[2]};
+    MarchingCubes mc(d, size, org);
+    mc.computeIsoSurface(t.data(), w.data(), r.data(), g.data(), bl.data());
+    return mc.savePly(file);
+}
+inline bool write_sdf(const std::string& file, const int dim[3], float vs, const std::vector<float>& dist) {
+    CropBox b = crop_box(dim, dist, vs); if (!b.any) return false;
+    std::ofstream f(file.c_str()); if (!f.is_open()) return false;
+    f << b.hi[0] - b.lo[0] + 1 << " " << b.hi[1] - b.lo[1] + 1 << " " << b.hi[2] - b.lo[2] + 1 << "\n";
+    f << b.lo[0] * vs << " " << b.lo[1] * vs << " " << b.lo[2] * vs << "\n" << vs << "\n";
+    for (int k = b.lo[2]; k <= b.hi[2]; ++k) for (int j = b.lo[1]; j <= b.hi[1]; ++j) for (int i = b.lo[0]; i <= b.hi[0]; ++i)
+        f << -dist[(size_t)i + (size_t)j * dim[0] + (size_t)k * dim[0] * dim[1]] << "\n";
+    return true;
+}
+
+// SoA image of VolumetricGradSdf's state (x-fastest, VoxelGrid.h:79-82).  Two modes: host arrays handed to the optimiser
+// (voxelps_scene), or -- when created with `attach` -- a volume that lives on the device from the first frame on
+// (voxelPS: VolumetricGradSdf::update and the tracker run there too).
 struct VolumetricGradSdf {
     int grid_dim_[3] = {0, 0, 0};
     float voxel_size_ = 0, T_ = 0;
     float shift_[3] = {0, 0, 0};
+    float z_min_ = 0.5f, z_max_ = 10.0f;             // Sdf.h:40-41
+    size_t counter_ = 0;
     std::vector<float> dist, grad, weight, rgb;      // N, 3N (x|y|z), N, 3N (r|g|b)
     std::vector<uint64_t> vis; int vis_words = 1;    // N*vis_words, bit c = seen by integrated frame c
+    psgsdf_ctx* ctx = nullptr;                       // device-resident mode (owned)
     size_t num_voxels() const { return (size_t)grid_dim_[0] * grid_dim_[1] * grid_dim_[2]; }
+    ~VolumetricGradSdf() { if (ctx) psgsdf_destroy(ctx); }
+
+    // VolumetricGradSdf(grid_dim, voxel_size, shift, T) + init() on the device (main_ps.cpp:183)
+    bool attach(const int dim[3], float voxel_size, const float shift[3], float T, const Mat3f& K, const psgsdf_settings& s, int max_frames) {
+        for (int a = 0; a < 3; ++a) { grid_dim_[a] = dim[a]; shift_[a] = shift[a]; }
+        voxel_size_ = voxel_size; T_ = T;
+        psgsdf_grid_desc g{}; for (int a = 0; a < 3; ++a) { g.dim[a] = dim[a]; g.shift[a] = shift[a]; } g.voxel_size = voxel_size; g.truncation = T;
+        if (psgsdf_create(&g, K.v, &s, 0, &ctx)) { ctx = nullptr; return false; }
+        std::cout << "Number of voxels: " << num_voxels() << std::endl;
+        return psgsdf_volume_init(ctx, max_frames) == 0;
+    }
+    void set_zmin(float z) { z_min_ = z; }
+    void set_zmax(float z) { z_max_ = z; }
+    void increase_counter() { ++counter_; }
+    // VolumetricGradSdf::update (VolumetricGradSdf.cpp:51-138): FALS normals + fusion, both on the device
+    bool update(const ImageRGB& color, const std::vector<float>& depth, const Mat4f& pose) {
+        std::vector<float> nrm((size_t)3 * color.rows * color.cols);
+        if (psgsdf_estimate_normals(ctx, depth.data(), color.cols, color.rows, nrm.data())) return false;
+        return psgsdf_integrate_frame(ctx, color.data.data(), depth.data(), nrm.data(), color.cols, color.rows, pose.data(), (int)counter_, z_min_, z_max_) == 0;
+    }
+    bool sync_host() {
+        const size_t n = num_voxels();
+        dist.resize(n); grad.resize(3 * n); weight.resize(n); rgb.resize(3 * n);
+        return psgsdf_download_volume(ctx, dist.data(), grad.data(), weight.data(), rgb.data(), nullptr) == 0;
+    }
+    bool extract_mesh(const std::string& filename) { return sync_host() && write_mesh(filename, grid_dim_, voxel_size_, dist, weight, rgb); }
+    bool saveSDF(const std::string& filename) { return sync_host() && write_sdf(filename, grid_dim_, voxel_size_, dist); }
+    // extract_pc, VolumetricGradSdf.cpp:320-376: x y z nx ny nz r g b of every voxel with |d| < sqrt(3) vs and weight > 0
+    bool extract_pc(const std::string& filename) {
+        if (!sync_host()) return false;
+        const size_t n = num_voxels(); std::vector<size_t> sel;
+        for (size_t lin = 0; lin < n; ++lin) if (weight[lin] > 0 && std::fabs(dist[lin]) < std::sqrt(3) * voxel_size_) sel.push_back(lin);
+        std::ofstream ply(filename.c_str()); if (!ply.is_open()) return false;
+        ply << "ply\nformat ascii 1.0\nelement vertex " << sel.size() << "\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+            << "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header" << std::endl;
+        const int nx = grid_dim_[0], nxy = grid_dim_[0] * grid_dim_[1];
+        for (size_t lin : sel) {
+            int k = (int)(lin / nxy), rest = (int)(lin - (size_t)k * nxy), j = rest / nx, i = rest - j * nx;
+            float g[3] = {grad[lin], grad[n + lin], grad[2 * n + lin]}; float z = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+            if (z > 0) { float s = std::sqrt(z); g[0] /= s; g[1] /= s; g[2] /= s; }
+            ply << voxel_size_ * i - dist[lin] * g[0] << " " << voxel_size_ * j - dist[lin] * g[1] << " " << voxel_size_ * k - dist[lin] * g[2] << " " << g[0] << " " << g[1] << " " << g[2] << " "
+                << int(255 * rgb[lin]) << " " << int(255 * rgb[n + lin]) << " " << int(255 * rgb[2 * n + lin]) << std::endl;
+        }
+        return true;
+    }
+};
+
+// RigidPointOptimizer (sdf_tracker/RigidPointOptimizer.{h,cpp}, RigidOptimizer.h:41-47): frame-to-model tracking on the device volume
+class RigidPointOptimizer {
+    VolumetricGradSdf* tSDF_;
+    int num_iterations_ = 50; float conv_threshold_ = 1e-3f, damping_ = 1.0f;
+    Mat4f pose_ = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+public:
+    explicit RigidPointOptimizer(VolumetricGradSdf* tSDF) : tSDF_(tSDF) {}
+    void set_pose(const Mat4f& p) { pose_ = p; }
+    Mat4f pose() const { return pose_; }
+    bool optimize(const std::vector<float>& depth, int cols, int rows) {
+        int iters = 0, conv = 0;
+        if (psgsdf_track(tSDF_->ctx, depth.data(), cols, rows, pose_.data(), tSDF_->z_min_, tSDF_->z_max_, num_iterations_, conv_threshold_, damping_, &iters, &conv)) return false;
+        if (conv) std::cout << "... Convergence after " << iters << " iterations!" << std::endl;
+        return conv != 0;
+    }
 };
 
 class Optimizer {
@@ -65,7 +176,7 @@ protected:
     std::vector<std::shared_ptr<ImageRGB>> images_;
     std::vector<Mat4f> poses_;
     std::vector<std::string> key_stamps_;
-    psgsdf_ctx* ctx_ = nullptr;
+    psgsdf_ctx* ctx_ = nullptr; bool borrowed_ = false;
     size_t num_frames_ = 0, num_voxels_ = 0;
     std::ofstream doc_;
 
@@ -98,9 +209,14 @@ protected:
         }
         std::cout << "===> [" << iter << "]: relative diff " << r->rel_diff << std::endl;
         if (doc_.is_open()) doc_ << "===> [" << iter << "]: relative diff " << r->rel_diff << "\n";
+        if (r->upsampled) {   // PsOptimizer.cpp:397-398
+            save_pointcloud("upsample_after_" + std::to_string(iter));
+            extract_mesh("upsample_after_" + std::to_string(iter));
+        }
         if (iter_done % 3 == 0) {
             savePoses("after_poses_opt_" + std::to_string(iter_done));
             save_pointcloud("after_iter_" + std::to_string(iter_done));
+            extract_mesh("after_iter_" + std::to_string(iter_done));
         }
         return 0;
     }
@@ -108,7 +224,7 @@ protected:
 public:
     Optimizer(VolumetricGradSdf* tSDF, const float voxel_size, const Mat3f& K, std::string save_path, OptimizerSettings* settings)
         : tSDF_(tSDF), voxel_size_(voxel_size), K_(K), save_path_(save_path), settings_(settings) {}
-    virtual ~Optimizer() { if (ctx_) psgsdf_destroy(ctx_); }
+    virtual ~Optimizer() { if (ctx_ && !borrowed_) psgsdf_destroy(ctx_); }
 
     void setImages(std::vector<std::shared_ptr<ImageRGB>> images) { images_ = images; }          // Optimizer.h:137-140
     void setPoses(std::vector<Mat4f>& pose) { poses_ = pose; }                                    // Optimizer.h:142-145
@@ -121,6 +237,20 @@ public:
         num_frames_ = frame_idx_.size();
         num_voxels_ = tSDF_->num_voxels();
         if (num_frames_ == 0) return;
+        if (tSDF_->ctx) {   // device-resident volume: the fused state is already there
+            ctx_ = tSDF_->ctx; borrowed_ = true;
+            const int W = images_[0]->cols, H = images_[0]->rows;
+            std::vector<float> img((size_t)num_frames_ * W * H * 3), P(num_frames_ * 16);
+            for (size_t f = 0; f < num_frames_; ++f) {
+                std::copy(images_[f]->data.begin(), images_[f]->data.end(), img.begin() + f * (size_t)W * H * 3);
+                std::copy(poses_[f].begin(), poses_[f].end(), P.begin() + f * 16);
+            }
+            int rc = psgsdf_set_keyframes(ctx_, (int)num_frames_, frame_idx_.data(), img.data(), W, H, P.data());
+            if (rc) { fail("psgsdf_set_keyframes", rc); return; }
+            rc = psgsdf_init(ctx_);
+            if (rc) fail("psgsdf_init", rc);
+            return;
+        }
         if (ctx_) { psgsdf_destroy(ctx_); ctx_ = nullptr; }
         psgsdf_grid_desc g{};
         for (int a = 0; a < 3; ++a) { g.dim[a] = tSDF_->grid_dim_[a]; g.shift[a] = tSDF_->shift_[a]; }
@@ -164,7 +294,9 @@ public:
             on_iter(n_done, &recs[n_done - 1]);   // the callback is not invoked for the terminating iteration
             std::cout << "===> [" << iter << "]: " << (result ? "converged!" : "diverged!") << std::endl;
             doc_ << "===> [" << iter << "]: " << (result ? "converged! \n" : "diverged!\n");
-            save_pointcloud("final_refined");                      // PsOptimizer.cpp:372,379
+            save_pointcloud("final_refined");                      // PsOptimizer.cpp:372-373,379-380
+            extract_mesh("final_refined");
+            if (settings_->model == LED) saveSDF("refined_sdf.sdf");   // LedOptimizer.cpp:422,430
         }
         // the reference mutates the shared settings (B9): report the effective weights back the same way
         psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
@@ -241,6 +373,23 @@ public:
         return true;
     }
 
+    // extract_mesh / saveSDF, OptimizerAux.cpp:278-363,513-577
+    bool extract_mesh(std::string filename) {
+        psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
+        size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
+        std::vector<float> d(n), w(n), rgb(3 * n);
+        if (psgsdf_download_volume(ctx_, d.data(), nullptr, w.data(), rgb.data(), nullptr)) return false;
+        bool ok = write_mesh(save_path_ + filename + "_mesh.ply", info.dim, info.voxel_size, d, w, rgb);
+        if (!ok) std::cout << "couldn't save mesh " << save_path_ << filename << std::endl;
+        return ok;
+    }
+    bool saveSDF(std::string filename) {
+        psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
+        size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
+        std::vector<float> d(n);
+        if (psgsdf_download_volume(ctx_, d.data(), nullptr, nullptr, nullptr, nullptr)) return false;
+        return write_sdf(save_path_ + filename, info.dim, info.voxel_size, d);
+    }
     psgsdf_ctx* context() { return ctx_; }
 };
 

@@ -1,0 +1,187 @@
+// voxelPS — drop-in for the reference executable: `voxelPS --config_file <config.json>` (cpp/voxel_ps/src/main_ps.cpp:41-343),
+// same JSON keys (ConfigLoader.h:16-170), same exit codes, same output files under the "output" prefix.  Every numerical
+// stage runs on the GPU through libpsgsdf.so: FALS normals, depth tracking, fusion, the photometric-stereo optimisation.
+// Extra optional keys: "grid dim" (default 128, main_ps.cpp:123), "max keyframes" (default 40, :312).
+#include "image_loader.hpp"
+#include "mini_json.hpp"
+
+using namespace psgsdf_host;
+
+// compute_centroid, main_ps.cpp:346-375
+static void compute_centroid(const Mat3f& K, const DepthImage& depth, const Mat4f& T, float out[3]) {
+    double c[3] = {0, 0, 0}; int counter = 0;
+    const float fx_inv = 1.f / K.v[0], fy_inv = 1.f / K.v[4], cx = K.v[2], cy = K.v[5];
+    for (int y = 0; y < depth.rows; ++y) for (int x = 0; x < depth.cols; ++x) {
+        float z = depth.data[(size_t)y * depth.cols + x];
+        if (z > 0.0) {
+            float p[3] = {(float(x) - cx) * fx_inv * z, (float(y) - cy) * fy_inv * z, z};
+            for (int a = 0; a < 3; ++a) c[a] += T[a * 4] * p[0] + T[a * 4 + 1] * p[1] + T[a * 4 + 2] * p[2] + T[a * 4 + 3];
+            ++counter;
+        }
+    }
+    for (int a = 0; a < 3; ++a) out[a] = (float)(c[a] / counter);
+}
+// sampleKeyFrame, main_ps.cpp:392-421
+template <class A, class B, class C_, class D>
+static void sampleKeyFrame(A& frames, B& stamps, C_& images, D& poses, int max_num) {
+    if ((int)frames.size() < max_num) return;
+    max_num -= 1;
+    float step = static_cast<float>(frames.size()) / static_cast<float>(max_num), idx = 0;
+    A f2; B s2; C_ i2; D p2;
+    for (int count = 0; count < max_num; ++count) { int i = static_cast<int>(idx); f2.push_back(frames[i]); s2.push_back(stamps[i]); i2.push_back(images[i]); p2.push_back(poses[i]); idx += step; }
+    f2.push_back(frames.back()); s2.push_back(stamps.back()); i2.push_back(images.back()); p2.push_back(poses.back());
+    frames = f2; stamps = s2; images = i2; poses = p2;
+}
+static void quat_of(const Mat4f& M, float q[4]) {   // Eigen::Quaternionf(Matrix3f): x y z w
+    float t = M[0] + M[5] + M[10];
+    if (t > 0) { t = std::sqrt(t + 1.0f); q[3] = 0.5f * t; t = 0.5f / t; q[0] = (M[9] - M[6]) * t; q[1] = (M[2] - M[8]) * t; q[2] = (M[4] - M[1]) * t; }
+    else { int a = 0; if (M[5] > M[0]) a = 1; if (M[10] > M[a * 5]) a = 2; int b = (a + 1) % 3, c = (b + 1) % 3;
+        t = std::sqrt(M[a * 5] - M[b * 5] - M[c * 5] + 1.0f); q[a] = 0.5f * t; t = 0.5f / t;
+        q[3] = (M[c * 4 + b] - M[b * 4 + c]) * t; q[b] = (M[b * 4 + a] + M[a * 4 + b]) * t; q[c] = (M[c * 4 + a] + M[a * 4 + c]) * t; }
+}
+
+// host-side self tests that need no GPU (tests/test_host_tools.py): PNG decoding and the generated marching-cubes table
+static int selftest_png(const char* path) {
+    PngImage p; if (!read_png(path, p)) { std::cout << "FAIL" << std::endl; return 1; }
+    unsigned long long sum = 0; for (uint16_t v : p.px) sum += v;
+    std::cout << p.width << " " << p.height << " " << p.channels << " " << p.bit_depth << " " << sum << std::endl; return 0;
+}
+static int selftest_mc() {
+    int dim[3] = {24, 24, 24}; float size[3] = {24, 24, 24}, org[3] = {0, 0, 0};
+    MarchingCubes mc(dim, size, org);
+    int ntri = 0; for (int c = 0; c < 256; ++c) ntri += (int)mc.table(c).size() / 3;
+    std::vector<float> t(24 * 24 * 24), w(t.size(), 1.f); std::vector<unsigned char> col(t.size() + 2, 128);
+    for (int k = 0; k < 24; ++k) for (int j = 0; j < 24; ++j) for (int i = 0; i < 24; ++i) { float dx = i - 11.3f, dy = j - 11.7f, dz = k - 11.1f; t[(k * 24 + j) * 24 + i] = 7.2f - std::sqrt(dx * dx + dy * dy + dz * dz); }
+    mc.computeIsoSurface(t.data(), w.data(), col.data(), col.data(), col.data());
+    double vol = 0, maxr = 0, minr = 1e9; auto& v = mc.vertices();
+    for (size_t f = 0; f + 2 < v.size(); f += 3) { const auto &a = v[f], &b = v[f + 1], &c = v[f + 2];
+        vol += (a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0])) / 6.0;
+        for (int q = 0; q < 3; ++q) { double r = std::sqrt(std::pow(v[f + q][0] - 11.3, 2) + std::pow(v[f + q][1] - 11.7, 2) + std::pow(v[f + q][2] - 11.1, 2)); maxr = std::max(maxr, r); minr = std::min(minr, r); } }
+    std::cout << ntri << " " << mc.num_faces() << " " << vol << " " << minr << " " << maxr << std::endl; return 0;
+}
+
+int main(int argc, char* argv[]) {
+    if (argc >= 3 && std::string(argv[1]) == "--selftest-png") return selftest_png(argv[2]);
+    if (argc >= 2 && std::string(argv[1]) == "--selftest-mc") return selftest_mc();
+    std::string configfile;
+    for (int i = 1; i < argc; ++i) { std::string a = argv[i]; if (a == "--config_file" && i + 1 < argc) configfile = argv[++i]; else if (a.rfind("--config_file=", 0) == 0) configfile = a.substr(14); }
+    std::cout << "load the config file from: " << configfile << std::endl;
+    JsonObject config;
+    if (!config.load(configfile)) { std::cout << "can't load config file!" << std::endl << "fail to load the config file!" << std::endl; return 1; }
+    if (!config.contains("input") || !config.contains("output") || !config.contains("datatype")) {
+        std::cout << "missing necessary input arguments (input/out folder/datatype) in config file!" << std::endl << "fail to load the config file!" << std::endl; return 1; }
+    const std::string input = config.str("input"), output = config.str("output"), datatype = config.str("datatype");
+    ImageLoader* loader;
+    if (datatype == "tum") loader = new TumrgbdLoader(input);
+    else if (datatype == "led" || datatype == "synth") loader = new SynthLoader(input);
+    else if (datatype == "intrinsic3d" || datatype == "multiview") loader = new MultiviewLoader(input);
+    else { std::cerr << "Your specified dataset type is not supported (yet)." << std::endl; return 1; }
+    // TrackingSettings.h:26-38 defaults
+    std::string pose_file = "pose.txt"; size_t first = 0, last = (size_t)-1; float voxel_size = 0.02f, truncation_factor = 5, zmin = 0.5f, zmax = 3.5f, sharp_thr = 0.5f;
+    if (config.contains("pose filename")) pose_file = config.str("pose filename");
+    if (config.contains("first")) first = (size_t)config.num("first");
+    if (config.contains("last")) last = (size_t)config.num("last");
+    if (config.contains("voxel size")) voxel_size = (float)config.num("voxel size");
+    if (config.contains("truncation factor")) truncation_factor = (float)config.num("truncation factor");
+    if (config.contains("sharpness threshold")) sharp_thr = (float)config.num("sharpness threshold");
+    if (config.contains("zmin")) zmin = (float)config.num("zmin");
+    if (config.contains("zmax")) zmax = (float)config.num("zmax");
+    OptimizerSettings* opt_set_ = new OptimizerSettings();
+    if (config.contains("model type")) {
+        std::string m = config.str("model type");
+        if (m == "SH1") { opt_set_->model = SH1; opt_set_->order = 1; } else if (m == "SH2") { opt_set_->model = SH2; opt_set_->order = 2; } else if (m == "LED") opt_set_->model = LED;
+        else { std::cerr << "Your specified model type is not supported (yet)." << std::endl; return 1; }
+    }
+    if (config.contains("loss function")) {
+        std::string l = config.str("loss function");
+        if (l == "cauchy") opt_set_->loss = CAUCHY; else if (l == "l2") opt_set_->loss = L2; else if (l == "huber") opt_set_->loss = HUBER;
+        else if (l == "trunc_l2") opt_set_->loss = TRUNC_L2;   // the reference leaves the loss uninitialised here (ConfigLoader.h:126, B7); we honour the key
+        else if (l == "tukey") opt_set_->loss = TUKEY;
+        else { std::cerr << "Your specified loss function type is not supported (yet)." << std::endl; return 1; }
+    }
+    if (config.contains("reg albedo")) opt_set_->reg_weight_rho = (float)config.num("reg albedo");
+    if (config.contains("reg norm")) opt_set_->reg_weight_n = (float)config.num("reg norm");
+    if (config.contains("reg laplacian")) opt_set_->reg_weight_l = (float)config.num("reg laplacian");
+    if (config.contains("max iter")) opt_set_->max_it = (int)config.num("max iter");
+    if (config.contains("damping")) opt_set_->damping = (float)config.num("damping");
+    if (config.contains("converge threshold")) opt_set_->conv_threshold = (float)config.num("converge threshold");
+    if (config.contains("upsample")) opt_set_->upsample = config.boolean("upsample");
+    if (config.contains("lambda")) { opt_set_->lambda = (float)config.num("lambda"); opt_set_->lambda_sq = opt_set_->lambda * opt_set_->lambda; }
+    { std::ofstream save_conf(output + "saved_config.json"); if (!save_conf.is_open()) std::cout << "could not save config file." << std::endl; config.dump(save_conf); }
+    bool light = false, albedo = false, distance = false, pose = false;
+    if (config.contains("--light")) light = config.boolean("--light");
+    if (config.contains("--albedo")) albedo = config.boolean("--albedo");
+    if (config.contains("--distance")) distance = config.boolean("--distance");
+    if (config.contains("--pose")) pose = config.boolean("--pose");
+    const int grid = config.contains("grid dim") ? (int)config.num("grid dim") : 128;
+    const int max_key = config.contains("max keyframes") ? (int)config.num("max keyframes") : 40;
+    const float truncation = truncation_factor * voxel_size;
+
+    if (!loader->load_intrinsics("intrinsics.txt")) { std::cerr << "No intrinsics file found in " << input << "!" << std::endl; return 1; }
+    const Mat3f K = loader->K();
+    ImageRGB color; DepthImage depth;
+    if (!loader->load_next(color, depth)) { std::cerr << " -> Frame could not be loaded!" << std::endl; return 1; }
+    if (color.rows != depth.rows || color.cols != depth.cols) { std::cerr << "-> depth image and color image sizes don't match." << std::endl; return 1; }
+    loader->reset_counter();
+
+    int grid_dim[3] = {grid, grid, grid};
+    VolumetricGradSdf* tSDF = new VolumetricGradSdf();
+    RigidPointOptimizer* pOpt = nullptr; Optimizer* vOpt = nullptr;
+    std::ofstream pose_out(output + "tracking_poses.txt");
+    std::vector<Mat4f> poses; std::vector<int> keyframes{0}; std::vector<std::string> key_stamps; std::vector<std::shared_ptr<ImageRGB>> key_images;
+    const Mat4f I4 = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::vector<Mat4f> key_poses{I4};   // key_poses[0] is Identity even with GT poses (main_ps.cpp:139, B1)
+    int dist_to_last_keyframe = 0; bool GT_pose = false;
+    if (!loader->load_pose(pose_file, poses)) { std::cout << "GT poses is not avalible!" << std::endl; poses.push_back(I4); }
+    else { std::cout << poses.size() << " GT poses are loaded." << std::endl; GT_pose = true; }
+    for (size_t i = 0; i < first; ++i) loader->load_next(color, depth);
+    Mat4f cur_pose = I4;
+    for (size_t i = first; i <= last; ++i) {
+        std::cout << "Working on frame: " << i << std::endl;
+        if (!loader->load_next(color, depth)) { std::cerr << " -> Frame " << i << " could not be loaded!" << std::endl; break; }
+        if (GT_pose && i >= poses.size()) break;
+        if (i == first) {
+            float centroid[3]; compute_centroid(K, depth, poses[0], centroid);
+            psgsdf_settings s{};
+            s.model = opt_set_->model == LED ? PSGSDF_LED : (opt_set_->model == SH2 ? PSGSDF_SH2 : PSGSDF_SH1); s.loss = (int)opt_set_->loss; s.lambda = opt_set_->lambda; s.damping = opt_set_->damping;
+            s.reg_weight_rho = opt_set_->reg_weight_rho; s.reg_weight_n = opt_set_->reg_weight_n; s.reg_weight_l = opt_set_->reg_weight_l; s.max_it = opt_set_->max_it;
+            s.conv_threshold = opt_set_->conv_threshold; s.upsample = opt_set_->upsample ? 1 : 0; s.ref_quirks = 1;
+            const int max_frames = (int)std::min<size_t>(last - first + 1, 4096);
+            if (!tSDF->attach(grid_dim, voxel_size, centroid, truncation, K, s, max_frames)) { std::cerr << "could not create the device volume" << std::endl; return 1; }
+            tSDF->set_zmin(zmin); tSDF->set_zmax(zmax);
+            pOpt = new RigidPointOptimizer(tSDF);
+            if (opt_set_->model == LED) vOpt = new LedOptimizer(tSDF, voxel_size, K, output, opt_set_); else vOpt = new PsOptimizer(tSDF, voxel_size, K, output, opt_set_);
+            tSDF->update(color, depth.data, poses[0]);
+            cur_pose = poses[0];
+            key_stamps.push_back(loader->rgb_timestamp());
+            key_images.push_back(std::make_shared<ImageRGB>(color));
+        } else {
+            tSDF->increase_counter();
+            bool integrated = false;
+            if (GT_pose) { tSDF->update(color, depth.data, poses[i]); cur_pose = poses[i]; integrated = true; }
+            else { bool conv = pOpt->optimize(depth.data, depth.cols, depth.rows); cur_pose = pOpt->pose(); if (conv) { tSDF->update(color, depth.data, cur_pose); integrated = true; } }
+            if (integrated) {
+                if (sharpDetector(color, sharp_thr) || dist_to_last_keyframe > 5) {
+                    dist_to_last_keyframe = 0;
+                    keyframes.push_back((int)(i - first)); key_stamps.push_back(loader->rgb_timestamp()); key_poses.push_back(cur_pose);
+                    key_images.push_back(std::make_shared<ImageRGB>(color));
+                } else ++dist_to_last_keyframe;
+            }
+        }
+        float q[4]; quat_of(cur_pose, q);
+        pose_out << loader->depth_timestamp() << " " << cur_pose[3] << " " << cur_pose[7] << " " << cur_pose[11] << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << "\n";
+    }
+    pose_out.close();
+    if (!vOpt) { std::cerr << "no frame was processed" << std::endl; return 1; }
+    if (!tSDF->extract_mesh(output + "init_mesh.ply")) std::cerr << "Could not save mesh to " << output + "init_mesh.ply" << "!" << std::endl;
+    if (!tSDF->extract_pc(output + "init_pointcloud.ply")) std::cerr << "Could not save point cloud to " << output + "init_pointcloud.ply" << "!" << std::endl;
+    if (!tSDF->saveSDF(output + "init_sdf.sdf")) std::cerr << "Could not save sdf to " << output + "init_sdf.sdf" << "!" << std::endl;
+    std::cout << " selected key frame: " << std::endl; for (int k : keyframes) std::cout << k << " "; std::cout << std::endl;
+    if ((int)keyframes.size() > max_key) sampleKeyFrame(keyframes, key_stamps, key_images, key_poses, max_key);
+    std::cout << " selected key frame after sampling: " << std::endl; for (int k : keyframes) std::cout << k << " "; std::cout << std::endl;
+    vOpt->setImages(key_images); vOpt->setKeyframes(keyframes); vOpt->setKeytimestamps(key_stamps); vOpt->setPoses(key_poses);
+    vOpt->init();
+    vOpt->alternatingOptimize(light, albedo, distance, pose);
+    delete vOpt; delete pOpt; delete tSDF; delete loader; delete opt_set_;
+    return 0;
+}
