@@ -43,7 +43,8 @@ def algorithmic_bytes(kernel, S, n_obs, W, H, F, laplacian=False):
         "sweep_pose": S * B_v + U,
         "sweep_dist": S * B_v + U + 56 * S,
         "energy": S * B_v + U,
-        "pcg_mv": 124 * S,
+        "pcg_pass": 144 * S,    # 13 coefficients 52 + 12 columns 48 + record {r,t,p,inv} read 16 + write 16 + x 8 + rare-column flag 4
+        "pcg_mv": 124 * S,      # two-kernel form (multi-rank phases)
         "pcg_upd": 40 * S,
         "assemble": (56 + 80 + 12) * S,
         "derive": (4 + 12 + 24 + 36 + 12) * S,
@@ -182,7 +183,7 @@ def main():
                            "launches_timed": int(watched[1])}
         # whole-iteration algorithmic bytes (SURVEY.md §8d formula) for reference
         U = min(48 * n_obs, 12 * args.width * args.height * args.frames)
-        B_iter = 4 * (S * 60 + U) + 120 * S + 124 * cg_iters * S
+        B_iter = 4 * (S * 60 + U) + 120 * S + 124 * cg_iters * S   # SURVEY §8d per-pass figure kept (the fused pass moves 144 B/row)
         if run is not None:
             out["config"]["collectives_per_step"] = run.n_collectives / max(args.steps + args.warmup, 1)
         out["iteration"] = {"algorithmic_bytes": B_iter, "achieved_GBs": B_iter * (value / world) / 1e9,

@@ -306,6 +306,13 @@ class Api:
                                                    y.ctypes.data_as(C.c_void_p) if x is not None else None), "debug_dist_system")
         return diag, rhs, y
 
+    def debug_time_pcg_pass(self, blocks=0, rows=2, ablate=0, reps=50, stamps=False):
+        ms = C.c_double(0)
+        st = np.zeros((max(blocks, 1), 8), np.int64) if stamps else None
+        self._check(self._fn("debug_time_pcg_pass")(self.ctx, C.c_int(blocks), C.c_int(rows), C.c_int(ablate | (1024 if stamps else 0)), C.c_int(reps), C.byref(ms),
+                                                     st.ctypes.data_as(C.c_void_p) if stamps else None), "debug_time_pcg_pass")
+        return (ms.value, st) if stamps else ms.value
+
     def debug_frame_system(self, block):
         i = self.info()
         if block == LIGHT:

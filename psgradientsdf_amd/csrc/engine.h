@@ -65,6 +65,7 @@ struct Band {
     int* hx;                  // [Spad] 1 if any of the 6 rare columns of this row is non-zero
     float* rhs; float* x; float* r; float* t; float* p; float* inv;
     float2* zp;               // [Spad] {z_i, p_i of the previous PCG pass}: ONE 8-byte gather per matrix column
+    float4* rec[2];           // [Spad] fused PCG (single GPU): {r, t, p, inv} of the previous pass, double-buffered
     // per-frame observation lists (static per band): rows visible in frame f, ascending
     int* obs_ptr;             // [F+1]
     int* obs_rows;            // [obs_ptr[F]]
@@ -79,6 +80,7 @@ struct Accum {
 };
 constexpr int kFrameRow = 64;        // doubles per frame accumulator row (SH2: 45 + 9 + 2 = 56)
 constexpr int kPcgMaxBlocks = 2048;  // workgroups of one PCG pass (grid-stride)
+constexpr int kCgfMaxBlocks = 768;   // workgroups of one fused PCG pass: at most 3 partials per thread and sum (kernels.hip)
 
 enum { SC_ENERGY = 0, SC_NOBS = 1, SC_EN = 2, SC_EL = 3, SC_ACCEPT = 4, SC_AUX0 = 5, SC_AUX1 = 6, SC_AUX2 = 7, SC_COUNT = 8 };
 
@@ -133,6 +135,8 @@ void launch_pcg_init(const SweepArgs& a, double* sc, double* part, int G, hipStr
 void launch_pcg_mv(const SweepArgs& a, double* sc, double* part, int G, int k, int with_damping, hipStream_t s);
 void launch_pcg_upd(const SweepArgs& a, double* sc, double* part, int G, int k, hipStream_t s);
 void launch_pcg_final(double* sc, double* part, int G, int k0, int k, double* host_out, hipStream_t s);
+void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s);
+void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int rows, int k, int kmax, double* mb, hipStream_t s, int ablate = 0);
 void launch_matvec(const SweepArgs& a, const float* x, float* y, hipStream_t s);   // debug: y = H x (no damping)
 void launch_apply_dist(const SweepArgs& a, hipStream_t s);
 void launch_upsample(const DenseView& src, const DenseView& dst, const GridP& g_old, hipStream_t s);

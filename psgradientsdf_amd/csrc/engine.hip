@@ -204,7 +204,7 @@ int build_band(psgsdf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int Spad = ((S + kBlock - 1) / kBlock) * kBlock + kBlock;
     // planes (4-byte units per row): see Band
-    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 11;
+    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 11 + 8;
     const size_t bytes = (n4 * 4 + (size_t)KW * 8) * Spad + 256;
     if (c->band_mem) { hipFree(c->band_mem); c->band_mem = nullptr; }
     HIPCHK(c, hipMalloc(&c->band_mem, bytes));
@@ -215,6 +215,7 @@ int build_band(psgsdf_ctx* c) {
     Band& b = c->band;
     b.S = S; b.Spad = Spad; b.KW = KW;
     b.vis = (uint64_t*)take(KW, 8);
+    b.rec[0] = (float4*)take(4, 4); b.rec[1] = (float4*)take(4, 4);
     b.lin = (int*)take(1, 4);
     b.dist = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.g[a] = (float*)take(1, 4);
@@ -307,49 +308,61 @@ int ps_energy(psgsdf_ctx* c, double* E, int64_t* nobs) {
     return 0;
 }
 
+// Launch shape of the fused PCG pass.  The pass is one memory round-trip chain per workgroup (coefficients + column
+// indices -> records -> reduction), so the fastest shape keeps EVERY row's loads in flight in ONE generation of resident
+// workgroups: 1 row per thread while 768 workgroups cover the band (4 waves/SIMD resident), else 3 rows per thread in
+// <= 512 workgroups (256 VGPRs, 2 waves/SIMD resident); bigger bands take several trips of that shape.
+// Measured on the 256^3 band (1317 row-blocks): 3 rows x 439 workgroups 17.4 us, 1 row x 659 x 2 trips 18.0 us,
+// 2 rows x 659 (two generations) 19.6 us  (tools/pcg_ablate.py, profiles/r01_notes.md).
+static void cgf_shape(int nblk, int* G, int* rows) {
+    nblk = std::max(1, nblk);
+    int r = nblk <= kCgfMaxBlocks ? 1 : 3, cap = r == 1 ? kCgfMaxBlocks : 512;
+    if (const char* e = getenv("PSGSDF_PCG_ROWS")) { int v = atoi(e); if (v == 1 || v == 3) r = v; }       // tuning knobs
+    if (const char* e = getenv("PSGSDF_PCG_BLOCKS")) { int v = atoi(e); if (v > 0 && v <= kCgfMaxBlocks) cap = v; }
+    const int per = (nblk + r - 1) / r;                 // workgroups if every thread took r rows once
+    const int trips = (per + cap - 1) / cap;
+    *G = (per + trips - 1) / trips; *rows = r;
+}
+
+// Fused PCG (kernels.hip: k_cgf_pass): kernel k finishes pass k-1 and runs pass k, so a chunk of n kernels tells the host
+// about the passes up to k0+n-2; the kernel that detects convergence (or hits the cap) is also the one that finalises x.
 int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_out, double* err_out) {
     const int S = c->band.S;
     int cap = c->set.cg_max_it > 0 ? c->set.cg_max_it : 2 * S;
     if (cap > c->pcg_cap) cap = c->pcg_cap;
-    // balanced grid-stride: the fewest equal passes that fit the workgroup budget
-    const int nblk = std::max(1, band_blocks(c));
-    int maxb = 704;   // ~2 rows per thread at the 256^3 band size measured best (profiles/r01_notes.md)
-    if (const char* e = getenv("PSGSDF_PCG_BLOCKS")) { int v = atoi(e); if (v > 0 && v <= kPcgMaxBlocks) maxb = v; }   // tuning knob
-    const int passes = (nblk + maxb - 1) / maxb;
-    const int G = (nblk + passes - 1) / passes;
-    // every scalar the kernels or the host read is written by an earlier kernel of this solve: no memset needed
-    timed(c, "pcg_init", [&] { launch_pcg_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
+    int G, rows;
+    cgf_shape(band_blocks(c), &G, &rows);
+    timed(c, "pcg_init", [&] { launch_cgf_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
     // first chunk sized from the previous solve (the count is stable between Gauss-Newton iterations)
-    int chunk = std::min(60, std::max(4, c->last_cg_iters + 2));
-    int k = 0, iters = -1;
-    double rhsNorm2 = 0;
-    float rn2_last = 0;
+    int chunk = std::min(64, std::max(4, c->last_cg_iters + 2));
+    int k = 0, iters = -1;            // k = next kernel index; kernels 0..cap exist (kernel cap only finalises)
+    float rhsN = 0, rn2_last = 0, threshold = 0;
     while (true) {
-        int n = chunk; if (k + n > cap) n = cap - k;
-        if (n <= 0) { iters = cap; break; }
-        for (int q = 0; q < n; ++q) {
-            timed(c, "pcg_mv", [&] { launch_pcg_mv(a, c->pcg_sc, c->pcg_part, G, k + q, 1, c->stream); });
-            timed(c, "pcg_upd", [&] { launch_pcg_upd(a, c->pcg_sc, c->pcg_part, G, k + q, c->stream); });
-        }
-        if (c->mbox_used + 64 > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
-        const size_t off = c->mbox_used; c->mbox_used += 64;
-        launch_pcg_final(c->pcg_sc, c->pcg_part, G, k, k + n - 1, c->mbox_dev + off, c->stream);
+        const int n = std::min(chunk, cap + 1 - k);
+        if (c->mbox_used + (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+        const size_t off = c->mbox_used; c->mbox_used += n;
+        for (int q = 0; q < n; ++q)
+            timed(c, "pcg_pass", [&] { launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, k + q, cap, c->mbox_dev + off + q, c->stream); });
         { int rc = flush(c); if (rc) return rc; }
         const double* st = c->mbox + off;
-        rhsNorm2 = st[0];
-        float rhsN = (float)rhsNorm2;
-        if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }
-        float threshold = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
-        for (int q = 0; q < n; ++q) {
-            rn2_last = (float)st[1 + q];
-            if (rn2_last < threshold) { iters = k + q; break; }
+        for (int q = 0; q < n && iters < 0; ++q) {
+            const int kk = k + q;
+            if (kk == 0) {
+                rhsN = (float)st[0];
+                if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }
+                threshold = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
+                rn2_last = rhsN;
+                continue;
+            }
+            rn2_last = (float)st[q];                       // |r|^2 after pass kk-1
+            if (rn2_last < threshold) iters = kk - 1;      // Eigen breaks before ++i
+            else if (kk == cap) iters = cap;
         }
         if (iters >= 0) break;
         k += n;
-        if (k >= cap) { iters = cap; break; }
         chunk = 4;
     }
-    double err = sqrt((double)rn2_last / (double)(float)rhsNorm2);
+    double err = sqrt((double)rn2_last / (double)rhsN);
     *iters_out = iters; *err_out = err; *success_out = err <= (double)FLT_EPSILON;
     c->last_cg_iters = iters;
     return 0;
@@ -627,7 +640,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     c->cam.fx = K[0]; c->cam.fy = K[4]; c->cam.cx = K[2]; c->cam.cy = K[5];
     bool ok = hipStreamCreate(&c->stream) == hipSuccess
         && hipMalloc(&c->pcg_sc, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap)) == hipSuccess
-        && hipMalloc(&c->pcg_part, sizeof(double) * 6 * kPcgMaxBlocks) == hipSuccess
+        && hipMalloc(&c->pcg_part, sizeof(double) * 14 * kPcgMaxBlocks) == hipSuccess
         && hipMalloc(&c->mg_scal, sizeof(double) * 16) == hipSuccess && hipMalloc(&c->mg_ext, sizeof(double) * 4) == hipSuccess
         && hipMalloc(&c->mg_slots, sizeof(int) * 8) == hipSuccess
         && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess
@@ -1207,6 +1220,33 @@ int psgsdf_debug_dist_system(psgsdf_ctx* c, float* diag, float* rhs, const float
         HIPCHK(c, hipMemcpyAsync(y, c->band.t, sizeof(float) * S, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSGSDF_OK;
+}
+
+// timing ablations of the PCG pass (tools/pcg_ablate.py): `reps` launches of k_cgf_pass with the given grid and ablation
+// bits on the current (already assembled) distance system; results of the solve are garbage afterwards
+int psgsdf_debug_time_pcg_pass(psgsdf_ctx* c, int blocks, int rows, int ablate, int reps, double* avg_ms, long long* stamps) {
+    if (!c || !c->inited || !avg_ms) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SweepArgs a = make_args(c, c->reg_l != 0.f);
+    launch_sweep_dist(a, c->stream);
+    launch_assemble(a, c->stream);
+    int G, rdef; cgf_shape(band_blocks(c), &G, &rdef);
+    if (blocks > 0) G = std::min(blocks, kCgfMaxBlocks);
+    if (rows <= 0) rows = rdef;
+    launch_cgf_init(a, c->pcg_sc, c->pcg_part, G, c->stream);
+    hipEvent_t e0, e1; HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    for (int q = 0; q < 3; ++q) launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, q, 1 << 30, c->mbox_dev, c->stream, ablate | 16);
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int q = 0; q < reps; ++q) launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, 3 + q, 1 << 30, c->mbox_dev, c->stream, ablate | 16);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *avg_ms = (double)ms / reps;
+    if (stamps) {   // [G][8] wall-clock ticks (100 MHz) of the LAST launch, taken with ablate | 1024
+        HIPCHK(c, hipMemcpy(stamps, c->pcg_sc + 16, sizeof(long long) * 8 * G, hipMemcpyDeviceToHost));
+    }
     return PSGSDF_OK;
 }
 

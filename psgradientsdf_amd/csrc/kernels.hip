@@ -1616,6 +1616,225 @@ __global__ void __launch_bounds__(kBlock) k_pcg_sum(const double* __restrict__ p
 void launch_pcg_sum(const double* part, int G, int k, int which, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_pcg_sum, dim3(1), dim3(kBlock), 0, s, part, G, k, which, out);
 }
+
+// ------------------------------------------------------------------------------------------
+// Fused Jacobi-PCG: ONE kernel and ONE reduction per CG iteration, same recurrences as Eigen's conjugate_gradient
+// (single-GPU path; the multi-rank phases keep the two-kernel form above, whose dot products the host all-reduces).
+// Pass k (t = A p_k) also reduces, over the same rows,
+//     P = p.t   B = sum inv r t   C = sum inv t^2   D = sum r t   E = sum t^2   Z = r.z   R = |r|^2      (r = r_k, double)
+// from which the NEXT kernel derives alpha_k = Z / P and, without ever reducing r_{k+1} = r_k - alpha t separately,
+//     r_{k+1}.z_{k+1} = Z - 2 alpha B + alpha^2 C        |r_{k+1}|^2 = R - 2 alpha D + alpha^2 E
+// (Z and R are re-summed from the vectors every pass, so the expansions never chain and the cancellation costs at most the
+// digits of one pass's residual drop, taken from a double).  The vector updates x += alpha p, r -= alpha t, z = inv r,
+// p = z + beta p are applied lazily in float exactly as the reference does them: kernel k first finishes pass k-1 for its
+// own rows, and re-derives r_k, z_k, p_k of every gathered column from that column's record {r, t, p, inv} of pass k-1
+// (ONE 16-byte gather per column; records double-buffered because neighbours still read the old ones).
+//   fs (device doubles): [0] |b|^2   [1] done (0 = running)
+//   part: [2 parity][kCgfSums][kPcgMaxBlocks]
+//   mb  : mapped host slot of THIS kernel: k = 0 -> |b|^2, k > 0 -> |r|^2 after pass k-1 (what the host loop tests)
+// ------------------------------------------------------------------------------------------
+constexpr int kCgfSums = 7;
+__device__ __forceinline__ double* fpart(double* part, int k, int kind) { return part + ((size_t)((k & 1) * kCgfSums + kind)) * kPcgMaxBlocks; }
+
+// n sums at once, identical in every thread of every workgroup.  All loads of a thread are issued before the first use
+// (fixed trip count, predicated): ONE memory round trip however many partials there are -- a dynamic-trip loop made it three.
+template <int N>
+__device__ __forceinline__ void block_total_n(double* const* src, int n, double* red /*[N * kBlock/64]*/, double* out) {
+    constexpr int T = kCgfMaxBlocks / kBlock;
+    double ld[T][N];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const int i = threadIdx.x + j * kBlock;
+#pragma unroll
+        for (int q = 0; q < N; ++q) ld[j][q] = i < n ? src[q][i] : 0.0;
+    }
+    double v[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        v[q] = ld[0][q];
+#pragma unroll
+        for (int j = 1; j < T; ++j) v[q] += ld[j][q];
+        v[q] = wave_sum(v[q]);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) red[q * (kBlock / 64) + w] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        double s = 0;
+#pragma unroll
+        for (int i = 0; i < kBlock / 64; ++i) s += red[q * (kBlock / 64) + i];
+        out[q] = s;
+    }
+}
+template <int N>
+__device__ __forceinline__ void block_part_store_n(const double* vin, double* const* dst, double* red) {
+    double v[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = wave_sum(vin[q]);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) red[q * (kBlock / 64) + w] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        double s = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[threadIdx.x * (kBlock / 64) + i];
+        dst[threadIdx.x][blockIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_cgf_init(SweepArgs a, double* fs, double* part) {
+    __shared__ double red[kBlock / 64];
+    const Band& b = a.b;
+    double bb = 0;
+    for (int i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x; i < a.row1; i += gridDim.x * blockDim.x) {
+        float dg = b.H[i];
+        if (a.damping != 0.0f) dg += a.damping * dg;
+        const float inv = dg != 0.f ? 1.0f / dg : 1.0f;
+        const float r = b.rhs[i];
+        b.x[i] = 0.f;
+        b.rec[1][i] = make_float4(r, 0.f, 0.f, inv);      // {r_0, t_{-1} = 0, p_{-1} = 0, inv}: read by kernel 0
+        bb += (double)r * (double)r;
+    }
+    block_part_store(bb, fpart(part, -1, 6), red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) fs[1] = 0.0;
+}
+void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s) {
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_cgf_init, dim3(G), dim3(kBlock), 0, s, a, fs, part);
+}
+// kernel k: finishes pass k-1 (k > 0), decides convergence, then runs pass k unless k == kmax (the iteration cap).
+// The pass is latency-bound (column index -> 16-byte gather -> 13 fused multiply-adds), so each thread keeps the loads of
+// kCgfRows rows in flight at once and the raw records of the first group are requested BEFORE the partial sums of the
+// previous pass are reduced (the records do not depend on alpha / beta; only the arithmetic on them does).
+struct CgfRow { float h[kNQCommon]; int c[kNQCommon]; float4 o[kNQCommon]; float x; int i, hx; bool live; };
+// phase 1: everything addressed by the row itself; phase 2: the records addressed by the column indices of phase 1.
+// The caller runs phase 1 of ALL its rows before phase 2 of any, so that a thread waits for two round trips, not 2 x rows.
+__device__ __forceinline__ void cgf_load1(const Band& b, int i, int row1, CgfRow& w, int ab) {
+    w.i = i; w.live = i < row1;
+    const int ii = w.live ? i : row1 - 1;
+#pragma unroll
+    for (int q = 0; q < kNQCommon; ++q) { w.h[q] = (ab & 8) ? 1.0f : b.H[(size_t)q * b.Spad + ii]; w.c[q] = (q == 0 || (ab & 2)) ? ii : b.col[(size_t)q * b.Spad + ii]; }
+    w.hx = (ab & 128) ? 0 : b.hx[ii]; w.x = b.x[ii];
+}
+__device__ __forceinline__ void cgf_load2(const float4* __restrict__ rin, float damping, CgfRow& w) {
+#pragma unroll
+    for (int q = 0; q < kNQCommon; ++q) w.o[q] = rin[w.c[q]];
+    if (damping != 0.0f) w.h[0] += damping * w.h[0];
+}
+template <int kCgfRows, int kMinWaves>
+__global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, double* fs, double* part, int k, int kmax, double* mb, int ab) {   // ab: timing ablations (tools/), 0 in production
+    __shared__ double red[kCgfSums * kBlock / 64];
+    const Band& b = a.b;
+    long long* ts = (long long*)(fs + 16) + (size_t)blockIdx.x * 8;   // ab & 1024: stage timestamps of every workgroup
+#define CGF_STAMP(j) do { if ((ab & 1024) && threadIdx.x == 0) { ts[j] = clock64(); if (j == 0) ts[6] = wall_clock64(); if (j == 4) ts[7] = wall_clock64(); } } while (0)
+    CGF_STAMP(0);
+    const float4* __restrict__ rin = b.rec[(k + 1) & 1];
+    float4* __restrict__ rout = b.rec[k & 1];
+    const int stride = gridDim.x * blockDim.x;
+    int i0 = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    CgfRow w[kCgfRows];
+    const double stopped = fs[1];
+#pragma unroll
+    for (int u = 0; u < kCgfRows; ++u) cgf_load1(b, i0 + u * stride, a.row1, w[u], ab);
+#pragma unroll
+    for (int u = 0; u < kCgfRows; ++u) cgf_load2(rin, a.damping, w[u]);
+
+    CGF_STAMP(1);
+    float alpha_prev = 0.f, beta = 0.f, rr_cur, rhsNorm2;
+    if (ab & 1) { alpha_prev = 0.01f; beta = 0.5f; rr_cur = 1.f; rhsNorm2 = 1.f; }
+    else if (!(ab & 16) && stopped != 0.0 && stopped <= (double)k) return;   // stopped by an EARLIER kernel of this solve (kernel j writes j + 1)
+    else if (k == 0) {
+        double* src[1] = {fpart(part, -1, 6)}; double bb;
+        block_total_n<1>(src, gridDim.x, red, &bb);
+        rhsNorm2 = (float)bb; rr_cur = rhsNorm2;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { fs[0] = bb; mb[0] = bb; }
+    } else {
+        double* src[kCgfSums]; double t[kCgfSums];
+#pragma unroll
+        for (int q = 0; q < kCgfSums; ++q) src[q] = fpart(part, k - 1, q);
+        block_total_n<kCgfSums>(src, gridDim.x, red, t);
+        rhsNorm2 = (float)fs[0];
+        const float rz_old = (float)t[5];
+        alpha_prev = rz_old / (float)t[0];                // alpha = absNew / p.dot(tmp)
+        const double al = (double)alpha_prev;
+        const float rz_cur = (float)(t[5] - 2.0 * al * t[1] + al * al * t[2]);
+        rr_cur = (float)(t[6] - 2.0 * al * t[3] + al * al * t[4]);
+        beta = rz_cur / rz_old;                            // beta = absNew / absOld
+        if (blockIdx.x == 0 && threadIdx.x == 0) mb[0] = (double)rr_cur;
+    }
+    CGF_STAMP(2);
+    const bool rhs_zero = rhsNorm2 == 0.f;
+    const bool stop = !(ab & 16) && (rhs_zero || k == kmax || (k > 0 && rr_cur < pcg_threshold(rhsNorm2)));
+    if (stop && blockIdx.x == 0 && threadIdx.x == 0) fs[1] = (double)(k + 1);
+    double s[kCgfSums];
+#pragma unroll
+    for (int q = 0; q < kCgfSums; ++q) s[q] = 0;
+    while (true) {
+#pragma unroll
+        for (int u = 0; u < kCgfRows; ++u) {
+            const CgfRow& r = w[u];
+            const float4 me = r.o[0];
+            // finish pass k-1 for the own row: x += alpha p ; residual -= alpha tmp
+            if (r.live && k > 0 && !(ab & 32)) b.x[r.i] = r.x + alpha_prev * me.z;
+            if (stop) continue;
+            const float r_i = me.x - alpha_prev * me.y;
+            const float z_i = me.w * r_i;
+            const float p_i = z_i + beta * me.z;
+            double acc = (double)r.h[0] * (double)p_i;
+#pragma unroll
+            for (int q = 1; q < kNQCommon; ++q) {
+                const float4 o = r.o[q];
+                const float rc = o.x - alpha_prev * o.y;
+                acc += (double)r.h[q] * (double)(o.w * rc + beta * o.z);
+            }
+            const int ii = r.live ? r.i : a.row1 - 1;
+            if (__any(r.live && r.hx)) {                   // the 6 rare columns: wave-uniform skip
+#pragma unroll
+                for (int q = kNQCommon; q < kNQ; ++q) {
+                    const float hq = b.H[(size_t)q * b.Spad + ii];
+                    const float4 o = rin[b.col[(size_t)q * b.Spad + ii]];
+                    const float rc = o.x - alpha_prev * o.y;
+                    acc += (double)hq * (double)(o.w * rc + beta * o.z);
+                }
+            }
+            if (r.live) {
+                const float t = (float)acc;
+                if (!(ab & 64)) rout[r.i] = make_float4(r_i, t, p_i, me.w);
+                const double rd = (double)r_i, td = (double)t, iv = (double)me.w;
+                s[0] += (double)p_i * td; s[1] += iv * rd * td; s[2] += iv * td * td; s[3] += rd * td; s[4] += td * td;
+                s[5] += rd * (double)z_i; s[6] += rd * rd;
+            }
+        }
+        i0 += kCgfRows * stride;
+        if (i0 - (int)threadIdx.x >= a.row1) break;          // workgroup-uniform
+#pragma unroll
+        for (int u = 0; u < kCgfRows; ++u) cgf_load1(b, i0 + u * stride, a.row1, w[u], ab);
+#pragma unroll
+        for (int u = 0; u < kCgfRows; ++u) cgf_load2(rin, a.damping, w[u]);
+    }
+    CGF_STAMP(3);
+    if (stop || (ab & 4)) return;
+    double* dst[kCgfSums];
+#pragma unroll
+    for (int q = 0; q < kCgfSums; ++q) dst[q] = fpart(part, k, q);
+    block_part_store_n<kCgfSums>(s, dst, red);
+    CGF_STAMP(4);
+#undef CGF_STAMP
+}
+void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int rows, int k, int kmax, double* mb, hipStream_t s, int ablate) {
+    if (a.row1 <= a.row0) return;
+    // rows per thread kept in flight at once <-> registers <-> resident workgroups per CU (launch bound = waves per SIMD)
+    if (rows >= 3) hipLaunchKernelGGL((k_cgf_pass<3, 2>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
+    else hipLaunchKernelGGL((k_cgf_pass<1, 4>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
+}
+
 // debug: y = H x without damping
 __global__ void __launch_bounds__(kBlock) k_matvec(SweepArgs a, const float* x, float* y) {
     const Band& b = a.b;
