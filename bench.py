@@ -105,7 +105,7 @@ def main():
         run.normalize_weights()
         S = run.S // world                      # per-slab band size
         n_obs = run.step(capi.ALBEDO)["n_obs"] // world
-        iterate = lambda k: run.iterate(capi.ALL, k)
+        iterate = lambda k: run.iterate(capi.ALL, k, gather=False)   # the final all-gather of the refined band is an output step, not part of the loop body
     else:
         eng.load_scene(sc)
         eng.init_albedo()

@@ -233,12 +233,13 @@ int psgsdf_comm_unique_id(uint8_t id[128]);
 int psgsdf_comm_init(psgsdf_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
 /* run every launch of this context on a caller-owned HIP stream (e.g. torch's current stream) */
 int psgsdf_set_stream(psgsdf_ctx* ctx, void* hip_stream);
-/* out = { S, Spad, row0, row1, halo, F, rank, n_ranks }: owned rows [row0,row1), halo = widest stencil reach in rows;
- * a rank's halo is the contiguous ranges [row0-halo,row0) and [row1,row1+halo) clipped to [0,S) */
-int psgsdf_mg_info(psgsdf_ctx* ctx, int32_t out[8]);
+/* out = { S, Spad, row0, row1, halo, F, rank, n_ranks, need_lo, need_hi }: owned rows [row0,row1); the stencils of the
+ * owned rows read the contiguous ranges [row0-need_lo,row0) and [row1,row1+need_hi) of the neighbouring slabs (the band is
+ * sorted by linear index); halo = max(need_lo, need_hi).  What a rank has to SEND is its neighbours' need. */
+int psgsdf_mg_info(psgsdf_ctx* ctx, int32_t out[10]);
 /* device pointers of the arrays the host program exchanges between phases */
 enum psgsdf_mg_buf { PSGSDF_MG_BUF_FRAME_ACC = 0, PSGSDF_MG_BUF_SCAL = 1, PSGSDF_MG_BUF_PCG = 2, PSGSDF_MG_BUF_DIST = 3,
-                     PSGSDF_MG_BUF_BLK = 4, PSGSDF_MG_BUF_ZP = 5, PSGSDF_MG_BUF_RHO = 6, PSGSDF_MG_BUF_GRAD = 7 };
+                     PSGSDF_MG_BUF_BLK = 4, PSGSDF_MG_BUF_REC0 = 5, PSGSDF_MG_BUF_RHO = 6, PSGSDF_MG_BUF_GRAD = 7, PSGSDF_MG_BUF_REC1 = 8 };
 int psgsdf_mg_buffer(psgsdf_ctx* ctx, int which, void** ptr, int64_t* count);
 /* the phases of one Gauss-Newton iteration on the owned rows; what must be exchanged after each is listed in
  * psgradientsdf_amd/distributed.py, which is the reference host program for them */
@@ -246,11 +247,18 @@ enum psgsdf_mg_phase_id {
     PSGSDF_MG_ENERGY = 0, PSGSDF_MG_INIT_ALBEDO = 1, PSGSDF_MG_LED_SUMS = 2, PSGSDF_MG_LED_SET = 3,
     PSGSDF_MG_SWEEP_ALBEDO = 4, PSGSDF_MG_APPLY_ALBEDO = 5, PSGSDF_MG_SWEEP_LIGHT = 6, PSGSDF_MG_SOLVE_LIGHT = 7,
     PSGSDF_MG_SWEEP_POSE = 8, PSGSDF_MG_SOLVE_POSE = 9, PSGSDF_MG_SWEEP_DIST = 10, PSGSDF_MG_ASSEMBLE = 11,
-    PSGSDF_MG_PCG_INIT = 12, PSGSDF_MG_PCG_MV = 13, PSGSDF_MG_PCG_UPD = 14, PSGSDF_MG_APPLY_DIST = 15,
-    PSGSDF_MG_DERIVE = 16, PSGSDF_MG_SET_REG_SUMS = 17
+    PSGSDF_MG_PCG_INIT = 12, PSGSDF_MG_PCG_PASS = 13, PSGSDF_MG_APPLY_DIST = 14, PSGSDF_MG_DERIVE = 15
 };
 int psgsdf_mg_phase(psgsdf_ctx* ctx, int phase, int arg);
+/* PCG protocol (fused Jacobi-PCG, one kernel + one all-reduce per iteration): PCG_INIT, all-reduce PCG[0:1]; then for
+ * k = 0, 1, ...: exchange the halo rows of REC[(k+1)&1], PCG_PASS(k), all-reduce PCG[0:7].  PCG_PASS(k) finishes pass
+ * k-1 and runs pass k; once a pass has converged (or k reached the cap) the following PCG_PASS calls are no-ops.
+ * psgsdf_mg_pcg_status (host sync) after kernels [k0,k0+n): iters >= 0 once the solve has stopped, else -1. */
 int psgsdf_mg_pcg_status(psgsdf_ctx* ctx, int k0, int n, int32_t* iters, double* err);
+/* offset (doubles) in the SCAL buffer where the following phases fold their scalars (energy, counts, ...) */
+int psgsdf_mg_fold_base(psgsdf_ctx* ctx, int base);
+/* all-reduced Eikonal / Laplacian energy sums for the context's energy bookkeeping */
+int psgsdf_mg_set_reg_sums(psgsdf_ctx* ctx, double en_sum, double el_sum);
 int psgsdf_mg_set_weights(psgsdf_ctx* ctx, float reg_weight_n, float reg_weight_l);
 /* before / after the final all-gather of dist, rho and grad planes (no-ops for the engine) */
 int psgsdf_mg_pack_state(psgsdf_ctx* ctx);

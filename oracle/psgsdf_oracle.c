@@ -64,8 +64,9 @@ typedef struct orc_ctx {
     int inited;
     /* multi-rank (slab) mode: owned band rows [row0,row1); exchange buffers mirror the engine's layout */
     int rank, n_ranks, row0, row1, halo, Spad;
-    double* mg_frame; double mg_scal[16]; double mg_ext[4];
-    float *mg_dist, *mg_blk, *mg_zp, *mg_rho, *mg_grad;
+    double* mg_frame; double mg_scal[64]; double mg_ext[8]; int mg_fold_base; int need[2];
+    float *mg_dist, *mg_blk, *mg_rec[2], *mg_rho, *mg_grad;
+    double cg_bb; int cg_stop; double* cg_hist;
     float *cg_x, *cg_r, *cg_t, *cg_p, *cg_inv; double* cg_sc;
     void* mg_sys; /* dist_sys* of the current solve */
     int solver_mode; /* 0 = direct per-block solves, 1 = Eigen-style global Jacobi-PCG */
@@ -899,7 +900,7 @@ static void dist_system(const orc_ctx* c, int normal_reg, int laplacian_reg, dis
 static void dist_assemble(const orc_ctx* c, dist_sys* s) {
     int S = c->S;
     long stride[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
-    int jlo = c->row0 - c->halo < 0 ? 0 : c->row0 - c->halo, jhi = c->row1 + c->halo > S ? S : c->row1 + c->halo;
+    int jlo = c->row0 - c->need[0] < 0 ? 0 : c->row0 - c->need[0], jhi = c->row1 + c->need[1] > S ? S : c->row1 + c->need[1];
     if (c->n_ranks > 1) for (int j = jlo; j < jhi; ++j) {   /* stencil columns of halo voxels are static: recompute */
         if (j >= c->row0 && j < c->row1) continue;
         int lin = c->band[j]; int idx[3]; line2idx(c, lin, idx);
@@ -1066,23 +1067,27 @@ static void mg_setup(orc_ctx* c) {
     int C = (S + c->n_ranks - 1) / c->n_ranks;
     c->row0 = c->rank * C < S ? c->rank * C : S; c->row1 = c->row0 + C < S ? c->row0 + C : S;
     c->Spad = ((S + 255) / 256) * 256 + 256;
-    /* halo = widest reach of any ELL column of the distance rows (self, 6 axis, 12 pair offsets) */
-    c->halo = 0;
+    /* rows the stencils of the owned rows reach outside [row0,row1): ELL columns = self, 6 axis, 12 pair offsets */
+    c->halo = 0; c->need[0] = c->need[1] = 0;
     if (c->n_ranks > 1) {
         long st[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
-        for (int i = 0; i < S; ++i) for (int ox = -1; ox <= 1; ++ox) for (int oy = -1; oy <= 1; ++oy) for (int oz = -1; oz <= 1; ++oz) {
+        for (int i = c->row0; i < c->row1; ++i) for (int ox = -1; ox <= 1; ++ox) for (int oy = -1; oy <= 1; ++oy) for (int oz = -1; oz <= 1; ++oz) {
             if ((ox != 0) + (oy != 0) + (oz != 0) > 2) continue;
             long ln = (long)c->band[i] + ox * st[0] + oy * st[1] + oz * st[2];
             if (ln < 0 || (size_t)ln >= c->nvox) continue;
             int r = c->row_of[ln]; if (r < 0) continue;
-            int d = r > i ? r - i : i - r; if (d > c->halo) c->halo = d;
+            if (r < c->row0 && c->row0 - r > c->need[0]) c->need[0] = c->row0 - r;
+            if (r >= c->row1 && r - c->row1 + 1 > c->need[1]) c->need[1] = r - c->row1 + 1;
         }
+        c->halo = c->need[0] > c->need[1] ? c->need[0] : c->need[1];
     }
-    free(c->mg_frame); free(c->mg_dist); free(c->mg_blk); free(c->mg_zp); free(c->mg_rho); free(c->mg_grad);
+    free(c->mg_frame); free(c->mg_dist); free(c->mg_blk); free(c->mg_rec[0]); free(c->mg_rec[1]); free(c->mg_rho); free(c->mg_grad); free(c->cg_hist);
     free(c->cg_x); free(c->cg_r); free(c->cg_t); free(c->cg_p); free(c->cg_inv); free(c->cg_sc);
     c->mg_frame = (double*)calloc((size_t)(c->F > 0 ? c->F : 1) * FROW, sizeof(double));
     c->mg_dist = (float*)calloc(c->Spad, sizeof(float)); c->mg_blk = (float*)calloc((size_t)14 * c->Spad, sizeof(float));
-    c->mg_zp = (float*)calloc((size_t)2 * c->Spad, sizeof(float)); c->mg_rho = (float*)calloc((size_t)3 * c->Spad, sizeof(float)); c->mg_grad = (float*)calloc((size_t)3 * c->Spad, sizeof(float));
+    c->mg_rec[0] = (float*)calloc((size_t)4 * c->Spad, sizeof(float)); c->mg_rec[1] = (float*)calloc((size_t)4 * c->Spad, sizeof(float));
+    c->cg_hist = (double*)calloc(4096 + 2, sizeof(double)); c->mg_fold_base = 0;
+    c->mg_rho = (float*)calloc((size_t)3 * c->Spad, sizeof(float)); c->mg_grad = (float*)calloc((size_t)3 * c->Spad, sizeof(float));
     c->cg_x = (float*)calloc(c->Spad, sizeof(float)); c->cg_r = (float*)calloc(c->Spad, sizeof(float)); c->cg_t = (float*)calloc(c->Spad, sizeof(float));
     c->cg_p = (float*)calloc(c->Spad, sizeof(float)); c->cg_inv = (float*)calloc(c->Spad, sizeof(float));
     c->cg_sc = (double*)calloc(4 + 3 * 4096, sizeof(double));
@@ -1091,9 +1096,9 @@ static int sym4(int a, int b) { if (a > b) { int t = a; a = b; b = t; } return a
 
 int orc_comm_init(orc_ctx* c, const uint8_t* id, int rank, int n_ranks) { (void)id; if (!c || rank < 0 || rank >= n_ranks) return PSGSDF_ERR_ARG; c->rank = rank; c->n_ranks = n_ranks; c->inited = 0; return 0; }
 int orc_set_stream(orc_ctx* c, void* s) { (void)c; (void)s; return 0; }
-int orc_mg_info(orc_ctx* c, int32_t out[8]) {
+int orc_mg_info(orc_ctx* c, int32_t out[10]) {
     if (!c || !c->inited) return PSGSDF_ERR_STATE;
-    out[0] = c->S; out[1] = c->Spad; out[2] = c->row0; out[3] = c->row1; out[4] = c->halo; out[5] = c->F; out[6] = c->rank; out[7] = c->n_ranks;
+    out[0] = c->S; out[1] = c->Spad; out[2] = c->row0; out[3] = c->row1; out[4] = c->halo; out[5] = c->F; out[6] = c->rank; out[7] = c->n_ranks; out[8] = c->need[0]; out[9] = c->need[1];
     return 0;
 }
 int orc_mg_buffer(orc_ctx* c, int which, void** ptr, int64_t* count) {
@@ -1101,11 +1106,12 @@ int orc_mg_buffer(orc_ctx* c, int which, void** ptr, int64_t* count) {
     int64_t Sp = c->Spad;
     switch (which) {
         case PSGSDF_MG_BUF_FRAME_ACC: *ptr = c->mg_frame; *count = (int64_t)c->F * FROW; break;
-        case PSGSDF_MG_BUF_SCAL: *ptr = c->mg_scal; *count = 16; break;
-        case PSGSDF_MG_BUF_PCG: *ptr = c->mg_ext; *count = 3; break;
+        case PSGSDF_MG_BUF_SCAL: *ptr = c->mg_scal; *count = 64; break;
+        case PSGSDF_MG_BUF_PCG: *ptr = c->mg_ext; *count = 8; break;
         case PSGSDF_MG_BUF_DIST: *ptr = c->mg_dist; *count = Sp; break;
         case PSGSDF_MG_BUF_BLK: *ptr = c->mg_blk; *count = 14 * Sp; break;
-        case PSGSDF_MG_BUF_ZP: *ptr = c->mg_zp; *count = 2 * Sp; break;
+        case PSGSDF_MG_BUF_REC0: *ptr = c->mg_rec[0]; *count = 4 * Sp; break;
+        case PSGSDF_MG_BUF_REC1: *ptr = c->mg_rec[1]; *count = 4 * Sp; break;
         case PSGSDF_MG_BUF_RHO: *ptr = c->mg_rho; *count = 3 * Sp; break;
         case PSGSDF_MG_BUF_GRAD: *ptr = c->mg_grad; *count = 3 * Sp; break;
         default: return PSGSDF_ERR_ARG;
@@ -1133,8 +1139,9 @@ int orc_mg_phase(orc_ctx* c, int phase, int arg) {
     if (!c || !c->inited) return PSGSDF_ERR_STATE;
     int S = c->S, Sp = c->Spad, F = c->F;
     int led = c->set.model == PSGSDF_LED;
+    double* fold = c->mg_scal + c->mg_fold_base;   /* where this phase's scalars land (orc_mg_fold_base) */
     switch (phase) {
-        case PSGSDF_MG_ENERGY: { long long n; double e = ps_energy(c, &n); c->mg_scal[0] = e * S; c->mg_scal[1] = (double)n; return 0; }
+        case PSGSDF_MG_ENERGY: { long long n; double e = ps_energy(c, &n); fold[0] = e * S; fold[1] = (double)n; return 0; }
         case PSGSDF_MG_INIT_ALBEDO: init_albedo(c); return 0;
         case PSGSDF_MG_LED_SUMS: { float keep[3] = {c->light[0], c->light[1], c->light[2]}; init_light(c); (void)keep; return 0; }   /* leaves sums in mg_scal[0..5] */
         case PSGSDF_MG_LED_SET: for (int ch = 0; ch < 3; ++ch) c->light[ch] = (float)c->mg_scal[ch] / (float)c->mg_scal[3 + ch]; return 0;
@@ -1142,14 +1149,14 @@ int orc_mg_phase(orc_ctx* c, int phase, int arg) {
             float* H = (float*)malloc(sizeof(float) * 3 * (S + 1)); float* b = (float*)malloc(sizeof(float) * 3 * (S + 1));
             double e; long long n; albedo_system(c, H, b, &e, &n);
             for (int j = c->row0; j < c->row1; ++j) for (int ch = 0; ch < 3; ++ch) { c->mg_blk[(size_t)ch * Sp + j] = H[3 * j + ch]; c->mg_blk[(size_t)(3 + ch) * Sp + j] = b[3 * j + ch]; }
-            c->mg_scal[0] = e * S; c->mg_scal[1] = (double)n; free(H); free(b); return 0; }
+            fold[0] = e * S; fold[1] = (double)n; free(H); free(b); return 0; }
         case PSGSDF_MG_APPLY_ALBEDO: {
             long long count = 0; float damping = c->set.damping;
             for (int j = c->row0; j < c->row1; ++j) { int lin = c->band[j]; float* rho[3] = {&c->r[lin], &c->g[lin], &c->b[lin]};
                 for (int ch = 0; ch < 3; ++ch) { float h = c->mg_blk[(size_t)ch * Sp + j]; if (damping != 0.0f) h += damping * h;
                     float delta = (h != 0.f) ? c->mg_blk[(size_t)(3 + ch) * Sp + j] / h : 0.f; float v = *rho[ch] - delta;
                     if (v > 0.0f && v < 1.0f) { *rho[ch] = v; count++; } } }
-            c->mg_scal[0] = (double)count; return 0; }
+            fold[0] = (double)count; return 0; }
         case PSGSDF_MG_SWEEP_LIGHT: {
             int nb = led ? 1 : F, n = c->basis, nh = led ? 3 : n * (n + 1) / 2;
             double* H = (double*)malloc(sizeof(double) * nb * n * n); double* b = (double*)malloc(sizeof(double) * nb * n); double e; long long no;
@@ -1188,76 +1195,86 @@ int orc_mg_phase(orc_ctx* c, int phase, int arg) {
             for (int j = c->row0; j < c->row1; ++j) { int q = 0;
                 for (int a = 0; a < 4; ++a) for (int bq = a; bq < 4; ++bq) c->mg_blk[(size_t)(q++) * Sp + j] = (float)sy->B[16 * j + a * 4 + bq];
                 for (int a = 0; a < 4; ++a) c->mg_blk[(size_t)(10 + a) * Sp + j] = (float)sy->g[4 * j + a]; }
-            c->mg_scal[0] = e * S; c->mg_scal[1] = (double)no; return 0; }
+            fold[0] = e * S; fold[1] = (double)no; return 0; }
         case PSGSDF_MG_ASSEMBLE: {
             dist_sys* sy = (dist_sys*)c->mg_sys; if (!sy) return PSGSDF_ERR_STATE;
             if (c->n_ranks > 1) {
-                int jlo = c->row0 - c->halo < 0 ? 0 : c->row0 - c->halo, jhi = c->row1 + c->halo > S ? S : c->row1 + c->halo;
+                int jlo = c->row0 - c->need[0] < 0 ? 0 : c->row0 - c->need[0], jhi = c->row1 + c->need[1] > S ? S : c->row1 + c->need[1];
                 for (int j = jlo; j < jhi; ++j) { if (j >= c->row0 && j < c->row1) continue;
                     for (int a = 0; a < 4; ++a) { for (int bq = 0; bq < 4; ++bq) sy->B[16 * j + a * 4 + bq] = (double)c->mg_blk[(size_t)sym4(a, bq) * Sp + j]; sy->g[4 * j + a] = (double)c->mg_blk[(size_t)(10 + a) * Sp + j]; } }
                 dist_assemble(c, sy);
             }
             return 0; }
+        /* Fused Jacobi-PCG in the formulation of the engine's k_cgf_pass (kernels.hip): kernel k finishes pass k-1 for the
+         * owned rows (x += alpha p), re-derives r_k, z_k, p_k of every column from that column's record {r, t, p, inv} of
+         * pass k-1 (halo records exchanged by the host program), runs t = A p_k and leaves the 7 local sums in mg_ext;
+         * alpha, beta and the convergence test come from the all-reduced sums of pass k-1 found in mg_ext on entry.
+         * Same recurrences as eigen_cg() above (Eigen ConjugateGradient.h), scalars in float, sums in double. */
         case PSGSDF_MG_PCG_INIT: {
             dist_sys* sy = (dist_sys*)c->mg_sys; if (!sy || !sy->rowptr) return PSGSDF_ERR_STATE;
-            memset(c->cg_sc, 0, sizeof(double) * (4 + 3 * 4096));
-            double bb = 0, rz = 0;
+            double bb = 0; float* rec = c->mg_rec[1];
             for (int i = c->row0; i < c->row1; ++i) { float dg = sy->diag[i]; if (c->set.damping != 0.f) dg += c->set.damping * dg;
-                float inv = dg != 0.f ? 1.0f / dg : 1.0f; float r = sy->rhs[i]; float z = inv * r;
-                c->cg_inv[i] = inv; c->cg_x[i] = 0.f; c->cg_r[i] = r; c->mg_zp[2 * i] = z; c->mg_zp[2 * i + 1] = 0.f; c->cg_p[i] = 0.f;
-                bb += (double)r * r; rz += (double)r * z; }
-            c->mg_ext[0] = bb; c->mg_ext[1] = rz; return 0; }
-        case PSGSDF_MG_PCG_MV: {
-            dist_sys* sy = (dist_sys*)c->mg_sys; int k = arg; double* sc = c->cg_sc;
-            double s1 = c->mg_ext[0], s2 = c->mg_ext[1];
-            if (k == 0) { sc[0] = s1; sc[1] = s2; } else { sc[4 + 3 * (k - 1) + 1] = s1; sc[4 + 3 * (k - 1) + 2] = s2; }
-            float rhsN = (float)(k == 0 ? s1 : sc[0]);
-            c->mg_ext[2] = 0;
-            if (rhsN == 0.f) return 0;
-            if (k > 0 && (float)s1 < pcg_thr(rhsN)) return 0;
-            float beta = 0.f;
-            if (k > 0) { float absNew = (float)s2; float absOld = (float)(k == 1 ? sc[1] : sc[4 + 3 * (k - 2) + 2]); beta = absNew / absOld; }
-            double pt = 0;
+                float inv = dg != 0.f ? 1.0f / dg : 1.0f; float r = sy->rhs[i];
+                c->cg_x[i] = 0.f; rec[4 * i] = r; rec[4 * i + 1] = 0.f; rec[4 * i + 2] = 0.f; rec[4 * i + 3] = inv;
+                bb += (double)r * r; }
+            c->cg_stop = 0; c->cg_bb = 0; memset(c->mg_ext, 0, sizeof(c->mg_ext)); c->mg_ext[0] = bb; return 0; }
+        case PSGSDF_MG_PCG_PASS: {
+            dist_sys* sy = (dist_sys*)c->mg_sys; int k = arg; if (!sy || !sy->rowptr || k < 0 || k > 4096) return PSGSDF_ERR_ARG;
+            int cap = c->set.cg_max_it > 0 ? c->set.cg_max_it : 2 * S; if (cap > 4096) cap = 4096;
+            if (c->cg_stop && c->cg_stop <= k) return 0;
+            float alpha_prev = 0.f, beta = 0.f, rr_cur, rhsN;
+            if (k == 0) { c->cg_bb = c->mg_ext[0]; rhsN = (float)c->cg_bb; rr_cur = rhsN; c->cg_hist[0] = c->cg_bb; }
+            else { const double* t = c->mg_ext; rhsN = (float)c->cg_bb;
+                float rz_old = (float)t[5]; alpha_prev = rz_old / (float)t[0]; double al = (double)alpha_prev;
+                float rz_cur = (float)(t[5] - 2.0 * al * t[1] + al * al * t[2]);
+                rr_cur = (float)(t[6] - 2.0 * al * t[3] + al * al * t[4]);
+                beta = rz_cur / rz_old; c->cg_hist[k] = (double)rr_cur; }
+            int stop = rhsN == 0.f || k == cap || (k > 0 && rr_cur < pcg_thr(rhsN));
+            if (stop) c->cg_stop = k + 1;
+            const float* rin = c->mg_rec[(k + 1) & 1]; float* rout = c->mg_rec[k & 1];
+            double sm[7] = {0, 0, 0, 0, 0, 0, 0};
             for (int i = c->row0; i < c->row1; ++i) {
+                const float* me = rin + 4 * i;
+                if (k > 0) c->cg_x[i] += alpha_prev * me[2];
+                if (stop) continue;
+                float r_i = me[0] - alpha_prev * me[1], z_i = me[3] * r_i, p_i = z_i + beta * me[2];
                 double acc = 0;
                 for (int q = sy->rowptr[i]; q < sy->rowptr[i + 1]; ++q) { int cc = sy->colidx[q]; float v = sy->val[q];
-                    if (cc == i && c->set.damping != 0.f) v += c->set.damping * v;
-                    acc += (double)v * (double)(c->mg_zp[2 * cc] + beta * c->mg_zp[2 * cc + 1]); }
-                float pi = c->mg_zp[2 * i] + beta * c->mg_zp[2 * i + 1]; float t = (float)acc;
-                c->cg_p[i] = pi; c->cg_t[i] = t; pt += (double)pi * (double)t; }
-            c->mg_ext[2] = pt; return 0; }
-        case PSGSDF_MG_PCG_UPD: {
-            int k = arg; double* sc = c->cg_sc; float rhsN = (float)sc[0];
-            int done = rhsN == 0.f || (k > 0 && (float)sc[4 + 3 * (k - 1) + 1] < pcg_thr(rhsN));
-            if (done) { c->mg_ext[0] = 0; c->mg_ext[1] = 0; return 0; }
-            double ptot = c->mg_ext[2]; sc[4 + 3 * k] = ptot;
-            float absNew = (float)(k == 0 ? sc[1] : sc[4 + 3 * (k - 1) + 2]); float alpha = absNew / (float)ptot;
-            double rr = 0, rz = 0;
-            for (int i = c->row0; i < c->row1; ++i) { float pi = c->cg_p[i]; float x = c->cg_x[i] + alpha * pi; float r = c->cg_r[i] - alpha * c->cg_t[i]; float z = c->cg_inv[i] * r;
-                c->cg_x[i] = x; c->cg_r[i] = r; c->mg_zp[2 * i] = z; c->mg_zp[2 * i + 1] = pi; rr += (double)r * r; rz += (double)r * z; }
-            c->mg_ext[0] = rr; c->mg_ext[1] = rz; return 0; }
+                    if (cc == i) { if (c->set.damping != 0.f) v += c->set.damping * v; acc += (double)v * (double)p_i; }
+                    else { const float* o = rin + 4 * cc; float rc = o[0] - alpha_prev * o[1]; acc += (double)v * (double)(o[3] * rc + beta * o[2]); } }
+                float t = (float)acc;
+                rout[4 * i] = r_i; rout[4 * i + 1] = t; rout[4 * i + 2] = p_i; rout[4 * i + 3] = me[3];
+                double rd = r_i, td = t, iv = me[3];
+                sm[0] += (double)p_i * td; sm[1] += iv * rd * td; sm[2] += iv * td * td; sm[3] += rd * td; sm[4] += td * td; sm[5] += rd * (double)z_i; sm[6] += rd * rd;
+            }
+            if (!stop) for (int q = 0; q < 7; ++q) c->mg_ext[q] = sm[q];
+            return 0; }
         case PSGSDF_MG_APPLY_DIST: {
             long long count = 0;
             for (int j = c->row0; j < c->row1; ++j) { float d = c->cg_x[j]; if ((double)fabsf(d) < sqrt(3.0) * (double)c->vs) { c->dist[c->band[j]] -= d; count++; } }
-            pack_state(c); c->mg_scal[0] = (double)count; return 0; }
+            pack_state(c); fold[0] = (double)count; return 0; }
         case PSGSDF_MG_DERIVE: {
-            int lo = c->row0 - c->halo < 0 ? 0 : c->row0 - c->halo, hi = c->row1 + c->halo > S ? S : c->row1 + c->halo;
+            int lo = c->row0 - c->need[0] < 0 ? 0 : c->row0 - c->need[0], hi = c->row1 + c->need[1] > S ? S : c->row1 + c->need[1];
             if (c->n_ranks > 1) unpack_state(c, lo, hi, 0);
             if (arg) update_grad(c);
-            c->mg_scal[0] = normal_energy(c) * S; c->mg_scal[1] = laplacian_energy(c) * S; return 0; }
-        case PSGSDF_MG_SET_REG_SUMS: return 0;   /* the oracle recomputes regulariser energies on demand */
+            fold[0] = normal_energy(c) * S; fold[1] = laplacian_energy(c) * S; return 0; }
         default: return PSGSDF_ERR_ARG;
     }
 }
 int orc_mg_pcg_status(orc_ctx* c, int k0, int n, int32_t* iters, double* err) {
-    double* sc = c->cg_sc; float rhsN = (float)sc[0];
+    if (!c || !c->inited || !iters || !err || k0 < 0 || n < 1 || n > 64) return PSGSDF_ERR_ARG;
+    int cap = c->set.cg_max_it > 0 ? c->set.cg_max_it : 2 * c->S; if (cap > 4096) cap = 4096;
+    float rhsN = (float)c->cg_hist[0];
     *iters = -1; *err = 0;
     if (rhsN == 0.f) { *iters = 0; return 0; }
-    float thr = pcg_thr(rhsN), rn2 = 0;
-    for (int q = 0; q < n; ++q) { rn2 = (float)(q == n - 1 ? c->mg_ext[0] : sc[4 + 3 * (k0 + q) + 1]); if (rn2 < thr) { *iters = k0 + q; break; } }
+    float thr = pcg_thr(rhsN), rn2 = rhsN;
+    for (int q = 0; q < n && *iters < 0; ++q) { int kk = k0 + q; if (kk == 0) continue;
+        rn2 = (float)c->cg_hist[kk]; if (rn2 < thr) *iters = kk - 1; else if (kk == cap) *iters = cap; }
     *err = sqrt((double)rn2 / (double)rhsN);
     return 0;
 }
+int orc_mg_fold_base(orc_ctx* c, int base) { if (!c || base < 0 || base >= 64) return PSGSDF_ERR_ARG; c->mg_fold_base = base; return 0; }
+int orc_mg_set_reg_sums(orc_ctx* c, double en_sum, double el_sum) { (void)c; (void)en_sum; (void)el_sum; return 0; }   /* the oracle recomputes regulariser energies on demand */
 int orc_mg_set_weights(orc_ctx* c, float reg_n, float reg_l) { c->reg_n = reg_n; c->reg_l = reg_l; return 0; }
 /* final state gather support: owned rows -> exchange planes, all rows <- exchange planes */
 int orc_mg_pack_state(orc_ctx* c) { pack_state(c); return 0; }

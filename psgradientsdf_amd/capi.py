@@ -252,9 +252,9 @@ class Api:
         self._check(self._fn("set_stream")(self.ctx, C.c_void_p(stream_ptr)), "set_stream")
 
     def mg_info(self):
-        out = (C.c_int32 * 8)()
+        out = (C.c_int32 * 10)()
         self._check(self._fn("mg_info")(self.ctx, out), "mg_info")
-        return dict(zip(["S", "Spad", "row0", "row1", "halo", "F", "rank", "n_ranks"], list(out)))
+        return dict(zip(["S", "Spad", "row0", "row1", "halo", "F", "rank", "n_ranks", "need_lo", "need_hi"], list(out)))
 
     def mg_buffer(self, which):
         ptr = C.c_void_p(); n = C.c_int64()
@@ -268,6 +268,12 @@ class Api:
         it = C.c_int32(); err = C.c_double()
         self._check(self._fn("mg_pcg_status")(self.ctx, C.c_int(k0), C.c_int(n), C.byref(it), C.byref(err)), "mg_pcg_status")
         return it.value, err.value
+
+    def mg_fold_base(self, base):
+        self._check(self._fn("mg_fold_base")(self.ctx, C.c_int(base)), "mg_fold_base")
+
+    def mg_set_reg_sums(self, en_sum, el_sum):
+        self._check(self._fn("mg_set_reg_sums")(self.ctx, C.c_double(en_sum), C.c_double(el_sum)), "mg_set_reg_sums")
 
     def mg_set_weights(self, reg_n, reg_l):
         self._check(self._fn("mg_set_weights")(self.ctx, C.c_float(reg_n), C.c_float(reg_l)), "mg_set_weights")

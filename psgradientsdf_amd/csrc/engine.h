@@ -63,9 +63,8 @@ struct Band {
     float* blk;               // [14][Spad]
     float* H;                 // [kNQ][Spad]
     int* hx;                  // [Spad] 1 if any of the 6 rare columns of this row is non-zero
-    float* rhs; float* x; float* r; float* t; float* p; float* inv;
-    float2* zp;               // [Spad] {z_i, p_i of the previous PCG pass}: ONE 8-byte gather per matrix column
-    float4* rec[2];           // [Spad] fused PCG (single GPU): {r, t, p, inv} of the previous pass, double-buffered
+    float* rhs; float* x; float* t;
+    float4* rec[2];           // [Spad] PCG records {r, t, p, inv} of the previous pass, double-buffered: ONE 16-byte gather per column
     // per-frame observation lists (static per band): rows visible in frame f, ascending
     int* obs_ptr;             // [F+1]
     int* obs_rows;            // [obs_ptr[F]]
@@ -99,7 +98,7 @@ struct SweepArgs {
     int normal_reg, laplacian_reg;
     float damping;
     int row0, row1;           // band rows this context owns: [row0, row1) (whole band on one GPU; a z-slab per rank otherwise)
-    const double* ext;        // multi-rank PCG: globally reduced scalars {|b|^2 or |r|^2, r.z, p.t} supplied by the host program, else nullptr
+    const double* ext;        // multi-rank PCG: the 7 globally reduced sums of the previous pass (|b|^2 in ext[0] for pass 0), else nullptr
 };
 
 // ---- launchers implemented in kernels.hip (all asynchronous on `s`) ----------------------
@@ -114,12 +113,11 @@ void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s);
 constexpr int kObsChunk = 2048;      // rows per workgroup of the observation-list builders
 void launch_obs_count(const Band& b, int F, int row0, int row1, int* counts, hipStream_t s);       // counts[F][nch]
 void launch_obs_fill(const Band& b, int F, int row0, int row1, const int* offsets, hipStream_t s); // offsets[F][nch] -> b.obs_rows
-void launch_reach(const Band& b, int* d_reach, hipStream_t s);                                     // max |col - row| over the band
+void launch_reach(const Band& b, int row0, int row1, int* d_need, hipStream_t s);                   // rows needed below row0 / from row1 up
 struct SlotList { int n; int id[8]; };
 void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, hipStream_t s);
 void launch_frame_cols(const double* frame, int F, int col, double* out, hipStream_t s);
 void launch_zero_f64(double* p, int n, hipStream_t s);
-void launch_pcg_sum(const double* part, int G, int k, int which, double* out, hipStream_t s);      // which 0: p.t of pass k; 1: |r|^2, r.z of pass k (-1 = init)
 void launch_init_albedo(const SweepArgs& a, hipStream_t s);
 void launch_led_light_init(const SweepArgs& a, hipStream_t s);
 void launch_energy(const SweepArgs& a, hipStream_t s);
@@ -131,12 +129,9 @@ void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, hi
 void launch_solve_pose(const SweepArgs& a, FrameP* frames, hipStream_t s);
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s);
 void launch_assemble(const SweepArgs& a, hipStream_t s);
-void launch_pcg_init(const SweepArgs& a, double* sc, double* part, int G, hipStream_t s);
-void launch_pcg_mv(const SweepArgs& a, double* sc, double* part, int G, int k, int with_damping, hipStream_t s);
-void launch_pcg_upd(const SweepArgs& a, double* sc, double* part, int G, int k, hipStream_t s);
-void launch_pcg_final(double* sc, double* part, int G, int k0, int k, double* host_out, hipStream_t s);
 void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s);
 void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int rows, int k, int kmax, double* mb, hipStream_t s, int ablate = 0);
+void launch_cgf_sum(double* part, int G, int k, double* out, hipStream_t s);   // multi-rank: partials of pass k -> out[0..6]
 void launch_matvec(const SweepArgs& a, const float* x, float* y, hipStream_t s);   // debug: y = H x (no damping)
 void launch_apply_dist(const SweepArgs& a, hipStream_t s);
 void launch_upsample(const DenseView& src, const DenseView& dst, const GridP& g_old, hipStream_t s);
@@ -146,6 +141,5 @@ void launch_track(const DenseView& d, const GridP& g, const Cam& cam, const Fram
 void launch_integrate(const DenseView& d, uint64_t* vis_seq, int wpv_seq, const GridP& g, const Cam& cam, const FrameP& fp,
                       const float* rgb, const float* depth, const float* normals, int counter, float z_min, float z_max, hipStream_t s);
 
-constexpr int kPcgScalHead = 4;   // sc[0]=|b|^2, sc[1]=r0.z0, then 3 doubles per iteration: p.t, |r|^2, r.z
 
 }  // namespace psg

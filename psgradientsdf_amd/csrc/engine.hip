@@ -18,6 +18,7 @@
 using namespace psg;
 
 namespace {
+constexpr int kMgScal = 64;   // doubles in the folded-scalar exchange buffer
 
 struct KTime { double ms = 0; int64_t n = 0; };
 
@@ -70,8 +71,11 @@ struct psgsdf_ctx {
     // row partition (multi-rank): this context owns band rows [row0, row1); halo = widest column reach
     int rank = 0, n_ranks = 1;
     int row0 = 0, row1 = 0, halo = 0;
-    double* mg_scal = nullptr;           // [16] folded local sums the host program all-reduces
-    double* mg_ext = nullptr;            // [3] globally reduced PCG scalars {|r|^2, r.z, p.t}
+    double* mg_scal = nullptr;           // [kMgScal] folded local sums the host program all-reduces (phase results land at mg_fold_base)
+    double* mg_ext = nullptr;            // [8] PCG: local sums of a pass out, globally reduced sums in
+    double* mg_hist = nullptr;           // [pcg_cap + 2] PCG: what kernel k published (|b|^2, then |r|^2 after pass k-1)
+    int mg_fold_base = 0;
+    int need[2] = {0, 0}; int* d_need = nullptr;   // halo rows needed below row0 / from row1 up
     int* mg_slots = nullptr;             // [8] device copy of slot ids for k_sum_parts
     bool own_stream = true;
     // profiling
@@ -204,7 +208,7 @@ int build_band(psgsdf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int Spad = ((S + kBlock - 1) / kBlock) * kBlock + kBlock;
     // planes (4-byte units per row): see Band
-    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 11 + 8;
+    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 4 + 8;
     const size_t bytes = (n4 * 4 + (size_t)KW * 8) * Spad + 256;
     if (c->band_mem) { hipFree(c->band_mem); c->band_mem = nullptr; }
     HIPCHK(c, hipMalloc(&c->band_mem, bytes));
@@ -227,21 +231,20 @@ int build_band(psgsdf_ctx* c) {
     for (int a = 0; a < 3; ++a) b.nfd[a] = (float*)take(1, 4);
     b.aH = (float*)take(3, 4); b.ab = (float*)take(3, 4);
     b.blk = (float*)take(14, 4); b.H = (float*)take(kNQ, 4);
-    b.zp = (float2*)take(2, 4);
     b.hx = (int*)take(1, 4);
-    b.rhs = (float*)take(1, 4); b.x = (float*)take(1, 4); b.r = (float*)take(1, 4); b.t = (float*)take(1, 4);
-    b.p = (float*)take(1, 4); b.inv = (float*)take(1, 4);
+    b.rhs = (float*)take(1, 4); b.x = (float*)take(1, 4); b.t = (float*)take(1, 4);
     timed(c, "band_fill", [&] { launch_band_fill(c->dense, c->grid, b, c->stream); });
     // row partition: equal band count per rank = z-slabs (the band is sorted by linear index, z slowest)
     {
         const int C = (S + c->n_ranks - 1) / c->n_ranks;
         c->row0 = std::min(S, c->rank * C); c->row1 = std::min(S, c->row0 + C);
-        c->halo = 0;
+        c->halo = 0; c->need[0] = c->need[1] = 0;
         if (c->n_ranks > 1 && S > 0) {
-            HIPCHK(c, hipMemsetAsync(c->d_total, 0, sizeof(int), c->stream));
-            launch_reach(b, c->d_total, c->stream);
-            HIPCHK(c, hipMemcpyAsync(&c->halo, c->d_total, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_need, 0, 2 * sizeof(int), c->stream));
+            launch_reach(b, c->row0, c->row1, c->d_need, c->stream);
+            HIPCHK(c, hipMemcpyAsync(c->need, c->d_need, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->halo = std::max(c->need[0], c->need[1]);
             if (c->halo > C) return fail(c, PSGSDF_ERR_UNSUPPORTED, "slab of %d rows is thinner than the stencil reach %d: use fewer ranks", C, c->halo);
         }
     }
@@ -284,7 +287,7 @@ int build_band(psgsdf_ctx* c) {
         }
         c->mbox_used = 0; c->deferred.clear();
     }
-    return ensure_host_buf(c, (size_t)SC_COUNT * c->PB + (size_t)c->F * kFrameRow + kPcgScalHead + 3 * 4096 + 64);
+    return ensure_host_buf(c, (size_t)SC_COUNT * c->PB + (size_t)c->F * kFrameRow + 4096 + 64);
 }
 
 int derive(psgsdf_ctx* c, int update_grad) {
@@ -639,9 +642,10 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     for (int a = 0; a < 3; ++a) g.origin[a] = c->shift[a] - (float)(0.5 * (double)g.vs) * (float)g.dim[a];   // VoxelGrid.h:130
     c->cam.fx = K[0]; c->cam.fy = K[4]; c->cam.cx = K[2]; c->cam.cy = K[5];
     bool ok = hipStreamCreate(&c->stream) == hipSuccess
-        && hipMalloc(&c->pcg_sc, sizeof(double) * (kPcgScalHead + 3 * (size_t)c->pcg_cap)) == hipSuccess
+        && hipMalloc(&c->pcg_sc, sizeof(double) * (16 + 8 * (size_t)kPcgMaxBlocks)) == hipSuccess   // fs[0..1] + stage stamps of the timing hook
         && hipMalloc(&c->pcg_part, sizeof(double) * 14 * kPcgMaxBlocks) == hipSuccess
-        && hipMalloc(&c->mg_scal, sizeof(double) * 16) == hipSuccess && hipMalloc(&c->mg_ext, sizeof(double) * 4) == hipSuccess
+        && hipMalloc(&c->mg_scal, sizeof(double) * kMgScal) == hipSuccess && hipMalloc(&c->mg_ext, sizeof(double) * 8) == hipSuccess
+        && hipMalloc(&c->mg_hist, sizeof(double) * ((size_t)c->pcg_cap + 2)) == hipSuccess && hipMalloc(&c->d_need, 2 * sizeof(int)) == hipSuccess
         && hipMalloc(&c->mg_slots, sizeof(int) * 8) == hipSuccess
         && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess
         && hipMalloc(&c->led_light, sizeof(float) * 3) == hipSuccess
@@ -663,7 +667,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mg_slots);
+    hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mg_hist); hipFree(c->d_need); hipFree(c->mg_slots);
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1078,9 +1082,9 @@ int psgsdf_set_stream(psgsdf_ctx* c, void* hip_stream) {
     c->stream = (hipStream_t)hip_stream; c->own_stream = false;
     return PSGSDF_OK;
 }
-int psgsdf_mg_info(psgsdf_ctx* c, int32_t out[8]) {
+int psgsdf_mg_info(psgsdf_ctx* c, int32_t out[10]) {
     if (!c || !c->inited) return PSGSDF_ERR_STATE;
-    out[0] = c->band.S; out[1] = c->band.Spad; out[2] = c->row0; out[3] = c->row1; out[4] = c->halo; out[5] = c->F; out[6] = c->rank; out[7] = c->n_ranks;
+    out[0] = c->band.S; out[1] = c->band.Spad; out[2] = c->row0; out[3] = c->row1; out[4] = c->halo; out[5] = c->F; out[6] = c->rank; out[7] = c->n_ranks; out[8] = c->need[0]; out[9] = c->need[1];
     return PSGSDF_OK;
 }
 int psgsdf_mg_buffer(psgsdf_ctx* c, int which, void** ptr, int64_t* count) {
@@ -1088,11 +1092,12 @@ int psgsdf_mg_buffer(psgsdf_ctx* c, int which, void** ptr, int64_t* count) {
     const int64_t Sp = c->band.Spad;
     switch (which) {
         case PSGSDF_MG_BUF_FRAME_ACC: *ptr = c->acc_frame; *count = (int64_t)c->F * kFrameRow; break;   /* f64 */
-        case PSGSDF_MG_BUF_SCAL: *ptr = c->mg_scal; *count = 16; break;                                 /* f64 */
-        case PSGSDF_MG_BUF_PCG: *ptr = c->mg_ext; *count = 3; break;                                    /* f64 */
+        case PSGSDF_MG_BUF_SCAL: *ptr = c->mg_scal; *count = kMgScal; break;                            /* f64 */
+        case PSGSDF_MG_BUF_PCG: *ptr = c->mg_ext; *count = 8; break;                                    /* f64 */
         case PSGSDF_MG_BUF_DIST: *ptr = c->band.dist; *count = Sp; break;                               /* f32 */
         case PSGSDF_MG_BUF_BLK: *ptr = c->band.blk; *count = 14 * Sp; break;                            /* f32, 14 planes */
-        case PSGSDF_MG_BUF_ZP: *ptr = c->band.zp; *count = 2 * Sp; break;                               /* f32 pairs */
+        case PSGSDF_MG_BUF_REC0: *ptr = c->band.rec[0]; *count = 4 * Sp; break;                         /* f32 x 4 per row */
+        case PSGSDF_MG_BUF_REC1: *ptr = c->band.rec[1]; *count = 4 * Sp; break;
         case PSGSDF_MG_BUF_RHO: *ptr = c->band.rho[0]; *count = 3 * Sp; break;                          /* f32, 3 planes */
         case PSGSDF_MG_BUF_GRAD: *ptr = c->band.g[0]; *count = 3 * Sp; break;                           /* f32, 3 planes */
         default: return PSGSDF_ERR_ARG;
@@ -1101,14 +1106,11 @@ int psgsdf_mg_buffer(psgsdf_ctx* c, int which, void** ptr, int64_t* count) {
 }
 static int mg_fold(psgsdf_ctx* c, std::initializer_list<int> slots) {
     SlotList sl; sl.n = 0; for (int s_ : slots) sl.id[sl.n++] = s_;
-    launch_sum_parts(c->part, c->PB, band_blocks(c), sl, c->mg_scal, c->stream);
+    if (c->mg_fold_base < 0 || c->mg_fold_base + sl.n > kMgScal) return fail(c, PSGSDF_ERR_ARG, "fold base %d out of range", c->mg_fold_base);
+    launch_sum_parts(c->part, c->PB, band_blocks(c), sl, c->mg_scal + c->mg_fold_base, c->stream);
     return 0;
 }
-static int mg_pcg_grid(psgsdf_ctx* c) {
-    const int nblk = std::max(1, band_blocks(c));
-    const int passes = (nblk + 704 - 1) / 704;
-    return (nblk + passes - 1) / passes;
-}
+static int mg_pcg_cap(psgsdf_ctx* c) { int cap = c->set.cg_max_it > 0 ? c->set.cg_max_it : 2 * c->band.S; return std::min(cap, c->pcg_cap); }
 int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
     if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1131,52 +1133,54 @@ int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
         case PSGSDF_MG_SOLVE_POSE: timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->stream); }); return 0;
         case PSGSDF_MG_SWEEP_DIST: timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); }); return mg_fold(c, {SC_ENERGY, SC_NOBS});
         case PSGSDF_MG_ASSEMBLE: timed(c, "assemble", [&] { launch_assemble(a, c->stream); }); return 0;
-        case PSGSDF_MG_PCG_INIT:
-            launch_pcg_init(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), c->stream);
-            launch_pcg_sum(c->pcg_part, mg_pcg_grid(c), -1, 1, c->mg_ext, c->stream);
-            return 0;
-        case PSGSDF_MG_PCG_MV:
-            a.ext = c->mg_ext; a.laplacian_reg = 0;
-            timed(c, "pcg_mv", [&] { launch_pcg_mv(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), arg, 1, c->stream); });
-            launch_pcg_sum(c->pcg_part, mg_pcg_grid(c), arg, 0, c->mg_ext, c->stream);
-            return 0;
-        case PSGSDF_MG_PCG_UPD:
-            a.ext = c->mg_ext; a.laplacian_reg = 0;
-            timed(c, "pcg_upd", [&] { launch_pcg_upd(a, c->pcg_sc, c->pcg_part, mg_pcg_grid(c), arg, c->stream); });
-            launch_pcg_sum(c->pcg_part, mg_pcg_grid(c), arg, 1, c->mg_ext, c->stream);
-            return 0;
-        case PSGSDF_MG_APPLY_DIST: timed(c, "apply_dist", [&] { launch_apply_dist(a, c->stream); }); return mg_fold(c, {SC_ACCEPT});
-        case PSGSDF_MG_DERIVE: a.laplacian_reg = 0; timed(c, "derive", [&] { launch_derive(a, arg, c->stream); }); return mg_fold(c, {SC_EN, SC_EL});
-        case PSGSDF_MG_SET_REG_SUMS: {   // mg_scal[0..1] = all-reduced Eikonal / Laplacian sums -> energy cache
-            double s_[2]; HIPCHK(c, hipMemcpyAsync(s_, c->mg_scal, sizeof(s_), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
-            c->en_sum = s_[0]; c->el_sum = s_[1];
+        case PSGSDF_MG_PCG_INIT: {
+            int G, rows; cgf_shape(band_blocks(c), &G, &rows);
+            timed(c, "pcg_init", [&] { launch_cgf_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
+            launch_cgf_sum(c->pcg_part, G, -1, c->mg_ext, c->stream);      // local |b|^2 -> ext[0]
             return 0;
         }
+        case PSGSDF_MG_PCG_PASS: {   // arg = kernel index k: finishes pass k-1, runs pass k; ext holds the all-reduced sums of pass k-1
+            if (arg < 0 || arg > mg_pcg_cap(c)) return fail(c, PSGSDF_ERR_ARG, "PCG kernel index %d out of range", arg);
+            int G, rows; cgf_shape(band_blocks(c), &G, &rows);
+            a.ext = c->mg_ext; a.laplacian_reg = 0;
+            timed(c, "pcg_pass", [&] { launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, arg, mg_pcg_cap(c), c->mg_hist + arg, c->stream); });
+            launch_cgf_sum(c->pcg_part, G, arg, c->mg_ext, c->stream);     // local sums of pass k -> ext[0..6]
+            return 0;
+        }
+        case PSGSDF_MG_APPLY_DIST: timed(c, "apply_dist", [&] { launch_apply_dist(a, c->stream); }); return mg_fold(c, {SC_ACCEPT});
+        case PSGSDF_MG_DERIVE: a.laplacian_reg = 0; timed(c, "derive", [&] { launch_derive(a, arg, c->stream); }); return mg_fold(c, {SC_EN, SC_EL});
         default: return fail(c, PSGSDF_ERR_ARG, "unknown phase %d", phase);
     }
     return rc;
 }
-// after a chunk of PCG passes [k0, k0+n): did it converge?  (mg_ext holds the reduced |r|^2, r.z of the last pass)
+// after the PCG kernels [k0, k0+n) have been enqueued: did the solve stop?  iters = -1 while it is still running.
+// Kernel k publishes |b|^2 (k = 0) or |r|^2 after pass k-1; every rank sees the same (all-reduced) values.
 int psgsdf_mg_pcg_status(psgsdf_ctx* c, int k0, int n, int32_t* iters, double* err) {
-    if (!c || !c->inited || n < 1 || n > 60) return PSGSDF_ERR_ARG;
-    HIPCHK(c, hipMemcpyAsync(c->host_buf, c->pcg_sc, sizeof(double) * kPcgScalHead, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->host_buf + kPcgScalHead, c->pcg_sc + kPcgScalHead + 3 * (size_t)k0, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->host_buf + kPcgScalHead + 3 * n, c->mg_ext, sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));
+    if (!c || !c->inited || !iters || !err || k0 < 0 || n < 1 || n > 64) return PSGSDF_ERR_ARG;
+    const int cap = mg_pcg_cap(c);
+    HIPCHK(c, hipMemcpyAsync(c->host_buf, c->mg_hist, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->host_buf + 1, c->mg_hist + k0, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    float rhsN = (float)c->host_buf[0];
+    const float rhsN = (float)c->host_buf[0];
     *iters = -1; *err = 0;
-    if (rhsN == 0.f) { *iters = 0; return PSGSDF_OK; }
-    float thr = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
-    float rn2 = 0;
-    for (int q = 0; q < n; ++q) {
-        // |r|^2 of pass k0+q is published by the NEXT mv; for the last pass of the chunk it is still in mg_ext
-        rn2 = (float)(q == n - 1 ? c->host_buf[kPcgScalHead + 3 * n + 0] : c->host_buf[kPcgScalHead + 3 * q + 1]);
-        if (rn2 < thr) { *iters = k0 + q; break; }
+    if (rhsN == 0.f) { *iters = 0; c->last_cg_iters = 0; return PSGSDF_OK; }
+    const float thr = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
+    float rn2 = rhsN;
+    for (int q = 0; q < n && *iters < 0; ++q) {
+        const int kk = k0 + q;
+        if (kk == 0) continue;
+        rn2 = (float)c->host_buf[1 + q];
+        if (rn2 < thr) *iters = kk - 1; else if (kk == cap) *iters = cap;
     }
     *err = sqrt((double)rn2 / (double)rhsN);
     if (*iters >= 0) c->last_cg_iters = *iters;
     return PSGSDF_OK;
 }
+// where (offset in doubles) the scalars folded by the following phases land in the SCAL buffer: the host program gives every
+// phase of an iteration its own slots and all-reduces / reads the buffer ONCE per iteration
+int psgsdf_mg_fold_base(psgsdf_ctx* c, int base) { if (!c || base < 0 || base >= kMgScal) return PSGSDF_ERR_ARG; c->mg_fold_base = base; return PSGSDF_OK; }
+// all-reduced Eikonal / Laplacian energy sums (host values) -> the context's energy bookkeeping
+int psgsdf_mg_set_reg_sums(psgsdf_ctx* c, double en_sum, double el_sum) { if (!c) return PSGSDF_ERR_ARG; c->en_sum = en_sum; c->el_sum = el_sum; return PSGSDF_OK; }
 // the engine's band planes ARE the exchange planes: nothing to pack (the CPU oracle keeps a dense grid and needs these)
 int psgsdf_mg_pack_state(psgsdf_ctx* c) { return c ? PSGSDF_OK : PSGSDF_ERR_ARG; }
 int psgsdf_mg_unpack_state(psgsdf_ctx* c) { return c ? PSGSDF_OK : PSGSDF_ERR_ARG; }

@@ -11,7 +11,7 @@
 //   per voxel  : k_derive (FD gradient / surface point / Eikonal+Laplacian energies), k_init_albedo,
 //                k_energy, k_sweep_albedo, k_sweep_dist            (voxel-major, set-bit iteration)
 //   per frame  : k_sweep_light, k_sweep_pose                        (frame-major, wave+LDS reduction)
-//   solves     : k_solve_light, k_solve_pose (LDL^T per frame), k_assemble, k_pcg_init/mv/upd
+//   solves     : k_solve_light, k_solve_pose (LDL^T per frame), k_assemble, k_cgf_init/pass (fused Jacobi-PCG)
 #include "engine.h"
 #include <float.h>
 
@@ -705,18 +705,18 @@ void launch_obs_fill(const Band& b, int F, int row0, int row1, const int* offset
     int nch = (row1 - row0 + kObsChunk - 1) / kObsChunk;
     if (nch > 0 && F > 0) hipLaunchKernelGGL(k_obs_fill, dim3(nch, F), dim3(kBlock), 0, s, b, F, row0, row1, offsets);
 }
-// halo width of a row partition: the largest |column row - row| over all ELL columns (contiguous halo ranges suffice
-// because the band is sorted by linear index)
-__global__ void __launch_bounds__(kBlock) k_reach(Band b, int* __restrict__ reach) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int r = 0;
-    if (i < b.S) for (int q = 1; q < kNQ; ++q) { int c = b.col[(size_t)q * b.Spad + i]; int d = c > i ? c - i : i - c; r = d > r ? d : r; }
+// halo of a row partition: how many rows below row0 / from row1 upward the ELL columns of the owned rows reach
+// (contiguous ranges suffice because the band is sorted by linear index).  need[0] = rows below, need[1] = rows above.
+__global__ void __launch_bounds__(kBlock) k_reach(Band b, int row0, int row1, int* __restrict__ need) {
+    int i = row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    int lo = 0, hi = 0;
+    if (i < row1) for (int q = 1; q < kNQ; ++q) { int c = b.col[(size_t)q * b.Spad + i]; if (c < row0) lo = max(lo, row0 - c); if (c >= row1) hi = max(hi, c - row1 + 1); }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) r = max(r, __shfl_down(r, o, 64));
-    if ((threadIdx.x & 63) == 0 && r > 0) atomicMax(reach, r);
+    for (int o = 32; o > 0; o >>= 1) { lo = max(lo, __shfl_down(lo, o, 64)); hi = max(hi, __shfl_down(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { if (lo > 0) atomicMax(need, lo); if (hi > 0) atomicMax(need + 1, hi); }
 }
-void launch_reach(const Band& b, int* d_reach, hipStream_t s) {
-    if (b.S > 0) hipLaunchKernelGGL(k_reach, dim3((b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, b, d_reach);
+void launch_reach(const Band& b, int row0, int row1, int* d_need, hipStream_t s) {
+    if (row1 > row0) hipLaunchKernelGGL(k_reach, dim3((row1 - row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, b, row0, row1, d_need);
 }
 // fold per-workgroup partials into a few doubles.  `out` may be host-mapped pinned memory: the host then needs no
 // D2H copy (each hipMemcpyAsync costs ~10 us of GPU idle around it), only the stream synchronisation it does anyway.
@@ -1454,172 +1454,11 @@ void launch_assemble(const SweepArgs& a, hipStream_t s) {
     if (a.row1 > a.row0) hipLaunchKernelGGL(k_assemble, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 
-// Jacobi-PCG with Eigen::ConjugateGradient semantics: x0 = 0, threshold = max(eps^2 |b|^2, FLT_MIN),
-// scalar recurrences in float, dot products accumulated in double.  Two kernels per iteration, each a grid-stride
-// pass of G <= kPcgMaxBlocks workgroups.  Dot products: every workgroup stores ONE partial; the consumer kernel sums
-// the G partials in a fixed order in every workgroup (deterministic, no atomics) and workgroup 0 publishes the
-// scalar to `sc` for the host and for later kernels.
-//   sc[0] = |b|^2, sc[1] = r0.z0, then per iteration k: sc[4+3k] = p.t, sc[5+3k] = |r|^2, sc[6+3k] = r.z
-//   part layout: [parity 2][kind 3: p.t, |r|^2, r.z][kPcgMaxBlocks]; the init partials use parity 1 kinds 1,2 (= "iteration -1")
-__device__ __forceinline__ double* pcg_part(double* part, int k, int kind) { return part + ((size_t)((k & 1) * 3 + kind)) * kPcgMaxBlocks; }
-
-__global__ void __launch_bounds__(kBlock) k_pcg_init(SweepArgs a, double* sc, double* part) {
-    __shared__ double red[kBlock / 64];
-    const Band& b = a.b;
-    double bb = 0, rz = 0;
-    for (int i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x; i < a.row1; i += gridDim.x * blockDim.x) {
-        float dg = b.H[i];
-        if (a.damping != 0.0f) dg += a.damping * dg;
-        float inv = dg != 0.f ? 1.0f / dg : 1.0f;
-        float r = b.rhs[i];
-        float z = inv * r;
-        b.inv[i] = inv; b.x[i] = 0.f; b.r[i] = r; b.zp[i] = make_float2(z, 0.f); b.p[i] = 0.f;
-        bb += (double)r * (double)r; rz += (double)r * (double)z;
-    }
-    block_part_store(bb, pcg_part(part, -1, 1), red);
-    block_part_store(rz, pcg_part(part, -1, 2), red);
-}
-void launch_pcg_init(const SweepArgs& a, double* sc, double* part, int G, hipStream_t s) {
-    if (a.row1 > a.row0) hipLaunchKernelGGL(k_pcg_init, dim3(G), dim3(kBlock), 0, s, a, sc, part);
-}
 __device__ __forceinline__ float pcg_threshold(float rhsNorm2) { return fmaxf(FLT_EPSILON * FLT_EPSILON * rhsNorm2, FLT_MIN); }
 
-// sum of two partial arrays at once (one pair of barriers), identical in every thread of every block
-__device__ __forceinline__ void block_total2(const double* p1, const double* p2, int n, double* red /*[2*kBlock/64]*/, double& s1, double& s2) {
-    double v1 = 0, v2 = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { v1 += p1[i]; v2 += p2[i]; }
-    v1 = wave_sum(v1); v2 = wave_sum(v2);
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { red[2 * w] = v1; red[2 * w + 1] = v2; }
-    __syncthreads();
-    s1 = 0; s2 = 0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { s1 += red[2 * i]; s2 += red[2 * i + 1]; }
-}
-// p_k = z + beta p_{k-1} (recomputed for every gathered column from the {z,p} pair), t = A p_k, partial p.t
-__global__ void __launch_bounds__(kBlock) k_pcg_mv(SweepArgs a, double* sc, double* part, int k, int with_damping) {
-    __shared__ double red[2 * kBlock / 64];
-    const Band& b = a.b;
-    // reduce what the previous kernel produced: |r|^2 and r.z of iteration k-1 (k = 0: |b|^2 and r0.z0)
-    double s1, s2;
-    if (a.ext) { s1 = a.ext[0]; s2 = a.ext[1]; }   // multi-rank: already reduced over workgroups and ranks
-    else block_total2(pcg_part(part, k - 1, 1), pcg_part(part, k - 1, 2), gridDim.x, red, s1, s2);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (k == 0) { sc[0] = s1; sc[1] = s2; } else { sc[kPcgScalHead + 3 * (k - 1) + 1] = s1; sc[kPcgScalHead + 3 * (k - 1) + 2] = s2; }
-    }
-    const float rhsNorm2 = (float)(k == 0 ? s1 : sc[0]);
-    if (rhsNorm2 == 0.f) return;
-    if (k > 0 && (float)s1 < pcg_threshold(rhsNorm2)) return;   // converged in pass k-1
-    float beta = 0.f;
-    if (k > 0) {
-        float absNew = (float)s2;
-        float absOld = (float)(k == 1 ? sc[1] : sc[kPcgScalHead + 3 * (k - 2) + 2]);
-        beta = absNew / absOld;
-    }
-    double pt = 0;
-    for (int i0 = a.row0 + blockIdx.x * blockDim.x; i0 < a.row1; i0 += gridDim.x * blockDim.x) {
-        const int i = i0 + threadIdx.x;
-        const bool live = i < a.row1;
-        const int ii = live ? i : a.row1 - 1;
-        // 13 common columns: coefficient, column and gather loads are all independent of each other
-        float h[kNQCommon]; int c[kNQCommon];
-#pragma unroll
-        for (int q = 0; q < kNQCommon; ++q) { h[q] = b.H[(size_t)q * b.Spad + ii]; c[q] = q == 0 ? ii : b.col[(size_t)q * b.Spad + ii]; }
-        if (with_damping && a.damping != 0.0f) h[0] += a.damping * h[0];
-        double acc = 0; float pi = 0.f;
-#pragma unroll
-        for (int q = 0; q < kNQCommon; ++q) {
-            const float2 zpc = b.zp[c[q]];
-            const float pc = zpc.x + beta * zpc.y;
-            if (q == 0) pi = pc;
-            acc += (double)h[q] * (double)pc;
-        }
-        // the 6 rare columns exist only next to backward-forced stencils: wave-uniform skip
-        if (__any(live && b.hx[ii])) {
-#pragma unroll
-            for (int q = kNQCommon; q < kNQ; ++q) {
-                const float hq = b.H[(size_t)q * b.Spad + ii];
-                const float2 zpc = b.zp[b.col[(size_t)q * b.Spad + ii]];
-                acc += (double)hq * (double)(zpc.x + beta * zpc.y);
-            }
-        }
-        if (live) {
-            float t = (float)acc;
-            b.p[i] = pi; b.t[i] = t;
-            pt += (double)pi * (double)t;
-        }
-    }
-    block_part_store(pt, pcg_part(part, k, 0), red);
-}
-void launch_pcg_mv(const SweepArgs& a, double* sc, double* part, int G, int k, int with_damping, hipStream_t s) {
-    if (a.row1 > a.row0) hipLaunchKernelGGL(k_pcg_mv, dim3(G), dim3(kBlock), 0, s, a, sc, part, k, with_damping);
-}
-// x += alpha p ; r -= alpha t ; z = M^-1 r ; partial |r|^2 and r.z
-__global__ void __launch_bounds__(kBlock) k_pcg_upd(SweepArgs a, double* sc, double* part, int k) {
-    __shared__ double red[kBlock / 64];
-    const Band& b = a.b;
-    const float rhsNorm2 = (float)sc[0];
-    bool done = rhsNorm2 == 0.f || (k > 0 && (float)sc[kPcgScalHead + 3 * (k - 1) + 1] < pcg_threshold(rhsNorm2));
-    if (done) {   // keep the partials of this (skipped) pass at zero so that later passes stay skipped
-        if (threadIdx.x == 0) { pcg_part(part, k, 1)[blockIdx.x] = 0.0; pcg_part(part, k, 2)[blockIdx.x] = 0.0; }
-        return;
-    }
-    const double ptot = a.ext ? a.ext[2] : block_total(pcg_part(part, k, 0), gridDim.x, red);
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc[kPcgScalHead + 3 * k + 0] = ptot;
-    float absNew = (float)(k == 0 ? sc[1] : sc[kPcgScalHead + 3 * (k - 1) + 2]);
-    float alpha = absNew / (float)ptot;
-    double rr = 0, rz = 0;
-    for (int i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x; i < a.row1; i += gridDim.x * blockDim.x) {
-        const float pi = b.p[i];
-        float x = b.x[i] + alpha * pi;
-        float r = b.r[i] - alpha * b.t[i];
-        float z = b.inv[i] * r;
-        b.x[i] = x; b.r[i] = r; b.zp[i] = make_float2(z, pi);
-        rr += (double)r * (double)r; rz += (double)r * (double)z;
-    }
-    block_part_store(rr, pcg_part(part, k, 1), red);
-    block_part_store(rz, pcg_part(part, k, 2), red);
-}
-void launch_pcg_upd(const SweepArgs& a, double* sc, double* part, int G, int k, hipStream_t s) {
-    if (a.row1 > a.row0) hipLaunchKernelGGL(k_pcg_upd, dim3(G), dim3(kBlock), 0, s, a, sc, part, k);
-}
-// publish |r|^2 and r.z of pass k (end of a chunk: the host has to see them)
-__global__ void __launch_bounds__(kBlock) k_pcg_final(double* sc, double* part, int G, int k0, int k, double* host_out) {
-    __shared__ double red[kBlock / 64];
-    const double s1 = block_total(pcg_part(part, k, 1), G, red);
-    const double s2 = block_total(pcg_part(part, k, 2), G, red);
-    if (threadIdx.x == 0) {
-        float rhsNorm2 = (float)sc[0];
-        bool prev_done = rhsNorm2 == 0.f || (k > 0 && (float)sc[kPcgScalHead + 3 * (k - 1) + 1] < pcg_threshold(rhsNorm2));
-        double rn2_k = 0.0;
-        if (!prev_done) { sc[kPcgScalHead + 3 * k + 1] = s1; sc[kPcgScalHead + 3 * k + 2] = s2; rn2_k = s1; }
-        if (host_out) {   // {|b|^2, |r|^2 of passes k0..k}: everything the host needs to decide, no D2H copy
-            host_out[0] = sc[0];
-            for (int q = k0; q < k; ++q) host_out[1 + q - k0] = sc[kPcgScalHead + 3 * q + 1];
-            host_out[1 + k - k0] = rn2_k;
-        }
-    }
-}
-void launch_pcg_final(double* sc, double* part, int G, int k0, int k, double* host_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_final, dim3(1), dim3(kBlock), 0, s, sc, part, G, k0, k, host_out);
-}
-__global__ void __launch_bounds__(kBlock) k_pcg_sum(const double* __restrict__ part_c, int G, int k, int which, double* __restrict__ out) {
-    __shared__ double red[kBlock / 64];
-    double* part = const_cast<double*>(part_c);
-    if (which == 0) { double t = block_total(pcg_part(part, k, 0), G, red); if (threadIdx.x == 0) out[2] = t; }
-    else {
-        double t1 = block_total(pcg_part(part, k, 1), G, red);
-        __syncthreads();
-        double t2 = block_total(pcg_part(part, k, 2), G, red);
-        if (threadIdx.x == 0) { out[0] = t1; out[1] = t2; }
-    }
-}
-void launch_pcg_sum(const double* part, int G, int k, int which, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_sum, dim3(1), dim3(kBlock), 0, s, part, G, k, which, out);
-}
-
 // ------------------------------------------------------------------------------------------
-// Fused Jacobi-PCG: ONE kernel and ONE reduction per CG iteration, same recurrences as Eigen's conjugate_gradient
-// (single-GPU path; the multi-rank phases keep the two-kernel form above, whose dot products the host all-reduces).
+// Jacobi-PCG with Eigen::ConjugateGradient semantics: x0 = 0, threshold = max(eps^2 |b|^2, FLT_MIN), scalar
+// recurrences in float, dot products accumulated in double.  ONE kernel and ONE reduction per CG iteration:
 // Pass k (t = A p_k) also reduces, over the same rows,
 //     P = p.t   B = sum inv r t   C = sum inv t^2   D = sum r t   E = sum t^2   Z = r.z   R = |r|^2      (r = r_k, double)
 // from which the NEXT kernel derives alpha_k = Z / P and, without ever reducing r_{k+1} = r_k - alpha t separately,
@@ -1630,8 +1469,12 @@ void launch_pcg_sum(const double* part, int G, int k, int which, double* out, hi
 // own rows, and re-derives r_k, z_k, p_k of every gathered column from that column's record {r, t, p, inv} of pass k-1
 // (ONE 16-byte gather per column; records double-buffered because neighbours still read the old ones).
 //   fs (device doubles): [0] |b|^2   [1] done (0 = running)
-//   part: [2 parity][kCgfSums][kPcgMaxBlocks]
-//   mb  : mapped host slot of THIS kernel: k = 0 -> |b|^2, k > 0 -> |r|^2 after pass k-1 (what the host loop tests)
+//   part: [2 parity][kCgfSums][kPcgMaxBlocks] per-workgroup partial sums, summed in a fixed order by every workgroup of
+//         the next kernel (deterministic, no atomics)
+//   mb  : slot of THIS kernel (mapped host memory on one GPU): k = 0 -> |b|^2, k > 0 -> |r|^2 after pass k-1
+// Multi-rank (a.ext != nullptr): a 1-workgroup kernel folds the partials of a pass into a.ext[0..6], the host program
+// all-reduces them over the ranks, and the next kernel reads the global sums from a.ext instead of the partials; the
+// records of the halo rows are exchanged before each pass.
 // ------------------------------------------------------------------------------------------
 constexpr int kCgfSums = 7;
 __device__ __forceinline__ double* fpart(double* part, int k, int kind) { return part + ((size_t)((k & 1) * kCgfSums + kind)) * kPcgMaxBlocks; }
@@ -1751,15 +1594,19 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
     if (ab & 1) { alpha_prev = 0.01f; beta = 0.5f; rr_cur = 1.f; rhsNorm2 = 1.f; }
     else if (!(ab & 16) && stopped != 0.0 && stopped <= (double)k) return;   // stopped by an EARLIER kernel of this solve (kernel j writes j + 1)
     else if (k == 0) {
-        double* src[1] = {fpart(part, -1, 6)}; double bb;
-        block_total_n<1>(src, gridDim.x, red, &bb);
+        double bb;
+        if (a.ext) bb = a.ext[0];
+        else { double* src[1] = {fpart(part, -1, 6)}; block_total_n<1>(src, gridDim.x, red, &bb); }
         rhsNorm2 = (float)bb; rr_cur = rhsNorm2;
         if (blockIdx.x == 0 && threadIdx.x == 0) { fs[0] = bb; mb[0] = bb; }
     } else {
         double* src[kCgfSums]; double t[kCgfSums];
 #pragma unroll
         for (int q = 0; q < kCgfSums; ++q) src[q] = fpart(part, k - 1, q);
-        block_total_n<kCgfSums>(src, gridDim.x, red, t);
+        if (a.ext) {
+#pragma unroll
+            for (int q = 0; q < kCgfSums; ++q) t[q] = a.ext[q];
+        } else block_total_n<kCgfSums>(src, gridDim.x, red, t);
         rhsNorm2 = (float)fs[0];
         const float rz_old = (float)t[5];
         alpha_prev = rz_old / (float)t[0];                // alpha = absNew / p.dot(tmp)
@@ -1833,6 +1680,25 @@ void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int ro
     // rows per thread kept in flight at once <-> registers <-> resident workgroups per CU (launch bound = waves per SIMD)
     if (rows >= 3) hipLaunchKernelGGL((k_cgf_pass<3, 2>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
     else hipLaunchKernelGGL((k_cgf_pass<1, 4>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
+}
+
+// multi-rank: fold the partials of pass k (k = -1: |b|^2 of the init) into out[0..6] for the host program's all-reduce
+__global__ void __launch_bounds__(kBlock) k_cgf_sum(double* part, int G, int k, double* __restrict__ out) {
+    __shared__ double red[kCgfSums * kBlock / 64];
+    if (k < 0) {
+        double* src[1] = {fpart(part, -1, 6)}; double bb;
+        block_total_n<1>(src, G, red, &bb);
+        if (threadIdx.x == 0) out[0] = bb;
+    } else {
+        double* src[kCgfSums]; double t[kCgfSums];
+#pragma unroll
+        for (int q = 0; q < kCgfSums; ++q) src[q] = fpart(part, k, q);
+        block_total_n<kCgfSums>(src, G, red, t);
+        if (threadIdx.x < kCgfSums) out[threadIdx.x] = t[threadIdx.x];
+    }
+}
+void launch_cgf_sum(double* part, int G, int k, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_cgf_sum, dim3(1), dim3(kBlock), 0, s, part, G, k, out);
 }
 
 // debug: y = H x without damping

