@@ -273,7 +273,8 @@ int psgsdf_reset_kernel_times(psgsdf_ctx* ctx);
 /* enable per-kernel hipEvent timing (adds a sync per launch: measurement mode only) */
 int psgsdf_set_profiling(psgsdf_ctx* ctx, int enabled);
 /* time ONE kernel (by its name in psgsdf_kernel_times) with hipEvent pairs recorded on the launch
- * stream and no host synchronisation; resolved by the next psgsdf_kernel_times call.  NULL/"" = off. */
+ * stream and no host synchronisation; resolved by the next psgsdf_kernel_times call.  NULL/"" = off.
+ * "name/N" samples every N-th launch (an event pair costs ~3 us of stream time). */
 int psgsdf_watch_kernel(psgsdf_ctx* ctx, const char* name);
 /* Builds the distance normal equations at the current state and returns, for the n_band rows:
  * diag (H_ii before damping), rhs b, and y = H*x for the supplied x (may be NULL). */

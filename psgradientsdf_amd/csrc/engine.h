@@ -83,6 +83,10 @@ constexpr int kCgfMaxBlocks = 768;   // workgroups of one fused PCG pass: at mos
 
 enum { SC_ENERGY = 0, SC_NOBS = 1, SC_EN = 2, SC_EL = 3, SC_ACCEPT = 4, SC_AUX0 = 5, SC_AUX1 = 6, SC_AUX2 = 7, SC_COUNT = 8 };
 
+// a pending fold of per-workgroup partials (previous kernel's scalar reductions) that the NEXT kernel performs in its
+// first workgroup instead of a 1-workgroup kernel of its own (saves a launch + boundary per scalar read-back)
+struct FoldReq { int n; int id[4]; int nblk; double* out; };
+
 struct SweepArgs {
     Band b;
     const FrameP* frames;     // [F]
@@ -98,6 +102,7 @@ struct SweepArgs {
     int normal_reg, laplacian_reg;
     float damping;
     int row0, row1;           // band rows this context owns: [row0, row1) (whole band on one GPU; a z-slab per rank otherwise)
+    FoldReq fold;             // n = 0: nothing pending
     const double* ext;        // multi-rank PCG: the 7 globally reduced sums of the previous pass (|b|^2 in ext[0] for pass 0), else nullptr
 };
 
@@ -125,8 +130,8 @@ void launch_sweep_albedo(const SweepArgs& a, hipStream_t s);
 void launch_apply_albedo(const SweepArgs& a, hipStream_t s);
 void launch_sweep_light(const SweepArgs& a, hipStream_t s);
 void launch_sweep_pose(const SweepArgs& a, hipStream_t s);
-void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, hipStream_t s);
-void launch_solve_pose(const SweepArgs& a, FrameP* frames, hipStream_t s);
+void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, hipStream_t s);   // also sums the energy columns -> e_out (nullable) and clears the rows
+void launch_solve_pose(const SweepArgs& a, FrameP* frames, double* e_out, hipStream_t s);
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s);
 void launch_assemble(const SweepArgs& a, hipStream_t s);
 void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s);

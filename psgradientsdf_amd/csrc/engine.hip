@@ -75,6 +75,10 @@ struct psgsdf_ctx {
     double* mg_ext = nullptr;            // [8] PCG: local sums of a pass out, globally reduced sums in
     double* mg_hist = nullptr;           // [pcg_cap + 2] PCG: what kernel k published (|b|^2, then |r|^2 after pass k-1)
     int mg_fold_base = 0;
+    FoldReq pending_fold{};              // scalar fold waiting for the next kernel (read_parts_deferred / take_fold)
+    bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
+    double* frame_e_slot = nullptr;      // mailbox slot the next per-frame solve writes its sweep's energy sums to
+    bool pcg_poll = true;                // PCG stop test by watching the mapped mailbox (PSGSDF_PCG_POLL=0: drain the stream instead)
     int need[2] = {0, 0}; int* d_need = nullptr;   // halo rows needed below row0 / from row1 up
     int* mg_slots = nullptr;             // [8] device copy of slot ids for k_sum_parts
     bool own_stream = true;
@@ -86,7 +90,7 @@ struct psgsdf_ctx {
     // asynchronous watch of ONE kernel name: event pairs recorded on the launch stream, resolved on query
     std::string watch;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> watch_pool;
-    size_t watch_used = 0;
+    size_t watch_used = 0; int watch_every = 1; size_t watch_seen = 0;
     char err[512] = {0};
 };
 
@@ -101,7 +105,7 @@ int fail(psgsdf_ctx* c, int code, const char* fmt, ...) {
 
 template <class Fn> void timed(psgsdf_ctx* c, const char* name, Fn&& fn) {
     if (!c->profiling) {
-        if (!c->watch.empty() && c->watch == name) {
+        if (!c->watch.empty() && c->watch == name && (c->watch_seen++ % c->watch_every) == 0) {   // a sample of the launches: the event pair costs ~3 us of stream time
             if (c->watch_used == c->watch_pool.size()) {
                 hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); c->watch_pool.emplace_back(a, b);
             }
@@ -126,6 +130,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.b = c->band; a.frames = c->frames; a.img = c->img; a.F = c->F; a.cam = c->cam; a.grid = c->grid;
     a.rob.loss = c->set.loss; a.rob.lambda = c->set.lambda; a.rob.lambda_sq = c->set.lambda * c->set.lambda; a.rob.inv_lambda = 1.0f / c->set.lambda;
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
+    a.fold.n = 0;
     a.model = c->set.model; a.quirks = c->set.ref_quirks;
     a.reg_n = c->reg_n; a.reg_l = c->reg_l;
     a.normal_reg = c->reg_n != 0.0f; a.laplacian_reg = laplacian_reg;
@@ -138,6 +143,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
 inline int band_blocks(const psgsdf_ctx* c) { return (c->row1 - c->row0 + kBlock - 1) / kBlock; }
 int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<void(const double*)> consume);
 int read_frame_energy_deferred(psgsdf_ctx* c, int col_e, std::function<void(double, double)> consume);
+void materialize_fold(psgsdf_ctx* c);
 // blocking variants
 int read_parts(psgsdf_ctx* c, const int* slots, int n, double* out) {
     int rc = read_parts_deferred(c, slots, n, [out, n](const double* v) { for (int i = 0; i < n; ++i) out[i] = v[i]; });
@@ -149,17 +155,39 @@ int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs) {
 }
 // synchronise the stream once and run every deferred consumer in submission order
 int flush(psgsdf_ctx* c) {
+    materialize_fold(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto& f : c->deferred) f();
     c->deferred.clear(); c->mbox_used = 0;
     return 0;
 }
-// sum of per-workgroup partials of `slots`, delivered to `consume(sums)` at the next flush (no host sync here)
+// sum of per-workgroup partials of `slots`, delivered to `consume(sums)` at the next flush (no host sync here).
+// The fold itself is left pending: the next kernel that can take it (take_fold) does it in its first workgroup;
+// anything else that needs the value first (flush, a kernel that writes those slots) launches k_sum_parts.
+void materialize_fold(psgsdf_ctx* c) {
+    if (!c->pending_fold.n) return;
+    SlotList sl; sl.n = c->pending_fold.n; for (int i = 0; i < sl.n; ++i) sl.id[i] = c->pending_fold.id[i];
+    launch_sum_parts(c->part, c->PB, c->pending_fold.nblk, sl, c->pending_fold.out, c->stream);
+    c->pending_fold.n = 0;
+}
+// hand the pending fold to a kernel about to be launched with `a`; `writes` = bit mask of the partial slots that kernel writes
+void take_fold(psgsdf_ctx* c, SweepArgs& a, unsigned writes) {
+    a.fold.n = 0;
+    if (!c->pending_fold.n) return;
+    for (int i = 0; i < c->pending_fold.n; ++i) if (writes & (1u << c->pending_fold.id[i])) { materialize_fold(c); return; }
+    a.fold = c->pending_fold; c->pending_fold.n = 0;
+}
 int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<void(const double*)> consume) {
+    materialize_fold(c);
     if (c->mbox_used + (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
     const size_t off = c->mbox_used; c->mbox_used += n;
-    SlotList sl; sl.n = n; for (int i = 0; i < n; ++i) sl.id[i] = slots[i];
-    launch_sum_parts(c->part, c->PB, band_blocks(c), sl, c->mbox_dev + off, c->stream);
+    if (n <= 4 && c->fold_in_next) {
+        c->pending_fold.n = n; for (int i = 0; i < n; ++i) c->pending_fold.id[i] = slots[i];
+        c->pending_fold.nblk = band_blocks(c); c->pending_fold.out = c->mbox_dev + off;
+    } else {
+        SlotList sl; sl.n = n; for (int i = 0; i < n; ++i) sl.id[i] = slots[i];
+        launch_sum_parts(c->part, c->PB, band_blocks(c), sl, c->mbox_dev + off, c->stream);
+    }
     const double* src = c->mbox + off;
     c->deferred.push_back([src, consume] { consume(src); });
     return 0;
@@ -168,6 +196,15 @@ int read_frame_energy_deferred(psgsdf_ctx* c, int col_e, std::function<void(doub
     if (c->mbox_used + 2 > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
     const size_t off = c->mbox_used; c->mbox_used += 2;
     launch_frame_cols(c->acc_frame, c->F, col_e, c->mbox_dev + off, c->stream);
+    const double* src = c->mbox + off;
+    c->deferred.push_back([src, consume] { consume(src[0], src[1]); });
+    return 0;
+}
+// deferred variant without a kernel of its own: the solve kernel that follows the sweep writes the two sums to *dev_slot
+int reserve_frame_energy_deferred(psgsdf_ctx* c, std::function<void(double, double)> consume, double** dev_slot) {
+    if (c->mbox_used + 2 > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+    const size_t off = c->mbox_used; c->mbox_used += 2;
+    *dev_slot = c->mbox_dev + off;
     const double* src = c->mbox + off;
     c->deferred.push_back([src, consume] { consume(src[0], src[1]); });
     return 0;
@@ -304,6 +341,7 @@ inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l) { 
 
 int ps_energy(psgsdf_ctx* c, double* E, int64_t* nobs) {
     SweepArgs a = make_args(c, 0);
+    take_fold(c, a, (1u << SC_ENERGY) | (1u << SC_NOBS) | (1u << SC_AUX0) | (1u << SC_AUX1) | (1u << SC_AUX2));
     timed(c, "energy", [&] { launch_energy(a, c->stream); });
     const int slots[2] = {SC_ENERGY, SC_NOBS}; double s[2];
     int rc = read_parts(c, slots, 2, s); if (rc) return rc;
@@ -344,23 +382,39 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         const int n = std::min(chunk, cap + 1 - k);
         if (c->mbox_used + (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
         const size_t off = c->mbox_used; c->mbox_used += n;
+        volatile double* st = c->mbox + off;
+        for (int q = 0; q < n; ++q) st[q] = NAN;       // "not published yet" (kernel q of the chunk overwrites its slot)
         for (int q = 0; q < n; ++q)
             timed(c, "pcg_pass", [&] { launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, k + q, cap, c->mbox_dev + off + q, c->stream); });
-        { int rc = flush(c); if (rc) return rc; }
-        const double* st = c->mbox + off;
+        // Watch the mapped slots instead of waiting for the stream to drain: the kernel that detects convergence publishes
+        // at its START, so the host learns the outcome while that kernel and the surplus (no-op) kernels of the chunk are
+        // still running, and enqueues the rest of the iteration behind them without a bubble.
+        bool drained = !c->pcg_poll;
+        if (drained) { int rc = flush(c); if (rc) return rc; }
         for (int q = 0; q < n && iters < 0; ++q) {
             const int kk = k + q;
+            while (!drained && std::isnan(st[q])) {
+                if (hipStreamQuery(c->stream) == hipSuccess) drained = true;   // nothing left that could publish
+            }
+            const double v = st[q];
+            if (std::isnan(v)) return fail(c, PSGSDF_ERR_DEVICE, "PCG kernel %d published nothing", kk);
             if (kk == 0) {
-                rhsN = (float)st[0];
-                if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }
+                rhsN = (float)v;
+                if (rhsN == 0.f) { iters = 0; break; }
                 threshold = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
                 rn2_last = rhsN;
                 continue;
             }
-            rn2_last = (float)st[q];                       // |r|^2 after pass kk-1
+            rn2_last = (float)v;                           // |r|^2 after pass kk-1
             if (rn2_last < threshold) iters = kk - 1;      // Eigen breaks before ++i
             else if (kk == cap) iters = cap;
         }
+        if (!drained && c->pending_fold.n) { int rc = flush(c); if (rc) return rc; drained = true; }   // (cannot happen: assemble took it)
+        if (!drained) {   // every deferred read-back enqueued before the chunk has landed (in-order stream): deliver them
+            for (auto& f : c->deferred) f();
+            c->deferred.clear(); c->mbox_used = 0;
+        }
+        if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }
         if (iters >= 0) break;
         k += n;
         chunk = 4;
@@ -384,7 +438,7 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
     int rc;
     switch (block) {
         case PSGSDF_ALBEDO: case PSGSDF_DIST: {
-            if (block == PSGSDF_ALBEDO) timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); });
+            if (block == PSGSDF_ALBEDO) { take_fold(c, a, (1u << SC_ENERGY) | (1u << SC_NOBS)); timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); }); }
             else timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); });
             const int slots[2] = {SC_ENERGY, SC_NOBS}; double s[2];
             if (deferred_consumer) return read_parts_deferred(c, slots, 2, [deferred_consumer](const double* v) { deferred_consumer(v[0], v[1]); });
@@ -393,14 +447,14 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
             break;
         }
         case PSGSDF_LIGHT: case PSGSDF_POSE: {
-            launch_zero_f64(c->acc_frame, (int)c->acc_frame_n, c->stream);
-            int col;
+            int col;   // the frame accumulator is all-zero here: whoever consumed it last cleared it (kernels.hip: frame_rows_finish)
             if (block == PSGSDF_LIGHT) {
+                take_fold(c, a, 0u);
                 timed(c, "sweep_light", [&] { launch_sweep_light(a, c->stream); });
                 const int n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4), nh = led ? 3 : n * (n + 1) / 2;
                 col = nh + n;
-            } else { timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); }); col = 27; }
-            if (deferred_consumer) return read_frame_energy_deferred(c, col, deferred_consumer);
+            } else { take_fold(c, a, 0u); timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); }); col = 27; }
+            if (deferred_consumer) return reserve_frame_energy_deferred(c, deferred_consumer, &c->frame_e_slot);   // filled by the solve kernel
             if ((rc = read_frame_energy(c, col, &e_sum, &nobs))) return rc;
             break;
         }
@@ -416,6 +470,7 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
     int rc;
     switch (block) {
         case PSGSDF_ALBEDO: {
+            take_fold(c, a, 1u << SC_ACCEPT);
             timed(c, "apply_albedo", [&] { launch_apply_albedo(a, c->stream); });
             const int slots[1] = {SC_ACCEPT}; double s[1];
             if (c->want_counts) { if ((rc = read_parts(c, slots, 1, s))) return rc; st->n_accepted = (int64_t)s[0]; }
@@ -423,14 +478,17 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
             break;
         }
         case PSGSDF_LIGHT:
-            timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->stream); });
+            timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->frame_e_slot, c->stream); });
+            c->frame_e_slot = nullptr;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = led ? 1 : c->F;
             break;
         case PSGSDF_POSE:
-            timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->stream); });
+            timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->frame_e_slot, c->stream); });
+            c->frame_e_slot = nullptr;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = c->F;
             break;
         case PSGSDF_DIST: {
+            take_fold(c, a, 0u);
             timed(c, "assemble", [&] { launch_assemble(a, c->stream); });
             int iters = 0, ok = 1; double err = 0;
             if ((rc = pcg_solve(c, a, &iters, &ok, &err))) return rc;
@@ -546,7 +604,10 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
                 close_iteration(c, L, &prev, prev_slot, (float)st.e_in, full);
                 have_prev = false;
                 if ((rc = finalize(prev, iter - 1))) return rc;
-                if (stop) break;   // converged / diverged / aborted: nothing of this iteration has been applied
+                if (stop) {        // converged / diverged / aborted: nothing of this iteration has been applied
+                    if (blk == PSGSDF_LIGHT || blk == PSGSDF_POSE) launch_zero_f64(c->acc_frame, (int)c->acc_frame_n, c->stream);   // the sweep's rows stay unconsumed
+                    break;
+                }
             } else {
                 // no stop decision pending (psgsdf_iterate never exits early): even the closing energy of the previous
                 // iteration is delivered lazily, at the next host sync (the PCG status read of this iteration)
@@ -634,6 +695,8 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (hipSetDevice(device) != hipSuccess) return PSGSDF_ERR_DEVICE;
     psgsdf_ctx* c = new psgsdf_ctx();
     c->device = device;
+    if (const char* e = getenv("PSGSDF_PCG_POLL")) c->pcg_poll = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_FOLD_IN_NEXT")) c->fold_in_next = atoi(e) != 0;
     c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l;
     GridP& g = c->grid;
     for (int a = 0; a < 3; ++a) { g.dim[a] = grid->dim[a]; c->shift[a] = grid->shift[a]; }
@@ -747,6 +810,7 @@ int psgsdf_set_keyframes(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, 
     HIPCHK(c, hipMalloc(&c->frames, sizeof(FrameP) * n_frames));
     c->acc_frame_n = (size_t)n_frames * 64;
     HIPCHK(c, hipMalloc(&c->acc_frame, sizeof(double) * c->acc_frame_n));
+    HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));   // invariant: zero outside [sweep, solve]
     HIPCHK(c, hipMemcpyAsync(c->frame_idx, frame_idx, sizeof(int) * n_frames, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->img, rgb_images, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
     c->frames_h.assign(n_frames, FrameP{});
@@ -1128,9 +1192,9 @@ int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
         case PSGSDF_MG_SWEEP_ALBEDO: timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); }); return mg_fold(c, {SC_ENERGY, SC_NOBS});
         case PSGSDF_MG_APPLY_ALBEDO: timed(c, "apply_albedo", [&] { launch_apply_albedo(a, c->stream); }); return mg_fold(c, {SC_ACCEPT});
         case PSGSDF_MG_SWEEP_LIGHT: HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream)); timed(c, "sweep_light", [&] { launch_sweep_light(a, c->stream); }); return 0;
-        case PSGSDF_MG_SOLVE_LIGHT: timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->stream); }); return 0;
+        case PSGSDF_MG_SOLVE_LIGHT: timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, nullptr, c->stream); }); return 0;
         case PSGSDF_MG_SWEEP_POSE: HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream)); timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); }); return 0;
-        case PSGSDF_MG_SOLVE_POSE: timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->stream); }); return 0;
+        case PSGSDF_MG_SOLVE_POSE: timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, nullptr, c->stream); }); return 0;
         case PSGSDF_MG_SWEEP_DIST: timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); }); return mg_fold(c, {SC_ENERGY, SC_NOBS});
         case PSGSDF_MG_ASSEMBLE: timed(c, "assemble", [&] { launch_assemble(a, c->stream); }); return 0;
         case PSGSDF_MG_PCG_INIT: {
@@ -1193,7 +1257,11 @@ int psgsdf_reset_kernel_times(psgsdf_ctx* c) { if (!c) return PSGSDF_ERR_ARG; c-
 int psgsdf_watch_kernel(psgsdf_ctx* c, const char* name) {
     if (!c) return PSGSDF_ERR_ARG;
     hipStreamSynchronize(c->stream);
-    c->watch = name ? name : ""; c->watch_used = 0;
+    // "name" or "name/N": HIP events around every N-th launch of that kernel (default every launch)
+    std::string w = name ? name : ""; int every = 1;
+    const size_t sl = w.find('/');
+    if (sl != std::string::npos) { every = std::max(1, atoi(w.c_str() + sl + 1)); w.resize(sl); }
+    c->watch = w; c->watch_every = every; c->watch_seen = 0; c->watch_used = 0;
     return PSGSDF_OK;
 }
 int psgsdf_kernel_times(psgsdf_ctx* c, const char** names, double* ms, int64_t* launches, int cap) {
@@ -1266,6 +1334,7 @@ int psgsdf_debug_frame_system(psgsdf_ctx* c, int block, double* H, double* b) {
     else return fail(c, PSGSDF_ERR_ARG, "block must be LIGHT or POSE");
     std::vector<double> acc(c->acc_frame_n);
     HIPCHK(c, hipMemcpyAsync(acc.data(), c->acc_frame, sizeof(double) * c->acc_frame_n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (led && block == PSGSDF_LIGHT) {   // one global system: sum the per-frame rows
         for (int i = 0; i < 9; ++i) H[i] = 0;

@@ -116,6 +116,16 @@ __device__ __forceinline__ double block_total(const double* part, int n, double*
     return s;
 }
 #define PART(a, slot) ((a).acc.part + (size_t)(slot) * (a).acc.PB)
+// a.fold: sum the partial slots the PREVIOUS kernel left behind (first workgroup only; all its threads must call).
+// The calling kernel must not write the folded slots itself (engine.hip: take_fold checks).
+__device__ __forceinline__ void fold_pending(const SweepArgs& a, double* red /*[kBlock/64]*/) {
+    if (a.fold.n == 0 || blockIdx.x != 0 || blockIdx.y != 0) return;
+    for (int s = 0; s < a.fold.n; ++s) {
+        const double t = block_total(PART(a, a.fold.id[s]), a.fold.nblk, red);
+        if (threadIdx.x == 0) a.fold.out[s] = t;
+    }
+    __syncthreads();
+}
 
 // frame records (pose, light) of all keyframes staged in dynamic LDS: F * 96 B (<= 60 KiB, F <= kMaxFramesLds)
 extern __shared__ __align__(16) unsigned char psg_dyn_smem[];
@@ -790,6 +800,7 @@ void launch_init_albedo(const SweepArgs& a, hipStream_t s) {
 // LedOptimizer.cpp:76-112 (sums of observed and rendered intensity)
 template <int MODEL, bool LED_INIT>
 __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
     FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
     __shared__ double red[kBlock / 64];
@@ -845,6 +856,7 @@ void launch_led_light_init(const SweepArgs& a, hipStream_t s) {
 // albedoJacobian PsOptimizerJa.cpp:375-422, computeResidual :567-626.  Also yields the PS energy of the input state.
 template <int MODEL>
 __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
     FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
     __shared__ double red[kBlock / 64];
@@ -892,6 +904,7 @@ void launch_sweep_albedo(const SweepArgs& a, hipStream_t s) {
 }
 // delta = b / ((1+damping) H), updateAlbedo accept rule OptimizerAux.cpp:120-150
 __global__ void __launch_bounds__(kBlock) k_apply_albedo(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     __shared__ double red[kBlock / 64];
     const Band& b = a.b;
     int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -923,6 +936,7 @@ constexpr int kChunk = kBlock * kRowsPerThread;
 // LED LightJacobian LedOptimizerJa.cpp:101-115,299-346 (one global diagonal 3x3)
 template <int MODEL>
 __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
     constexpr int NH = LED ? 3 : NB * (NB + 1) / 2;
@@ -1014,6 +1028,7 @@ __device__ __forceinline__ void image_pi_grad(const Cam& cam, const Proj& pr, co
 // pose normal equations: poseJacobian PsOptimizerJa.cpp:61-115,427-475 / LedOptimizerJa.cpp:32-81,351-399
 template <int MODEL>
 __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
     constexpr int NV = 21 + 6 + 2;
@@ -1125,17 +1140,35 @@ __device__ void solve_spd(const double* Hin, const double* bin, double* x) {
     for (int i = N - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k]; x[i] = s; }
 }
 
+// The per-frame solves run as ONE workgroup (a thread takes frames tid, tid+256, ...), which lets the same kernel do
+// what used to be two more launches around every frame-major sweep: sum the energy / n_obs columns of the rows
+// (e_out, may be host-mapped) and clear the rows for the next sweep.  Invariant: the frame accumulator is all-zero
+// outside [sweep, solve].
+__device__ __forceinline__ void frame_rows_finish(const SweepArgs& a, int col_e, double* e_out, double* red) {
+    __syncthreads();                                       // every thread has read the rows it solves from
+    if (e_out) {
+        double e = 0, n = 0;
+        for (int f = threadIdx.x; f < a.F; f += blockDim.x) { e += a.acc.frame[(size_t)f * kFrameRow + col_e]; n += a.acc.frame[(size_t)f * kFrameRow + col_e + 1]; }
+        e = wave_sum(e); n = wave_sum(n);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) { red[2 * w] = e; red[2 * w + 1] = n; }
+        __syncthreads();
+        if (threadIdx.x == 0) { double te = 0, tn = 0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { te += red[2 * i]; tn += red[2 * i + 1]; } e_out[0] = te; e_out[1] = tn; }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < a.F * kFrameRow; i += blockDim.x) a.acc.frame[i] = 0.0;
+}
+
 // optimizeLightAll: PsOptimizer.cpp:175-203 (no damping) / LedOptimizer.cpp:134-160 (damped, one RGB vector)
 template <int MODEL>
-__global__ void k_solve_light(SweepArgs a, FrameP* frames, float* led_light) {
+__global__ void __launch_bounds__(kBlock) k_solve_light(SweepArgs a, FrameP* frames, float* led_light, double* e_out) {
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
     constexpr int NH = LED ? 3 : NB * (NB + 1) / 2;
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double red[2 * kBlock / 64];
     if (LED) {
-        if (f >= a.F) return;
-        // every thread sums the per-frame rows, solves the same 3 scalar equations and updates its own record
-        float nl[3];
+        // every thread sums the per-frame rows, solves the same 3 scalar equations and updates its own records
+        float dl[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             double hs = 0, bs = 0;
@@ -1144,30 +1177,31 @@ __global__ void k_solve_light(SweepArgs a, FrameP* frames, float* led_light) {
             if (a.damping != 0.0f) h += a.damping * h;
             double Hd[1] = {(double)h}, bd[1] = {(double)bb}, xd[1];
             solve_spd<1>(Hd, bd, xd);
-            nl[ch] = frames[f].l[ch] - (float)xd[0];
+            dl[ch] = (float)xd[0];
         }
+        for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) { frames[f].l[ch] = nl[ch]; if (f == 0) led_light[ch] = nl[ch]; }
-        return;
+            for (int ch = 0; ch < 3; ++ch) { const float nl = frames[f].l[ch] - dl[ch]; frames[f].l[ch] = nl; if (f == 0) led_light[ch] = nl; }
+        }
     } else {
-        if (f >= a.F) return;
-        const double* acc = a.acc.frame + (size_t)f * kFrameRow;
-        double Hd[NB * NB], bd[NB], xd[NB];
-        int q = 0;
-        for (int i = 0; i < NB; ++i) for (int k = i; k < NB; ++k) { double v = (double)(float)acc[q++]; Hd[i * NB + k] = v; Hd[k * NB + i] = v; }
-        for (int i = 0; i < NB; ++i) bd[i] = (double)(float)acc[NH + i];
-        solve_spd<NB>(Hd, bd, xd);
-        for (int i = 0; i < NB; ++i) frames[f].l[i] -= (float)xd[i];
+        for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
+            const double* acc = a.acc.frame + (size_t)f * kFrameRow;
+            double Hd[NB * NB], bd[NB], xd[NB];
+            int q = 0;
+            for (int i = 0; i < NB; ++i) for (int k = i; k < NB; ++k) { double v = (double)(float)acc[q++]; Hd[i * NB + k] = v; Hd[k * NB + i] = v; }
+            for (int i = 0; i < NB; ++i) bd[i] = (double)(float)acc[NH + i];
+            solve_spd<NB>(Hd, bd, xd);
+            for (int i = 0; i < NB; ++i) frames[f].l[i] -= (float)xd[i];
+        }
     }
+    frame_rows_finish(a, NH + NB, e_out, red);
 }
-// the frame accumulator rows are consumed: clear them for the next frame-major sweep (replaces a memset node)
-__global__ void k_clear_frame_rows(double* frame, int n) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) frame[i] = 0.0; }
-void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, hipStream_t s) {
+void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, hipStream_t s) {
     if (a.F <= 0) return;
-    dim3 g((a.F + 63) / 64), bl(64);
-    if (a.model == 0) hipLaunchKernelGGL((k_solve_light<0>), g, bl, 0, s, a, frames, led_light);
-    else if (a.model == 1) hipLaunchKernelGGL((k_solve_light<1>), g, bl, 0, s, a, frames, led_light);
-    else hipLaunchKernelGGL((k_solve_light<2>), g, bl, 0, s, a, frames, led_light);
+    dim3 g(1), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_solve_light<0>), g, bl, 0, s, a, frames, led_light, e_out);
+    else if (a.model == 1) hipLaunchKernelGGL((k_solve_light<1>), g, bl, 0, s, a, frames, led_light, e_out);
+    else hipLaunchKernelGGL((k_solve_light<2>), g, bl, 0, s, a, frames, led_light, e_out);
 }
 
 // Sophus SO3::exp(w).matrix() (quaternion exponential + Eigen toRotationMatrix)
@@ -1190,33 +1224,35 @@ __device__ void so3_exp(const float* w, float* R) {
     R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
 }
 // optimizePosesAll PsOptimizer.cpp:207-234 + updatePose OptimizerAux.cpp:190-205
-__global__ void k_solve_pose(SweepArgs a, FrameP* frames) {
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= a.F) return;
-    const double* acc = a.acc.frame + (size_t)f * kFrameRow;
-    double Hd[36], bd[6], xd[6];
-    int q = 0;
-    for (int i = 0; i < 6; ++i) for (int k = i; k < 6; ++k) {
-        float v = (float)acc[q++];
-        if (i == k && a.damping != 0.0f) v += a.damping * v;
-        Hd[i * 6 + k] = (double)v; Hd[k * 6 + i] = (double)v;
+__global__ void __launch_bounds__(kBlock) k_solve_pose(SweepArgs a, FrameP* frames, double* e_out) {
+    __shared__ double red[2 * kBlock / 64];
+    for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
+        const double* acc = a.acc.frame + (size_t)f * kFrameRow;
+        double Hd[36], bd[6], xd[6];
+        int q = 0;
+        for (int i = 0; i < 6; ++i) for (int k = i; k < 6; ++k) {
+            float v = (float)acc[q++];
+            if (i == k && a.damping != 0.0f) v += a.damping * v;
+            Hd[i * 6 + k] = (double)v; Hd[k * 6 + i] = (double)v;
+        }
+        for (int i = 0; i < 6; ++i) bd[i] = (double)(float)acc[21 + i];
+        solve_spd<6>(Hd, bd, xd);
+        float xi[6];
+        for (int i = 0; i < 6; ++i) xi[i] = (float)xd[i];
+        float R[9], t[3];
+        for (int i = 0; i < 9; ++i) R[i] = frames[f].R[i];
+        for (int i = 0; i < 3; ++i) t[i] = frames[f].t[i];
+        float mw[3] = {-xi[3], -xi[4], -xi[5]}, E3[9];
+        so3_exp(mw, E3);
+        for (int i = 0; i < 3; ++i) {
+            frames[f].t[i] = t[i] - xi[i];
+            for (int k = 0; k < 3; ++k) frames[f].R[i * 3 + k] = (R[i * 3 + 0] * E3[0 * 3 + k] + R[i * 3 + 1] * E3[1 * 3 + k]) + R[i * 3 + 2] * E3[2 * 3 + k];
+        }
     }
-    for (int i = 0; i < 6; ++i) bd[i] = (double)(float)acc[21 + i];
-    solve_spd<6>(Hd, bd, xd);
-    float xi[6];
-    for (int i = 0; i < 6; ++i) xi[i] = (float)xd[i];
-    float R[9], t[3];
-    for (int i = 0; i < 9; ++i) R[i] = frames[f].R[i];
-    for (int i = 0; i < 3; ++i) t[i] = frames[f].t[i];
-    float mw[3] = {-xi[3], -xi[4], -xi[5]}, E3[9];
-    so3_exp(mw, E3);
-    for (int i = 0; i < 3; ++i) {
-        frames[f].t[i] = t[i] - xi[i];
-        for (int k = 0; k < 3; ++k) frames[f].R[i * 3 + k] = (R[i * 3 + 0] * E3[0 * 3 + k] + R[i * 3 + 1] * E3[1 * 3 + k]) + R[i * 3 + 2] * E3[2 * 3 + k];
-    }
+    frame_rows_finish(a, 27, e_out, red);
 }
-void launch_solve_pose(const SweepArgs& a, FrameP* frames, hipStream_t s) {
-    if (a.F > 0) hipLaunchKernelGGL(k_solve_pose, dim3((a.F + 63) / 64), dim3(64), 0, s, a, frames);
+void launch_solve_pose(const SweepArgs& a, FrameP* frames, double* e_out, hipStream_t s) {
+    if (a.F > 0) hipLaunchKernelGGL(k_solve_pose, dim3(1), dim3(kBlock), 0, s, a, frames, e_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1414,6 +1450,7 @@ void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
 // slices from itself, from each lower neighbour (whose forward stencil points at it) and from each
 // upper neighbour whose stencil was forced backward.  Accumulation in LDS (dynamic column index).
 __global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     __shared__ double acc[kNQ][kBlock];
     const Band& b = a.b;
     int i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
@@ -1598,7 +1635,7 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
         if (a.ext) bb = a.ext[0];
         else { double* src[1] = {fpart(part, -1, 6)}; block_total_n<1>(src, gridDim.x, red, &bb); }
         rhsNorm2 = (float)bb; rr_cur = rhsNorm2;
-        if (blockIdx.x == 0 && threadIdx.x == 0) { fs[0] = bb; mb[0] = bb; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { fs[0] = bb; mb[0] = bb; __threadfence_system(); }   // mb may be host-mapped: the host watches it
     } else {
         double* src[kCgfSums]; double t[kCgfSums];
 #pragma unroll
@@ -1614,7 +1651,7 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
         const float rz_cur = (float)(t[5] - 2.0 * al * t[1] + al * al * t[2]);
         rr_cur = (float)(t[6] - 2.0 * al * t[3] + al * al * t[4]);
         beta = rz_cur / rz_old;                            // beta = absNew / absOld
-        if (blockIdx.x == 0 && threadIdx.x == 0) mb[0] = (double)rr_cur;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { mb[0] = (double)rr_cur; __threadfence_system(); }
     }
     CGF_STAMP(2);
     const bool rhs_zero = rhsNorm2 == 0.f;

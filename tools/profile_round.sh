@@ -1,0 +1,18 @@
+#!/bin/bash
+# One profiling pass for profiles/: kernel trace + stats of the default bench command, then FETCH_SIZE / WRITE_SIZE PMC passes.
+# usage (on the GPU box): tools/profile_round.sh <tag>     -> gpurun_out/prof_<tag>/
+set -u
+tag=$1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/prof_$tag; mkdir -p $out
+rocprofv3 --kernel-trace --stats -d $out/trace -o kt -- python bench.py --no-cpu-baseline > $out/bench_traced.json 2> $out/trace.err
+python tools/rocpd_stats.py $out/trace/kt_results.db > $out/kernel_stats.md 2>> $out/trace.err
+python tools/gap_stats.py $out/trace/kt_results.db > $out/gaps.txt 2>> $out/trace.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-breakdown > $out/pmc_$c.json 2> $out/pmc_$c.err
+done
+f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python tools/pmc_summary.py "$f" "$w" > $out/pmc_summary.json
+python bench.py > $out/bench.json 2> $out/bench.err
+rm -rf $out/trace/*.db $out/pmc_*/    # keep the summaries only (the databases are tens of MB)
+head -20 $out/kernel_stats.md; cat $out/pmc_summary.json | head -30; cut -c 1-300 $out/bench.json
