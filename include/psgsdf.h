@@ -64,7 +64,7 @@ typedef struct psgsdf_settings {
     int32_t loss;           /* psgsdf_loss                                                    */
     float lambda;           /* robust-loss scale                                              */
     float damping;          /* LM damping: H_ii *= (1+damping)                                */
-    float reg_weight_rho;   /* "reg albedo"   (must be 0: PSGSDF_ERR_UNSUPPORTED otherwise)   */
+    float reg_weight_rho;   /* "reg albedo"   (single-rank only: the multi-rank phases reject it) */
     float reg_weight_n;     /* "reg norm"     Eikonal weight                                  */
     float reg_weight_l;     /* "reg laplacian"                                                */
     int32_t max_it;         /* "max iter"                                                     */
@@ -100,6 +100,7 @@ typedef struct psgsdf_iter_stats {
     int32_t converged;      /* rel_diff < conv_threshold                                       */
     int32_t diverged;       /* E_total > E_prev                                                */
     int32_t upsampled;      /* this iteration ended with the 2x refine                         */
+    double e_r;             /* un-weighted albedo-gradient energy (Optimizer.cpp:122-136) after the albedo step; 0 unless "reg albedo" */
 } psgsdf_iter_stats;
 
 /* sizes the caller needs for downloads */

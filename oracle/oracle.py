@@ -55,6 +55,11 @@ class Oracle(capi.Api):
         ok = self._lib.orc_probe_pose_jacobian(self.ctx, C.c_int(j), C.c_int(f), J)
         return bool(ok), np.array(J[:], np.float32).reshape(3, 6)
 
+    def probe_albedo_reg(self, j):
+        J = (C.c_float * 12)(); res = (C.c_float * 3)(); nb = (C.c_int64 * 3)()
+        self._lib.orc_probe_albedo_reg(self.ctx, C.c_int(j), J, res, nb)
+        return np.array(J[:], np.float32).reshape(4, 3), np.array(res[:], np.float32), list(nb)
+
     def probe_rho_jacobian(self, j, f):
         J = (C.c_float * 3)()
         self._lib.orc_probe_rho_jacobian(self.ctx, C.c_int(j), C.c_int(f), J)

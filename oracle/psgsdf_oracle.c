@@ -46,6 +46,7 @@ typedef struct orc_ctx {
     float fx, fy, cx, cy;
     psgsdf_settings set;
     float reg_n, reg_l; /* effective weights (settings_->reg_weight_n/l are mutated, B9) */
+    float reg_r;        /* "reg albedo": never normalised (PsOptimizer.cpp:279) */
     /* dense voxel state (SdfVoxel, Sdfvoxel.h:6-13) in SoA */
     float *dist, *gx, *gy, *gz, *weight, *r, *g, *b;
     uint64_t* vis_seq; int wpv_seq;  /* per integrated frame */
@@ -370,6 +371,41 @@ static double laplacian_energy(const orc_ctx* c) {
     return c->S ? E / (double)c->S : 0.0;
 }
 
+/* Optimizer.cpp:396-460 computeAlbedoGrad: G[ch][axis] = dir_axis * (rho_ch(neighbour) - rho_ch(v)) / vs with the stencil
+ * direction of the distance gradient (forward iff the forward neighbour is a band voxel); the neighbour is read from the
+ * grid whether or not it is in the band.  nb_lin[a] = its linear index (the voxel itself if that would leave the grid). */
+static void albedo_grad(const orc_ctx* c, int lin, float G[9], float dir[3], long nb_lin[3]) {
+    int idx[3]; line2idx(c, lin, idx);
+    long stride[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
+    const float* rho[3] = {c->r, c->g, c->b};
+    for (int a = 0; a < 3; ++a) {
+        dir[a] = valid_forward(c, lin, idx, a) ? 1.0f : -1.0f;
+        long ln = (long)lin + (long)dir[a] * stride[a];          /* idx2line arithmetic, as the neighbour tables of the distance stencil */
+        if (ln < 0 || (size_t)ln >= c->nvox) ln = lin;           /* the reference reads out of bounds here (UB): zero difference */
+        nb_lin[a] = ln;
+        for (int ch = 0; ch < 3; ++ch) G[ch * 3 + a] = (dir[a] * (rho[ch][ln] - rho[ch][lin])) * c->vs_inv;
+    }
+}
+/* Optimizer.cpp:122-136 getAlbedoRegEnergy: mean over the band of sum_ch ||grad rho_ch|| (the norm, not its square) */
+static double albedo_reg_energy(const orc_ctx* c) {
+    double E = 0.0;
+    for (int j = c->row0; j < c->row1; ++j) { float G[9], dir[3]; long nb[3]; albedo_grad(c, c->band[j], G, dir, nb);
+        float e = 0.f; for (int ch = 0; ch < 3; ++ch) e += norm3(G + 3 * ch); E += (double)e; }
+    return c->S ? E / (double)c->S : 0.0;
+}
+/* Optimizer.cpp:221-245 albedoRegJacobian(v): J[slot][ch], slot 0 = the voxel, 1..3 = its x/y/z stencil neighbour; res[ch] = ||grad rho_ch|| */
+static void albedo_reg_jacobian(const orc_ctx* c, int lin, float J[4][3], float res[3], long nb_lin[3]) {
+    float G[9], dir[3]; albedo_grad(c, lin, G, dir, nb_lin);
+    float r_d[3] = {-c->vs_inv * dir[0], -c->vs_inv * dir[1], -c->vs_inv * dir[2]};
+    for (int ch = 0; ch < 3; ++ch) {
+        const float* g = G + 3 * ch;
+        float gn = norm3(g); res[ch] = gn;
+        J[0][ch] = (g[0] * r_d[0] + g[1] * r_d[1]) + g[2] * r_d[2];
+        for (int a = 0; a < 3; ++a) J[a + 1][ch] = g[a] * (c->vs_inv * dir[a]);
+        if (gn != 0.0f) for (int q = 0; q < 4; ++q) J[q][ch] /= gn;
+    }
+}
+
 /* ------------------------------------------------------------------ linear algebra */
 
 /* Eigen::ConjugateGradient<SparseMatrix<float>> with the default DiagonalPreconditioner
@@ -548,6 +584,48 @@ static void albedo_system(const orc_ctx* c, float* H, float* b, double* e_in, lo
     if (nobs_out) *nobs_out = nobs;
 }
 
+typedef struct { long long key; double v; } coo_t;
+static int coo_cmp(const void* a, const void* b) { long long x = ((const coo_t*)a)->key, y = ((const coo_t*)b)->key; return x < y ? -1 : (x > y ? 1 : 0); }
+typedef struct { int n; const int* rowptr; const int* colidx; const float* val; float damping; } csr_mv_ctx;
+static void csr_mv(void* user, const float* p, float* out) {
+    const csr_mv_ctx* m = (const csr_mv_ctx*)user;
+    for (int i = 0; i < m->n; ++i) { double acc = 0;
+        for (int k = m->rowptr[i]; k < m->rowptr[i + 1]; ++k) { float v = m->val[k]; if (m->colidx[k] == i && m->damping != 0.f) v += m->damping * v; acc += (double)v * (double)p[m->colidx[k]]; }
+        out[i] = (float)acc; }
+}
+/* optimizeAlbedoAll with the ||grad rho|| regulariser (PsOptimizer.cpp:85-121, Optimizer.cpp:593-647): H = J^T W J (diagonal)
+ * + reg_rho Jr^T Jr over the 3S unknowns (3*row + channel), Eigen ConjugateGradient, update only on success for the SH
+ * optimiser (PsOptimizer.cpp:117-119), always for the LED one (LedOptimizer.cpp:195).  Quirk (ref_quirks): the blue
+ * self-entry of Jr sits in the GREEN column (Optimizer.cpp:617 `Tri2(3*row+2, 3*row+1, ...)`). */
+static int step_albedo_reg(orc_ctx* c, const float* Hd, const float* bd, float* delta, cg_result* cr) {
+    const int S = c->S, n = 3 * S;
+    coo_t* coo = (coo_t*)malloc(sizeof(coo_t) * ((size_t)48 * S + (size_t)n + 1)); size_t nc = 0;
+    double* rhs = (double*)calloc(n + 1, sizeof(double));
+    for (int i = 0; i < n; ++i) { coo[nc].key = (long long)i * n + i; coo[nc].v = (double)Hd[i]; nc++; rhs[i] = (double)bd[i]; }
+    for (int j = 0; j < S; ++j) {
+        float J[4][3], res[3]; long nb[3]; albedo_reg_jacobian(c, c->band[j], J, res, nb);
+        for (int ch = 0; ch < 3; ++ch) {
+            int col[4]; float e[4]; int m = 0;
+            col[m] = 3 * j + ((ch == 2 && c->set.ref_quirks) ? 1 : ch); e[m] = J[0][ch]; m++;
+            for (int a = 0; a < 3; ++a) { int r = (nb[a] != (long)c->band[j]) ? c->row_of[nb[a]] : -1; if (r >= 0) { col[m] = 3 * r + ch; e[m] = J[a + 1][ch]; m++; } }
+            for (int p = 0; p < m; ++p) { rhs[col[p]] += (double)c->reg_r * (double)e[p] * (double)res[ch];
+                for (int q = 0; q < m; ++q) { coo[nc].key = (long long)col[p] * n + col[q]; coo[nc].v = (double)c->reg_r * (double)e[p] * (double)e[q]; nc++; } }
+        }
+    }
+    qsort(coo, nc, sizeof(coo_t), coo_cmp);
+    int* rowptr = (int*)calloc(n + 2, sizeof(int)); int* colidx = (int*)malloc(sizeof(int) * (nc + 1)); float* val = (float*)malloc(sizeof(float) * (nc + 1));
+    float* diag = (float*)calloc(n + 1, sizeof(float)); float* rf = (float*)malloc(sizeof(float) * (n + 1));
+    size_t nnz = 0;
+    for (size_t i = 0; i < nc;) { size_t k = i; double v = 0; while (k < nc && coo[k].key == coo[i].key) { v += coo[k].v; ++k; }
+        int row = (int)(coo[i].key / n), cl = (int)(coo[i].key % n); colidx[nnz] = cl; val[nnz] = (float)v; rowptr[row + 1]++; if (row == cl) diag[row] = (float)v; nnz++; i = k; }
+    for (int i = 0; i < n; ++i) rowptr[i + 1] += rowptr[i];
+    for (int i = 0; i < n; ++i) { rf[i] = (float)rhs[i]; if (c->set.damping != 0.f) diag[i] += c->set.damping * diag[i]; }
+    csr_mv_ctx m = {n, rowptr, colidx, val, c->set.damping};
+    *cr = eigen_cg(n, csr_mv, &m, diag, rf, delta, c->set.cg_max_it);
+    free(coo); free(rhs); free(rowptr); free(colidx); free(val); free(diag); free(rf);
+    return 0;
+}
+
 static int step_albedo(orc_ctx* c, psgsdf_step_stats* st) {
     int n = 3 * c->S;
     float* H = (float*)malloc(sizeof(float) * (n > 0 ? n : 1)); float* b = (float*)malloc(sizeof(float) * (n > 0 ? n : 1));
@@ -555,20 +633,30 @@ static int step_albedo(orc_ctx* c, psgsdf_step_stats* st) {
     albedo_system(c, H, b, &e_in, &nobs);
     float damping = c->set.damping;
     long long count = 0;
-    /* diagonal system: Jacobi-PCG is exact after one step: delta = b / H */
-    for (int j = c->row0; j < c->row1; ++j) {
+    cg_result cr = {1, 0.0, 1}; int apply = 1;
+    float* delta = NULL;
+    if (c->reg_r != 0.0f) {
+        if (c->n_ranks > 1) { free(H); free(b); return PSGSDF_ERR_UNSUPPORTED; }
+        delta = (float*)calloc(n + 1, sizeof(float));
+        step_albedo_reg(c, H, b, delta, &cr);
+        if (c->set.model != PSGSDF_LED && !cr.success) apply = 0;      /* PsOptimizer.cpp:117-119 */
+    }
+    /* without the regulariser the system is diagonal: Jacobi-PCG is exact after one step: delta = b / H */
+    if (apply) for (int j = c->row0; j < c->row1; ++j) {
         int lin = c->band[j];
         float* rho[3] = {&c->r[lin], &c->g[lin], &c->b[lin]};
         for (int ch = 0; ch < 3; ++ch) {
-            float h = H[3 * j + ch];
-            if (damping != 0.0f) h += damping * h; /* PsOptimizer.cpp:103-105 */
-            float delta = (h != 0.f) ? b[3 * j + ch] / h : 0.f;
-            float v = *rho[ch] - delta; /* updateAlbedo, OptimizerAux.cpp:120-150 */
+            float dl;
+            if (delta) dl = delta[3 * j + ch];
+            else { float h = H[3 * j + ch];
+                if (damping != 0.0f) h += damping * h; /* PsOptimizer.cpp:103-105 */
+                dl = (h != 0.f) ? b[3 * j + ch] / h : 0.f; }
+            float v = *rho[ch] - dl; /* updateAlbedo, OptimizerAux.cpp:120-150 */
             if (v > 0.0f && v < 1.0f) { *rho[ch] = v; count++; }
         }
     }
-    if (st) { st->block = PSGSDF_ALBEDO; st->cg_iters = 1; st->cg_converged = 1; st->applied = 1; st->e_in = e_in; st->cg_error = 0; st->n_accepted = count; st->n_obs = nobs; }
-    free(H); free(b);
+    if (st) { st->block = PSGSDF_ALBEDO; st->cg_iters = cr.iters; st->cg_converged = cr.success; st->applied = apply; st->e_in = e_in; st->cg_error = cr.error; st->n_accepted = count; st->n_obs = nobs; }
+    free(H); free(b); free(delta);
     return 0;
 }
 
@@ -833,9 +921,7 @@ typedef struct dist_sys {
     int* rowptr; int* colidx; float* val; float* diag; float* rhs;
 } dist_sys;
 
-typedef struct { long long key; double v; } coo_t;
 static void dist_assemble(const orc_ctx* c, dist_sys* s);
-static int coo_cmp(const void* a, const void* b) { long long x = ((const coo_t*)a)->key, y = ((const coo_t*)b)->key; return x < y ? -1 : (x > y ? 1 : 0); }
 
 static void dist_sys_free(dist_sys* s) { free(s->cols); free(s->B); free(s->g); free(s->rowptr); free(s->colidx); free(s->val); free(s->diag); free(s->rhs); memset(s, 0, sizeof(*s)); }
 
@@ -1287,7 +1373,6 @@ int orc_mg_unpack_state(orc_ctx* c) { unpack_state(c, 0, c->S, 1); return 0; }
 int orc_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_settings* settings, int device, orc_ctx** out) {
     (void)device;
     if (!grid || !K || !settings || !out) return PSGSDF_ERR_ARG;
-    if (settings->reg_weight_rho != 0.0f) return PSGSDF_ERR_UNSUPPORTED;
     orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
     for (int a = 0; a < 3; ++a) { c->dim[a] = grid->dim[a]; c->shift[a] = grid->shift[a]; }
     c->nvox = (size_t)c->dim[0] * c->dim[1] * c->dim[2];
@@ -1295,7 +1380,7 @@ int orc_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_sett
     /* VoxelGrid.h:130: origin_ = shift_ - 0.5*voxel_size*grid_dim_.cast<float>() */
     for (int a = 0; a < 3; ++a) c->origin[a] = c->shift[a] - (float)(0.5 * (double)c->vs) * (float)c->dim[a];
     c->fx = K[0]; c->fy = K[4]; c->cx = K[2]; c->cy = K[5];
-    c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l;
+    c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l; c->reg_r = settings->reg_weight_rho;
     c->threads = 1; c->rank = 0; c->n_ranks = 1;
     *out = c;
     return 0;
@@ -1534,12 +1619,12 @@ int orc_init(orc_ctx* c) {
 }
 int orc_init_albedo(orc_ctx* c) { if (!c || !c->inited) return PSGSDF_ERR_STATE; init_albedo(c); return 0; }
 
-static float total_energy(const orc_ctx* c, float E, float E_n, float E_l) { return E + c->reg_n * E_n + c->reg_l * E_l; /* OptimizerAux.cpp:261 (reg_rho term is 0) */ }
+static float total_energy(const orc_ctx* c, float E, float E_n, float E_l, float E_r) { return E + c->reg_n * E_n + c->reg_l * E_l + c->reg_r * E_r; /* OptimizerAux.cpp:261 */ }
 
 int orc_energy(orc_ctx* c, double out[4]) {
     if (!c || !c->inited) return PSGSDF_ERR_STATE;
     out[0] = ps_energy(c, NULL); out[1] = normal_energy(c); out[2] = laplacian_energy(c);
-    out[3] = (double)total_energy(c, (float)out[0], c->reg_n != 0.f ? (float)out[1] : 0.f, c->reg_l != 0.f ? (float)out[2] : 0.f);
+    out[3] = (double)total_energy(c, (float)out[0], c->reg_n != 0.f ? (float)out[1] : 0.f, c->reg_l != 0.f ? (float)out[2] : 0.f, c->reg_r != 0.f ? (float)albedo_reg_energy(c) : 0.f);
     return 0;
 }
 int orc_normalize_weights(orc_ctx* c, double* e_total) {
@@ -1547,7 +1632,7 @@ int orc_normalize_weights(orc_ctx* c, double* e_total) {
     float E = (float)ps_energy(c, NULL), E_n = 0, E_l = 0;
     if (c->reg_n != 0.f) { E_n = (float)normal_energy(c); c->reg_n *= E / E_n; }
     if (c->reg_l != 0.f) { E_l = (float)laplacian_energy(c); c->reg_l *= E / E_l; }
-    if (e_total) *e_total = (double)total_energy(c, E, E_n, E_l);
+    if (e_total) *e_total = (double)total_energy(c, E, E_n, E_l, c->reg_r != 0.f ? (float)albedo_reg_energy(c) : 0.f);   /* reg_rho is not normalised (PsOptimizer.cpp:279) */
     return 0;
 }
 int orc_step_ex(orc_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) {
@@ -1564,7 +1649,7 @@ int orc_step(orc_ctx* c, int block, psgsdf_step_stats* st) { return orc_step_ex(
 
 /* one body of the alternation loop; order SH: albedo,light,dist,pose (PsOptimizer.cpp:304-360),
  * LED: light,albedo,dist,pose (LedOptimizer.cpp:345-403) */
-static void iterate_once(orc_ctx* c, int flags, int laplacian_reg, float* E, float* E_n, float* E_l, psgsdf_iter_stats* rec) {
+static void iterate_once(orc_ctx* c, int flags, int laplacian_reg, float* E, float* E_n, float* E_l, float* E_r, psgsdf_iter_stats* rec) {
     int led = c->set.model == PSGSDF_LED;
     int order[4] = {led ? PSGSDF_LIGHT : PSGSDF_ALBEDO, led ? PSGSDF_ALBEDO : PSGSDF_LIGHT, PSGSDF_DIST, PSGSDF_POSE};
     for (int q = 0; q < 4; ++q) rec->e_after[q] = NAN;
@@ -1580,21 +1665,23 @@ static void iterate_once(orc_ctx* c, int flags, int laplacian_reg, float* E, flo
             if (c->reg_n != 0.f) *E_n = (float)normal_energy(c);
             if (laplacian_reg) *E_l = (float)laplacian_energy(c);
         }
+        if (blk == PSGSDF_ALBEDO && c->reg_r != 0.f) *E_r = (float)albedo_reg_energy(c);   /* PsOptimizer.cpp:312 */
         int slot = blk == PSGSDF_ALBEDO ? 0 : blk == PSGSDF_LIGHT ? 1 : blk == PSGSDF_DIST ? 2 : 3;
         rec->e_after[slot] = (double)*E;
     }
-    rec->e_n = *E_n; rec->e_l = *E_l;
-    rec->e_total = (double)total_energy(c, *E, *E_n, *E_l);
+    rec->e_n = *E_n; rec->e_l = *E_l; rec->e_r = *E_r;
+    rec->e_total = (double)total_energy(c, *E, *E_n, *E_l, *E_r);
     rec->reg_weight_n = c->reg_n; rec->reg_weight_l = c->reg_l;
 }
 
 int orc_iterate(orc_ctx* c, int flags, int n_iters, psgsdf_iter_stats* stats) {
     if (!c || !c->inited) return PSGSDF_ERR_STATE;
     float E = (float)ps_energy(c, NULL), E_n = c->reg_n != 0.f ? (float)normal_energy(c) : 0.f, E_l = c->reg_l != 0.f ? (float)laplacian_energy(c) : 0.f;
-    float E_prev = total_energy(c, E, E_n, E_l);
+    float E_r = c->reg_r != 0.f ? (float)albedo_reg_energy(c) : 0.f;
+    float E_prev = total_energy(c, E, E_n, E_l, E_r);
     for (int it = 0; it < n_iters; ++it) {
         psgsdf_iter_stats rec; memset(&rec, 0, sizeof(rec));
-        iterate_once(c, flags, c->reg_l != 0.f, &E, &E_n, &E_l, &rec);
+        iterate_once(c, flags, c->reg_l != 0.f, &E, &E_n, &E_l, &E_r, &rec);
         float Et = (float)rec.e_total;
         rec.rel_diff = (double)(fabsf(E_prev - Et) / E_prev);
         rec.converged = rec.rel_diff < (double)c->set.conv_threshold; rec.diverged = E_prev < Et;
@@ -1613,11 +1700,12 @@ int orc_optimize(orc_ctx* c, int flags, psgsdf_iter_stats* stats, int stats_cap,
     float E = (float)ps_energy(c, NULL), E_n = 0, E_l = 0;
     if (c->reg_n != 0.f) { E_n = (float)normal_energy(c); c->reg_n *= E / E_n; }
     if (laplacian_reg) { E_l = (float)laplacian_energy(c); c->reg_l *= E / E_l; if (c->set.upsample) laplacian_reg = 0; }
-    float E_prev = total_energy(c, E, E_n, E_l);
+    float E_r = c->reg_r != 0.f ? (float)albedo_reg_energy(c) : 0.f;   /* PsOptimizer.cpp:279 */
+    float E_prev = total_energy(c, E, E_n, E_l, E_r);
     int iter = 0, done = 0; if (result) *result = 0;
     while (iter < c->set.max_it) {
         psgsdf_iter_stats rec; memset(&rec, 0, sizeof(rec));
-        iterate_once(c, flags, laplacian_reg, &E, &E_n, &E_l, &rec);
+        iterate_once(c, flags, laplacian_reg, &E, &E_n, &E_l, &E_r, &rec);
         float Et = (float)rec.e_total;
         rec.rel_diff = (double)(fabsf(E_prev - Et) / E_prev);
         rec.converged = rec.rel_diff < (double)c->set.conv_threshold;
@@ -1630,7 +1718,7 @@ int orc_optimize(orc_ctx* c, int flags, psgsdf_iter_stats* stats, int stats_cap,
             upsample2x(c);
             E_l = (float)laplacian_energy(c);
             c->reg_l *= E / E_l;
-            E_last = total_energy(c, E, E_n, E_l);
+            E_last = total_energy(c, E, E_n, E_l, E_r);
             rec.upsampled = 1;
         }
         if (!stop && c->set.upsample && (led ? iter == 15 : iter > 15)) c->reg_l = 0.0f;
@@ -1727,6 +1815,13 @@ int orc_probe_pose_jacobian(orc_ctx* c, int j, int f, float J[18]) {
 }
 int orc_probe_rho_jacobian(orc_ctx* c, int j, int f, float J[3]) {
     int lin = c->band[j]; float R[9], t[3]; pose_Rt(c, f, R, t); rho_jacobian(c, lin, f, R, t, J); return 1;
+}
+/* albedo regulariser of band row j: J[slot][ch] (slot 0 = the voxel, 1..3 = x/y/z stencil neighbour), res[ch] = ||grad rho_ch||, nb[a] = linear index of the neighbour */
+int orc_probe_albedo_reg(orc_ctx* c, int j, float J[12], float res[3], int64_t nb[3]) {
+    float Jm[4][3]; long nl[3]; albedo_reg_jacobian(c, c->band[j], Jm, res, nl);
+    for (int q = 0; q < 4; ++q) for (int ch = 0; ch < 3; ++ch) J[q * 3 + ch] = Jm[q][ch];
+    for (int a = 0; a < 3; ++a) nb[a] = (int64_t)nl[a];
+    return 1;
 }
 /* direct state pokes for finite-difference tests */
 int orc_poke_dist(orc_ctx* c, int lin, float v) { c->dist[lin] = v; return 0; }

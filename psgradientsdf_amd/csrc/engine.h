@@ -83,6 +83,17 @@ constexpr int kCgfMaxBlocks = 768;   // workgroups of one fused PCG pass: at mos
 
 enum { SC_ENERGY = 0, SC_NOBS = 1, SC_EN = 2, SC_EL = 3, SC_ACCEPT = 4, SC_AUX0 = 5, SC_AUX1 = 6, SC_AUX2 = 7, SC_COUNT = 8 };
 
+// "reg albedo" (||grad rho_c|| regulariser, Optimizer.cpp:221-245,396-460,593-647): allocated only when the weight is non-zero
+struct AlbedoReg {
+    int* anb;        // [3][Spad] band row of the stencil neighbour of each axis (forward iff in band), -1 = outside the band
+    int* back;       // [Spad] bit a set: axis a uses the backward neighbour
+    float* anrho;    // [9][Spad] (axis, channel) static albedo of a stencil neighbour outside the band
+    float* J;        // [12][Spad] (slot, channel): d ||grad rho_c|| / d rho_c(slot), slot 0 = the voxel, 1..3 = x/y/z neighbour
+    float* res;      // [3][Spad] ||grad rho_c||
+    float* rhs; float* diag; float* diag0; float* x; float* r; float* p; float* q; float* t;   // CG over the 3S unknowns, [3][Spad] each (diag0 = undamped diagonal)
+    float weight;
+};
+
 // a pending fold of per-workgroup partials (previous kernel's scalar reductions) that the NEXT kernel performs in its
 // first workgroup instead of a 1-workgroup kernel of its own (saves a launch + boundary per scalar read-back)
 struct FoldReq { int n; int id[4]; int nblk; double* out; };
@@ -103,6 +114,7 @@ struct SweepArgs {
     float damping;
     int row0, row1;           // band rows this context owns: [row0, row1) (whole band on one GPU; a z-slab per rank otherwise)
     FoldReq fold;             // n = 0: nothing pending
+    AlbedoReg ar;             // ar.anb == nullptr unless "reg albedo" != 0
     const double* ext;        // multi-rank PCG: the 7 globally reduced sums of the previous pass (|b|^2 in ext[0] for pass 0), else nullptr
 };
 
@@ -137,6 +149,16 @@ void launch_assemble(const SweepArgs& a, hipStream_t s);
 void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s);
 void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int rows, int k, int kmax, double* mb, hipStream_t s, int ablate = 0);
 void launch_cgf_sum(double* part, int G, int k, double* out, hipStream_t s);   // multi-rank: partials of pass k -> out[0..6]
+// "reg albedo" path (kernels.hip, albedo regulariser section); every launch covers the whole band (single rank only)
+void launch_areg_tables(const DenseView& d, const GridP& g, const SweepArgs& a, hipStream_t s);
+void launch_areg_build(const SweepArgs& a, hipStream_t s);                       // J, res from the current albedo; sum of res -> SC_AUX0
+void launch_areg_system(const SweepArgs& a, hipStream_t s);                      // rhs, diag (damped) from aH/ab + weight Jr^T(.)
+void launch_areg_jx(const SweepArgs& a, const float* p, float* t, hipStream_t s);               // t = Jr p
+void launch_areg_jt(const SweepArgs& a, const float* p, const float* t, float* q, hipStream_t s);   // q = (H_d + damping diag) p + weight Jr^T t; p.q -> SC_AUX0
+void launch_areg_cg_init(const SweepArgs& a, hipStream_t s);                     // x = 0, r = rhs, p = r/diag; |b|^2 -> SC_AUX0, r.z -> SC_AUX1
+void launch_areg_cg_update(const SweepArgs& a, float alpha, hipStream_t s);      // x += alpha p, r -= alpha q; |r|^2 -> SC_AUX0, r.z -> SC_AUX1
+void launch_areg_cg_dir(const SweepArgs& a, float beta, hipStream_t s);          // p = r/diag + beta p
+void launch_apply_albedo_delta(const SweepArgs& a, const float* delta, hipStream_t s);
 void launch_matvec(const SweepArgs& a, const float* x, float* y, hipStream_t s);   // debug: y = H x (no damping)
 void launch_apply_dist(const SweepArgs& a, hipStream_t s);
 void launch_upsample(const DenseView& src, const DenseView& dst, const GridP& g_old, hipStream_t s);

@@ -75,6 +75,9 @@ struct psgsdf_ctx {
     double* mg_ext = nullptr;            // [8] PCG: local sums of a pass out, globally reduced sums in
     double* mg_hist = nullptr;           // [pcg_cap + 2] PCG: what kernel k published (|b|^2, then |r|^2 after pass k-1)
     int mg_fold_base = 0;
+    float reg_r = 0.f;                   // "reg albedo" (never normalised, PsOptimizer.cpp:279)
+    void* areg_mem = nullptr; AlbedoReg ar{};   // planes of the albedo regulariser, allocated with the band when reg_r != 0
+    double er_sum = 0;                   // sum over the band of sum_c ||grad rho_c|| at the last evaluation
     FoldReq pending_fold{};              // scalar fold waiting for the next kernel (read_parts_deferred / take_fold)
     bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
     double* frame_e_slot = nullptr;      // mailbox slot the next per-frame solve writes its sweep's energy sums to
@@ -131,6 +134,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.rob.loss = c->set.loss; a.rob.lambda = c->set.lambda; a.rob.lambda_sq = c->set.lambda * c->set.lambda; a.rob.inv_lambda = 1.0f / c->set.lambda;
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
     a.fold.n = 0;
+    a.ar = c->ar; a.ar.weight = c->reg_r;
     a.model = c->set.model; a.quirks = c->set.ref_quirks;
     a.reg_n = c->reg_n; a.reg_l = c->reg_l;
     a.normal_reg = c->reg_n != 0.0f; a.laplacian_reg = laplacian_reg;
@@ -271,6 +275,20 @@ int build_band(psgsdf_ctx* c) {
     b.hx = (int*)take(1, 4);
     b.rhs = (float*)take(1, 4); b.x = (float*)take(1, 4); b.t = (float*)take(1, 4);
     timed(c, "band_fill", [&] { launch_band_fill(c->dense, c->grid, b, c->stream); });
+    if (c->areg_mem) { hipFree(c->areg_mem); c->areg_mem = nullptr; c->ar = AlbedoReg{}; }
+    if (c->reg_r != 0.f) {   // "reg albedo": stencil tables + matrix-free CG vectors over the 3S unknowns
+        if (c->n_ranks > 1) return fail(c, PSGSDF_ERR_UNSUPPORTED, "reg albedo is single-rank only");
+        const size_t planes = 3 + 1 + 9 + 12 + 3 + 8 * 3;
+        HIPCHK(c, hipMalloc(&c->areg_mem, planes * 4 * (size_t)Spad));
+        HIPCHK(c, hipMemsetAsync(c->areg_mem, 0, planes * 4 * (size_t)Spad, c->stream));
+        char* q = (char*)c->areg_mem;
+        auto tk = [&](size_t n) { void* r = q; q += n * 4 * (size_t)Spad; return r; };
+        AlbedoReg& ar = c->ar;
+        ar.anb = (int*)tk(3); ar.back = (int*)tk(1); ar.anrho = (float*)tk(9); ar.J = (float*)tk(12); ar.res = (float*)tk(3);
+        ar.rhs = (float*)tk(3); ar.diag = (float*)tk(3); ar.diag0 = (float*)tk(3); ar.x = (float*)tk(3); ar.r = (float*)tk(3); ar.p = (float*)tk(3); ar.q = (float*)tk(3); ar.t = (float*)tk(3);
+        SweepArgs at{}; at.b = b; at.ar = ar;
+        launch_areg_tables(c->dense, c->grid, at, c->stream);
+    }
     // row partition: equal band count per rank = z-slabs (the band is sorted by linear index, z slowest)
     {
         const int C = (S + c->n_ranks - 1) / c->n_ranks;
@@ -337,7 +355,7 @@ int derive(psgsdf_ctx* c, int update_grad) {
 }
 
 inline double band_mean(const psgsdf_ctx* c, double sum) { return c->band.S ? sum / (double)c->band.S : 0.0; }
-inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l) { return E + c->reg_n * E_n + c->reg_l * E_l; }
+inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l, float E_r = 0.f) { return E + c->reg_n * E_n + c->reg_l * E_l + c->reg_r * E_r; }   // OptimizerAux.cpp:261
 
 int ps_energy(psgsdf_ctx* c, double* E, int64_t* nobs) {
     SweepArgs a = make_args(c, 0);
@@ -425,6 +443,51 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
     return 0;
 }
 
+// "reg albedo": mean over the band of sum_c ||grad rho_c|| (Optimizer.cpp:122-136); also refreshes the Jacobian planes
+int albedo_reg_energy(psgsdf_ctx* c, double* Er) {
+    SweepArgs a = make_args(c, 0);
+    launch_areg_build(a, c->stream);
+    const int slots[1] = {SC_AUX0}; double s[1];
+    int rc = read_parts(c, slots, 1, s); if (rc) return rc;
+    c->er_sum = s[0]; *Er = band_mean(c, s[0]);
+    return 0;
+}
+// optimizeAlbedoAll with the regulariser (PsOptimizer.cpp:85-121): Eigen ConjugateGradient over the 3S unknowns on
+// H = H_d + reg_rho Jr^T Jr applied matrix-free (kernels.hip).  Host-driven, two read-backs per CG iteration: no shipped
+// configuration enables this term.  The step is left in ar.x.
+int albedo_reg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* ok_out, double* err_out) {
+    const AlbedoReg& ar = a.ar;
+    launch_areg_build(a, c->stream);
+    launch_areg_system(a, c->stream);
+    launch_areg_cg_init(a, c->stream);
+    const int two[2] = {SC_AUX0, SC_AUX1}, one[1] = {SC_AUX0}; double s[2];
+    int rc = read_parts(c, two, 2, s); if (rc) return rc;
+    const float rhsN = (float)s[0];
+    *iters_out = 0; *ok_out = 1; *err_out = 0;
+    if (rhsN == 0.f) return 0;
+    const float thr = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
+    float res2 = rhsN, absNew = (float)s[1];
+    const int maxIters = c->set.cg_max_it > 0 ? c->set.cg_max_it : 6 * c->band.S;
+    int i = 0;
+    if (res2 >= thr) {
+        while (i < maxIters) {
+            launch_areg_jx(a, ar.p, ar.t, c->stream);
+            launch_areg_jt(a, ar.p, ar.t, ar.q, c->stream);
+            if ((rc = read_parts(c, one, 1, s))) return rc;
+            const float alpha = absNew / (float)s[0];
+            launch_areg_cg_update(a, alpha, c->stream);
+            if ((rc = read_parts(c, two, 2, s))) return rc;
+            res2 = (float)s[0];
+            if (res2 < thr) break;
+            const float absOld = absNew; absNew = (float)s[1];
+            launch_areg_cg_dir(a, absNew / absOld, c->stream);
+            ++i;
+        }
+    }
+    *iters_out = i; *err_out = sqrt((double)res2 / (double)rhsN); *ok_out = *err_out <= (double)FLT_EPSILON;
+    return 0;
+}
+
 // A sub-step in two halves so that the alternation loop can look at the energy of the state a sweep started from
 // (= the energy AFTER the previous block, PsOptimizer.cpp:311,323,338,354) before anything is modified:
 //   step_begin : the sweep (normal equations + PS energy of the input state)          -> st->e_in, st->n_obs
@@ -470,9 +533,18 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
     int rc;
     switch (block) {
         case PSGSDF_ALBEDO: {
+            const int slots[1] = {SC_ACCEPT}; double s[1];
+            if (c->reg_r != 0.f) {
+                int iters = 0, ok = 1; double err = 0;
+                if ((rc = albedo_reg_solve(c, a, &iters, &ok, &err))) return rc;
+                const int apply = (led || ok) ? 1 : 0;      // PsOptimizer.cpp:117-119 (only on success) / LedOptimizer.cpp:195 (always)
+                if (apply) timed(c, "apply_albedo", [&] { launch_apply_albedo_delta(a, c->ar.x, c->stream); });
+                if (apply && c->want_counts) { if ((rc = read_parts(c, slots, 1, s))) return rc; st->n_accepted = (int64_t)s[0]; }
+                st->cg_iters = iters; st->cg_converged = ok; st->cg_error = err; st->applied = apply;
+                break;
+            }
             take_fold(c, a, 1u << SC_ACCEPT);
             timed(c, "apply_albedo", [&] { launch_apply_albedo(a, c->stream); });
-            const int slots[1] = {SC_ACCEPT}; double s[1];
             if (c->want_counts) { if ((rc = read_parts(c, slots, 1, s))) return rc; st->n_accepted = (int64_t)s[0]; }
             st->cg_iters = 1; st->cg_converged = 1; st->applied = 1;
             break;
@@ -522,14 +594,14 @@ int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) 
 // convergence / divergence exit still leaves exactly the state the reference would leave.  Only the last iteration
 // (and the one that triggers the 2x refinement) needs a stand-alone energy sweep.
 int do_upsample(psgsdf_ctx* c);
-struct LoopState { float E, E_n, E_l, E_prev; int laplacian_reg; };
+struct LoopState { float E, E_n, E_l, E_prev; int laplacian_reg; float E_r; };
 
 // closes record `rec` of an iteration with the PS energy E that followed its last block
 void close_iteration(psgsdf_ctx* c, LoopState& L, psgsdf_iter_stats* rec, int pending_slot, float E, bool early_exit_semantics) {
     L.E = E;
     if (pending_slot >= 0) rec->e_after[pending_slot] = (double)E;
-    rec->e_n = L.E_n; rec->e_l = L.E_l;
-    rec->e_total = (double)total_energy(c, L.E, L.E_n, L.E_l);
+    rec->e_n = L.E_n; rec->e_l = L.E_l; rec->e_r = L.E_r;
+    rec->e_total = (double)total_energy(c, L.E, L.E_n, L.E_l, L.E_r);
     rec->reg_weight_n = c->reg_n; rec->reg_weight_l = c->reg_l;
     float Et = (float)rec->e_total;
     rec->rel_diff = (double)(fabsf(L.E_prev - Et) / L.E_prev);
@@ -557,7 +629,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
             int rc = do_upsample(c); if (rc) return rc;
             L.E_l = (float)band_mean(c, c->el_sum);
             c->reg_l *= L.E / L.E_l;
-            E_last = total_energy(c, L.E, L.E_n, L.E_l);
+            E_last = total_energy(c, L.E, L.E_n, L.E_l, L.E_r);
             r.upsampled = 1;
         }
         if (full && !term && c->set.upsample && (led ? it == 15 : it > 15)) c->reg_l = 0.0f;   // PsOptimizer.cpp:411-413 / LedOptimizer.cpp:461-463
@@ -569,7 +641,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
         return 0;
     };
     // per-iteration values that arrive through deferred read-backs (stable addresses: two alternating slots)
-    struct Late { double e_in[4]; int blk_of[4]; int n; bool dist_ran; int cg_iters; } late[2];
+    struct Late { double e_in[4]; int blk_of[4]; int n; bool dist_ran; int cg_iters; bool alb_reg; float e_r; } late[2];
     int li = 0;
     auto apply_late = [&](psgsdf_iter_stats& r, const Late& lt, int first_slot_pending) {
         // e_in of sweep q is the energy AFTER the block that ran before it in the same iteration
@@ -578,6 +650,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
             if (pend >= 0 && q > 0) { r.e_after[pend] = (double)(float)band_mean(c, lt.e_in[q]); }   // deferred values are raw sums
             pend = lt.blk_of[q] == PSGSDF_ALBEDO ? 0 : lt.blk_of[q] == PSGSDF_LIGHT ? 1 : lt.blk_of[q] == PSGSDF_DIST ? 2 : 3;
         }
+        if (lt.alb_reg) L.E_r = lt.e_r;
         if (lt.dist_ran) {
             r.cg_iters = lt.cg_iters;
             if (c->reg_n != 0.f) L.E_n = (float)band_mean(c, c->en_sum);
@@ -589,7 +662,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
     while (iter < max_iters && !stop) {
         memset(&rec, 0, sizeof(rec));
         for (int q = 0; q < 4; ++q) rec.e_after[q] = NAN;
-        Late& lt = late[li]; lt.n = 0; lt.dist_ran = false; lt.cg_iters = 0;
+        Late& lt = late[li]; lt.n = 0; lt.dist_ran = false; lt.cg_iters = 0; lt.alb_reg = false; lt.e_r = 0.f;
         int pending = -1;
         for (int q = 0; q < 4 && !stop; ++q) {
             const int blk = order[q];
@@ -616,6 +689,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
                 if (have_prev && prev_close == nullptr) prev_close = slot_e;
             }
             int rc = step_finish(c, blk, L.laplacian_reg, &st, true); if (rc) return rc;
+            if (blk == PSGSDF_ALBEDO && c->reg_r != 0.f) { double er; if ((rc = albedo_reg_energy(c, &er))) return rc; lt.alb_reg = true; lt.e_r = (float)er; }   // PsOptimizer.cpp:312 (enters L when the record closes)
             if (blk == PSGSDF_DIST) { lt.dist_ran = true; lt.cg_iters = st.cg_iters; }
             if (have_prev && prev_close && !std::isnan(*prev_close)) {   // the lazy closing energy has arrived
                 apply_late(prev, *prev_late, -1);
@@ -688,7 +762,6 @@ const char* psgsdf_last_error(const psgsdf_ctx* c) { return c ? c->err : "null c
 
 int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_settings* settings, int device, psgsdf_ctx** out) {
     if (!grid || !K || !settings || !out) return PSGSDF_ERR_ARG;
-    if (settings->reg_weight_rho != 0.0f) return PSGSDF_ERR_UNSUPPORTED;
     if (settings->model < 0 || settings->model > 2) return PSGSDF_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PSGSDF_ERR_DEVICE;
@@ -697,7 +770,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     c->device = device;
     if (const char* e = getenv("PSGSDF_PCG_POLL")) c->pcg_poll = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FOLD_IN_NEXT")) c->fold_in_next = atoi(e) != 0;
-    c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l;
+    c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l; c->reg_r = settings->reg_weight_rho;
     GridP& g = c->grid;
     for (int a = 0; a < 3; ++a) { g.dim[a] = grid->dim[a]; c->shift[a] = grid->shift[a]; }
     g.nvox = (long long)g.dim[0] * g.dim[1] * g.dim[2];
@@ -730,7 +803,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mg_hist); hipFree(c->d_need); hipFree(c->mg_slots);
+    hipFree(c->areg_mem); hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mg_hist); hipFree(c->d_need); hipFree(c->mg_slots);
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -878,7 +951,8 @@ int psgsdf_energy(psgsdf_ctx* c, double out[4]) {
     HIPCHK(c, hipSetDevice(c->device));
     double E; int rc = ps_energy(c, &E, nullptr); if (rc) return rc;
     out[0] = E; out[1] = band_mean(c, c->en_sum); out[2] = band_mean(c, c->el_sum);
-    out[3] = (double)total_energy(c, (float)out[0], c->reg_n != 0.f ? (float)out[1] : 0.f, c->reg_l != 0.f ? (float)out[2] : 0.f);
+    double er = 0; if (c->reg_r != 0.f && (rc = albedo_reg_energy(c, &er))) return rc;
+    out[3] = (double)total_energy(c, (float)out[0], c->reg_n != 0.f ? (float)out[1] : 0.f, c->reg_l != 0.f ? (float)out[2] : 0.f, (float)er);
     return PSGSDF_OK;
 }
 
@@ -889,7 +963,8 @@ int psgsdf_normalize_weights(psgsdf_ctx* c, double* e_total) {
     float E = (float)e, E_n = 0, E_l = 0;
     if (c->reg_n != 0.f) { E_n = (float)band_mean(c, c->en_sum); c->reg_n *= E / E_n; }   // PsOptimizer.cpp:275-278
     if (c->reg_l != 0.f) { E_l = (float)band_mean(c, c->el_sum); c->reg_l *= E / E_l; }   // PsOptimizer.cpp:281-284
-    if (e_total) *e_total = (double)total_energy(c, E, E_n, E_l);
+    double er = 0; if (c->reg_r != 0.f && (rc = albedo_reg_energy(c, &er))) return rc;   // reg_rho is not normalised (PsOptimizer.cpp:279)
+    if (e_total) *e_total = (double)total_energy(c, E, E_n, E_l, (float)er);
     return PSGSDF_OK;
 }
 
@@ -906,7 +981,8 @@ int psgsdf_iterate(psgsdf_ctx* c, int flags, int n_iters, psgsdf_iter_stats* sta
     LoopState L{};
     L.E = (float)e;
     L.E_n = c->reg_n != 0.f ? (float)band_mean(c, c->en_sum) : 0.f; L.E_l = c->reg_l != 0.f ? (float)band_mean(c, c->el_sum) : 0.f;
-    L.E_prev = total_energy(c, L.E, L.E_n, L.E_l);
+    if (c->reg_r != 0.f) { double er; if ((rc = albedo_reg_energy(c, &er))) return rc; L.E_r = (float)er; }
+    L.E_prev = total_energy(c, L.E, L.E_n, L.E_l, L.E_r);
     L.laplacian_reg = c->reg_l != 0.f;
     int done = 0;
     return run_loop(c, flags, L, n_iters, false, stats, stats ? n_iters : 0, &done, nullptr, nullptr, nullptr);
@@ -922,7 +998,8 @@ int psgsdf_optimize(psgsdf_ctx* c, int flags, psgsdf_iter_stats* stats, int stat
     L.E = (float)e;
     if (c->reg_n != 0.f) { L.E_n = (float)band_mean(c, c->en_sum); c->reg_n *= L.E / L.E_n; }                                             // PsOptimizer.cpp:275-278
     if (L.laplacian_reg) { L.E_l = (float)band_mean(c, c->el_sum); c->reg_l *= L.E / L.E_l; if (c->set.upsample) L.laplacian_reg = 0; }   // :281-285
-    L.E_prev = total_energy(c, L.E, L.E_n, L.E_l);
+    if (c->reg_r != 0.f) { double er; if ((rc = albedo_reg_energy(c, &er))) return rc; L.E_r = (float)er; }   // PsOptimizer.cpp:279
+    L.E_prev = total_energy(c, L.E, L.E_n, L.E_l, L.E_r);
     return run_loop(c, flags, L, c->set.max_it, true, stats, stats_cap, n_done, result, on_iter, user);
 }
 

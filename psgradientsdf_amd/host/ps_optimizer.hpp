@@ -188,11 +188,11 @@ protected:
 
     // getTotalEnergy's log line, OptimizerAux.cpp:259-269
     void log_energy(double E, const psgsdf_iter_stats* r) {
-        double en = r->reg_weight_n * r->e_n, el = r->reg_weight_l * r->e_l;
+        double en = r->reg_weight_n * r->e_n, el = r->reg_weight_l * r->e_l, er = settings_->reg_weight_rho * r->e_r;
         for (std::ostream* o : {static_cast<std::ostream*>(&std::cout), static_cast<std::ostream*>(&doc_)})
             if (o == &std::cout || doc_.is_open())
-                *o << "PS energy: " << E << "\t normal reg energy: " << en << "\t laplacian reg energy: " << el << "\t rho reg energy: " << 0
-                   << "\t total energy: " << (float)(E + en + el) << std::endl;
+                *o << "PS energy: " << E << "\t normal reg energy: " << en << "\t laplacian reg energy: " << el << "\t rho reg energy: " << er
+                   << "\t total energy: " << (float)(E + en + el + er) << std::endl;
     }
     // the per-iteration narration of PsOptimizer.cpp:304-366 and the periodic dumps of :419-423
     int on_iter(int iter_done, const psgsdf_iter_stats* r) {

@@ -34,11 +34,11 @@ def test_bad_arguments_are_status_codes(built):
     lib = ctypes.CDLL(capi.ENGINE_LIB)
     lib.psgsdf_create.restype = ctypes.c_int
     assert lib.psgsdf_create(None, None, None, 0, None) == -1
-    st = capi.default_settings(capi.SH1, reg_weight_rho=1.0)
+    st = capi.default_settings(capi.SH1); st.model = 7
     g = capi.GridDesc(); g.dim[:] = [8, 8, 8]; g.voxel_size = 0.01
     K = (ctypes.c_float * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
     ctx = ctypes.c_void_p()
-    assert lib.psgsdf_create(ctypes.byref(g), K, ctypes.byref(st), 0, ctypes.byref(ctx)) == -3   # reg albedo unsupported
+    assert lib.psgsdf_create(ctypes.byref(g), K, ctypes.byref(st), 0, ctypes.byref(ctx)) == -1   # unknown model
 
 
 def test_no_cpu_fallback_without_library(monkeypatch, tmp_path):

@@ -253,3 +253,48 @@ def test_robust_losses():
         e0 = o.energy()[0]
         o.step(capi.ALBEDO); o.step(capi.LIGHT)
         assert np.isfinite(e0) and o.energy()[0] <= e0 * (1 + 1e-4)
+
+
+def test_albedo_reg_jacobian_numeric_and_energy():
+    """Optimizer.cpp:221-245: J[slot][ch] is the slope of ||grad rho_ch|| in the albedo of the voxel / of its stencil neighbours;
+    getAlbedoRegEnergy (Optimizer.cpp:122-136) is the band mean of the sum of the three norms."""
+    sc, o = make("SH1", N=24, F=4, reg_weight_rho=0.05)
+    o.init_albedo()
+    band = o.download_band()
+    rng = np.random.default_rng(3)
+    checked = 0
+    for j in rng.integers(len(band), size=60):
+        J, res, nb = o.probe_albedo_reg(int(j))
+        lin = int(band[j])
+        if res.min() < 0.2:           # the norm is not differentiable at 0 (and its curvature grows towards it)
+            continue
+        for slot, target in enumerate([lin] + nb):
+            if slot > 0 and target == lin:
+                continue
+            base = o.peek_rgb(target)
+            for ch in range(3):
+                h = 1e-4
+                v = base.copy(); v[ch] += h; o.poke_rgb(target, v); rp = o.probe_albedo_reg(int(j))[1][ch]
+                v = base.copy(); v[ch] -= h; o.poke_rgb(target, v); rm = o.probe_albedo_reg(int(j))[1][ch]
+                o.poke_rgb(target, base)
+                num = (rp - rm) / (2 * h)
+                assert abs(num - J[slot, ch]) <= 1e-2 * abs(J[slot, ch]) + 0.1, (j, slot, ch, num, J[slot, ch])
+                checked += 1
+    assert checked > 100
+    e = o.energy()
+    tot = sum(o.probe_albedo_reg(j)[1].sum() for j in range(len(band))) / len(band)
+    st = o._settings
+    # total = E + wn E_n + wl E_l + wr E_r (OptimizerAux.cpp:261)
+    assert abs(e[3] - (np.float32(e[0]) + np.float32(o.info().reg_weight_n) * np.float32(e[1]) + np.float32(o.info().reg_weight_l) * np.float32(e[2]) * (o.info().reg_weight_l != 0) + np.float32(0.05) * np.float32(tot))) <= 1e-4 * abs(e[3])
+
+
+def test_albedo_reg_step_descends_and_quirk_couples_green_blue():
+    """the regularised albedo step (PsOptimizer.cpp:85-121) lowers reg_rho*E_r + E; with ref_quirks the blue self-entry sits in the
+    green column (Optimizer.cpp:617), without it the three channels decouple"""
+    for quirks in (1, 0):
+        sc, o = make("SH1", N=24, F=4, reg_weight_rho=0.05, ref_quirks=quirks)
+        o.init_albedo(); o.normalize_weights()
+        e0 = o.energy()[3]
+        st = o.step(capi.ALBEDO)
+        assert st["cg_converged"] == 1 and st["cg_iters"] > 1 and st["applied"] == 1
+        assert o.energy()[3] < e0

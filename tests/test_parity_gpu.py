@@ -108,3 +108,32 @@ def test_upsample_and_optimize(built):
     assert np.array_equal(eng.download_band(), orc.download_band())
     for a, b in zip(re_, ro):
         assert abs(a["e_total"] - b["e_total"]) <= 1e-3 * abs(b["e_total"]), (a, b)
+
+
+@pytest.mark.parametrize("name,mid", [("SH1", capi.SH1), ("LED", capi.LED)])
+def test_albedo_regulariser(built, name, mid):
+    """"reg albedo" != 0 (Optimizer.cpp:221-245,593-647): energy, regularised albedo step (matrix-free CG on the engine, assembled
+    sparse system in the oracle) and two full iterations"""
+    from oracle import oracle
+    sc = synth.make_scene(N=40, F=6, W=160, H=120, model=name)
+    st = capi.default_settings(mid, reg_weight_rho=0.02)
+    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=4)
+    for api in (eng, orc):
+        api.load_scene(sc); api.init_albedo()
+    ee, eo = eng.energy(), orc.energy()
+    assert abs(ee[3] - eo[3]) <= 2e-5 * abs(eo[3])
+    for api in (eng, orc):
+        api.normalize_weights()
+    band = eng.download_band()
+    if mid == capi.LED:
+        eng.step(capi.LIGHT); orc.step(capi.LIGHT)
+    se, so = eng.step(capi.ALBEDO), orc.step(capi.ALBEDO)
+    assert so["cg_iters"] > 1 and abs(se["cg_iters"] - so["cg_iters"]) <= 1 and se["cg_converged"] == so["cg_converged"] == 1
+    ve, vo = eng.download_volume(), orc.download_volume()
+    assert np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max() <= 1e-4
+    re_, ro = eng.iterate(capi.ALL, 2), orc.iterate(capi.ALL, 2)
+    for a, b in zip(re_, ro):
+        assert abs(a["e_r"] - b["e_r"]) <= 2e-4 * abs(b["e_r"]) and b["e_r"] > 0
+        assert abs(a["e_total"] - b["e_total"]) <= 2e-4 * abs(b["e_total"])
+    ve, vo = eng.download_volume(), orc.download_volume()
+    assert np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max() <= 2e-4
