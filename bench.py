@@ -168,6 +168,8 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live with HIP events inside the timed region
         lap = st.reg_weight_l != 0.0
+        # event pairs recorded on the launch stream around every 8th launch: the pair also reads the dispatch latency, so this is
+        # ~2.5 us above the kernel duration rocprofv3 --kernel-trace reports (profiles/): the roofline fraction errs low
         avg_ms = watched[0] / max(watched[1], 1) if watched[1] else float("nan")
         nbytes = algorithmic_bytes(dom, S, n_obs, args.width, args.height, args.frames, lap)   # per GPU (one slab)
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
@@ -180,7 +182,8 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms,
-                           "launches_timed": int(watched[1])}
+                           "launches_timed": int(watched[1]),
+                           "traffic_source": "profiles/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 (gfx950), KiB -> bytes" if traffic else None}
         # whole-iteration algorithmic bytes (SURVEY.md §8d formula) for reference
         U = min(48 * n_obs, 12 * args.width * args.height * args.frames)
         B_iter = 4 * (S * 60 + U) + 120 * S + 124 * cg_iters * S   # SURVEY §8d per-pass figure kept (the fused pass moves 144 B/row)
