@@ -170,13 +170,16 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
             continue
         dd = d[idx]
         s = t0[idx].copy()
-        alive = np.ones(len(s), bool)
+        smax = t0[idx] + 4 * (R0 + 2 * A)
+        act = np.arange(len(s))                           # rays still marching: converged / escaped ones drop out
         for _ in range(60):
-            x = t + dd * s[:, None]
+            x = t + dd[act] * s[act, None]
             fv, gv = fmin(x)
             step = fv / np.linalg.norm(gv, axis=-1)
-            s = s + np.where(alive, 0.9 * step, 0)
-            alive &= s < t0[idx] + 4 * (R0 + 2 * A)
+            s[act] += 0.9 * step
+            act = act[(np.abs(step) > 1e-14 * extent) & (s[act] < smax[act])]
+            if len(act) == 0:
+                break
         x = t + dd * s[:, None]
         fv, gv = fmin(x)
         good = np.abs(fv) < 1e-6 * extent + 1e-9
@@ -213,10 +216,20 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         k1 = min(N * z_mult, k0 + chunk)
         Z, Y, X = np.meshgrid(kk[k0:k1], ii, ii, indexing="ij")
         x = origin + vs * np.stack([X, Y, Z], -1).reshape(-1, 3)
-        fv, gv = fmin(x)
-        gn = np.linalg.norm(gv, axis=-1)
-        d = fv / gn
-        nrm = gv / gn[:, None]
+        # far from every blob the clipped distance is +-T whatever the bumps do: skip the trigonometry there
+        # (|f| >= ||x-c|-R0| - A, and d = f / |grad f| with the bound gmax below)
+        rr = np.stack([np.linalg.norm(x - c, axis=-1) for c in centres], 0)
+        sin_t = np.stack([np.hypot(x[:, 0] - c[0], x[:, 1] - c[1]) for c in centres], 0) / np.maximum(rr, 1e-12)
+        gmax = 1.0 + 8.0 * A / np.maximum(rr, 1e-12) * (1.0 + 1.0 / np.maximum(sin_t, 1e-6))     # >= |grad f| (the phi term blows up at the poles)
+        rc = rr - R0
+        cand = np.nonzero(((np.abs(rc) - A) <= 1.05 * T * gmax).any(0))[0]
+        d = np.where(rc.min(0) < 0, -2.0 * T, 2.0 * T)
+        nrm = np.zeros((len(x), 3))
+        if len(cand):
+            fv, gv = fmin(x[cand])
+            gn = np.linalg.norm(gv, axis=-1)
+            d[cand] = fv / gn
+            nrm[cand] = gv / gn[:, None]
         sl = slice(k0 * plane, k1 * plane)
         near = np.abs(d) < T
         dn = np.clip(d, -T, T)
