@@ -1,0 +1,53 @@
+"""The engine's latency tricks must not change results: PCG stop test by watching the mapped mailbox vs draining the stream
+(PSGSDF_PCG_POLL), scalar folds done by the next kernel vs by a kernel of their own (PSGSDF_FOLD_IN_NEXT), launch shape of the
+fused PCG pass (PSGSDF_PCG_ROWS / PSGSDF_PCG_BLOCKS).  Each variant runs in its own process (the knobs are read at create time)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+from psgradientsdf_amd import capi, synth
+sc = synth.make_scene(N=64, F=8, W=160, H=120, model=sys.argv[1])
+st = capi.default_settings(sc.model_id)
+eng = capi.load_engine(sc, sc.K, st, 0); eng.load_scene(sc); eng.init_albedo(); eng.normalize_weights()
+recs = eng.iterate(capi.ALL, 3)
+recs2, conv = eng.optimize(capi.ALL) if len(sys.argv) > 2 else ([], False)
+v = eng.download_volume(); band = eng.download_band()
+print(json.dumps(dict(e=[r["e_total"] for r in recs], after=[r["e_after"] for r in recs], cg=[r["cg_iters"] for r in recs],
+                      n2=len(recs2), e2=[r["e_total"] for r in recs2],
+                      dsum=float(np.abs(v["dist"][band]).astype(np.float64).sum()), rsum=float(v["rgb"][:, band].astype(np.float64).sum()),
+                      psum=float(np.abs(eng.download_poses()).astype(np.float64).sum()))))
+""" % ROOT
+
+
+def run(model, env, full=False):
+    e = dict(os.environ); e.update(env)
+    out = subprocess.run([sys.executable, "-c", WORKER, model] + (["full"] if full else []), capture_output=True, text=True, env=e, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("model", ["SH1", "LED"])
+def test_host_side_knobs_are_bitwise_neutral(built, model):
+    ref = run(model, {}, full=True)
+    for env in ({"PSGSDF_PCG_POLL": "0"}, {"PSGSDF_FOLD_IN_NEXT": "0"}, {"PSGSDF_PCG_POLL": "0", "PSGSDF_FOLD_IN_NEXT": "0"}):
+        got = run(model, env, full=True)
+        assert got == ref, (env, got, ref)
+
+
+def test_pcg_launch_shape_only_changes_rounding(built):
+    ref = run("SH1", {})
+    for env in ({"PSGSDF_PCG_ROWS": "3", "PSGSDF_PCG_BLOCKS": "7"}, {"PSGSDF_PCG_ROWS": "1", "PSGSDF_PCG_BLOCKS": "5"}, {"PSGSDF_PCG_ROWS": "3", "PSGSDF_PCG_BLOCKS": "512"}):
+        got = run("SH1", env)
+        assert all(abs(a - b) <= 1 for a, b in zip(got["cg"], ref["cg"]))
+        assert all(abs(a - b) <= 2e-5 * abs(b) for a, b in zip(got["e"], ref["e"])), (env, got["e"], ref["e"])
+        assert abs(got["dsum"] - ref["dsum"]) <= 1e-5 * ref["dsum"]

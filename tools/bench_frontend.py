@@ -19,14 +19,15 @@ for f in range(F):
     eng.track(sc.depth[f], sc.poses_gt[f], num_iterations=3)
 kt = eng.kernel_times()
 nvox = N ** 3
-# algorithmic bytes of one fusion sweep: 8 float planes + 1 visibility word read (40 B) per voxel; written back only where the
-# frame sees the voxel (counted from the result)
-vol = eng.download_volume()
-touched = int((vol["weight"] > 0).sum())
-out = {"grid": N, "image": [W, H]}
+# algorithmic bytes of one fusion sweep: every voxel is projected (no memory) and taps the depth image once if it lands in it
+# (4 B, upper bound: all voxels); only voxels inside the frame's truncation band touch their record: 8 float planes + one
+# visibility word read and written back (2 x 40 B).  The number of voxels a frame updates is counted from the visibility bits.
+vis = eng.download_vis_seq((F + 63) // 64)     # sequence-indexed visibility bits written by the fusion
+per_frame = float(sum(int(np.unpackbits(np.ascontiguousarray(vis[:, w]).view(np.uint8)).sum()) for w in range(vis.shape[1]))) / F   # (re-integrating a frame sets the same bit)
+out = {"grid": N, "image": [W, H], "voxels_updated_per_frame": per_frame}
 for k, (ms, n) in kt.items():
     out[k] = {"avg_ms": ms / n, "launches": n}
-b = 40 * nvox + 40 * touched / 1.0
+b = 4.0 * nvox + 80.0 * per_frame
 t = kt["integrate_frame"][0] / kt["integrate_frame"][1] * 1e-3
 out["integrate_frame"]["algorithmic_bytes"] = b
 out["integrate_frame"]["GBs"] = b / t / 1e9
