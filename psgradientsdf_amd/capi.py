@@ -320,6 +320,11 @@ class Api:
                                                      st.ctypes.data_as(C.c_void_p) if stamps else None), "debug_time_pcg_pass")
         return (ms.value, st) if stamps else ms.value
 
+    def debug_rare_rows(self):
+        r = C.c_int64(); w = C.c_int64()
+        self._check(self._fn("debug_rare_rows")(self.ctx, C.byref(r), C.byref(w)), "debug_rare_rows")
+        return r.value, w.value
+
     def debug_frame_system(self, block):
         i = self.info()
         if block == LIGHT:

@@ -367,16 +367,16 @@ int ps_energy(psgsdf_ctx* c, double* E, int64_t* nobs) {
     return 0;
 }
 
-// Launch shape of the fused PCG pass.  The pass is one memory round-trip chain per workgroup (coefficients + column
-// indices -> records -> reduction), so the fastest shape keeps EVERY row's loads in flight in ONE generation of resident
-// workgroups: 1 row per thread while 768 workgroups cover the band (4 waves/SIMD resident), else 3 rows per thread in
-// <= 512 workgroups (256 VGPRs, 2 waves/SIMD resident); bigger bands take several trips of that shape.
-// Measured on the 256^3 band (1317 row-blocks): 3 rows x 439 workgroups 17.4 us, 1 row x 659 x 2 trips 18.0 us,
-// 2 rows x 659 (two generations) 19.6 us  (tools/pcg_ablate.py, profiles/r01_notes.md).
+// Launch shape of the fused PCG pass.  The pass is a chain of memory round trips per workgroup (coefficients + column
+// indices -> two batches of record gathers, the second overlapping the reduction), so what matters is how many rows have
+// their loads in flight at once.  One row per thread at 114 VGPRs keeps 4 waves per SIMD resident (1024 workgroups); the
+// reduction of the previous pass's partials costs every workgroup G x 7 doubles, which caps G at 768.  Measured on the
+// 256^3 band (1317 row-blocks): 659 workgroups x 2 trips 17.3 us, 768 x 2 trips 18.1 us, 512 x 3 trips 18.8 us
+// (tools/pcg_ablate.py, profiles/r01_notes.md).
 static void cgf_shape(int nblk, int* G, int* rows) {
     nblk = std::max(1, nblk);
-    int r = nblk <= kCgfMaxBlocks ? 1 : 3, cap = r == 1 ? kCgfMaxBlocks : 512;
-    if (const char* e = getenv("PSGSDF_PCG_ROWS")) { int v = atoi(e); if (v == 1 || v == 3) r = v; }       // tuning knobs
+    int r = 1, cap = kCgfMaxBlocks;
+    if (const char* e = getenv("PSGSDF_PCG_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 2) r = v; }       // tuning knobs
     if (const char* e = getenv("PSGSDF_PCG_BLOCKS")) { int v = atoi(e); if (v > 0 && v <= kCgfMaxBlocks) cap = v; }
     const int per = (nblk + r - 1) / r;                 // workgroups if every thread took r rows once
     const int trips = (per + cap - 1) / cap;
@@ -1396,6 +1396,22 @@ int psgsdf_debug_time_pcg_pass(psgsdf_ctx* c, int blocks, int rows, int ablate, 
     if (stamps) {   // [G][8] wall-clock ticks (100 MHz) of the LAST launch, taken with ablate | 1024
         HIPCHK(c, hipMemcpy(stamps, c->pcg_sc + 16, sizeof(long long) * 8 * G, hipMemcpyDeviceToHost));
     }
+    return PSGSDF_OK;
+}
+
+// how many rows of the assembled distance system carry any of the 6 "rare" ELL columns, and how many 64-row groups
+// (wavefronts of a one-row-per-thread launch) contain such a row
+int psgsdf_debug_rare_rows(psgsdf_ctx* c, int64_t* rows, int64_t* waves) {
+    if (!c || !c->inited || !rows || !waves) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SweepArgs a = make_args(c, c->reg_l != 0.f);
+    launch_sweep_dist(a, c->stream);
+    launch_assemble(a, c->stream);
+    std::vector<int> hx(c->band.S);
+    HIPCHK(c, hipMemcpyAsync(hx.data(), c->band.hx, sizeof(int) * hx.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *rows = 0; *waves = 0;
+    for (size_t i = 0; i < hx.size(); i += 64) { bool any = false; for (size_t k = i; k < std::min(hx.size(), i + 64); ++k) if (hx[k]) { ++*rows; any = true; } *waves += any; }
     return PSGSDF_OK;
 }
 

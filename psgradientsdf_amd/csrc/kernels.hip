@@ -1753,22 +1753,24 @@ __device__ __forceinline__ double* fpart(double* part, int k, int kind) { return
 
 // n sums at once, identical in every thread of every workgroup.  All loads of a thread are issued before the first use
 // (fixed trip count, predicated): ONE memory round trip however many partials there are -- a dynamic-trip loop made it three.
+template <int N> struct PartLoads { double ld[kCgfMaxBlocks / kBlock][N]; };
 template <int N>
-__device__ __forceinline__ void block_total_n(double* const* src, int n, double* red /*[N * kBlock/64]*/, double* out) {
-    constexpr int T = kCgfMaxBlocks / kBlock;
-    double ld[T][N];
+__device__ __forceinline__ void block_total_issue(double* const* src, int n, PartLoads<N>& pl) {
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
+    for (int j = 0; j < kCgfMaxBlocks / kBlock; ++j) {
         const int i = threadIdx.x + j * kBlock;
 #pragma unroll
-        for (int q = 0; q < N; ++q) ld[j][q] = i < n ? src[q][i] : 0.0;
+        for (int q = 0; q < N; ++q) pl.ld[j][q] = i < n ? src[q][i] : 0.0;
     }
+}
+template <int N>
+__device__ __forceinline__ void block_total_finish(const PartLoads<N>& pl, double* red /*[N * kBlock/64]*/, double* out) {
     double v[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) {
-        v[q] = ld[0][q];
+        v[q] = pl.ld[0][q];
 #pragma unroll
-        for (int j = 1; j < T; ++j) v[q] += ld[j][q];
+        for (int j = 1; j < kCgfMaxBlocks / kBlock; ++j) v[q] += pl.ld[j][q];
         v[q] = wave_sum(v[q]);
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1785,6 +1787,12 @@ __device__ __forceinline__ void block_total_n(double* const* src, int n, double*
         for (int i = 0; i < kBlock / 64; ++i) s += red[q * (kBlock / 64) + i];
         out[q] = s;
     }
+}
+template <int N>
+__device__ __forceinline__ void block_total_n(double* const* src, int n, double* red /*[N * kBlock/64]*/, double* out) {
+    PartLoads<N> pl;
+    block_total_issue<N>(src, n, pl);
+    block_total_finish<N>(pl, red, out);
 }
 template <int N>
 __device__ __forceinline__ void block_part_store_n(const double* vin, double* const* dst, double* red) {
@@ -1825,23 +1833,83 @@ void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStr
     if (a.row1 > a.row0) hipLaunchKernelGGL(k_cgf_init, dim3(G), dim3(kBlock), 0, s, a, fs, part);
 }
 // kernel k: finishes pass k-1 (k > 0), decides convergence, then runs pass k unless k == kmax (the iteration cap).
-// The pass is latency-bound (column index -> 16-byte gather -> 13 fused multiply-adds), so each thread keeps the loads of
-// kCgfRows rows in flight at once and the raw records of the first group are requested BEFORE the partial sums of the
-// previous pass are reduced (the records do not depend on alpha / beta; only the arithmetic on them does).
-struct CgfRow { float h[kNQCommon]; int c[kNQCommon]; float4 o[kNQCommon]; float x; int i, hx; bool live; };
-// phase 1: everything addressed by the row itself; phase 2: the records addressed by the column indices of phase 1.
-// The caller runs phase 1 of ALL its rows before phase 2 of any, so that a thread waits for two round trips, not 2 x rows.
-__device__ __forceinline__ void cgf_load1(const Band& b, int i, int row1, CgfRow& w, int ab) {
-    w.i = i; w.live = i < row1;
-    const int ii = w.live ? i : row1 - 1;
+//
+// The pass is a chain of memory round trips (column indices -> 16-byte record gathers -> reduction of the previous pass's
+// partials), not a bandwidth problem, so the kernel is arranged to need nothing from the reduction until the very end:
+// t = A p_k with p_k[c] = inv_c (r_c - alpha t_c) + beta p_c is LINEAR in the three gathered fields,
+//     t = A1 - alpha A2 + beta A3,   A1 = sum_c h_c inv_c r_c,  A2 = sum_c h_c inv_c t_c,  A3 = sum_c h_c p_c   (double),
+// so the three sums are accumulated as the gathers arrive, before alpha and beta exist, and the records never have to be
+// kept in registers.  (p_k of a NEIGHBOUR is therefore not rounded to float before it enters the product, unlike Eigen's
+// explicit vector; the row's own r, z, p, x are updated in float exactly as the reference does.  DESIGN.md §2, deviation 3.)
+// All 19 ELL columns are treated alike: at the band sizes of this path 61 % of the rows and every wavefront use the 6
+// columns that only backward-forced stencils produce.
+struct CgfRow { double A1, A2, A3; float4 me; float x; int i; bool live; };
+// The gathers of a thread's rows are issued in two batches (10 + 9 columns): all 57 records of 3 rows at once would need
+// 228 registers.  The second batch is in flight
+// while the caller reduces the previous pass's partials; cgf_rows_finish folds it in afterwards.
+constexpr int kCgfB1 = 10;   // columns of the first gather batch (the split is about registers, not about which columns are common)
+template <int R> struct CgfPending { float h[R][kNQ - kCgfB1]; float4 o[R][kNQ - kCgfB1]; };
+// The streamed loads go through buffer instructions (scalar resource + ONE 32-bit lane offset per row, the plane offset
+// q * Spad in the scalar offset operand): with flat 64-bit addresses the 38 streamed loads of a row cost two address
+// registers each and the kernel spilled.
+// (The record gathers stay flat loads: this compiler narrows `raw.ptr.buffer.load.v4i32` to a one-dword load.)
+template <int R>
+__device__ __forceinline__ void cgf_rows(const Band& b, const float4* __restrict__ rin, int i0, int stride, int row1, float damping, CgfRow* w, CgfPending<R>& pend, int ab) {
+    const int plane = b.Spad * 4;              // bytes of one ELL column plane
+    const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)b.H, 0, kNQ * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)b.col, 0, kNQ * plane, 0x00020000);
+    float h[R][kNQ]; int c[R][kNQ];
+    // round trip 1: everything addressed by the rows themselves, for ALL rows of the thread
 #pragma unroll
-    for (int q = 0; q < kNQCommon; ++q) { w.h[q] = (ab & 8) ? 1.0f : b.H[(size_t)q * b.Spad + ii]; w.c[q] = (q == 0 || (ab & 2)) ? ii : b.col[(size_t)q * b.Spad + ii]; }
-    w.hx = (ab & 128) ? 0 : b.hx[ii]; w.x = b.x[ii];
+    for (int u = 0; u < R; ++u) {
+        const int i = i0 + u * stride;
+        w[u].i = i; w[u].live = i < row1;
+        const int ii = w[u].live ? i : row1 - 1;
+#pragma unroll
+        for (int q = 0; q < kNQ; ++q) {
+            h[u][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rH, ii * 4, q * plane, 0));
+            c[u][q] = q == 0 ? ii : (int)__builtin_amdgcn_raw_buffer_load_b32(rC, ii * 4, q * plane, 0);
+        }
+        w[u].x = b.x[ii];
+    }
+    // round trip 2: the records of the first batch of columns of every row, folded into the three sums as they arrive
+    float4 o[R][kCgfB1];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+#pragma unroll
+        for (int q = 0; q < kCgfB1; ++q) o[u][q] = rin[c[u][q]];
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        if (damping != 0.0f) h[u][0] += damping * h[u][0];
+        double A1 = 0, A2 = 0, A3 = 0;
+#pragma unroll
+        for (int q = 0; q < kCgfB1; ++q) {
+            const double hq = (double)h[u][q], iv = (double)o[u][q].w;
+            A1 += hq * (iv * (double)o[u][q].x); A2 += hq * (iv * (double)o[u][q].y); A3 += hq * (double)o[u][q].z;
+        }
+        w[u].A1 = A1; w[u].A2 = A2; w[u].A3 = A3; w[u].me = o[u][0];
+    }
+    __builtin_amdgcn_sched_barrier(0);        // keep the second batch behind the first one's consumption (register budget)
+    // round trip 3 (overlaps the caller's reduction): the remaining columns
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+#pragma unroll
+        for (int q = kCgfB1; q < kNQ; ++q) { pend.h[u][q - kCgfB1] = h[u][q]; pend.o[u][q - kCgfB1] = rin[c[u][q]]; }
+    }
 }
-__device__ __forceinline__ void cgf_load2(const float4* __restrict__ rin, float damping, CgfRow& w) {
+template <int R>
+__device__ __forceinline__ void cgf_rows_finish(CgfRow* w, const CgfPending<R>& pend) {
 #pragma unroll
-    for (int q = 0; q < kNQCommon; ++q) w.o[q] = rin[w.c[q]];
-    if (damping != 0.0f) w.h[0] += damping * w.h[0];
+    for (int u = 0; u < R; ++u) {
+        double A1 = w[u].A1, A2 = w[u].A2, A3 = w[u].A3;
+#pragma unroll
+        for (int q = 0; q < kNQ - kCgfB1; ++q) {
+            const double hq = (double)pend.h[u][q], iv = (double)pend.o[u][q].w;
+            A1 += hq * (iv * (double)pend.o[u][q].x); A2 += hq * (iv * (double)pend.o[u][q].y); A3 += hq * (double)pend.o[u][q].z;
+        }
+        w[u].A1 = A1; w[u].A2 = A2; w[u].A3 = A3;
+    }
 }
 template <int kCgfRows, int kMinWaves>
 __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, double* fs, double* part, int k, int kmax, double* mb, int ab) {   // ab: timing ablations (tools/), 0 in production
@@ -1854,21 +1922,19 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
     float4* __restrict__ rout = b.rec[k & 1];
     const int stride = gridDim.x * blockDim.x;
     int i0 = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
-    CgfRow w[kCgfRows];
+    CgfRow w[kCgfRows]; CgfPending<kCgfRows> pend;
     const double stopped = fs[1];
-#pragma unroll
-    for (int u = 0; u < kCgfRows; ++u) cgf_load1(b, i0 + u * stride, a.row1, w[u], ab);
-#pragma unroll
-    for (int u = 0; u < kCgfRows; ++u) cgf_load2(rin, a.damping, w[u]);
+    cgf_rows<kCgfRows>(b, rin, i0, stride, a.row1, a.damping, w, pend, ab);
 
     CGF_STAMP(1);
     float alpha_prev = 0.f, beta = 0.f, rr_cur, rhsNorm2;
-    if (ab & 1) { alpha_prev = 0.01f; beta = 0.5f; rr_cur = 1.f; rhsNorm2 = 1.f; }
+    if (ab & 1) { alpha_prev = 0.01f; beta = 0.5f; rr_cur = 1.f; rhsNorm2 = 1.f; cgf_rows_finish<kCgfRows>(w, pend); }
     else if (!(ab & 16) && stopped != 0.0 && stopped <= (double)k) return;   // stopped by an EARLIER kernel of this solve (kernel j writes j + 1)
     else if (k == 0) {
         double bb;
         if (a.ext) bb = a.ext[0];
         else { double* src[1] = {fpart(part, -1, 6)}; block_total_n<1>(src, gridDim.x, red, &bb); }
+        cgf_rows_finish<kCgfRows>(w, pend);
         rhsNorm2 = (float)bb; rr_cur = rhsNorm2;
         if (blockIdx.x == 0 && threadIdx.x == 0) { fs[0] = bb; mb[0] = bb; __threadfence_system(); }   // mb may be host-mapped: the host watches it
     } else {
@@ -1878,7 +1944,13 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
         if (a.ext) {
 #pragma unroll
             for (int q = 0; q < kCgfSums; ++q) t[q] = a.ext[q];
-        } else block_total_n<kCgfSums>(src, gridDim.x, red, t);
+            cgf_rows_finish<kCgfRows>(w, pend);
+        } else {   // the partial sums of the previous pass are requested while the second gather batch is still in flight
+            PartLoads<kCgfSums> pl;
+            block_total_issue<kCgfSums>(src, gridDim.x, pl);
+            cgf_rows_finish<kCgfRows>(w, pend);
+            block_total_finish<kCgfSums>(pl, red, t);
+        }
         rhsNorm2 = (float)fs[0];
         const float rz_old = (float)t[5];
         alpha_prev = rz_old / (float)t[0];                // alpha = absNew / p.dot(tmp)
@@ -1899,44 +1971,23 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
 #pragma unroll
         for (int u = 0; u < kCgfRows; ++u) {
             const CgfRow& r = w[u];
-            const float4 me = r.o[0];
+            const float4 me = r.me;
             // finish pass k-1 for the own row: x += alpha p ; residual -= alpha tmp
             if (r.live && k > 0 && !(ab & 32)) b.x[r.i] = r.x + alpha_prev * me.z;
-            if (stop) continue;
+            if (stop || !r.live) continue;
             const float r_i = me.x - alpha_prev * me.y;
             const float z_i = me.w * r_i;
             const float p_i = z_i + beta * me.z;
-            double acc = (double)r.h[0] * (double)p_i;
-#pragma unroll
-            for (int q = 1; q < kNQCommon; ++q) {
-                const float4 o = r.o[q];
-                const float rc = o.x - alpha_prev * o.y;
-                acc += (double)r.h[q] * (double)(o.w * rc + beta * o.z);
-            }
-            const int ii = r.live ? r.i : a.row1 - 1;
-            if (__any(r.live && r.hx)) {                   // the 6 rare columns: wave-uniform skip
-#pragma unroll
-                for (int q = kNQCommon; q < kNQ; ++q) {
-                    const float hq = b.H[(size_t)q * b.Spad + ii];
-                    const float4 o = rin[b.col[(size_t)q * b.Spad + ii]];
-                    const float rc = o.x - alpha_prev * o.y;
-                    acc += (double)hq * (double)(o.w * rc + beta * o.z);
-                }
-            }
-            if (r.live) {
-                const float t = (float)acc;
-                if (!(ab & 64)) rout[r.i] = make_float4(r_i, t, p_i, me.w);
-                const double rd = (double)r_i, td = (double)t, iv = (double)me.w;
-                s[0] += (double)p_i * td; s[1] += iv * rd * td; s[2] += iv * td * td; s[3] += rd * td; s[4] += td * td;
-                s[5] += rd * (double)z_i; s[6] += rd * rd;
-            }
+            const float t = (float)(r.A1 - (double)alpha_prev * r.A2 + (double)beta * r.A3);
+            if (!(ab & 64)) rout[r.i] = make_float4(r_i, t, p_i, me.w);
+            const double rd = (double)r_i, td = (double)t, iv = (double)me.w;
+            s[0] += (double)p_i * td; s[1] += iv * rd * td; s[2] += iv * td * td; s[3] += rd * td; s[4] += td * td;
+            s[5] += rd * (double)z_i; s[6] += rd * rd;
         }
         i0 += kCgfRows * stride;
         if (i0 - (int)threadIdx.x >= a.row1) break;          // workgroup-uniform
-#pragma unroll
-        for (int u = 0; u < kCgfRows; ++u) cgf_load1(b, i0 + u * stride, a.row1, w[u], ab);
-#pragma unroll
-        for (int u = 0; u < kCgfRows; ++u) cgf_load2(rin, a.damping, w[u]);
+        cgf_rows<kCgfRows>(b, rin, i0, stride, a.row1, a.damping, w, pend, ab);
+        cgf_rows_finish<kCgfRows>(w, pend);
     }
     CGF_STAMP(3);
     if (stop || (ab & 4)) return;
@@ -1949,8 +2000,10 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
 }
 void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int rows, int k, int kmax, double* mb, hipStream_t s, int ablate) {
     if (a.row1 <= a.row0) return;
-    // rows per thread kept in flight at once <-> registers <-> resident workgroups per CU (launch bound = waves per SIMD)
-    if (rows >= 3) hipLaunchKernelGGL((k_cgf_pass<3, 2>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
+    // rows per thread in flight at once <-> registers <-> resident workgroups per CU (launch bound = waves per SIMD).
+    // One row per thread (114 VGPRs, 4 waves per SIMD) is the production shape; two rows spill at 3 waves per SIMD and are
+    // kept for the timing tool only.
+    if (rows >= 2) hipLaunchKernelGGL((k_cgf_pass<2, 2>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
     else hipLaunchKernelGGL((k_cgf_pass<1, 4>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
 }
 

@@ -23,7 +23,7 @@ def test_oracle_mirrors_the_abi(built):
     from oracle import oracle
     lib = oracle.lib()
     skip = {"psgsdf_comm_init", "psgsdf_comm_unique_id", "psgsdf_kernel_times", "psgsdf_reset_kernel_times",
-            "psgsdf_set_profiling", "psgsdf_watch_kernel", "psgsdf_debug_time_pcg_pass"}
+            "psgsdf_set_profiling", "psgsdf_watch_kernel", "psgsdf_debug_time_pcg_pass", "psgsdf_debug_rare_rows"}
     for n in g._declared_symbols():
         if n in skip:
             continue

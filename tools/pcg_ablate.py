@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the fused PCG pass (k_cgf_pass) on the bench scene: grid x rows-in-flight sweep, ablations, stage timeline.
-ablation bits: 1 no reduction of the previous pass's partials, 2 gathers hit the own row (no column loads), 4 no partial
-store, 8 no coefficient loads, 32 no x update, 64 no record store, 128 no rare-column check."""
+ablation bits: 1 no reduction of the previous pass's partials, 4 no partial store, 32 no x update, 64 no record store."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,17 +14,19 @@ eng.iterate(capi.ALL, 2)
 S = eng.info().n_band
 nb = (S + 255) // 256
 print("band", S, "one-row grid", nb)
-for rows in (1, 2, 3):
+rr, rw = eng.debug_rare_rows()
+print(f"rows with rare columns: {rr} ({100.0 * rr / S:.1f} %), 64-row groups containing one: {rw} ({100.0 * rw / ((S + 63) // 64):.1f} %)")
+for rows in (1, 2):
     g1 = (nb + rows - 1) // rows
     for blocks in sorted({min(768, g1), min(768, (g1 + 1) // 2), 512, 768}):
         ms, stp = eng.debug_time_pcg_pass(blocks, rows, 0, 100, stamps=True)
         print(f"rows {rows} blocks {blocks}: {ms * 1e3:.2f} us   entry spread {(stp[:, 6].max() - stp[:, 6].min()) * 0.01:.2f} us")
-for rows, blocks in ((2, (nb + 1) // 2), (3, (nb + 2) // 3)):
-    print("rows", rows, "blocks", blocks, " ".join(f"ab{ab}={1e3 * eng.debug_time_pcg_pass(blocks, rows, ab, 100):.2f}us" for ab in (0, 1, 2, 4, 8, 32, 64, 128, 1 | 4, 2 | 8, 1 | 2 | 4 | 8 | 32 | 64 | 128)))
+for rows, blocks in ((1, (nb + 1) // 2), (2, (nb + 3) // 4)):
+    print("rows", rows, "blocks", blocks, " ".join(f"ab{ab}={1e3 * eng.debug_time_pcg_pass(blocks, rows, ab, 100):.2f}us" for ab in (0, 1, 4, 32, 64, 1 | 4, 1 | 4 | 32 | 64)))
     ms, stp = eng.debug_time_pcg_pass(blocks, rows, 0, 20, stamps=True)
     wall = (stp[:, 7] - stp[:, 6]) * 0.01; cyc = stp[:, 4] - stp[:, 0]
     mhz = np.median(cyc / np.maximum(wall, 1e-9))
     print(f"  launch avg {ms * 1e3:.2f} us; shader clock ~{mhz:.0f} ticks/us; first entry -> last exit {(stp[:, 7].max() - stp[:, 6].min()) * 0.01:.2f} us; entry spread {(stp[:, 6].max() - stp[:, 6].min()) * 0.01:.2f} us")
     d = np.diff(stp[:, :5], axis=1) / mhz
-    for j, name in enumerate(["issue row loads", "wait + reduce previous pass", "rows (wait gathers, fma, stores)", "partial store"]):
+    for j, name in enumerate(["issue loads, fold first batch", "wait + reduce previous pass", "fold second batch, rows, stores", "partial store"]):
         print(f"  {name:34s} median {np.median(d[:, j]):6.2f} us   max {d[:, j].max():6.2f} us")
