@@ -102,6 +102,7 @@ struct SweepArgs {
     Band b;
     const FrameP* frames;     // [F]
     const float* img;         // [F][H][W][3]
+    bool img32;               // the image stack is < 4 GiB: tap offsets fit 32 bits (kernels.hip: sample)
     int F;
     Cam cam;
     GridP grid;

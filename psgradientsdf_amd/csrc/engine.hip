@@ -131,6 +131,7 @@ template <class Fn> void timed(psgsdf_ctx* c, const char* name, Fn&& fn) {
 SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     SweepArgs a{};
     a.b = c->band; a.frames = c->frames; a.img = c->img; a.F = c->F; a.cam = c->cam; a.grid = c->grid;
+    a.img32 = (size_t)c->F * c->cam.W * c->cam.H * 12 < ((size_t)1 << 32);
     a.rob.loss = c->set.loss; a.rob.lambda = c->set.lambda; a.rob.lambda_sq = c->set.lambda * c->set.lambda; a.rob.inv_lambda = 1.0f / c->set.lambda;
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
     a.fold.n = 0;

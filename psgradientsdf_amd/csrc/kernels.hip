@@ -165,15 +165,28 @@ __device__ __forceinline__ const float* pix(const float* img, const Cam& cam, in
 
 // Auxilary.h:41-61 interpolateImage + Auxilary.h:64-123 computeImageGradient from one set of taps.
 // (row coordinate n_row, column coordinate m_col); gu = d/d(col), gv = d/d(row).
+// `base` is wave-uniform (the image stack, or one frame of it), `frame` selects the image inside it (0 for a frame pointer).
+// idx32: the whole stack is < 4 GiB, so a tap's byte offset fits 32 bits and the loads take the scalar-base form (one address
+// register, no 64-bit integer multiply-adds, which issue at quarter rate and made up ~10 % of a sweep's instruction slots).
 template <bool GRAD>
-__device__ __forceinline__ void sample(const float* img, const Cam& cam, float m_col, float n_row, float* I, float* gu, float* gv) {
+__device__ __forceinline__ void sample(const float* base, int frame, bool idx32, const Cam& cam, float m_col, float n_row, float* I, float* gu, float* gv) {
     const float m = n_row, n = m_col;  // names of Auxilary.h: m = row, n = column
     int x = (int)floorf(m), y = (int)floorf(n);
+    const float* img = base + (size_t)frame * cam.H * cam.W * 3;   // only the rare border path below uses it
     if ((x + 1) < cam.H && (y + 1) < cam.W) {
-        const float* p00 = img + ((size_t)x * cam.W + y) * 3;
-        const float* p10 = p00 + (size_t)cam.W * 3;
-        float a00[3] = {p00[0], p00[1], p00[2]}, a01[3] = {p00[3], p00[4], p00[5]};
-        float a10[3] = {p10[0], p10[1], p10[2]}, a11[3] = {p10[3], p10[4], p10[5]};
+        float a00[3], a01[3], a10[3], a11[3];
+        if (idx32) {
+            const unsigned e = (((unsigned)frame * (unsigned)cam.H + (unsigned)x) * (unsigned)cam.W + (unsigned)y) * 3u;
+            const float* p00 = (const float*)((const char*)base + (size_t)(e << 2));
+            const float* p10 = (const float*)((const char*)base + (size_t)((e + 3u * (unsigned)cam.W) << 2));
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { a00[ch] = p00[ch]; a01[ch] = p00[3 + ch]; a10[ch] = p10[ch]; a11[ch] = p10[3 + ch]; }
+        } else {
+            const float* p00 = img + ((size_t)x * cam.W + y) * 3;
+            const float* p10 = p00 + (size_t)cam.W * 3;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { a00[ch] = p00[ch]; a01[ch] = p00[3 + ch]; a10[ch] = p10[ch]; a11[ch] = p10[3 + ch]; }
+        }
         // reference: weights partly in double (Auxilary.h:47); float weights agree to ~1e-7 relative
         const float fm = m - (float)x, fn = n - (float)y;
         const float w1 = (1.0f - fn) * fm, w2 = (1.0f - fn) * (1.0f - fm), w3 = fn * fm, w4 = fn * (1.0f - fm);
@@ -784,7 +797,7 @@ __global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
         Proj pr = project(xs, sf[f], a.cam);
         if (!pr.ok) continue;
         float I[3];
-        sample<false>(a.img + (size_t)f * a.cam.H * a.cam.W * 3, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        sample<false>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, nullptr, nullptr);
         rho[0] += I[0]; rho[1] += I[1]; rho[2] += I[2]; count++;
     }
     if (count) {
@@ -818,7 +831,7 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], ren[3];
-            sample<false>(a.img + (size_t)f * a.cam.H * a.cam.W * 3, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+            sample<false>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, nullptr, nullptr);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
             if (LED_INIT) {
 #pragma unroll
@@ -875,7 +888,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], ren[3], J[3];
-            sample<false>(a.img + (size_t)f * a.cam.H * a.cam.W * 3, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+            sample<false>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, nullptr, nullptr);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
             rho_jac<MODEL>(fp, pr, v.gn, shg, J);
             float l = 0.f;
@@ -1198,7 +1211,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
         float shfd[kMaxBasis], shg[kMaxBasis];
         if (!LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
         float I[3], ren[3];
-        sample<false>(img, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        sample<false>(img, 0, true, a.cam, pr.m, pr.n, I, nullptr, nullptr);
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
         float refl = 0.f;
         if (LED) { float Rp[3]; mul3(fp.R, pr.p, Rp); refl = dot3(v.gn, Rp); float pn = norm3(pr.p); double pd = (double)pn; refl /= (float)(pd * pd * pd); }
@@ -1289,7 +1302,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
         float shfd[kMaxBasis];
         if (!LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
         float I[3], gu[3], gv[3], ren[3];
-        sample<true>(img, a.cam, pr.m, pr.n, I, gu, gv);
+        sample<true>(img, 0, true, a.cam, pr.m, pr.n, I, gu, gv);
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
         float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
         float J[18];
@@ -1568,7 +1581,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], gu[3], gv[3], ren[3];
-            sample<true>(a.img + (size_t)f * a.cam.H * a.cam.W * 3, a.cam, pr.m, pr.n, I, gu, gv);
+            sample<true>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, gu, gv);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
             float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
             float GRt[9];
