@@ -1201,11 +1201,19 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.f;
     const int beg = b.obs_ptr[f], end = b.obs_ptr[f + 1];
-    for (int it = 0; it < kRowsPerThread; ++it) {
-        int e = beg + blockIdx.x * kChunk + it * kBlock + threadIdx.x;
-        if (e >= end) break;
-        const int j = b.obs_rows[e];
-        Vox v; load_vox(b, j, v);
+    // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
+    // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
+    // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
+    int e = beg + blockIdx.x * kChunk + threadIdx.x;
+    int j_cur = e < end ? b.obs_rows[e] : -1;
+    int j_nxt = (kRowsPerThread > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
+    Vox vn;
+    if (j_cur >= 0) load_vox(b, j_cur, vn);
+    for (int it = 0; it < kRowsPerThread && j_cur >= 0; ++it, e += kBlock) {
+        const Vox v = vn;
+        const int j_nn = (it + 2 < kRowsPerThread && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
+        if (j_nxt >= 0) load_vox(b, j_nxt, vn);
+        j_cur = j_nxt; j_nxt = j_nn;
         Proj pr = project(v.xs, fp, a.cam);
         if (!pr.ok) continue;
         float shfd[kMaxBasis], shg[kMaxBasis];
@@ -1292,11 +1300,19 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.f;
     const int beg = b.obs_ptr[f], end = b.obs_ptr[f + 1];
-    for (int it = 0; it < kRowsPerThread; ++it) {
-        int e = beg + blockIdx.x * kChunk + it * kBlock + threadIdx.x;
-        if (e >= end) break;
-        const int j = b.obs_rows[e];
-        Vox v; load_vox(b, j, v);
+    // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
+    // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
+    // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
+    int e = beg + blockIdx.x * kChunk + threadIdx.x;
+    int j_cur = e < end ? b.obs_rows[e] : -1;
+    int j_nxt = (kRowsPerThread > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
+    Vox vn;
+    if (j_cur >= 0) load_vox(b, j_cur, vn);
+    for (int it = 0; it < kRowsPerThread && j_cur >= 0; ++it, e += kBlock) {
+        const Vox v = vn;
+        const int j_nn = (it + 2 < kRowsPerThread && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
+        if (j_nxt >= 0) load_vox(b, j_nxt, vn);
+        j_cur = j_nxt; j_nxt = j_nn;
         Proj pr = project(v.xs, fp, a.cam);
         if (!pr.ok) continue;
         float shfd[kMaxBasis];
