@@ -43,7 +43,7 @@ def algorithmic_bytes(kernel, S, n_obs, W, H, F, laplacian=False):
         "sweep_pose": S * B_v + U,
         "sweep_dist": S * B_v + U + 56 * S,
         "energy": S * B_v + U,
-        "pcg_pass": 144 * S,    # 13 coefficients 52 + 12 columns 48 + record {r,t,p,inv} read 16 + write 16 + x 8 + rare-column flag 4
+        "pcg_pass": 152 * S,    # 19 ELL coefficients 76 + 18 column deltas (16 bit) 36 + record {r,t,p,inv} read 16 + write 16 + x read/write 8
         "pcg_mv": 124 * S,      # two-kernel form (multi-rank phases)
         "pcg_upd": 40 * S,
         "assemble": (56 + 80 + 12) * S,

@@ -51,7 +51,9 @@ struct Band {
     uint64_t* vis;            // [KW][Spad] keyframe visibility words
     int* nb;                  // [6][Spad] band row of +x,-x,+y,-y,+z,-z neighbour or -1
     float* nbd;               // [6][Spad] distance of that neighbour when it is NOT in the band (static)
-    int* col;                 // [kNQ][Spad] band row of each ELL column offset or -1
+    int* col;                 // [kNQ][Spad] band row of each ELL column offset (absent: the row itself)
+    unsigned* colp;           // [9][Spad] the same as 16-bit deltas col - row, columns (2w+1, 2w+2) in word w: half the index bytes of a PCG pass
+    int col16;                // 1 if every |col - row| fits 16 bits (then the PCG reads colp instead of col)
     // derived per voxel, refreshed whenever dist / grad change (k_derive)
     float* xs[3];             // surface point x_v - d*normalized(grad)      (OptimizerAux.cpp:215)
     float* gn[3];             // normalized(stored grad)
@@ -125,7 +127,7 @@ void launch_band_flags(const float* dist, const uint64_t* vis_key, int KW, float
 // exclusive scan of flags -> row_of (-1 where flag==0); returns total through d_total (device int)
 void launch_band_scan(int* flags_inout_rowof, long long nvox, int* block_sums, int* d_total, hipStream_t s);
 struct DenseView { float* dist; float* g[3]; float* weight; float* rho[3]; uint64_t* vis; int KW; int* row_of; };
-void launch_band_fill(const DenseView& d, const GridP& grid, Band b, hipStream_t s);
+void launch_band_fill(const DenseView& d, const GridP& grid, Band b, int* d_reach, hipStream_t s);   // *d_reach = max |col - row| (atomicMax; zero it first)
 void launch_band_scatter(const DenseView& d, Band b, hipStream_t s);
 void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s);
 constexpr int kObsChunk = 2048;      // rows per workgroup of the observation-list builders

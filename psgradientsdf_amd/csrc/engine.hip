@@ -250,7 +250,7 @@ int build_band(psgsdf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int Spad = ((S + kBlock - 1) / kBlock) * kBlock + kBlock;
     // planes (4-byte units per row): see Band
-    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 4 + 8;
+    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 4 + 8 + 9;
     const size_t bytes = (n4 * 4 + (size_t)KW * 8) * Spad + 256;
     if (c->band_mem) { hipFree(c->band_mem); c->band_mem = nullptr; }
     HIPCHK(c, hipMalloc(&c->band_mem, bytes));
@@ -266,7 +266,7 @@ int build_band(psgsdf_ctx* c) {
     b.dist = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.g[a] = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.rho[a] = (float*)take(1, 4);
-    b.nb = (int*)take(6, 4); b.nbd = (float*)take(6, 4); b.col = (int*)take(kNQ, 4);
+    b.nb = (int*)take(6, 4); b.nbd = (float*)take(6, 4); b.col = (int*)take(kNQ, 4); b.colp = (unsigned*)take(9, 4);
     for (int a = 0; a < 3; ++a) b.xs[a] = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.gn[a] = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.gfd[a] = (float*)take(1, 4);
@@ -275,7 +275,15 @@ int build_band(psgsdf_ctx* c) {
     b.blk = (float*)take(14, 4); b.H = (float*)take(kNQ, 4);
     b.hx = (int*)take(1, 4);
     b.rhs = (float*)take(1, 4); b.x = (float*)take(1, 4); b.t = (float*)take(1, 4);
-    timed(c, "band_fill", [&] { launch_band_fill(c->dense, c->grid, b, c->stream); });
+    HIPCHK(c, hipMemsetAsync(c->d_total, 0, sizeof(int), c->stream));
+    timed(c, "band_fill", [&] { launch_band_fill(c->dense, c->grid, b, c->d_total, c->stream); });
+    {   // 16-bit column deltas are usable if the widest reach of any ELL column fits (PSGSDF_PCG_COL16=0 forces the 32-bit table)
+        int reach = 0;
+        HIPCHK(c, hipMemcpyAsync(&reach, c->d_total, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        b.col16 = reach <= 32767;
+        if (const char* e = getenv("PSGSDF_PCG_COL16")) if (atoi(e) == 0) b.col16 = 0;
+    }
     if (c->areg_mem) { hipFree(c->areg_mem); c->areg_mem = nullptr; c->ar = AlbedoReg{}; }
     if (c->reg_r != 0.f) {   // "reg albedo": stencil tables + matrix-free CG vectors over the 3S unknowns
         if (c->n_ranks > 1) return fail(c, PSGSDF_ERR_UNSUPPORTED, "reg albedo is single-rank only");

@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(kBlock) k_band_fill(DenseView d, GridP grid, B
     }
 }
 // neighbour tables: membership by linear index exactly as Optimizer.cpp:462-474 does it
-__global__ void __launch_bounds__(kBlock) k_band_nb(DenseView d, GridP grid, Band b) {
+__global__ void __launch_bounds__(kBlock) k_band_nb(DenseView d, GridP grid, Band b, int* __restrict__ reach) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= b.S) return;
     long long lin = b.lin[j];
@@ -403,17 +403,25 @@ __global__ void __launch_bounds__(kBlock) k_band_nb(DenseView d, GridP grid, Ban
         b.nb[(size_t)q * b.Spad + j] = in ? d.row_of[ln] : -1;
         b.nbd[(size_t)q * b.Spad + j] = in ? d.dist[ln] : dj;   // reference reads out of bounds here (UB): use own value
     }
+    int dl[kNQ], far = 0;
     for (int q = 0; q < kNQ; ++q) {
         int o[3]; q_offset(q, o);
         long long ln = lin + o[0] * stride[0] + o[1] * stride[1] + o[2] * stride[2];
         int r = (ln >= 0 && ln < grid.nvox) ? d.row_of[ln] : -1;
         b.col[(size_t)q * b.Spad + j] = r >= 0 ? r : j;   // absent column: coefficient is 0, point at self so gathers stay in range
+        dl[q] = r >= 0 ? r - j : 0;
+        far = max(far, abs(dl[q]));
     }
+    for (int w = 0; w < (kNQ - 1) / 2; ++w)
+        b.colp[(size_t)w * b.Spad + j] = ((unsigned)dl[2 * w + 1] & 0xffffu) | ((unsigned)dl[2 * w + 2] << 16);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) far = max(far, __shfl_down(far, o, 64));
+    if ((threadIdx.x & 63) == 0 && far > 0) atomicMax(reach, far);
 }
-void launch_band_fill(const DenseView& d, const GridP& grid, Band b, hipStream_t s) {
+void launch_band_fill(const DenseView& d, const GridP& grid, Band b, int* d_reach, hipStream_t s) {
     int g1 = (int)min((grid.nvox + kBlock - 1) / kBlock, (long long)256 * 16);
     hipLaunchKernelGGL(k_band_fill, dim3(g1), dim3(kBlock), 0, s, d, grid, b);
-    if (b.S > 0) hipLaunchKernelGGL(k_band_nb, dim3((b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d, grid, b);
+    if (b.S > 0) hipLaunchKernelGGL(k_band_nb, dim3((b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d, grid, b, d_reach);
 }
 __global__ void __launch_bounds__(kBlock) k_band_scatter(DenseView d, Band b) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1882,11 +1890,12 @@ template <int R> struct CgfPending { float h[R][kNQ - kCgfB1]; float4 o[R][kNQ -
 // q * Spad in the scalar offset operand): with flat 64-bit addresses the 38 streamed loads of a row cost two address
 // registers each and the kernel spilled.
 // (The record gathers stay flat loads: this compiler narrows `raw.ptr.buffer.load.v4i32` to a one-dword load.)
-template <int R>
+template <int R, bool C16>
 __device__ __forceinline__ void cgf_rows(const Band& b, const float4* __restrict__ rin, int i0, int stride, int row1, float damping, CgfRow* w, CgfPending<R>& pend, int ab) {
     const int plane = b.Spad * 4;              // bytes of one ELL column plane
     const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)b.H, 0, kNQ * plane, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)b.col, 0, kNQ * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC = C16 ? __builtin_amdgcn_make_buffer_rsrc((void*)b.colp, 0, (kNQ - 1) / 2 * plane, 0x00020000)
+                                          : __builtin_amdgcn_make_buffer_rsrc((void*)b.col, 0, kNQ * plane, 0x00020000);
     float h[R][kNQ]; int c[R][kNQ];
     // round trip 1: everything addressed by the rows themselves, for ALL rows of the thread
 #pragma unroll
@@ -1895,9 +1904,18 @@ __device__ __forceinline__ void cgf_rows(const Band& b, const float4* __restrict
         w[u].i = i; w[u].live = i < row1;
         const int ii = w[u].live ? i : row1 - 1;
 #pragma unroll
-        for (int q = 0; q < kNQ; ++q) {
-            h[u][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rH, ii * 4, q * plane, 0));
-            c[u][q] = q == 0 ? ii : (int)__builtin_amdgcn_raw_buffer_load_b32(rC, ii * 4, q * plane, 0);
+        for (int q = 0; q < kNQ; ++q) h[u][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rH, ii * 4, q * plane, 0));
+        c[u][0] = ii;
+        if (C16) {   // 9 words of two 16-bit deltas
+#pragma unroll
+            for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) {
+                const int pk = (int)__builtin_amdgcn_raw_buffer_load_b32(rC, ii * 4, wd * plane, 0);
+                c[u][2 * wd + 1] = ii + ((pk << 16) >> 16);
+                c[u][2 * wd + 2] = ii + (pk >> 16);
+            }
+        } else {
+#pragma unroll
+            for (int q = 1; q < kNQ; ++q) c[u][q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rC, ii * 4, q * plane, 0);
         }
         w[u].x = b.x[ii];
     }
@@ -1940,7 +1958,7 @@ __device__ __forceinline__ void cgf_rows_finish(CgfRow* w, const CgfPending<R>& 
         w[u].A1 = A1; w[u].A2 = A2; w[u].A3 = A3;
     }
 }
-template <int kCgfRows, int kMinWaves>
+template <int kCgfRows, int kMinWaves, bool C16>
 __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, double* fs, double* part, int k, int kmax, double* mb, int ab) {   // ab: timing ablations (tools/), 0 in production
     __shared__ double red[kCgfSums * kBlock / 64];
     const Band& b = a.b;
@@ -1953,7 +1971,7 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
     int i0 = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     CgfRow w[kCgfRows]; CgfPending<kCgfRows> pend;
     const double stopped = fs[1];
-    cgf_rows<kCgfRows>(b, rin, i0, stride, a.row1, a.damping, w, pend, ab);
+    cgf_rows<kCgfRows, C16>(b, rin, i0, stride, a.row1, a.damping, w, pend, ab);
 
     CGF_STAMP(1);
     float alpha_prev = 0.f, beta = 0.f, rr_cur, rhsNorm2;
@@ -2015,7 +2033,7 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
         }
         i0 += kCgfRows * stride;
         if (i0 - (int)threadIdx.x >= a.row1) break;          // workgroup-uniform
-        cgf_rows<kCgfRows>(b, rin, i0, stride, a.row1, a.damping, w, pend, ab);
+        cgf_rows<kCgfRows, C16>(b, rin, i0, stride, a.row1, a.damping, w, pend, ab);
         cgf_rows_finish<kCgfRows>(w, pend);
     }
     CGF_STAMP(3);
@@ -2032,8 +2050,9 @@ void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int ro
     // rows per thread in flight at once <-> registers <-> resident workgroups per CU (launch bound = waves per SIMD).
     // One row per thread (114 VGPRs, 4 waves per SIMD) is the production shape; two rows spill at 3 waves per SIMD and are
     // kept for the timing tool only.
-    if (rows >= 2) hipLaunchKernelGGL((k_cgf_pass<2, 2>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
-    else hipLaunchKernelGGL((k_cgf_pass<1, 4>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
+    if (rows >= 2) hipLaunchKernelGGL((k_cgf_pass<2, 2, false>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
+    else if (a.b.col16) hipLaunchKernelGGL((k_cgf_pass<1, 4, true>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
+    else hipLaunchKernelGGL((k_cgf_pass<1, 4, false>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
 }
 
 // multi-rank: fold the partials of pass k (k = -1: |b|^2 of the init) into out[0..6] for the host program's all-reduce
