@@ -80,8 +80,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
+        # PSGSDF_BENCH_SHARE_GPU=1: every rank on GPU 0 over gloo -- a functional check of this code path on a one-GPU box, not a measurement
+        share = os.environ.get("PSGSDF_BENCH_SHARE_GPU") == "1"
+        if share:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if share:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     device = local_rank if world > 1 else 0
 
     t_gen = time.time()
@@ -162,7 +169,7 @@ def main():
         "config": {"workload": f"synthetic {args.width}x{args.height} RGB-D bumpy sphere, {args.grid}^3 grid, {args.model}, {args.frames} keyframes, "
                                "albedo+light+distance+pose blocks, Cauchy IRLS, Eikonal reg (config_skorates.json settings)",
                    "band_voxels": int(S), "observations": int(n_obs), "pcg_iters_per_step": cg_iters,
-                   "parallelism": "single GPU" if world == 1 else f"{world} z-slabs (one per GPU), grid 256x256x{256 * world}, {args.frames * world} keyframes, RCCL halo exchange + all-reduce"},
+                   "parallelism": "single GPU" if world == 1 else f"{world} z-slabs (one per GPU), grid {args.grid}x{args.grid}x{args.grid * world}, {args.frames * world} keyframes, RCCL halo exchange + all-reduce"},
     }
 
     if rank == 0:
@@ -175,7 +182,7 @@ def main():
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and (args.grid, args.frames, args.model, world) == (256, 50, "SH1", 1):   # the counters were collected on this configuration
             try:
                 traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
