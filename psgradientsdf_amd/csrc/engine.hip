@@ -396,6 +396,7 @@ static void cgf_shape(int nblk, int* G, int* rows) {
 // about the passes up to k0+n-2; the kernel that detects convergence (or hits the cap) is also the one that finalises x.
 int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_out, double* err_out) {
     const int S = c->band.S;
+    if (a.row1 <= a.row0) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }   // empty band: b = 0, x = 0, Success
     int cap = c->set.cg_max_it > 0 ? c->set.cg_max_it : 2 * S;
     if (cap > c->pcg_cap) cap = c->pcg_cap;
     int G, rows;
