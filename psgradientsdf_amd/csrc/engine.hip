@@ -303,6 +303,7 @@ int build_band(psgsdf_ctx* c) {
         const int C = (S + c->n_ranks - 1) / c->n_ranks;
         c->row0 = std::min(S, c->rank * C); c->row1 = std::min(S, c->row0 + C);
         c->halo = 0; c->need[0] = c->need[1] = 0;
+        if (c->n_ranks > 1 && c->row1 <= c->row0) return fail(c, PSGSDF_ERR_UNSUPPORTED, "rank %d of %d would own no band rows (band of %d): use fewer ranks", c->rank, c->n_ranks, S);
         if (c->n_ranks > 1 && S > 0) {
             HIPCHK(c, hipMemsetAsync(c->d_need, 0, 2 * sizeof(int), c->stream));
             launch_reach(b, c->row0, c->row1, c->d_need, c->stream);
@@ -1258,6 +1259,10 @@ int psgsdf_mg_buffer(psgsdf_ctx* c, int which, void** ptr, int64_t* count) {
 static int mg_fold(psgsdf_ctx* c, std::initializer_list<int> slots) {
     SlotList sl; sl.n = 0; for (int s_ : slots) sl.id[sl.n++] = s_;
     if (c->mg_fold_base < 0 || c->mg_fold_base + sl.n > kMgScal) return fail(c, PSGSDF_ERR_ARG, "fold base %d out of range", c->mg_fold_base);
+    if (c->row1 <= c->row0) {   // this rank owns no rows: its kernels were not launched, its contribution to every sum is 0
+        HIPCHK(c, hipMemsetAsync(c->mg_scal + c->mg_fold_base, 0, sizeof(double) * sl.n, c->stream));
+        return 0;
+    }
     launch_sum_parts(c->part, c->PB, band_blocks(c), sl, c->mg_scal + c->mg_fold_base, c->stream);
     return 0;
 }
@@ -1287,7 +1292,8 @@ int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
         case PSGSDF_MG_PCG_INIT: {
             int G, rows; cgf_shape(band_blocks(c), &G, &rows);
             timed(c, "pcg_init", [&] { launch_cgf_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
-            launch_cgf_sum(c->pcg_part, G, -1, c->mg_ext, c->stream);      // local |b|^2 -> ext[0]
+            if (c->row1 <= c->row0) HIPCHK(c, hipMemsetAsync(c->mg_ext, 0, sizeof(double) * 8, c->stream));   // no rows: contributes 0
+            else launch_cgf_sum(c->pcg_part, G, -1, c->mg_ext, c->stream);      // local |b|^2 -> ext[0]
             return 0;
         }
         case PSGSDF_MG_PCG_PASS: {   // arg = kernel index k: finishes pass k-1, runs pass k; ext holds the all-reduced sums of pass k-1
@@ -1295,7 +1301,8 @@ int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
             int G, rows; cgf_shape(band_blocks(c), &G, &rows);
             a.ext = c->mg_ext; a.laplacian_reg = 0;
             timed(c, "pcg_pass", [&] { launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, arg, mg_pcg_cap(c), c->mg_hist + arg, c->stream); });
-            launch_cgf_sum(c->pcg_part, G, arg, c->mg_ext, c->stream);     // local sums of pass k -> ext[0..6]
+            if (c->row1 <= c->row0) HIPCHK(c, hipMemsetAsync(c->mg_ext, 0, sizeof(double) * 8, c->stream));
+            else launch_cgf_sum(c->pcg_part, G, arg, c->mg_ext, c->stream);     // local sums of pass k -> ext[0..6]
             return 0;
         }
         case PSGSDF_MG_APPLY_DIST: timed(c, "apply_dist", [&] { launch_apply_dist(a, c->stream); }); return mg_fold(c, {SC_ACCEPT});
