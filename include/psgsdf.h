@@ -281,7 +281,7 @@ int psgsdf_watch_kernel(psgsdf_ctx* ctx, const char* name);
  * diag (H_ii before damping), rhs b, and y = H*x for the supplied x (may be NULL). */
 int psgsdf_debug_dist_system(psgsdf_ctx* ctx, float* diag, float* rhs, const float* x, float* y);
 /* timing only: average ms of `reps` back-to-back launches of the fused PCG pass on the current distance system with
- * `blocks` workgroups (0 = one row per thread) and ablation bits (see kernels.hip: k_cgf_pass); leaves the PCG state undefined */
+ * `blocks` workgroups (0 = one row per thread) and ablation bits (see pcg.hip: k_cgf_pass); leaves the PCG state undefined */
 int psgsdf_debug_time_pcg_pass(psgsdf_ctx* ctx, int blocks, int rows_in_flight, int ablate, int reps, double* avg_ms, long long* stamps /* nullable: [blocks][8] */);
 /* rows / 64-row groups of the current distance system that use any of the 6 rare ELL columns (launch-shape diagnostics) */
 int psgsdf_debug_rare_rows(psgsdf_ctx* ctx, int64_t* rows, int64_t* waves);

@@ -1291,7 +1291,7 @@ int orc_mg_phase(orc_ctx* c, int phase, int arg) {
                 dist_assemble(c, sy);
             }
             return 0; }
-        /* Fused Jacobi-PCG in the formulation of the engine's k_cgf_pass (kernels.hip): kernel k finishes pass k-1 for the
+        /* Fused Jacobi-PCG in the formulation of the engine's k_cgf_pass (pcg.hip): kernel k finishes pass k-1 for the
          * owned rows (x += alpha p), re-derives r_k, z_k, p_k of every column from that column's record {r, t, p, inv} of
          * pass k-1 (halo records exchanged by the host program), runs t = A p_k and leaves the 7 local sums in mg_ext;
          * alpha, beta and the convergence test come from the all-reduced sums of pass k-1 found in mg_ext on entry.

@@ -1,0 +1,340 @@
+// device_common.h -- device-side helpers shared by the gfx950 kernel files (band.hip, frontend.hip, sweeps.hip,
+// albedo_reg.hip, dist.hip, pcg.hip): small vector algebra, robust weights, workgroup reductions, projection + image
+// sampling, shading, the finite-difference stencil on the compact band, ELL column numbering.  Internal; the public
+// boundary is include/psgsdf.h.
+//
+// Reference arithmetic is cited per function (paths relative to /root/reference/cpp/include/).  Per-observation arithmetic
+// is float32 in the reference's operation order; sums over many observations are accumulated in double.
+//
+// Kernel map:
+//   band.hip       : k_select_vis, k_band_flags, k_scan_*, k_band_fill, k_band_nb, k_band_scatter, k_upsample, k_derive, k_obs_*, k_sum_parts
+//   sweeps.hip     : k_init_albedo, k_energy, k_sweep_albedo (voxel-major, set-bit iteration); k_sweep_light, k_sweep_pose
+//                    (frame-major, wave + LDS reduction); k_solve_light, k_solve_pose (LDL^T per frame)
+//   dist.hip       : k_sweep_dist, k_assemble          pcg.hip: k_cgf_init, k_cgf_pass (fused Jacobi-PCG), k_apply_dist
+//   albedo_reg.hip : k_areg_*                          frontend.hip: k_integrate, k_normals_h/v, k_track
+#pragma once
+#include "engine.h"
+#include <float.h>
+
+// Floating-point contraction: ON for the Jacobian / normal-equation algebra (FMA: fewer instructions, one rounding
+// less), OFF inside the functions whose results feed discrete decisions or must match the CPU reference build bit for
+// bit (baseline x86-64, no FMA): normalisation, the surface point, the projection (floor / in-image test), FD gradient.
+#pragma clang fp contract(fast)
+
+namespace psg {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+__device__ __forceinline__ float norm3(const float* a) { return sqrtf(dot3(a, a)); }
+// Eigen normalized(): z>0 ? v/sqrt(z) : v
+__device__ __forceinline__ void normalized3(const float* v, float* o) {
+#pragma clang fp contract(off)
+    float z = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    if (z > 0.f) { float s = sqrtf(z); o[0] = v[0] / s; o[1] = v[1] / s; o[2] = v[2] / s; }
+    else { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; }
+}
+__device__ __forceinline__ void mulT3(const float* M, const float* v, float* o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = (M[0 * 3 + i] * v[0] + M[1 * 3 + i] * v[1]) + M[2 * 3 + i] * v[2];
+}
+__device__ __forceinline__ void mul3(const float* M, const float* v, float* o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = (M[i * 3 + 0] * v[0] + M[i * 3 + 1] * v[1]) + M[i * 3 + 2] * v[2];
+}
+template <int NB> __device__ __forceinline__ float dotn(const float* a, const float* b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) s += a[i] * b[i];
+    return s;
+}
+// PsOptimizerJa.cpp:17-28
+template <int NB> __device__ __forceinline__ void SH(const float* n, float* sh) {
+    sh[0] = 1.0f; sh[1] = n[0]; sh[2] = n[1]; sh[3] = n[2];
+    if (NB == 9) { sh[4] = n[0] * n[1]; sh[5] = n[0] * n[2]; sh[6] = n[1] * n[2]; sh[7] = n[0] * n[0] - n[1] * n[1]; sh[8] = n[0] * n[0] - n[2] * n[2]; }
+}
+template <int MODEL> struct ModelTraits { static constexpr int NB = MODEL == 1 ? 9 : (MODEL == 0 ? 4 : 3); static constexpr bool LED = MODEL == 2; };
+
+// Optimizer.cpp:140-161 / 164-186
+__device__ __forceinline__ float robust_weight(const Robust& rb, float r) {
+    switch (rb.loss) {
+        case 1: { float x = r * rb.inv_lambda; return __builtin_amdgcn_rcpf(1.0f + x * x); }   // v_rcp_f32: 1 ulp
+        case 3: { float x = r * rb.inv_lambda; float w = (1.0f - x * x); w = w * w; return (r * r < rb.lambda_sq) ? w : 0.0f; }
+        case 2: { float w = rb.lambda * fabsf(__builtin_amdgcn_rcpf(r)); return (r * r < rb.lambda_sq) ? 1.0f : w; }
+        case 4: return (r * r < rb.lambda_sq) ? 1.0f : 0.0f;
+        default: return 1.0f;
+    }
+}
+__device__ __forceinline__ float robust_loss(const Robust& rb, float r) {
+    switch (rb.loss) {
+        case 1: { float x = r * rb.inv_lambda; return __logf(1.0f + x * x); }
+        case 3: { float x = r * rb.inv_lambda; float u = 1.0f - x * x; float v = 1.0f - u * u * u; return (r * r < rb.lambda_sq) ? v : 1.0f; }
+        case 2: return (r * r < rb.lambda_sq) ? 0.5f * (r * r) : rb.lambda * (fabsf(r) - 0.5f * rb.lambda * 1.0f);
+        case 4: { float x = fminf(fmaxf(r, -rb.lambda), rb.lambda); return x * x; }
+        default: return r * r;
+    }
+}
+
+// wavefront (64 lanes) and workgroup reductions; one device-scope atomic per workgroup
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sumf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// Workgroup reduction -> ONE plain store per workgroup into a per-block partial slot (no atomics: 1300+
+// workgroups hitting one address serialise at ~12 ns each, which made trivial kernels take 30 us).
+// All threads of the block must call; red is __shared__ double[kBlock/64].  The partials are summed by the
+// consumer (host, or the next PCG kernel) in a fixed order, so results are run-to-run deterministic.
+__device__ __forceinline__ void block_part_store(double v, double* part_slot, double* red) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+        part_slot[blockIdx.x] = s;
+    }
+}
+// sum of n partials, identical in every thread of every block (fixed order)
+__device__ __forceinline__ double block_total(const double* part, int n, double* red) {
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += part[i];
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;
+}
+#define PART(a, slot) ((a).acc.part + (size_t)(slot) * (a).acc.PB)
+// a.fold: sum the partial slots the PREVIOUS kernel left behind (first workgroup only; all its threads must call).
+// The calling kernel must not write the folded slots itself (engine.hip: take_fold checks).
+__device__ __forceinline__ void fold_pending(const SweepArgs& a, double* red /*[kBlock/64]*/) {
+    if (a.fold.n == 0 || blockIdx.x != 0 || blockIdx.y != 0) return;
+    for (int s = 0; s < a.fold.n; ++s) {
+        const double t = block_total(PART(a, a.fold.id[s]), a.fold.nblk, red);
+        if (threadIdx.x == 0) a.fold.out[s] = t;
+    }
+    __syncthreads();
+}
+
+// frame records (pose, light) of all keyframes staged in dynamic LDS: F * 96 B (<= 60 KiB, F <= kMaxFramesLds)
+extern __shared__ __align__(16) unsigned char psg_dyn_smem[];
+__device__ __forceinline__ void load_frames(FrameP* sf, const FrameP* frames, int F) {
+    const float* src = (const float*)frames; float* dst = (float*)sf;
+    for (int i = threadIdx.x; i < F * (int)(sizeof(FrameP) / 4); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// projection + image sampling
+// ------------------------------------------------------------------------------------------
+struct Proj { float p[3]; float m, n, z_inv; bool ok; };
+
+// OptimizerAux.cpp:207-226 (surface point precomputed in xs = x_v - d*normalized(grad))
+__device__ __forceinline__ Proj project(const float* xs, const FrameP& fp, const Cam& cam) {
+#pragma clang fp contract(off)
+    Proj o;
+    float tmp[3] = {xs[0] - fp.t[0], xs[1] - fp.t[1], xs[2] - fp.t[2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.p[i] = (fp.R[0 * 3 + i] * tmp[0] + fp.R[1 * 3 + i] * tmp[1]) + fp.R[2 * 3 + i] * tmp[2];
+    // reference: (float)(1. / point[2]) evaluated in double (OptimizerAux.cpp:219); the correctly rounded float
+    // reciprocal differs from that only in double-rounding corner cases (~1e-8 of all inputs)
+    const float z_inv = 1.0f / o.p[2];
+    o.z_inv = z_inv;
+    o.m = cam.fx * o.p[0] * z_inv + cam.cx;
+    o.n = cam.fy * o.p[1] * z_inv + cam.cy;
+    o.ok = (o.m >= 0.f && o.m < (float)cam.W && o.n >= 0.f && o.n < (float)cam.H);
+    return o;
+}
+
+__device__ __forceinline__ const float* pix(const float* img, const Cam& cam, int row, int col) {
+    row = row < 0 ? 0 : (row >= cam.H ? cam.H - 1 : row);
+    col = col < 0 ? 0 : (col >= cam.W ? cam.W - 1 : col);
+    return img + ((size_t)row * cam.W + col) * 3;
+}
+
+// Auxilary.h:41-61 interpolateImage + Auxilary.h:64-123 computeImageGradient from one set of taps.
+// (row coordinate n_row, column coordinate m_col); gu = d/d(col), gv = d/d(row).
+// `base` is wave-uniform (the image stack, or one frame of it), `frame` selects the image inside it (0 for a frame pointer).
+// idx32: the whole stack is < 4 GiB, so a tap's byte offset fits 32 bits and the loads take the scalar-base form (one address
+// register, no 64-bit integer multiply-adds, which issue at quarter rate and made up ~10 % of a sweep's instruction slots).
+template <bool GRAD>
+__device__ __forceinline__ void sample(const float* base, int frame, bool idx32, const Cam& cam, float m_col, float n_row, float* I, float* gu, float* gv) {
+    const float m = n_row, n = m_col;  // names of Auxilary.h: m = row, n = column
+    int x = (int)floorf(m), y = (int)floorf(n);
+    const float* img = base + (size_t)frame * cam.H * cam.W * 3;   // only the rare border path below uses it
+    if ((x + 1) < cam.H && (y + 1) < cam.W) {
+        float a00[3], a01[3], a10[3], a11[3];
+        if (idx32) {
+            const unsigned e = (((unsigned)frame * (unsigned)cam.H + (unsigned)x) * (unsigned)cam.W + (unsigned)y) * 3u;
+            const float* p00 = (const float*)((const char*)base + (size_t)(e << 2));
+            const float* p10 = (const float*)((const char*)base + (size_t)((e + 3u * (unsigned)cam.W) << 2));
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { a00[ch] = p00[ch]; a01[ch] = p00[3 + ch]; a10[ch] = p10[ch]; a11[ch] = p10[3 + ch]; }
+        } else {
+            const float* p00 = img + ((size_t)x * cam.W + y) * 3;
+            const float* p10 = p00 + (size_t)cam.W * 3;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { a00[ch] = p00[ch]; a01[ch] = p00[3 + ch]; a10[ch] = p10[ch]; a11[ch] = p10[3 + ch]; }
+        }
+        // reference: weights partly in double (Auxilary.h:47); float weights agree to ~1e-7 relative
+        const float fm = m - (float)x, fn = n - (float)y;
+        const float w1 = (1.0f - fn) * fm, w2 = (1.0f - fn) * (1.0f - fm), w3 = fn * fm, w4 = fn * (1.0f - fm);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) I[ch] = ((a10[ch] * w1 + a00[ch] * w2) + a11[ch] * w3) + a01[ch] * w4;
+        if (GRAD) {
+            const float w01 = fm, w11 = fn, w00 = 1.0f - fm, w10 = 1.0f - fn;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                gu[ch] = w00 * (a01[ch] - a00[ch]) + w01 * (a11[ch] - a10[ch]);
+                gv[ch] = w10 * (a10[ch] - a00[ch]) + w11 * (a11[ch] - a01[ch]);
+            }
+        }
+    } else {  // last row / column: nearest sample, one-sided differences (Auxilary.h:55-57,90-121)
+        const float* p = pix(img, cam, x, y);
+        I[0] = p[0]; I[1] = p[1]; I[2] = p[2];
+        if (GRAD) {
+            float w01 = m - (float)x, w11 = n - (float)y;
+            float w00 = (float)(1.0 - (double)w01), w10 = (float)(1.0 - (double)w11);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                if ((x + 1) >= cam.H) gu[ch] = pix(img, cam, x, y + 1)[ch] - pix(img, cam, x, y)[ch];
+                else { float v0 = -pix(img, cam, x, y - 1)[ch] + pix(img, cam, x, y)[ch]; float v1 = -pix(img, cam, x + 1, y - 1)[ch] + pix(img, cam, x + 1, y)[ch]; gu[ch] = w00 * v0 + w01 * v1; }
+                if ((x + 1) >= cam.H && (y + 1) < cam.W) { float v0 = -pix(img, cam, x - 1, y)[ch] + pix(img, cam, x, y)[ch]; float v1 = -pix(img, cam, x - 1, y + 1)[ch] + pix(img, cam, x, y + 1)[ch]; gv[ch] = w10 * v0 + w11 * v1; }
+                else gv[ch] = pix(img, cam, x + 1, y)[ch] - pix(img, cam, x, y)[ch];
+            }
+        }
+    }
+}
+
+// rendered intensity: PsOptimizerJa.cpp:30-40 (SH) / LedOptimizerJa.cpp:15-29 (LED).
+// nfd = normalized FD gradient, shfd = SH(nfd) (SH models only)
+template <int MODEL>
+__device__ __forceinline__ void rendered(const FrameP& fp, const Proj& pr, const float* nfd, const float* shfd, const float* rho, float* out) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    float irr;
+    if (ModelTraits<MODEL>::LED) {
+        float Rp[3]; mul3(fp.R, pr.p, Rp);
+        irr = -dot3(nfd, Rp);
+        float pn = norm3(pr.p); double pd = (double)pn;
+        float ld = (float)(pd * pd * pd);
+        irr /= ld;
+        out[0] = rho[0] * fp.l[0] * irr; out[1] = rho[1] * fp.l[1] * irr; out[2] = rho[2] * fp.l[2] * irr;
+    } else {
+        irr = dotn<NB>(fp.l, shfd);
+        out[0] = rho[0] * irr; out[1] = rho[1] * irr; out[2] = rho[2] * irr;
+    }
+}
+
+// rhoJacobian: PsOptimizerJa.cpp:118-122 / LedOptimizerJa.cpp:85-99 (stored normal gn)
+template <int MODEL>
+__device__ __forceinline__ void rho_jac(const FrameP& fp, const Proj& pr, const float* gn, const float* shg, float* J) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    if (ModelTraits<MODEL>::LED) {
+        float Rp[3]; mul3(fp.R, pr.p, Rp);
+        float refl = dot3(gn, Rp);
+        float pn = norm3(pr.p); double pd = (double)pn;
+        refl /= (float)(pd * pd * pd);
+        J[0] = refl * fp.l[0]; J[1] = refl * fp.l[1]; J[2] = refl * fp.l[2];
+    } else {
+        float j = -dotn<NB>(fp.l, shg);
+        J[0] = J[1] = J[2] = j;
+    }
+}
+
+// per-voxel state in registers
+struct Vox { float xs[3], gn[3], nfd[3], rho[3]; };
+__device__ __forceinline__ void load_vox(const Band& b, int j, Vox& v) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { v.xs[a] = b.xs[a][j]; v.gn[a] = b.gn[a][j]; v.rho[a] = b.rho[a][j]; v.nfd[a] = b.nfd[a][j]; }
+}
+
+// ELL column offsets of one assembled distance row: self, 6 axis neighbours, 12 axis pairs
+__host__ __device__ inline void q_offset(int q, int* o) {
+    o[0] = o[1] = o[2] = 0;
+    if (q == 0) return;
+    if (q <= 6) { int a = (q - 1) >> 1; o[a] = ((q - 1) & 1) ? -1 : 1; return; }
+    // q 7..12: mixed-sign axis pairs (the only pair columns a forward-only stencil produces), q 13..18: (+,+) / (-,-)
+    int pi, sa, sb;
+    if (q < kNQCommon) { pi = (q - 7) >> 1; sa = ((q - 7) & 1) ? -1 : 1; sb = -sa; }
+    else { pi = (q - kNQCommon) >> 1; sa = ((q - kNQCommon) & 1) ? -1 : 1; sb = sa; }
+    int a = pi == 2 ? 1 : 0, b = pi == 0 ? 1 : 2;
+    o[a] = sa; o[b] = sb;
+}
+__device__ __forceinline__ int q_of(const int* o) {
+    int nz = (o[0] != 0) + (o[1] != 0) + (o[2] != 0);
+    if (nz == 0) return 0;
+    if (nz == 1) { int a = o[0] ? 0 : (o[1] ? 1 : 2); return 1 + 2 * a + (o[a] < 0 ? 1 : 0); }
+    int a = o[0] ? 0 : 1, b = o[2] ? 2 : 1;
+    int pi = (a == 0 && b == 1) ? 0 : ((a == 0) ? 1 : 2);
+    if (o[a] != o[b]) return 7 + 2 * pi + (o[a] < 0 ? 1 : 0);
+    return kNQCommon + 2 * pi + (o[a] < 0 ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// per-voxel derived quantities
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nb_dist(const Band& b, int q, int j) {
+    int r = b.nb[(size_t)q * b.Spad + j];
+    return r >= 0 ? b.dist[r] : b.nbd[(size_t)q * b.Spad + j];
+}
+// Optimizer.cpp:287-364 computeDistGrad -> (n, dir)
+__device__ __forceinline__ void fd_grad(const Band& b, int j, float vs_inv, float* n, float* dir) {
+#pragma clang fp contract(off)
+    float d = b.dist[j];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        bool fwd = b.nb[(size_t)(2 * a) * b.Spad + j] >= 0;
+        dir[a] = fwd ? 1.0f : -1.0f;
+        float dn = fwd ? b.dist[b.nb[(size_t)(2 * a) * b.Spad + j]] : nb_dist(b, 2 * a + 1, j);
+        n[a] = dir[a] * (dn - d);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) n[a] = n[a] * vs_inv;
+}
+// Optimizer.cpp:368-393 computeDistLaplacian
+__device__ __forceinline__ float laplacian(const Band& b, int j, float vs_inv) {
+    float d = b.dist[j];
+    float dd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { float p1 = nb_dist(b, 2 * a, j), p0 = nb_dist(b, 2 * a + 1, j); dd[a] = p1 + p0 - 2 * d; }
+    return (dd[0] + dd[1] + dd[2]) * vs_inv * vs_inv;
+}
+
+// ------------------------------------------------------------------------------------------
+// voxel-major sweeps: one thread per band voxel, iterating the set bits of its visibility mask
+// ------------------------------------------------------------------------------------------
+#define FOR_EACH_VISIBLE_FRAME(b, j, F, f)                                                   \
+    for (int _w = 0; _w < (b).KW; ++_w)                                                      \
+        for (uint64_t _m = (b).vis[(size_t)_w * (b).Spad + (j)]; _m; _m &= _m - 1)            \
+            if (int f = 64 * _w + __builtin_ctzll(_m); f < (F))
+
+// G = image_grad(3x2) * pi_grad(2x3), PsOptimizerJa.cpp:78-90
+__device__ __forceinline__ void image_pi_grad(const Cam& cam, const Proj& pr, const float* gu, const float* gv, float* G) {
+    const float z_inv = pr.z_inv;
+    float z_inv_sq = z_inv * z_inv;
+    float p00 = cam.fx * z_inv, p02 = -cam.fx * pr.p[0] * z_inv_sq, p11 = cam.fy * z_inv, p12 = -cam.fy * pr.p[1] * z_inv_sq;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        G[ch * 3 + 0] = gu[ch] * p00 + gv[ch] * 0.0f;
+        G[ch * 3 + 1] = gu[ch] * 0.0f + gv[ch] * p11;
+        G[ch * 3 + 2] = gu[ch] * p02 + gv[ch] * p12;
+    }
+}
+__device__ __forceinline__ int sym4(int a, int b) {   // index into the 10 upper-triangular entries
+    if (a > b) { int t = a; a = b; b = t; }
+    return a * 4 - (a * (a - 1)) / 2 + (b - a);
+}
+
+}  // namespace psg

@@ -1,0 +1,240 @@
+// dist.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Gradient-SDF photometric-stereo hot path:
+// the distance block: per-voxel normal-equation blocks and their ELL assembly.  No CUDA compatibility layer, no other back end.
+// Shared device helpers: device_common.h; the launchers are declared in engine.h.
+#include "device_common.h"
+
+namespace psg {
+
+// ------------------------------------------------------------------------------------------
+// distance block: per-voxel 4x4 normal-equation blocks, ELL assembly, Jacobi-PCG
+// ------------------------------------------------------------------------------------------
+// Optimizer.cpp:269-284 normalJacobian(grad, direction, lag=false)
+__device__ __forceinline__ void normal_jacobian(float vs_inv, const float* grad, const float* direction, float* J) {
+    float n_d[3] = {-vs_inv * direction[0], -vs_inv * direction[1], -vs_inv * direction[2]};
+    float N_inv = (float)(1.0 / (double)fmaxf(norm3(grad), 0.001f));
+    double Nd = (double)N_inv;
+    float dN = (float)((Nd * Nd * Nd) * (double)dot3(n_d, grad));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) J[k] = N_inv * n_d[k] - dN * grad[k];
+}
+
+// distJacobian per observation PsOptimizerJa.cpp:160-289 / LedOptimizerJa.cpp:117-218, accumulated directly
+// into the per-voxel block over {self, x-, y-, z-stencil neighbour}; regularisers Optimizer.cpp:196-218,477-590.
+template <int MODEL>
+__global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    constexpr bool LED = ModelTraits<MODEL>::LED;
+    FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
+    __shared__ double red[kBlock / 64];
+    load_frames(sf, a.frames, a.F);
+    const Band& b = a.b;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    double E = 0, nobs = 0;
+    if (j < a.row1) {
+        Vox v; load_vox(b, j, v);
+        const float vs_inv = a.grid.vs_inv;
+        float grad[3] = {b.gfd[0][j], b.gfd[1][j], b.gfd[2][j]};
+        float dir[3]; bool exists[4]; exists[0] = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bool fwd = b.nb[(size_t)(2 * k) * b.Spad + j] >= 0;
+            dir[k] = fwd ? 1.0f : -1.0f;
+            exists[k + 1] = fwd ? true : (b.nb[(size_t)(2 * k + 1) * b.Spad + j] >= 0);
+        }
+        float dn[4][3];
+        normal_jacobian(vs_inv, grad, dir, dn[0]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float nd[3] = {0.f, 0.f, 0.f};
+            if (LED && a.quirks) nd[k] += dir[k]; else nd[k] -= dir[k];   // B6: LedOptimizerJa.cpp:157-167 vs PsOptimizerJa.cpp:200-210
+            normal_jacobian(vs_inv, grad, nd, dn[k + 1]);
+        }
+        const float d = b.dist[j];
+        float dx[4][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dx[0][k] = -v.gn[k] - d * dn[0][k];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dx[q][k] = -d * dn[q][k];
+        float shfd[kMaxBasis];
+        if (!LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
+        float Dm[3][9];
+        if (NB == 9) {
+            const float* nh = v.nfd;
+            float D0[9] = {0, 1, 0, 0, nh[1], nh[2], 0, 2 * nh[0], 2 * nh[0]};
+            float D1[9] = {0, 0, 1, 0, nh[0], 0, nh[2], -2 * nh[1], 0};
+            float D2[9] = {0, 0, 0, 1, 0, nh[0], nh[1], 0, -2 * nh[2]};
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { Dm[0][i] = D0[i]; Dm[1][i] = D1[i]; Dm[2][i] = D2[i]; }
+        }
+        float B[10], g[4];   // <= F terms each: float accumulation (oracle: double) differs ~1e-7 relative
+        float Ef = 0.f; int nobs_i = 0;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) B[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = 0;
+        FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
+            const FrameP& fp = sf[f];
+            Proj pr = project(v.xs, fp, a.cam);
+            if (!pr.ok) continue;
+            float I[3], gu[3], gv[3], ren[3];
+            sample<true>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, gu, gv);
+            rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
+            float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
+            float GRt[9];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) GRt[ch * 3 + k] = (G[ch * 3 + 0] * fp.R[k * 3 + 0] + G[ch * 3 + 1] * fp.R[k * 3 + 1]) + G[ch * 3 + 2] * fp.R[k * 3 + 2];
+            float J[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mul3(GRt, dx[q], J[q]);   // dI_q
+            if (!LED) {
+                if (NB == 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            float dr[3] = {v.rho[ch] * fp.l[1], v.rho[ch] * fp.l[2], v.rho[ch] * fp.l[3]};
+                            J[q][ch] = J[q][ch] - dot3(dr, dn[q]);
+                        }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float dsh[9];
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) dsh[i] = (Dm[0][i] * dn[q][0] + Dm[1][i] * dn[q][1]) + Dm[2][i] * dn[q][2];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            float s = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 9; ++i) s += (v.rho[ch] * fp.l[i]) * dsh[i];
+                            J[q][ch] = J[q][ch] - s;
+                        }
+                    }
+                }
+            } else {
+                float Rp[3]; mul3(fp.R, pr.p, Rp);
+                float pn = norm3(pr.p); double pd = (double)pn;
+                float radius = (float)(pd * pd * pd);
+                float p5 = (float)(pd * pd * pd * pd * pd);
+                float nRp = dot3(v.nfd, Rp);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float dm = dot3(dn[q], Rp) + dot3(v.nfd, dx[q]);
+                    float tmp[3]; mulT3(fp.R, dx[q], tmp);
+                    float dm2 = -3 * dot3(pr.p, tmp) / p5;
+                    dm = dm / radius + dm2 * nRp;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) J[q][ch] = J[q][ch] + (v.rho[ch] * fp.l[ch]) * dm;
+                }
+            }
+            float l = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
+                l += robust_loss(a.rob, r);
+                int q = 0;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float jw = J[p][ch] * w;
+#pragma unroll
+                    for (int k = p; k < 4; ++k) B[q++] += jw * J[k][ch];
+                    g[p] += jw * r;
+                }
+            }
+            Ef += l; nobs_i += 1;
+        }
+        E = (double)Ef; nobs = (double)nobs_i;
+        if (a.normal_reg) {   // Eikonal row, Optimizer.cpp:196-218 + residual :509
+            float n_d[3] = {-vs_inv * dir[0], -vs_inv * dir[1], -vs_inv * dir[2]};
+            float Jr[4];
+            Jr[0] = dot3(grad, n_d);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Jr[k + 1] = grad[k] * (vs_inv * dir[k]);
+            float gnrm = norm3(grad);
+            if (gnrm > 0.0f) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Jr[k] /= gnrm;
+            }
+            float res = gnrm - 1;
+            int q = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int k = p; k < 4; ++k) B[q++] += a.reg_n * (Jr[p] * Jr[k]);
+                g[p] += a.reg_n * (Jr[p] * res);
+            }
+        }
+        if (a.laplacian_reg) {   // diagonal only (reference drops the off-diagonals), Optimizer.cpp:540-590
+            float vs2 = vs_inv * vs_inv; float Jl = -6 * vs2; float res = laplacian(b, j, vs_inv);
+            B[0] += a.reg_l * (Jl * Jl); g[0] += a.reg_l * (Jl * res);
+        }
+        // columns whose stencil neighbour is outside the band are dropped (PsOptimizerJa.cpp:536-552)
+        int q = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int k = p; k < 4; ++k) { b.blk[(size_t)q * b.Spad + j] = (exists[p] && exists[k]) ? B[q] : 0.f; ++q; }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) b.blk[(size_t)(10 + p) * b.Spad + j] = exists[p] ? g[p] : 0.f;
+    }
+    block_part_store(E, PART(a, SC_ENERGY), red);
+    block_part_store(nobs, PART(a, SC_NOBS), red);
+}
+void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
+    if (a.row1 <= a.row0) return;
+    dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_dist<0>), g, bl, a.F * sizeof(FrameP), s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_dist<1>), g, bl, a.F * sizeof(FrameP), s, a);
+    else hipLaunchKernelGGL((k_sweep_dist<2>), g, bl, a.F * sizeof(FrameP), s, a);
+}
+
+// H = sum_j P_j^T B_j P_j assembled row-wise into 19 fixed column offsets (ELL); a row receives
+// slices from itself, from each lower neighbour (whose forward stencil points at it) and from each
+// upper neighbour whose stencil was forced backward.  Accumulation in LDS (dynamic column index).
+__global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
+    __shared__ double acc[kNQ][kBlock];
+    const Band& b = a.b;
+    int i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < kNQ; ++q) acc[q][tid] = 0.0;
+    if (i >= a.row1) return;
+    double rhs = 0.0;
+    for (int c = 0; c < 7; ++c) {
+        int jrow, s; int coff[3] = {0, 0, 0};
+        if (c == 0) { jrow = i; s = 0; }
+        else {
+            int ax = (c - 1) >> 1; bool upper = (c - 1) & 1;
+            jrow = b.nb[(size_t)(2 * ax + (upper ? 0 : 1)) * b.Spad + i];
+            if (jrow < 0) continue;
+            if (upper && b.nb[(size_t)(2 * ax) * b.Spad + jrow] >= 0) continue;   // its stencil is forward: does not touch row i
+            s = ax + 1; coff[ax] = upper ? 1 : -1;
+        }
+        int dirj[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dirj[k] = b.nb[(size_t)(2 * k) * b.Spad + jrow] >= 0 ? 1 : -1;
+        rhs += (double)b.blk[(size_t)(10 + s) * b.Spad + jrow];
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {
+            int o[3] = {coff[0], coff[1], coff[2]};
+            if (bq > 0) o[bq - 1] += dirj[bq - 1];
+            float val = b.blk[(size_t)sym4(s, bq) * b.Spad + jrow];
+            if (val != 0.f) acc[q_of(o)][tid] += (double)val;
+        }
+    }
+    int extra = 0;
+#pragma unroll
+    for (int q = 0; q < kNQ; ++q) { float h = (float)acc[q][tid]; b.H[(size_t)q * b.Spad + i] = h; if (q >= kNQCommon && h != 0.f) extra = 1; }
+    b.hx[i] = extra;
+    b.rhs[i] = (float)rhs;
+}
+void launch_assemble(const SweepArgs& a, hipStream_t s) {
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_assemble, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+}
+
+}  // namespace psg

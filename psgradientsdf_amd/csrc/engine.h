@@ -1,5 +1,5 @@
 // engine.h — data layout shared by the host orchestration (engine.hip) and the gfx950 kernels
-// (kernels.hip).  Internal: the public boundary is include/psgsdf.h.
+// (band.hip, sweeps.hip, dist.hip, pcg.hip, albedo_reg.hip, frontend.hip).  Internal: the public boundary is include/psgsdf.h.
 //
 // Layout in HBM:
 //   dense grid  : SoA planes dist | gx | gy | gz | weight | r | g | b (float, x-fastest) + packed
@@ -81,7 +81,7 @@ struct Accum {
 };
 constexpr int kFrameRow = 64;        // doubles per frame accumulator row (SH2: 45 + 9 + 2 = 56)
 constexpr int kPcgMaxBlocks = 2048;  // workgroups of one PCG pass (grid-stride)
-constexpr int kCgfMaxBlocks = 768;   // workgroups of one fused PCG pass: at most 3 partials per thread and sum (kernels.hip)
+constexpr int kCgfMaxBlocks = 768;   // workgroups of one fused PCG pass: at most 3 partials per thread and sum (pcg.hip)
 
 enum { SC_ENERGY = 0, SC_NOBS = 1, SC_EN = 2, SC_EL = 3, SC_ACCEPT = 4, SC_AUX0 = 5, SC_AUX1 = 6, SC_AUX2 = 7, SC_COUNT = 8 };
 
@@ -104,7 +104,7 @@ struct SweepArgs {
     Band b;
     const FrameP* frames;     // [F]
     const float* img;         // [F][H][W][3]
-    bool img32;               // the image stack is < 4 GiB: tap offsets fit 32 bits (kernels.hip: sample)
+    bool img32;               // the image stack is < 4 GiB: tap offsets fit 32 bits (device_common.h: sample)
     int F;
     Cam cam;
     GridP grid;
@@ -121,7 +121,7 @@ struct SweepArgs {
     const double* ext;        // multi-rank PCG: the 7 globally reduced sums of the previous pass (|b|^2 in ext[0] for pass 0), else nullptr
 };
 
-// ---- launchers implemented in kernels.hip (all asynchronous on `s`) ----------------------
+// ---- launchers implemented in the kernel files (all asynchronous on `s`) ----------------------
 void launch_select_vis(const uint64_t* vis_seq, int wpv_seq, uint64_t* vis_key, int KW, const int* frame_idx, int F, long long nvox, hipStream_t s);
 void launch_band_flags(const float* dist, const uint64_t* vis_key, int KW, float vs, long long nvox, int* flags, hipStream_t s);
 // exclusive scan of flags -> row_of (-1 where flag==0); returns total through d_total (device int)
@@ -152,7 +152,7 @@ void launch_assemble(const SweepArgs& a, hipStream_t s);
 void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s);
 void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int rows, int k, int kmax, double* mb, hipStream_t s, int ablate = 0);
 void launch_cgf_sum(double* part, int G, int k, double* out, hipStream_t s);   // multi-rank: partials of pass k -> out[0..6]
-// "reg albedo" path (kernels.hip, albedo regulariser section); every launch covers the whole band (single rank only)
+// "reg albedo" path (albedo_reg.hip); every launch covers the whole band (single rank only)
 void launch_areg_tables(const DenseView& d, const GridP& g, const SweepArgs& a, hipStream_t s);
 void launch_areg_build(const SweepArgs& a, hipStream_t s);                       // J, res from the current albedo; sum of res -> SC_AUX0
 void launch_areg_system(const SweepArgs& a, hipStream_t s);                      // rhs, diag (damped) from aH/ab + weight Jr^T(.)

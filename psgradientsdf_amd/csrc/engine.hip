@@ -1,5 +1,5 @@
 // engine.hip — host orchestration of the HIP engine and the C ABI of include/psgsdf.h.
-// One context = one HIP device + one stream.  All kernels live in kernels.hip.
+// One context = one HIP device + one stream.  The kernels live in band / sweeps / dist / pcg / albedo_reg / frontend .hip.
 #include "engine.h"
 #include "../../include/psgsdf.h"
 
@@ -393,7 +393,7 @@ static void cgf_shape(int nblk, int* G, int* rows) {
     *G = (per + trips - 1) / trips; *rows = r;
 }
 
-// Fused PCG (kernels.hip: k_cgf_pass): kernel k finishes pass k-1 and runs pass k, so a chunk of n kernels tells the host
+// Fused PCG (pcg.hip: k_cgf_pass): kernel k finishes pass k-1 and runs pass k, so a chunk of n kernels tells the host
 // about the passes up to k0+n-2; the kernel that detects convergence (or hits the cap) is also the one that finalises x.
 int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_out, double* err_out) {
     const int S = c->band.S;
@@ -464,7 +464,7 @@ int albedo_reg_energy(psgsdf_ctx* c, double* Er) {
     return 0;
 }
 // optimizeAlbedoAll with the regulariser (PsOptimizer.cpp:85-121): Eigen ConjugateGradient over the 3S unknowns on
-// H = H_d + reg_rho Jr^T Jr applied matrix-free (kernels.hip).  Host-driven, two read-backs per CG iteration: no shipped
+// H = H_d + reg_rho Jr^T Jr applied matrix-free (albedo_reg.hip).  Host-driven, two read-backs per CG iteration: no shipped
 // configuration enables this term.  The step is left in ar.x.
 int albedo_reg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* ok_out, double* err_out) {
     const AlbedoReg& ar = a.ar;
@@ -521,7 +521,7 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
             break;
         }
         case PSGSDF_LIGHT: case PSGSDF_POSE: {
-            int col;   // the frame accumulator is all-zero here: whoever consumed it last cleared it (kernels.hip: frame_rows_finish)
+            int col;   // the frame accumulator is all-zero here: whoever consumed it last cleared it (sweeps.hip: frame_rows_finish)
             if (block == PSGSDF_LIGHT) {
                 take_fold(c, a, 0u);
                 timed(c, "sweep_light", [&] { launch_sweep_light(a, c->stream); });

@@ -1,0 +1,350 @@
+// pcg.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Gradient-SDF photometric-stereo hot path:
+// the fused Jacobi-PCG of the distance system and the distance update.  No CUDA compatibility layer, no other back end.
+// Shared device helpers: device_common.h; the launchers are declared in engine.h.
+#include "device_common.h"
+
+namespace psg {
+
+__device__ __forceinline__ float pcg_threshold(float rhsNorm2) { return fmaxf(FLT_EPSILON * FLT_EPSILON * rhsNorm2, FLT_MIN); }
+
+// Jacobi-PCG with Eigen::ConjugateGradient semantics: x0 = 0, threshold = max(eps^2 |b|^2, FLT_MIN), scalar
+// recurrences in float, dot products accumulated in double.  ONE kernel and ONE reduction per CG iteration:
+// Pass k (t = A p_k) also reduces, over the same rows,
+//     P = p.t   B = sum inv r t   C = sum inv t^2   D = sum r t   E = sum t^2   Z = r.z   R = |r|^2      (r = r_k, double)
+// from which the NEXT kernel derives alpha_k = Z / P and, without ever reducing r_{k+1} = r_k - alpha t separately,
+//     r_{k+1}.z_{k+1} = Z - 2 alpha B + alpha^2 C        |r_{k+1}|^2 = R - 2 alpha D + alpha^2 E
+// (Z and R are re-summed from the vectors every pass, so the expansions never chain and the cancellation costs at most the
+// digits of one pass's residual drop, taken from a double).  The vector updates x += alpha p, r -= alpha t, z = inv r,
+// p = z + beta p are applied lazily in float exactly as the reference does them: kernel k first finishes pass k-1 for its
+// own rows, and re-derives r_k, z_k, p_k of every gathered column from that column's record {r, t, p, inv} of pass k-1
+// (ONE 16-byte gather per column; records double-buffered because neighbours still read the old ones).
+//   fs (device doubles): [0] |b|^2   [1] done (0 = running)
+//   part: [2 parity][kCgfSums][kPcgMaxBlocks] per-workgroup partial sums, summed in a fixed order by every workgroup of
+//         the next kernel (deterministic, no atomics)
+//   mb  : slot of THIS kernel (mapped host memory on one GPU): k = 0 -> |b|^2, k > 0 -> |r|^2 after pass k-1
+// Multi-rank (a.ext != nullptr): a 1-workgroup kernel folds the partials of a pass into a.ext[0..6], the host program
+// all-reduces them over the ranks, and the next kernel reads the global sums from a.ext instead of the partials; the
+// records of the halo rows are exchanged before each pass.
+// ------------------------------------------------------------------------------------------
+constexpr int kCgfSums = 7;
+__device__ __forceinline__ double* fpart(double* part, int k, int kind) { return part + ((size_t)((k & 1) * kCgfSums + kind)) * kPcgMaxBlocks; }
+
+// n sums at once, identical in every thread of every workgroup.  All loads of a thread are issued before the first use
+// (fixed trip count, predicated): ONE memory round trip however many partials there are -- a dynamic-trip loop made it three.
+template <int N> struct PartLoads { double ld[kCgfMaxBlocks / kBlock][N]; };
+template <int N>
+__device__ __forceinline__ void block_total_issue(double* const* src, int n, PartLoads<N>& pl) {
+#pragma unroll
+    for (int j = 0; j < kCgfMaxBlocks / kBlock; ++j) {
+        const int i = threadIdx.x + j * kBlock;
+#pragma unroll
+        for (int q = 0; q < N; ++q) pl.ld[j][q] = i < n ? src[q][i] : 0.0;
+    }
+}
+template <int N>
+__device__ __forceinline__ void block_total_finish(const PartLoads<N>& pl, double* red /*[N * kBlock/64]*/, double* out) {
+    double v[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        v[q] = pl.ld[0][q];
+#pragma unroll
+        for (int j = 1; j < kCgfMaxBlocks / kBlock; ++j) v[q] += pl.ld[j][q];
+        v[q] = wave_sum(v[q]);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) red[q * (kBlock / 64) + w] = v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        double s = 0;
+#pragma unroll
+        for (int i = 0; i < kBlock / 64; ++i) s += red[q * (kBlock / 64) + i];
+        out[q] = s;
+    }
+}
+template <int N>
+__device__ __forceinline__ void block_total_n(double* const* src, int n, double* red /*[N * kBlock/64]*/, double* out) {
+    PartLoads<N> pl;
+    block_total_issue<N>(src, n, pl);
+    block_total_finish<N>(pl, red, out);
+}
+template <int N>
+__device__ __forceinline__ void block_part_store_n(const double* vin, double* const* dst, double* red) {
+    double v[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = wave_sum(vin[q]);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) red[q * (kBlock / 64) + w] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        double s = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[threadIdx.x * (kBlock / 64) + i];
+        dst[threadIdx.x][blockIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_cgf_init(SweepArgs a, double* fs, double* part) {
+    __shared__ double red[kBlock / 64];
+    const Band& b = a.b;
+    double bb = 0;
+    for (int i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x; i < a.row1; i += gridDim.x * blockDim.x) {
+        float dg = b.H[i];
+        if (a.damping != 0.0f) dg += a.damping * dg;
+        const float inv = dg != 0.f ? 1.0f / dg : 1.0f;
+        const float r = b.rhs[i];
+        b.x[i] = 0.f;
+        b.rec[1][i] = make_float4(r, 0.f, 0.f, inv);      // {r_0, t_{-1} = 0, p_{-1} = 0, inv}: read by kernel 0
+        bb += (double)r * (double)r;
+    }
+    block_part_store(bb, fpart(part, -1, 6), red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) fs[1] = 0.0;
+}
+void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s) {
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_cgf_init, dim3(G), dim3(kBlock), 0, s, a, fs, part);
+}
+// kernel k: finishes pass k-1 (k > 0), decides convergence, then runs pass k unless k == kmax (the iteration cap).
+//
+// The pass is a chain of memory round trips (column indices -> 16-byte record gathers -> reduction of the previous pass's
+// partials), not a bandwidth problem, so the kernel is arranged to need nothing from the reduction until the very end:
+// t = A p_k with p_k[c] = inv_c (r_c - alpha t_c) + beta p_c is LINEAR in the three gathered fields,
+//     t = A1 - alpha A2 + beta A3,   A1 = sum_c h_c inv_c r_c,  A2 = sum_c h_c inv_c t_c,  A3 = sum_c h_c p_c   (double),
+// so the three sums are accumulated as the gathers arrive, before alpha and beta exist, and the records never have to be
+// kept in registers.  (p_k of a NEIGHBOUR is therefore not rounded to float before it enters the product, unlike Eigen's
+// explicit vector; the row's own r, z, p, x are updated in float exactly as the reference does.  DESIGN.md §2, deviation 3.)
+// All 19 ELL columns are treated alike: at the band sizes of this path 61 % of the rows and every wavefront use the 6
+// columns that only backward-forced stencils produce.
+struct CgfRow { double A1, A2, A3; float4 me; float x; int i; bool live; };
+// The gathers of a thread's rows are issued in two batches (10 + 9 columns): all 57 records of 3 rows at once would need
+// 228 registers.  The second batch is in flight
+// while the caller reduces the previous pass's partials; cgf_rows_finish folds it in afterwards.
+constexpr int kCgfB1 = 10;   // columns of the first gather batch (the split is about registers, not about which columns are common)
+template <int R> struct CgfPending { float h[R][kNQ - kCgfB1]; float4 o[R][kNQ - kCgfB1]; };
+// The streamed loads go through buffer instructions (scalar resource + ONE 32-bit lane offset per row, the plane offset
+// q * Spad in the scalar offset operand): with flat 64-bit addresses the 38 streamed loads of a row cost two address
+// registers each and the kernel spilled.
+// (The record gathers stay flat loads: this compiler narrows `raw.ptr.buffer.load.v4i32` to a one-dword load.)
+template <int R, bool C16>
+__device__ __forceinline__ void cgf_rows(const Band& b, const float4* __restrict__ rin, int i0, int stride, int row1, float damping, CgfRow* w, CgfPending<R>& pend, int ab) {
+    const int plane = b.Spad * 4;              // bytes of one ELL column plane
+    const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)b.H, 0, kNQ * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC = C16 ? __builtin_amdgcn_make_buffer_rsrc((void*)b.colp, 0, (kNQ - 1) / 2 * plane, 0x00020000)
+                                          : __builtin_amdgcn_make_buffer_rsrc((void*)b.col, 0, kNQ * plane, 0x00020000);
+    float h[R][kNQ]; int c[R][kNQ];
+    // round trip 1: everything addressed by the rows themselves, for ALL rows of the thread
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int i = i0 + u * stride;
+        w[u].i = i; w[u].live = i < row1;
+        const int ii = w[u].live ? i : row1 - 1;
+#pragma unroll
+        for (int q = 0; q < kNQ; ++q) h[u][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rH, ii * 4, q * plane, 0));
+        c[u][0] = ii;
+        if (C16) {   // 9 words of two 16-bit deltas
+#pragma unroll
+            for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) {
+                const int pk = (int)__builtin_amdgcn_raw_buffer_load_b32(rC, ii * 4, wd * plane, 0);
+                c[u][2 * wd + 1] = ii + ((pk << 16) >> 16);
+                c[u][2 * wd + 2] = ii + (pk >> 16);
+            }
+        } else {
+#pragma unroll
+            for (int q = 1; q < kNQ; ++q) c[u][q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rC, ii * 4, q * plane, 0);
+        }
+        w[u].x = b.x[ii];
+    }
+    // round trip 2: the records of the first batch of columns of every row, folded into the three sums as they arrive
+    float4 o[R][kCgfB1];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+#pragma unroll
+        for (int q = 0; q < kCgfB1; ++q) o[u][q] = rin[c[u][q]];
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        if (damping != 0.0f) h[u][0] += damping * h[u][0];
+        double A1 = 0, A2 = 0, A3 = 0;
+#pragma unroll
+        for (int q = 0; q < kCgfB1; ++q) {
+            const double hq = (double)h[u][q], iv = (double)o[u][q].w;
+            A1 += hq * (iv * (double)o[u][q].x); A2 += hq * (iv * (double)o[u][q].y); A3 += hq * (double)o[u][q].z;
+        }
+        w[u].A1 = A1; w[u].A2 = A2; w[u].A3 = A3; w[u].me = o[u][0];
+    }
+    __builtin_amdgcn_sched_barrier(0);        // keep the second batch behind the first one's consumption (register budget)
+    // round trip 3 (overlaps the caller's reduction): the remaining columns
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+#pragma unroll
+        for (int q = kCgfB1; q < kNQ; ++q) { pend.h[u][q - kCgfB1] = h[u][q]; pend.o[u][q - kCgfB1] = rin[c[u][q]]; }
+    }
+}
+template <int R>
+__device__ __forceinline__ void cgf_rows_finish(CgfRow* w, const CgfPending<R>& pend) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        double A1 = w[u].A1, A2 = w[u].A2, A3 = w[u].A3;
+#pragma unroll
+        for (int q = 0; q < kNQ - kCgfB1; ++q) {
+            const double hq = (double)pend.h[u][q], iv = (double)pend.o[u][q].w;
+            A1 += hq * (iv * (double)pend.o[u][q].x); A2 += hq * (iv * (double)pend.o[u][q].y); A3 += hq * (double)pend.o[u][q].z;
+        }
+        w[u].A1 = A1; w[u].A2 = A2; w[u].A3 = A3;
+    }
+}
+template <int kCgfRows, int kMinWaves, bool C16>
+__global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, double* fs, double* part, int k, int kmax, double* mb, int ab) {   // ab: timing ablations (tools/), 0 in production
+    __shared__ double red[kCgfSums * kBlock / 64];
+    const Band& b = a.b;
+    long long* ts = (long long*)(fs + 16) + (size_t)blockIdx.x * 8;   // ab & 1024: stage timestamps of every workgroup
+#define CGF_STAMP(j) do { if ((ab & 1024) && threadIdx.x == 0) { ts[j] = clock64(); if (j == 0) ts[6] = wall_clock64(); if (j == 4) ts[7] = wall_clock64(); } } while (0)
+    CGF_STAMP(0);
+    const float4* __restrict__ rin = b.rec[(k + 1) & 1];
+    float4* __restrict__ rout = b.rec[k & 1];
+    const int stride = gridDim.x * blockDim.x;
+    int i0 = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    CgfRow w[kCgfRows]; CgfPending<kCgfRows> pend;
+    const double stopped = fs[1];
+    cgf_rows<kCgfRows, C16>(b, rin, i0, stride, a.row1, a.damping, w, pend, ab);
+
+    CGF_STAMP(1);
+    float alpha_prev = 0.f, beta = 0.f, rr_cur, rhsNorm2;
+    if (ab & 1) { alpha_prev = 0.01f; beta = 0.5f; rr_cur = 1.f; rhsNorm2 = 1.f; cgf_rows_finish<kCgfRows>(w, pend); }
+    else if (!(ab & 16) && stopped != 0.0 && stopped <= (double)k) return;   // stopped by an EARLIER kernel of this solve (kernel j writes j + 1)
+    else if (k == 0) {
+        double bb;
+        if (a.ext) bb = a.ext[0];
+        else { double* src[1] = {fpart(part, -1, 6)}; block_total_n<1>(src, gridDim.x, red, &bb); }
+        cgf_rows_finish<kCgfRows>(w, pend);
+        rhsNorm2 = (float)bb; rr_cur = rhsNorm2;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { fs[0] = bb; mb[0] = bb; __threadfence_system(); }   // mb may be host-mapped: the host watches it
+    } else {
+        double* src[kCgfSums]; double t[kCgfSums];
+#pragma unroll
+        for (int q = 0; q < kCgfSums; ++q) src[q] = fpart(part, k - 1, q);
+        if (a.ext) {
+#pragma unroll
+            for (int q = 0; q < kCgfSums; ++q) t[q] = a.ext[q];
+            cgf_rows_finish<kCgfRows>(w, pend);
+        } else {   // the partial sums of the previous pass are requested while the second gather batch is still in flight
+            PartLoads<kCgfSums> pl;
+            block_total_issue<kCgfSums>(src, gridDim.x, pl);
+            cgf_rows_finish<kCgfRows>(w, pend);
+            block_total_finish<kCgfSums>(pl, red, t);
+        }
+        rhsNorm2 = (float)fs[0];
+        const float rz_old = (float)t[5];
+        alpha_prev = rz_old / (float)t[0];                // alpha = absNew / p.dot(tmp)
+        const double al = (double)alpha_prev;
+        const float rz_cur = (float)(t[5] - 2.0 * al * t[1] + al * al * t[2]);
+        rr_cur = (float)(t[6] - 2.0 * al * t[3] + al * al * t[4]);
+        beta = rz_cur / rz_old;                            // beta = absNew / absOld
+        if (blockIdx.x == 0 && threadIdx.x == 0) { mb[0] = (double)rr_cur; __threadfence_system(); }
+    }
+    CGF_STAMP(2);
+    const bool rhs_zero = rhsNorm2 == 0.f;
+    const bool stop = !(ab & 16) && (rhs_zero || k == kmax || (k > 0 && rr_cur < pcg_threshold(rhsNorm2)));
+    if (stop && blockIdx.x == 0 && threadIdx.x == 0) fs[1] = (double)(k + 1);
+    double s[kCgfSums];
+#pragma unroll
+    for (int q = 0; q < kCgfSums; ++q) s[q] = 0;
+    while (true) {
+#pragma unroll
+        for (int u = 0; u < kCgfRows; ++u) {
+            const CgfRow& r = w[u];
+            const float4 me = r.me;
+            // finish pass k-1 for the own row: x += alpha p ; residual -= alpha tmp
+            if (r.live && k > 0 && !(ab & 32)) b.x[r.i] = r.x + alpha_prev * me.z;
+            if (stop || !r.live) continue;
+            const float r_i = me.x - alpha_prev * me.y;
+            const float z_i = me.w * r_i;
+            const float p_i = z_i + beta * me.z;
+            const float t = (float)(r.A1 - (double)alpha_prev * r.A2 + (double)beta * r.A3);
+            if (!(ab & 64)) rout[r.i] = make_float4(r_i, t, p_i, me.w);
+            const double rd = (double)r_i, td = (double)t, iv = (double)me.w;
+            s[0] += (double)p_i * td; s[1] += iv * rd * td; s[2] += iv * td * td; s[3] += rd * td; s[4] += td * td;
+            s[5] += rd * (double)z_i; s[6] += rd * rd;
+        }
+        i0 += kCgfRows * stride;
+        if (i0 - (int)threadIdx.x >= a.row1) break;          // workgroup-uniform
+        cgf_rows<kCgfRows, C16>(b, rin, i0, stride, a.row1, a.damping, w, pend, ab);
+        cgf_rows_finish<kCgfRows>(w, pend);
+    }
+    CGF_STAMP(3);
+    if (stop || (ab & 4)) return;
+    double* dst[kCgfSums];
+#pragma unroll
+    for (int q = 0; q < kCgfSums; ++q) dst[q] = fpart(part, k, q);
+    block_part_store_n<kCgfSums>(s, dst, red);
+    CGF_STAMP(4);
+#undef CGF_STAMP
+}
+void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int rows, int k, int kmax, double* mb, hipStream_t s, int ablate) {
+    if (a.row1 <= a.row0) return;
+    // rows per thread in flight at once <-> registers <-> resident workgroups per CU (launch bound = waves per SIMD).
+    // One row per thread (114 VGPRs, 4 waves per SIMD) is the production shape; two rows spill at 3 waves per SIMD and are
+    // kept for the timing tool only.
+    if (rows >= 2) hipLaunchKernelGGL((k_cgf_pass<2, 2, false>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
+    else if (a.b.col16) hipLaunchKernelGGL((k_cgf_pass<1, 4, true>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
+    else hipLaunchKernelGGL((k_cgf_pass<1, 4, false>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
+}
+
+// multi-rank: fold the partials of pass k (k = -1: |b|^2 of the init) into out[0..6] for the host program's all-reduce
+__global__ void __launch_bounds__(kBlock) k_cgf_sum(double* part, int G, int k, double* __restrict__ out) {
+    __shared__ double red[kCgfSums * kBlock / 64];
+    if (k < 0) {
+        double* src[1] = {fpart(part, -1, 6)}; double bb;
+        block_total_n<1>(src, G, red, &bb);
+        if (threadIdx.x == 0) out[0] = bb;
+    } else {
+        double* src[kCgfSums]; double t[kCgfSums];
+#pragma unroll
+        for (int q = 0; q < kCgfSums; ++q) src[q] = fpart(part, k, q);
+        block_total_n<kCgfSums>(src, G, red, t);
+        if (threadIdx.x < kCgfSums) out[threadIdx.x] = t[threadIdx.x];
+    }
+}
+void launch_cgf_sum(double* part, int G, int k, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_cgf_sum, dim3(1), dim3(kBlock), 0, s, part, G, k, out);
+}
+
+// debug: y = H x without damping
+__global__ void __launch_bounds__(kBlock) k_matvec(SweepArgs a, const float* x, float* y) {
+    const Band& b = a.b;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.S) return;
+    double acc = 0;
+    for (int q = 0; q < kNQ; ++q) {
+        int c = q == 0 ? i : b.col[(size_t)q * b.Spad + i];
+        if (c < 0) continue;
+        acc += (double)b.H[(size_t)q * b.Spad + i] * (double)x[c];
+    }
+    y[i] = (float)acc;
+}
+void launch_matvec(const SweepArgs& a, const float* x, float* y, hipStream_t s) {
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_matvec, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, x, y);
+}
+// updateDist accept rule OptimizerAux.cpp:162-188
+__global__ void __launch_bounds__(kBlock) k_apply_dist(SweepArgs a) {
+    __shared__ double red[kBlock / 64];
+    const Band& b = a.b;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    double cnt = 0;
+    if (j < a.row1) {
+        float d = b.x[j];
+        if ((double)fabsf(d) < sqrt(3.0) * (double)a.grid.vs) { b.dist[j] -= d; cnt = 1.0; }
+    }
+    block_part_store(cnt, PART(a, SC_ACCEPT), red);
+}
+void launch_apply_dist(const SweepArgs& a, hipStream_t s) {
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_apply_dist, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+}
+
+}  // namespace psg

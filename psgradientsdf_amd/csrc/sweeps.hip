@@ -1,0 +1,496 @@
+// sweeps.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Gradient-SDF photometric-stereo hot path:
+// the photometric sweeps (initial albedo, PS energy, albedo / light / pose normal equations) and the small per-frame solves.  No CUDA compatibility layer, no other back end.
+// Shared device helpers: device_common.h; the launchers are declared in engine.h.
+#include "device_common.h"
+
+namespace psg {
+
+// Optimizer.cpp:50-81 initAlbedo
+__global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
+#pragma clang fp contract(off)
+    FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
+    load_frames(sf, a.frames, a.F);
+    const Band& b = a.b;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.row1) return;
+    float xs[3] = {b.xs[0][j], b.xs[1][j], b.xs[2][j]};
+    int count = 0; float rho[3] = {0, 0, 0};
+    FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
+        Proj pr = project(xs, sf[f], a.cam);
+        if (!pr.ok) continue;
+        float I[3];
+        sample<false>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        rho[0] += I[0]; rho[1] += I[1]; rho[2] += I[2]; count++;
+    }
+    if (count) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) b.rho[k][j] = rho[k] / (float)count;
+    }
+}
+void launch_init_albedo(const SweepArgs& a, hipStream_t s) {
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_init_albedo, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), a.F * sizeof(FrameP), s, a);
+}
+
+// getPSEnergy PsOptimizer.cpp:47-78 / LedOptimizer.cpp:40-71; LED_INIT: computeLightIntensive
+// LedOptimizer.cpp:76-112 (sums of observed and rendered intensity)
+template <int MODEL, bool LED_INIT>
+__global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
+    __shared__ double red[kBlock / 64];
+    load_frames(sf, a.frames, a.F);
+    const Band& b = a.b;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    double E = 0, nobs = 0, sI[3] = {0, 0, 0}, sR[3] = {0, 0, 0};
+    float Ef = 0.f;
+    if (j < a.row1) {
+        Vox v; load_vox(b, j, v);
+        float shfd[kMaxBasis];
+        if (!ModelTraits<MODEL>::LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
+        FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
+            const FrameP& fp = sf[f];
+            Proj pr = project(v.xs, fp, a.cam);
+            if (!pr.ok) continue;
+            float I[3], ren[3];
+            sample<false>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+            rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
+            if (LED_INIT) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) { sI[ch] += (double)I[ch]; sR[ch] += (double)ren[ch]; }
+            } else {
+                float l = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) l += robust_loss(a.rob, I[ch] - ren[ch]);
+                Ef += l; nobs += 1.0;
+            }
+        }
+    }
+    E = (double)Ef;
+    if (LED_INIT) {
+        // 6 sums: observed rgb into SC_AUX0.., rendered into SC_EN/SC_EL/SC_ACCEPT slots (scratch use at init only)
+        block_part_store(sI[0], PART(a, SC_AUX0), red); block_part_store(sI[1], PART(a, SC_AUX1), red); block_part_store(sI[2], PART(a, SC_AUX2), red);
+        block_part_store(sR[0], PART(a, SC_EN), red); block_part_store(sR[1], PART(a, SC_EL), red); block_part_store(sR[2], PART(a, SC_ACCEPT), red);
+    } else {
+        block_part_store(E, PART(a, SC_ENERGY), red);
+        block_part_store(nobs, PART(a, SC_NOBS), red);
+    }
+}
+void launch_energy(const SweepArgs& a, hipStream_t s) {
+    if (a.row1 <= a.row0) return;
+    dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_energy<0, false>), g, bl, a.F * sizeof(FrameP), s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_energy<1, false>), g, bl, a.F * sizeof(FrameP), s, a);
+    else hipLaunchKernelGGL((k_energy<2, false>), g, bl, a.F * sizeof(FrameP), s, a);
+}
+void launch_led_light_init(const SweepArgs& a, hipStream_t s) {
+    if (a.row1 > a.row0) hipLaunchKernelGGL((k_energy<2, true>), dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), a.F * sizeof(FrameP), s, a);
+}
+
+// albedo normal equations (diagonal): optimizeAlbedoAll PsOptimizer.cpp:85-121 / LedOptimizer.cpp:162-196,
+// albedoJacobian PsOptimizerJa.cpp:375-422, computeResidual :567-626.  Also yields the PS energy of the input state.
+template <int MODEL>
+__global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
+    __shared__ double red[kBlock / 64];
+    load_frames(sf, a.frames, a.F);
+    const Band& b = a.b;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    double E = 0, nobs = 0;
+    if (j < a.row1) {
+        Vox v; load_vox(b, j, v);
+        float shfd[kMaxBasis], shg[kMaxBasis];
+        if (!ModelTraits<MODEL>::LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
+        float Hd[3] = {0, 0, 0}, bd[3] = {0, 0, 0};
+        float Ef = 0.f; int nobs_i = 0;
+        FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
+            const FrameP& fp = sf[f];
+            Proj pr = project(v.xs, fp, a.cam);
+            if (!pr.ok) continue;
+            float I[3], ren[3], J[3];
+            sample<false>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+            rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
+            rho_jac<MODEL>(fp, pr, v.gn, shg, J);
+            float l = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
+                float jw = J[ch] * w;
+                Hd[ch] += jw * J[ch]; bd[ch] += jw * r;
+                l += robust_loss(a.rob, r);
+            }
+            Ef += l; nobs_i += 1;
+        }
+        E = (double)Ef; nobs = (double)nobs_i;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { b.aH[(size_t)ch * b.Spad + j] = Hd[ch]; b.ab[(size_t)ch * b.Spad + j] = bd[ch]; }
+    }
+    block_part_store(E, PART(a, SC_ENERGY), red);
+    block_part_store(nobs, PART(a, SC_NOBS), red);
+}
+void launch_sweep_albedo(const SweepArgs& a, hipStream_t s) {
+    if (a.row1 <= a.row0) return;
+    dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_albedo<0>), g, bl, a.F * sizeof(FrameP), s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_albedo<1>), g, bl, a.F * sizeof(FrameP), s, a);
+    else hipLaunchKernelGGL((k_sweep_albedo<2>), g, bl, a.F * sizeof(FrameP), s, a);
+}
+// delta = b / ((1+damping) H), updateAlbedo accept rule OptimizerAux.cpp:120-150
+__global__ void __launch_bounds__(kBlock) k_apply_albedo(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
+    __shared__ double red[kBlock / 64];
+    const Band& b = a.b;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    double cnt = 0;
+    if (j < a.row1) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float h = b.aH[(size_t)ch * b.Spad + j];
+            if (a.damping != 0.0f) h += a.damping * h;
+            float delta = (h != 0.f) ? b.ab[(size_t)ch * b.Spad + j] / h : 0.f;
+            float v = b.rho[ch][j] - delta;
+            if (v > 0.0f && v < 1.0f) { b.rho[ch][j] = v; cnt += 1.0; }
+        }
+    }
+    block_part_store(cnt, PART(a, SC_ACCEPT), red);
+}
+void launch_apply_albedo(const SweepArgs& a, hipStream_t s) {
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_apply_albedo, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// frame-major sweeps: grid = (row chunks, F); per-thread accumulation over several voxels of ONE
+// frame, then wavefront shuffle reduction -> LDS -> one double atomic per value per workgroup
+// ------------------------------------------------------------------------------------------
+constexpr int kRowsPerThread = 16;
+constexpr int kChunk = kBlock * kRowsPerThread;
+
+// light normal equations: lightJacobian PsOptimizerJa.cpp:132-143,323-371 (per frame NBxNB),
+// LED LightJacobian LedOptimizerJa.cpp:101-115,299-346 (one global diagonal 3x3)
+template <int MODEL>
+__global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    constexpr bool LED = ModelTraits<MODEL>::LED;
+    constexpr int NH = LED ? 3 : NB * (NB + 1) / 2;
+    constexpr int NV = NH + NB + 2;   // + energy, n_obs
+    __shared__ FrameP sfp;
+    __shared__ double lds[(kBlock / 64) * NV];
+    const int f = blockIdx.y;
+    if (threadIdx.x < (int)(sizeof(FrameP) / 4)) ((float*)&sfp)[threadIdx.x] = ((const float*)(a.frames + f))[threadIdx.x];
+    __syncthreads();
+    const Band& b = a.b;
+    const FrameP& fp = sfp;
+    const float* img = a.img + (size_t)f * a.cam.H * a.cam.W * 3;
+    float acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+    const int beg = b.obs_ptr[f], end = b.obs_ptr[f + 1];
+    // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
+    // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
+    // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
+    int e = beg + blockIdx.x * kChunk + threadIdx.x;
+    int j_cur = e < end ? b.obs_rows[e] : -1;
+    int j_nxt = (kRowsPerThread > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
+    Vox vn;
+    if (j_cur >= 0) load_vox(b, j_cur, vn);
+    for (int it = 0; it < kRowsPerThread && j_cur >= 0; ++it, e += kBlock) {
+        const Vox v = vn;
+        const int j_nn = (it + 2 < kRowsPerThread && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
+        if (j_nxt >= 0) load_vox(b, j_nxt, vn);
+        j_cur = j_nxt; j_nxt = j_nn;
+        Proj pr = project(v.xs, fp, a.cam);
+        if (!pr.ok) continue;
+        float shfd[kMaxBasis], shg[kMaxBasis];
+        if (!LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
+        float I[3], ren[3];
+        sample<false>(img, 0, true, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
+        float refl = 0.f;
+        if (LED) { float Rp[3]; mul3(fp.R, pr.p, Rp); refl = dot3(v.gn, Rp); float pn = norm3(pr.p); double pd = (double)pn; refl /= (float)(pd * pd * pd); }
+        float l = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
+            l += robust_loss(a.rob, r);
+            if (LED) {
+                float J = refl * v.rho[ch]; float jw = J * w;
+                acc[ch] += jw * J; acc[NH + ch] += jw * r;
+            } else {
+                float J[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) J[i] = -v.rho[ch] * shg[i];
+                int q = 0;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    float jw = J[i] * w;
+#pragma unroll
+                    for (int k = i; k < NB; ++k) acc[q++] += jw * J[k];
+                    acc[NH + i] += jw * r;
+                }
+            }
+        }
+        acc[NH + NB] += l; acc[NH + NB + 1] += 1.0f;
+    }
+    // one atomic per value per workgroup into THIS frame's row (<= S/2048 workgroups contend per address);
+    // row layout: [NH H entries | NB rhs | energy | n_obs]
+    double* dst = a.acc.frame + (size_t)f * kFrameRow;
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }   // double: SH2 light blocks are ill-conditioned
+    __syncthreads();
+    for (int k = threadIdx.x; k < NV; k += blockDim.x) {
+        double s = 0;
+        for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + k];
+        if (s != 0.0) atomicAdd(dst + k, s);
+    }
+}
+void launch_sweep_light(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return;
+    dim3 g((a.b.obs_max + kChunk - 1) / kChunk, a.F), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_light<0>), g, bl, 0, s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_light<1>), g, bl, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_light<2>), g, bl, 0, s, a);
+}
+
+// pose normal equations: poseJacobian PsOptimizerJa.cpp:61-115,427-475 / LedOptimizerJa.cpp:32-81,351-399
+template <int MODEL>
+__global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    constexpr bool LED = ModelTraits<MODEL>::LED;
+    constexpr int NV = 21 + 6 + 2;
+    __shared__ FrameP sfp;
+    __shared__ double lds[(kBlock / 64) * NV];
+    const int f = blockIdx.y;
+    if (threadIdx.x < (int)(sizeof(FrameP) / 4)) ((float*)&sfp)[threadIdx.x] = ((const float*)(a.frames + f))[threadIdx.x];
+    __syncthreads();
+    const Band& b = a.b;
+    const FrameP& fp = sfp;
+    const float* img = a.img + (size_t)f * a.cam.H * a.cam.W * 3;
+    float acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+    const int beg = b.obs_ptr[f], end = b.obs_ptr[f + 1];
+    // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
+    // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
+    // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
+    int e = beg + blockIdx.x * kChunk + threadIdx.x;
+    int j_cur = e < end ? b.obs_rows[e] : -1;
+    int j_nxt = (kRowsPerThread > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
+    Vox vn;
+    if (j_cur >= 0) load_vox(b, j_cur, vn);
+    for (int it = 0; it < kRowsPerThread && j_cur >= 0; ++it, e += kBlock) {
+        const Vox v = vn;
+        const int j_nn = (it + 2 < kRowsPerThread && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
+        if (j_nxt >= 0) load_vox(b, j_nxt, vn);
+        j_cur = j_nxt; j_nxt = j_nn;
+        Proj pr = project(v.xs, fp, a.cam);
+        if (!pr.ok) continue;
+        float shfd[kMaxBasis];
+        if (!LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
+        float I[3], gu[3], gv[3], ren[3];
+        sample<true>(img, 0, true, a.cam, pr.m, pr.n, I, gu, gv);
+        rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
+        float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
+        float J[18];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float s = (G[ch * 3 + 0] * fp.R[k * 3 + 0] + G[ch * 3 + 1] * fp.R[k * 3 + 1]) + G[ch * 3 + 2] * fp.R[k * 3 + 2];
+                J[ch * 6 + k] = -s;
+            }
+        const float* p = pr.p;
+        float sk[9] = {0, -p[2], p[1], p[2], 0, -p[0], -p[1], p[0], 0};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) J[ch * 6 + 3 + k] = (G[ch * 3 + 0] * sk[0 * 3 + k] + G[ch * 3 + 1] * sk[1 * 3 + k]) + G[ch * 3 + 2] * sk[2 * 3 + k];
+        if (LED) {
+            float pn = norm3(p); double pd = (double)pn; float l3 = (float)(pd * pd * pd);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float s = -(v.rho[ch] * fp.l[ch] / l3);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) J[ch * 6 + k] += s * v.gn[k];
+            }
+        }
+        float l = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
+            l += robust_loss(a.rob, r);
+            int q = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float jw = J[ch * 6 + i] * w;
+#pragma unroll
+                for (int k = i; k < 6; ++k) acc[q++] += jw * J[ch * 6 + k];
+                acc[21 + i] += jw * r;
+            }
+        }
+        acc[27] += l; acc[28] += 1.0f;
+    }
+    double* dst = a.acc.frame + (size_t)f * kFrameRow;   // [21 H | 6 rhs | energy | n_obs]
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }   // double: SH2 light blocks are ill-conditioned
+    __syncthreads();
+    for (int k = threadIdx.x; k < NV; k += blockDim.x) {
+        double s = 0;
+        for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + k];
+        if (s != 0.0) atomicAdd(dst + k, s);
+    }
+}
+void launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return;
+    dim3 g((a.b.obs_max + kChunk - 1) / kChunk, a.F), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_pose<0>), g, bl, 0, s, a);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_pose<1>), g, bl, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep_pose<2>), g, bl, 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// small dense solves (one thread per frame): LDL^T in double, zero step on non-positive pivots
+// ------------------------------------------------------------------------------------------
+template <int N>
+__device__ void solve_spd(const double* Hin, const double* bin, double* x) {
+    double L[N * N], D[N], y[N];
+    double scale = 0;
+    for (int i = 0; i < N; ++i) scale = fmax(scale, fabs(Hin[i * N + i]));
+    const double tiny = scale * 1e-12;
+    for (int i = 0; i < N * N; ++i) L[i] = 0;
+    for (int j = 0; j < N; ++j) {
+        double d = Hin[j * N + j];
+        for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k] * D[k];
+        D[j] = d; L[j * N + j] = 1.0;
+        for (int i = j + 1; i < N; ++i) {
+            double s = Hin[i * N + j];
+            for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k] * D[k];
+            L[i * N + j] = (d > tiny) ? s / d : 0.0;
+        }
+    }
+    for (int i = 0; i < N; ++i) { double s = bin[i]; for (int k = 0; k < i; ++k) s -= L[i * N + k] * y[k]; y[i] = s; }
+    for (int i = 0; i < N; ++i) y[i] = (D[i] > tiny) ? y[i] / D[i] : 0.0;
+    for (int i = N - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k]; x[i] = s; }
+}
+
+// The per-frame solves run as ONE workgroup (a thread takes frames tid, tid+256, ...), which lets the same kernel do
+// what used to be two more launches around every frame-major sweep: sum the energy / n_obs columns of the rows
+// (e_out, may be host-mapped) and clear the rows for the next sweep.  Invariant: the frame accumulator is all-zero
+// outside [sweep, solve].
+__device__ __forceinline__ void frame_rows_finish(const SweepArgs& a, int col_e, double* e_out, double* red) {
+    __syncthreads();                                       // every thread has read the rows it solves from
+    if (e_out) {
+        double e = 0, n = 0;
+        for (int f = threadIdx.x; f < a.F; f += blockDim.x) { e += a.acc.frame[(size_t)f * kFrameRow + col_e]; n += a.acc.frame[(size_t)f * kFrameRow + col_e + 1]; }
+        e = wave_sum(e); n = wave_sum(n);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) { red[2 * w] = e; red[2 * w + 1] = n; }
+        __syncthreads();
+        if (threadIdx.x == 0) { double te = 0, tn = 0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { te += red[2 * i]; tn += red[2 * i + 1]; } e_out[0] = te; e_out[1] = tn; }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < a.F * kFrameRow; i += blockDim.x) a.acc.frame[i] = 0.0;
+}
+
+// optimizeLightAll: PsOptimizer.cpp:175-203 (no damping) / LedOptimizer.cpp:134-160 (damped, one RGB vector)
+template <int MODEL>
+__global__ void __launch_bounds__(kBlock) k_solve_light(SweepArgs a, FrameP* frames, float* led_light, double* e_out) {
+    constexpr int NB = ModelTraits<MODEL>::NB;
+    constexpr bool LED = ModelTraits<MODEL>::LED;
+    constexpr int NH = LED ? 3 : NB * (NB + 1) / 2;
+    __shared__ double red[2 * kBlock / 64];
+    if (LED) {
+        // every thread sums the per-frame rows, solves the same 3 scalar equations and updates its own records
+        float dl[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            double hs = 0, bs = 0;
+            for (int ff = 0; ff < a.F; ++ff) { hs += a.acc.frame[(size_t)ff * kFrameRow + ch]; bs += a.acc.frame[(size_t)ff * kFrameRow + NH + ch]; }
+            float h = (float)hs, bb = (float)bs;
+            if (a.damping != 0.0f) h += a.damping * h;
+            double Hd[1] = {(double)h}, bd[1] = {(double)bb}, xd[1];
+            solve_spd<1>(Hd, bd, xd);
+            dl[ch] = (float)xd[0];
+        }
+        for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { const float nl = frames[f].l[ch] - dl[ch]; frames[f].l[ch] = nl; if (f == 0) led_light[ch] = nl; }
+        }
+    } else {
+        for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
+            const double* acc = a.acc.frame + (size_t)f * kFrameRow;
+            double Hd[NB * NB], bd[NB], xd[NB];
+            int q = 0;
+            for (int i = 0; i < NB; ++i) for (int k = i; k < NB; ++k) { double v = (double)(float)acc[q++]; Hd[i * NB + k] = v; Hd[k * NB + i] = v; }
+            for (int i = 0; i < NB; ++i) bd[i] = (double)(float)acc[NH + i];
+            solve_spd<NB>(Hd, bd, xd);
+            for (int i = 0; i < NB; ++i) frames[f].l[i] -= (float)xd[i];
+        }
+    }
+    frame_rows_finish(a, NH + NB, e_out, red);
+}
+void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, hipStream_t s) {
+    if (a.F <= 0) return;
+    dim3 g(1), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_solve_light<0>), g, bl, 0, s, a, frames, led_light, e_out);
+    else if (a.model == 1) hipLaunchKernelGGL((k_solve_light<1>), g, bl, 0, s, a, frames, led_light, e_out);
+    else hipLaunchKernelGGL((k_solve_light<2>), g, bl, 0, s, a, frames, led_light, e_out);
+}
+
+// Sophus SO3::exp(w).matrix() (quaternion exponential + Eigen toRotationMatrix)
+__device__ void so3_exp(const float* w, float* R) {
+    float theta_sq = dot3(w, w);
+    float imag, real;
+    if (theta_sq < 1e-10f) {
+        float theta_po4 = theta_sq * theta_sq;
+        imag = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_po4;
+        real = 1.0f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_po4;
+    } else {
+        float theta = sqrtf(theta_sq), half = 0.5f * theta;
+        imag = sinf(half) / theta; real = cosf(half);
+    }
+    float qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+    float tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+// optimizePosesAll PsOptimizer.cpp:207-234 + updatePose OptimizerAux.cpp:190-205
+__global__ void __launch_bounds__(kBlock) k_solve_pose(SweepArgs a, FrameP* frames, double* e_out) {
+    __shared__ double red[2 * kBlock / 64];
+    for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
+        const double* acc = a.acc.frame + (size_t)f * kFrameRow;
+        double Hd[36], bd[6], xd[6];
+        int q = 0;
+        for (int i = 0; i < 6; ++i) for (int k = i; k < 6; ++k) {
+            float v = (float)acc[q++];
+            if (i == k && a.damping != 0.0f) v += a.damping * v;
+            Hd[i * 6 + k] = (double)v; Hd[k * 6 + i] = (double)v;
+        }
+        for (int i = 0; i < 6; ++i) bd[i] = (double)(float)acc[21 + i];
+        solve_spd<6>(Hd, bd, xd);
+        float xi[6];
+        for (int i = 0; i < 6; ++i) xi[i] = (float)xd[i];
+        float R[9], t[3];
+        for (int i = 0; i < 9; ++i) R[i] = frames[f].R[i];
+        for (int i = 0; i < 3; ++i) t[i] = frames[f].t[i];
+        float mw[3] = {-xi[3], -xi[4], -xi[5]}, E3[9];
+        so3_exp(mw, E3);
+        for (int i = 0; i < 3; ++i) {
+            frames[f].t[i] = t[i] - xi[i];
+            for (int k = 0; k < 3; ++k) frames[f].R[i * 3 + k] = (R[i * 3 + 0] * E3[0 * 3 + k] + R[i * 3 + 1] * E3[1 * 3 + k]) + R[i * 3 + 2] * E3[2 * 3 + k];
+        }
+    }
+    frame_rows_finish(a, 27, e_out, red);
+}
+void launch_solve_pose(const SweepArgs& a, FrameP* frames, double* e_out, hipStream_t s) {
+    if (a.F > 0) hipLaunchKernelGGL(k_solve_pose, dim3(1), dim3(kBlock), 0, s, a, frames, e_out);
+}
+
+}  // namespace psg
