@@ -120,13 +120,17 @@ __global__ void __launch_bounds__(kBlock) k_band_nb(DenseView d, GridP grid, Ban
     long long lin = b.lin[j];
     long long stride[3] = {1, grid.dim[0], (long long)grid.dim[0] * grid.dim[1]};
     float dj = d.dist[lin];
+    int fwd = 0;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         long long ln = lin + ((q & 1) ? -stride[q >> 1] : stride[q >> 1]);
         bool in = ln >= 0 && ln < grid.nvox;
-        b.nb[(size_t)q * b.Spad + j] = in ? d.row_of[ln] : -1;
+        const int r = in ? d.row_of[ln] : -1;
+        b.nb[(size_t)q * b.Spad + j] = r;
         b.nbd[(size_t)q * b.Spad + j] = in ? d.dist[ln] : dj;   // reference reads out of bounds here (UB): use own value
+        if (!(q & 1) && r >= 0) fwd |= 1 << (q >> 1);
     }
+    b.dirb[j] = fwd;
     int dl[kNQ], far = 0;
     for (int q = 0; q < kNQ; ++q) {
         int o[3]; q_offset(q, o);

@@ -195,6 +195,8 @@ void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
 // H = sum_j P_j^T B_j P_j assembled row-wise into 19 fixed column offsets (ELL); a row receives
 // slices from itself, from each lower neighbour (whose forward stencil points at it) and from each
 // upper neighbour whose stencil was forced backward.  Accumulation in LDS (dynamic column index).
+// The loads are arranged in three rounds for ALL seven possible contributors at once (neighbour rows -> their stencil
+// direction bits -> their block entries); a loop over the contributors made 7 x 3 dependent round trips (30 us).
 __global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     __shared__ double acc[kNQ][kBlock];
@@ -204,27 +206,40 @@ __global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
 #pragma unroll
     for (int q = 0; q < kNQ; ++q) acc[q][tid] = 0.0;
     if (i >= a.row1) return;
-    double rhs = 0.0;
-    for (int c = 0; c < 7; ++c) {
-        int jrow, s; int coff[3] = {0, 0, 0};
-        if (c == 0) { jrow = i; s = 0; }
-        else {
-            int ax = (c - 1) >> 1; bool upper = (c - 1) & 1;
-            jrow = b.nb[(size_t)(2 * ax + (upper ? 0 : 1)) * b.Spad + i];
-            if (jrow < 0) continue;
-            if (upper && b.nb[(size_t)(2 * ax) * b.Spad + jrow] >= 0) continue;   // its stencil is forward: does not touch row i
-            s = ax + 1; coff[ax] = upper ? 1 : -1;
-        }
-        int dirj[3];
+    // round 1: the six axis neighbours (contributor 0 is the row itself; 1,2 = x lower / upper; 3,4 = y; 5,6 = z)
+    int jr[7]; jr[0] = i;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dirj[k] = b.nb[(size_t)(2 * k) * b.Spad + jrow] >= 0 ? 1 : -1;
-        rhs += (double)b.blk[(size_t)(10 + s) * b.Spad + jrow];
+    for (int c = 1; c < 7; ++c) { const int ax = (c - 1) >> 1; const bool upper = (c - 1) & 1; jr[c] = b.nb[(size_t)(2 * ax + (upper ? 0 : 1)) * b.Spad + i]; }
+    // round 2: their stencil directions
+    int db[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) db[c] = b.dirb[jr[c] >= 0 ? jr[c] : i];
+    bool use[7]; use[0] = true;
+#pragma unroll
+    for (int c = 1; c < 7; ++c) { const int ax = (c - 1) >> 1; const bool upper = (c - 1) & 1; use[c] = jr[c] >= 0 && !(upper && ((db[c] >> ax) & 1)); }   // an upper neighbour with a forward stencil does not touch row i
+    // round 3: their block entries (row s of the symmetric 4x4 block + rhs entry s)
+    float val[7][4], gr[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        const int s = c == 0 ? 0 : ((c - 1) >> 1) + 1;
+        const int jrow = use[c] ? jr[c] : i;
+        gr[c] = b.blk[(size_t)(10 + s) * b.Spad + jrow];
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) val[c][bq] = b.blk[(size_t)sym4(s, bq) * b.Spad + jrow];
+    }
+    double rhs = 0.0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        if (!use[c]) continue;
+        const int ax = c == 0 ? 0 : (c - 1) >> 1; const bool upper = c > 0 && ((c - 1) & 1);
+        int coff[3] = {0, 0, 0};
+        if (c > 0) coff[ax] = upper ? 1 : -1;
+        rhs += (double)gr[c];
 #pragma unroll
         for (int bq = 0; bq < 4; ++bq) {
             int o[3] = {coff[0], coff[1], coff[2]};
-            if (bq > 0) o[bq - 1] += dirj[bq - 1];
-            float val = b.blk[(size_t)sym4(s, bq) * b.Spad + jrow];
-            if (val != 0.f) acc[q_of(o)][tid] += (double)val;
+            if (bq > 0) o[bq - 1] += ((db[c] >> (bq - 1)) & 1) ? 1 : -1;
+            if (val[c][bq] != 0.f) acc[q_of(o)][tid] += (double)val[c][bq];
         }
     }
     int extra = 0;

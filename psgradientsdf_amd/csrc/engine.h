@@ -50,6 +50,7 @@ struct Band {
     float* rho[3];            // albedo r,g,b
     uint64_t* vis;            // [KW][Spad] keyframe visibility words
     int* nb;                  // [6][Spad] band row of +x,-x,+y,-y,+z,-z neighbour or -1
+    int* dirb;                // [Spad] bit k set: the +k neighbour is in the band, i.e. the stencil of axis k is forward (static)
     float* nbd;               // [6][Spad] distance of that neighbour when it is NOT in the band (static)
     int* col;                 // [kNQ][Spad] band row of each ELL column offset (absent: the row itself)
     unsigned* colp;           // [9][Spad] the same as 16-bit deltas col - row, columns (2w+1, 2w+2) in word w: half the index bytes of a PCG pass

@@ -250,7 +250,7 @@ int build_band(psgsdf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int Spad = ((S + kBlock - 1) / kBlock) * kBlock + kBlock;
     // planes (4-byte units per row): see Band
-    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 4 + 8 + 9;
+    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 4 + 8 + 9 + 1;
     const size_t bytes = (n4 * 4 + (size_t)KW * 8) * Spad + 256;
     if (c->band_mem) { hipFree(c->band_mem); c->band_mem = nullptr; }
     HIPCHK(c, hipMalloc(&c->band_mem, bytes));
@@ -266,7 +266,7 @@ int build_band(psgsdf_ctx* c) {
     b.dist = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.g[a] = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.rho[a] = (float*)take(1, 4);
-    b.nb = (int*)take(6, 4); b.nbd = (float*)take(6, 4); b.col = (int*)take(kNQ, 4); b.colp = (unsigned*)take(9, 4);
+    b.nb = (int*)take(6, 4); b.nbd = (float*)take(6, 4); b.col = (int*)take(kNQ, 4); b.colp = (unsigned*)take(9, 4); b.dirb = (int*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.xs[a] = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.gn[a] = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.gfd[a] = (float*)take(1, 4);
