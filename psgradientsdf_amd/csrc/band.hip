@@ -198,6 +198,7 @@ void launch_upsample(const DenseView& src, const DenseView& dst, const GridP& g_
 __global__ void __launch_bounds__(kBlock) k_derive(SweepArgs a, int update_grad) {
 #pragma clang fp contract(off)
     __shared__ double red[kBlock / 64];
+    if (a.gate && *a.gate == 0.0) return;       // launched speculatively behind a PCG chunk that did not finish the solve
     const Band& b = a.b;
     int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double en = 0, el = 0;

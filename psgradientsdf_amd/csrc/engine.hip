@@ -134,7 +134,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.img32 = (size_t)c->F * c->cam.W * c->cam.H * 12 < ((size_t)1 << 32);
     a.rob.loss = c->set.loss; a.rob.lambda = c->set.lambda; a.rob.lambda_sq = c->set.lambda * c->set.lambda; a.rob.inv_lambda = 1.0f / c->set.lambda;
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
-    a.fold.n = 0;
+    a.fold.n = 0; a.gate = nullptr;
     a.ar = c->ar; a.ar.weight = c->reg_r;
     a.model = c->set.model; a.quirks = c->set.ref_quirks;
     a.reg_n = c->reg_n; a.reg_l = c->reg_l;
@@ -395,8 +395,14 @@ static void cgf_shape(int nblk, int* G, int* rows) {
 
 // Fused PCG (pcg.hip: k_cgf_pass): kernel k finishes pass k-1 and runs pass k, so a chunk of n kernels tells the host
 // about the passes up to k0+n-2; the kernel that detects convergence (or hits the cap) is also the one that finalises x.
-int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_out, double* err_out) {
+// `tail(gate)`, if given, enqueues what follows a finished solve (distance update + regrad) right behind every chunk of passes,
+// gated on the device-side 'solve finished' flag: when the chunk converges -- the normal case -- the GPU runs it without
+// waiting for the host to notice; when it does not, the gated kernels do nothing and the tail is enqueued again behind the
+// next chunk.  *tail_ran tells the caller whether the enqueued tail is the one that took effect.
+int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_out, double* err_out,
+              const std::function<void(const double*)>& tail = nullptr, bool gate_on_converged = true, bool* tail_ran = nullptr) {
     const int S = c->band.S;
+    if (tail_ran) *tail_ran = false;
     if (a.row1 <= a.row0) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }   // empty band: b = 0, x = 0, Success
     int cap = c->set.cg_max_it > 0 ? c->set.cg_max_it : 2 * S;
     if (cap > c->pcg_cap) cap = c->pcg_cap;
@@ -415,6 +421,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         for (int q = 0; q < n; ++q) st[q] = NAN;       // "not published yet" (kernel q of the chunk overwrites its slot)
         for (int q = 0; q < n; ++q)
             timed(c, "pcg_pass", [&] { launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, k + q, cap, c->mbox_dev + off + q, c->stream); });
+        if (tail && c->pcg_poll && !c->profiling) { tail(c->pcg_sc + (gate_on_converged ? 2 : 1)); if (tail_ran) *tail_ran = true; }
         // Watch the mapped slots instead of waiting for the stream to drain: the kernel that detects convergence publishes
         // at its START, so the host learns the outcome while that kernel and the surplus (no-op) kernels of the chunk are
         // still running, and enqueues the rest of the iteration behind them without a bubble.
@@ -574,14 +581,20 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
             take_fold(c, a, 0u);
             timed(c, "assemble", [&] { launch_assemble(a, c->stream); });
             int iters = 0, ok = 1; double err = 0;
-            if ((rc = pcg_solve(c, a, &iters, &ok, &err))) return rc;
-            int apply = 1;
-            if (!led && c->set.ref_quirks && !ok) apply = 0;   // PsOptimizer.cpp:168-170 (B8)
-            if (apply) {
-                timed(c, "apply_dist", [&] { launch_apply_dist(a, c->stream); });
-                // regrad + Eikonal / Laplacian sums; one read-back for the accepted count and the two sums
-                SweepArgs a2 = make_args(c, 0);
+            const bool only_on_success = !led && c->set.ref_quirks;   // PsOptimizer.cpp:168-170 (B8): SH skips the update unless the solve reports Success
+            bool tail_ran = false;
+            auto tail = [&](const double* gate) {                     // distance update + regrad, gated on the device-side outcome of the solve
+                SweepArgs ag = a; ag.fold.n = 0; ag.gate = gate;
+                timed(c, "apply_dist", [&] { launch_apply_dist(ag, c->stream); });
+                SweepArgs a2 = make_args(c, 0); a2.gate = gate;
                 timed(c, "derive", [&] { launch_derive(a2, 1, c->stream); });
+            };
+            if ((rc = pcg_solve(c, a, &iters, &ok, &err, tail, only_on_success, &tail_ran))) return rc;
+            int apply = 1;
+            if (only_on_success && !ok) apply = 0;
+            if (apply) {
+                if (!tail_ran) tail(nullptr);
+                // regrad + Eikonal / Laplacian sums; one read-back for the accepted count and the two sums
                 const int slots[3] = {SC_ACCEPT, SC_EN, SC_EL}; double s[3];
                 if (defer_reg_sums) { if ((rc = read_parts_deferred(c, slots, 3, [c](const double* v) { c->en_sum = v[1]; c->el_sum = v[2]; }))) return rc; }
                 else { if ((rc = read_parts(c, slots, 3, s))) return rc; st->n_accepted = (int64_t)s[0]; c->en_sum = s[1]; c->el_sum = s[2]; }

@@ -18,7 +18,7 @@ __device__ __forceinline__ float pcg_threshold(float rhsNorm2) { return fmaxf(FL
 // p = z + beta p are applied lazily in float exactly as the reference does them: kernel k first finishes pass k-1 for its
 // own rows, and re-derives r_k, z_k, p_k of every gathered column from that column's record {r, t, p, inv} of pass k-1
 // (ONE 16-byte gather per column; records double-buffered because neighbours still read the old ones).
-//   fs (device doubles): [0] |b|^2   [1] done (0 = running)
+//   fs (device doubles): [0] |b|^2   [1] done (0 = running, else stopping kernel + 1)   [2] 1 if it stopped because it converged
 //   part: [2 parity][kCgfSums][kPcgMaxBlocks] per-workgroup partial sums, summed in a fixed order by every workgroup of
 //         the next kernel (deterministic, no atomics)
 //   mb  : slot of THIS kernel (mapped host memory on one GPU): k = 0 -> |b|^2, k > 0 -> |r|^2 after pass k-1
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(kBlock) k_cgf_init(SweepArgs a, double* fs, do
         bb += (double)r * (double)r;
     }
     block_part_store(bb, fpart(part, -1, 6), red);
-    if (blockIdx.x == 0 && threadIdx.x == 0) fs[1] = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { fs[1] = 0.0; fs[2] = 0.0; }
 }
 void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s) {
     if (a.row1 > a.row0) hipLaunchKernelGGL(k_cgf_init, dim3(G), dim3(kBlock), 0, s, a, fs, part);
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
     CGF_STAMP(2);
     const bool rhs_zero = rhsNorm2 == 0.f;
     const bool stop = !(ab & 16) && (rhs_zero || k == kmax || (k > 0 && rr_cur < pcg_threshold(rhsNorm2)));
-    if (stop && blockIdx.x == 0 && threadIdx.x == 0) fs[1] = (double)(k + 1);
+    if (stop && blockIdx.x == 0 && threadIdx.x == 0) { fs[1] = (double)(k + 1); fs[2] = (rhs_zero || sqrt((double)rr_cur / (double)rhsNorm2) <= (double)FLT_EPSILON) ? 1.0 : 0.0; }   // fs[2]: Eigen's info() == Success, the host's rule (engine.hip: pcg_solve)
     double s[kCgfSums];
 #pragma unroll
     for (int q = 0; q < kCgfSums; ++q) s[q] = 0;
@@ -334,6 +334,7 @@ void launch_matvec(const SweepArgs& a, const float* x, float* y, hipStream_t s) 
 // updateDist accept rule OptimizerAux.cpp:162-188
 __global__ void __launch_bounds__(kBlock) k_apply_dist(SweepArgs a) {
     __shared__ double red[kBlock / 64];
+    if (a.gate && *a.gate == 0.0) return;       // launched speculatively behind a PCG chunk that did not finish the solve
     const Band& b = a.b;
     int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double cnt = 0;
