@@ -1,0 +1,345 @@
+// api.hip -- the C ABI of include/psgsdf.h: context, volume, keyframes, init, energies, steps, loops, downloads.
+#include "engine_internal.h"
+
+using namespace psge;
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+extern "C" {
+
+const char* psgsdf_version(void) { return "psgsdf-hip gfx950 r1"; }
+const char* psgsdf_last_error(const psgsdf_ctx* c) { return c ? c->err : "null context"; }
+
+int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_settings* settings, int device, psgsdf_ctx** out) {
+    if (!grid || !K || !settings || !out) return PSGSDF_ERR_ARG;
+    if (settings->model < 0 || settings->model > 2) return PSGSDF_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PSGSDF_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return PSGSDF_ERR_DEVICE;
+    psgsdf_ctx* c = new psgsdf_ctx();
+    c->device = device;
+    if (const char* e = getenv("PSGSDF_PCG_POLL")) c->pcg_poll = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_FOLD_IN_NEXT")) c->fold_in_next = atoi(e) != 0;
+    c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l; c->reg_r = settings->reg_weight_rho;
+    GridP& g = c->grid;
+    for (int a = 0; a < 3; ++a) { g.dim[a] = grid->dim[a]; c->shift[a] = grid->shift[a]; }
+    g.nvox = (long long)g.dim[0] * g.dim[1] * g.dim[2];
+    g.vs = grid->voxel_size; g.vs_inv = 1.f / g.vs; g.T = grid->truncation;
+    for (int a = 0; a < 3; ++a) g.origin[a] = c->shift[a] - (float)(0.5 * (double)g.vs) * (float)g.dim[a];   // VoxelGrid.h:130
+    c->cam.fx = K[0]; c->cam.fy = K[4]; c->cam.cx = K[2]; c->cam.cy = K[5];
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess
+        && hipMalloc(&c->pcg_sc, sizeof(double) * (16 + 8 * (size_t)kPcgMaxBlocks)) == hipSuccess   // fs[0..1] + stage stamps of the timing hook
+        && hipMalloc(&c->pcg_part, sizeof(double) * 14 * kPcgMaxBlocks) == hipSuccess
+        && hipMalloc(&c->mg_scal, sizeof(double) * kMgScal) == hipSuccess && hipMalloc(&c->mg_ext, sizeof(double) * 8) == hipSuccess
+        && hipMalloc(&c->mg_hist, sizeof(double) * ((size_t)c->pcg_cap + 2)) == hipSuccess && hipMalloc(&c->d_need, 2 * sizeof(int)) == hipSuccess
+        && hipMalloc(&c->mg_slots, sizeof(int) * 8) == hipSuccess
+        && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess
+        && hipMalloc(&c->led_light, sizeof(float) * 3) == hipSuccess
+        && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    if (!ok) { delete c; return PSGSDF_ERR_DEVICE; }
+    *out = c;
+    return PSGSDF_OK;
+}
+
+void psgsdf_destroy(psgsdf_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    free_dense(c);
+    hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->frames); hipFree(c->led_light);
+    hipFree(c->band_mem); hipFree(c->obs_mem); hipFree(c->stage);
+    hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->d_total);
+    if (c->host_buf) hipHostFree(c->host_buf);
+    if (c->mbox) hipHostFree(c->mbox);
+    if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
+    for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    hipFree(c->areg_mem); hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mg_hist); hipFree(c->d_need); hipFree(c->mg_slots);
+    if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int psgsdf_upload_volume(psgsdf_ctx* c, const float* dist, const float* grad_xyz, const float* weight, const float* rgb, const uint64_t* vis_words, int words_per_voxel) {
+    if (!c || !dist || !grad_xyz || !weight || !rgb || !vis_words || words_per_voxel < 1) return fail(c, PSGSDF_ERR_ARG, "upload_volume: null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long n = c->grid.nvox;
+    free_dense(c);
+    if (c->vis_seq) { hipFree(c->vis_seq); c->vis_seq = nullptr; }
+    int rc = alloc_dense(c, c->dense, n, 0, true); if (rc) return rc;
+    HIPCHK(c, hipMalloc(&c->vis_seq, sizeof(uint64_t) * n * words_per_voxel));
+    c->wpv_seq = words_per_voxel;
+    HIPCHK(c, hipMemcpyAsync(c->dense.dist, dist, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    for (int a = 0; a < 3; ++a) {
+        HIPCHK(c, hipMemcpyAsync(c->dense.g[a], grad_xyz + (size_t)a * n, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dense.rho[a], rgb + (size_t)a * n, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->dense.weight, weight, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->vis_seq, vis_words, sizeof(uint64_t) * n * words_per_voxel, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_volume = true; c->inited = false;
+    return PSGSDF_OK;
+}
+
+int psgsdf_volume_init(psgsdf_ctx* c, int max_frames) {
+    if (!c || max_frames < 1) return fail(c, PSGSDF_ERR_ARG, "volume_init: max_frames");
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long n = c->grid.nvox;
+    free_dense(c);
+    if (c->vis_seq) { hipFree(c->vis_seq); c->vis_seq = nullptr; }
+    int rc = alloc_dense(c, c->dense, n, 0, true); if (rc) return rc;
+    c->wpv_seq = (max_frames + 63) / 64;
+    HIPCHK(c, hipMalloc(&c->vis_seq, sizeof(uint64_t) * n * c->wpv_seq));
+    launch_fill_f32(c->dense.dist, c->grid.T, n, c->stream);
+    for (int a = 0; a < 3; ++a) { HIPCHK(c, hipMemsetAsync(c->dense.g[a], 0, sizeof(float) * n, c->stream)); HIPCHK(c, hipMemsetAsync(c->dense.rho[a], 0, sizeof(float) * n, c->stream)); }
+    HIPCHK(c, hipMemsetAsync(c->dense.weight, 0, sizeof(float) * n, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->vis_seq, 0, sizeof(uint64_t) * n * c->wpv_seq, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_volume = true; c->inited = false;
+    return PSGSDF_OK;
+}
+
+int psgsdf_integrate_frame(psgsdf_ctx* c, const float* rgb, const float* depth, const float* normals_xyz, int width, int height, const float pose[16], int counter, float z_min, float z_max) {
+    if (!c || !c->have_volume || !c->vis_seq) return fail(c, PSGSDF_ERR_STATE, "integrate_frame: volume_init or upload_volume first");
+    if (!rgb || !depth || !normals_xyz || !pose || width < 2 || height < 2 || counter < 0 || counter >= 64 * c->wpv_seq) return fail(c, PSGSDF_ERR_ARG, "integrate_frame: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npx = (size_t)width * height;
+    if (c->stage_px < npx) {
+        hipFree(c->stage); c->stage = nullptr; c->stage_px = 0;
+        HIPCHK(c, hipMalloc(&c->stage, sizeof(float) * npx * 7));
+        c->stage_px = npx;
+    }
+    float* d_rgb = c->stage; float* d_depth = c->stage + 3 * npx; float* d_nrm = c->stage + 4 * npx;
+    HIPCHK(c, hipMemcpyAsync(d_rgb, rgb, sizeof(float) * 3 * npx, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_depth, depth, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_nrm, normals_xyz, sizeof(float) * 3 * npx, hipMemcpyHostToDevice, c->stream));
+    Cam cam = c->cam; cam.W = width; cam.H = height;
+    FrameP fp{};
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) fp.R[i * 3 + j] = pose[i * 4 + j]; fp.t[i] = pose[i * 4 + 3]; }
+    timed(c, "integrate_frame", [&] { launch_integrate(c->dense, c->vis_seq, c->wpv_seq, c->grid, cam, fp, d_rgb, d_depth, d_nrm, counter, z_min, z_max, c->stream); });
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->inited = false;
+    return PSGSDF_OK;
+}
+
+int psgsdf_set_keyframes(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_images, int width, int height, const float* poses) {
+    if (!c || n_frames <= 0 || !frame_idx || !rgb_images || !poses || width <= 1 || height <= 1) return fail(c, PSGSDF_ERR_ARG, "set_keyframes: bad argument");
+    if (n_frames > kMaxFramesLds) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d keyframes", kMaxFramesLds);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipFree(c->frame_idx); hipFree(c->img); hipFree(c->frames); hipFree(c->acc_frame);
+    c->frame_idx = nullptr; c->img = nullptr; c->frames = nullptr; c->acc_frame = nullptr;
+    c->F = n_frames; c->cam.W = width; c->cam.H = height;
+    const size_t npx = (size_t)n_frames * width * height * 3;
+    HIPCHK(c, hipMalloc(&c->frame_idx, sizeof(int) * n_frames));
+    HIPCHK(c, hipMalloc(&c->img, sizeof(float) * npx));
+    HIPCHK(c, hipMalloc(&c->frames, sizeof(FrameP) * n_frames));
+    c->acc_frame_n = (size_t)n_frames * 64;
+    HIPCHK(c, hipMalloc(&c->acc_frame, sizeof(double) * c->acc_frame_n));
+    HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));   // invariant: zero outside [sweep, solve]
+    HIPCHK(c, hipMemcpyAsync(c->frame_idx, frame_idx, sizeof(int) * n_frames, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->img, rgb_images, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
+    c->frames_h.assign(n_frames, FrameP{});
+    for (int f = 0; f < n_frames; ++f) {
+        const float* P = poses + 16 * f;
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) c->frames_h[f].R[i * 3 + j] = P[i * 4 + j]; c->frames_h[f].t[i] = P[i * 4 + 3]; }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->frames, c->frames_h.data(), sizeof(FrameP) * n_frames, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_frames = true; c->inited = false;
+    return PSGSDF_OK;
+}
+
+int psgsdf_init(psgsdf_ctx* c) {
+    if (!c || !c->have_volume || !c->have_frames) return fail(c, PSGSDF_ERR_STATE, "init: upload_volume and set_keyframes first");
+    if (!c->vis_seq) return fail(c, PSGSDF_ERR_STATE, "init: volume was refined; upload it again");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int KW = (c->F + 63) / 64;
+    if (c->dense.vis) { hipFree(c->dense.vis); c->dense.vis = nullptr; }
+    HIPCHK(c, hipMalloc(&c->dense.vis, sizeof(uint64_t) * c->grid.nvox * KW));
+    c->dense.KW = KW;
+    timed(c, "select_vis", [&] { launch_select_vis(c->vis_seq, c->wpv_seq, c->dense.vis, KW, c->frame_idx, c->F, c->grid.nvox, c->stream); });
+    int rc = build_band(c); if (rc) return rc;
+    // light initialisation: PsOptimizer.cpp:30-37 l = SH(R*(0,0,-1)), l[0] = 0.02 ; LED: ones, then intensity ratio
+    const bool led = c->set.model == PSGSDF_LED;
+    for (int f = 0; f < c->F; ++f) {
+        FrameP& fp = c->frames_h[f];
+        for (int i = 0; i < 9; ++i) fp.l[i] = 0.f;
+        if (led) { fp.l[0] = fp.l[1] = fp.l[2] = 1.0f; continue; }
+        float n[3];
+        for (int i = 0; i < 3; ++i) n[i] = (fp.R[i * 3 + 0] * 0.0f + fp.R[i * 3 + 1] * 0.0f) + fp.R[i * 3 + 2] * -1.0f;
+        fp.l[0] = 0.02f; fp.l[1] = n[0]; fp.l[2] = n[1]; fp.l[3] = n[2];
+        if (c->set.model == PSGSDF_SH2) { fp.l[4] = n[0] * n[1]; fp.l[5] = n[0] * n[2]; fp.l[6] = n[1] * n[2]; fp.l[7] = n[0] * n[0] - n[1] * n[1]; fp.l[8] = n[0] * n[0] - n[2] * n[2]; }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->frames, c->frames_h.data(), sizeof(FrameP) * c->F, hipMemcpyHostToDevice, c->stream));
+    if ((rc = derive(c, 0))) return rc;
+    if (led && c->n_ranks == 1) {   // computeLightIntensive, LedOptimizer.cpp:76-112 (multi-rank: phases MG_LED_SUMS / MG_LED_SET)
+        SweepArgs a = make_args(c, 0);
+        timed(c, "led_light_init", [&] { launch_led_light_init(a, c->stream); });
+        const int slots[6] = {SC_AUX0, SC_AUX1, SC_AUX2, SC_EN, SC_EL, SC_ACCEPT}; double s[6];
+        if ((rc = read_parts(c, slots, 6, s))) return rc;
+        float L[3] = {(float)s[0] / (float)s[3], (float)s[1] / (float)s[4], (float)s[2] / (float)s[5]};
+        std::vector<FrameP> fr(c->F);
+        HIPCHK(c, hipMemcpy(fr.data(), c->frames, sizeof(FrameP) * c->F, hipMemcpyDeviceToHost));
+        for (int f = 0; f < c->F; ++f) for (int ch = 0; ch < 3; ++ch) fr[f].l[ch] = L[ch];
+        HIPCHK(c, hipMemcpy(c->frames, fr.data(), sizeof(FrameP) * c->F, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->led_light, L, sizeof(L), hipMemcpyHostToDevice));
+        if ((rc = derive(c, 0))) return rc;   // restores the cached Eikonal / Laplacian sums
+    }
+    c->inited = true;
+    return PSGSDF_OK;
+}
+
+int psgsdf_init_albedo(psgsdf_ctx* c) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SweepArgs a = make_args(c, 0);
+    timed(c, "init_albedo", [&] { launch_init_albedo(a, c->stream); });
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSGSDF_OK;
+}
+
+int psgsdf_energy(psgsdf_ctx* c, double out[4]) {
+    if (!c || !c->inited || !out) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    double E; int rc = ps_energy(c, &E, nullptr); if (rc) return rc;
+    out[0] = E; out[1] = band_mean(c, c->en_sum); out[2] = band_mean(c, c->el_sum);
+    double er = 0; if (c->reg_r != 0.f && (rc = albedo_reg_energy(c, &er))) return rc;
+    out[3] = (double)total_energy(c, (float)out[0], c->reg_n != 0.f ? (float)out[1] : 0.f, c->reg_l != 0.f ? (float)out[2] : 0.f, (float)er);
+    return PSGSDF_OK;
+}
+
+int psgsdf_normalize_weights(psgsdf_ctx* c, double* e_total) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;
+    float E = (float)e, E_n = 0, E_l = 0;
+    if (c->reg_n != 0.f) { E_n = (float)band_mean(c, c->en_sum); c->reg_n *= E / E_n; }   // PsOptimizer.cpp:275-278
+    if (c->reg_l != 0.f) { E_l = (float)band_mean(c, c->el_sum); c->reg_l *= E / E_l; }   // PsOptimizer.cpp:281-284
+    double er = 0; if (c->reg_r != 0.f && (rc = albedo_reg_energy(c, &er))) return rc;   // reg_rho is not normalised (PsOptimizer.cpp:279)
+    if (e_total) *e_total = (double)total_energy(c, E, E_n, E_l, (float)er);
+    return PSGSDF_OK;
+}
+
+int psgsdf_step(psgsdf_ctx* c, int block, psgsdf_step_stats* stats) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    return do_step(c, block, c->reg_l != 0.f, stats);
+}
+
+int psgsdf_iterate(psgsdf_ctx* c, int flags, int n_iters, psgsdf_iter_stats* stats) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;
+    LoopState L{};
+    L.E = (float)e;
+    L.E_n = c->reg_n != 0.f ? (float)band_mean(c, c->en_sum) : 0.f; L.E_l = c->reg_l != 0.f ? (float)band_mean(c, c->el_sum) : 0.f;
+    if (c->reg_r != 0.f) { double er; if ((rc = albedo_reg_energy(c, &er))) return rc; L.E_r = (float)er; }
+    L.E_prev = total_energy(c, L.E, L.E_n, L.E_l, L.E_r);
+    L.laplacian_reg = c->reg_l != 0.f;
+    int done = 0;
+    return run_loop(c, flags, L, n_iters, false, stats, stats ? n_iters : 0, &done, nullptr, nullptr, nullptr);
+}
+
+int psgsdf_optimize(psgsdf_ctx* c, int flags, psgsdf_iter_stats* stats, int stats_cap, int* n_done, int* result, psgsdf_iter_cb on_iter, void* user) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    LoopState L{};
+    L.laplacian_reg = c->reg_l != 0.f;
+    int rc = psgsdf_init_albedo(c); if (rc) return rc;
+    double e; if ((rc = ps_energy(c, &e, nullptr))) return rc;
+    L.E = (float)e;
+    if (c->reg_n != 0.f) { L.E_n = (float)band_mean(c, c->en_sum); c->reg_n *= L.E / L.E_n; }                                             // PsOptimizer.cpp:275-278
+    if (L.laplacian_reg) { L.E_l = (float)band_mean(c, c->el_sum); c->reg_l *= L.E / L.E_l; if (c->set.upsample) L.laplacian_reg = 0; }   // :281-285
+    if (c->reg_r != 0.f) { double er; if ((rc = albedo_reg_energy(c, &er))) return rc; L.E_r = (float)er; }   // PsOptimizer.cpp:279
+    L.E_prev = total_energy(c, L.E, L.E_n, L.E_l, L.E_r);
+    return run_loop(c, flags, L, c->set.max_it, true, stats, stats_cap, n_done, result, on_iter, user);
+}
+
+int psgsdf_upsample2x(psgsdf_ctx* c) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    return do_upsample(c);
+}
+
+int psgsdf_get_info(psgsdf_ctx* c, psgsdf_info* info) {
+    if (!c || !info) return PSGSDF_ERR_ARG;
+    for (int a = 0; a < 3; ++a) { info->dim[a] = c->grid.dim[a]; info->origin[a] = c->grid.origin[a]; }
+    info->voxel_size = c->grid.vs; info->n_frames = c->F; info->n_band = c->inited ? c->band.S : 0;
+    info->light_stride = c->set.model == PSGSDF_LED ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4);
+    info->vis_words = c->dense.KW; info->reg_weight_n = c->reg_n; info->reg_weight_l = c->reg_l;
+    return PSGSDF_OK;
+}
+
+int psgsdf_download_volume(psgsdf_ctx* c, float* dist, float* grad_xyz, float* weight, float* rgb, uint64_t* vis_words) {
+    if (!c || !c->have_volume) return fail(c, PSGSDF_ERR_STATE, "no volume");
+    HIPCHK(c, hipSetDevice(c->device));
+    const long long n = c->grid.nvox;
+    if (c->inited) launch_band_scatter(c->dense, c->band, c->stream);
+    if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->dense.dist, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    for (int a = 0; a < 3; ++a) {
+        if (grad_xyz) HIPCHK(c, hipMemcpyAsync(grad_xyz + (size_t)a * n, c->dense.g[a], sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+        if (rgb) HIPCHK(c, hipMemcpyAsync(rgb + (size_t)a * n, c->dense.rho[a], sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (weight) HIPCHK(c, hipMemcpyAsync(weight, c->dense.weight, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    if (vis_words) {
+        if (!c->dense.vis) return fail(c, PSGSDF_ERR_STATE, "visibility not selected yet");
+        HIPCHK(c, hipMemcpyAsync(vis_words, c->dense.vis, sizeof(uint64_t) * n * c->dense.KW, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSGSDF_OK;
+}
+
+int psgsdf_download_vis_seq(psgsdf_ctx* c, uint64_t* out) {
+    if (!c || !c->vis_seq || !out) return PSGSDF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(out, c->vis_seq, sizeof(uint64_t) * c->grid.nvox * c->wpv_seq, hipMemcpyDeviceToHost));
+    return c->wpv_seq;
+}
+
+int psgsdf_download_band(psgsdf_ctx* c, int32_t* lin_idx) {
+    if (!c || !c->inited || !lin_idx) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(lin_idx, c->band.lin, sizeof(int) * c->band.S, hipMemcpyDeviceToHost));
+    return PSGSDF_OK;
+}
+
+int psgsdf_download_poses(psgsdf_ctx* c, float* poses) {
+    if (!c || !c->have_frames || !poses) return fail(c, PSGSDF_ERR_STATE, "no keyframes");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<FrameP> fr(c->F);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(fr.data(), c->frames, sizeof(FrameP) * c->F, hipMemcpyDeviceToHost));
+    for (int f = 0; f < c->F; ++f) {
+        float* P = poses + 16 * f;
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) P[i * 4 + j] = fr[f].R[i * 3 + j]; P[i * 4 + 3] = fr[f].t[i]; }
+        P[12] = P[13] = P[14] = 0.f; P[15] = 1.f;
+    }
+    return PSGSDF_OK;
+}
+
+int psgsdf_download_light(psgsdf_ctx* c, float* light) {
+    if (!c || !c->inited || !light) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<FrameP> fr(c->F);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(fr.data(), c->frames, sizeof(FrameP) * c->F, hipMemcpyDeviceToHost));
+    if (c->set.model == PSGSDF_LED) { for (int ch = 0; ch < 3; ++ch) light[ch] = fr[0].l[ch]; return PSGSDF_OK; }
+    const int nb = c->set.model == PSGSDF_SH2 ? 9 : 4;
+    for (int f = 0; f < c->F; ++f) for (int i = 0; i < nb; ++i) light[(size_t)f * nb + i] = fr[f].l[i];
+    return PSGSDF_OK;
+}
+
+int psgsdf_upload_light(psgsdf_ctx* c, const float* light) {
+    if (!c || !c->inited || !light) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<FrameP> fr(c->F);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(fr.data(), c->frames, sizeof(FrameP) * c->F, hipMemcpyDeviceToHost));
+    const bool led = c->set.model == PSGSDF_LED;
+    const int nb = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4);
+    for (int f = 0; f < c->F; ++f) for (int i = 0; i < nb; ++i) fr[f].l[i] = led ? light[i] : light[(size_t)f * nb + i];
+    HIPCHK(c, hipMemcpy(c->frames, fr.data(), sizeof(FrameP) * c->F, hipMemcpyHostToDevice));
+    if (led) HIPCHK(c, hipMemcpy(c->led_light, light, sizeof(float) * 3, hipMemcpyHostToDevice));
+    return PSGSDF_OK;
+}
+
+}  // extern "C"

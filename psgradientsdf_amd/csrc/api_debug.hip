@@ -1,0 +1,138 @@
+// api_debug.hip -- measurement and test hooks (not part of the reference seam).
+#include "engine_internal.h"
+
+using namespace psge;
+
+extern "C" {
+// ---- measurement / test hooks -------------------------------------------------------------
+int psgsdf_set_profiling(psgsdf_ctx* c, int enabled) { if (!c) return PSGSDF_ERR_ARG; c->profiling = enabled != 0; return PSGSDF_OK; }
+int psgsdf_reset_kernel_times(psgsdf_ctx* c) { if (!c) return PSGSDF_ERR_ARG; c->ktimes.clear(); c->watch_used = 0; return PSGSDF_OK; }
+int psgsdf_watch_kernel(psgsdf_ctx* c, const char* name) {
+    if (!c) return PSGSDF_ERR_ARG;
+    hipStreamSynchronize(c->stream);
+    // "name" or "name/N": HIP events around every N-th launch of that kernel (default every launch)
+    std::string w = name ? name : ""; int every = 1;
+    const size_t sl = w.find('/');
+    if (sl != std::string::npos) { every = std::max(1, atoi(w.c_str() + sl + 1)); w.resize(sl); }
+    c->watch = w; c->watch_every = every; c->watch_seen = 0; c->watch_used = 0;
+    return PSGSDF_OK;
+}
+int psgsdf_kernel_times(psgsdf_ctx* c, const char** names, double* ms, int64_t* launches, int cap) {
+    if (!c) return 0;
+    if (c->watch_used) {   // resolve the asynchronous event pairs of the watched kernel
+        hipStreamSynchronize(c->stream);
+        KTime& k = c->ktimes[c->watch];
+        for (size_t i = 0; i < c->watch_used; ++i) { float t = 0; if (hipEventElapsedTime(&t, c->watch_pool[i].first, c->watch_pool[i].second) == hipSuccess) { k.ms += t; k.n += 1; } }
+        c->watch_used = 0;
+    }
+    int n = 0;
+    for (auto& kv : c->ktimes) { if (n >= cap) break; names[n] = kv.first.c_str(); ms[n] = kv.second.ms; launches[n] = kv.second.n; ++n; }
+    return n;
+}
+
+int psgsdf_debug_dist_system(psgsdf_ctx* c, float* diag, float* rhs, const float* x, float* y) {
+    if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SweepArgs a = make_args(c, c->reg_l != 0.f);
+    launch_sweep_dist(a, c->stream);
+    launch_assemble(a, c->stream);
+    const int S = c->band.S;
+    if (diag) HIPCHK(c, hipMemcpyAsync(diag, c->band.H, sizeof(float) * S, hipMemcpyDeviceToHost, c->stream));
+    if (rhs) HIPCHK(c, hipMemcpyAsync(rhs, c->band.rhs, sizeof(float) * S, hipMemcpyDeviceToHost, c->stream));
+    if (x && y) {
+        HIPCHK(c, hipMemcpyAsync(c->band.x, x, sizeof(float) * S, hipMemcpyHostToDevice, c->stream));
+        launch_matvec(a, c->band.x, c->band.t, c->stream);
+        HIPCHK(c, hipMemcpyAsync(y, c->band.t, sizeof(float) * S, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSGSDF_OK;
+}
+
+// timing ablations of the PCG pass (tools/pcg_ablate.py): `reps` launches of k_cgf_pass with the given grid and ablation
+// bits on the current (already assembled) distance system; results of the solve are garbage afterwards
+int psgsdf_debug_time_pcg_pass(psgsdf_ctx* c, int blocks, int rows, int ablate, int reps, double* avg_ms, long long* stamps) {
+    if (!c || !c->inited || !avg_ms) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SweepArgs a = make_args(c, c->reg_l != 0.f);
+    launch_sweep_dist(a, c->stream);
+    launch_assemble(a, c->stream);
+    int G, rdef; cgf_shape(band_blocks(c), &G, &rdef);
+    if (blocks > 0) G = std::min(blocks, kCgfMaxBlocks);
+    if (rows <= 0) rows = rdef;
+    launch_cgf_init(a, c->pcg_sc, c->pcg_part, G, c->stream);
+    hipEvent_t e0, e1; HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    for (int q = 0; q < 3; ++q) launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, q, 1 << 30, c->mbox_dev, c->stream, ablate | 16);
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int q = 0; q < reps; ++q) launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, 3 + q, 1 << 30, c->mbox_dev, c->stream, ablate | 16);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *avg_ms = (double)ms / reps;
+    if (stamps) {   // [G][8] wall-clock ticks (100 MHz) of the LAST launch, taken with ablate | 1024
+        HIPCHK(c, hipMemcpy(stamps, c->pcg_sc + 16, sizeof(long long) * 8 * G, hipMemcpyDeviceToHost));
+    }
+    return PSGSDF_OK;
+}
+
+// how many rows of the assembled distance system carry any of the 6 "rare" ELL columns, and how many 64-row groups
+// (wavefronts of a one-row-per-thread launch) contain such a row
+int psgsdf_debug_rare_rows(psgsdf_ctx* c, int64_t* rows, int64_t* waves) {
+    if (!c || !c->inited || !rows || !waves) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SweepArgs a = make_args(c, c->reg_l != 0.f);
+    launch_sweep_dist(a, c->stream);
+    launch_assemble(a, c->stream);
+    std::vector<int> hx(c->band.S);
+    HIPCHK(c, hipMemcpyAsync(hx.data(), c->band.hx, sizeof(int) * hx.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *rows = 0; *waves = 0;
+    for (size_t i = 0; i < hx.size(); i += 64) { bool any = false; for (size_t k = i; k < std::min(hx.size(), i + 64); ++k) if (hx[k]) { ++*rows; any = true; } *waves += any; }
+    return PSGSDF_OK;
+}
+
+int psgsdf_debug_frame_system(psgsdf_ctx* c, int block, double* H, double* b) {
+    if (!c || !c->inited || !H || !b) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
+    SweepArgs a = make_args(c, 0);
+    const bool led = c->set.model == PSGSDF_LED;
+    int n, nb, nh;
+    if (block == PSGSDF_LIGHT) { launch_sweep_light(a, c->stream); n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4); nb = led ? 1 : c->F; nh = led ? 3 : n * (n + 1) / 2; }
+    else if (block == PSGSDF_POSE) { launch_sweep_pose(a, c->stream); n = 6; nb = c->F; nh = 21; }
+    else return fail(c, PSGSDF_ERR_ARG, "block must be LIGHT or POSE");
+    std::vector<double> acc(c->acc_frame_n);
+    HIPCHK(c, hipMemcpyAsync(acc.data(), c->acc_frame, sizeof(double) * c->acc_frame_n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (led && block == PSGSDF_LIGHT) {   // one global system: sum the per-frame rows
+        for (int i = 0; i < 9; ++i) H[i] = 0;
+        for (int i = 0; i < 3; ++i) { b[i] = 0; for (int f = 0; f < c->F; ++f) { H[i * 3 + i] += acc[(size_t)f * kFrameRow + i]; b[i] += acc[(size_t)f * kFrameRow + 3 + i]; } }
+        return PSGSDF_OK;
+    }
+    for (int k = 0; k < nb; ++k) {
+        const double* A = acc.data() + (size_t)k * kFrameRow;
+        double* Hk = H + (size_t)k * n * n; double* bk = b + (size_t)k * n;
+        for (int i = 0; i < n * n; ++i) Hk[i] = 0;
+        int q = 0;
+        for (int i = 0; i < n; ++i) for (int j = i; j < n; ++j) { Hk[i * n + j] = A[q]; Hk[j * n + i] = A[q]; ++q; }
+        for (int i = 0; i < n; ++i) bk[i] = A[nh + i];
+    }
+    return PSGSDF_OK;
+}
+
+int psgsdf_debug_albedo_system(psgsdf_ctx* c, float* H, float* b) {
+    if (!c || !c->inited || !H || !b) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    SweepArgs a = make_args(c, 0);
+    launch_sweep_albedo(a, c->stream);
+    const int S = c->band.S, Sp = c->band.Spad;
+    std::vector<float> h(3 * (size_t)Sp), bb(3 * (size_t)Sp);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->band.aH, sizeof(float) * 3 * Sp, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(bb.data(), c->band.ab, sizeof(float) * 3 * Sp, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int j = 0; j < S; ++j) for (int ch = 0; ch < 3; ++ch) { H[3 * j + ch] = h[(size_t)ch * Sp + j]; b[3 * j + ch] = bb[(size_t)ch * Sp + j]; }
+    return PSGSDF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// api_frontend.hip -- C ABI of the state producers next to the hot path: FALS normals and the depth tracker.
+#include "engine_internal.h"
+
+using namespace psge;
+
+// ---- front end: FALS normals and depth tracker -------------------------------------------
+namespace {
+inline int reflect101_h(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * n - 2 - i; } return i; }
+void box_filter_h(const std::vector<double>& src, std::vector<double>& dst, int W, int H, int r) {
+    std::vector<double> tmp((size_t)W * H);
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) { double s = 0; for (int k = -r; k <= r; ++k) s += src[(size_t)y * W + reflect101_h(x + k, W)]; tmp[(size_t)y * W + x] = s; }
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) { double s = 0; for (int k = -r; k <= r; ++k) s += tmp[(size_t)reflect101_h(y + k, H) * W + x]; dst[(size_t)y * W + x] = s; }
+}
+// NormalEstimator::cache (NormalEstimator.h:52-125), once per image size: double on the host, 9 float planes on the device
+int normals_cache(psgsdf_ctx* c, int W, int H) {
+    if (c->ncache && c->ncache_w == W && c->ncache_h == H) return 0;
+    const size_t n = (size_t)W * H;
+    hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); c->ncache = nullptr; c->ntmp = nullptr; c->nout = nullptr; c->ndepth = nullptr;
+    std::vector<double> a[6], M[6]; for (int i = 0; i < 6; ++i) { a[i].resize(n); M[i].resize(n); }
+    std::vector<float> out(9 * n);
+    const double fx_inv = 1. / (double)c->cam.fx, fy_inv = 1. / (double)c->cam.fy, cx = (double)c->cam.cx, cy = (double)c->cam.cy;
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+        size_t p = (size_t)y * W + x;
+        double x0 = fx_inv * ((double)x - cx), y0 = fy_inv * ((double)y - cy), nsi = 1. / (1. + x0 * x0 + y0 * y0);
+        a[0][p] = x0 * x0 * nsi; a[1][p] = x0 * y0 * nsi; a[2][p] = x0 * nsi; a[3][p] = y0 * y0 * nsi; a[4][p] = y0 * nsi; a[5][p] = nsi;
+        out[p] = (float)(x0 * nsi); out[n + p] = (float)(y0 * nsi); out[2 * n + p] = (float)nsi;
+    }
+    for (int i = 0; i < 6; ++i) box_filter_h(a[i], M[i], W, H, 5);
+    for (size_t p = 0; p < n; ++p) {
+        double M11 = M[0][p], M12 = M[1][p], M13 = M[2][p], M22 = M[3][p], M23 = M[4][p], M33 = M[5][p];
+        double det = M11 * (M22 * M33) + 2 * M12 * (M23 * M13) - (M13 * (M13 * M22) + M12 * (M12 * M33) + M23 * (M23 * M11));
+        double di = 1. / det;
+        out[3 * n + p] = (float)(di * (M22 * M33 - M23 * M23)); out[4 * n + p] = (float)(di * (M13 * M23 - M12 * M33));
+        out[5 * n + p] = (float)(di * (M12 * M23 - M13 * M22)); out[6 * n + p] = (float)(di * (M11 * M33 - M13 * M13));
+        out[7 * n + p] = (float)(di * (M12 * M13 - M11 * M23)); out[8 * n + p] = (float)(di * (M11 * M22 - M12 * M12));
+    }
+    HIPCHK(c, hipMalloc(&c->ncache, sizeof(float) * 9 * n)); HIPCHK(c, hipMalloc(&c->ntmp, sizeof(double) * 3 * n));
+    HIPCHK(c, hipMalloc(&c->nout, sizeof(float) * 3 * n)); HIPCHK(c, hipMalloc(&c->ndepth, sizeof(float) * n));
+    HIPCHK(c, hipMemcpy(c->ncache, out.data(), sizeof(float) * 9 * n, hipMemcpyHostToDevice));
+    c->ncache_w = W; c->ncache_h = H;
+    return 0;
+}
+}  // namespace
+
+extern "C" int psgsdf_estimate_normals(psgsdf_ctx* c, const float* depth, int width, int height, float* normals_xyz) {
+    if (!c || !depth || !normals_xyz || width < 2 || height < 2) return fail(c, PSGSDF_ERR_ARG, "estimate_normals: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = normals_cache(c, width, height); if (rc) return rc;
+    const size_t n = (size_t)width * height;
+    HIPCHK(c, hipMemcpyAsync(c->ndepth, depth, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    timed(c, "normals", [&] { launch_normals(c->ndepth, c->ncache, width, height, 5, c->ntmp, c->nout, c->stream); });
+    HIPCHK(c, hipMemcpyAsync(normals_xyz, c->nout, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PSGSDF_OK;
+}
+
+// RigidPointOptimizer::optimize_sampled (RigidPointOptimizer.cpp:12-79), sampling = 1: frame-to-model tracking on the dense volume
+extern "C" int psgsdf_track(psgsdf_ctx* c, const float* depth, int width, int height, float pose[16], float z_min, float z_max,
+                            int num_iterations, float conv_threshold, float damping, int* iters_out, int* converged) {
+    if (!c || !c->have_volume || !depth || !pose) return fail(c, PSGSDF_ERR_STATE, "track: volume first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)width * height;
+    int rc = normals_cache(c, width, height); if (rc) return rc;   // (allocates the depth staging buffer)
+    const int nblk = 256;
+    if (!c->track_part) { HIPCHK(c, hipMalloc(&c->track_part, sizeof(double) * nblk * 29)); HIPCHK(c, hipHostMalloc(&c->track_host, sizeof(double) * nblk * 29)); }
+    HIPCHK(c, hipMemcpyAsync(c->ndepth, depth, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    Cam cam = c->cam; cam.W = width; cam.H = height;
+    if (converged) *converged = 0;
+    int k = 0;
+    for (; k < num_iterations; ++k) {
+        FrameP fp{};
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) fp.R[i * 3 + j] = pose[i * 4 + j]; fp.t[i] = pose[i * 4 + 3]; }
+        timed(c, "track", [&] { launch_track(c->dense, c->grid, cam, fp, c->ndepth, z_min, z_max, c->track_part, nblk, c->stream); });
+        HIPCHK(c, hipMemcpyAsync(c->track_host, c->track_part, sizeof(double) * nblk * 29, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        double acc[29] = {0};
+        for (int b = 0; b < nblk; ++b) for (int q = 0; q < 29; ++q) acc[q] += c->track_host[(size_t)b * 29 + q];
+        if (acc[28] == 0) break;
+        // xi = damping * H.llt().solve(g): 6x6 LDL^T in double on the host
+        double Hd[36], gd[6], L[36] = {0}, D[6], y[6], xd[6]; int q = 0;
+        for (int i = 0; i < 6; ++i) { for (int j = i; j < 6; ++j) { Hd[i * 6 + j] = (double)(float)acc[q]; Hd[j * 6 + i] = (double)(float)acc[q]; ++q; } gd[i] = (double)(float)acc[21 + i]; }
+        double scale = 0; for (int i = 0; i < 6; ++i) scale = std::max(scale, fabs(Hd[i * 6 + i])); const double tiny = scale * 1e-12;
+        for (int j = 0; j < 6; ++j) { double dd = Hd[j * 6 + j]; for (int m = 0; m < j; ++m) dd -= L[j * 6 + m] * L[j * 6 + m] * D[m]; D[j] = dd; L[j * 6 + j] = 1;
+            for (int i = j + 1; i < 6; ++i) { double s = Hd[i * 6 + j]; for (int m = 0; m < j; ++m) s -= L[i * 6 + m] * L[j * 6 + m] * D[m]; L[i * 6 + j] = dd > tiny ? s / dd : 0; } }
+        for (int i = 0; i < 6; ++i) { double s = gd[i]; for (int m = 0; m < i; ++m) s -= L[i * 6 + m] * y[m]; y[i] = s; }
+        for (int i = 0; i < 6; ++i) y[i] = D[i] > tiny ? y[i] / D[i] : 0;
+        for (int i = 5; i >= 0; --i) { double s = y[i]; for (int m = i + 1; m < 6; ++m) s -= L[m * 6 + i] * xd[m]; xd[i] = s; }
+        float xi[6], n2 = 0; for (int i = 0; i < 6; ++i) { xi[i] = damping * (float)xd[i]; n2 += xi[i] * xi[i]; }
+        if (n2 < conv_threshold * conv_threshold) { if (converged) *converged = 1; break; }
+        // pose = SE3::exp(-xi) * pose
+        float w[3] = {-xi[3], -xi[4], -xi[5]}, u[3] = {-xi[0], -xi[1], -xi[2]};
+        float th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+        float Rm[9];
+        {   // SO3::exp via quaternion (same form as the device so3_exp)
+            float imag, real;
+            if (th2 < 1e-10f) { float t4 = th2 * th2; imag = 0.5f - (1.0f / 48.0f) * th2 + (1.0f / 3840.0f) * t4; real = 1.0f - (1.0f / 8.0f) * th2 + (1.0f / 384.0f) * t4; }
+            else { float th = sqrtf(th2), half = 0.5f * th; imag = sinf(half) / th; real = cosf(half); }
+            float qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+            float tx = 2 * qx, ty = 2 * qy, tz = 2 * qz, twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+            Rm[0] = 1 - (tyy + tzz); Rm[1] = txy - twz; Rm[2] = txz + twy; Rm[3] = txy + twz; Rm[4] = 1 - (txx + tzz); Rm[5] = tyz - twx; Rm[6] = txz - twy; Rm[7] = tyz + twx; Rm[8] = 1 - (txx + tyy);
+        }
+        float Om[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0}, Om2[9], V[9];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Om2[i * 3 + j] = (Om[i * 3] * Om[j] + Om[i * 3 + 1] * Om[3 + j]) + Om[i * 3 + 2] * Om[6 + j];
+        if (th2 < 1e-10f) { for (int i = 0; i < 9; ++i) V[i] = Rm[i]; }
+        else { float th = sqrtf(th2), a = (1.f - cosf(th)) / th2, bq = (th - sinf(th)) / (th2 * th); for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0 ? 1.f : 0.f) + a * Om[i] + bq * Om2[i]; }
+        float E[16] = {0}, P[16];
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) E[i * 4 + j] = Rm[i * 3 + j]; E[i * 4 + 3] = (V[i * 3] * u[0] + V[i * 3 + 1] * u[1]) + V[i * 3 + 2] * u[2]; }
+        E[15] = 1;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float s = 0; for (int m = 0; m < 4; ++m) s += E[i * 4 + m] * pose[m * 4 + j]; P[i * 4 + j] = s; }
+        memcpy(pose, P, sizeof(P));
+    }
+    if (iters_out) *iters_out = k;
+    return PSGSDF_OK;
+}

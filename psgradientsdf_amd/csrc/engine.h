@@ -1,4 +1,4 @@
-// engine.h — data layout shared by the host orchestration (engine.hip) and the gfx950 kernels
+// engine.h — data layout shared by the host orchestration (engine.hip, loop.hip, api*.hip; engine_internal.h) and the gfx950 kernels
 // (band.hip, sweeps.hip, dist.hip, pcg.hip, albedo_reg.hip, frontend.hip).  Internal: the public boundary is include/psgsdf.h.
 //
 // Layout in HBM:

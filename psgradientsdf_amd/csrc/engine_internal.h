@@ -1,0 +1,166 @@
+// engine_internal.h -- the context and the host-side helpers shared by the engine's source files:
+//   engine.hip        context plumbing: launch timing, deferred read-backs through the mapped mailbox, band construction, energies
+//   loop.hip          the solves and the alternation loop (fused PCG driver, sub-steps, psgsdf_iterate / psgsdf_optimize control flow)
+//   api.hip           the C ABI of include/psgsdf.h (volume, keyframes, init, steps, downloads)
+//   api_frontend.hip  frame fusion, FALS normals, depth tracker        api_multi_gpu.hip  the z-slab phase API
+//   api_debug.hip     measurement and test hooks
+// Internal: nothing here is part of the boundary (include/psgsdf.h).
+#pragma once
+#include "engine.h"
+#include "../../include/psgsdf.h"
+
+#include <math.h>
+#include <float.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace psge {
+constexpr int kMgScal = 64;   // doubles in the folded-scalar exchange buffer
+struct KTime { double ms = 0; int64_t n = 0; };
+}  // namespace psge
+using psge::KTime;
+using namespace psg;   // the layout structs of engine.h
+
+struct psgsdf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    psgsdf_settings set{};
+    float reg_n = 0, reg_l = 0;
+    GridP grid{};
+    float shift[3]{};
+    Cam cam{};
+    // dense
+    DenseView dense{};
+    uint64_t* vis_seq = nullptr; int wpv_seq = 0;
+    int* block_sums = nullptr; int* d_total = nullptr;
+    bool have_volume = false;
+    // frames
+    int F = 0;
+    int* frame_idx = nullptr;
+    float* img = nullptr;
+    FrameP* frames = nullptr;            // device
+    std::vector<FrameP> frames_h;        // host mirror of the initial records
+    float* led_light = nullptr;          // device [3]
+    bool have_frames = false;
+    // band
+    void* band_mem = nullptr; size_t band_bytes = 0;
+    void* obs_mem = nullptr;
+    float* stage = nullptr; size_t stage_px = 0;   // device staging of one RGB-D frame (integrate_frame)
+    // front end: FALS cache (9 float planes), box-filter scratch, tracker partials
+    float* ncache = nullptr; double* ntmp = nullptr; float* nout = nullptr; float* ndepth = nullptr; int ncache_w = 0, ncache_h = 0;
+    double* track_part = nullptr; double* track_host = nullptr;
+    Band band{};
+    bool inited = false;
+    // accumulators
+    double* acc_frame = nullptr; size_t acc_frame_n = 0;
+    double* part = nullptr; int PB = 0;  // [SC_COUNT][PB] per-workgroup partials
+    double* pcg_sc = nullptr; int pcg_cap = 4096;
+    double* pcg_part = nullptr;          // [2][3][kPcgMaxBlocks]
+    int last_cg_iters = 0;
+    bool want_counts = true;             // read back the accepted-update counts (debug statistic of the reference)
+    double* host_buf = nullptr; size_t host_buf_n = 0;   // pinned readback
+    // deferred read-backs: small fold kernels write into a host-mapped pinned mailbox (no D2H copies), consumed at the
+    // next host sync
+    double* mbox = nullptr; double* mbox_dev = nullptr; size_t mbox_n = 0, mbox_used = 0;
+    std::vector<std::function<void()>> deferred;
+    // cached energies
+    double en_sum = 0, el_sum = 0;       // sums over the band from the last k_derive
+    // row partition (multi-rank): this context owns band rows [row0, row1); halo = widest column reach
+    int rank = 0, n_ranks = 1;
+    int row0 = 0, row1 = 0, halo = 0;
+    double* mg_scal = nullptr;           // [kMgScal] folded local sums the host program all-reduces (phase results land at mg_fold_base)
+    double* mg_ext = nullptr;            // [8] PCG: local sums of a pass out, globally reduced sums in
+    double* mg_hist = nullptr;           // [pcg_cap + 2] PCG: what kernel k published (|b|^2, then |r|^2 after pass k-1)
+    int mg_fold_base = 0;
+    float reg_r = 0.f;                   // "reg albedo" (never normalised, PsOptimizer.cpp:279)
+    void* areg_mem = nullptr; AlbedoReg ar{};   // planes of the albedo regulariser, allocated with the band when reg_r != 0
+    double er_sum = 0;                   // sum over the band of sum_c ||grad rho_c|| at the last evaluation
+    FoldReq pending_fold{};              // scalar fold waiting for the next kernel (read_parts_deferred / take_fold)
+    bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
+    double* frame_e_slot = nullptr;      // mailbox slot the next per-frame solve writes its sweep's energy sums to
+    bool pcg_poll = true;                // PCG stop test by watching the mapped mailbox (PSGSDF_PCG_POLL=0: drain the stream instead)
+    int need[2] = {0, 0}; int* d_need = nullptr;   // halo rows needed below row0 / from row1 up
+    int* mg_slots = nullptr;             // [8] device copy of slot ids for k_sum_parts
+    bool own_stream = true;
+    // profiling
+    bool profiling = false;
+    std::map<std::string, KTime> ktimes;
+    std::vector<const char*> kt_names;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // asynchronous watch of ONE kernel name: event pairs recorded on the launch stream, resolved on query
+    std::string watch;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> watch_pool;
+    size_t watch_used = 0; int watch_every = 1; size_t watch_seen = 0;
+    char err[512] = {0};
+};
+
+namespace psge {
+using namespace psg;
+
+int fail(psgsdf_ctx* c, int code, const char* fmt, ...);
+#define HIPCHK(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(c, PSGSDF_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+
+template <class Fn> void timed(psgsdf_ctx* c, const char* name, Fn&& fn) {
+    if (!c->profiling) {
+        if (!c->watch.empty() && c->watch == name && (c->watch_seen++ % c->watch_every) == 0) {   // a sample of the launches: the event pair costs ~3 us of stream time
+            if (c->watch_used == c->watch_pool.size()) {
+                hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); c->watch_pool.emplace_back(a, b);
+            }
+            auto& pr = c->watch_pool[c->watch_used++];
+            hipEventRecord(pr.first, c->stream);
+            fn();
+            hipEventRecord(pr.second, c->stream);
+            return;
+        }
+        fn(); return;
+    }
+    hipEventRecord(c->ev0, c->stream);
+    fn();
+    hipEventRecord(c->ev1, c->stream);
+    hipEventSynchronize(c->ev1);
+    float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    KTime& k = c->ktimes[name]; k.ms += ms; k.n += 1;
+}
+
+// ---- engine.hip
+SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg);
+inline int band_blocks(const psgsdf_ctx* c) { return (c->row1 - c->row0 + kBlock - 1) / kBlock; }
+inline double band_mean(const psgsdf_ctx* c, double sum) { return c->band.S ? sum / (double)c->band.S : 0.0; }
+inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l, float E_r = 0.f) { return E + c->reg_n * E_n + c->reg_l * E_l + c->reg_r * E_r; }   // OptimizerAux.cpp:261
+int flush(psgsdf_ctx* c);
+int read_parts(psgsdf_ctx* c, const int* slots, int n, double* out);
+int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs);
+int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<void(const double*)> consume);
+int read_frame_energy_deferred(psgsdf_ctx* c, int col_e, std::function<void(double, double)> consume);
+int reserve_frame_energy_deferred(psgsdf_ctx* c, std::function<void(double, double)> consume, double** dev_slot);
+void materialize_fold(psgsdf_ctx* c);
+void take_fold(psgsdf_ctx* c, SweepArgs& a, unsigned writes);
+int ensure_host_buf(psgsdf_ctx* c, size_t n);
+void free_dense(psgsdf_ctx* c);
+int alloc_dense(psgsdf_ctx* c, DenseView& d, long long nvox, int KW, bool with_rowof);
+int build_band(psgsdf_ctx* c);
+int derive(psgsdf_ctx* c, int update_grad);
+int ps_energy(psgsdf_ctx* c, double* E, int64_t* nobs);
+
+// ---- loop.hip
+struct LoopState { float E, E_n, E_l, E_prev; int laplacian_reg; float E_r; };
+void cgf_shape(int nblk, int* G, int* rows);
+int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_out, double* err_out,
+              const std::function<void(const double*)>& tail = nullptr, bool gate_on_converged = true, bool* tail_ran = nullptr);
+int albedo_reg_energy(psgsdf_ctx* c, double* Er);
+int albedo_reg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* ok_out, double* err_out);
+int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, std::function<void(double, double)> deferred_consumer = nullptr);
+int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, bool defer_reg_sums = false);
+int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st);
+int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, psgsdf_iter_stats* stats, int stats_cap, int* n_done, int* result,
+             psgsdf_iter_cb on_iter, void* user);
+int do_upsample(psgsdf_ctx* c);
+
+}  // namespace psge

@@ -1,0 +1,402 @@
+// loop.hip -- the solves and the alternation loop: launch shape and host driver of the fused PCG, the regularised albedo solve,
+// the four sub-steps (sweep + solve + update), the control flow of psgsdf_iterate / psgsdf_optimize, the 2x refinement.
+#include "engine_internal.h"
+
+namespace psge {
+
+// Launch shape of the fused PCG pass.  The pass is a chain of memory round trips per workgroup (coefficients + column
+// indices -> two batches of record gathers, the second overlapping the reduction), so what matters is how many rows have
+// their loads in flight at once.  One row per thread at 114 VGPRs keeps 4 waves per SIMD resident (1024 workgroups); the
+// reduction of the previous pass's partials costs every workgroup G x 7 doubles, which caps G at 768.  Measured on the
+// 256^3 band (1317 row-blocks): 659 workgroups x 2 trips 17.3 us, 768 x 2 trips 18.1 us, 512 x 3 trips 18.8 us
+// (tools/pcg_ablate.py, profiles/r01_notes.md).
+void cgf_shape(int nblk, int* G, int* rows) {
+    nblk = std::max(1, nblk);
+    int r = 1, cap = kCgfMaxBlocks;
+    if (const char* e = getenv("PSGSDF_PCG_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 2) r = v; }       // tuning knobs
+    if (const char* e = getenv("PSGSDF_PCG_BLOCKS")) { int v = atoi(e); if (v > 0 && v <= kCgfMaxBlocks) cap = v; }
+    const int per = (nblk + r - 1) / r;                 // workgroups if every thread took r rows once
+    const int trips = (per + cap - 1) / cap;
+    *G = (per + trips - 1) / trips; *rows = r;
+}
+
+// Fused PCG (pcg.hip: k_cgf_pass): kernel k finishes pass k-1 and runs pass k, so a chunk of n kernels tells the host
+// about the passes up to k0+n-2; the kernel that detects convergence (or hits the cap) is also the one that finalises x.
+// `tail(gate)`, if given, enqueues what follows a finished solve (distance update + regrad) right behind every chunk of passes,
+// gated on the device-side 'solve finished' flag: when the chunk converges -- the normal case -- the GPU runs it without
+// waiting for the host to notice; when it does not, the gated kernels do nothing and the tail is enqueued again behind the
+// next chunk.  *tail_ran tells the caller whether the enqueued tail is the one that took effect.
+int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_out, double* err_out,
+              const std::function<void(const double*)>& tail, bool gate_on_converged, bool* tail_ran) {
+    const int S = c->band.S;
+    if (tail_ran) *tail_ran = false;
+    if (a.row1 <= a.row0) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }   // empty band: b = 0, x = 0, Success
+    int cap = c->set.cg_max_it > 0 ? c->set.cg_max_it : 2 * S;
+    if (cap > c->pcg_cap) cap = c->pcg_cap;
+    int G, rows;
+    cgf_shape(band_blocks(c), &G, &rows);
+    timed(c, "pcg_init", [&] { launch_cgf_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
+    // first chunk sized from the previous solve (the count is stable between Gauss-Newton iterations)
+    int chunk = std::min(64, std::max(4, c->last_cg_iters + 2));
+    int k = 0, iters = -1;            // k = next kernel index; kernels 0..cap exist (kernel cap only finalises)
+    float rhsN = 0, rn2_last = 0, threshold = 0;
+    while (true) {
+        const int n = std::min(chunk, cap + 1 - k);
+        if (c->mbox_used + (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+        const size_t off = c->mbox_used; c->mbox_used += n;
+        volatile double* st = c->mbox + off;
+        for (int q = 0; q < n; ++q) st[q] = NAN;       // "not published yet" (kernel q of the chunk overwrites its slot)
+        for (int q = 0; q < n; ++q)
+            timed(c, "pcg_pass", [&] { launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, k + q, cap, c->mbox_dev + off + q, c->stream); });
+        if (tail && c->pcg_poll && !c->profiling) { tail(c->pcg_sc + (gate_on_converged ? 2 : 1)); if (tail_ran) *tail_ran = true; }
+        // Watch the mapped slots instead of waiting for the stream to drain: the kernel that detects convergence publishes
+        // at its START, so the host learns the outcome while that kernel and the surplus (no-op) kernels of the chunk are
+        // still running, and enqueues the rest of the iteration behind them without a bubble.
+        bool drained = !c->pcg_poll;
+        if (drained) { int rc = flush(c); if (rc) return rc; }
+        for (int q = 0; q < n && iters < 0; ++q) {
+            const int kk = k + q;
+            while (!drained && std::isnan(st[q])) {
+                if (hipStreamQuery(c->stream) == hipSuccess) drained = true;   // nothing left that could publish
+            }
+            const double v = st[q];
+            if (std::isnan(v)) return fail(c, PSGSDF_ERR_DEVICE, "PCG kernel %d published nothing", kk);
+            if (kk == 0) {
+                rhsN = (float)v;
+                if (rhsN == 0.f) { iters = 0; break; }
+                threshold = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
+                rn2_last = rhsN;
+                continue;
+            }
+            rn2_last = (float)v;                           // |r|^2 after pass kk-1
+            if (rn2_last < threshold) iters = kk - 1;      // Eigen breaks before ++i
+            else if (kk == cap) iters = cap;
+        }
+        if (!drained && c->pending_fold.n) { int rc = flush(c); if (rc) return rc; drained = true; }   // (cannot happen: assemble took it)
+        if (!drained) {   // every deferred read-back enqueued before the chunk has landed (in-order stream): deliver them
+            for (auto& f : c->deferred) f();
+            c->deferred.clear(); c->mbox_used = 0;
+        }
+        if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }
+        if (iters >= 0) break;
+        k += n;
+        chunk = 4;
+    }
+    double err = sqrt((double)rn2_last / (double)rhsN);
+    *iters_out = iters; *err_out = err; *success_out = err <= (double)FLT_EPSILON;
+    c->last_cg_iters = iters;
+    return 0;
+}
+
+// "reg albedo": mean over the band of sum_c ||grad rho_c|| (Optimizer.cpp:122-136); also refreshes the Jacobian planes
+int albedo_reg_energy(psgsdf_ctx* c, double* Er) {
+    SweepArgs a = make_args(c, 0);
+    launch_areg_build(a, c->stream);
+    const int slots[1] = {SC_AUX0}; double s[1];
+    int rc = read_parts(c, slots, 1, s); if (rc) return rc;
+    c->er_sum = s[0]; *Er = band_mean(c, s[0]);
+    return 0;
+}
+// optimizeAlbedoAll with the regulariser (PsOptimizer.cpp:85-121): Eigen ConjugateGradient over the 3S unknowns on
+// H = H_d + reg_rho Jr^T Jr applied matrix-free (albedo_reg.hip).  Host-driven, two read-backs per CG iteration: no shipped
+// configuration enables this term.  The step is left in ar.x.
+int albedo_reg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* ok_out, double* err_out) {
+    const AlbedoReg& ar = a.ar;
+    launch_areg_build(a, c->stream);
+    launch_areg_system(a, c->stream);
+    launch_areg_cg_init(a, c->stream);
+    const int two[2] = {SC_AUX0, SC_AUX1}, one[1] = {SC_AUX0}; double s[2];
+    int rc = read_parts(c, two, 2, s); if (rc) return rc;
+    const float rhsN = (float)s[0];
+    *iters_out = 0; *ok_out = 1; *err_out = 0;
+    if (rhsN == 0.f) return 0;
+    const float thr = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
+    float res2 = rhsN, absNew = (float)s[1];
+    const int maxIters = c->set.cg_max_it > 0 ? c->set.cg_max_it : 6 * c->band.S;
+    int i = 0;
+    if (res2 >= thr) {
+        while (i < maxIters) {
+            launch_areg_jx(a, ar.p, ar.t, c->stream);
+            launch_areg_jt(a, ar.p, ar.t, ar.q, c->stream);
+            if ((rc = read_parts(c, one, 1, s))) return rc;
+            const float alpha = absNew / (float)s[0];
+            launch_areg_cg_update(a, alpha, c->stream);
+            if ((rc = read_parts(c, two, 2, s))) return rc;
+            res2 = (float)s[0];
+            if (res2 < thr) break;
+            const float absOld = absNew; absNew = (float)s[1];
+            launch_areg_cg_dir(a, absNew / absOld, c->stream);
+            ++i;
+        }
+    }
+    *iters_out = i; *err_out = sqrt((double)res2 / (double)rhsN); *ok_out = *err_out <= (double)FLT_EPSILON;
+    return 0;
+}
+
+// A sub-step in two halves so that the alternation loop can look at the energy of the state a sweep started from
+// (= the energy AFTER the previous block, PsOptimizer.cpp:311,323,338,354) before anything is modified:
+//   step_begin : the sweep (normal equations + PS energy of the input state)          -> st->e_in, st->n_obs
+//   step_finish: solve + update (albedo apply / light, pose solves / distance PCG + apply + regrad)
+int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, std::function<void(double, double)> deferred_consumer) {
+    memset(st, 0, sizeof(*st));
+    st->block = block;
+    SweepArgs a = make_args(c, laplacian_reg);
+    const bool led = c->set.model == PSGSDF_LED;
+    double e_sum = 0, nobs = 0;
+    int rc;
+    switch (block) {
+        case PSGSDF_ALBEDO: case PSGSDF_DIST: {
+            if (block == PSGSDF_ALBEDO) { take_fold(c, a, (1u << SC_ENERGY) | (1u << SC_NOBS)); timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); }); }
+            else timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); });
+            const int slots[2] = {SC_ENERGY, SC_NOBS}; double s[2];
+            if (deferred_consumer) return read_parts_deferred(c, slots, 2, [deferred_consumer](const double* v) { deferred_consumer(v[0], v[1]); });
+            if ((rc = read_parts(c, slots, 2, s))) return rc;
+            e_sum = s[0]; nobs = s[1];
+            break;
+        }
+        case PSGSDF_LIGHT: case PSGSDF_POSE: {
+            int col;   // the frame accumulator is all-zero here: whoever consumed it last cleared it (sweeps.hip: frame_rows_finish)
+            if (block == PSGSDF_LIGHT) {
+                take_fold(c, a, 0u);
+                timed(c, "sweep_light", [&] { launch_sweep_light(a, c->stream); });
+                const int n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4), nh = led ? 3 : n * (n + 1) / 2;
+                col = nh + n;
+            } else { take_fold(c, a, 0u); timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); }); col = 27; }
+            if (deferred_consumer) return reserve_frame_energy_deferred(c, deferred_consumer, &c->frame_e_slot);   // filled by the solve kernel
+            if ((rc = read_frame_energy(c, col, &e_sum, &nobs))) return rc;
+            break;
+        }
+        default: return fail(c, PSGSDF_ERR_ARG, "unknown block %d", block);
+    }
+    st->e_in = band_mean(c, e_sum);
+    st->n_obs = (int64_t)nobs;
+    return 0;
+}
+int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, bool defer_reg_sums) {
+    SweepArgs a = make_args(c, laplacian_reg);
+    const bool led = c->set.model == PSGSDF_LED;
+    int rc;
+    switch (block) {
+        case PSGSDF_ALBEDO: {
+            const int slots[1] = {SC_ACCEPT}; double s[1];
+            if (c->reg_r != 0.f) {
+                int iters = 0, ok = 1; double err = 0;
+                if ((rc = albedo_reg_solve(c, a, &iters, &ok, &err))) return rc;
+                const int apply = (led || ok) ? 1 : 0;      // PsOptimizer.cpp:117-119 (only on success) / LedOptimizer.cpp:195 (always)
+                if (apply) timed(c, "apply_albedo", [&] { launch_apply_albedo_delta(a, c->ar.x, c->stream); });
+                if (apply && c->want_counts) { if ((rc = read_parts(c, slots, 1, s))) return rc; st->n_accepted = (int64_t)s[0]; }
+                st->cg_iters = iters; st->cg_converged = ok; st->cg_error = err; st->applied = apply;
+                break;
+            }
+            take_fold(c, a, 1u << SC_ACCEPT);
+            timed(c, "apply_albedo", [&] { launch_apply_albedo(a, c->stream); });
+            if (c->want_counts) { if ((rc = read_parts(c, slots, 1, s))) return rc; st->n_accepted = (int64_t)s[0]; }
+            st->cg_iters = 1; st->cg_converged = 1; st->applied = 1;
+            break;
+        }
+        case PSGSDF_LIGHT:
+            timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->frame_e_slot, c->stream); });
+            c->frame_e_slot = nullptr;
+            st->cg_converged = 1; st->applied = 1; st->n_accepted = led ? 1 : c->F;
+            break;
+        case PSGSDF_POSE:
+            timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->frame_e_slot, c->stream); });
+            c->frame_e_slot = nullptr;
+            st->cg_converged = 1; st->applied = 1; st->n_accepted = c->F;
+            break;
+        case PSGSDF_DIST: {
+            take_fold(c, a, 0u);
+            timed(c, "assemble", [&] { launch_assemble(a, c->stream); });
+            int iters = 0, ok = 1; double err = 0;
+            const bool only_on_success = !led && c->set.ref_quirks;   // PsOptimizer.cpp:168-170 (B8): SH skips the update unless the solve reports Success
+            bool tail_ran = false;
+            auto tail = [&](const double* gate) {                     // distance update + regrad, gated on the device-side outcome of the solve
+                SweepArgs ag = a; ag.fold.n = 0; ag.gate = gate;
+                timed(c, "apply_dist", [&] { launch_apply_dist(ag, c->stream); });
+                SweepArgs a2 = make_args(c, 0); a2.gate = gate;
+                timed(c, "derive", [&] { launch_derive(a2, 1, c->stream); });
+            };
+            if ((rc = pcg_solve(c, a, &iters, &ok, &err, tail, only_on_success, &tail_ran))) return rc;
+            int apply = 1;
+            if (only_on_success && !ok) apply = 0;
+            if (apply) {
+                if (!tail_ran) tail(nullptr);
+                // regrad + Eikonal / Laplacian sums; one read-back for the accepted count and the two sums
+                const int slots[3] = {SC_ACCEPT, SC_EN, SC_EL}; double s[3];
+                if (defer_reg_sums) { if ((rc = read_parts_deferred(c, slots, 3, [c](const double* v) { c->en_sum = v[1]; c->el_sum = v[2]; }))) return rc; }
+                else { if ((rc = read_parts(c, slots, 3, s))) return rc; st->n_accepted = (int64_t)s[0]; c->en_sum = s[1]; c->el_sum = s[2]; }
+            }
+            st->cg_iters = iters; st->cg_converged = ok; st->cg_error = err; st->applied = apply;
+            break;
+        }
+        default: return fail(c, PSGSDF_ERR_ARG, "unknown block %d", block);
+    }
+    return 0;
+}
+int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st) {
+    psgsdf_step_stats tmp; if (!st) st = &tmp;
+    int rc = step_begin(c, block, laplacian_reg, st); if (rc) return rc;
+    return step_finish(c, block, laplacian_reg, st);
+}
+
+// The alternation loop (PsOptimizer.cpp:303-425 / LedOptimizer.cpp:343-475).  The reference evaluates getPSEnergy after
+// every block; here the energy after block k is the `e_in` of block k+1's sweep, and the energy that closes iteration i
+// is the `e_in` of the FIRST sweep of iteration i+1, which runs before anything of iteration i+1 is applied -- so the
+// convergence / divergence exit still leaves exactly the state the reference would leave.  Only the last iteration
+// (and the one that triggers the 2x refinement) needs a stand-alone energy sweep.
+
+// closes record `rec` of an iteration with the PS energy E that followed its last block
+void close_iteration(psgsdf_ctx* c, LoopState& L, psgsdf_iter_stats* rec, int pending_slot, float E, bool early_exit_semantics) {
+    L.E = E;
+    if (pending_slot >= 0) rec->e_after[pending_slot] = (double)E;
+    rec->e_n = L.E_n; rec->e_l = L.E_l; rec->e_r = L.E_r;
+    rec->e_total = (double)total_energy(c, L.E, L.E_n, L.E_l, L.E_r);
+    rec->reg_weight_n = c->reg_n; rec->reg_weight_l = c->reg_l;
+    float Et = (float)rec->e_total;
+    rec->rel_diff = (double)(fabsf(L.E_prev - Et) / L.E_prev);
+    rec->converged = rec->rel_diff < (double)c->set.conv_threshold;
+    rec->diverged = early_exit_semantics ? (!rec->converged && (L.E_prev < Et)) : (L.E_prev < Et);
+}
+
+// Runs iterations [first, ...) until max_iters or (if stop_early) convergence / divergence.  `on_iter`, upsampling and
+// the Laplacian schedule only apply when `full` (psgsdf_optimize).
+int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, psgsdf_iter_stats* stats, int stats_cap, int* n_done, int* result,
+             psgsdf_iter_cb on_iter, void* user) {
+    const bool led = c->set.model == PSGSDF_LED;
+    const int order[4] = {led ? PSGSDF_LIGHT : PSGSDF_ALBEDO, led ? PSGSDF_ALBEDO : PSGSDF_LIGHT, PSGSDF_DIST, PSGSDF_POSE};
+    psgsdf_iter_stats rec; memset(&rec, 0, sizeof(rec));
+    psgsdf_iter_stats prev; int prev_slot = -1; bool have_prev = false;   // iteration waiting for its closing energy
+    struct CountsOff { psgsdf_ctx* c; bool old; CountsOff(psgsdf_ctx* c_) : c(c_), old(c_->want_counts) { c->want_counts = false; } ~CountsOff() { c->want_counts = old; } } counts_off(c);
+    int done = 0, iter = 0; if (result) *result = 0;
+    bool stop = false;
+    auto finalize = [&](psgsdf_iter_stats& r, int it) -> int {   // everything that happens after E_total(it) is known
+        const bool term = full && (r.converged || r.diverged);
+        float E_last = (float)r.e_total;
+        if (full && !term && it == 5 && c->set.upsample) {   // PsOptimizer.cpp:386-409
+            if (c->reg_l == 0.0f) c->reg_l = 1.0f;
+            L.laplacian_reg = 1;
+            int rc = do_upsample(c); if (rc) return rc;
+            L.E_l = (float)band_mean(c, c->el_sum);
+            c->reg_l *= L.E / L.E_l;
+            E_last = total_energy(c, L.E, L.E_n, L.E_l, L.E_r);
+            r.upsampled = 1;
+        }
+        if (full && !term && c->set.upsample && (led ? it == 15 : it > 15)) c->reg_l = 0.0f;   // PsOptimizer.cpp:411-413 / LedOptimizer.cpp:461-463
+        L.E_prev = E_last;
+        if (stats && done < stats_cap) stats[done] = r;
+        done++;
+        if (term) { if (result && r.converged) *result = 1; stop = true; return 0; }
+        if (full && on_iter && on_iter(user, it + 1, &r)) stop = true;
+        return 0;
+    };
+    // per-iteration values that arrive through deferred read-backs (stable addresses: two alternating slots)
+    struct Late { double e_in[4]; int blk_of[4]; int n; bool dist_ran; int cg_iters; bool alb_reg; float e_r; } late[2];
+    int li = 0;
+    auto apply_late = [&](psgsdf_iter_stats& r, const Late& lt, int first_slot_pending) {
+        // e_in of sweep q is the energy AFTER the block that ran before it in the same iteration
+        int pend = first_slot_pending;
+        for (int q = 0; q < lt.n; ++q) {
+            if (pend >= 0 && q > 0) { r.e_after[pend] = (double)(float)band_mean(c, lt.e_in[q]); }   // deferred values are raw sums
+            pend = lt.blk_of[q] == PSGSDF_ALBEDO ? 0 : lt.blk_of[q] == PSGSDF_LIGHT ? 1 : lt.blk_of[q] == PSGSDF_DIST ? 2 : 3;
+        }
+        if (lt.alb_reg) L.E_r = lt.e_r;
+        if (lt.dist_ran) {
+            r.cg_iters = lt.cg_iters;
+            if (c->reg_n != 0.f) L.E_n = (float)band_mean(c, c->en_sum);
+            if (L.laplacian_reg) L.E_l = (float)band_mean(c, c->el_sum);
+        }
+    };
+    Late* prev_late = nullptr;
+    double* prev_close = nullptr;   // where the lazily delivered closing energy of `prev` will appear
+    while (iter < max_iters && !stop) {
+        memset(&rec, 0, sizeof(rec));
+        for (int q = 0; q < 4; ++q) rec.e_after[q] = NAN;
+        Late& lt = late[li]; lt.n = 0; lt.dist_ran = false; lt.cg_iters = 0; lt.alb_reg = false; lt.e_r = 0.f;
+        int pending = -1;
+        for (int q = 0; q < 4 && !stop; ++q) {
+            const int blk = order[q];
+            if (!(flags & blk)) continue;
+            psgsdf_step_stats st;
+            const int qi = lt.n;
+            lt.blk_of[qi] = blk; lt.e_in[qi] = NAN; lt.n++;
+            if (have_prev && full) {   // synchronous: this sweep's input energy closes the previous iteration (stop decision)
+                int rc = step_begin(c, blk, L.laplacian_reg, &st); if (rc) return rc;   // (flushes every deferred read of the previous iteration)
+                lt.e_in[qi] = st.e_in;
+                apply_late(prev, *prev_late, -1);
+                close_iteration(c, L, &prev, prev_slot, (float)st.e_in, full);
+                have_prev = false;
+                if ((rc = finalize(prev, iter - 1))) return rc;
+                if (stop) {        // converged / diverged / aborted: nothing of this iteration has been applied
+                    if (blk == PSGSDF_LIGHT || blk == PSGSDF_POSE) launch_zero_f64(c->acc_frame, (int)c->acc_frame_n, c->stream);   // the sweep's rows stay unconsumed
+                    break;
+                }
+            } else {
+                // no stop decision pending (psgsdf_iterate never exits early): even the closing energy of the previous
+                // iteration is delivered lazily, at the next host sync (the PCG status read of this iteration)
+                double* slot_e = &lt.e_in[qi];
+                int rc = step_begin(c, blk, L.laplacian_reg, &st, [slot_e](double e_sum, double) { *slot_e = e_sum; }); if (rc) return rc;
+                if (have_prev && prev_close == nullptr) prev_close = slot_e;
+            }
+            int rc = step_finish(c, blk, L.laplacian_reg, &st, true); if (rc) return rc;
+            if (blk == PSGSDF_ALBEDO && c->reg_r != 0.f) { double er; if ((rc = albedo_reg_energy(c, &er))) return rc; lt.alb_reg = true; lt.e_r = (float)er; }   // PsOptimizer.cpp:312 (enters L when the record closes)
+            if (blk == PSGSDF_DIST) { lt.dist_ran = true; lt.cg_iters = st.cg_iters; }
+            if (have_prev && prev_close && !std::isnan(*prev_close)) {   // the lazy closing energy has arrived
+                apply_late(prev, *prev_late, -1);
+                close_iteration(c, L, &prev, prev_slot, (float)band_mean(c, *prev_close), full);
+                have_prev = false; prev_close = nullptr;
+                if ((rc = finalize(prev, iter - 1))) return rc;
+            }
+            pending = blk == PSGSDF_ALBEDO ? 0 : blk == PSGSDF_LIGHT ? 1 : blk == PSGSDF_DIST ? 2 : 3;
+        }
+        if (stop) break;
+        if (have_prev && prev_close) {   // still open (no host sync happened during this iteration): force one
+            int rc = flush(c); if (rc) return rc;
+            apply_late(prev, *prev_late, -1);
+            close_iteration(c, L, &prev, prev_slot, (float)band_mean(c, *prev_close), full);
+            have_prev = false; prev_close = nullptr;
+            if ((rc = finalize(prev, iter - 1))) return rc;
+        }
+        // deferred e_in values are raw sums (not yet divided by S) except the synchronous first one: normalise on use
+        const bool last = iter + 1 >= max_iters;
+        const bool refine_next = full && c->set.upsample && iter == 5;
+        if (pending >= 0 && !last && !refine_next) { prev = rec; prev_slot = pending; have_prev = true; prev_late = &lt; li ^= 1; }
+        else {
+            double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;   // flushes the deferred reads of this iteration
+            apply_late(rec, lt, -1);
+            close_iteration(c, L, &rec, pending, (float)e, full);
+            if ((rc = finalize(rec, iter))) return rc;
+        }
+        ++iter;
+    }
+    if (have_prev && !stop) {   // loop ended by max_iters while an iteration was still open (cannot happen: `last` closes it)
+        double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;
+        apply_late(prev, *prev_late, -1);
+        close_iteration(c, L, &prev, prev_slot, (float)e, full);
+        if ((rc = finalize(prev, iter - 1))) return rc;
+    }
+    if (n_done) *n_done = done;
+    return 0;
+}
+
+int do_upsample(psgsdf_ctx* c) {
+    // bring the dense grid up to date, refine, rebuild the band
+    timed(c, "band_scatter", [&] { launch_band_scatter(c->dense, c->band, c->stream); });
+    DenseView nd{};
+    const long long nn = 8 * c->grid.nvox;
+    int rc = alloc_dense(c, nd, nn, c->dense.KW, true); if (rc) return rc;
+    timed(c, "upsample", [&] { launch_upsample(c->dense, nd, c->grid, c->stream); });
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_dense(c);
+    c->dense = nd;
+    if (c->vis_seq) { hipFree(c->vis_seq); c->vis_seq = nullptr; }
+    GridP& g = c->grid;
+    g.vs *= 0.5f;
+    for (int a = 0; a < 3; ++a) g.dim[a] *= 2;
+    for (int a = 0; a < 3; ++a) g.origin[a] = c->shift[a] - (float)(0.5 * (double)g.vs) * (float)g.dim[a] - (float)(0.5 * (double)g.vs) * 1.0f;   // VoxelGrid.h:143-149
+    g.nvox = nn;
+    g.vs_inv = (float)(1.0 / (double)g.vs);
+    if ((rc = build_band(c))) return rc;
+    return derive(c, 0);
+}
+
+}  // namespace psge

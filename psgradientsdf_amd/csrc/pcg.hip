@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
     CGF_STAMP(2);
     const bool rhs_zero = rhsNorm2 == 0.f;
     const bool stop = !(ab & 16) && (rhs_zero || k == kmax || (k > 0 && rr_cur < pcg_threshold(rhsNorm2)));
-    if (stop && blockIdx.x == 0 && threadIdx.x == 0) { fs[1] = (double)(k + 1); fs[2] = (rhs_zero || sqrt((double)rr_cur / (double)rhsNorm2) <= (double)FLT_EPSILON) ? 1.0 : 0.0; }   // fs[2]: Eigen's info() == Success, the host's rule (engine.hip: pcg_solve)
+    if (stop && blockIdx.x == 0 && threadIdx.x == 0) { fs[1] = (double)(k + 1); fs[2] = (rhs_zero || sqrt((double)rr_cur / (double)rhsNorm2) <= (double)FLT_EPSILON) ? 1.0 : 0.0; }   // fs[2]: Eigen's info() == Success, the host's rule (loop.hip: pcg_solve)
     double s[kCgfSums];
 #pragma unroll
     for (int q = 0; q < kCgfSums; ++q) s[q] = 0;
