@@ -87,7 +87,6 @@ struct psgsdf_ctx {
     double* frame_e_slot = nullptr;      // mailbox slot the next per-frame solve writes its sweep's energy sums to
     bool pcg_poll = true;                // PCG stop test by watching the mapped mailbox (PSGSDF_PCG_POLL=0: drain the stream instead)
     int need[2] = {0, 0}; int* d_need = nullptr;   // halo rows needed below row0 / from row1 up
-    int* mg_slots = nullptr;             // [8] device copy of slot ids for k_sum_parts
     bool own_stream = true;
     // profiling
     bool profiling = false;
