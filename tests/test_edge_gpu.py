@@ -90,3 +90,28 @@ def test_other_robust_losses_led(built, loss):
     st = capi.default_settings(capi.LED, loss=loss)
     eng, orc = pair(sc, st)
     compare(eng, orc, sc, iters=1, tol=5e-4)
+
+
+@pytest.mark.parametrize("name,mid", [("SH1", capi.SH1), ("LED", capi.LED)])
+def test_without_reference_quirks(built, name, mid):
+    """ref_quirks = 0: the LED neighbour-column sign (B6) and the 'skip the update unless CG reports Success' gate (B8) are off"""
+    sc = synth.make_scene(N=32, F=5, W=128, H=96, model=name)
+    st = capi.default_settings(mid, ref_quirks=0)
+    if mid == capi.LED:
+        st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0      # config_basket_LED.json
+    eng, orc = pair(sc, st)
+    compare(eng, orc, sc, iters=2, tol=5e-4)
+
+
+def test_laplacian_and_upsample_schedule(built):
+    """psgsdf_optimize with the 2x refinement at iteration 5 and the Laplacian schedule (PsOptimizer.cpp:386-413)"""
+    sc = synth.make_scene(N=24, F=5, W=128, H=96, model="SH1")
+    st = capi.default_settings(capi.SH1, upsample=1, max_it=8, conv_threshold=0.0)
+    eng, orc = pair(sc, st)
+    re_, ce = eng.optimize(capi.ALL); ro, co = orc.optimize(capi.ALL)
+    assert len(re_) == len(ro) and ce == co
+    assert [r["upsampled"] for r in re_] == [r["upsampled"] for r in ro]
+    assert [(r["converged"], r["diverged"]) for r in re_] == [(r["converged"], r["diverged"]) for r in ro]
+    for a, b in zip(re_, ro):
+        assert abs(a["e_total"] - b["e_total"]) <= 2e-3 * abs(b["e_total"]), (a["e_total"], b["e_total"])
+    assert eng.info().n_band == orc.info().n_band
