@@ -58,3 +58,26 @@ def test_headline_size_sample_against_oracle(built, big_scene):
     assert np.abs(He[idx] - Ho[idx]).max() <= 2e-5 * np.abs(Ho).max() and np.abs(be[idx] - bo[idx]).max() <= 2e-5 * np.abs(bo).max()
     ee, eo = eng.energy(), orc.energy()
     assert abs(ee[0] - eo[0]) <= 1e-5 * eo[0] and abs(ee[1] - eo[1]) <= 1e-6 * eo[1]
+
+
+def test_config1_against_the_oracle(built):
+    """BASELINE.json configs[1]: synthetic 640x480 RGB-D, 128^3 grid, SH1, 30 keyframes -- one full Gauss-Newton iteration
+    against the oracle (8 host threads), tolerance of the north star: <= 1e-4 relative SDF error."""
+    from oracle import oracle
+    sc = synth.make_scene(N=128, F=30, W=640, H=480, model="SH1")
+    st = capi.default_settings(capi.SH1)
+    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=8)
+    for api in (eng, orc):
+        api.load_scene(sc); api.init_albedo(); api.normalize_weights()
+    assert eng.info().n_band == orc.info().n_band > 5e4
+    re_, ro = eng.iterate(capi.ALL, 1)[0], orc.iterate(capi.ALL, 1)[0]
+    assert abs(re_["e_total"] - ro["e_total"]) <= 1e-4 * abs(ro["e_total"])
+    assert abs(re_["cg_iters"] - ro["cg_iters"]) <= 1
+    band = eng.download_band()
+    ve, vo = eng.download_volume(), orc.download_volume()
+    vs = float(sc.voxel_size)
+    d = np.abs(ve["dist"][band] - vo["dist"][band]) / vs
+    assert d.max() <= 1e-4, d.max()
+    assert np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max() <= 1e-4
+    assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 1e-5
+    assert np.abs(eng.download_light() - orc.download_light()).max() <= 1e-4 * np.abs(orc.download_light()).max()
