@@ -32,7 +32,8 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
         && hipMalloc(&c->pcg_sc, sizeof(double) * (16 + 8 * (size_t)kPcgMaxBlocks)) == hipSuccess   // fs[0..1] + stage stamps of the timing hook
         && hipMalloc(&c->pcg_part, sizeof(double) * 14 * kPcgMaxBlocks) == hipSuccess
         && hipMalloc(&c->mg_scal, sizeof(double) * kMgScal) == hipSuccess && hipMalloc(&c->mg_ext, sizeof(double) * 8) == hipSuccess
-        && hipMalloc(&c->mg_hist, sizeof(double) * ((size_t)c->pcg_cap + 2)) == hipSuccess && hipMalloc(&c->d_need, 2 * sizeof(int)) == hipSuccess
+        && hipHostMalloc(&c->mg_hist, sizeof(double) * ((size_t)c->pcg_cap + 2), hipHostMallocMapped) == hipSuccess
+        && hipHostGetDevicePointer((void**)&c->mg_hist_dev, c->mg_hist, 0) == hipSuccess && hipMalloc(&c->d_need, 2 * sizeof(int)) == hipSuccess
         && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess
         && hipMalloc(&c->led_light, sizeof(float) * 3) == hipSuccess
         && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
@@ -53,7 +54,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    hipFree(c->areg_mem); hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mg_hist); hipFree(c->d_need);
+    hipFree(c->areg_mem); hipFree(c->mg_scal); hipFree(c->mg_ext); if (c->mg_hist) hipHostFree(c->mg_hist); hipFree(c->d_need);
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }

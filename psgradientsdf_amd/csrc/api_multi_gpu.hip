@@ -89,7 +89,8 @@ int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
             if (arg < 0 || arg > mg_pcg_cap(c)) return fail(c, PSGSDF_ERR_ARG, "PCG kernel index %d out of range", arg);
             int G, rows; cgf_shape(band_blocks(c), &G, &rows);
             a.ext = c->mg_ext; a.laplacian_reg = 0;
-            timed(c, "pcg_pass", [&] { launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, arg, mg_pcg_cap(c), c->mg_hist + arg, c->stream); });
+            c->mg_hist[arg] = NAN;   // "not published yet": psgsdf_mg_pcg_status watches the mapped slot
+            timed(c, "pcg_pass", [&] { launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, arg, mg_pcg_cap(c), c->mg_hist_dev + arg, c->stream); });
             if (c->row1 <= c->row0) HIPCHK(c, hipMemsetAsync(c->mg_ext, 0, sizeof(double) * 8, c->stream));
             else launch_cgf_sum(c->pcg_part, G, arg, c->mg_ext, c->stream);     // local sums of pass k -> ext[0..6]
             return 0;
@@ -105,9 +106,19 @@ int psgsdf_mg_phase(psgsdf_ctx* c, int phase, int arg) {
 int psgsdf_mg_pcg_status(psgsdf_ctx* c, int k0, int n, int32_t* iters, double* err) {
     if (!c || !c->inited || !iters || !err || k0 < 0 || n < 1 || n > 64) return PSGSDF_ERR_ARG;
     const int cap = mg_pcg_cap(c);
-    HIPCHK(c, hipMemcpyAsync(c->host_buf, c->mg_hist, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->host_buf + 1, c->mg_hist + k0, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // The kernels publish into host-mapped slots, so the outcome is visible while the passes enqueued behind the converged one
+    // (no-ops) and their all-reduces are still draining: the host program can enqueue the rest of the iteration without a bubble.
+    // A slot that is still NaN when the stream has drained belongs to a kernel that returned early (the solve had stopped).
+    volatile double* hist = c->mg_hist;
+    bool drained = false;
+    for (int q = 0; q < n; ++q) {
+        while (!drained && std::isnan(hist[k0 + q])) { if (hipStreamQuery(c->stream) == hipSuccess) drained = true; }
+        if (std::isnan(hist[k0 + q])) break;
+        if (k0 + q > 0 && (float)hist[k0 + q] < fmaxf(FLT_EPSILON * FLT_EPSILON * (float)hist[0], FLT_MIN)) break;   // decided: no need to wait for later slots
+        if ((float)hist[0] == 0.f) break;
+    }
+    c->host_buf[0] = hist[0];
+    for (int q = 0; q < n; ++q) c->host_buf[1 + q] = hist[k0 + q];
     const float rhsN = (float)c->host_buf[0];
     *iters = -1; *err = 0;
     if (rhsN == 0.f) { *iters = 0; c->last_cg_iters = 0; return PSGSDF_OK; }
@@ -116,6 +127,7 @@ int psgsdf_mg_pcg_status(psgsdf_ctx* c, int k0, int n, int32_t* iters, double* e
     for (int q = 0; q < n && *iters < 0; ++q) {
         const int kk = k0 + q;
         if (kk == 0) continue;
+        if (std::isnan(c->host_buf[1 + q])) break;      // never published: an earlier kernel had already stopped the solve
         rn2 = (float)c->host_buf[1 + q];
         if (rn2 < thr) *iters = kk - 1; else if (kk == cap) *iters = cap;
     }

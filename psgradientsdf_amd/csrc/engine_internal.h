@@ -77,7 +77,8 @@ struct psgsdf_ctx {
     int row0 = 0, row1 = 0, halo = 0;
     double* mg_scal = nullptr;           // [kMgScal] folded local sums the host program all-reduces (phase results land at mg_fold_base)
     double* mg_ext = nullptr;            // [8] PCG: local sums of a pass out, globally reduced sums in
-    double* mg_hist = nullptr;           // [pcg_cap + 2] PCG: what kernel k published (|b|^2, then |r|^2 after pass k-1)
+    double* mg_hist = nullptr;           // [pcg_cap + 2] PCG: what kernel k published (|b|^2, then |r|^2 after pass k-1); host-mapped, watched by psgsdf_mg_pcg_status
+    double* mg_hist_dev = nullptr;
     int mg_fold_base = 0;
     float reg_r = 0.f;                   // "reg albedo" (never normalised, PsOptimizer.cpp:279)
     void* areg_mem = nullptr; AlbedoReg ar{};   // planes of the albedo regulariser, allocated with the band when reg_r != 0
