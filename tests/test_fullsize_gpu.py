@@ -81,3 +81,25 @@ def test_config1_against_the_oracle(built):
     assert np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max() <= 1e-4
     assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 1e-5
     assert np.abs(eng.download_light() - orc.download_light()).max() <= 1e-4 * np.abs(orc.download_light()).max()
+
+
+@pytest.mark.parametrize("model,N,F,iters", [("SH1", 96, 20, 12), ("LED", 64, 12, 12), ("SH2", 64, 12, 8)])
+def test_long_run_stays_within_the_north_star_tolerance(built, model, N, F, iters):
+    """engine vs oracle over a whole optimisation's worth of iterations (rounding differences are amplified by the discrete accept
+    rules, so a handful of voxels wander; tools/long_parity.py prints the growth): norm-wise relative SDF error <= 1e-4 and
+    99.9 % of the band within 1e-4 voxel"""
+    from oracle import oracle
+    sc = synth.make_scene(N=N, F=F, W=320, H=240, model=model)
+    st = capi.default_settings(sc.model_id)
+    if model == "LED":
+        st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0      # config_basket_LED.json
+    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=16)
+    for api in (eng, orc):
+        api.load_scene(sc); api.init_albedo(); api.normalize_weights()
+    re_, ro = eng.iterate(capi.ALL, iters), orc.iterate(capi.ALL, iters)
+    band = eng.download_band(); vs = float(sc.voxel_size)
+    de, do = eng.download_volume()["dist"][band].astype(np.float64), orc.download_volume()["dist"][band].astype(np.float64)
+    rel = np.linalg.norm(de - do) / np.linalg.norm(do)
+    d = np.abs(de - do) / vs
+    assert rel <= 1e-4 and np.quantile(d, 0.999) <= 1e-4, (rel, np.quantile(d, 0.999), d.max())
+    assert abs(re_[-1]["e_total"] - ro[-1]["e_total"]) <= 5e-4 * abs(ro[-1]["e_total"])
