@@ -103,3 +103,23 @@ def test_long_run_stays_within_the_north_star_tolerance(built, model, N, F, iter
     d = np.abs(de - do) / vs
     assert rel <= 1e-4 and np.quantile(d, 0.999) <= 1e-4, (rel, np.quantile(d, 0.999), d.max())
     assert abs(re_[-1]["e_total"] - ro[-1]["e_total"]) <= 5e-4 * abs(ro[-1]["e_total"])
+
+
+def test_headline_size_against_the_oracle(built, big_scene):
+    """256^3 x 50 keyframes 640x480: two full Gauss-Newton iterations, every band voxel against the oracle (64 host threads)"""
+    from oracle import oracle
+    sc = big_scene
+    st = capi.default_settings(capi.SH1)
+    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=64)
+    for api in (eng, orc):
+        api.load_scene(sc); api.init_albedo(); api.normalize_weights()
+    assert eng.info().n_band == orc.info().n_band
+    re_, ro = eng.iterate(capi.ALL, 2), orc.iterate(capi.ALL, 2)
+    for a, b in zip(re_, ro):
+        assert abs(a["e_total"] - b["e_total"]) <= 1e-4 * abs(b["e_total"]) and abs(a["cg_iters"] - b["cg_iters"]) <= 1
+    band = eng.download_band(); vs = float(sc.voxel_size)
+    ve, vo = eng.download_volume(), orc.download_volume()
+    d = np.abs(ve["dist"][band] - vo["dist"][band]) / vs
+    assert d.max() <= 1e-4, (d.max(), np.quantile(d, 0.999))
+    assert np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max() <= 1e-4
+    assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 1e-5
