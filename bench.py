@@ -216,6 +216,14 @@ def main():
                                    "sample": f"1 full Gauss-Newton iteration of the same {args.grid}^3 x {args.frames} scene "
                                              f"(4 blocks + 4 energy evaluations), single-threaded C oracle with indexed band lookup, {tc:.1f} s"}
             orc.close()
+            # the same port with its sweeps spread over the host's cores (OpenMP): informative only, `value` stays the one-core figure
+            nthr = min(64, os.cpu_count() or 1)
+            if nthr > 1:
+                orc = oracle.Oracle(sc, sc.K, st, threads=nthr)
+                orc.load_scene(sc); orc.init_albedo(); orc.normalize_weights()
+                tc = time.perf_counter(); orc.iterate(capi.ALL, 1); tc = time.perf_counter() - tc
+                out["cpu_baseline"]["multithreaded"] = {"value": 1.0 / tc, "unit": "it/s", "cores": nthr}
+                orc.close()
         print(json.dumps(out), file=real_stdout, flush=True)
     eng.close()
     if dist is not None:
