@@ -255,9 +255,15 @@ __device__ __forceinline__ void rho_jac(const FrameP& fp, const Proj& pr, const 
 
 // per-voxel state in registers
 struct Vox { float xs[3], gn[3], nfd[3], rho[3]; };
+// Plane element at a band row with the byte offset computed in 32 BITS: uniform base pointer + zero-extended 32-bit offset
+// selects the scalar-base form of global_load, ONE offset register shared by all the planes of a row.  (`p[j]` makes the
+// compiler build a 64-bit address per plane -- two registers and a 64-bit shift-add each -- because j * 4 may not fit 32 bits.)
+// Valid while a plane is < 4 GiB, i.e. Spad < 2^30 rows.
+template <class T> __device__ __forceinline__ T at32(const T* p, unsigned byte_off) { return *(const T*)((const char*)p + (size_t)byte_off); }
 __device__ __forceinline__ void load_vox(const Band& b, int j, Vox& v) {
+    const unsigned o = (unsigned)j << 2;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { v.xs[a] = b.xs[a][j]; v.gn[a] = b.gn[a][j]; v.rho[a] = b.rho[a][j]; v.nfd[a] = b.nfd[a][j]; }
+    for (int a = 0; a < 3; ++a) { v.xs[a] = at32(b.xs[a], o); v.gn[a] = at32(b.gn[a], o); v.rho[a] = at32(b.rho[a], o); v.nfd[a] = at32(b.nfd[a], o); }
 }
 
 // ELL column offsets of one assembled distance row: self, 6 axis neighbours, 12 axis pairs
