@@ -7,8 +7,8 @@ extern "C" {
 // ---- multi-rank (z-slab) phase API ---------------------------------------------------------
 // One process per GPU.  Every rank holds the whole band but owns rows [row0,row1) (equal band count = z-slabs);
 // the host program (psgradientsdf_amd/distributed.py) runs the phases below and performs the exchanges between them
-// with torch.distributed (RCCL on the GPUs): all-reduce of the frame accumulators / folded scalars / PCG scalars,
-// halo exchange of contiguous row ranges of `blk`, `{z,p}` and `dist`.  DESIGN.md §7.
+// with torch.distributed (RCCL on the GPUs): all-reduce of the frame accumulators / folded scalars / the 7 sums of a PCG
+// pass, halo exchange of contiguous row ranges of `blk`, the PCG records and `dist`.  DESIGN.md §7.
 int psgsdf_comm_unique_id(uint8_t id[128]) { (void)id; return PSGSDF_ERR_UNSUPPORTED; }   // collectives live in the host program
 int psgsdf_comm_init(psgsdf_ctx* c, const uint8_t id[128], int rank, int n_ranks) {
     (void)id;
