@@ -91,28 +91,20 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) mul3(GRt, dx[q], J[q]);   // dI_q
             if (!LED) {
-                if (NB == 4) {
+                // shading term rho_c * (l . dSH/dd_q): the frame's light is contracted with the (per-voxel) normal derivative ONCE per
+                // stencil slot and then scaled by the three albedos, instead of forming rho_c * l per channel first (the reference's
+                // order, PsOptimizerJa.cpp:225-278; same value up to the rounding of one product, a third of the instructions)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q) {
+                    float sq;
+                    if (NB == 4) sq = (fp.l[1] * dn[q][0] + fp.l[2] * dn[q][1]) + fp.l[3] * dn[q][2];
+                    else {
+                        sq = 0.f;
 #pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) {
-                            float dr[3] = {v.rho[ch] * fp.l[1], v.rho[ch] * fp.l[2], v.rho[ch] * fp.l[3]};
-                            J[q][ch] = J[q][ch] - dot3(dr, dn[q]);
-                        }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float dsh[9];
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) dsh[i] = (Dm[0][i] * dn[q][0] + Dm[1][i] * dn[q][1]) + Dm[2][i] * dn[q][2];
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) {
-                            float s = 0.f;
-#pragma unroll
-                            for (int i = 0; i < 9; ++i) s += (v.rho[ch] * fp.l[i]) * dsh[i];
-                            J[q][ch] = J[q][ch] - s;
-                        }
+                        for (int i = 0; i < 9; ++i) sq += fp.l[i] * ((Dm[0][i] * dn[q][0] + Dm[1][i] * dn[q][1]) + Dm[2][i] * dn[q][2]);
                     }
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) J[q][ch] = J[q][ch] - v.rho[ch] * sq;
                 }
             } else {
                 float Rp[3]; mul3(fp.R, pr.p, Rp);
