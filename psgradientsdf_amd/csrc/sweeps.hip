@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
         float refl = 0.f;
         if (LED) { float Rp[3]; mul3(fp.R, pr.p, Rp); refl = dot3(v.gn, Rp); float pn = norm3(pr.p); double pd = (double)pn; refl /= (float)(pd * pd * pd); }
-        float l = 0.f;
+        float l = 0.f, w2 = 0.f, r1 = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
@@ -218,18 +218,19 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
             if (LED) {
                 float J = refl * v.rho[ch]; float jw = J * w;
                 acc[ch] += jw * J; acc[NH + ch] += jw * r;
-            } else {
-                float J[NB];
+            } else {   // J_c = -rho_c SH(g): the three channels share the direction SH(g), so their normal equations are ONE outer product
+                w2 += w * (v.rho[ch] * v.rho[ch]);
+                r1 -= w * (v.rho[ch] * r);
+            }
+        }
+        if (!LED) {    // H += (sum_c w_c rho_c^2) SH SH^T ; b += (-sum_c w_c rho_c r_c) SH   (lightJacobian, PsOptimizerJa.cpp:132-143,323-371)
+            int q = 0;
 #pragma unroll
-                for (int i = 0; i < NB; ++i) J[i] = -v.rho[ch] * shg[i];
-                int q = 0;
+            for (int i = 0; i < NB; ++i) {
+                const float sw = shg[i] * w2;
 #pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    float jw = J[i] * w;
-#pragma unroll
-                    for (int k = i; k < NB; ++k) acc[q++] += jw * J[k];
-                    acc[NH + i] += jw * r;
-                }
+                for (int k = i; k < NB; ++k) acc[q++] += sw * shg[k];
+                acc[NH + i] += shg[i] * r1;
             }
         }
         acc[NH + NB] += l; acc[NH + NB + 1] += 1.0f;
