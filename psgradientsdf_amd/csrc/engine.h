@@ -72,6 +72,7 @@ struct Band {
     int* obs_ptr;             // [F+1]
     int* obs_rows;            // [obs_ptr[F]]
     int obs_max;              // longest list
+    long long obs_ptr_total;  // obs_ptr[F]: all observations of the owned rows
 };
 
 // accumulators for the per-frame normal equations and the scalar reductions (double)

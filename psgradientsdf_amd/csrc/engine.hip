@@ -194,7 +194,7 @@ int build_band(psgsdf_ctx* c) {
     {
         const int nch = (c->row1 - c->row0 + kObsChunk - 1) / kObsChunk, F = c->F;
         if (c->obs_mem) { hipFree(c->obs_mem); c->obs_mem = nullptr; }
-        b.obs_ptr = nullptr; b.obs_rows = nullptr; b.obs_max = 0;
+        b.obs_ptr = nullptr; b.obs_rows = nullptr; b.obs_max = 0; b.obs_ptr_total = 0;
         if (nch > 0 && F > 0) {
             int* d_counts = nullptr;
             HIPCHK(c, hipMalloc(&d_counts, sizeof(int) * (size_t)nch * F));
@@ -206,7 +206,7 @@ int build_band(psgsdf_ctx* c) {
             for (int f = 0; f < F; ++f) { ptr[f] = run; for (int k = 0; k < nch; ++k) { off[(size_t)f * nch + k] = run; run += cnt[(size_t)f * nch + k]; } mx = std::max(mx, run - ptr[f]); }
             ptr[F] = run;
             HIPCHK(c, hipMalloc(&c->obs_mem, sizeof(int) * ((size_t)run + F + 2)));
-            b.obs_ptr = (int*)c->obs_mem; b.obs_rows = b.obs_ptr + (F + 1); b.obs_max = mx;
+            b.obs_ptr = (int*)c->obs_mem; b.obs_rows = b.obs_ptr + (F + 1); b.obs_max = mx; b.obs_ptr_total = run;
             HIPCHK(c, hipMemcpyAsync(b.obs_ptr, ptr.data(), sizeof(int) * (F + 1), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(d_counts, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice, c->stream));
             launch_obs_fill(b, F, c->row0, c->row1, d_counts, c->stream);

@@ -164,13 +164,22 @@ void launch_apply_albedo(const SweepArgs& a, hipStream_t s) {
 // frame-major sweeps: grid = (row chunks, F); per-thread accumulation over several voxels of ONE
 // frame, then wavefront shuffle reduction -> LDS -> one double atomic per value per workgroup
 // ------------------------------------------------------------------------------------------
-constexpr int kRowsPerThread = 16;
-constexpr int kChunk = kBlock * kRowsPerThread;
+// Observations per thread: a launch parameter.  A workgroup's life is `rows` sequential observations per lane, and these kernels
+// are VALU-bound per SIMD, so the grid should fill the resident workgroup slots of the chip evenly in ONE generation; a fixed 16
+// left 13 % of the pose sweep's workgroups for a second, nearly empty generation (fm_rows below).
+static int fm_rows(const SweepArgs& a, int slots_per_cu) {
+    if (const char* e = getenv("PSGSDF_FM_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 256) return v; }   // tuning knob
+    const long long total = a.b.obs_ptr_total > 0 ? a.b.obs_ptr_total : (long long)a.b.obs_max * a.F;
+    const long long slots = 256LL * slots_per_cu;                       // resident workgroups on the chip
+    // every frame wastes half a chunk on average: aim at ~92 % of the slots
+    long long r = (total + (long long)(0.92 * slots) * kBlock - 1) / ((long long)(0.92 * slots) * kBlock);
+    return (int)std::min<long long>(std::max<long long>(r, 4), 64);
+}
 
 // light normal equations: lightJacobian PsOptimizerJa.cpp:132-143,323-371 (per frame NBxNB),
 // LED LightJacobian LedOptimizerJa.cpp:101-115,299-346 (one global diagonal 3x3)
 template <int MODEL>
-__global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
+__global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
@@ -191,14 +200,14 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
     // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
     // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
     // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
-    int e = beg + blockIdx.x * kChunk + threadIdx.x;
+    int e = beg + blockIdx.x * (kBlock * rows) + threadIdx.x;
     int j_cur = e < end ? b.obs_rows[e] : -1;
-    int j_nxt = (kRowsPerThread > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
+    int j_nxt = (rows > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
     Vox vn;
     if (j_cur >= 0) load_vox(b, j_cur, vn);
-    for (int it = 0; it < kRowsPerThread && j_cur >= 0; ++it, e += kBlock) {
+    for (int it = 0; it < rows && j_cur >= 0; ++it, e += kBlock) {
         const Vox v = vn;
-        const int j_nn = (it + 2 < kRowsPerThread && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
+        const int j_nn = (it + 2 < rows && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
         if (j_nxt >= 0) load_vox(b, j_nxt, vn);
         j_cur = j_nxt; j_nxt = j_nn;
         Proj pr = project(v.xs, fp, a.cam);
@@ -250,15 +259,17 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a) {
 }
 void launch_sweep_light(const SweepArgs& a, hipStream_t s) {
     if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return;
-    dim3 g((a.b.obs_max + kChunk - 1) / kChunk, a.F), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_sweep_light<0>), g, bl, 0, s, a);
-    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_light<1>), g, bl, 0, s, a);
-    else hipLaunchKernelGGL((k_sweep_light<2>), g, bl, 0, s, a);
+    const int rows = fm_rows(a, a.model == 1 ? 3 : 5);           // resident workgroups per CU at this kernel's register count
+    const int chunk = kBlock * rows;
+    dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_light<0>), g, bl, 0, s, a, rows);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_light<1>), g, bl, 0, s, a, rows);
+    else hipLaunchKernelGGL((k_sweep_light<2>), g, bl, 0, s, a, rows);
 }
 
 // pose normal equations: poseJacobian PsOptimizerJa.cpp:61-115,427-475 / LedOptimizerJa.cpp:32-81,351-399
 template <int MODEL>
-__global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
+__global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
@@ -278,14 +289,14 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
     // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
     // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
     // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
-    int e = beg + blockIdx.x * kChunk + threadIdx.x;
+    int e = beg + blockIdx.x * (kBlock * rows) + threadIdx.x;
     int j_cur = e < end ? b.obs_rows[e] : -1;
-    int j_nxt = (kRowsPerThread > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
+    int j_nxt = (rows > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
     Vox vn;
     if (j_cur >= 0) load_vox(b, j_cur, vn);
-    for (int it = 0; it < kRowsPerThread && j_cur >= 0; ++it, e += kBlock) {
+    for (int it = 0; it < rows && j_cur >= 0; ++it, e += kBlock) {
         const Vox v = vn;
-        const int j_nn = (it + 2 < kRowsPerThread && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
+        const int j_nn = (it + 2 < rows && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
         if (j_nxt >= 0) load_vox(b, j_nxt, vn);
         j_cur = j_nxt; j_nxt = j_nn;
         Proj pr = project(v.xs, fp, a.cam);
@@ -348,10 +359,12 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a) {
 }
 void launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
     if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return;
-    dim3 g((a.b.obs_max + kChunk - 1) / kChunk, a.F), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_sweep_pose<0>), g, bl, 0, s, a);
-    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_pose<1>), g, bl, 0, s, a);
-    else hipLaunchKernelGGL((k_sweep_pose<2>), g, bl, 0, s, a);
+    const int rows = fm_rows(a, 4);
+    const int chunk = kBlock * rows;
+    dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
+    if (a.model == 0) hipLaunchKernelGGL((k_sweep_pose<0>), g, bl, 0, s, a, rows);
+    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_pose<1>), g, bl, 0, s, a, rows);
+    else hipLaunchKernelGGL((k_sweep_pose<2>), g, bl, 0, s, a, rows);
 }
 
 // ------------------------------------------------------------------------------------------
