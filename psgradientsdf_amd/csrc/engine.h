@@ -120,6 +120,7 @@ struct SweepArgs {
     int row0, row1;           // band rows this context owns: [row0, row1) (whole band on one GPU; a z-slab per rank otherwise)
     FoldReq fold;             // n = 0: nothing pending
     AlbedoReg ar;             // ar.anb == nullptr unless "reg albedo" != 0
+    int fuse_apply;           // albedo sweep: solve the voxel's diagonal system and apply the update in the same thread (no normal equations stored)
     const double* gate;       // speculative launch: the kernel does nothing unless *gate != 0 (nullptr = always run); see pcg_solve
     const double* ext;        // multi-rank PCG: the 7 globally reduced sums of the previous pass (|b|^2 in ext[0] for pass 0), else nullptr
 };

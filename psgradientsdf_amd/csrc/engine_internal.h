@@ -84,7 +84,9 @@ struct psgsdf_ctx {
     void* areg_mem = nullptr; AlbedoReg ar{};   // planes of the albedo regulariser, allocated with the band when reg_r != 0
     double er_sum = 0;                   // sum over the band of sum_c ||grad rho_c|| at the last evaluation
     FoldReq pending_fold{};              // scalar fold waiting for the next kernel (read_parts_deferred / take_fold)
+    bool fuse_albedo = true;             // PSGSDF_FUSE_ALBEDO=0: separate k_apply_albedo launch
     bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
+    bool albedo_applied = false;         // the last albedo sweep already applied its update (step_begin -> step_finish)
     double* frame_e_slot = nullptr;      // mailbox slot the next per-frame solve writes its sweep's energy sums to
     bool pcg_poll = true;                // PCG stop test by watching the mapped mailbox (PSGSDF_PCG_POLL=0: drain the stream instead)
     int need[2] = {0, 0}; int* d_need = nullptr;   // halo rows needed below row0 / from row1 up
@@ -156,7 +158,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
               const std::function<void(const double*)>& tail = nullptr, bool gate_on_converged = true, bool* tail_ran = nullptr);
 int albedo_reg_energy(psgsdf_ctx* c, double* Er);
 int albedo_reg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* ok_out, double* err_out);
-int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, std::function<void(double, double)> deferred_consumer = nullptr);
+int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, std::function<void(double, double)> deferred_consumer = nullptr, bool may_apply = true);
 int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, bool defer_reg_sums = false);
 int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st);
 int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, psgsdf_iter_stats* stats, int stats_cap, int* n_done, int* result,

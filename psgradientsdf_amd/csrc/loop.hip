@@ -137,7 +137,7 @@ int albedo_reg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* ok_
 // (= the energy AFTER the previous block, PsOptimizer.cpp:311,323,338,354) before anything is modified:
 //   step_begin : the sweep (normal equations + PS energy of the input state)          -> st->e_in, st->n_obs
 //   step_finish: solve + update (albedo apply / light, pose solves / distance PCG + apply + regrad)
-int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, std::function<void(double, double)> deferred_consumer) {
+int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, std::function<void(double, double)> deferred_consumer, bool may_apply) {
     memset(st, 0, sizeof(*st));
     st->block = block;
     SweepArgs a = make_args(c, laplacian_reg);
@@ -146,8 +146,15 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
     int rc;
     switch (block) {
         case PSGSDF_ALBEDO: case PSGSDF_DIST: {
-            if (block == PSGSDF_ALBEDO) { take_fold(c, a, (1u << SC_ENERGY) | (1u << SC_NOBS)); timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); }); }
-            else timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); });
+            if (block == PSGSDF_ALBEDO) {
+                // without the albedo regulariser the system is diagonal: the sweep applies the update itself (may_apply = false: the caller
+                // has a stop decision pending on this sweep's input energy and nothing may be modified yet)
+                c->albedo_applied = may_apply && c->reg_r == 0.f && c->fuse_albedo;
+                a.fuse_apply = c->albedo_applied ? 1 : 0;
+                take_fold(c, a, (1u << SC_ENERGY) | (1u << SC_NOBS) | (c->albedo_applied ? (1u << SC_ACCEPT) : 0u));
+                timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); });
+            }
+            else { materialize_fold(c); timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); }); }   // (LED: the fused albedo sweep's sums are still pending and this sweep writes the same slots)
             const int slots[2] = {SC_ENERGY, SC_NOBS}; double s[2];
             if (deferred_consumer) return read_parts_deferred(c, slots, 2, [deferred_consumer](const double* v) { deferred_consumer(v[0], v[1]); });
             if ((rc = read_parts(c, slots, 2, s))) return rc;
@@ -188,8 +195,11 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
                 st->cg_iters = iters; st->cg_converged = ok; st->cg_error = err; st->applied = apply;
                 break;
             }
-            take_fold(c, a, 1u << SC_ACCEPT);
-            timed(c, "apply_albedo", [&] { launch_apply_albedo(a, c->stream); });
+            if (!c->albedo_applied) {
+                take_fold(c, a, 1u << SC_ACCEPT);
+                timed(c, "apply_albedo", [&] { launch_apply_albedo(a, c->stream); });
+            }
+            c->albedo_applied = false;
             if (c->want_counts) { if ((rc = read_parts(c, slots, 1, s))) return rc; st->n_accepted = (int64_t)s[0]; }
             st->cg_iters = 1; st->cg_converged = 1; st->applied = 1;
             break;
@@ -320,7 +330,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
             const int qi = lt.n;
             lt.blk_of[qi] = blk; lt.e_in[qi] = NAN; lt.n++;
             if (have_prev && full) {   // synchronous: this sweep's input energy closes the previous iteration (stop decision)
-                int rc = step_begin(c, blk, L.laplacian_reg, &st); if (rc) return rc;   // (flushes every deferred read of the previous iteration)
+                int rc = step_begin(c, blk, L.laplacian_reg, &st, nullptr, false); if (rc) return rc;   // (flushes every deferred read of the previous iteration)
                 lt.e_in[qi] = st.e_in;
                 apply_late(prev, *prev_late, -1);
                 close_iteration(c, L, &prev, prev_slot, (float)st.e_in, full);

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
     int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
-    double E = 0, nobs = 0;
+    double E = 0, nobs = 0, cnt = 0;
     if (j < a.row1) {
         Vox v; load_vox(b, j, v);
         float shfd[kMaxBasis], shg[kMaxBasis];
@@ -124,11 +124,23 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
             Ef += l; nobs_i += 1;
         }
         E = (double)Ef; nobs = (double)nobs_i;
+        if (a.fuse_apply) {   // the system is diagonal and the voxel's albedo is read by this thread only: k_apply_albedo's arithmetic, here
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) { b.aH[(size_t)ch * b.Spad + j] = Hd[ch]; b.ab[(size_t)ch * b.Spad + j] = bd[ch]; }
+            for (int ch = 0; ch < 3; ++ch) {
+                float h = Hd[ch];
+                if (a.damping != 0.0f) h += a.damping * h;
+                const float delta = (h != 0.f) ? bd[ch] / h : 0.f;
+                const float nv = v.rho[ch] - delta;
+                if (nv > 0.0f && nv < 1.0f) { b.rho[ch][j] = nv; cnt += 1.0; }
+            }
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { b.aH[(size_t)ch * b.Spad + j] = Hd[ch]; b.ab[(size_t)ch * b.Spad + j] = bd[ch]; }
+        }
     }
     block_part_store(E, PART(a, SC_ENERGY), red);
     block_part_store(nobs, PART(a, SC_NOBS), red);
+    if (a.fuse_apply) block_part_store(cnt, PART(a, SC_ACCEPT), red);
 }
 void launch_sweep_albedo(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;

@@ -1,5 +1,5 @@
 """The engine's latency tricks must not change results: PCG stop test by watching the mapped mailbox vs draining the stream
-(PSGSDF_PCG_POLL), scalar folds done by the next kernel vs by a kernel of their own (PSGSDF_FOLD_IN_NEXT), launch shape of the
+(PSGSDF_PCG_POLL), scalar folds done by the next kernel vs by a kernel of their own (PSGSDF_FOLD_IN_NEXT), albedo update applied by the sweep vs by its own kernel (PSGSDF_FUSE_ALBEDO), launch shape of the
 fused PCG pass (PSGSDF_PCG_ROWS / PSGSDF_PCG_BLOCKS).  Each variant runs in its own process (the knobs are read at create time)."""
 import json
 import os
@@ -39,14 +39,16 @@ def run(model, env, full=False):
 @pytest.mark.parametrize("model", ["SH1", "LED"])
 def test_host_side_knobs_are_bitwise_neutral(built, model):
     ref = run(model, {}, full=True)
-    for env in ({"PSGSDF_PCG_POLL": "0"}, {"PSGSDF_FOLD_IN_NEXT": "0"}, {"PSGSDF_PCG_POLL": "0", "PSGSDF_FOLD_IN_NEXT": "0"}):
+    for env in ({"PSGSDF_PCG_POLL": "0"}, {"PSGSDF_FOLD_IN_NEXT": "0"}, {"PSGSDF_PCG_POLL": "0", "PSGSDF_FOLD_IN_NEXT": "0"},
+                {"PSGSDF_FUSE_ALBEDO": "0"}):
         got = run(model, env, full=True)
         assert got == ref, (env, got, ref)
 
 
 def test_pcg_launch_shape_only_changes_rounding(built):
     ref = run("SH1", {})
-    for env in ({"PSGSDF_PCG_ROWS": "2", "PSGSDF_PCG_BLOCKS": "7"}, {"PSGSDF_PCG_ROWS": "1", "PSGSDF_PCG_BLOCKS": "5"}, {"PSGSDF_PCG_ROWS": "2", "PSGSDF_PCG_BLOCKS": "512"}):
+    for env in ({"PSGSDF_PCG_ROWS": "2", "PSGSDF_PCG_BLOCKS": "7"}, {"PSGSDF_PCG_ROWS": "1", "PSGSDF_PCG_BLOCKS": "5"}, {"PSGSDF_PCG_ROWS": "2", "PSGSDF_PCG_BLOCKS": "512"},
+                {"PSGSDF_FM_ROWS": "16"}, {"PSGSDF_FM_ROWS": "5"}):   # observations per thread of the frame-major sweeps: summation order only
         got = run("SH1", env)
         assert all(abs(a - b) <= 1 for a, b in zip(got["cg"], ref["cg"]))
         assert all(abs(a - b) <= 2e-5 * abs(b) for a, b in zip(got["e"], ref["e"])), (env, got["e"], ref["e"])
