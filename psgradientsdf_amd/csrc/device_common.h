@@ -77,10 +77,23 @@ __device__ __forceinline__ float robust_loss(const Robust& rb, float r) {
 }
 
 // wavefront (64 lanes) and workgroup reductions; one device-scope atomic per workgroup
+// Cross-lane adds through DPP (register-to-register, no LDS round trip as with ds_bpermute): butterfly inside each row of 16
+// lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows
+// 2 and 3; lane 63 holds the total, which is broadcast through an SGPR.  Fixed order, so still run-to-run deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);     // row_mirror
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 -> rows 1, 3
+    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 -> rows 2, 3
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 __device__ __forceinline__ float wave_sumf(float v) {
 #pragma unroll
