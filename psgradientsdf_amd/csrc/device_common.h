@@ -95,6 +95,39 @@ __device__ __forceinline__ double wave_sum(double v) {
     v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 -> rows 2, 3
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_get(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// Eight wavefront sums at once as a reduce-scatter: lanes exchange HALF of their values with lane^1, then half of the rest with
+// lane^2 (8 -> 4 -> 2 values per lane), the two survivors are summed over the four lanes of the row that share the low lane bits
+// (row_ror 4, 8) and over the four rows (two shuffles).  66 instructions instead of 8 x 20; afterwards EVERY lane holds the
+// totals of the values  4 (lane & 1) + (lane & 2) + {0, 1}  in t0, t1.
+__device__ __forceinline__ void wave_sum8(const double (&v)[8], double& t0, double& t1) {
+    const int lane = threadIdx.x & 63;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    double u[4], t[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const double keep = b0 ? v[4 + j] : v[j], give = b0 ? v[j] : v[4 + j]; u[j] = keep + dpp_get<0xB1>(give); }   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const double keep = b1 ? u[2 + j] : u[j], give = b1 ? u[j] : u[2 + j]; t[j] = keep + dpp_get<0x4E>(give); }   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        t[j] += dpp_get<0x124>(t[j]);      // row_ror:4
+        t[j] += dpp_get<0x128>(t[j]);      // row_ror:8
+        t[j] += __shfl_xor(t[j], 16, 64);
+        t[j] += __shfl_xor(t[j], 32, 64);
+    }
+    t0 = t[0]; t1 = t[1];
+}
+// lanes 0..3 of wavefront w file the eight totals under red[value * NW + w]
+template <int NW>
+__device__ __forceinline__ void wave_sum8_store(double t0, double t1, double* red, int w) {
+    const int lane = threadIdx.x & 63;
+    if (lane < 4) { const int base = 4 * (lane & 1) + (lane & 2); red[base * NW + w] = t0; red[(base + 1) * NW + w] = t1; }
+}
 __device__ __forceinline__ float wave_sumf(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

@@ -42,20 +42,29 @@ __device__ __forceinline__ void block_total_issue(double* const* src, int n, Par
     }
 }
 template <int N>
-__device__ __forceinline__ void block_total_finish(const PartLoads<N>& pl, double* red /*[N * kBlock/64]*/, double* out) {
-    double v[N];
+__device__ __forceinline__ void block_total_finish(const PartLoads<N>& pl, double* red /*[8 * kBlock/64]*/, double* out) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = 0.0;
 #pragma unroll
     for (int q = 0; q < N; ++q) {
         v[q] = pl.ld[0][q];
 #pragma unroll
         for (int j = 1; j < kCgfMaxBlocks / kBlock; ++j) v[q] += pl.ld[j][q];
-        v[q] = wave_sum(v[q]);
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) {
+    if constexpr (N > 2) {
+        double t0, t1; wave_sum8(v, t0, t1);
+        __syncthreads();
+        wave_sum8_store<kBlock / 64>(t0, t1, red, w);
+    } else {
 #pragma unroll
-        for (int q = 0; q < N; ++q) red[q * (kBlock / 64) + w] = v[q];
+        for (int q = 0; q < N; ++q) v[q] = wave_sum(v[q]);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < N; ++q) red[q * (kBlock / 64) + w] = v[q];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -73,16 +82,15 @@ __device__ __forceinline__ void block_total_n(double* const* src, int n, double*
     block_total_finish<N>(pl, red, out);
 }
 template <int N>
-__device__ __forceinline__ void block_part_store_n(const double* vin, double* const* dst, double* red) {
-    double v[N];
+__device__ __forceinline__ void block_part_store_n(const double* vin, double* const* dst, double* red /*[8 * kBlock/64]*/) {
+    static_assert(N > 2 && N <= 8, "reduce-scatter of up to eight sums");
+    double v[8];
 #pragma unroll
-    for (int q = 0; q < N; ++q) v[q] = wave_sum(vin[q]);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int q = 0; q < 8; ++q) v[q] = q < N ? vin[q] : 0.0;
+    const int w = threadIdx.x >> 6;
+    double t0, t1; wave_sum8(v, t0, t1);
     __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < N; ++q) red[q * (kBlock / 64) + w] = v[q];
-    }
+    wave_sum8_store<kBlock / 64>(t0, t1, red, w);
     __syncthreads();
     if (threadIdx.x < N) {
         double s = 0;
@@ -201,7 +209,7 @@ __device__ __forceinline__ void cgf_rows_finish(CgfRow* w, const CgfPending<R>& 
 }
 template <int kCgfRows, int kMinWaves, bool C16>
 __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, double* fs, double* part, int k, int kmax, double* mb, int ab) {   // ab: timing ablations (tools/), 0 in production
-    __shared__ double red[kCgfSums * kBlock / 64];
+    __shared__ double red[8 * kBlock / 64];
     const Band& b = a.b;
     long long* ts = (long long*)(fs + 16) + (size_t)blockIdx.x * 8;   // ab & 1024: stage timestamps of every workgroup
 #define CGF_STAMP(j) do { if ((ab & 1024) && threadIdx.x == 0) { ts[j] = clock64(); if (j == 0) ts[6] = wall_clock64(); if (j == 4) ts[7] = wall_clock64(); } } while (0)
@@ -298,7 +306,7 @@ void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int ro
 
 // multi-rank: fold the partials of pass k (k = -1: |b|^2 of the init) into out[0..6] for the host program's all-reduce
 __global__ void __launch_bounds__(kBlock) k_cgf_sum(double* part, int G, int k, double* __restrict__ out) {
-    __shared__ double red[kCgfSums * kBlock / 64];
+    __shared__ double red[8 * kBlock / 64];
     if (k < 0) {
         double* src[1] = {fpart(part, -1, 6)}; double bb;
         block_total_n<1>(src, G, red, &bb);
