@@ -128,6 +128,20 @@ __device__ __forceinline__ void wave_sum8_store(double t0, double t1, double* re
     const int lane = threadIdx.x & 63;
     if (lane < 4) { const int base = 4 * (lane & 1) + (lane & 2); red[base * NW + w] = t0; red[(base + 1) * NW + w] = t1; }
 }
+// NV wavefront sums of float accumulators, in double, eight at a time -> row[0..NV) (written by lanes 0..3)
+template <int NV>
+__device__ __forceinline__ void wave_sums_to(const float* acc, double* row) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int g = 0; g < (NV + 7) / 8; ++g) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 8 * g + q < NV ? (double)acc[8 * g + q] : 0.0;
+        double t0, t1; wave_sum8(v, t0, t1);
+        const int k = 8 * g + 4 * (lane & 1) + (lane & 2);
+        if (lane < 4) { if (k < NV) row[k] = t0; if (k + 1 < NV) row[k + 1] = t1; }
+    }
+}
 __device__ __forceinline__ float wave_sumf(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

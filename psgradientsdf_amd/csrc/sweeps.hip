@@ -259,9 +259,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
     // one atomic per value per workgroup into THIS frame's row (<= S/2048 workgroups contend per address);
     // row layout: [NH H entries | NB rhs | energy | n_obs]
     double* dst = a.acc.frame + (size_t)f * kFrameRow;
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }   // double: SH2 light blocks are ill-conditioned
+    const int w = threadIdx.x >> 6;
+    wave_sums_to<NV>(acc, lds + w * NV);   // double: SH2 light blocks are ill-conditioned
     __syncthreads();
     for (int k = threadIdx.x; k < NV; k += blockDim.x) {
         double s = 0;
@@ -359,9 +358,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
         acc[27] += l; acc[28] += 1.0f;
     }
     double* dst = a.acc.frame + (size_t)f * kFrameRow;   // [21 H | 6 rhs | energy | n_obs]
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) { double vv = wave_sum((double)acc[k]); if (lane == 0) lds[w * NV + k] = vv; }   // double: SH2 light blocks are ill-conditioned
+    const int w = threadIdx.x >> 6;
+    wave_sums_to<NV>(acc, lds + w * NV);   // double: SH2 light blocks are ill-conditioned
     __syncthreads();
     for (int k = threadIdx.x; k < NV; k += blockDim.x) {
         double s = 0;
