@@ -77,6 +77,10 @@ __device__ __forceinline__ float robust_loss(const Robust& rb, float r) {
 }
 
 // wavefront (64 lanes) and workgroup reductions; one device-scope atomic per workgroup
+// fused PCG (pcg.hip): per-workgroup partial sums [2 parity][kCgfSums][kPcgMaxBlocks]; k = -1 / kind 6 holds |b|^2 of the initialisation
+constexpr int kCgfSums = 7;
+__device__ __forceinline__ double* fpart(double* part, int k, int kind) { return part + ((size_t)((k & 1) * kCgfSums + kind)) * kPcgMaxBlocks; }
+
 // Cross-lane adds through DPP (register-to-register, no LDS round trip as with ds_bpermute): butterfly inside each row of 16
 // lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows
 // 2 and 3; lane 63 holds the total, which is broadcast through an SGPR.  Fixed order, so still run-to-run deterministic.

@@ -197,7 +197,8 @@ __global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < kNQ; ++q) acc[q][tid] = 0.0;
-    if (i >= a.row1) return;
+    double bb = 0.0;
+    if (i < a.row1) {
     // round 1: the six axis neighbours (contributor 0 is the row itself; 1,2 = x lower / upper; 3,4 = y; 5,6 = z)
     int jr[7]; jr[0] = i;
 #pragma unroll
@@ -239,6 +240,21 @@ __global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
     for (int q = 0; q < kNQ; ++q) { float h = (float)acc[q][tid]; b.H[(size_t)q * b.Spad + i] = h; if (q >= kNQCommon && h != 0.f) extra = 1; }
     b.hx[i] = extra;
     b.rhs[i] = (float)rhs;
+    if (a.pcg_fuse_init) {   // k_cgf_init's work for this row (pcg.hip)
+        float dg = (float)acc[0][tid];
+        if (a.damping != 0.0f) dg += a.damping * dg;
+        const float inv = dg != 0.f ? 1.0f / dg : 1.0f;
+        const float r = (float)rhs;
+        b.x[i] = 0.f;
+        b.rec[1][i] = make_float4(r, 0.f, 0.f, inv);
+        bb = (double)r * (double)r;
+    }
+    }
+    if (a.pcg_fuse_init) {
+        __shared__ double red[kBlock / 64];
+        block_part_store(bb, fpart(a.pcg_part, -1, 6), red);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.pcg_fs[1] = 0.0; a.pcg_fs[2] = 0.0; }
+    }
 }
 void launch_assemble(const SweepArgs& a, hipStream_t s) {
     if (a.row1 > a.row0) hipLaunchKernelGGL(k_assemble, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);

@@ -84,6 +84,7 @@ struct psgsdf_ctx {
     void* areg_mem = nullptr; AlbedoReg ar{};   // planes of the albedo regulariser, allocated with the band when reg_r != 0
     double er_sum = 0;                   // sum over the band of sum_c ||grad rho_c|| at the last evaluation
     FoldReq pending_fold{};              // scalar fold waiting for the next kernel (read_parts_deferred / take_fold)
+    bool fuse_pcg_init = true;           // PSGSDF_FUSE_PCG_INIT=0: separate k_cgf_init launch
     bool fuse_albedo = true;             // PSGSDF_FUSE_ALBEDO=0: separate k_apply_albedo launch
     bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
     bool albedo_applied = false;         // the last albedo sweep already applied its update (step_begin -> step_finish)

@@ -35,7 +35,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
     if (cap > c->pcg_cap) cap = c->pcg_cap;
     int G, rows;
     cgf_shape(band_blocks(c), &G, &rows);
-    timed(c, "pcg_init", [&] { launch_cgf_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
+    if (!a.pcg_fuse_init) timed(c, "pcg_init", [&] { launch_cgf_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
     // first chunk sized from the previous solve (the count is stable between Gauss-Newton iterations)
     int chunk = std::min(64, std::max(4, c->last_cg_iters + 2));
     int k = 0, iters = -1;            // k = next kernel index; kernels 0..cap exist (kernel cap only finalises)
@@ -216,6 +216,7 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
             break;
         case PSGSDF_DIST: {
             take_fold(c, a, 0u);
+            if (c->fuse_pcg_init && band_blocks(c) <= kPcgMaxBlocks) { a.pcg_fuse_init = 1; a.pcg_init_blocks = band_blocks(c); }   // the assembly kernel initialises the PCG
             timed(c, "assemble", [&] { launch_assemble(a, c->stream); });
             int iters = 0, ok = 1; double err = 0;
             const bool only_on_success = !led && c->set.ref_quirks;   // PsOptimizer.cpp:168-170 (B8): SH skips the update unless the solve reports Success

@@ -26,8 +26,6 @@ __device__ __forceinline__ float pcg_threshold(float rhsNorm2) { return fmaxf(FL
 // all-reduces them over the ranks, and the next kernel reads the global sums from a.ext instead of the partials; the
 // records of the halo rows are exchanged before each pass.
 // ------------------------------------------------------------------------------------------
-constexpr int kCgfSums = 7;
-__device__ __forceinline__ double* fpart(double* part, int k, int kind) { return part + ((size_t)((k & 1) * kCgfSums + kind)) * kPcgMaxBlocks; }
 
 // n sums at once, identical in every thread of every workgroup.  All loads of a thread are issued before the first use
 // (fixed trip count, predicated): ONE memory round trip however many partials there are -- a dynamic-trip loop made it three.
@@ -229,6 +227,7 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
     else if (k == 0) {
         double bb;
         if (a.ext) bb = a.ext[0];
+        else if (a.pcg_init_blocks > 0) bb = block_total(fpart(part, -1, 6), a.pcg_init_blocks, red);   // written by the assembly kernel's grid
         else { double* src[1] = {fpart(part, -1, 6)}; block_total_n<1>(src, gridDim.x, red, &bb); }
         cgf_rows_finish<kCgfRows>(w, pend);
         rhsNorm2 = (float)bb; rr_cur = rhsNorm2;
