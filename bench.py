@@ -141,7 +141,8 @@ def main():
         kernels = {k: {"ms_per_iter": v[0] / nprof, "launches_per_iter": v[1] / nprof} for k, v in kt.items()}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_iter"] if algorithmic_bytes(k, 1, 1, 1, 1, 1) else -1)
     eng.reset_kernel_times()
-    eng.watch_kernel(dom + "/8")      # HIP events around every 8th launch of the dominant kernel (each pair costs ~3 us of stream time)
+    if os.environ.get("PSGSDF_NO_WATCH") != "1":   # (tools/gap_run.sh: trace without the event pairs)
+        eng.watch_kernel(dom + "/8")  # HIP events around every 8th launch of the dominant kernel (each pair costs ~3 us of stream time)
     barrier()
     t0 = time.perf_counter()
     recs = iterate(args.steps)
