@@ -184,21 +184,11 @@ void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((k_sweep_dist<2>), g, bl, a.F * sizeof(FrameP), s, a);
 }
 
-// H = sum_j P_j^T B_j P_j assembled row-wise into 19 fixed column offsets (ELL); a row receives
-// slices from itself, from each lower neighbour (whose forward stencil points at it) and from each
-// upper neighbour whose stencil was forced backward.  Accumulation in LDS (dynamic column index).
-// The loads are arranged in three rounds for ALL seven possible contributors at once (neighbour rows -> their stencil
-// direction bits -> their block entries); a loop over the contributors made 7 x 3 dependent round trips (30 us).
-__global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
-    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
-    __shared__ double acc[kNQ][kBlock];
+// one ELL row (and, if a.pcg_fuse_init, the PCG initialisation of that row: returns r_0^2)
+__device__ __forceinline__ double assemble_row(const SweepArgs& a, int i, double (*acc)[kBlock]) {
     const Band& b = a.b;
-    int i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int q = 0; q < kNQ; ++q) acc[q][tid] = 0.0;
     double bb = 0.0;
-    if (i < a.row1) {
     // round 1: the six axis neighbours (contributor 0 is the row itself; 1,2 = x lower / upper; 3,4 = y; 5,6 = z)
     int jr[7]; jr[0] = i;
 #pragma unroll
@@ -249,7 +239,21 @@ __global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
         b.rec[1][i] = make_float4(r, 0.f, 0.f, inv);
         bb = (double)r * (double)r;
     }
-    }
+    return bb;
+}
+// H = sum_j P_j^T B_j P_j assembled row-wise into 19 fixed column offsets (ELL); a row receives
+// slices from itself, from each lower neighbour (whose forward stencil points at it) and from each
+// upper neighbour whose stencil was forced backward.  Accumulation in LDS (dynamic column index).
+// The loads are arranged in three rounds for ALL seven possible contributors at once (neighbour rows -> their stencil
+// direction bits -> their block entries); a loop over the contributors made 7 x 3 dependent round trips (30 us).
+__global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
+    { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
+    __shared__ double acc[kNQ][kBlock];
+    int i = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < kNQ; ++q) acc[q][tid] = 0.0;
+    const double bb = i < a.row1 ? assemble_row(a, i, acc) : 0.0;
     if (a.pcg_fuse_init) {
         __shared__ double red[kBlock / 64];
         block_part_store(bb, fpart(a.pcg_part, -1, 6), red);

@@ -137,13 +137,14 @@ template <int R> struct CgfPending { float h[R][kNQ - kCgfB1]; float4 o[R][kNQ -
 // q * Spad in the scalar offset operand): with flat 64-bit addresses the 38 streamed loads of a row cost two address
 // registers each and the kernel spilled.
 // (The record gathers stay flat loads: this compiler narrows `raw.ptr.buffer.load.v4i32` to a one-dword load.)
+template <int R> struct CgfStream { float h[R][kNQ]; int c[R][kNQ]; };
 template <int R, bool C16>
-__device__ __forceinline__ void cgf_rows(const Band& b, const float4* __restrict__ rin, int i0, int stride, int row1, float damping, CgfRow* w, CgfPending<R>& pend, int ab) {
+__device__ __forceinline__ void cgf_stream_issue(const Band& b, int i0, int stride, int row1, CgfRow* w, CgfStream<R>& sl) {
     const int plane = b.Spad * 4;              // bytes of one ELL column plane
     const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)b.H, 0, kNQ * plane, 0x00020000);
     const __amdgpu_buffer_rsrc_t rC = C16 ? __builtin_amdgcn_make_buffer_rsrc((void*)b.colp, 0, (kNQ - 1) / 2 * plane, 0x00020000)
                                           : __builtin_amdgcn_make_buffer_rsrc((void*)b.col, 0, kNQ * plane, 0x00020000);
-    float h[R][kNQ]; int c[R][kNQ];
+    auto& h = sl.h; auto& c = sl.c;
     // round trip 1: everything addressed by the rows themselves, for ALL rows of the thread
 #pragma unroll
     for (int u = 0; u < R; ++u) {
@@ -166,6 +167,10 @@ __device__ __forceinline__ void cgf_rows(const Band& b, const float4* __restrict
         }
         w[u].x = b.x[ii];
     }
+}
+template <int R>
+__device__ __forceinline__ void cgf_gather(const float4* __restrict__ rin, float damping, CgfRow* w, CgfStream<R>& sl, CgfPending<R>& pend) {
+    auto& h = sl.h; auto& c = sl.c;
     // round trip 2: the records of the first batch of columns of every row, folded into the three sums as they arrive
     float4 o[R][kCgfB1];
 #pragma unroll
@@ -216,9 +221,10 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
     float4* __restrict__ rout = b.rec[k & 1];
     const int stride = gridDim.x * blockDim.x;
     int i0 = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
-    CgfRow w[kCgfRows]; CgfPending<kCgfRows> pend;
+    CgfRow w[kCgfRows]; CgfPending<kCgfRows> pend; CgfStream<kCgfRows> sl;
     const double stopped = fs[1];
-    cgf_rows<kCgfRows, C16>(b, rin, i0, stride, a.row1, a.damping, w, pend, ab);
+    cgf_stream_issue<kCgfRows, C16>(b, i0, stride, a.row1, w, sl);
+    cgf_gather<kCgfRows>(rin, a.damping, w, sl, pend);
 
     CGF_STAMP(1);
     float alpha_prev = 0.f, beta = 0.f, rr_cur, rhsNorm2;
@@ -262,10 +268,10 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
     double s[kCgfSums];
 #pragma unroll
     for (int q = 0; q < kCgfSums; ++q) s[q] = 0;
-    while (true) {
+    auto rows_out = [&](const CgfRow* wr) {
 #pragma unroll
         for (int u = 0; u < kCgfRows; ++u) {
-            const CgfRow& r = w[u];
+            const CgfRow& r = wr[u];
             const float4 me = r.me;
             // finish pass k-1 for the own row: x += alpha p ; residual -= alpha tmp
             if (r.live && k > 0 && !(ab & 32)) b.x[r.i] = r.x + alpha_prev * me.z;
@@ -279,10 +285,15 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
             s[0] += (double)p_i * td; s[1] += iv * rd * td; s[2] += iv * td * td; s[3] += rd * td; s[4] += td * td;
             s[5] += rd * (double)z_i; s[6] += rd * rd;
         }
-        i0 += kCgfRows * stride;
-        if (i0 - (int)threadIdx.x >= a.row1) break;          // workgroup-uniform
-        cgf_rows<kCgfRows, C16>(b, rin, i0, stride, a.row1, a.damping, w, pend, ab);
+    };
+    rows_out(w);
+    i0 += kCgfRows * stride;
+    while (i0 - (int)threadIdx.x < a.row1) {          // workgroup-uniform
+        cgf_stream_issue<kCgfRows, C16>(b, i0, stride, a.row1, w, sl);
+        cgf_gather<kCgfRows>(rin, a.damping, w, sl, pend);
         cgf_rows_finish<kCgfRows>(w, pend);
+        rows_out(w);
+        i0 += kCgfRows * stride;
     }
     CGF_STAMP(3);
     if (stop || (ab & 4)) return;
