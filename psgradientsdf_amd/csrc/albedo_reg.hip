@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_albedo_delta(SweepArgs a, cons
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             const float v = b.rho[ch][j] - delta[(size_t)ch * b.Spad + j];
-            if (v > 0.0f && v < 1.0f) { b.rho[ch][j] = v; cnt += 1.0; }
+            if (v > 0.0f && v < 1.0f) { set_rho(b, j, ch, v); cnt += 1.0; }
         }
     }
     block_part_store(cnt, PART(a, SC_ACCEPT), red);

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(kBlock) k_band_fill(DenseView d, GridP grid, B
         b.lin[j] = (int)lin;
         b.dist[j] = d.dist[lin];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { b.g[a][j] = d.g[a][lin]; b.rho[a][j] = d.rho[a][lin]; }
+        for (int a = 0; a < 3; ++a) { b.g[a][j] = d.g[a][lin]; set_rho(b, j, a, d.rho[a][lin]); }
         for (int w = 0; w < b.KW; ++w) b.vis[(size_t)w * b.Spad + j] = d.vis[lin * b.KW + w];
     }
 }
@@ -210,19 +210,20 @@ __global__ void __launch_bounds__(kBlock) k_derive(SweepArgs a, int update_grad)
         for (int k = 0; k < 3; ++k) { b.gfd[k][j] = n[k]; if (update_grad) b.g[k][j] = n[k]; g[k] = update_grad ? n[k] : b.g[k][j]; }
         float gn[3]; normalized3(g, gn);
         float nn[3]; normalized3(n, nn);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) b.nfd[k][j] = nn[k];
         long long lin = b.lin[j];
         int nxy = a.grid.dim[0] * a.grid.dim[1];
         int kz = (int)(lin / nxy); int rest = (int)(lin - (long long)kz * nxy); int jy = rest / a.grid.dim[0]; int ix = rest - jy * a.grid.dim[0];
         int idx[3] = {ix, jy, kz};
         float d = b.dist[j];
+        float xs[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float xv = a.grid.origin[k] + a.grid.vs * (float)idx[k];   // VoxelGrid.h:38-40
-            b.gn[k][j] = gn[k];
-            b.xs[k][j] = xv - d * gn[k];
+            xs[k] = xv - d * gn[k];
         }
+        b.vp[0][j] = make_float4(xs[0], xs[1], xs[2], b.rho[0][j]);
+        b.vp[1][j] = make_float4(gn[0], gn[1], gn[2], b.rho[1][j]);
+        b.vp[2][j] = make_float4(nn[0], nn[1], nn[2], b.rho[2][j]);
         float e = norm3(n) - 1; en = (double)(e * e);
         float l = laplacian(b, j, a.grid.vs_inv); el = (double)(l * l);
     }

@@ -324,10 +324,15 @@ struct Vox { float xs[3], gn[3], nfd[3], rho[3]; };
 // compiler build a 64-bit address per plane -- two registers and a 64-bit shift-add each -- because j * 4 may not fit 32 bits.)
 // Valid while a plane is < 4 GiB, i.e. Spad < 2^30 rows.
 template <class T> __device__ __forceinline__ T at32(const T* p, unsigned byte_off) { return *(const T*)((const char*)p + (size_t)byte_off); }
+
+// the packed mirror (Band::vp): every writer of rho goes through set_rho; k_derive rewrites the whole record
+__device__ __forceinline__ void set_rho(const Band& b, int j, int ch, float v) { b.rho[ch][j] = v; reinterpret_cast<float*>(b.vp[ch] + j)[3] = v; }
 __device__ __forceinline__ void load_vox(const Band& b, int j, Vox& v) {
-    const unsigned o = (unsigned)j << 2;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { v.xs[a] = at32(b.xs[a], o); v.gn[a] = at32(b.gn[a], o); v.rho[a] = at32(b.rho[a], o); v.nfd[a] = at32(b.nfd[a], o); }
+    const unsigned o = (unsigned)j << 4;
+    const float4 p0 = at32(b.vp[0], o), p1 = at32(b.vp[1], o), p2 = at32(b.vp[2], o);
+    v.xs[0] = p0.x; v.xs[1] = p0.y; v.xs[2] = p0.z; v.rho[0] = p0.w;
+    v.gn[0] = p1.x; v.gn[1] = p1.y; v.gn[2] = p1.z; v.rho[1] = p1.w;
+    v.nfd[0] = p2.x; v.nfd[1] = p2.y; v.nfd[2] = p2.z; v.rho[2] = p2.w;
 }
 
 // ELL column offsets of one assembled distance row: self, 6 axis neighbours, 12 axis pairs

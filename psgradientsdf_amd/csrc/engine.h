@@ -56,10 +56,11 @@ struct Band {
     unsigned* colp;           // [9][Spad] the same as 16-bit deltas col - row, columns (2w+1, 2w+2) in word w: half the index bytes of a PCG pass
     int col16;                // 1 if every |col - row| fits 16 bits (then the PCG reads colp instead of col)
     // derived per voxel, refreshed whenever dist / grad change (k_derive)
-    float* xs[3];             // surface point x_v - d*normalized(grad)      (OptimizerAux.cpp:215)
-    float* gn[3];             // normalized(stored grad)
     float* gfd[3];            // finite-difference gradient (Optimizer.cpp:287-364), un-normalised
-    float* nfd[3];            // normalized(gfd): the normal every residual is rendered with
+    float4* vp[3];            // derived state, packed because the frame-major sweeps GATHER it per observation and are bound by L1 line
+                              // look-ups (3 16-byte gathers instead of 12 4-byte ones): {xs, rho.r}, {gn, rho.g}, {nfd, rho.b} with
+                              // xs = x_v - d*normalized(grad) (OptimizerAux.cpp:215), gn = normalized(stored grad), nfd = normalized(gfd)
+                              // (the normal every residual is rendered with); .w mirrors rho (set_rho)
     // albedo diagonal system
     float* aH; float* ab;     // [3][Spad]
     // distance system: per-voxel 4x4 block (10 sym) + 4 rhs, then assembled ELL rows

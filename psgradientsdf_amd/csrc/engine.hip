@@ -128,7 +128,7 @@ int build_band(psgsdf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int Spad = ((S + kBlock - 1) / kBlock) * kBlock + kBlock;
     // planes (4-byte units per row): see Band
-    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 4 + 8 + 9 + 1;
+    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 4 + 8 + 9 + 1 + 3;   // (xs, gn, nfd live in the packed planes vp: 12 instead of 9 words)
     const size_t bytes = (n4 * 4 + (size_t)KW * 8) * Spad + 256;
     if (c->band_mem) { hipFree(c->band_mem); c->band_mem = nullptr; }
     HIPCHK(c, hipMalloc(&c->band_mem, bytes));
@@ -145,14 +145,13 @@ int build_band(psgsdf_ctx* c) {
     for (int a = 0; a < 3; ++a) b.g[a] = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.rho[a] = (float*)take(1, 4);
     b.nb = (int*)take(6, 4); b.nbd = (float*)take(6, 4); b.col = (int*)take(kNQ, 4); b.colp = (unsigned*)take(9, 4); b.dirb = (int*)take(1, 4);
-    for (int a = 0; a < 3; ++a) b.xs[a] = (float*)take(1, 4);
-    for (int a = 0; a < 3; ++a) b.gn[a] = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.gfd[a] = (float*)take(1, 4);
-    for (int a = 0; a < 3; ++a) b.nfd[a] = (float*)take(1, 4);
+    for (int a = 0; a < 3; ++a) b.vp[a] = (float4*)take(4, 4);
     b.aH = (float*)take(3, 4); b.ab = (float*)take(3, 4);
     b.blk = (float*)take(14, 4); b.H = (float*)take(kNQ, 4);
     b.hx = (int*)take(1, 4);
     b.rhs = (float*)take(1, 4); b.x = (float*)take(1, 4); b.t = (float*)take(1, 4);
+    if ((size_t)(p - (char*)c->band_mem) > bytes) return fail(c, PSGSDF_ERR_DEVICE, "band arena overrun: %zu > %zu bytes", (size_t)(p - (char*)c->band_mem), bytes);
     HIPCHK(c, hipMemsetAsync(c->d_total, 0, sizeof(int), c->stream));
     timed(c, "band_fill", [&] { launch_band_fill(c->dense, c->grid, b, c->d_total, c->stream); });
     {   // 16-bit column deltas are usable if the widest reach of any ELL column fits (PSGSDF_PCG_COL16=0 forces the 32-bit table)

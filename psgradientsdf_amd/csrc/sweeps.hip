@@ -13,7 +13,8 @@ __global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
     const Band& b = a.b;
     int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.row1) return;
-    float xs[3] = {b.xs[0][j], b.xs[1][j], b.xs[2][j]};
+    const float4 p0 = b.vp[0][j];
+    float xs[3] = {p0.x, p0.y, p0.z};
     int count = 0; float rho[3] = {0, 0, 0};
     FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
         Proj pr = project(xs, sf[f], a.cam);
@@ -24,7 +25,7 @@ __global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
     }
     if (count) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) b.rho[k][j] = rho[k] / (float)count;
+        for (int k = 0; k < 3; ++k) set_rho(b, j, k, rho[k] / (float)count);
     }
 }
 void launch_init_albedo(const SweepArgs& a, hipStream_t s) {
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
                 if (a.damping != 0.0f) h += a.damping * h;
                 const float delta = (h != 0.f) ? bd[ch] / h : 0.f;
                 const float nv = v.rho[ch] - delta;
-                if (nv > 0.0f && nv < 1.0f) { b.rho[ch][j] = nv; cnt += 1.0; }
+                if (nv > 0.0f && nv < 1.0f) { set_rho(b, j, ch, nv); cnt += 1.0; }
             }
         } else {
 #pragma unroll
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_albedo(SweepArgs a) {
             if (a.damping != 0.0f) h += a.damping * h;
             float delta = (h != 0.f) ? b.ab[(size_t)ch * b.Spad + j] / h : 0.f;
             float v = b.rho[ch][j] - delta;
-            if (v > 0.0f && v < 1.0f) { b.rho[ch][j] = v; cnt += 1.0; }
+            if (v > 0.0f && v < 1.0f) { set_rho(b, j, ch, v); cnt += 1.0; }
         }
     }
     block_part_store(cnt, PART(a, SC_ACCEPT), red);
