@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--model", default="SH1", choices=["SH1", "SH2", "LED"])
+    ap.add_argument("--u8-images", action="store_true", help="keyframes quantised to 8 bits and handed over as 8-bit RGB (psgsdf_set_keyframes_u8) instead of float RGB")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--force-slab", action="store_true", help="run the multi-rank host program even with one rank (overhead measurement)")
@@ -92,7 +93,10 @@ def main():
     device = local_rank if world > 1 else 0
 
     t_gen = time.time()
-    sc = synth.make_scene(N=args.grid, F=args.frames, W=args.width, H=args.height, model=args.model)
+    # --u8-images: keyframes quantised to 8 bits and handed over the way the reference's loader receives them (8-bit RGB + 1/255,
+    # ImageLoader.h:167-181); the oracle always gets the converted floats.  Same speed as the float path (profiles/r01_notes.md, step n).
+    use_u8 = args.u8_images
+    sc = synth.make_scene(N=args.grid, F=args.frames, W=args.width, H=args.height, model=args.model, u8=use_u8)
     t_gen = time.time() - t_gen
     model_id = synth.MODELS[args.model]
     st = capi.default_settings(model_id)
@@ -106,7 +110,7 @@ def main():
         from psgradientsdf_amd.distributed import SlabRunner
         eng.comm_init(rank, world)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        eng.load_scene(sc)
+        eng.load_scene(sc, u8=use_u8)
         run = SlabRunner(eng, dist, cuda=True)
         run.init_albedo()
         run.normalize_weights()
@@ -114,7 +118,7 @@ def main():
         n_obs = run.step(capi.ALBEDO)["n_obs"] // world
         iterate = lambda k: run.iterate(capi.ALL, k, gather=False)   # the final all-gather of the refined band is an output step, not part of the loop body
     else:
-        eng.load_scene(sc)
+        eng.load_scene(sc, u8=use_u8)
         eng.init_albedo()
         eng.normalize_weights()
         S = eng.info().n_band
@@ -166,7 +170,7 @@ def main():
         else f"Gauss-Newton iterations/sec (full PS sweep), {args.grid}^3 grid x {args.frames} frames",
         "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic (8-bit RGB keyframes)" if use_u8 else "synthetic",
         "config": {"workload": f"synthetic {args.width}x{args.height} RGB-D bumpy sphere, {args.grid}^3 grid, {args.model}, {args.frames} keyframes, "
                                "albedo+light+distance+pose blocks, Cauchy IRLS, Eikonal reg (config_skorates.json settings)",
                    "band_voxels": int(S), "observations": int(n_obs), "pcg_iters_per_step": cg_iters,

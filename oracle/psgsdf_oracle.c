@@ -1599,6 +1599,18 @@ int orc_track(orc_ctx* c, const float* depth, int W, int H, float pose[16], floa
 }
 int orc_track_system(orc_ctx* c, const float* depth, int W, int H, const float pose[16], float z_min, float z_max, double acc[29]) { track_accumulate(c, depth, W, H, pose, z_min, z_max, acc); return 0; }
 
+int orc_set_keyframes(orc_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_images, int width, int height, const float* poses);
+/* 8-bit keyframes: the reference's own conversion (ImageLoader.h:181, convertTo(CV_32FC3, scale): (float)byte * scale), then the float path */
+int orc_set_keyframes_u8(orc_ctx* c, int n_frames, const int32_t* frame_idx, const uint8_t* rgb_images, float scale, int width, int height, const float* poses) {
+    if (!c || n_frames <= 0 || !rgb_images || width <= 1 || height <= 1) ORC_FAIL(c, PSGSDF_ERR_ARG, "set_keyframes_u8: bad argument");
+    const size_t n = (size_t)n_frames * width * height * 3;
+    float* f = (float*)malloc(sizeof(float) * n);
+    if (!f) ORC_FAIL(c, PSGSDF_ERR_DEVICE, "out of memory");
+    for (size_t i = 0; i < n; ++i) f[i] = (float)rgb_images[i] * scale;
+    const int rc = orc_set_keyframes(c, n_frames, frame_idx, f, width, height, poses);
+    free(f);
+    return rc;
+}
 int orc_set_keyframes(orc_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_images, int width, int height, const float* poses) {
     if (!c || n_frames < 0 || (n_frames > 0 && (!frame_idx || !rgb_images || !poses))) return PSGSDF_ERR_ARG;
     free(c->frame_idx); free(c->img); free(c->poses);

@@ -128,9 +128,26 @@ class Api:
         a = [_fp(frame_idx, np.int32), _fp(images), _fp(poses)]
         self._check(self._fn("set_keyframes")(self.ctx, C.c_int(F), a[0][1], a[1][1], C.c_int(W), C.c_int(H), a[2][1]), "set_keyframes")
 
-    def load_scene(self, sc):
+    def set_keyframes_u8(self, frame_idx, images_u8, scale, poses):
+        """8-bit RGB keyframes [F][H][W][3] + the loader's conversion factor (colour = byte * scale)"""
+        F, H, W = images_u8.shape[:3]
+        img = np.ascontiguousarray(images_u8, dtype=np.uint8)
+        a = [_fp(frame_idx, np.int32), _fp(poses)]
+        self._check(self._fn("set_keyframes_u8")(self.ctx, C.c_int(F), a[0][1], img.ctypes.data_as(C.c_void_p), C.c_float(scale),
+                                                    C.c_int(W), C.c_int(H), a[1][1]), "set_keyframes_u8")
+
+    def load_scene(self, sc, u8=None):
+        """u8: hand the keyframes over as 8-bit RGB when the scene has them (default: whenever it has)"""
         self.upload_volume(sc.dist, sc.grad, sc.weight, sc.rgb, sc.vis, sc.vis_words)
-        self.set_keyframes(sc.frame_idx, sc.images, sc.poses)
+        has_u8 = getattr(sc, "images_u8", None) is not None
+        if u8 is None:
+            u8 = has_u8
+        if u8:
+            if not has_u8:
+                raise ValueError("scene has no 8-bit images")
+            self.set_keyframes_u8(sc.frame_idx, sc.images_u8, sc.image_scale, sc.poses)
+        else:
+            self.set_keyframes(sc.frame_idx, sc.images, sc.poses)
         self.init()
 
     def init(self):

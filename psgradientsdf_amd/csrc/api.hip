@@ -49,7 +49,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     free_dense(c);
-    hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->frames); hipFree(c->led_light);
+    hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->led_light);
     hipFree(c->band_mem); hipFree(c->obs_mem); hipFree(c->stage);
     hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->d_total);
     if (c->host_buf) hipHostFree(c->host_buf);
@@ -123,22 +123,36 @@ int psgsdf_integrate_frame(psgsdf_ctx* c, const float* rgb, const float* depth, 
     return PSGSDF_OK;
 }
 
-int psgsdf_set_keyframes(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_images, int width, int height, const float* poses) {
-    if (!c || n_frames <= 0 || !frame_idx || !rgb_images || !poses || width <= 1 || height <= 1) return fail(c, PSGSDF_ERR_ARG, "set_keyframes: bad argument");
+// everything of set_keyframes but the pixels; exactly one of rgb_f32 / rgb_u8 is given
+static int set_keyframes_impl(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_f32, const uint8_t* rgb_u8, float scale,
+                              int width, int height, const float* poses) {
+    if (!c || n_frames <= 0 || !frame_idx || (!rgb_f32 && !rgb_u8) || !poses || width <= 1 || height <= 1) return fail(c, PSGSDF_ERR_ARG, "set_keyframes: bad argument");
     if (n_frames > kMaxFramesLds) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d keyframes", kMaxFramesLds);
+    if (rgb_u8 && (size_t)n_frames * width * height >= ((size_t)1 << 30)) return fail(c, PSGSDF_ERR_UNSUPPORTED, "8-bit keyframes: at most 2^30 pixels");
     HIPCHK(c, hipSetDevice(c->device));
-    hipFree(c->frame_idx); hipFree(c->img); hipFree(c->frames); hipFree(c->acc_frame);
-    c->frame_idx = nullptr; c->img = nullptr; c->frames = nullptr; c->acc_frame = nullptr;
+    hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->acc_frame);
+    c->frame_idx = nullptr; c->img = nullptr; c->img8 = nullptr; c->frames = nullptr; c->acc_frame = nullptr;
     c->F = n_frames; c->cam.W = width; c->cam.H = height;
-    const size_t npx = (size_t)n_frames * width * height * 3;
+    const size_t npix = (size_t)n_frames * width * height;
     HIPCHK(c, hipMalloc(&c->frame_idx, sizeof(int) * n_frames));
-    HIPCHK(c, hipMalloc(&c->img, sizeof(float) * npx));
     HIPCHK(c, hipMalloc(&c->frames, sizeof(FrameP) * n_frames));
     c->acc_frame_n = (size_t)n_frames * 64;
     HIPCHK(c, hipMalloc(&c->acc_frame, sizeof(double) * c->acc_frame_n));
     HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));   // invariant: zero outside [sweep, solve]
     HIPCHK(c, hipMemcpyAsync(c->frame_idx, frame_idx, sizeof(int) * n_frames, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->img, rgb_images, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
+    if (rgb_f32) {
+        HIPCHK(c, hipMalloc(&c->img, sizeof(float) * npix * 3));
+        HIPCHK(c, hipMemcpyAsync(c->img, rgb_f32, sizeof(float) * npix * 3, hipMemcpyHostToDevice, c->stream));
+    } else {
+        uint8_t* tmp = nullptr;
+        HIPCHK(c, hipMalloc(&c->img8, sizeof(unsigned) * npix));
+        HIPCHK(c, hipMalloc(&tmp, npix * 3));
+        HIPCHK(c, hipMemcpyAsync(tmp, rgb_u8, npix * 3, hipMemcpyHostToDevice, c->stream));
+        launch_pack_rgb8(tmp, c->img8, npix, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(tmp);
+        c->img_scale = scale;
+    }
     c->frames_h.assign(n_frames, FrameP{});
     for (int f = 0; f < n_frames; ++f) {
         const float* P = poses + 16 * f;
@@ -148,6 +162,12 @@ int psgsdf_set_keyframes(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_frames = true; c->inited = false;
     return PSGSDF_OK;
+}
+int psgsdf_set_keyframes(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_images, int width, int height, const float* poses) {
+    return set_keyframes_impl(c, n_frames, frame_idx, rgb_images, nullptr, 0.f, width, height, poses);
+}
+int psgsdf_set_keyframes_u8(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, const uint8_t* rgb_images, float scale, int width, int height, const float* poses) {
+    return set_keyframes_impl(c, n_frames, frame_idx, nullptr, rgb_images, scale, width, height, poses);
 }
 
 int psgsdf_init(psgsdf_ctx* c) {

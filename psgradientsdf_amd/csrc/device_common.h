@@ -229,8 +229,42 @@ __device__ __forceinline__ const float* pix(const float* img, const Cam& cam, in
 }
 
 // Auxilary.h:41-61 interpolateImage + Auxilary.h:64-123 computeImageGradient from one set of taps.
-// (row coordinate n_row, column coordinate m_col); gu = d/d(col), gv = d/d(row).
-// `base` is wave-uniform (the image stack, or one frame of it), `frame` selects the image inside it (0 for a frame pointer).
+// Output convention (col=m_col / row=n_row are the projected pixel coordinates): I = bilinear colour, gu = d/d(col), gv = d/d(row).
+template <bool GRAD>
+__device__ __forceinline__ void interp_taps(const float* a00, const float* a01, const float* a10, const float* a11, float fm, float fn, float* I, float* gu, float* gv) {
+    // reference: weights partly in double (Auxilary.h:47); float weights agree to ~1e-7 relative
+    const float w1 = (1.0f - fn) * fm, w2 = (1.0f - fn) * (1.0f - fm), w3 = fn * fm, w4 = fn * (1.0f - fm);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) I[ch] = ((a10[ch] * w1 + a00[ch] * w2) + a11[ch] * w3) + a01[ch] * w4;
+    if (GRAD) {
+        const float w01 = fm, w11 = fn, w00 = 1.0f - fm, w10 = 1.0f - fn;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            gu[ch] = w00 * (a01[ch] - a00[ch]) + w01 * (a11[ch] - a10[ch]);
+            gv[ch] = w10 * (a10[ch] - a00[ch]) + w11 * (a11[ch] - a01[ch]);
+        }
+    }
+}
+// last row / column: nearest sample, one-sided differences (Auxilary.h:55-57,90-121); TEX(row, col, out[3]) clamps like pix()
+template <bool GRAD, class TEX>
+__device__ __forceinline__ void sample_border(const TEX& tex, const Cam& cam, int x, int y, float m, float n, float* I, float* gu, float* gv) {
+    float p[3]; tex(x, y, p);
+    I[0] = p[0]; I[1] = p[1]; I[2] = p[2];
+    if (GRAD) {
+        float w01 = m - (float)x, w11 = n - (float)y;
+        float w00 = (float)(1.0 - (double)w01), w10 = (float)(1.0 - (double)w11);
+        float q_y1[3], q_ym[3], q_x1ym[3], q_x1[3], q_xm[3], q_xmy1[3];
+        tex(x, y + 1, q_y1); tex(x, y - 1, q_ym); tex(x + 1, y - 1, q_x1ym); tex(x + 1, y, q_x1); tex(x - 1, y, q_xm); tex(x - 1, y + 1, q_xmy1);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            if ((x + 1) >= cam.H) gu[ch] = q_y1[ch] - p[ch];
+            else { float v0 = -q_ym[ch] + p[ch]; float v1 = -q_x1ym[ch] + q_x1[ch]; gu[ch] = w00 * v0 + w01 * v1; }
+            if ((x + 1) >= cam.H && (y + 1) < cam.W) { float v0 = -q_xm[ch] + p[ch]; float v1 = -q_xmy1[ch] + q_y1[ch]; gv[ch] = w10 * v0 + w11 * v1; }
+            else gv[ch] = q_x1[ch] - p[ch];
+        }
+    }
+}
+// float RGB images [F][H][W][3].
 // idx32: the whole stack is < 4 GiB, so a tap's byte offset fits 32 bits and the loads take the scalar-base form (one address
 // register, no 64-bit integer multiply-adds, which issue at quarter rate and made up ~10 % of a sweep's instruction slots).
 template <bool GRAD>
@@ -252,34 +286,48 @@ __device__ __forceinline__ void sample(const float* base, int frame, bool idx32,
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { a00[ch] = p00[ch]; a01[ch] = p00[3 + ch]; a10[ch] = p10[ch]; a11[ch] = p10[3 + ch]; }
         }
-        // reference: weights partly in double (Auxilary.h:47); float weights agree to ~1e-7 relative
-        const float fm = m - (float)x, fn = n - (float)y;
-        const float w1 = (1.0f - fn) * fm, w2 = (1.0f - fn) * (1.0f - fm), w3 = fn * fm, w4 = fn * (1.0f - fm);
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) I[ch] = ((a10[ch] * w1 + a00[ch] * w2) + a11[ch] * w3) + a01[ch] * w4;
-        if (GRAD) {
-            const float w01 = fm, w11 = fn, w00 = 1.0f - fm, w10 = 1.0f - fn;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                gu[ch] = w00 * (a01[ch] - a00[ch]) + w01 * (a11[ch] - a10[ch]);
-                gv[ch] = w10 * (a10[ch] - a00[ch]) + w11 * (a11[ch] - a01[ch]);
-            }
-        }
-    } else {  // last row / column: nearest sample, one-sided differences (Auxilary.h:55-57,90-121)
-        const float* p = pix(img, cam, x, y);
-        I[0] = p[0]; I[1] = p[1]; I[2] = p[2];
-        if (GRAD) {
-            float w01 = m - (float)x, w11 = n - (float)y;
-            float w00 = (float)(1.0 - (double)w01), w10 = (float)(1.0 - (double)w11);
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                if ((x + 1) >= cam.H) gu[ch] = pix(img, cam, x, y + 1)[ch] - pix(img, cam, x, y)[ch];
-                else { float v0 = -pix(img, cam, x, y - 1)[ch] + pix(img, cam, x, y)[ch]; float v1 = -pix(img, cam, x + 1, y - 1)[ch] + pix(img, cam, x + 1, y)[ch]; gu[ch] = w00 * v0 + w01 * v1; }
-                if ((x + 1) >= cam.H && (y + 1) < cam.W) { float v0 = -pix(img, cam, x - 1, y)[ch] + pix(img, cam, x, y)[ch]; float v1 = -pix(img, cam, x - 1, y + 1)[ch] + pix(img, cam, x, y + 1)[ch]; gv[ch] = w10 * v0 + w11 * v1; }
-                else gv[ch] = pix(img, cam, x + 1, y)[ch] - pix(img, cam, x, y)[ch];
-            }
-        }
+        interp_taps<GRAD>(a00, a01, a10, a11, m - (float)x, n - (float)y, I, gu, gv);
+    } else {
+        auto tex = [&](int row, int col, float* o) { const float* q = pix(img, cam, row, col); o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; };
+        sample_border<GRAD>(tex, cam, x, y, m, n, I, gu, gv);
     }
+}
+// 8-bit RGB images as the reference's loader receives them (ImageLoader.h:167-181: cv::imread, then convertTo(CV_32FC3, 1/255)),
+// stored as one RGBA8 word per pixel [F][H][W]: the two taps of an image row are ONE 8-byte load instead of two 12-byte ones and a
+// cache line holds 16 pixels instead of 5 (measured: no faster than the float path -- the taps are not what bounds the sweeps --
+// but a quarter of the upload and a third of the resident bytes).
+// (float)byte * scale is exactly the float the reference's conversion produces.
+__device__ __forceinline__ void unpack_rgb8(unsigned w, float scale, float* o) {
+    // __fmul_rn: a rounded product, never contracted into a following add -- the taps must be the floats the reference holds
+    o[0] = __fmul_rn((float)(w & 0xffu), scale); o[1] = __fmul_rn((float)((w >> 8) & 0xffu), scale); o[2] = __fmul_rn((float)((w >> 16) & 0xffu), scale);
+}
+template <bool GRAD>
+__device__ __forceinline__ void sample_u8(const unsigned* base, float scale, int frame, const Cam& cam, float m_col, float n_row, float* I, float* gu, float* gv) {
+    const float m = n_row, n = m_col;
+    int x = (int)floorf(m), y = (int)floorf(n);
+    if ((x + 1) < cam.H && (y + 1) < cam.W) {
+        const unsigned e = ((unsigned)frame * (unsigned)cam.H + (unsigned)x) * (unsigned)cam.W + (unsigned)y;      // < 2^30 pixels (engine.hip checks)
+        const unsigned* p0 = (const unsigned*)((const char*)base + (size_t)(e << 2));
+        const unsigned* p1 = (const unsigned*)((const char*)base + (size_t)((e + (unsigned)cam.W) << 2));
+        const unsigned t00 = p0[0], t01 = p0[1], t10 = p1[0], t11 = p1[1];
+        float a00[3], a01[3], a10[3], a11[3];
+        unpack_rgb8(t00, scale, a00); unpack_rgb8(t01, scale, a01); unpack_rgb8(t10, scale, a10); unpack_rgb8(t11, scale, a11);
+        interp_taps<GRAD>(a00, a01, a10, a11, m - (float)x, n - (float)y, I, gu, gv);
+    } else {
+        const unsigned* img = base + (size_t)frame * cam.H * cam.W;
+        auto tex = [&](int row, int col, float* o) {
+            row = row < 0 ? 0 : (row >= cam.H ? cam.H - 1 : row);
+            col = col < 0 ? 0 : (col >= cam.W ? cam.W - 1 : col);
+            unpack_rgb8(img[(size_t)row * cam.W + col], scale, o);
+        };
+        sample_border<GRAD>(tex, cam, x, y, m, n, I, gu, gv);
+    }
+}
+// either format, chosen by the (wavefront-uniform) image source of the launch
+template <bool GRAD>
+__device__ __forceinline__ void sample(const ImgSrc& s, int frame, const Cam& cam, float m_col, float n_row, float* I, float* gu, float* gv) {
+    if (s.u8) sample_u8<GRAD>(s.u8, s.scale, frame, cam, m_col, n_row, I, gu, gv);
+    else sample<GRAD>(s.f32, frame, s.idx32, cam, m_col, n_row, I, gu, gv);
 }
 
 // rendered intensity: PsOptimizerJa.cpp:30-40 (SH) / LedOptimizerJa.cpp:15-29 (LED).

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(kBlock, MODEL == 0 ? 5 : 1) k_sweep_dist(Sweep
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], gu[3], gv[3], ren[3];
-            sample<true>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, gu, gv);
+            sample<true>(a.im, f, a.cam, pr.m, pr.n, I, gu, gv);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
             float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
             float GRt[9];

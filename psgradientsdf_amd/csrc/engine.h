@@ -103,11 +103,17 @@ struct AlbedoReg {
 // first workgroup instead of a 1-workgroup kernel of its own (saves a launch + boundary per scalar read-back)
 struct FoldReq { int n; int id[4]; int nblk; double* out; };
 
+// keyframe images: float RGB [F][H][W][3] (psgsdf_set_keyframes) or RGBA8 words [F][H][W] (psgsdf_set_keyframes_u8); exactly one is set
+struct ImgSrc {
+    const float* f32;
+    const unsigned* u8; float scale;   // colour = (float)byte * scale
+    bool idx32;                        // f32: the stack is < 4 GiB, tap offsets fit 32 bits (device_common.h: sample)
+};
+
 struct SweepArgs {
     Band b;
     const FrameP* frames;     // [F]
-    const float* img;         // [F][H][W][3]
-    bool img32;               // the image stack is < 4 GiB: tap offsets fit 32 bits (device_common.h: sample)
+    ImgSrc im;
     int F;
     Cam cam;
     GridP grid;
@@ -130,6 +136,7 @@ struct SweepArgs {
 };
 
 // ---- launchers implemented in the kernel files (all asynchronous on `s`) ----------------------
+void launch_pack_rgb8(const uint8_t* rgb, unsigned* rgba, size_t npix, hipStream_t s);   // [npix][3] bytes -> one RGBA8 word per pixel
 void launch_select_vis(const uint64_t* vis_seq, int wpv_seq, uint64_t* vis_key, int KW, const int* frame_idx, int F, long long nvox, hipStream_t s);
 void launch_band_flags(const float* dist, const uint64_t* vis_key, int KW, float vs, long long nvox, int* flags, hipStream_t s);
 // exclusive scan of flags -> row_of (-1 where flag==0); returns total through d_total (device int)

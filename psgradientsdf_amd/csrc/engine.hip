@@ -11,8 +11,9 @@ int fail(psgsdf_ctx* c, int code, const char* fmt, ...) {
 }
 SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     SweepArgs a{};
-    a.b = c->band; a.frames = c->frames; a.img = c->img; a.F = c->F; a.cam = c->cam; a.grid = c->grid;
-    a.img32 = (size_t)c->F * c->cam.W * c->cam.H * 12 < ((size_t)1 << 32);
+    a.b = c->band; a.frames = c->frames; a.F = c->F; a.cam = c->cam; a.grid = c->grid;
+    a.im.f32 = c->img; a.im.u8 = c->img8; a.im.scale = c->img_scale;
+    a.im.idx32 = (size_t)c->F * c->cam.W * c->cam.H * 12 < ((size_t)1 << 32);
     a.rob.loss = c->set.loss; a.rob.lambda = c->set.lambda; a.rob.lambda_sq = c->set.lambda * c->set.lambda; a.rob.inv_lambda = 1.0f / c->set.lambda;
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
     a.fold.n = 0; a.gate = nullptr; a.fuse_apply = 0;

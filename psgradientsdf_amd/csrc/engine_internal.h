@@ -88,6 +88,7 @@ struct psgsdf_ctx {
     bool fuse_albedo = true;             // PSGSDF_FUSE_ALBEDO=0: separate k_apply_albedo launch
     bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
     bool albedo_applied = false;         // the last albedo sweep already applied its update (step_begin -> step_finish)
+    unsigned* img8 = nullptr; float img_scale = 0.f;   // keyframes uploaded as 8-bit RGB (psgsdf_set_keyframes_u8): RGBA8 words, c->img stays null
     double* frame_e_slot = nullptr;      // mailbox slot the next per-frame solve writes its sweep's energy sums to
     bool pcg_poll = true;                // PCG stop test by watching the mapped mailbox (PSGSDF_PCG_POLL=0: drain the stream instead)
     int need[2] = {0, 0}; int* d_need = nullptr;   // halo rows needed below row0 / from row1 up

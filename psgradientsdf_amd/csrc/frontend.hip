@@ -157,4 +157,13 @@ void launch_fill_f32(float* p, float v, long long n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_fill_f32, dim3(grid), dim3(kBlock), 0, s, p, v, n);
 }
 
+// 8-bit keyframes: interleaved RGB bytes -> one word per pixel (psgsdf_set_keyframes_u8)
+__global__ void __launch_bounds__(kBlock) k_pack_rgb8(const uint8_t* __restrict__ rgb, unsigned* __restrict__ rgba, size_t npix) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x)
+        rgba[i] = (unsigned)rgb[3 * i] | ((unsigned)rgb[3 * i + 1] << 8) | ((unsigned)rgb[3 * i + 2] << 16);
+}
+void launch_pack_rgb8(const uint8_t* rgb, unsigned* rgba, size_t npix, hipStream_t s) {
+    if (npix) hipLaunchKernelGGL(k_pack_rgb8, dim3((unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, 65535)), dim3(kBlock), 0, s, rgb, rgba, npix);
+}
+
 }  // namespace psg

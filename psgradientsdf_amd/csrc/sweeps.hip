@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
         Proj pr = project(xs, sf[f], a.cam);
         if (!pr.ok) continue;
         float I[3];
-        sample<false>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        sample<false>(a.im, f, a.cam, pr.m, pr.n, I, nullptr, nullptr);
         rho[0] += I[0]; rho[1] += I[1]; rho[2] += I[2]; count++;
     }
     if (count) {
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], ren[3];
-            sample<false>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+            sample<false>(a.im, f, a.cam, pr.m, pr.n, I, nullptr, nullptr);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
             if (LED_INIT) {
 #pragma unroll
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], ren[3], J[3];
-            sample<false>(a.img, f, a.img32, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+            sample<false>(a.im, f, a.cam, pr.m, pr.n, I, nullptr, nullptr);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
             rho_jac<MODEL>(fp, pr, v.gn, shg, J);
             float l = 0.f;
@@ -205,7 +205,9 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
     __syncthreads();
     const Band& b = a.b;
     const FrameP& fp = sfp;
-    const float* img = a.img + (size_t)f * a.cam.H * a.cam.W * 3;
+    ImgSrc img = a.im;                       // this frame's image as frame 0 of its own stack (offsets always fit 32 bits)
+    if (img.u8) img.u8 += (size_t)f * a.cam.H * a.cam.W; else img.f32 += (size_t)f * a.cam.H * a.cam.W * 3;
+    img.idx32 = true;
     float acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.f;
@@ -228,7 +230,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
         float shfd[kMaxBasis], shg[kMaxBasis];
         if (!LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
         float I[3], ren[3];
-        sample<false>(img, 0, true, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        sample<false>(img, 0, a.cam, pr.m, pr.n, I, nullptr, nullptr);
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
         float refl = 0.f;
         if (LED) { float Rp[3]; mul3(fp.R, pr.p, Rp); refl = dot3(v.gn, Rp); float pn = norm3(pr.p); double pd = (double)pn; refl /= (float)(pd * pd * pd); }
@@ -293,7 +295,9 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
     __syncthreads();
     const Band& b = a.b;
     const FrameP& fp = sfp;
-    const float* img = a.img + (size_t)f * a.cam.H * a.cam.W * 3;
+    ImgSrc img = a.im;                       // this frame's image as frame 0 of its own stack (offsets always fit 32 bits)
+    if (img.u8) img.u8 += (size_t)f * a.cam.H * a.cam.W; else img.f32 += (size_t)f * a.cam.H * a.cam.W * 3;
+    img.idx32 = true;
     float acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.f;
@@ -316,7 +320,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
         float shfd[kMaxBasis];
         if (!LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
         float I[3], gu[3], gv[3], ren[3];
-        sample<true>(img, 0, true, a.cam, pr.m, pr.n, I, gu, gv);
+        sample<true>(img, 0, a.cam, pr.m, pr.n, I, gu, gv);
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
         float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
         float J[18];

@@ -69,9 +69,13 @@ def _sh(n, order):
 
 
 def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, noise=True,
-               perturb=True, z_mult=1, dtype=np.float32, bump=1.0, arc=360.0):
+               perturb=True, z_mult=1, dtype=np.float32, bump=1.0, arc=360.0, u8=False):
     """Build a scene.  N: grid edge (z edge = N*z_mult, z_mult bumpy spheres stacked along z for the
     weak-scaling bench), F keyframes of W x H pixels.
+
+    u8: quantise the rendered keyframes to 8 bits the way a camera / PNG does; the scene then carries `images_u8` (uint8) with
+    `image_scale` = 1/255 next to `images` = images_u8 * image_scale (float32, exactly what the reference's loader would hold), and
+    everything derived from the images uses the quantised values.
 
     Intrinsics scale with the image so the object always fills the same fraction of the frame:
     fx = fy = 525 * W/640 (TUM-like 640x480 -> 525)."""
@@ -195,6 +199,11 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
     if noise:
         images = images + 0.005 * np.random.default_rng(1).standard_normal(images.shape)
     images = np.clip(images, 0.0, 1.0)
+    images_u8, image_scale = None, None
+    if u8:
+        images_u8 = np.rint(images * 255.0).astype(np.uint8)
+        image_scale = np.float32(1.0) / np.float32(255.0)
+        images = (images_u8.astype(np.float32) * image_scale).astype(np.float64)      # float32 product, as convertTo(CV_32FC3, 1/255) stores it
 
     # ---- analytic voxel state
     ii = np.arange(N, dtype=np.float64)
@@ -282,7 +291,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         shift=shift.astype(np.float32), truncation=np.float32(T), K=K,
         dist=dist, grad=np.ascontiguousarray(grad), weight=weight, rgb=np.ascontiguousarray(rgb),
         vis=np.ascontiguousarray(vis), vis_words=wpv, albedo_gt=albedo_gt,
-        images=np.ascontiguousarray(images.astype(np.float32)),
+        images=np.ascontiguousarray(images.astype(np.float32)), images_u8=images_u8, image_scale=image_scale,
         poses=np.ascontiguousarray(poses_used.reshape(F, 16).astype(np.float32)),
         poses_gt=poses.reshape(F, 16).astype(np.float32),
         light_gt=np.asarray(light, np.float32), frame_idx=np.arange(F, dtype=np.int32),
@@ -324,6 +333,7 @@ def tile_scene(sc, n):
     d = dict(sc.__dict__)
     d.update(F=F * n, dim=np.array([sc.dim[0], sc.dim[1], nz * n], np.int32), dist=tz(sc.dist), grad=tz(sc.grad), weight=tz(sc.weight),
              rgb=tz(sc.rgb), albedo_gt=tz(sc.albedo_gt), vis=vis, vis_words=wpv,
-             images=np.ascontiguousarray(np.tile(sc.images, (n, 1, 1, 1))), poses=poses.reshape(n * F, 16), poses_gt=poses_gt.reshape(n * F, 16),
+             images=np.ascontiguousarray(np.tile(sc.images, (n, 1, 1, 1))),
+             images_u8=None if getattr(sc, 'images_u8', None) is None else np.ascontiguousarray(np.tile(sc.images_u8, (n, 1, 1, 1))), poses=poses.reshape(n * F, 16), poses_gt=poses_gt.reshape(n * F, 16),
              light_gt=np.asarray(light, np.float32), frame_idx=np.arange(F * n, dtype=np.int32))
     return Scene(**d)

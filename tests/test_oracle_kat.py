@@ -298,3 +298,15 @@ def test_albedo_reg_step_descends_and_quirk_couples_green_blue():
         st = o.step(capi.ALBEDO)
         assert st["cg_converged"] == 1 and st["cg_iters"] > 1 and st["applied"] == 1
         assert o.energy()[3] < e0
+
+
+def test_8bit_keyframes_are_the_converted_floats(built):
+    """orc_set_keyframes_u8 = the reference loader's convertTo(CV_32FC3, 1/255) (ImageLoader.h:181) followed by the float path"""
+    from oracle import oracle
+    sc = synth.make_scene(N=24, F=4, W=80, H=60, u8=True)
+    assert np.array_equal(sc.images, sc.images_u8.astype(np.float32) * sc.image_scale)
+    st = capi.default_settings(capi.SH1)
+    a = oracle.Oracle(sc, sc.K, st); a.load_scene(sc, u8=True); a.init_albedo()
+    b = oracle.Oracle(sc, sc.K, st); b.load_scene(sc, u8=False); b.init_albedo()
+    assert a.energy() == b.energy()
+    assert np.array_equal(a.download_volume()["rgb"], b.download_volume()["rgb"])
