@@ -146,7 +146,7 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_iter"] if algorithmic_bytes(k, 1, 1, 1, 1, 1) else -1)
     eng.reset_kernel_times()
     if os.environ.get("PSGSDF_NO_WATCH") != "1":   # (tools/gap_run.sh: trace without the event pairs)
-        eng.watch_kernel(dom + "/8")  # HIP events around every 8th launch of the dominant kernel (each pair costs ~3 us of stream time)
+        eng.watch_kernel(dom + "/16")  # HIP events around every 16th launch of the dominant kernel (each pair breaks the back-to-back dispatch: ~6 us of stream time)
     barrier()
     t0 = time.perf_counter()
     recs = iterate(args.steps)
@@ -180,7 +180,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live with HIP events inside the timed region
         lap = st.reg_weight_l != 0.0
-        # event pairs recorded on the launch stream around every 8th launch: the pair also reads the dispatch latency, so this is
+        # event pairs recorded on the launch stream around every 16th launch: the pair also reads the dispatch latency, so this is
         # ~2.5 us above the kernel duration rocprofv3 --kernel-trace reports (profiles/): the roofline fraction errs low
         avg_ms = watched[0] / max(watched[1], 1) if watched[1] else float("nan")
         nbytes = algorithmic_bytes(dom, S, n_obs, args.width, args.height, args.frames, lap)   # per GPU (one slab)
