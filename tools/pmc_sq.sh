@@ -7,7 +7,7 @@ out=gpurun_out/pmcsq_$tag; mkdir -p $out
 for c in "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr TA_TA_BUSY_sum" \
          "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32" \
          "SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_ANY SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_VMEM_TA_ADDR_FIFO_FULL SQ_ACTIVE_INST_SCA" \
-         "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_TAG_STALL_sum TCC_BUSY_avr"; do
+         "TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-40)
   timeout 240 rocprofv3 --pmc $c -d $out/$n -o pmc --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-breakdown > $out/$n.json 2> $out/$n.err
 done
