@@ -57,8 +57,22 @@ template <int NB> __device__ __forceinline__ void SH(const float* n, float* sh) 
 template <int MODEL> struct ModelTraits { static constexpr int NB = MODEL == 1 ? 9 : (MODEL == 0 ? 4 : 3); static constexpr bool LED = MODEL == 2; };
 
 // Optimizer.cpp:140-161 / 164-186
+// launches K<model, loss>: the three shading models x {Cauchy compiled in, loss decided at run time}
+#define PSG_LAUNCH_BY_MODEL_AND_LOSS(K, args, grid, block, shmem, stream, ...) do { \
+        if ((args).rob.loss == 1) { \
+            if ((args).model == 0) hipLaunchKernelGGL((K<0, 1>), grid, block, shmem, stream, __VA_ARGS__); \
+            else if ((args).model == 1) hipLaunchKernelGGL((K<1, 1>), grid, block, shmem, stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((K<2, 1>), grid, block, shmem, stream, __VA_ARGS__); \
+        } else { \
+            if ((args).model == 0) hipLaunchKernelGGL((K<0, -1>), grid, block, shmem, stream, __VA_ARGS__); \
+            else if ((args).model == 1) hipLaunchKernelGGL((K<1, -1>), grid, block, shmem, stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((K<2, -1>), grid, block, shmem, stream, __VA_ARGS__); \
+        } } while (0)
+// LOSS: the loss function as a compile-time constant (the sweeps are instantiated for Cauchy, what every shipped config uses) or -1 =
+// decided at run time -- six wavefront-uniform switches per observation cost the sweeps 3-4 us each
+template <int LOSS = -1>
 __device__ __forceinline__ float robust_weight(const Robust& rb, float r) {
-    switch (rb.loss) {
+    switch (LOSS >= 0 ? LOSS : rb.loss) {
         case 1: { float x = r * rb.inv_lambda; return __builtin_amdgcn_rcpf(1.0f + x * x); }   // v_rcp_f32: 1 ulp
         case 3: { float x = r * rb.inv_lambda; float w = (1.0f - x * x); w = w * w; return (r * r < rb.lambda_sq) ? w : 0.0f; }
         case 2: { float w = rb.lambda * fabsf(__builtin_amdgcn_rcpf(r)); return (r * r < rb.lambda_sq) ? 1.0f : w; }
@@ -66,8 +80,9 @@ __device__ __forceinline__ float robust_weight(const Robust& rb, float r) {
         default: return 1.0f;
     }
 }
+template <int LOSS = -1>
 __device__ __forceinline__ float robust_loss(const Robust& rb, float r) {
-    switch (rb.loss) {
+    switch (LOSS >= 0 ? LOSS : rb.loss) {
         case 1: { float x = r * rb.inv_lambda; return __logf(1.0f + x * x); }
         case 3: { float x = r * rb.inv_lambda; float u = 1.0f - x * x; float v = 1.0f - u * u * u; return (r * r < rb.lambda_sq) ? v : 1.0f; }
         case 2: return (r * r < rb.lambda_sq) ? 0.5f * (r * r) : rb.lambda * (fabsf(r) - 0.5f * rb.lambda * 1.0f);

@@ -20,7 +20,7 @@ __device__ __forceinline__ void normal_jacobian(float vs_inv, const float* grad,
 
 // distJacobian per observation PsOptimizerJa.cpp:160-289 / LedOptimizerJa.cpp:117-218, accumulated directly
 // into the per-voxel block over {self, x-, y-, z-stencil neighbour}; regularisers Optimizer.cpp:196-218,477-590.
-template <int MODEL>
+template <int MODEL, int LOSS>
 __global__ void __launch_bounds__(kBlock, MODEL == 0 ? 5 : 1) k_sweep_dist(SweepArgs a) {
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
@@ -125,8 +125,8 @@ __global__ void __launch_bounds__(kBlock, MODEL == 0 ? 5 : 1) k_sweep_dist(Sweep
             float l = 0.f;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
-                l += robust_loss(a.rob, r);
+                float r = I[ch] - ren[ch]; float w = robust_weight<LOSS>(a.rob, r);
+                l += robust_loss<LOSS>(a.rob, r);
                 int q = 0;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -179,9 +179,7 @@ __global__ void __launch_bounds__(kBlock, MODEL == 0 ? 5 : 1) k_sweep_dist(Sweep
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;
     dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_sweep_dist<0>), g, bl, a.F * sizeof(FrameP), s, a);
-    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_dist<1>), g, bl, a.F * sizeof(FrameP), s, a);
-    else hipLaunchKernelGGL((k_sweep_dist<2>), g, bl, a.F * sizeof(FrameP), s, a);
+    PSG_LAUNCH_BY_MODEL_AND_LOSS(k_sweep_dist, a, g, bl, a.F * sizeof(FrameP), s, a);
 }
 
 // one ELL row (and, if a.pcg_fuse_init, the PCG initialisation of that row: returns r_0^2)

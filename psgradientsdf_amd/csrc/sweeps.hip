@@ -34,7 +34,7 @@ void launch_init_albedo(const SweepArgs& a, hipStream_t s) {
 
 // getPSEnergy PsOptimizer.cpp:47-78 / LedOptimizer.cpp:40-71; LED_INIT: computeLightIntensive
 // LedOptimizer.cpp:76-112 (sums of observed and rendered intensity)
-template <int MODEL, bool LED_INIT>
+template <int MODEL, bool LED_INIT, int LOSS>
 __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
             } else {
                 float l = 0.f;
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) l += robust_loss(a.rob, I[ch] - ren[ch]);
+                for (int ch = 0; ch < 3; ++ch) l += robust_loss<LOSS>(a.rob, I[ch] - ren[ch]);
                 Ef += l; nobs += 1.0;
             }
         }
@@ -80,17 +80,23 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
 void launch_energy(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;
     dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_energy<0, false>), g, bl, a.F * sizeof(FrameP), s, a);
-    else if (a.model == 1) hipLaunchKernelGGL((k_energy<1, false>), g, bl, a.F * sizeof(FrameP), s, a);
-    else hipLaunchKernelGGL((k_energy<2, false>), g, bl, a.F * sizeof(FrameP), s, a);
+    if (a.rob.loss == 1) {
+        if (a.model == 0) hipLaunchKernelGGL((k_energy<0, false, 1>), g, bl, a.F * sizeof(FrameP), s, a);
+        else if (a.model == 1) hipLaunchKernelGGL((k_energy<1, false, 1>), g, bl, a.F * sizeof(FrameP), s, a);
+        else hipLaunchKernelGGL((k_energy<2, false, 1>), g, bl, a.F * sizeof(FrameP), s, a);
+    } else {
+        if (a.model == 0) hipLaunchKernelGGL((k_energy<0, false, -1>), g, bl, a.F * sizeof(FrameP), s, a);
+        else if (a.model == 1) hipLaunchKernelGGL((k_energy<1, false, -1>), g, bl, a.F * sizeof(FrameP), s, a);
+        else hipLaunchKernelGGL((k_energy<2, false, -1>), g, bl, a.F * sizeof(FrameP), s, a);
+    }
 }
 void launch_led_light_init(const SweepArgs& a, hipStream_t s) {
-    if (a.row1 > a.row0) hipLaunchKernelGGL((k_energy<2, true>), dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), a.F * sizeof(FrameP), s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL((k_energy<2, true, -1>), dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), a.F * sizeof(FrameP), s, a);
 }
 
 // albedo normal equations (diagonal): optimizeAlbedoAll PsOptimizer.cpp:85-121 / LedOptimizer.cpp:162-196,
 // albedoJacobian PsOptimizerJa.cpp:375-422, computeResidual :567-626.  Also yields the PS energy of the input state.
-template <int MODEL>
+template <int MODEL, int LOSS>
 __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
@@ -117,10 +123,10 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
             float l = 0.f;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
+                float r = I[ch] - ren[ch]; float w = robust_weight<LOSS>(a.rob, r);
                 float jw = J[ch] * w;
                 Hd[ch] += jw * J[ch]; bd[ch] += jw * r;
-                l += robust_loss(a.rob, r);
+                l += robust_loss<LOSS>(a.rob, r);
             }
             Ef += l; nobs_i += 1;
         }
@@ -146,9 +152,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
 void launch_sweep_albedo(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;
     dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_sweep_albedo<0>), g, bl, a.F * sizeof(FrameP), s, a);
-    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_albedo<1>), g, bl, a.F * sizeof(FrameP), s, a);
-    else hipLaunchKernelGGL((k_sweep_albedo<2>), g, bl, a.F * sizeof(FrameP), s, a);
+    PSG_LAUNCH_BY_MODEL_AND_LOSS(k_sweep_albedo, a, g, bl, a.F * sizeof(FrameP), s, a);
 }
 // delta = b / ((1+damping) H), updateAlbedo accept rule OptimizerAux.cpp:120-150
 __global__ void __launch_bounds__(kBlock) k_apply_albedo(SweepArgs a) {
@@ -191,7 +195,7 @@ static int fm_rows(const SweepArgs& a, int slots_per_cu) {
 
 // light normal equations: lightJacobian PsOptimizerJa.cpp:132-143,323-371 (per frame NBxNB),
 // LED LightJacobian LedOptimizerJa.cpp:101-115,299-346 (one global diagonal 3x3)
-template <int MODEL>
+template <int MODEL, int LOSS>
 __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
@@ -237,8 +241,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
         float l = 0.f, w2 = 0.f, r1 = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
-            l += robust_loss(a.rob, r);
+            float r = I[ch] - ren[ch]; float w = robust_weight<LOSS>(a.rob, r);
+            l += robust_loss<LOSS>(a.rob, r);
             if (LED) {
                 float J = refl * v.rho[ch]; float jw = J * w;
                 acc[ch] += jw * J; acc[NH + ch] += jw * r;
@@ -276,13 +280,11 @@ void launch_sweep_light(const SweepArgs& a, hipStream_t s) {
     const int rows = fm_rows(a, a.model == 1 ? 3 : 5);           // resident workgroups per CU at this kernel's register count
     const int chunk = kBlock * rows;
     dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_sweep_light<0>), g, bl, 0, s, a, rows);
-    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_light<1>), g, bl, 0, s, a, rows);
-    else hipLaunchKernelGGL((k_sweep_light<2>), g, bl, 0, s, a, rows);
+    PSG_LAUNCH_BY_MODEL_AND_LOSS(k_sweep_light, a, g, bl, 0, s, a, rows);
 }
 
 // pose normal equations: poseJacobian PsOptimizerJa.cpp:61-115,427-475 / LedOptimizerJa.cpp:32-81,351-399
-template <int MODEL>
+template <int MODEL, int LOSS>
 __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
@@ -349,8 +351,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
         float l = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            float r = I[ch] - ren[ch]; float w = robust_weight(a.rob, r);
-            l += robust_loss(a.rob, r);
+            float r = I[ch] - ren[ch]; float w = robust_weight<LOSS>(a.rob, r);
+            l += robust_loss<LOSS>(a.rob, r);
             int q = 0;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -377,9 +379,7 @@ void launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
     const int rows = fm_rows(a, 4);
     const int chunk = kBlock * rows;
     dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_sweep_pose<0>), g, bl, 0, s, a, rows);
-    else if (a.model == 1) hipLaunchKernelGGL((k_sweep_pose<1>), g, bl, 0, s, a, rows);
-    else hipLaunchKernelGGL((k_sweep_pose<2>), g, bl, 0, s, a, rows);
+    PSG_LAUNCH_BY_MODEL_AND_LOSS(k_sweep_pose, a, g, bl, 0, s, a, rows);
 }
 
 // ------------------------------------------------------------------------------------------
