@@ -94,7 +94,7 @@ def main():
 
     t_gen = time.time()
     # --u8-images: keyframes quantised to 8 bits and handed over the way the reference's loader receives them (8-bit RGB + 1/255,
-    # ImageLoader.h:167-181); the oracle always gets the converted floats.  Same speed as the float path (profiles/r01_notes.md, step n).
+    # ImageLoader.h:167-181); the oracle always gets the converted floats.  ~3 % faster than the float path (profiles/r01_notes.md, step p).
     use_u8 = args.u8_images
     sc = synth.make_scene(N=args.grid, F=args.frames, W=args.width, H=args.height, model=args.model, u8=use_u8)
     t_gen = time.time() - t_gen

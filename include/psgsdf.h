@@ -146,8 +146,8 @@ int psgsdf_set_keyframes(psgsdf_ctx* ctx, int n_frames, const int32_t* frame_idx
 /* The same with the keyframes as the reference's loader receives them: 8-bit interleaved RGB [F][H][W][3] plus the factor
  * of its conversion (ImageLoader.h:167-181: cv::imread, then convertTo(CV_32FC3, 1.0f / 255.0f)).  The engine samples
  * colour = (float)byte * scale, bit for bit what that conversion stores, from one RGBA8 word per pixel: the same results as
- * psgsdf_set_keyframes on the converted images with a quarter of the upload and a third of the resident image bytes (the sweeps
- * run at the same speed: profiles/r01_notes.md, step n). */
+ * psgsdf_set_keyframes on the converted images with a quarter of the upload, a third of the resident image bytes and ~3 % more
+ * iterations per second (profiles/r01_notes.md, step p). */
 int psgsdf_set_keyframes_u8(psgsdf_ctx* ctx, int n_frames, const int32_t* frame_idx,
                             const uint8_t* rgb_images, float scale, int width, int height, const float* poses);
 

@@ -57,16 +57,22 @@ template <int NB> __device__ __forceinline__ void SH(const float* n, float* sh) 
 template <int MODEL> struct ModelTraits { static constexpr int NB = MODEL == 1 ? 9 : (MODEL == 0 ? 4 : 3); static constexpr bool LED = MODEL == 2; };
 
 // Optimizer.cpp:140-161 / 164-186
-// launches K<model, loss>: the three shading models x {Cauchy compiled in, loss decided at run time}
-#define PSG_LAUNCH_BY_MODEL_AND_LOSS(K, args, grid, block, shmem, stream, ...) do { \
-        if ((args).rob.loss == 1) { \
-            if ((args).model == 0) hipLaunchKernelGGL((K<0, 1>), grid, block, shmem, stream, __VA_ARGS__); \
-            else if ((args).model == 1) hipLaunchKernelGGL((K<1, 1>), grid, block, shmem, stream, __VA_ARGS__); \
-            else hipLaunchKernelGGL((K<2, 1>), grid, block, shmem, stream, __VA_ARGS__); \
+// launches K<model, loss, img>: the three shading models x {Cauchy loss and the image format compiled in, both decided at run time}.
+// frame_major: the kernel addresses one frame's image at a time, so float taps always fit 32-bit offsets.
+#define PSG_LAUNCH_SWEEP(K, args, frame_major, grid, block, shmem, stream, ...) do { \
+        const int img_ = (args).im.u8 ? 1 : (((frame_major) || (args).im.idx32) ? 0 : -1); \
+        if ((args).rob.loss == 1 && img_ == 0) { \
+            if ((args).model == 0) hipLaunchKernelGGL((K<0, 1, 0>), grid, block, shmem, stream, __VA_ARGS__); \
+            else if ((args).model == 1) hipLaunchKernelGGL((K<1, 1, 0>), grid, block, shmem, stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((K<2, 1, 0>), grid, block, shmem, stream, __VA_ARGS__); \
+        } else if ((args).rob.loss == 1 && img_ == 1) { \
+            if ((args).model == 0) hipLaunchKernelGGL((K<0, 1, 1>), grid, block, shmem, stream, __VA_ARGS__); \
+            else if ((args).model == 1) hipLaunchKernelGGL((K<1, 1, 1>), grid, block, shmem, stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((K<2, 1, 1>), grid, block, shmem, stream, __VA_ARGS__); \
         } else { \
-            if ((args).model == 0) hipLaunchKernelGGL((K<0, -1>), grid, block, shmem, stream, __VA_ARGS__); \
-            else if ((args).model == 1) hipLaunchKernelGGL((K<1, -1>), grid, block, shmem, stream, __VA_ARGS__); \
-            else hipLaunchKernelGGL((K<2, -1>), grid, block, shmem, stream, __VA_ARGS__); \
+            if ((args).model == 0) hipLaunchKernelGGL((K<0, -1, -1>), grid, block, shmem, stream, __VA_ARGS__); \
+            else if ((args).model == 1) hipLaunchKernelGGL((K<1, -1, -1>), grid, block, shmem, stream, __VA_ARGS__); \
+            else hipLaunchKernelGGL((K<2, -1, -1>), grid, block, shmem, stream, __VA_ARGS__); \
         } } while (0)
 // LOSS: the loss function as a compile-time constant (the sweeps are instantiated for Cauchy, what every shipped config uses) or -1 =
 // decided at run time -- six wavefront-uniform switches per observation cost the sweeps 3-4 us each
@@ -309,8 +315,8 @@ __device__ __forceinline__ void sample(const float* base, int frame, bool idx32,
 }
 // 8-bit RGB images as the reference's loader receives them (ImageLoader.h:167-181: cv::imread, then convertTo(CV_32FC3, 1/255)),
 // stored as one RGBA8 word per pixel [F][H][W]: the two taps of an image row are ONE 8-byte load instead of two 12-byte ones and a
-// cache line holds 16 pixels instead of 5 (measured: no faster than the float path -- the taps are not what bounds the sweeps --
-// but a quarter of the upload and a third of the resident bytes).
+// cache line holds 16 pixels instead of 5: ~3 % more iterations per second once the format is a template parameter of the sweeps
+// (behind a run-time branch it measured no faster than the float path), a quarter of the upload, a third of the resident bytes.
 // (float)byte * scale is exactly the float the reference's conversion produces.
 __device__ __forceinline__ void unpack_rgb8(unsigned w, float scale, float* o) {
     // __fmul_rn: a rounded product, never contracted into a following add -- the taps must be the floats the reference holds
@@ -339,9 +345,12 @@ __device__ __forceinline__ void sample_u8(const unsigned* base, float scale, int
     }
 }
 // either format, chosen by the (wavefront-uniform) image source of the launch
-template <bool GRAD>
+// IMG: 0 = float RGB with 32-bit tap offsets, 1 = RGBA8 words, -1 = look at the source (two more uniform branches per observation)
+template <bool GRAD, int IMG = -1>
 __device__ __forceinline__ void sample(const ImgSrc& s, int frame, const Cam& cam, float m_col, float n_row, float* I, float* gu, float* gv) {
-    if (s.u8) sample_u8<GRAD>(s.u8, s.scale, frame, cam, m_col, n_row, I, gu, gv);
+    if (IMG == 0) sample<GRAD>(s.f32, frame, true, cam, m_col, n_row, I, gu, gv);
+    else if (IMG == 1) sample_u8<GRAD>(s.u8, s.scale, frame, cam, m_col, n_row, I, gu, gv);
+    else if (s.u8) sample_u8<GRAD>(s.u8, s.scale, frame, cam, m_col, n_row, I, gu, gv);
     else sample<GRAD>(s.f32, frame, s.idx32, cam, m_col, n_row, I, gu, gv);
 }
 

@@ -20,7 +20,7 @@ __device__ __forceinline__ void normal_jacobian(float vs_inv, const float* grad,
 
 // distJacobian per observation PsOptimizerJa.cpp:160-289 / LedOptimizerJa.cpp:117-218, accumulated directly
 // into the per-voxel block over {self, x-, y-, z-stencil neighbour}; regularisers Optimizer.cpp:196-218,477-590.
-template <int MODEL, int LOSS>
+template <int MODEL, int LOSS, int IMG>
 __global__ void __launch_bounds__(kBlock, MODEL == 0 ? 5 : 1) k_sweep_dist(SweepArgs a) {
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(kBlock, MODEL == 0 ? 5 : 1) k_sweep_dist(Sweep
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], gu[3], gv[3], ren[3];
-            sample<true>(a.im, f, a.cam, pr.m, pr.n, I, gu, gv);
+            sample<true, IMG>(a.im, f, a.cam, pr.m, pr.n, I, gu, gv);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
             float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
             float GRt[9];
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(kBlock, MODEL == 0 ? 5 : 1) k_sweep_dist(Sweep
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;
     dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
-    PSG_LAUNCH_BY_MODEL_AND_LOSS(k_sweep_dist, a, g, bl, a.F * sizeof(FrameP), s, a);
+    PSG_LAUNCH_SWEEP(k_sweep_dist, a, false, g, bl, a.F * sizeof(FrameP), s, a);
 }
 
 // one ELL row (and, if a.pcg_fuse_init, the PCG initialisation of that row: returns r_0^2)

@@ -34,7 +34,7 @@ void launch_init_albedo(const SweepArgs& a, hipStream_t s) {
 
 // getPSEnergy PsOptimizer.cpp:47-78 / LedOptimizer.cpp:40-71; LED_INIT: computeLightIntensive
 // LedOptimizer.cpp:76-112 (sums of observed and rendered intensity)
-template <int MODEL, bool LED_INIT, int LOSS>
+template <int MODEL, int LOSS, int IMG, bool LED_INIT = false>
 __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], ren[3];
-            sample<false>(a.im, f, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+            sample<false, IMG>(a.im, f, a.cam, pr.m, pr.n, I, nullptr, nullptr);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
             if (LED_INIT) {
 #pragma unroll
@@ -80,23 +80,15 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
 void launch_energy(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;
     dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
-    if (a.rob.loss == 1) {
-        if (a.model == 0) hipLaunchKernelGGL((k_energy<0, false, 1>), g, bl, a.F * sizeof(FrameP), s, a);
-        else if (a.model == 1) hipLaunchKernelGGL((k_energy<1, false, 1>), g, bl, a.F * sizeof(FrameP), s, a);
-        else hipLaunchKernelGGL((k_energy<2, false, 1>), g, bl, a.F * sizeof(FrameP), s, a);
-    } else {
-        if (a.model == 0) hipLaunchKernelGGL((k_energy<0, false, -1>), g, bl, a.F * sizeof(FrameP), s, a);
-        else if (a.model == 1) hipLaunchKernelGGL((k_energy<1, false, -1>), g, bl, a.F * sizeof(FrameP), s, a);
-        else hipLaunchKernelGGL((k_energy<2, false, -1>), g, bl, a.F * sizeof(FrameP), s, a);
-    }
+    PSG_LAUNCH_SWEEP(k_energy, a, false, g, bl, a.F * sizeof(FrameP), s, a);
 }
 void launch_led_light_init(const SweepArgs& a, hipStream_t s) {
-    if (a.row1 > a.row0) hipLaunchKernelGGL((k_energy<2, true, -1>), dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), a.F * sizeof(FrameP), s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL((k_energy<2, -1, -1, true>), dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), a.F * sizeof(FrameP), s, a);
 }
 
 // albedo normal equations (diagonal): optimizeAlbedoAll PsOptimizer.cpp:85-121 / LedOptimizer.cpp:162-196,
 // albedoJacobian PsOptimizerJa.cpp:375-422, computeResidual :567-626.  Also yields the PS energy of the input state.
-template <int MODEL, int LOSS>
+template <int MODEL, int LOSS, int IMG>
 __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
@@ -117,7 +109,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], ren[3], J[3];
-            sample<false>(a.im, f, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+            sample<false, IMG>(a.im, f, a.cam, pr.m, pr.n, I, nullptr, nullptr);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
             rho_jac<MODEL>(fp, pr, v.gn, shg, J);
             float l = 0.f;
@@ -152,7 +144,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
 void launch_sweep_albedo(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;
     dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
-    PSG_LAUNCH_BY_MODEL_AND_LOSS(k_sweep_albedo, a, g, bl, a.F * sizeof(FrameP), s, a);
+    PSG_LAUNCH_SWEEP(k_sweep_albedo, a, false, g, bl, a.F * sizeof(FrameP), s, a);
 }
 // delta = b / ((1+damping) H), updateAlbedo accept rule OptimizerAux.cpp:120-150
 __global__ void __launch_bounds__(kBlock) k_apply_albedo(SweepArgs a) {
@@ -195,7 +187,7 @@ static int fm_rows(const SweepArgs& a, int slots_per_cu) {
 
 // light normal equations: lightJacobian PsOptimizerJa.cpp:132-143,323-371 (per frame NBxNB),
 // LED LightJacobian LedOptimizerJa.cpp:101-115,299-346 (one global diagonal 3x3)
-template <int MODEL, int LOSS>
+template <int MODEL, int LOSS, int IMG>
 __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
@@ -234,7 +226,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
         float shfd[kMaxBasis], shg[kMaxBasis];
         if (!LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
         float I[3], ren[3];
-        sample<false>(img, 0, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        sample<false, IMG>(img, 0, a.cam, pr.m, pr.n, I, nullptr, nullptr);
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
         float refl = 0.f;
         if (LED) { float Rp[3]; mul3(fp.R, pr.p, Rp); refl = dot3(v.gn, Rp); float pn = norm3(pr.p); double pd = (double)pn; refl /= (float)(pd * pd * pd); }
@@ -280,11 +272,11 @@ void launch_sweep_light(const SweepArgs& a, hipStream_t s) {
     const int rows = fm_rows(a, a.model == 1 ? 3 : 5);           // resident workgroups per CU at this kernel's register count
     const int chunk = kBlock * rows;
     dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
-    PSG_LAUNCH_BY_MODEL_AND_LOSS(k_sweep_light, a, g, bl, 0, s, a, rows);
+    PSG_LAUNCH_SWEEP(k_sweep_light, a, true, g, bl, 0, s, a, rows);
 }
 
 // pose normal equations: poseJacobian PsOptimizerJa.cpp:61-115,427-475 / LedOptimizerJa.cpp:32-81,351-399
-template <int MODEL, int LOSS>
+template <int MODEL, int LOSS, int IMG>
 __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
@@ -322,7 +314,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
         float shfd[kMaxBasis];
         if (!LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
         float I[3], gu[3], gv[3], ren[3];
-        sample<true>(img, 0, a.cam, pr.m, pr.n, I, gu, gv);
+        sample<true, IMG>(img, 0, a.cam, pr.m, pr.n, I, gu, gv);
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
         float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
         float J[18];
@@ -379,7 +371,7 @@ void launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
     const int rows = fm_rows(a, 4);
     const int chunk = kBlock * rows;
     dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
-    PSG_LAUNCH_BY_MODEL_AND_LOSS(k_sweep_pose, a, g, bl, 0, s, a, rows);
+    PSG_LAUNCH_SWEEP(k_sweep_pose, a, true, g, bl, 0, s, a, rows);
 }
 
 // ------------------------------------------------------------------------------------------
