@@ -56,8 +56,9 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         if (drained) { int rc = flush(c); if (rc) return rc; }
         for (int q = 0; q < n && iters < 0; ++q) {
             const int kk = k + q;
-            while (!drained && std::isnan(st[q])) {
-                if (hipStreamQuery(c->stream) == hipSuccess) drained = true;   // nothing left that could publish
+            for (unsigned spin = 0; !drained && std::isnan(st[q]); ++spin) {
+                // the slot is in host memory: re-reading it costs ~0.1 us, a hipStreamQuery several -- the runtime is only asked every ~0.1 s, as a way out if nothing is left that could publish
+                if ((spin & 0xfffffu) == 0xfffffu && hipStreamQuery(c->stream) == hipSuccess) drained = true;   // nothing left that could publish
             }
             const double v = st[q];
             if (std::isnan(v)) return fail(c, PSGSDF_ERR_DEVICE, "PCG kernel %d published nothing", kk);
