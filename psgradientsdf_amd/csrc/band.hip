@@ -328,6 +328,9 @@ __global__ void __launch_bounds__(kBlock) k_frame_cols(const double* __restrict_
 void launch_frame_cols(const double* frame, int F, int col, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_frame_cols, dim3(1), dim3(kBlock), 0, s, frame, F, col, out);
 }
+// flush marker: everything queued before it has completed when the host reads `v` from the mapped slot (engine.hip: flush)
+__global__ void k_marker(double* p, double v) { *p = v; __threadfence_system(); }
+void launch_marker(double* p, double v, hipStream_t s) { hipLaunchKernelGGL(k_marker, dim3(1), dim3(1), 0, s, p, v); }
 __global__ void k_zero_f64(double* p, int n) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.0; }
 void launch_zero_f64(double* p, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_zero_f64, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), dim3(256), 0, s, p, n); }
 

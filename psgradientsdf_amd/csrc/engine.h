@@ -153,6 +153,7 @@ struct SlotList { int n; int id[8]; };
 void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, hipStream_t s);
 void launch_frame_cols(const double* frame, int F, int col, double* out, hipStream_t s);
 void launch_zero_f64(double* p, int n, hipStream_t s);
+void launch_marker(double* p, double v, hipStream_t s);
 void launch_init_albedo(const SweepArgs& a, hipStream_t s);
 void launch_led_light_init(const SweepArgs& a, hipStream_t s);
 void launch_energy(const SweepArgs& a, hipStream_t s);

@@ -40,7 +40,18 @@ int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs) {
 // synchronise the stream once and run every deferred consumer in submission order
 int flush(psgsdf_ctx* c) {
     materialize_fold(c);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    bool synced = false;
+    if (c->pcg_poll && !c->profiling && c->mbox) {
+        // a marker kernel + re-reading its mapped slot instead of hipStreamSynchronize: the runtime call itself is slower and makes the
+        // next dispatch wait 5.8 us behind a system-scope fence (profiles/r01_notes.md, step p)
+        const double seq = (c->flush_seq += 1.0);
+        launch_marker(c->mbox_dev + c->mbox_n, seq, c->stream);
+        volatile double* m = c->mbox + c->mbox_n;
+        for (unsigned spin = 0; *m != seq; ++spin)
+            if ((spin & 0xfffffu) == 0xfffffu && hipStreamQuery(c->stream) == hipSuccess) break;      // way out: nothing left that could publish
+        synced = *m == seq;
+    }
+    if (!synced) HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto& f : c->deferred) f();
     c->deferred.clear(); c->mbox_used = 0;
     return 0;
@@ -221,12 +232,13 @@ int build_band(psgsdf_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->part, 0, sizeof(double) * SC_COUNT * c->PB, c->stream));
     {
         const size_t need = 4096;
-        if (need > c->mbox_n) {
+        if (need > c->mbox_alloc) {
             if (c->mbox) hipHostFree(c->mbox);
-            c->mbox = nullptr; c->mbox_n = 0;
+            c->mbox = nullptr; c->mbox_n = 0; c->mbox_alloc = 0;
             HIPCHK(c, hipHostMalloc(&c->mbox, sizeof(double) * need, hipHostMallocMapped));
             HIPCHK(c, hipHostGetDevicePointer((void**)&c->mbox_dev, c->mbox, 0));
-            c->mbox_n = need;
+            c->mbox_alloc = need; c->mbox_n = need - 1;      // [mbox_n] = flush marker
+            c->mbox[c->mbox_n] = 0.0; c->flush_seq = 0;
         }
         c->mbox_used = 0; c->deferred.clear();
     }

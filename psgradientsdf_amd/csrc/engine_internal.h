@@ -69,6 +69,7 @@ struct psgsdf_ctx {
     // deferred read-backs: small fold kernels write into a host-mapped pinned mailbox (no D2H copies), consumed at the
     // next host sync
     double* mbox = nullptr; double* mbox_dev = nullptr; size_t mbox_n = 0, mbox_used = 0;
+    size_t mbox_alloc = 0; double flush_seq = 0;    // the last slot of the allocation is the flush marker
     std::vector<std::function<void()>> deferred;
     // cached energies
     double en_sum = 0, el_sum = 0;       // sums over the band from the last k_derive
