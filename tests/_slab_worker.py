@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(rank, world, port, model, out, n_iters, N):
+def main(rank, world, port, model, out, n_iters, N, tile=False):
     import torch.distributed as dist
     from psgradientsdf_amd import capi, synth
     from psgradientsdf_amd.distributed import SlabRunner
@@ -16,6 +16,8 @@ def main(rank, world, port, model, out, n_iters, N):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = synth.make_scene(N=N, F=5, W=128, H=96, model=model)
+    if tile:          # bench.py's weak-scaling scene: one copy of the scene (and of its keyframes) per rank, stacked along z
+        sc = synth.tile_scene(sc, world)
     st = capi.default_settings(sc.model_id, reg_weight_l=2.0 if model == "SH1" else 0.0)
     o = oracle.Oracle(sc, sc.K, st)
     o.comm_init(rank, world)
@@ -33,4 +35,4 @@ def main(rank, world, port, model, out, n_iters, N):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7]))
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7]), len(sys.argv) > 8 and sys.argv[8] == "tile")

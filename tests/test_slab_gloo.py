@@ -52,3 +52,33 @@ def test_slab_runs_match_single_rank(built, tmp_path, model, world):
         assert np.abs(r["grad"][:, band] - v["grad"][:, band]).max() <= 1e-4 * k
         assert np.abs(r["poses"] - ref.download_poses()).max() <= 1e-6 * k
         assert np.abs(r["light"] - ref.download_light()).max() <= (5e-3 if model == "SH2" else 1e-5) * np.abs(ref.download_light()).max()
+
+
+def test_weak_scaling_scene_four_ranks(built, tmp_path):
+    """bench.py --gpus N: N copies of the scene stacked along z (synth.tile_scene), one slab per rank -- four gloo ranks on the
+    oracle reproduce the single-rank oracle on the same tiled scene (energies, CG iteration counts, refined band)"""
+    from oracle import oracle
+    world, N, n_iters = 4, 24, 2
+    port = free_port()
+    out = str(tmp_path / "tiled")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_slab_worker.py"), str(r), str(world), str(port), "SH1", out, str(n_iters), str(N), "tile"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, o[-3000:]
+    sc = synth.tile_scene(synth.make_scene(N=N, F=5, W=128, H=96, model="SH1"), world)
+    st = capi.default_settings(sc.model_id, reg_weight_l=2.0)
+    ref = oracle.Oracle(sc, sc.K, st, threads=4); ref.load_scene(sc)
+    ref.init_albedo(); e0 = ref.normalize_weights()
+    recs = ref.iterate(capi.ALL, n_iters)
+    band = ref.download_band(); v = ref.download_volume(); vs = float(sc.voxel_size)
+    res = [np.load(out + f".rank{r}.npz") for r in range(world)]
+    rows = [tuple(r["info"]) for r in res]
+    assert rows[0][0] == 0 and rows[-1][1] == len(band) and all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+    assert len({r[1] - r[0] for r in rows}) == 1          # equal slabs: every rank owns exactly one copy
+    for r in res:
+        assert abs(float(r["e0"]) - e0) <= 1e-6 * abs(e0)
+        assert np.allclose(r["e_total"], [x["e_total"] for x in recs], rtol=2e-6)
+        assert np.all(np.abs(r["cg"] - np.array([x["cg_iters"] for x in recs])) <= 1)
+        assert np.abs(r["dist"][band] - v["dist"][band]).max() <= 1e-5 * vs
+        assert np.abs(r["poses"] - ref.download_poses()).max() <= 1e-6
