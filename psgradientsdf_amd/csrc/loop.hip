@@ -6,9 +6,9 @@ namespace psge {
 
 // Launch shape of the fused PCG pass.  The pass is a chain of memory round trips per workgroup (coefficients + column
 // indices -> two batches of record gathers, the second overlapping the reduction), so what matters is how many rows have
-// their loads in flight at once.  One row per thread at 114 VGPRs keeps 4 waves per SIMD resident (1024 workgroups); the
+// their loads in flight at once.  One row per thread at ≤128 VGPRs keeps 4 waves per SIMD resident (1024 workgroups); the
 // reduction of the previous pass's partials costs every workgroup G x 7 doubles, which caps G at 768.  Measured on the
-// 256^3 band (1317 row-blocks): 659 workgroups x 2 trips 17.3 us, 768 x 2 trips 18.1 us, 512 x 3 trips 18.8 us
+// 256^3 band (1317 row-blocks): 659 workgroups x 2 trips 14.4 us, 512 x 3 trips 15.6 us (17.3 / 18.8 us before the DPP reductions)
 // (tools/pcg_ablate.py, profiles/r01_notes.md).
 void cgf_shape(int nblk, int* G, int* rows) {
     nblk = std::max(1, nblk);

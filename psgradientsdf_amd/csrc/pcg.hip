@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
 void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int rows, int k, int kmax, double* mb, hipStream_t s, int ablate) {
     if (a.row1 <= a.row0) return;
     // rows per thread in flight at once <-> registers <-> resident workgroups per CU (launch bound = waves per SIMD).
-    // One row per thread (114 VGPRs, 4 waves per SIMD) is the production shape; two rows spill at 3 waves per SIMD and are
+    // One row per thread (<= 128 VGPRs, 4 waves per SIMD) is the production shape; two rows spill at 3 waves per SIMD and are
     // kept for the timing tool only.
     if (rows >= 2) hipLaunchKernelGGL((k_cgf_pass<2, 2, false>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
     else if (a.b.col16) hipLaunchKernelGGL((k_cgf_pass<1, 4, true>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
