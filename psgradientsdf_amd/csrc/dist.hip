@@ -21,7 +21,7 @@ __device__ __forceinline__ void normal_jacobian(float vs_inv, const float* grad,
 // distJacobian per observation PsOptimizerJa.cpp:160-289 / LedOptimizerJa.cpp:117-218, accumulated directly
 // into the per-voxel block over {self, x-, y-, z-stencil neighbour}; regularisers Optimizer.cpp:196-218,477-590.
 template <int MODEL, int LOSS, int IMG>
-__global__ void __launch_bounds__(kBlock, MODEL == 0 ? 5 : 1) k_sweep_dist(SweepArgs a) {
+__global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
     FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
