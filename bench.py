@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--force-slab", action="store_true", help="run the multi-rank host program even with one rank (overhead measurement)")
     args = ap.parse_args()
 
+    if os.environ.get("PSGSDF_FAULT_DUMP"):   # diagnostics: dump every thread's Python stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PSGSDF_FAULT_DUMP"]), exit=True)
     # RCCL / HIP runtime banners go to the C-level stdout: keep the real stdout for the ONE JSON line only
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)

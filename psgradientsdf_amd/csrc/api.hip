@@ -102,8 +102,18 @@ int psgsdf_volume_init(psgsdf_ctx* c, int max_frames) {
 
 int psgsdf_integrate_frame(psgsdf_ctx* c, const float* rgb, const float* depth, const float* normals_xyz, int width, int height, const float pose[16], int counter, float z_min, float z_max) {
     if (!c || !c->have_volume || !c->vis_seq) return fail(c, PSGSDF_ERR_STATE, "integrate_frame: volume_init or upload_volume first");
-    if (!rgb || !depth || !normals_xyz || !pose || width < 2 || height < 2 || counter < 0 || counter >= 64 * c->wpv_seq) return fail(c, PSGSDF_ERR_ARG, "integrate_frame: bad argument");
+    if (!rgb || !depth || !normals_xyz || !pose || width < 2 || height < 2 || counter < 0) return fail(c, PSGSDF_ERR_ARG, "integrate_frame: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
+    if (counter >= 64 * c->wpv_seq) {   // the sequence is longer than volume_init was told (the reference's vector<bool> simply grows): widen the per-voxel words
+        const long long n = c->grid.nvox;
+        const int wnew = std::max(2 * c->wpv_seq, counter / 64 + 1);
+        uint64_t* grown = nullptr;
+        HIPCHK(c, hipMalloc(&grown, sizeof(uint64_t) * n * wnew));
+        HIPCHK(c, hipMemsetAsync(grown, 0, sizeof(uint64_t) * n * wnew, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(grown, sizeof(uint64_t) * wnew, c->vis_seq, sizeof(uint64_t) * c->wpv_seq, sizeof(uint64_t) * c->wpv_seq, (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->vis_seq); c->vis_seq = grown; c->wpv_seq = wnew;
+    }
     const size_t npx = (size_t)width * height;
     if (c->stage_px < npx) {
         hipFree(c->stage); c->stage = nullptr; c->stage_px = 0;

@@ -112,8 +112,11 @@ int psgsdf_mg_pcg_status(psgsdf_ctx* c, int k0, int n, int32_t* iters, double* e
     volatile double* hist = c->mg_hist;
     bool drained = false;
     for (int q = 0; q < n; ++q) {
-        for (unsigned spin = 0; !drained && std::isnan(hist[k0 + q]); ++spin)      // as loop.hip: pcg_solve (a hipStreamQuery costs the next dispatch 5.8 us)
-            if ((spin & 0xfffffu) == 0xfffffu && hipStreamQuery(c->stream) == hipSuccess) drained = true;
+        if (!drained && std::isnan(hist[k0 + q])) {
+            const int w = wait_mapped(c, [hist, k0, q] { return !std::isnan(hist[k0 + q]); }, "mg_pcg_status");
+            if (w < 0) return w;
+            drained = w == 1;
+        }
         if (std::isnan(hist[k0 + q])) break;
         if (k0 + q > 0 && (float)hist[k0 + q] < fmaxf(FLT_EPSILON * FLT_EPSILON * (float)hist[0], FLT_MIN)) break;   // decided: no need to wait for later slots
         if ((float)hist[0] == 0.f) break;

@@ -2,8 +2,31 @@
 // scalar folds, dense / band allocation and band construction, derived quantities, PS energy.  One context = one HIP device +
 // one stream.  The kernels live in band / sweeps / dist / pcg / albedo_reg / frontend .hip; the C ABI in api*.hip.
 #include "engine_internal.h"
+#include <chrono>
+#include <sched.h>
 
 namespace psge {
+
+int wait_mapped(psgsdf_ctx* c, const std::function<bool()>& ready, const char* what) {
+    using clk = std::chrono::steady_clock;
+    static const double limit_s = [] { const char* e = getenv("PSGSDF_WAIT_TIMEOUT_S"); double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 120.0; }();
+    clk::time_point t0{}, next_query{};
+    bool timing = false;
+    for (unsigned spin = 1;; ++spin) {
+        if (ready()) return 0;
+        if (spin & 0x3ffu) continue;                       // look at the clock every 1024 reads (~0.1 ms)
+        const clk::time_point now = clk::now();
+        if (!timing) { timing = true; t0 = now; next_query = now + std::chrono::milliseconds(20); continue; }
+        if (now - t0 > std::chrono::milliseconds(2)) sched_yield();   // long wait: let the runtime's own threads (and a rank sharing the cores) run
+        if (now < next_query) continue;
+        next_query = now + std::chrono::milliseconds(20);
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return ready() ? 0 : 1;        // drained: whatever was going to publish has
+        if (q != hipErrorNotReady) return fail(c, PSGSDF_ERR_DEVICE, "%s: stream error while waiting: %s", what, hipGetErrorString(q));
+        if (std::chrono::duration<double>(now - t0).count() > limit_s)
+            return fail(c, PSGSDF_ERR_DEVICE, "%s: nothing published within %.0f s (PSGSDF_WAIT_TIMEOUT_S)", what, limit_s);
+    }
+}
 
 int fail(psgsdf_ctx* c, int code, const char* fmt, ...) {
     if (c) { va_list ap; va_start(ap, fmt); vsnprintf(c->err, sizeof(c->err), fmt, ap); va_end(ap); }
@@ -47,11 +70,12 @@ int flush(psgsdf_ctx* c) {
         const double seq = (c->flush_seq += 1.0);
         launch_marker(c->mbox_dev + c->mbox_n, seq, c->stream);
         volatile double* m = c->mbox + c->mbox_n;
-        for (unsigned spin = 0; *m != seq; ++spin)
-            if ((spin & 0xfffffu) == 0xfffffu && hipStreamQuery(c->stream) == hipSuccess) break;      // way out: nothing left that could publish
-        synced = *m == seq;
+        const int w = wait_mapped(c, [m, seq] { return *m == seq; }, "flush");
+        if (w < 0) return w;
+        synced = w == 0;
     }
     if (!synced) HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());                            // asynchronous launch failures surface here, not never
     for (auto& f : c->deferred) f();
     c->deferred.clear(); c->mbox_used = 0;
     return 0;

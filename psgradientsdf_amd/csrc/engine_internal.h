@@ -134,6 +134,13 @@ template <class Fn> void timed(psgsdf_ctx* c, const char* name, Fn&& fn) {
     KTime& k = c->ktimes[name]; k.ms += ms; k.n += 1;
 }
 
+// Bounded wait on a host-mapped slot a kernel publishes to (flush marker, PCG status): re-read the slot (~0.1 us per read;
+// a hipStreamQuery costs the NEXT dispatch 5.8 us, profiles/r01_notes.md step p) and ask the runtime only every ~20 ms.
+//   returns 0  : ready() became true
+//           1  : the stream drained and ready() is still false (nothing is left that could publish)
+//          <0  : the stream reported an error, or the wall-clock bound expired -> PSGSDF_ERR_DEVICE (never spins forever)
+int wait_mapped(psgsdf_ctx* c, const std::function<bool()>& ready, const char* what);
+
 // ---- engine.hip
 SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg);
 inline int band_blocks(const psgsdf_ctx* c) { return (c->row1 - c->row0 + kBlock - 1) / kBlock; }

@@ -56,9 +56,10 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         if (drained) { int rc = flush(c); if (rc) return rc; }
         for (int q = 0; q < n && iters < 0; ++q) {
             const int kk = k + q;
-            for (unsigned spin = 0; !drained && std::isnan(st[q]); ++spin) {
-                // the slot is in host memory: re-reading it costs ~0.1 us, a hipStreamQuery several -- the runtime is only asked every ~0.1 s, as a way out if nothing is left that could publish
-                if ((spin & 0xfffffu) == 0xfffffu && hipStreamQuery(c->stream) == hipSuccess) drained = true;   // nothing left that could publish
+            if (!drained && std::isnan(st[q])) {
+                const int w = wait_mapped(c, [st, q] { return !std::isnan(st[q]); }, "pcg_solve");
+                if (w < 0) return w;
+                drained = w == 1;                              // nothing left that could publish
             }
             const double v = st[q];
             if (std::isnan(v)) return fail(c, PSGSDF_ERR_DEVICE, "PCG kernel %d published nothing", kk);
@@ -371,7 +372,10 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
         // deferred e_in values are raw sums (not yet divided by S) except the synchronous first one: normalise on use
         const bool last = iter + 1 >= max_iters;
         const bool refine_next = full && c->set.upsample && iter == 5;
-        if (pending >= 0 && !last && !refine_next) { prev = rec; prev_slot = pending; have_prev = true; prev_late = &lt; li ^= 1; }
+        // the Laplacian schedule (PsOptimizer.cpp:411-413 / LedOptimizer.cpp:461-463) zeroes reg_l in finalize(): the next iteration's first
+        // sweep must not be enqueued with the old weight, so this iteration is closed synchronously as well
+        const bool sched_next = full && c->set.upsample && c->reg_l != 0.0f && (led ? iter == 15 : iter == 16);
+        if (pending >= 0 && !last && !refine_next && !sched_next) { prev = rec; prev_slot = pending; have_prev = true; prev_late = &lt; li ^= 1; }
         else {
             double e; int rc = ps_energy(c, &e, nullptr); if (rc) return rc;   // flushes the deferred reads of this iteration
             apply_late(rec, lt, -1);

@@ -53,6 +53,8 @@ class SlabRunner:
 
     def __init__(self, api: capi.Api, dist=None, cuda=False):
         self.api, self.dist, self.cuda = api, dist, cuda
+        if cuda:   # the collectives below run on torch's current stream: the engine's kernels must be ordered on the same one
+            api.set_stream(torch.cuda.current_stream().cuda_stream)
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
         self.i = api.mg_info()

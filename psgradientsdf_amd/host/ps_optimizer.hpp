@@ -112,6 +112,7 @@ struct VolumetricGradSdf {
         std::cout << "Number of voxels: " << num_voxels() << std::endl;
         return psgsdf_volume_init(ctx, max_frames) == 0;
     }
+    const char* last_error() const { const char* e = ctx ? psgsdf_last_error(ctx) : "no device volume"; return e ? e : ""; }
     void set_zmin(float z) { z_min_ = z; }
     void set_zmax(float z) { z_max_ = z; }
     void increase_counter() { ++counter_; }

@@ -146,20 +146,23 @@ int main(int argc, char* argv[]) {
             s.model = opt_set_->model == LED ? PSGSDF_LED : (opt_set_->model == SH2 ? PSGSDF_SH2 : PSGSDF_SH1); s.loss = (int)opt_set_->loss; s.lambda = opt_set_->lambda; s.damping = opt_set_->damping;
             s.reg_weight_rho = opt_set_->reg_weight_rho; s.reg_weight_n = opt_set_->reg_weight_n; s.reg_weight_l = opt_set_->reg_weight_l; s.max_it = opt_set_->max_it;
             s.conv_threshold = opt_set_->conv_threshold; s.upsample = opt_set_->upsample ? 1 : 0; s.ref_quirks = 1;
-            const int max_frames = (int)std::min<size_t>(last - first + 1, 4096);
+            // frames to expect: the config's range when it has a "last", else unknown (the reference runs until the loader is exhausted,
+            // main_ps.cpp:222-258) -- the device volume widens its per-voxel visibility words when the sequence outgrows this
+            const int max_frames = last == (size_t)-1 ? 256 : (int)std::min<size_t>(last - first + 1, (size_t)1 << 20);
             if (!tSDF->attach(grid_dim, voxel_size, centroid, truncation, K, s, max_frames)) { std::cerr << "could not create the device volume" << std::endl; return 1; }
             tSDF->set_zmin(zmin); tSDF->set_zmax(zmax);
             pOpt = new RigidPointOptimizer(tSDF);
             if (opt_set_->model == LED) vOpt = new LedOptimizer(tSDF, voxel_size, K, output, opt_set_); else vOpt = new PsOptimizer(tSDF, voxel_size, K, output, opt_set_);
-            tSDF->update(color, depth.data, poses[0]);
+            if (!tSDF->update(color, depth.data, poses[0])) { std::cerr << " -> Frame " << i << " could not be fused: " << tSDF->last_error() << std::endl; return 1; }
             cur_pose = poses[0];
             key_stamps.push_back(loader->rgb_timestamp());
             key_images.push_back(std::make_shared<ImageRGB>(color));
         } else {
             tSDF->increase_counter();
             bool integrated = false;
-            if (GT_pose) { tSDF->update(color, depth.data, poses[i]); cur_pose = poses[i]; integrated = true; }
-            else { bool conv = pOpt->optimize(depth.data, depth.cols, depth.rows); cur_pose = pOpt->pose(); if (conv) { tSDF->update(color, depth.data, cur_pose); integrated = true; } }
+            if (GT_pose) { cur_pose = poses[i]; integrated = tSDF->update(color, depth.data, poses[i]); }
+            else { bool conv = pOpt->optimize(depth.data, depth.cols, depth.rows); cur_pose = pOpt->pose(); if (conv) integrated = tSDF->update(color, depth.data, cur_pose); }
+            if (!integrated && tSDF->last_error()[0]) { std::cerr << " -> Frame " << i << " could not be fused: " << tSDF->last_error() << std::endl; return 1; }   // a frame that is not in the volume must not become a keyframe
             if (integrated) {
                 if (sharpDetector(color, sharp_thr) || dist_to_last_keyframe > 5) {
                     dist_to_last_keyframe = 0;

@@ -25,7 +25,7 @@ def _one_json(out):
 
 def test_single_gpu_line(built):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--grid", "64", "--frames", "8"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _one_json(r.stdout)
     assert KEYS <= set(d) and "cpu_baseline" in d
@@ -36,10 +36,10 @@ def test_single_gpu_line(built):
 
 
 def test_two_ranks_share_the_gpu(built):
-    env = dict(os.environ, PSGSDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, PSGSDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PSGSDF_FAULT_DUMP="90")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),
                         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid", "64", "--frames", "8"],
-                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                       capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _one_json(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0

@@ -33,7 +33,7 @@ def test_cpp_mirror_matches_ctypes_and_oracle(built, tmp_path, model):
     ind, outd = str(tmp_path / "scene") + "/", str(tmp_path / "out") + "/"
     os.makedirs(outd)
     dump(sc, ind, max_it, conv, 0, st.reg_weight_n, st.reg_weight_l, st.damping)
-    r = subprocess.run([EXE, ind, outd], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([EXE, ind, outd], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     d_cpp = np.fromfile(outd + "dist_out.f32", np.float32)
     eng = capi.load_engine(sc, sc.K, st, 0); eng.load_scene(sc)

@@ -31,7 +31,7 @@ print(json.dumps(dict(e=[r["e_total"] for r in recs], after=[r["e_after"] for r 
 
 def run(model, env, full=False):
     e = dict(os.environ); e.update(env)
-    out = subprocess.run([sys.executable, "-c", WORKER, model] + (["full"] if full else []), capture_output=True, text=True, env=e, timeout=600)
+    out = subprocess.run([sys.executable, "-c", WORKER, model] + (["full"] if full else []), capture_output=True, text=True, env=e, timeout=200)
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads(out.stdout.strip().splitlines()[-1])
 

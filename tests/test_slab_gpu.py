@@ -26,9 +26,14 @@ def test_engine_slab_ranks_match_single_context(built, tmp_path, model, world, b
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_slab_worker_gpu.py"), str(r), str(world), str(port), model, out, str(n_iters), str(N), backend],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
-    for p in procs:
-        o, _ = p.communicate(timeout=900)
-        assert p.returncode == 0, o[-3000:]
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=150)
+            assert p.returncode == 0, o[-3000:]
+    finally:
+        for p in procs:      # a rank that is still alive here would keep the GPU (and the next test) busy
+            if p.poll() is None:
+                p.kill()
     sc = synth.make_scene(N=N, F=6, W=160, H=120, model=model)
     st = capi.default_settings(sc.model_id)
     ref = capi.load_engine(sc, sc.K, st, 0); ref.load_scene(sc)
