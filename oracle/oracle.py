@@ -55,6 +55,16 @@ class Oracle(capi.Api):
         ok = self._lib.orc_probe_pose_jacobian(self.ctx, C.c_int(j), C.c_int(f), J)
         return bool(ok), np.array(J[:], np.float32).reshape(3, 6)
 
+    def probe_eikonal(self, j):
+        J = (C.c_float * 4)(); res = C.c_float(); rows = (C.c_int * 4)()
+        self._lib.orc_probe_eikonal(self.ctx, C.c_int(j), J, C.byref(res), rows)
+        return np.array(J[:], np.float32), float(res.value), list(rows)
+
+    def probe_laplacian(self, j):
+        res = C.c_float(); Jd = C.c_float()
+        self._lib.orc_probe_laplacian(self.ctx, C.c_int(j), C.byref(res), C.byref(Jd))
+        return float(res.value), float(Jd.value)
+
     def probe_albedo_reg(self, j):
         J = (C.c_float * 12)(); res = (C.c_float * 3)(); nb = (C.c_int64 * 3)()
         self._lib.orc_probe_albedo_reg(self.ctx, C.c_int(j), J, res, nb)

@@ -1828,6 +1828,20 @@ int orc_probe_pose_jacobian(orc_ctx* c, int j, int f, float J[18]) {
 int orc_probe_rho_jacobian(orc_ctx* c, int j, int f, float J[3]) {
     int lin = c->band[j]; float R[9], t[3]; pose_Rt(c, f, R, t); rho_jacobian(c, lin, f, R, t, J); return 1;
 }
+/* Eikonal row of band row j (Optimizer.cpp:196-218): Jr[4] over {self, 3 stencil neighbours}, residual |g| - 1, stencil rows (-1 = column dropped) */
+int orc_probe_eikonal(orc_ctx* c, int j, float Jr[4], float* res, int rows[4]) {
+    int lin = c->band[j]; float dir[3];
+    eikonal_row(c, lin, Jr, res, dir);
+    long stride[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
+    rows[0] = j;
+    for (int a = 0; a < 3; ++a) { long ln = (long)lin + (long)dir[a] * stride[a]; rows[a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? c->row_of[ln] : -1; }
+    return 1;
+}
+/* Laplacian residual of band row j (Optimizer.cpp:368-393) and the only Jacobian entry the reference emits (B3): the diagonal -6 / vs^2 */
+int orc_probe_laplacian(orc_ctx* c, int j, float* res, float* Jdiag) {
+    *res = dist_laplacian(c, c->band[j]); *Jdiag = -6 * (c->vs_inv * c->vs_inv);
+    return 1;
+}
 /* albedo regulariser of band row j: J[slot][ch] (slot 0 = the voxel, 1..3 = x/y/z stencil neighbour), res[ch] = ||grad rho_ch||, nb[a] = linear index of the neighbour */
 int orc_probe_albedo_reg(orc_ctx* c, int j, float J[12], float res[3], int64_t nb[3]) {
     float Jm[4][3]; long nl[3]; albedo_reg_jacobian(c, c->band[j], Jm, res, nl);
