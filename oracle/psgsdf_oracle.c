@@ -1430,6 +1430,8 @@ int orc_integrate_frame(orc_ctx* c, const float* rgb, const float* depth, const 
     const float T = c->T, inv_T = (float)(1.0 / (double)c->T);
     const float* nxp = normals_xyz; const float* nyp = normals_xyz + (size_t)W * H; const float* nzp = normals_xyz + 2 * (size_t)W * H;
     const double fx_inv = 1.0 / (double)fx, fy_inv = 1.0 / (double)fy;
+    /* voxels are independent: the z-planes may be spread over host threads without changing a bit */
+#pragma omp parallel for schedule(static) num_threads(c->threads)
     for (int k = 0; k < c->dim[2]; ++k) for (int j = 0; j < c->dim[1]; ++j) for (int i = 0; i < c->dim[0]; ++i) {
         size_t lin = (size_t)i + (size_t)c->dim[0] * j + (size_t)c->dim[0] * c->dim[1] * k;
         int idx[3] = {i, j, k}; float xv[3]; voxel2world(c, idx, xv);

@@ -225,6 +225,19 @@ __device__ __forceinline__ void load_frames(FrameP* sf, const FrameP* frames, in
 // projection + image sampling
 // ------------------------------------------------------------------------------------------
 struct Proj { float p[3]; float m, n, z_inv; bool ok; };
+// The reference projects a second time inside its Jacobians, with fx*px/pz instead of fx*px*(1/pz) (PsOptimizerJa.cpp:70-76,
+// LedOptimizerJa.cpp:40-46): the pixel coordinate can differ by one ulp, and where that crosses a pixel boundary the image GRADIENT is taken
+// from the neighbouring cell (at a silhouette that one observation moves a pose block by 1e-3 of its largest entry).  The sweeps that
+// need gradients therefore carry both coordinates: (m, n) for the colour, (mj, nj) for the gradient and the Jacobian's own in-image test.
+struct ProjJ { float mj, nj; bool ok; };
+__device__ __forceinline__ ProjJ project_jac(const Proj& pr, const Cam& cam) {
+#pragma clang fp contract(off)
+    ProjJ o;
+    o.mj = cam.fx * pr.p[0] / pr.p[2] + cam.cx;
+    o.nj = cam.fy * pr.p[1] / pr.p[2] + cam.cy;
+    o.ok = (o.mj >= 0.f && o.mj < (float)cam.W && o.nj >= 0.f && o.nj < (float)cam.H);
+    return o;
+}
 
 // OptimizerAux.cpp:207-226 (surface point precomputed in xs = x_v - d*normalized(grad))
 __device__ __forceinline__ Proj project(const float* xs, const FrameP& fp, const Cam& cam) {
@@ -252,13 +265,13 @@ __device__ __forceinline__ const float* pix(const float* img, const Cam& cam, in
 // Auxilary.h:41-61 interpolateImage + Auxilary.h:64-123 computeImageGradient from one set of taps.
 // Output convention (col=m_col / row=n_row are the projected pixel coordinates): I = bilinear colour, gu = d/d(col), gv = d/d(row).
 template <bool GRAD>
-__device__ __forceinline__ void interp_taps(const float* a00, const float* a01, const float* a10, const float* a11, float fm, float fn, float* I, float* gu, float* gv) {
+__device__ __forceinline__ void interp_taps(const float* a00, const float* a01, const float* a10, const float* a11, float fm, float fn, float gm, float gn, float* I, float* gu, float* gv) {   // (fm, fn): fractions of the colour's coordinates, (gm, gn): of the gradient's
     // reference: weights partly in double (Auxilary.h:47); float weights agree to ~1e-7 relative
     const float w1 = (1.0f - fn) * fm, w2 = (1.0f - fn) * (1.0f - fm), w3 = fn * fm, w4 = fn * (1.0f - fm);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) I[ch] = ((a10[ch] * w1 + a00[ch] * w2) + a11[ch] * w3) + a01[ch] * w4;
     if (GRAD) {
-        const float w01 = fm, w11 = fn, w00 = 1.0f - fm, w10 = 1.0f - fn;
+        const float w01 = gm, w11 = gn, w00 = 1.0f - gm, w10 = 1.0f - gn;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             gu[ch] = w00 * (a01[ch] - a00[ch]) + w01 * (a11[ch] - a10[ch]);
@@ -289,7 +302,7 @@ __device__ __forceinline__ void sample_border(const TEX& tex, const Cam& cam, in
 // idx32: the whole stack is < 4 GiB, so a tap's byte offset fits 32 bits and the loads take the scalar-base form (one address
 // register, no 64-bit integer multiply-adds, which issue at quarter rate and made up ~10 % of a sweep's instruction slots).
 template <bool GRAD>
-__device__ __forceinline__ void sample(const float* base, int frame, bool idx32, const Cam& cam, float m_col, float n_row, float* I, float* gu, float* gv) {
+__device__ __forceinline__ void sample_cell(const float* base, int frame, bool idx32, const Cam& cam, float m_col, float n_row, float mj_col, float nj_row, float* I, float* gu, float* gv) {
     const float m = n_row, n = m_col;  // names of Auxilary.h: m = row, n = column
     int x = (int)floorf(m), y = (int)floorf(n);
     const float* img = base + (size_t)frame * cam.H * cam.W * 3;   // only the rare border path below uses it
@@ -307,10 +320,19 @@ __device__ __forceinline__ void sample(const float* base, int frame, bool idx32,
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { a00[ch] = p00[ch]; a01[ch] = p00[3 + ch]; a10[ch] = p10[ch]; a11[ch] = p10[3 + ch]; }
         }
-        interp_taps<GRAD>(a00, a01, a10, a11, m - (float)x, n - (float)y, I, gu, gv);
+        interp_taps<GRAD>(a00, a01, a10, a11, m - (float)x, n - (float)y, nj_row - (float)x, mj_col - (float)y, I, gu, gv);
     } else {
         auto tex = [&](int row, int col, float* o) { const float* q = pix(img, cam, row, col); o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; };
-        sample_border<GRAD>(tex, cam, x, y, m, n, I, gu, gv);
+        sample_border<GRAD>(tex, cam, x, y, nj_row, mj_col, I, gu, gv);
+    }
+}
+// colour at (m_col, n_row), gradient at (mj_col, nj_row): one set of taps unless the two fall into different pixel cells
+template <bool GRAD>
+__device__ __forceinline__ void sample(const float* base, int frame, bool idx32, const Cam& cam, float m_col, float n_row, float mj_col, float nj_row, float* I, float* gu, float* gv) {
+    sample_cell<GRAD>(base, frame, idx32, cam, m_col, n_row, mj_col, nj_row, I, gu, gv);
+    if (GRAD && (floorf(nj_row) != floorf(n_row) || floorf(mj_col) != floorf(m_col))) {   // the Jacobian's projection landed in the neighbouring cell (~1e-5 of the observations): redo the gradient there
+        float Iu[3];
+        sample_cell<true>(base, frame, idx32, cam, mj_col, nj_row, mj_col, nj_row, Iu, gu, gv);
     }
 }
 // 8-bit RGB images as the reference's loader receives them (ImageLoader.h:167-181: cv::imread, then convertTo(CV_32FC3, 1/255)),
@@ -323,7 +345,7 @@ __device__ __forceinline__ void unpack_rgb8(unsigned w, float scale, float* o) {
     o[0] = __fmul_rn((float)(w & 0xffu), scale); o[1] = __fmul_rn((float)((w >> 8) & 0xffu), scale); o[2] = __fmul_rn((float)((w >> 16) & 0xffu), scale);
 }
 template <bool GRAD>
-__device__ __forceinline__ void sample_u8(const unsigned* base, float scale, int frame, const Cam& cam, float m_col, float n_row, float* I, float* gu, float* gv) {
+__device__ __forceinline__ void sample_u8_cell(const unsigned* base, float scale, int frame, const Cam& cam, float m_col, float n_row, float mj_col, float nj_row, float* I, float* gu, float* gv) {
     const float m = n_row, n = m_col;
     int x = (int)floorf(m), y = (int)floorf(n);
     if ((x + 1) < cam.H && (y + 1) < cam.W) {
@@ -333,7 +355,7 @@ __device__ __forceinline__ void sample_u8(const unsigned* base, float scale, int
         const unsigned t00 = p0[0], t01 = p0[1], t10 = p1[0], t11 = p1[1];
         float a00[3], a01[3], a10[3], a11[3];
         unpack_rgb8(t00, scale, a00); unpack_rgb8(t01, scale, a01); unpack_rgb8(t10, scale, a10); unpack_rgb8(t11, scale, a11);
-        interp_taps<GRAD>(a00, a01, a10, a11, m - (float)x, n - (float)y, I, gu, gv);
+        interp_taps<GRAD>(a00, a01, a10, a11, m - (float)x, n - (float)y, nj_row - (float)x, mj_col - (float)y, I, gu, gv);
     } else {
         const unsigned* img = base + (size_t)frame * cam.H * cam.W;
         auto tex = [&](int row, int col, float* o) {
@@ -341,17 +363,31 @@ __device__ __forceinline__ void sample_u8(const unsigned* base, float scale, int
             col = col < 0 ? 0 : (col >= cam.W ? cam.W - 1 : col);
             unpack_rgb8(img[(size_t)row * cam.W + col], scale, o);
         };
-        sample_border<GRAD>(tex, cam, x, y, m, n, I, gu, gv);
+        sample_border<GRAD>(tex, cam, x, y, nj_row, mj_col, I, gu, gv);
+    }
+}
+template <bool GRAD>
+__device__ __forceinline__ void sample_u8(const unsigned* base, float scale, int frame, const Cam& cam, float m_col, float n_row, float mj_col, float nj_row, float* I, float* gu, float* gv) {
+    sample_u8_cell<GRAD>(base, scale, frame, cam, m_col, n_row, mj_col, nj_row, I, gu, gv);
+    if (GRAD && (floorf(nj_row) != floorf(n_row) || floorf(mj_col) != floorf(m_col))) {   // as in sample()
+        float Iu[3];
+        sample_u8_cell<true>(base, scale, frame, cam, mj_col, nj_row, mj_col, nj_row, Iu, gu, gv);
     }
 }
 // either format, chosen by the (wavefront-uniform) image source of the launch
 // IMG: 0 = float RGB with 32-bit tap offsets, 1 = RGBA8 words, -1 = look at the source (two more uniform branches per observation)
+// (mj_col, nj_row): where the gradient is taken (project_jac); pass (m_col, n_row) again when GRAD is off
+template <bool GRAD, int IMG = -1>
+__device__ __forceinline__ void sample(const ImgSrc& s, int frame, const Cam& cam, float m_col, float n_row, float mj_col, float nj_row, float* I, float* gu, float* gv) {
+    if (IMG == 0) sample<GRAD>(s.f32, frame, true, cam, m_col, n_row, mj_col, nj_row, I, gu, gv);
+    else if (IMG == 1) sample_u8<GRAD>(s.u8, s.scale, frame, cam, m_col, n_row, mj_col, nj_row, I, gu, gv);
+    else if (s.u8) sample_u8<GRAD>(s.u8, s.scale, frame, cam, m_col, n_row, mj_col, nj_row, I, gu, gv);
+    else sample<GRAD>(s.f32, frame, s.idx32, cam, m_col, n_row, mj_col, nj_row, I, gu, gv);
+}
 template <bool GRAD, int IMG = -1>
 __device__ __forceinline__ void sample(const ImgSrc& s, int frame, const Cam& cam, float m_col, float n_row, float* I, float* gu, float* gv) {
-    if (IMG == 0) sample<GRAD>(s.f32, frame, true, cam, m_col, n_row, I, gu, gv);
-    else if (IMG == 1) sample_u8<GRAD>(s.u8, s.scale, frame, cam, m_col, n_row, I, gu, gv);
-    else if (s.u8) sample_u8<GRAD>(s.u8, s.scale, frame, cam, m_col, n_row, I, gu, gv);
-    else sample<GRAD>(s.f32, frame, s.idx32, cam, m_col, n_row, I, gu, gv);
+    static_assert(!GRAD, "gradient samples carry the Jacobian's own pixel coordinates (project_jac)");
+    sample<false, IMG>(s, frame, cam, m_col, n_row, m_col, n_row, I, gu, gv);
 }
 
 // rendered intensity: PsOptimizerJa.cpp:30-40 (SH) / LedOptimizerJa.cpp:15-29 (LED).

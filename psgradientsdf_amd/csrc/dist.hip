@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], gu[3], gv[3], ren[3];
-            sample<true, IMG>(a.im, f, a.cam, pr.m, pr.n, I, gu, gv);
+            const ProjJ pj = project_jac(pr, a.cam);      // distJacobian projects again, with its own in-image test (PsOptimizerJa.cpp:180-190)
+            sample<true, IMG>(a.im, f, a.cam, pr.m, pr.n, pj.mj, pj.nj, I, gu, gv);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
             float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
             float GRt[9];
@@ -127,6 +128,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
             for (int ch = 0; ch < 3; ++ch) {
                 float r = I[ch] - ren[ch]; float w = robust_weight<LOSS>(a.rob, r);
                 l += robust_loss<LOSS>(a.rob, r);
+                w = pj.ok ? w : 0.f;                      // the residual counts for the energy, but the row has no Jacobian
                 int q = 0;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {

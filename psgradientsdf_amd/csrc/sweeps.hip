@@ -314,7 +314,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
         float shfd[kMaxBasis];
         if (!LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
         float I[3], gu[3], gv[3], ren[3];
-        sample<true, IMG>(img, 0, a.cam, pr.m, pr.n, I, gu, gv);
+        const ProjJ pj = project_jac(pr, a.cam);      // poseJacobian projects again, with its own in-image test (PsOptimizerJa.cpp:70-76)
+        sample<true, IMG>(img, 0, a.cam, pr.m, pr.n, pj.mj, pj.nj, I, gu, gv);
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
         float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
         float J[18];
@@ -345,6 +346,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
         for (int ch = 0; ch < 3; ++ch) {
             float r = I[ch] - ren[ch]; float w = robust_weight<LOSS>(a.rob, r);
             l += robust_loss<LOSS>(a.rob, r);
+            w = pj.ok ? w : 0.f;                      // the residual counts for the energy, but the row has no Jacobian
             int q = 0;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {

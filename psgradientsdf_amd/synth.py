@@ -68,8 +68,20 @@ def _sh(n, order):
     return np.stack(b, -1)
 
 
+def _run_parallel(fn, jobs, workers):
+    """numpy releases the GIL inside its kernels: a thread pool over frames / z-chunks scales with the host cores"""
+    jobs = list(jobs)
+    if workers <= 1 or len(jobs) <= 1:
+        for j in jobs:
+            fn(j)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        list(ex.map(fn, jobs))
+
+
 def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, noise=True,
-               perturb=True, z_mult=1, dtype=np.float32, bump=1.0, arc=360.0, u8=False):
+               perturb=True, z_mult=1, dtype=np.float32, bump=1.0, arc=360.0, u8=False, workers=None, zigzag=True):
     """Build a scene.  N: grid edge (z edge = N*z_mult, z_mult bumpy spheres stacked along z for the
     weak-scaling bench), F keyframes of W x H pixels.
 
@@ -79,6 +91,9 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
 
     Intrinsics scale with the image so the object always fills the same fraction of the frame:
     fx = fy = 525 * W/640 (TUM-like 640x480 -> 525)."""
+    if workers is None:
+        import os
+        workers = max(1, min(32, (os.cpu_count() or 1)))
     rng_l = np.random.default_rng(seed)
     vs = extent / N
     dim = np.array([N, N, N * z_mult], np.int32)
@@ -99,7 +114,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
     zspan = 0.5 * (z_mult - 1) * N * vs
     for f in range(F):
         az = np.deg2rad(arc) * f / F      # arc < 360: a short video-like sweep (frame-to-model tracking tests)
-        el = np.deg2rad(15.0) * (1 if f % 2 == 0 else -1)
+        el = np.deg2rad(15.0) * (1 if (f % 2 == 0 or not zigzag) else -1)      # zigzag=False: a smooth camera path (frame-to-model tracking over a stream)
         zc = 0.0 if z_mult == 1 else -zspan + 2 * zspan * ((f * 7) % F) / max(F - 1, 1)
         target = shift + np.array([0, 0, zc])
         pos = target + orbit * np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
@@ -153,7 +168,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
     normals_cam = np.zeros((F, 3, H, W), np.float32)     # camera-frame, inward-pointing (VolumetricGradSdf.cpp:123)
     uu, vv = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
     dirs_c = _unit(np.stack([(uu - cx) / fx, (vv - cy) / fy, np.ones_like(uu)], -1))
-    for f in range(F):
+    def render(f):
         R, t = poses[f, :3, :3], poses[f, :3, 3]
         d = dirs_c @ R.T
         # cull by the bounding spheres
@@ -171,7 +186,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
             hit_any |= ok
         idx = np.nonzero(hit_any)
         if len(idx[0]) == 0:
-            continue
+            return
         dd = d[idx]
         s = t0[idx].copy()
         smax = t0[idx] + 4 * (R0 + 2 * A)
@@ -196,6 +211,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         ncam = -(n @ R)                                   # R^T n_world, flipped to point into the surface
         for a in range(3):
             normals_cam[f, a][idx] = np.where(good, ncam[:, a], 0.0).astype(np.float32)
+    _run_parallel(render, range(F), workers)
     if noise:
         images = images + 0.005 * np.random.default_rng(1).standard_normal(images.shape)
     images = np.clip(images, 0.0, 1.0)
@@ -219,10 +235,11 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
     vis = np.zeros((nvox, wpv), np.uint64)
     # process z-planes in chunks to bound memory
     plane = N * N
-    chunk = max(1, (1 << 22) // plane)
+    chunk = max(1, (1 << 20) // plane)
     rng_d = np.random.default_rng(3)
-    for k0 in range(0, N * z_mult, chunk):
-        k1 = min(N * z_mult, k0 + chunk)
+
+    def voxel_chunk(job):
+        k0, k1, pert_noise = job
         Z, Y, X = np.meshgrid(kk[k0:k1], ii, ii, indexing="ij")
         x = origin + vs * np.stack([X, Y, Z], -1).reshape(-1, 3)
         # far from every blob the clipped distance is +-T whatever the bumps do: skip the trigonometry there
@@ -244,12 +261,12 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         dn = np.clip(d, -T, T)
         if perturb:
             pert = 0.3 * vs * np.sin(40.0 * x[:, 0] / extent * 2 + 1.0) * np.cos(34.0 * x[:, 1] / extent * 2) * np.sin(28.0 * x[:, 2] / extent * 2 + 0.5)
-            pert = pert + 0.03 * vs * rng_d.standard_normal(len(d))
+            pert = pert + 0.03 * vs * pert_noise
             dn = np.where(near, np.clip(d + pert, -T, T), dn)
         dist[sl] = dn
         nidx = np.nonzero(near)[0]
         if len(nidx) == 0:
-            continue
+            return
         xs = x[nidx] - d[nidx, None] * nrm[nidx]
         cnt = np.zeros(len(nidx))
         colsum = np.zeros((len(nidx), 3))
@@ -273,6 +290,16 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         rgb[:, g] = (colsum / np.maximum(cnt, 1)[:, None]).T
         albedo_gt[:, g] = _albedo(xs, shift, extent).T
         vis[g] = vbits
+
+    # the per-voxel noise comes from ONE generator consumed in chunk order (scenes are bit-reproducible whatever the worker count):
+    # draw a batch of chunks' worth, process the batch in parallel, repeat
+    starts = list(range(0, N * z_mult, chunk))
+    for b0 in range(0, len(starts), workers):
+        jobs = []
+        for k0 in starts[b0:b0 + workers]:
+            k1 = min(N * z_mult, k0 + chunk)
+            jobs.append((k0, k1, rng_d.standard_normal((k1 - k0) * plane) if perturb else None))
+        _run_parallel(voxel_chunk, jobs, workers)
 
     poses_used = poses.copy()
     if perturb:

@@ -1,0 +1,211 @@
+"""Every configuration BASELINE.json names, at its full size, through the C ABI against the CPU oracle ("What's missing" 2):
+
+  configs[0]  sokrates-mvs demo frames 0-20, 128^3 / 4 mm, SH1 (config_skorates.json): real RGB-D frames fused on both sides, then one
+              Gauss-Newton iteration                                        -> test_config0_sokrates_frames_0_20
+  configs[1]  synthetic 640x480, 128^3, SH1, 30 keyframes                   -> tests/test_fullsize_gpu.py::test_config1_against_the_oracle
+  configs[2]  TUM-style synthetic stream, 256^3, SH1 + pose tracking, 50 keyframes: FALS normals, tracker and fusion frame by frame,
+              then one Gauss-Newton iteration on the fused state            -> test_config2_stream_with_tracking_256
+  configs[3]  LED point light, 256^3, 50 keyframes (config_basket_LED.json) -> test_config3_led_256x50
+  configs[4]  512^3, SH2, 100 keyframes (one GPU holds it: 5.4 GB)          -> test_config4_sh2_512x100
+  headline    256^3, SH1, 50 keyframes                                      -> tests/test_fullsize_gpu.py::test_headline_size_against_the_oracle
+
+Tolerance of the north star: <= 1e-4 relative SDF error, denominator = voxel size."""
+import os
+
+import numpy as np
+import pytest
+
+from psgradientsdf_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sokrates_21")
+THREADS = min(64, os.cpu_count() or 1)
+
+
+def sdf_errors(eng, orc, vs):
+    band = eng.download_band()
+    de = eng.download_volume()["dist"][band].astype(np.float64); do = orc.download_volume()["dist"][band].astype(np.float64)
+    d = np.abs(de - do) / vs
+    return float(np.linalg.norm(de - do) / np.linalg.norm(do)), float(np.quantile(d, 0.999)), float(d.max())
+
+
+# ---------------------------------------------------------------------------------------------------- configs[0]
+def load_sokrates():
+    """the multiview layout of the reference's demo data (MultiviewLoader.h:35-58): colorNNNNNN.png / depthNNNNNN.png (uint16 mm),
+    intrinsics.txt, pose.txt `id tx ty tz qx qy qz qw` (camera -> world, ImageLoader.h:236-252)"""
+    from PIL import Image
+    from scipy.spatial.transform import Rotation
+    K = np.loadtxt(os.path.join(GOLD, "intrinsics.txt"))[:3].astype(np.float32)
+    color, depth, poses = [], [], []
+    for line in open(os.path.join(GOLD, "pose.txt")).read().strip().split("\n"):
+        v = [float(x) for x in line.split()[1:]]
+        P = np.eye(4); P[:3, :3] = Rotation.from_quat(v[3:7]).as_matrix(); P[:3, 3] = v[:3]
+        poses.append(P.astype(np.float32))
+    for n in range(1, len(poses) + 1):
+        c = np.asarray(Image.open(os.path.join(GOLD, f"color{n:06d}.png")).convert("RGB"))
+        d = np.asarray(Image.open(os.path.join(GOLD, f"depth{n:06d}.png")))
+        color.append(c.astype(np.float32) * np.float32(1.0 / 255.0))       # ImageLoader.h:181 convertTo(CV_32FC3, 1/255)
+        depth.append(d.astype(np.float32) * np.float32(1.0 / 1000.0))      # MultiviewLoader: unit 1/1000
+    return K, color, depth, poses
+
+
+def centroid(K, depth, T):
+    """compute_centroid, main_ps.cpp:346-375: mean of the back-projected valid depth pixels of the first frame, in world coordinates"""
+    H, W = depth.shape
+    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    ok = depth > 0
+    z = depth[ok].astype(np.float64)
+    p = np.stack([(u[ok] - K[0, 2]) / K[0, 0] * z, (v[ok] - K[1, 2]) / K[1, 1] * z, z], -1)
+    return (p @ T[:3, :3].T.astype(np.float64) + T[:3, 3].astype(np.float64)).mean(0).astype(np.float32)
+
+
+def test_config0_sokrates_frames_0_20(built):
+    """the reference's demo run (main_ps.cpp:123-330 with config_skorates.json, `last` = 20): grid 128^3 at 4 mm centred on the first frame's
+    centroid, every frame fused at its GT pose with FALS normals, sharpness threshold 0 => every frame is a keyframe, key_poses[0] = Identity
+    (quirk B1), then the optimiser.  Engine and oracle each run the WHOLE pipeline themselves; they are compared after the fusion and after
+    one Gauss-Newton iteration."""
+    from oracle import oracle
+    K, color, depth, poses = load_sokrates()
+    assert len(poses) == 21 and color[0].shape == (570, 380, 3)
+    vs = 0.004
+    g = capi.GridDesc(); g.dim[:] = [128, 128, 128]; g.voxel_size = vs; g.shift[:] = [float(x) for x in centroid(K, depth[0], poses[0])]; g.truncation = 5 * vs
+    st = capi.default_settings(capi.SH1)                                   # config_skorates.json: cauchy 0.2, damping 1, reg norm 10
+    eng = capi.load_engine(g, K.reshape(-1), st, 0); orc = oracle.Oracle(g, K.reshape(-1), st, threads=THREADS)
+    for api in (eng, orc):
+        api.volume_init(len(poses))
+        for f in range(len(poses)):
+            n = api.estimate_normals(depth[f])
+            api.integrate_frame(color[f], depth[f], n, poses[f], f, z_min=0.5, z_max=3.5)
+    ve, vo = eng.download_volume(), orc.download_volume()
+    # FALS normals differ by rounding between the two (2e-5, tests/test_frontend.py), and the fusion gates on them (dot(normal, ray)^2 >= 1/16,
+    # VolumetricGradSdf.cpp:112-116): a handful of voxels on the gate may take one observation more or less
+    differ = ve["weight"] != vo["weight"]
+    assert differ.mean() < 1e-5, differ.sum()
+    same = ~differ & (vo["weight"] > 0)
+    assert same.sum() > 2e5
+    for k in ("dist", "grad", "rgb"):
+        a, b = ve[k][..., same], vo[k][..., same]
+        assert np.abs(a - b).max() <= 5e-5 * max(1.0, np.abs(b).max()), k
+    key_poses = np.stack(poses).reshape(-1, 16).copy(); key_poses[0] = np.eye(4, dtype=np.float32).reshape(16)     # B1, main_ps.cpp:139
+    imgs = np.stack(color)
+    for api in (eng, orc):
+        api.set_keyframes(np.arange(len(poses), dtype=np.int32), imgs, key_poses)
+        api.init(); api.init_albedo()
+    be, bo = eng.download_band(), orc.download_band()
+    assert 3e4 < len(bo) < 2e5
+    if not np.array_equal(be, bo):     # the gate voxels above: the two volumes differ there, so run the optimiser comparison on ONE volume
+        eng.upload_volume(vo["dist"], vo["grad"], vo["weight"], vo["rgb"], orc.download_vis_seq(1), 1)
+        eng.set_keyframes(np.arange(len(poses), dtype=np.int32), imgs, key_poses); eng.init(); eng.init_albedo()
+        assert np.array_equal(eng.download_band(), bo)
+    e0e, e0o = eng.normalize_weights(), orc.normalize_weights()
+    assert abs(e0e - e0o) <= 2e-5 * abs(e0o)
+    re_, ro = eng.iterate(capi.ALL, 1)[0], orc.iterate(capi.ALL, 1)[0]
+    assert abs(re_["e_total"] - ro["e_total"]) <= 1e-4 * abs(ro["e_total"]) and abs(re_["cg_iters"] - ro["cg_iters"]) <= 1
+    rel, q999, dmax = sdf_errors(eng, orc, vs)
+    assert rel <= 1e-4 and q999 <= 1e-4, (rel, q999, dmax)
+    assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 2e-5
+    assert np.abs(eng.download_light() - orc.download_light()).max() <= 2e-4 * np.abs(orc.download_light()).max()
+
+
+# ---------------------------------------------------------------------------------------------------- configs[2]
+def test_config2_stream_with_tracking_256(built):
+    """a video-like sweep (0.6 deg between frames) of the bumpy object at 256^3 / 640x480 / 50 frames, processed the way main_ps.cpp:222-258
+    processes a stream without GT poses: FALS normals, frame-to-model tracking from the previous pose, fusion at the tracked pose; every
+    frame becomes a keyframe.  Per frame the engine's normals, its tracker result (3 passes from the same start: nearest-voxel look-ups
+    make longer runs piecewise) and its fused volume are compared with the oracle's on identical inputs; then one Gauss-Newton iteration
+    with the 50 tracked keyframe poses."""
+    from oracle import oracle
+    F = 50
+    sc = synth.make_scene(N=256, F=F, W=640, H=480, model="SH1", bump=6.0, arc=30.0, zigzag=False)   # smooth path: 0.6 deg = 4 voxels per frame
+    st = capi.default_settings(capi.SH1)
+    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=THREADS)
+    for api in (eng, orc):
+        api.volume_init(F)
+    pose = sc.poses_gt[0].reshape(4, 4).copy()
+    tracked = [pose.reshape(16).copy()]
+    worst_n = worst_t = 0.0
+    for f in range(F):
+        ne, no = eng.estimate_normals(sc.depth[f]), orc.estimate_normals(sc.depth[f])
+        ok = np.isfinite(no).all(0) & (sc.depth[f] > 0)
+        worst_n = max(worst_n, float(np.abs(ne[:, ok] - no[:, ok]).max()))
+        if f > 0:
+            Pe, ie, ce = eng.track(sc.depth[f], pose, num_iterations=3); Po, io, co = orc.track(sc.depth[f], pose, num_iterations=3)
+            assert (ie, ce) == (io, co), f
+            worst_t = max(worst_t, float(np.abs(Pe - Po).max()))
+            pose, _, _ = orc.track(sc.depth[f], Po, num_iterations=5)      # a few more passes drive the stream; both sides fuse at THIS pose
+            tracked.append(pose.reshape(16).copy())
+        for api in (eng, orc):
+            api.integrate_frame(sc.images[f], sc.depth[f], no, pose, f, z_min=0.05, z_max=10.0)
+    assert worst_n <= 5e-5 and worst_t <= 5e-5, (worst_n, worst_t)
+    drift = np.abs(np.stack(tracked)[:, [3, 7, 11]] - sc.poses_gt[:, [3, 7, 11]]).max()
+    assert drift < 0.01, drift                                             # the tracker follows the sweep (< 1 cm = 5 voxels after a 40 cm arc)
+    ve, vo = eng.download_volume(), orc.download_volume()
+    assert np.array_equal(ve["weight"], vo["weight"]) and np.array_equal(eng.download_vis_seq(1), orc.download_vis_seq(1))
+    for k in ("dist", "grad", "rgb"):
+        assert np.abs(ve[k] - vo[k]).max() <= 2e-6 * max(1.0, np.abs(vo[k]).max()), k
+    key_poses = np.stack(tracked)
+    for api in (eng, orc):
+        api.set_keyframes(np.arange(F, dtype=np.int32), sc.images, key_poses)
+        api.init(); api.init_albedo(); api.normalize_weights()
+    assert np.array_equal(eng.download_band(), orc.download_band()) and eng.info().n_band > 1e5
+    re_, ro = eng.iterate(capi.ALL, 1)[0], orc.iterate(capi.ALL, 1)[0]
+    assert abs(re_["e_total"] - ro["e_total"]) <= 1e-4 * abs(ro["e_total"]) and abs(re_["cg_iters"] - ro["cg_iters"]) <= 1
+    rel, q999, dmax = sdf_errors(eng, orc, float(sc.voxel_size))
+    assert rel <= 1e-4 and q999 <= 1e-4, (rel, q999, dmax)
+    assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------- configs[3]
+def test_config3_led_256x50(built):
+    """LED point-light model at the headline size with config_basket_LED.json's weights (reg norm 0.1, reg laplacian 5, damping 3):
+    light -> albedo -> distance -> pose (LedOptimizer.cpp:343-409), one iteration, every band voxel against the oracle"""
+    from oracle import oracle
+    sc = synth.make_scene(N=256, F=50, W=640, H=480, model="LED")
+    st = capi.default_settings(capi.LED)
+    st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0
+    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=THREADS)
+    for api in (eng, orc):
+        api.load_scene(sc); api.init_albedo(); api.normalize_weights()
+    assert eng.info().n_band == orc.info().n_band > 2.5e5
+    assert abs(eng.info().reg_weight_l - orc.info().reg_weight_l) <= 1e-5 * orc.info().reg_weight_l
+    re_, ro = eng.iterate(capi.ALL, 1)[0], orc.iterate(capi.ALL, 1)[0]
+    assert abs(re_["e_total"] - ro["e_total"]) <= 1e-4 * abs(ro["e_total"]) and abs(re_["cg_iters"] - ro["cg_iters"]) <= 1
+    assert np.allclose(re_["e_after"], ro["e_after"], rtol=1e-4)
+    rel, q999, dmax = sdf_errors(eng, orc, float(sc.voxel_size))
+    assert dmax <= 1e-4, (rel, q999, dmax)
+    band = eng.download_band()
+    assert np.abs(eng.download_volume()["rgb"][:, band] - orc.download_volume()["rgb"][:, band]).max() <= 1e-4
+    assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 1e-5
+    assert np.abs(eng.download_light() - orc.download_light()).max() <= 1e-4 * np.abs(orc.download_light()).max()
+
+
+# ---------------------------------------------------------------------------------------------------- configs[4]
+def test_config4_sh2_512x100(built):
+    """512^3 grid, SH2, 100 keyframes (two visibility words per voxel) on ONE GPU: the normal equations of every block against the oracle
+    (albedo / distance rows on a 2 000-voxel sample, the 100 light 9x9 and pose 6x6 blocks in full), then one whole Gauss-Newton iteration"""
+    from oracle import oracle
+    sc = synth.make_scene(N=512, F=100, W=640, H=480, model="SH2")
+    assert sc.vis_words == 2
+    st = capi.default_settings(capi.SH2)
+    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=THREADS)
+    for api in (eng, orc):
+        api.load_scene(sc); api.init_albedo(); api.normalize_weights()
+    S = eng.info().n_band
+    assert S == orc.info().n_band and 0.8e6 < S < 2e6
+    assert np.array_equal(eng.download_band(), orc.download_band())
+    idx = np.random.default_rng(1).choice(S, 2000, replace=False)
+    He, be = eng.debug_albedo_system(); Ho, bo = orc.debug_albedo_system()
+    assert np.abs(He[idx] - Ho[idx]).max() <= 2e-5 * np.abs(Ho).max() and np.abs(be[idx] - bo[idx]).max() <= 2e-5 * np.abs(bo).max()
+    for blk in (capi.LIGHT, capi.POSE):
+        He, be = eng.debug_frame_system(blk); Ho, bo = orc.debug_frame_system(blk)
+        assert np.abs(He - Ho).max() <= 2e-5 * np.abs(Ho).max() and np.abs(be - bo).max() <= 2e-5 * np.abs(bo).max(), blk
+    x = np.random.default_rng(0).standard_normal(S).astype(np.float32)
+    de, re_, ye = eng.debug_dist_system(x); do, ro, yo = orc.debug_dist_system(x)
+    for a, b in ((de, do), (re_, ro), (ye, yo)):
+        assert np.abs(a[idx] - b[idx]).max() <= 2e-5 * np.abs(b).max()
+    ie, io = eng.iterate(capi.ALL, 1)[0], orc.iterate(capi.ALL, 1)[0]
+    # SH2: the 9x9 light blocks are kept in float32 by the reference and have cond ~2e4 (tests/test_parity_gpu.py: LIGHT_RTOL)
+    assert abs(ie["e_total"] - io["e_total"]) <= 5e-4 * abs(io["e_total"]) and abs(ie["cg_iters"] - io["cg_iters"]) <= 1
+    rel, q999, dmax = sdf_errors(eng, orc, float(sc.voxel_size))
+    assert rel <= 1e-4 and q999 <= 1e-4, (rel, q999, dmax)
+    assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 2e-5
