@@ -9,9 +9,9 @@ scene, inputs resident in HBM before the timed region.  Prints ONE JSON line on 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: weak scaling over z-slabs.  The grid grows to 256 x 256 x (256*N) -- N copies of the scene stacked
-along z, each with its own 50 keyframes -- one process per GPU owns one slab; the host program
-psgradientsdf_amd/distributed.py runs the phases and exchanges halos / all-reduces over RCCL.  value = N * it/s of the
-whole job (256^3 x 50-frame equivalents per second).
+along z, each with its own 50 keyframes -- one process per GPU owns one slab and calls the SAME psgsdf_iterate: the engine's C++ host
+exchanges halos / all-reduces over its own RCCL communicator (comm.hip).  Python only launches the ranks, hands the RCCL id around and
+takes the time.  value = N * it/s of the whole job (256^3 x 50-frame equivalents per second).
 """
 from __future__ import annotations
 
@@ -43,9 +43,7 @@ def algorithmic_bytes(kernel, S, n_obs, W, H, F, laplacian=False):
         "sweep_pose": S * B_v + U,
         "sweep_dist": S * B_v + U + 56 * S,
         "energy": S * B_v + U,
-        "pcg_pass": 152 * S,    # 19 ELL coefficients 76 + 18 column deltas (16 bit) 36 + record {r,t,p,inv} read 16 + write 16 + x read/write 8
-        "pcg_mv": 124 * S,      # two-kernel form (multi-rank phases)
-        "pcg_upd": 40 * S,
+        "pcg_pass": 124 * S,    # B_cg = 124 B per band voxel per PCG iteration (block 40 + 3 nbr rows 12 + gather p 16 + scatter Ap 16 + 5 vector streams 40)
         "assemble": (56 + 80 + 12) * S,
         "derive": (4 + 12 + 24 + 36 + 12) * S,
     }
@@ -65,7 +63,7 @@ def main():
     ap.add_argument("--u8-images", action="store_true", help="keyframes quantised to 8 bits and handed over as 8-bit RGB (psgsdf_set_keyframes_u8) instead of float RGB")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--force-slab", action="store_true", help="run the multi-rank host program even with one rank (overhead measurement)")
+    ap.add_argument("--force-slab", action="store_true", help="attach the single rank to a one-rank RCCL communicator (overhead of the multi-rank code path)")
     args = ap.parse_args()
 
     if os.environ.get("PSGSDF_FAULT_DUMP"):   # diagnostics: dump every thread's Python stack after N seconds and exit
@@ -80,18 +78,21 @@ def main():
     dist = None
     import torch
     slab = world > 1 or args.force_slab
-    if slab:
+    share = False
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        # PSGSDF_BENCH_SHARE_GPU=1: every rank on GPU 0 over gloo -- a functional check of this code path on a one-GPU box, not a measurement
+        # PSGSDF_BENCH_SHARE_GPU=1: every rank on GPU 0 and the exchanges through the gloo test transport (RCCL refuses two ranks per
+        # device) -- a functional check of this code path on a one-GPU box (tests/test_bench_gpu.py), not a measurement
         share = os.environ.get("PSGSDF_BENCH_SHARE_GPU") == "1"
         if share:
             local_rank = 0
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         torch.cuda.set_device(local_rank)
         if share:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
+        else:      # torch's process group only carries the RCCL id, the barriers and the MAX of the elapsed time
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     device = local_rank if world > 1 else 0
 
@@ -108,25 +109,24 @@ def main():
     if world > 1:
         sc = synth.tile_scene(sc, world)
     eng = capi.load_engine(sc, sc.K, st, device)
-    run = None
+    transport = None
     if slab:
-        from psgradientsdf_amd.distributed import SlabRunner
-        eng.comm_init(rank, world)
-        eng.set_stream(torch.cuda.current_stream().cuda_stream)
-        eng.load_scene(sc, u8=use_u8)
-        run = SlabRunner(eng, dist, cuda=True)
-        run.init_albedo()
-        run.normalize_weights()
-        S = run.S // world                      # per-slab band size
-        n_obs = run.step(capi.ALBEDO)["n_obs"] // world
-        iterate = lambda k: run.iterate(capi.ALL, k, gather=False)   # the final all-gather of the refined band is an output step, not part of the loop body
-    else:
-        eng.load_scene(sc, u8=use_u8)
-        eng.init_albedo()
-        eng.normalize_weights()
-        S = eng.info().n_band
-        n_obs = eng.step(capi.ALBEDO)["n_obs"]
-        iterate = lambda k: eng.iterate(capi.ALL, k)
+        if share:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from _gloo_transport import GlooTransport
+            transport = GlooTransport(dist)
+            eng.comm_init_ext(transport.ops, rank, world)
+        else:
+            ident = [capi.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ident, src=0)
+            eng.comm_init(rank, world, ident[0])
+    eng.load_scene(sc, u8=use_u8)
+    eng.init_albedo()
+    eng.normalize_weights()
+    S = eng.info().n_band // world              # per-slab band size
+    n_obs = eng.step(capi.ALBEDO)["n_obs"] // world
+    iterate = lambda k: eng.iterate(capi.ALL, k)
 
     def barrier():
         torch.cuda.synchronize()
@@ -151,10 +151,12 @@ def main():
     if os.environ.get("PSGSDF_NO_WATCH") != "1":   # (tools/gap_run.sh: trace without the event pairs)
         eng.watch_kernel(dom + "/16")  # HIP events around every 16th launch of the dominant kernel (each pair breaks the back-to-back dispatch: ~6 us of stream time)
     barrier()
+    coll0 = eng.comm_stats()
     t0 = time.perf_counter()
     recs = iterate(args.steps)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    coll1 = eng.comm_stats()
     barrier()
     elapsed = t1 - t0
     if dist is not None:
@@ -163,6 +165,19 @@ def main():
         elapsed = float(tt.item())
     watched = eng.kernel_times().get(dom, (0.0, 0))
     eng.watch_kernel("")
+    # the loop voxelPS runs (psgsdf_optimize: stop decision after every iteration) on the same state, next to psgsdf_iterate's figure
+    opt_ms = None
+    if world == 1 and not slab:
+        st2 = capi.default_settings(model_id)
+        st2.reg_weight_n, st2.reg_weight_l, st2.damping = st.reg_weight_n, st.reg_weight_l, st.damping
+        st2.max_it, st2.conv_threshold, st2.upsample = args.steps, 0.0, 0
+        eng2 = capi.load_engine(sc, sc.K, st2, device)
+        eng2.load_scene(sc, u8=use_u8)
+        torch.cuda.synchronize(); to = time.perf_counter()      # (kernels are loaded: the first context ran them all)
+        recs2, _ = eng2.optimize(capi.ALL)              # initAlbedo + weight normalisation + up to `steps` iterations, as PsOptimizer::alternatingOptimize
+        torch.cuda.synchronize(); to = time.perf_counter() - to
+        opt_ms = 1e3 * to / max(len(recs2), 1)
+        eng2.close()
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
@@ -177,7 +192,7 @@ def main():
         "config": {"workload": f"synthetic {args.width}x{args.height} RGB-D bumpy sphere, {args.grid}^3 grid, {args.model}, {args.frames} keyframes, "
                                "albedo+light+distance+pose blocks, Cauchy IRLS, Eikonal reg (config_skorates.json settings)",
                    "band_voxels": int(S), "observations": int(n_obs), "pcg_iters_per_step": cg_iters,
-                   "parallelism": "single GPU" if world == 1 else f"{world} z-slabs (one per GPU), grid {args.grid}x{args.grid}x{args.grid * world}, {args.frames * world} keyframes, RCCL halo exchange + all-reduce"},
+                   "parallelism": "single GPU" if world == 1 else f"{world} z-slabs (one per GPU), grid {args.grid}x{args.grid}x{args.grid * world}, {args.frames * world} keyframes, native slab loop: RCCL halo exchange + all-reduce issued by the C++ host"},
     }
 
     if rank == 0:
@@ -187,25 +202,37 @@ def main():
         # ~2.5 us above the kernel duration rocprofv3 --kernel-trace reports (profiles/): the roofline fraction errs low
         avg_ms = watched[0] / max(watched[1], 1) if watched[1] else float("nan")
         nbytes = algorithmic_bytes(dom, S, n_obs, args.width, args.height, args.frames, lap)   # per GPU (one slab)
+        # the solve enqueues the previous solve's pass count + 2: the surplus kernels return at once (no-op launches, ~4.7 us) and are part
+        # of the sampled average; `avg_working_launch_ms` removes them with the measured ratio passes / launches
+        launches_per_step = kernels.get(dom, {}).get("launches_per_iter") if kernels else None
+        working_frac = min(1.0, (cg_iters + 1.0) / launches_per_step) if (dom == "pcg_pass" and launches_per_step) else 1.0
+        noop_ms = 0.0047
+        avg_work_ms = (avg_ms - (1.0 - working_frac) * noop_ms) / working_frac if working_frac > 0 else avg_ms
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc) and (args.grid, args.frames, args.model, world) == (256, 50, "SH1", 1):   # the counters were collected on this configuration
             try:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_src = f"static: profiles/pmc_summary.json @{pj.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 (gfx950), KiB -> bytes); not re-measured in this run"
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms,
-                           "launches_timed": int(watched[1]),
-                           "traffic_source": "profiles/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 (gfx950), KiB -> bytes" if traffic else None}
+                           "launches_timed": int(watched[1]), "avg_working_launch_ms": avg_work_ms, "working_launch_fraction": working_frac,
+                           "bytes_per_unit": "SURVEY 8d algorithmic figure (pcg_pass: 124 B per band voxel per pass; the engine's ELL storage streams 152 B)",
+                           "storage_bytes_per_launch": 152 * S if dom == "pcg_pass" else None,
+                           "traffic_source": traffic_src}
         # whole-iteration algorithmic bytes (SURVEY.md §8d formula) for reference
         U = min(48 * n_obs, 12 * args.width * args.height * args.frames)
         B_iter = 4 * (S * 60 + U) + 120 * S + 124 * cg_iters * S   # SURVEY §8d per-pass figure kept (the fused pass moves 144 B/row)
-        if run is not None:
-            out["config"]["collectives_per_step"] = run.n_collectives / max(args.steps + args.warmup, 1)
+        if slab:
+            out["config"]["collectives_per_step"] = (coll1 - coll0) / max(args.steps, 1)
         out["iteration"] = {"algorithmic_bytes": B_iter, "achieved_GBs": B_iter * (value / world) / 1e9,
                             "frac_of_hbm_peak": B_iter * (value / world) / 1e9 / HBM_PEAK_GBS}
+        if opt_ms is not None:
+            out["optimize_ms_per_step"] = opt_ms      # psgsdf_optimize (host decides convergence / divergence after every iteration)
         if kernels:
             out["kernels"] = {k: round(v["ms_per_iter"], 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_iter"])}
         out["setup_s"] = {"scene_generation": round(t_gen, 1)}

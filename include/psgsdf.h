@@ -39,7 +39,7 @@ enum psgsdf_status {
     PSGSDF_ERR_DEVICE = -2,     /* HIP runtime error (no device, OOM, launch failure)       */
     PSGSDF_ERR_UNSUPPORTED = -3,/* a setting the engine does not implement (e.g. reg albedo) */
     PSGSDF_ERR_STATE = -4,      /* called before the required earlier call                  */
-    PSGSDF_ERR_COMM = -5        /* RCCL failure                                             */
+    PSGSDF_ERR_COMM = -5        /* RCCL failure / no communicator on a multi-rank context    */
 };
 
 /* ModelType, OptimizerSettings.h:18-22 */
@@ -235,43 +235,41 @@ int psgsdf_upload_light(psgsdf_ctx* ctx, const float* light);
 
 /* ---- multi-GPU (z-slab partition, one context per rank, one process per GPU) -------------- */
 
-/* Attach this context to rank `rank` of `n_ranks` (before psgsdf_init).  The band, sorted by linear index (z
- * slowest), is cut into n_ranks contiguous row ranges of equal band count, i.e. z-slabs; this context owns one
- * and computes only there.  `id` is reserved (the collectives run in the host program, see below) and may be NULL. */
-int psgsdf_comm_unique_id(uint8_t id[128]);
+/* The reference is a single process (main_ps.cpp:41-343) and has no counterpart of this section.  The band, sorted by linear index (z
+ * slowest), is cut into n_ranks contiguous row ranges of equal band count, i.e. z-slabs; a context attached to a rank computes only
+ * there, and EVERY entry point above keeps its meaning: psgsdf_init / psgsdf_step / psgsdf_iterate / psgsdf_optimize / psgsdf_upsample2x /
+ * psgsdf_download_volume become collective calls (all ranks must make them, in the same order) that return the same global energies,
+ * counts, poses and lights on every rank.  The exchanges -- all-reduce of the per-frame light / pose rows, of the 7 sums of a PCG pass
+ * and of the folded scalars; halo rows of the per-voxel blocks, the PCG records and the distances with the two z-neighbours; an
+ * all-gather of the refined band before download / refinement -- are enqueued by the engine itself on its HIP stream.
+ *
+ *   rank 0:  psgsdf_comm_unique_id(id);  (hand the 128 bytes to the other ranks: file, socket, MPI_Bcast, torch.distributed ...)
+ *   all   :  psgsdf_create(.., device, &ctx);  psgsdf_comm_init(ctx, id, rank, n_ranks);  then the usual call sequence.
+ */
+int psgsdf_comm_unique_id(uint8_t id[128]);                       /* ncclGetUniqueId; PSGSDF_ERR_COMM if librccl cannot be loaded */
+/* RCCL communicator over xGMI for this context's device (ncclCommInitRank: blocks until all ranks have called).  Before psgsdf_init. */
 int psgsdf_comm_init(psgsdf_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
-/* run every launch of this context on a caller-owned HIP stream (e.g. torch's current stream) */
+
+/* The same with a transport supplied by the caller (a host that already owns a communicator: MPI, a test harness).  All pointers are
+ * device pointers; each primitive must be ordered after the work already enqueued on `hip_stream` and its result must be visible to
+ * work enqueued on that stream afterwards (a blocking implementation may simply synchronise the stream).  Return 0 on success. */
+typedef struct psgsdf_comm_xfer { void* ptr_dev; size_t bytes; int peer; } psgsdf_comm_xfer;
+typedef struct psgsdf_comm_ops {
+    void* user;
+    int (*allreduce_f64)(void* user, double* buf_dev, int n, void* hip_stream);                 /* in-place sum over all ranks */
+    int (*sendrecv)(void* user, const psgsdf_comm_xfer* sends, int n_sends,
+                    const psgsdf_comm_xfer* recvs, int n_recvs, void* hip_stream);              /* with rank-1 / rank+1; matched in list order per peer */
+    int (*allgather)(void* user, void* buf_dev, size_t bytes_per_rank, void* hip_stream);       /* in place: rank r's block lives at buf + r*bytes */
+} psgsdf_comm_ops;
+int psgsdf_comm_init_ext(psgsdf_ctx* ctx, const psgsdf_comm_ops* ops, int rank, int n_ranks);
+
+/* run every launch of this context on a caller-owned HIP stream */
 int psgsdf_set_stream(psgsdf_ctx* ctx, void* hip_stream);
-/* out = { S, Spad, row0, row1, halo, F, rank, n_ranks, need_lo, need_hi }: owned rows [row0,row1); the stencils of the
- * owned rows read the contiguous ranges [row0-need_lo,row0) and [row1,row1+need_hi) of the neighbouring slabs (the band is
- * sorted by linear index); halo = max(need_lo, need_hi).  What a rank has to SEND is its neighbours' need. */
+/* out = { S, Spad, row0, row1, halo, F, rank, n_ranks, need_lo, need_hi }: owned rows [row0,row1); the stencils of the owned rows read
+ * the contiguous ranges [row0-need_lo,row0) and [row1,row1+need_hi) of the neighbouring slabs; halo = max(need_lo, need_hi). */
 int psgsdf_mg_info(psgsdf_ctx* ctx, int32_t out[10]);
-/* device pointers of the arrays the host program exchanges between phases */
-enum psgsdf_mg_buf { PSGSDF_MG_BUF_FRAME_ACC = 0, PSGSDF_MG_BUF_SCAL = 1, PSGSDF_MG_BUF_PCG = 2, PSGSDF_MG_BUF_DIST = 3,
-                     PSGSDF_MG_BUF_BLK = 4, PSGSDF_MG_BUF_REC0 = 5, PSGSDF_MG_BUF_RHO = 6, PSGSDF_MG_BUF_GRAD = 7, PSGSDF_MG_BUF_REC1 = 8 };
-int psgsdf_mg_buffer(psgsdf_ctx* ctx, int which, void** ptr, int64_t* count);
-/* the phases of one Gauss-Newton iteration on the owned rows; what must be exchanged after each is listed in
- * psgradientsdf_amd/distributed.py, which is the reference host program for them */
-enum psgsdf_mg_phase_id {
-    PSGSDF_MG_ENERGY = 0, PSGSDF_MG_INIT_ALBEDO = 1, PSGSDF_MG_LED_SUMS = 2, PSGSDF_MG_LED_SET = 3,
-    PSGSDF_MG_SWEEP_ALBEDO = 4, PSGSDF_MG_APPLY_ALBEDO = 5, PSGSDF_MG_SWEEP_LIGHT = 6, PSGSDF_MG_SOLVE_LIGHT = 7,
-    PSGSDF_MG_SWEEP_POSE = 8, PSGSDF_MG_SOLVE_POSE = 9, PSGSDF_MG_SWEEP_DIST = 10, PSGSDF_MG_ASSEMBLE = 11,
-    PSGSDF_MG_PCG_INIT = 12, PSGSDF_MG_PCG_PASS = 13, PSGSDF_MG_APPLY_DIST = 14, PSGSDF_MG_DERIVE = 15
-};
-int psgsdf_mg_phase(psgsdf_ctx* ctx, int phase, int arg);
-/* PCG protocol (fused Jacobi-PCG, one kernel + one all-reduce per iteration): PCG_INIT, all-reduce PCG[0:1]; then for
- * k = 0, 1, ...: exchange the halo rows of REC[(k+1)&1], PCG_PASS(k), all-reduce PCG[0:7].  PCG_PASS(k) finishes pass
- * k-1 and runs pass k; once a pass has converged (or k reached the cap) the following PCG_PASS calls are no-ops.
- * psgsdf_mg_pcg_status (host sync) after kernels [k0,k0+n): iters >= 0 once the solve has stopped, else -1. */
-int psgsdf_mg_pcg_status(psgsdf_ctx* ctx, int k0, int n, int32_t* iters, double* err);
-/* offset (doubles) in the SCAL buffer where the following phases fold their scalars (energy, counts, ...) */
-int psgsdf_mg_fold_base(psgsdf_ctx* ctx, int base);
-/* all-reduced Eikonal / Laplacian energy sums for the context's energy bookkeeping */
-int psgsdf_mg_set_reg_sums(psgsdf_ctx* ctx, double en_sum, double el_sum);
-int psgsdf_mg_set_weights(psgsdf_ctx* ctx, float reg_weight_n, float reg_weight_l);
-/* before / after the final all-gather of dist, rho and grad planes (no-ops for the engine) */
-int psgsdf_mg_pack_state(psgsdf_ctx* ctx);
-int psgsdf_mg_unpack_state(psgsdf_ctx* ctx);
+/* collectives + halo exchanges this context has enqueued since it was created */
+int psgsdf_comm_stats(psgsdf_ctx* ctx, int64_t* n_collectives);
 
 /* ---- measurement / test hooks (not part of the reference seam) -------------------------- */
 

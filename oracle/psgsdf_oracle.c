@@ -1180,6 +1180,14 @@ static void mg_setup(orc_ctx* c) {
 }
 static int sym4(int a, int b) { if (a > b) { int t = a; a = b; b = t; } return a * 4 - (a * (a - 1)) / 2 + (b - a); }
 
+/* Phase API of the oracle's multi-rank mirror (driven by psgradientsdf_amd/distributed.py in the gloo CPU tests).  The engine runs its
+ * slab loop natively (loop.hip + comm.hip) and exports no phases; the ids below are private to the oracle and its host program. */
+enum { PSGSDF_MG_BUF_FRAME_ACC = 0, PSGSDF_MG_BUF_SCAL = 1, PSGSDF_MG_BUF_PCG = 2, PSGSDF_MG_BUF_DIST = 3,
+       PSGSDF_MG_BUF_BLK = 4, PSGSDF_MG_BUF_REC0 = 5, PSGSDF_MG_BUF_RHO = 6, PSGSDF_MG_BUF_GRAD = 7, PSGSDF_MG_BUF_REC1 = 8 };
+enum { PSGSDF_MG_ENERGY = 0, PSGSDF_MG_INIT_ALBEDO = 1, PSGSDF_MG_LED_SUMS = 2, PSGSDF_MG_LED_SET = 3,
+       PSGSDF_MG_SWEEP_ALBEDO = 4, PSGSDF_MG_APPLY_ALBEDO = 5, PSGSDF_MG_SWEEP_LIGHT = 6, PSGSDF_MG_SOLVE_LIGHT = 7,
+       PSGSDF_MG_SWEEP_POSE = 8, PSGSDF_MG_SOLVE_POSE = 9, PSGSDF_MG_SWEEP_DIST = 10, PSGSDF_MG_ASSEMBLE = 11,
+       PSGSDF_MG_PCG_INIT = 12, PSGSDF_MG_PCG_PASS = 13, PSGSDF_MG_APPLY_DIST = 14, PSGSDF_MG_DERIVE = 15 };
 int orc_comm_init(orc_ctx* c, const uint8_t* id, int rank, int n_ranks) { (void)id; if (!c || rank < 0 || rank >= n_ranks) return PSGSDF_ERR_ARG; c->rank = rank; c->n_ranks = n_ranks; c->inited = 0; return 0; }
 int orc_set_stream(orc_ctx* c, void* s) { (void)c; (void)s; return 0; }
 int orc_mg_info(orc_ctx* c, int32_t out[10]) {

@@ -262,10 +262,24 @@ class Api:
         a, p = _fp(light)
         self._check(self._fn("upload_light")(self.ctx, p), "upload_light")
 
-    # -- multi-rank phase API (driven by psgradientsdf_amd/distributed.py)
-    def comm_init(self, rank, n_ranks):
-        self._check(self._fn("comm_init")(self.ctx, None, C.c_int(rank), C.c_int(n_ranks)), "comm_init")
+    # -- multi-GPU: attach the context to a rank (before load_scene / init); afterwards every call is collective
+    def comm_init(self, rank, n_ranks, unique_id=None):
+        """unique_id: the 128 bytes rank 0 got from comm_unique_id() (RCCL).  The oracle's mirror (prefix orc_) takes no id: its exchanges
+        are done by the host program psgradientsdf_amd/distributed.py over its phase API below."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id)) if unique_id is not None else None
+        self._check(self._fn("comm_init")(self.ctx, buf, C.c_int(rank), C.c_int(n_ranks)), "comm_init")
 
+    def comm_init_ext(self, ops, rank, n_ranks):
+        """ops: a CommOps struct (caller-supplied transport); the caller keeps it (and its callbacks) alive"""
+        self._comm_ops = ops
+        self._check(self._fn("comm_init_ext")(self.ctx, C.byref(ops), C.c_int(rank), C.c_int(n_ranks)), "comm_init_ext")
+
+    def comm_stats(self):
+        n = C.c_int64()
+        self._check(self._fn("comm_stats")(self.ctx, C.byref(n)), "comm_stats")
+        return n.value
+
+    # -- phase API of the ORACLE's multi-rank mirror (orc_mg_*), driven by psgradientsdf_amd/distributed.py in the CPU tests
     def set_stream(self, stream_ptr):
         self._check(self._fn("set_stream")(self.ctx, C.c_void_p(stream_ptr)), "set_stream")
 
@@ -357,6 +371,30 @@ class Api:
         H = np.empty((S, 3), np.float32); b = np.empty((S, 3), np.float32)
         self._check(self._fn("debug_albedo_system")(self.ctx, H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)), "debug_albedo_system")
         return H, b
+
+
+class CommXfer(C.Structure):
+    _fields_ = [("ptr_dev", C.c_void_p), ("bytes", C.c_size_t), ("peer", C.c_int)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(CommXfer), C.c_int, C.POINTER(CommXfer), C.c_int, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class CommOps(C.Structure):
+    """psgsdf_comm_ops: a caller-supplied transport for psgsdf_comm_init_ext"""
+    _fields_ = [("user", C.c_void_p), ("allreduce_f64", ALLREDUCE_FN), ("sendrecv", SENDRECV_FN), ("allgather", ALLGATHER_FN)]
+
+
+def comm_unique_id() -> bytes:
+    """psgsdf_comm_unique_id (ncclGetUniqueId): call on rank 0, hand the bytes to every rank's comm_init"""
+    buf = (C.c_uint8 * 128)()
+    f = engine_lib().psgsdf_comm_unique_id; f.restype = C.c_int
+    rc = f(buf)
+    if rc != 0:
+        raise PsgsdfError(f"psgsdf_comm_unique_id failed rc={rc} (librccl could not be loaded?)")
+    return bytes(buf)
 
 
 def grid_of(sc) -> GridDesc:

@@ -34,8 +34,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
         && hipMalloc(&c->pcg_sc, sizeof(double) * (16 + 8 * (size_t)kPcgMaxBlocks)) == hipSuccess   // fs[0..1] + stage stamps of the timing hook
         && hipMalloc(&c->pcg_part, sizeof(double) * 14 * kPcgMaxBlocks) == hipSuccess
         && hipMalloc(&c->mg_scal, sizeof(double) * kMgScal) == hipSuccess && hipMalloc(&c->mg_ext, sizeof(double) * 8) == hipSuccess
-        && hipHostMalloc(&c->mg_hist, sizeof(double) * ((size_t)c->pcg_cap + 2), hipHostMallocMapped) == hipSuccess
-        && hipHostGetDevicePointer((void**)&c->mg_hist_dev, c->mg_hist, 0) == hipSuccess && hipMalloc(&c->d_need, 2 * sizeof(int)) == hipSuccess
+        && hipMalloc(&c->d_need, 2 * sizeof(int)) == hipSuccess
         && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess
         && hipMalloc(&c->led_light, sizeof(float) * 3) == hipSuccess
         && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
@@ -56,7 +55,8 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    hipFree(c->areg_mem); hipFree(c->mg_scal); hipFree(c->mg_ext); if (c->mg_hist) hipHostFree(c->mg_hist); hipFree(c->d_need);
+    comm_destroy(c);
+    hipFree(c->areg_mem); hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mbox_shadow); hipFree(c->d_need);
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -203,7 +203,7 @@ int psgsdf_init(psgsdf_ctx* c) {
     }
     HIPCHK(c, hipMemcpyAsync(c->frames, c->frames_h.data(), sizeof(FrameP) * c->F, hipMemcpyHostToDevice, c->stream));
     if ((rc = derive(c, 0))) return rc;
-    if (led && c->n_ranks == 1) {   // computeLightIntensive, LedOptimizer.cpp:76-112 (multi-rank: phases MG_LED_SUMS / MG_LED_SET)
+    if (led) {   // computeLightIntensive, LedOptimizer.cpp:76-112 (multi-rank: read_parts delivers the sums over all slabs)
         SweepArgs a = make_args(c, 0);
         timed(c, "led_light_init", [&] { launch_led_light_init(a, c->stream); });
         const int slots[6] = {SC_AUX0, SC_AUX1, SC_AUX2, SC_EN, SC_EL, SC_ACCEPT}; double s[6];
@@ -305,7 +305,7 @@ int psgsdf_download_volume(psgsdf_ctx* c, float* dist, float* grad_xyz, float* w
     if (!c || !c->have_volume) return fail(c, PSGSDF_ERR_STATE, "no volume");
     HIPCHK(c, hipSetDevice(c->device));
     const long long n = c->grid.nvox;
-    if (c->inited) launch_band_scatter(c->dense, c->band, c->stream);
+    if (c->inited) { int rc = gather_band_state(c); if (rc) return rc; launch_band_scatter(c->dense, c->band, c->stream); }   // multi-rank: a collective call
     if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->dense.dist, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     for (int a = 0; a < 3; ++a) {
         if (grad_xyz) HIPCHK(c, hipMemcpyAsync(grad_xyz + (size_t)a * n, c->dense.g[a], sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));

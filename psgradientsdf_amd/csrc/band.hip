@@ -332,6 +332,13 @@ void launch_frame_cols(const double* frame, int F, int col, double* out, hipStre
 __global__ void k_marker(double* p, double v) { *p = v; __threadfence_system(); }
 void launch_marker(double* p, double v, hipStream_t s) { hipLaunchKernelGGL(k_marker, dim3(1), dim3(1), 0, s, p, v); }
 __global__ void k_zero_f64(double* p, int n) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0.0; }
+// multi-rank scalar read-backs: all-reduced values from the device shadow into their (host-mapped) mailbox slots
+__global__ void k_copy_segs(const double* __restrict__ src, double* __restrict__ dst, CopySegs segs) {
+    for (int q = 0; q < segs.n; ++q)
+        for (unsigned i = threadIdx.x; i < segs.len[q]; i += blockDim.x) dst[segs.off[q] + i] = src[segs.off[q] + i];
+    __threadfence_system();
+}
+void launch_copy_segs(const double* src, double* dst, const CopySegs& segs, hipStream_t s) { if (segs.n > 0) hipLaunchKernelGGL(k_copy_segs, dim3(1), dim3(64), 0, s, src, dst, segs); }
 void launch_zero_f64(double* p, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(k_zero_f64, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), dim3(256), 0, s, p, n); }
 
 }  // namespace psg

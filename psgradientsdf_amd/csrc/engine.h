@@ -153,6 +153,8 @@ struct SlotList { int n; int id[8]; };
 void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, hipStream_t s);
 void launch_frame_cols(const double* frame, int F, int col, double* out, hipStream_t s);
 void launch_zero_f64(double* p, int n, hipStream_t s);
+struct CopySegs { int n; unsigned off[16]; unsigned len[16]; };
+void launch_copy_segs(const double* src, double* dst, const CopySegs& segs, hipStream_t s);   // dst[off + i] = src[off + i] for every segment
 void launch_marker(double* p, double v, hipStream_t s);
 void launch_init_albedo(const SweepArgs& a, hipStream_t s);
 void launch_led_light_init(const SweepArgs& a, hipStream_t s);

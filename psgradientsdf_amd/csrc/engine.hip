@@ -63,6 +63,7 @@ int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs) {
 // synchronise the stream once and run every deferred consumer in submission order
 int flush(psgsdf_ctx* c) {
     materialize_fold(c);
+    { int rc = mg_commit(c); if (rc) return rc; }
     bool synced = false;
     if (c->pcg_poll && !c->profiling && c->mbox) {
         // a marker kernel + re-reading its mapped slot instead of hipStreamSynchronize: the runtime call itself is slower and makes the
@@ -89,6 +90,33 @@ void materialize_fold(psgsdf_ctx* c) {
     launch_sum_parts(c->part, c->PB, c->pending_fold.nblk, sl, c->pending_fold.out, c->stream);
     c->pending_fold.n = 0;
 }
+// Multi-rank: the scalar read-backs staged in the mailbox shadow since the last commit are summed over the ranks in ONE all-reduce (the
+// contiguous range that spans them; slots in between belong to values that are global already -- frame-row sums, PCG status -- and are
+// not copied) and land in their mailbox slots.  Every rank runs the same control flow on the same global values, so the collectives
+// match up across ranks by construction.  Called wherever the host is about to wait on the mailbox (flush, pcg_solve).
+int mg_commit(psgsdf_ctx* c) {
+    if (c->n_ranks == 1 || c->mg_segs.empty()) return 0;
+    materialize_fold(c);
+    unsigned lo = ~0u, hi = 0;
+    for (const MgSeg& g : c->mg_segs) { lo = std::min(lo, g.off); hi = std::max(hi, g.off + g.n); }
+    int rc = comm_allreduce(c, c->mbox_shadow + lo, (int)(hi - lo)); if (rc) return rc;
+    for (size_t i = 0; i < c->mg_segs.size(); i += 16) {
+        CopySegs cs{}; cs.n = (int)std::min<size_t>(16, c->mg_segs.size() - i);
+        for (int q = 0; q < cs.n; ++q) { cs.off[q] = c->mg_segs[i + q].off; cs.len[q] = c->mg_segs[i + q].n; }
+        launch_copy_segs(c->mbox_shadow, c->mbox_dev, cs, c->stream);
+    }
+    c->mg_segs.clear();
+    return 0;
+}
+// every rank ends up with the refined rows of all slabs (distance, stored gradient, albedo): before the band is scattered back into the
+// dense grid for download / 2x refinement
+int gather_band_state(psgsdf_ctx* c) {
+    if (c->n_ranks == 1 || !c->inited || c->band.S == 0) return 0;
+    int rc;
+    if ((rc = comm_allgather_rows(c, c->band.dist, 1))) return rc;
+    if ((rc = comm_allgather_rows(c, c->band.g[0], 3))) return rc;
+    return comm_allgather_rows(c, c->band.rho[0], 3);
+}
 // hand the pending fold to a kernel about to be launched with `a`; `writes` = bit mask of the partial slots that kernel writes
 void take_fold(psgsdf_ctx* c, SweepArgs& a, unsigned writes) {
     a.fold.n = 0;
@@ -100,12 +128,15 @@ int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<vo
     materialize_fold(c);
     if (c->mbox_used + (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
     const size_t off = c->mbox_used; c->mbox_used += n;
+    // multi-rank: this slab's sums go to the device shadow of the mailbox; mg_commit all-reduces them and fills the mailbox slots
+    double* dst = (c->n_ranks > 1 ? c->mbox_shadow : c->mbox_dev) + off;
+    if (c->n_ranks > 1) c->mg_segs.push_back({(unsigned)off, (unsigned)n});
     if (n <= 4 && c->fold_in_next) {
         c->pending_fold.n = n; for (int i = 0; i < n; ++i) c->pending_fold.id[i] = slots[i];
-        c->pending_fold.nblk = band_blocks(c); c->pending_fold.out = c->mbox_dev + off;
+        c->pending_fold.nblk = band_blocks(c); c->pending_fold.out = dst;
     } else {
         SlotList sl; sl.n = n; for (int i = 0; i < n; ++i) sl.id[i] = slots[i];
-        launch_sum_parts(c->part, c->PB, band_blocks(c), sl, c->mbox_dev + off, c->stream);
+        launch_sum_parts(c->part, c->PB, band_blocks(c), sl, dst, c->stream);
     }
     const double* src = c->mbox + off;
     c->deferred.push_back([src, consume] { consume(src); });
@@ -215,7 +246,9 @@ int build_band(psgsdf_ctx* c) {
     {
         const int C = (S + c->n_ranks - 1) / c->n_ranks;
         c->row0 = std::min(S, c->rank * C); c->row1 = std::min(S, c->row0 + C);
-        c->halo = 0; c->need[0] = c->need[1] = 0;
+        c->halo = 0; c->need[0] = c->need[1] = 0; c->give[0] = c->give[1] = 0; c->halo_active = false; c->slab_rows = C;
+        if (c->n_ranks > 1 && !c->comm) return fail(c, PSGSDF_ERR_COMM, "rank %d of %d has no communicator (psgsdf_comm_init)", c->rank, c->n_ranks);
+        if (c->n_ranks > kMgScal / 2) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d ranks", kMgScal / 2);
         if (c->n_ranks > 1 && c->row1 <= c->row0) return fail(c, PSGSDF_ERR_UNSUPPORTED, "rank %d of %d would own no band rows (band of %d): use fewer ranks", c->rank, c->n_ranks, S);
         if (c->n_ranks > 1 && S > 0) {
             HIPCHK(c, hipMemsetAsync(c->d_need, 0, 2 * sizeof(int), c->stream));
@@ -224,6 +257,17 @@ int build_band(psgsdf_ctx* c) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             c->halo = std::max(c->need[0], c->need[1]);
             if (c->halo > C) return fail(c, PSGSDF_ERR_UNSUPPORTED, "slab of %d rows is thinner than the stencil reach %d: use fewer ranks", C, c->halo);
+            // what a slab has to SEND is its neighbours' need: one tiny all-reduce of {need_lo, need_hi} per rank
+            std::vector<double> needs(2 * (size_t)c->n_ranks, 0.0);
+            needs[2 * c->rank] = c->need[0]; needs[2 * c->rank + 1] = c->need[1];
+            HIPCHK(c, hipMemcpyAsync(c->mg_scal, needs.data(), sizeof(double) * needs.size(), hipMemcpyHostToDevice, c->stream));
+            int rcc = comm_allreduce(c, c->mg_scal, (int)needs.size()); if (rcc) return rcc;
+            HIPCHK(c, hipMemcpyAsync(needs.data(), c->mg_scal, sizeof(double) * needs.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const int own = c->row1 - c->row0;
+            if (c->rank > 0) c->give[0] = std::min((int)needs[2 * (c->rank - 1) + 1], own);               // the lower neighbour reaches up into my first rows
+            if (c->rank < c->n_ranks - 1) c->give[1] = std::min((int)needs[2 * (c->rank + 1)], own);       // the upper neighbour reaches down into my last rows
+            for (double v : needs) if (v != 0.0) c->halo_active = true;                                   // (global: every rank takes part in an exchange or none does)
         }
     }
     // per-frame observation lists of the owned rows (counts -> host prefix -> fill)
@@ -264,7 +308,11 @@ int build_band(psgsdf_ctx* c) {
             c->mbox_alloc = need; c->mbox_n = need - 1;      // [mbox_n] = flush marker
             c->mbox[c->mbox_n] = 0.0; c->flush_seq = 0;
         }
-        c->mbox_used = 0; c->deferred.clear();
+        if (c->n_ranks > 1 && !c->mbox_shadow) {
+            HIPCHK(c, hipMalloc(&c->mbox_shadow, sizeof(double) * c->mbox_alloc));
+            HIPCHK(c, hipMemsetAsync(c->mbox_shadow, 0, sizeof(double) * c->mbox_alloc, c->stream));
+        }
+        c->mbox_used = 0; c->deferred.clear(); c->mg_segs.clear();
     }
     return ensure_host_buf(c, (size_t)SC_COUNT * c->PB + (size_t)c->F * kFrameRow + 4096 + 64);
 }

@@ -22,8 +22,10 @@
 #include <vector>
 
 namespace psge {
-constexpr int kMgScal = 64;   // doubles in the folded-scalar exchange buffer
+constexpr int kMgScal = 64;   // doubles in the set-up exchange buffer (2 per rank: at most 32 ranks)
 struct KTime { double ms = 0; int64_t n = 0; };
+struct Comm;                  // comm.hip: RCCL communicator or caller-supplied transport
+struct MgSeg { unsigned off, n; };
 }  // namespace psge
 using psge::KTime;
 using namespace psg;   // the layout structs of engine.h
@@ -76,11 +78,17 @@ struct psgsdf_ctx {
     // row partition (multi-rank): this context owns band rows [row0, row1); halo = widest column reach
     int rank = 0, n_ranks = 1;
     int row0 = 0, row1 = 0, halo = 0;
-    double* mg_scal = nullptr;           // [kMgScal] folded local sums the host program all-reduces (phase results land at mg_fold_base)
+    psge::Comm* comm = nullptr;          // transport of the multi-rank exchanges (comm.hip); null on a single-rank context
+    double* mg_scal = nullptr;           // [kMgScal] set-up exchange (what each slab needs of its neighbours)
     double* mg_ext = nullptr;            // [8] PCG: local sums of a pass out, globally reduced sums in
-    double* mg_hist = nullptr;           // [pcg_cap + 2] PCG: what kernel k published (|b|^2, then |r|^2 after pass k-1); host-mapped, watched by psgsdf_mg_pcg_status
-    double* mg_hist_dev = nullptr;
-    int mg_fold_base = 0;
+    // multi-rank: deferred scalar read-backs are folded into a DEVICE shadow of the mailbox; before the host waits on the mailbox the
+    // segments written since the last commit are all-reduced in ONE collective and copied to their mailbox slots (engine.hip: mg_commit)
+    double* mbox_shadow = nullptr;
+    std::vector<psge::MgSeg> mg_segs;
+    int give[2] = {0, 0};                // rows the lower / upper neighbour needs of this slab
+    bool halo_active = false;            // any stencil of any slab crosses a cut
+    int slab_rows = 0;                   // C = rows per slab (the last slab may be shorter)
+    long long n_collectives = 0;
     float reg_r = 0.f;                   // "reg albedo" (never normalised, PsOptimizer.cpp:279)
     void* areg_mem = nullptr; AlbedoReg ar{};   // planes of the albedo regulariser, allocated with the band when reg_r != 0
     double er_sum = 0;                   // sum over the band of sum_c ||grad rho_c|| at the last evaluation
@@ -140,6 +148,17 @@ template <class Fn> void timed(psgsdf_ctx* c, const char* name, Fn&& fn) {
 //           1  : the stream drained and ready() is still false (nothing is left that could publish)
 //          <0  : the stream reported an error, or the wall-clock bound expired -> PSGSDF_ERR_DEVICE (never spins forever)
 int wait_mapped(psgsdf_ctx* c, const std::function<bool()>& ready, const char* what);
+
+// ---- comm.hip (all no-ops on a single-rank context; PSGSDF_ERR_COMM if a multi-rank context has no communicator)
+int comm_unique_id(uint8_t id[128]);
+int comm_create_rccl(psgsdf_ctx* c, const uint8_t id[128], int rank, int n);
+int comm_create_ext(psgsdf_ctx* c, const psgsdf_comm_ops* ops, int rank, int n);
+void comm_destroy(psgsdf_ctx* c);
+int comm_allreduce(psgsdf_ctx* c, double* buf, int n);                 // in-place sum of n doubles (device), on the context's stream
+int comm_halo(psgsdf_ctx* c, void* base, int planes, int width);       // halo rows of `planes` band planes of `width` 4-byte words per row
+int comm_allgather_rows(psgsdf_ctx* c, void* base, int planes);        // every rank gets all rows of `planes` band planes (4-byte elements)
+int mg_commit(psgsdf_ctx* c);                                          // engine.hip: all-reduce + deliver the staged scalar read-backs
+int gather_band_state(psgsdf_ctx* c);                                  // engine.hip: dist / grad / albedo rows of every slab on every rank
 
 // ---- engine.hip
 SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg);

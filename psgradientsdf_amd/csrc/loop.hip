@@ -10,6 +10,7 @@ namespace psge {
 // reduction of the previous pass's partials costs every workgroup G x 7 doubles, which caps G at 768.  Measured on the
 // 256^3 band (1317 row-blocks): 659 workgroups x 2 trips 14.4 us, 512 x 3 trips 15.6 us (17.3 / 18.8 us before the DPP reductions)
 // (tools/pcg_ablate.py, profiles/r01_notes.md).
+constexpr int kCgfSumsHost = 7;   // = kCgfSums (device_common.h): P, B, C, D, E, Z, R of a pass
 void cgf_shape(int nblk, int* G, int* rows) {
     nblk = std::max(1, nblk);
     int r = 1, cap = kCgfMaxBlocks;
@@ -36,6 +37,17 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
     int G, rows;
     cgf_shape(band_blocks(c), &G, &rows);
     if (!a.pcg_fuse_init) timed(c, "pcg_init", [&] { launch_cgf_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
+    // Multi-rank (z-slabs): the same fused kernel, reading the globally reduced sums of the previous pass from `ext` instead of its own
+    // partials.  Per pass: halo rows of the records it gathers from, the pass, a 1-workgroup fold of its partials, ONE all-reduce of 7 doubles.
+    // Every rank publishes the same values to its mailbox, so all ranks take the same decisions below.
+    const bool mr = c->n_ranks > 1;
+    SweepArgs ap = a;
+    if (mr) {
+        int rc = mg_commit(c); if (rc) return rc;      // the read-backs staged so far are delivered when the first slot of this solve is seen
+        launch_cgf_sum(c->pcg_part, a.pcg_fuse_init ? a.pcg_init_blocks : G, -1, c->mg_ext, c->stream);      // local |b|^2
+        if ((rc = comm_allreduce(c, c->mg_ext, 1))) return rc;
+        ap.ext = c->mg_ext;
+    }
     // first chunk sized from the previous solve (the count is stable between Gauss-Newton iterations)
     int chunk = std::min(64, std::max(4, c->last_cg_iters + 2));
     int k = 0, iters = -1;            // k = next kernel index; kernels 0..cap exist (kernel cap only finalises)
@@ -46,8 +58,14 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         const size_t off = c->mbox_used; c->mbox_used += n;
         volatile double* st = c->mbox + off;
         for (int q = 0; q < n; ++q) st[q] = NAN;       // "not published yet" (kernel q of the chunk overwrites its slot)
-        for (int q = 0; q < n; ++q)
-            timed(c, "pcg_pass", [&] { launch_cgf_pass(a, c->pcg_sc, c->pcg_part, G, rows, k + q, cap, c->mbox_dev + off + q, c->stream); });
+        for (int q = 0; q < n; ++q) {
+            if (mr) { int rc = comm_halo(c, c->band.rec[(k + q + 1) & 1], 1, 4); if (rc) return rc; }
+            timed(c, "pcg_pass", [&] { launch_cgf_pass(ap, c->pcg_sc, c->pcg_part, G, rows, k + q, cap, c->mbox_dev + off + q, c->stream); });
+            if (mr) {
+                launch_cgf_sum(c->pcg_part, G, k + q, c->mg_ext, c->stream);
+                int rc = comm_allreduce(c, c->mg_ext, kCgfSumsHost); if (rc) return rc;
+            }
+        }
         if (tail && c->pcg_poll && !c->profiling) { tail(c->pcg_sc + (gate_on_converged ? 2 : 1)); if (tail_ran) *tail_ran = true; }
         // Watch the mapped slots instead of waiting for the stream to drain: the kernel that detects convergence publishes
         // at its START, so the host learns the outcome while that kernel and the surplus (no-op) kernels of the chunk are
@@ -171,6 +189,9 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
                 const int n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4), nh = led ? 3 : n * (n + 1) / 2;
                 col = nh + n;
             } else { take_fold(c, a, 0u); timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); }); col = 27; }
+            // multi-rank: every slab has summed its own observations into the per-frame rows; after the all-reduce every rank holds the
+            // global normal equations and solves all F (tiny) systems itself
+            if ((rc = comm_allreduce(c, c->acc_frame, c->F * kFrameRow))) return rc;
             if (deferred_consumer) return reserve_frame_energy_deferred(c, deferred_consumer, &c->frame_e_slot);   // filled by the solve kernel
             if ((rc = read_frame_energy(c, col, &e_sum, &nobs))) return rc;
             break;
@@ -219,21 +240,24 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
         case PSGSDF_DIST: {
             take_fold(c, a, 0u);
             if (c->fuse_pcg_init && band_blocks(c) <= kPcgMaxBlocks) { a.pcg_fuse_init = 1; a.pcg_init_blocks = band_blocks(c); }   // the assembly kernel initialises the PCG
+            if ((rc = comm_halo(c, c->band.blk, 14, 1))) return rc;   // multi-rank: rows of H next to a cut take contributions from the neighbour slab's voxel blocks
             timed(c, "assemble", [&] { launch_assemble(a, c->stream); });
             int iters = 0, ok = 1; double err = 0;
             const bool only_on_success = !led && c->set.ref_quirks;   // PsOptimizer.cpp:168-170 (B8): SH skips the update unless the solve reports Success
-            bool tail_ran = false;
+            bool tail_ran = false; int tail_rc = 0;
             auto tail = [&](const double* gate) {                     // distance update + regrad, gated on the device-side outcome of the solve
                 SweepArgs ag = a; ag.fold.n = 0; ag.gate = gate;
                 timed(c, "apply_dist", [&] { launch_apply_dist(ag, c->stream); });
+                if (int hrc = comm_halo(c, c->band.dist, 1, 1)) tail_rc = hrc;   // multi-rank: the regrad's stencils read the neighbour slab's new distances (harmless when the gate is closed: nothing changed)
                 SweepArgs a2 = make_args(c, 0); a2.gate = gate;
                 timed(c, "derive", [&] { launch_derive(a2, 1, c->stream); });
             };
             if ((rc = pcg_solve(c, a, &iters, &ok, &err, tail, only_on_success, &tail_ran))) return rc;
+            if (tail_rc) return tail_rc;
             int apply = 1;
             if (only_on_success && !ok) apply = 0;
             if (apply) {
-                if (!tail_ran) tail(nullptr);
+                if (!tail_ran) { tail(nullptr); if (tail_rc) return tail_rc; }
                 // regrad + Eikonal / Laplacian sums; one read-back for the accepted count and the two sums
                 const int slots[3] = {SC_ACCEPT, SC_EN, SC_EL}; double s[3];
                 if (defer_reg_sums) { if ((rc = read_parts_deferred(c, slots, 3, [c](const double* v) { c->en_sum = v[1]; c->el_sum = v[2]; }))) return rc; }
@@ -395,7 +419,8 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
 }
 
 int do_upsample(psgsdf_ctx* c) {
-    // bring the dense grid up to date, refine, rebuild the band
+    // bring the dense grid up to date (multi-rank: with the refined rows of every slab), refine, rebuild the band
+    { int grc = gather_band_state(c); if (grc) return grc; }
     timed(c, "band_scatter", [&] { launch_band_scatter(c->dense, c->band, c->stream); });
     DenseView nd{};
     const long long nn = 8 * c->grid.nvox;

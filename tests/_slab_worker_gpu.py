@@ -1,39 +1,52 @@
-"""worker of tests/test_slab_gpu.py: one rank of a world_size-N run of the slab host program on the HIP engine.
-All ranks share cuda:0 (the GPU box has one device); backend gloo (RCCL refuses two ranks on one device)."""
+"""worker of tests/test_slab_gpu.py: one rank of a world_size-N run of the engine's NATIVE z-slab loop (psgsdf_iterate / psgsdf_optimize on a
+context attached to a rank).  transport "rccl": the engine's own RCCL communicator (one rank per device: world 1 on the one-GPU box);
+transport "gloo": all ranks share cuda:0 and the exchanges go through the caller-supplied transport of tests/_gloo_transport.py."""
+import faulthandler
 import os
 import sys
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main(rank, world, port, model, out, n_iters, N, backend):
+def main(rank, world, port, model, out, n_iters, N, transport, mode):
+    faulthandler.dump_traceback_later(110, exit=True)
     import torch
-    import torch.distributed as dist
     from psgradientsdf_amd import capi, synth
-    from psgradientsdf_amd.distributed import SlabRunner
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group(backend, rank=rank, world_size=world)
     sc = synth.make_scene(N=N, F=6, W=160, H=120, model=model)
-    st = capi.default_settings(sc.model_id)
+    kw = dict(upsample=1, max_it=8, conv_threshold=1e-9) if mode == "optimize" else {}
+    st = capi.default_settings(sc.model_id, **kw)
     eng = capi.load_engine(sc, sc.K, st, 0)
-    eng.comm_init(rank, world)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    tr = None
+    if transport == "rccl":
+        assert world == 1
+        eng.comm_init(rank, world, capi.comm_unique_id())
+    else:
+        import torch.distributed as dist
+        from _gloo_transport import GlooTransport
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port); os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        tr = GlooTransport(dist)
+        eng.comm_init_ext(tr.ops, rank, world)
     eng.load_scene(sc)
-    run = SlabRunner(eng, dist, cuda=True)
-    run.init_albedo()
-    e0 = run.normalize_weights()
-    recs = run.iterate(capi.ALL, n_iters)
-    torch.cuda.synchronize()
-    v = eng.download_volume()
+    info = eng.mg_info()
+    if mode == "optimize":
+        recs, conv = eng.optimize(capi.ALL); e0 = 0.0
+    else:
+        eng.init_albedo()
+        e0 = eng.normalize_weights()
+        recs = eng.iterate(capi.ALL, n_iters)
+    v = eng.download_volume()          # collective: gathers the refined rows of every slab
     np.savez(out + f".rank{rank}.npz", dist=v["dist"], rgb=v["rgb"], grad=v["grad"], poses=eng.download_poses(), light=eng.download_light(),
-             e_total=[r["e_total"] for r in recs], cg=[r["cg_iters"] for r in recs], e0=e0, info=[run.r0, run.r1, run.halo, run.S], ncoll=run.n_collectives)
-    dist.barrier()
-    dist.destroy_process_group()
+             e_total=[r["e_total"] for r in recs], cg=[r["cg_iters"] for r in recs], e0=e0, band=eng.download_band(),
+             info=[info["row0"], info["row1"], info["halo"], info["S"], info["need_lo"], info["need_hi"]], ncoll=eng.comm_stats(), dim=list(eng.info().dim))
+    eng.close()
+    if tr is not None:
+        dist.barrier(); dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7]), sys.argv[8])
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7]), sys.argv[8], sys.argv[9])

@@ -22,12 +22,29 @@ def test_oracle_mirrors_the_abi(built):
     import __graft_entry__ as g
     from oracle import oracle
     lib = oracle.lib()
-    skip = {"psgsdf_comm_init", "psgsdf_comm_unique_id", "psgsdf_kernel_times", "psgsdf_reset_kernel_times",
+    # (the oracle's multi-rank mirror is driven through its own phase API by psgradientsdf_amd/distributed.py: no communicator entry points)
+    skip = {"psgsdf_comm_unique_id", "psgsdf_comm_init_ext", "psgsdf_comm_stats", "psgsdf_kernel_times", "psgsdf_reset_kernel_times",
             "psgsdf_set_profiling", "psgsdf_watch_kernel", "psgsdf_debug_time_pcg_pass", "psgsdf_debug_rare_rows"}
     for n in g._declared_symbols():
         if n in skip:
             continue
         assert hasattr(lib, n.replace("psgsdf_", "orc_")), n
+
+
+def test_comm_entry_points_fail_cleanly_without_a_gpu(built):
+    """the communicator entry points are status codes too: no context -> ARG; a NULL id -> ARG; librccl is only bound when asked for"""
+    lib = ctypes.CDLL(capi.ENGINE_LIB)
+    for f in ("psgsdf_comm_init", "psgsdf_comm_init_ext", "psgsdf_comm_unique_id", "psgsdf_comm_stats"):
+        getattr(lib, f).restype = ctypes.c_int
+    assert lib.psgsdf_comm_init(None, None, 0, 1) == -1
+    assert lib.psgsdf_comm_init_ext(None, None, 0, 1) == -1
+    assert lib.psgsdf_comm_unique_id(None) == -1
+    assert lib.psgsdf_comm_stats(None, None) == -1
+    import subprocess, sys
+    code = ("import ctypes; lib = ctypes.CDLL(%r); lib.psgsdf_comm_init(None, None, 0, 1); "
+            "print('librccl' in open('/proc/self/maps').read())" % capi.ENGINE_LIB)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.stdout.strip() == "False", out.stdout + out.stderr      # loading the engine pulls no RCCL into a single-GPU process
 
 
 def test_bad_arguments_are_status_codes(built):

@@ -56,4 +56,4 @@ def test_two_ranks_share_the_gpu(built):
     assert outs[1][0].strip() == ""                     # only rank 0 prints
     d = _one_json(outs[0][0])
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
-    assert "cpu_baseline" not in d
+    assert "cpu_baseline" not in d and d["config"]["collectives_per_step"] > 10

@@ -147,7 +147,7 @@ def test_config2_stream_with_tracking_256(built):
     for api in (eng, orc):
         api.set_keyframes(np.arange(F, dtype=np.int32), sc.images, key_poses)
         api.init(); api.init_albedo(); api.normalize_weights()
-    assert np.array_equal(eng.download_band(), orc.download_band()) and eng.info().n_band > 1e5
+    assert np.array_equal(eng.download_band(), orc.download_band()) and eng.info().n_band > 5e4      # (a 30 degree sweep sees a quarter of the object)
     re_, ro = eng.iterate(capi.ALL, 1)[0], orc.iterate(capi.ALL, 1)[0]
     assert abs(re_["e_total"] - ro["e_total"]) <= 1e-4 * abs(ro["e_total"]) and abs(re_["cg_iters"] - ro["cg_iters"]) <= 1
     rel, q999, dmax = sdf_errors(eng, orc, float(sc.voxel_size))
