@@ -110,7 +110,7 @@ static int need_comm(psgsdf_ctx* c) {
 
 // in-place sum over the ranks of n doubles at device pointer buf, ordered on the context's stream
 int comm_allreduce(psgsdf_ctx* c, double* buf, int n) {
-    if (c->n_ranks == 1 || n <= 0) return 0;
+    if (!slab_mode(c) || n <= 0) return 0;
     int rc = need_comm(c); if (rc) return rc;
     c->n_collectives++;
     if (c->comm->is_ext) { if (c->comm->ext.allreduce_f64(c->comm->ext.user, buf, n, c->stream)) return fail(c, PSGSDF_ERR_COMM, "ext allreduce failed"); return 0; }
@@ -149,7 +149,7 @@ int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
 // every rank ends up with all rows of `planes` planes (4-byte elements): rank r owns rows [r*C, (r+1)*C) of each plane (C = rows per
 // slab; the padded planes hold n*C rows), so this is an in-place all-gather per plane
 int comm_allgather_rows(psgsdf_ctx* c, void* base, int planes) {
-    if (c->n_ranks == 1) return 0;
+    if (!slab_mode(c)) return 0;
     int rc = need_comm(c); if (rc) return rc;
     const int C = c->slab_rows;
     if ((long long)C * c->n_ranks > c->band.Spad) return fail(c, PSGSDF_ERR_UNSUPPORTED, "band planes too short for the all-gather (%d x %d > %d)", C, c->n_ranks, c->band.Spad);

@@ -95,7 +95,7 @@ void materialize_fold(psgsdf_ctx* c) {
 // not copied) and land in their mailbox slots.  Every rank runs the same control flow on the same global values, so the collectives
 // match up across ranks by construction.  Called wherever the host is about to wait on the mailbox (flush, pcg_solve).
 int mg_commit(psgsdf_ctx* c) {
-    if (c->n_ranks == 1 || c->mg_segs.empty()) return 0;
+    if (!slab_mode(c) || c->mg_segs.empty()) return 0;
     materialize_fold(c);
     unsigned lo = ~0u, hi = 0;
     for (const MgSeg& g : c->mg_segs) { lo = std::min(lo, g.off); hi = std::max(hi, g.off + g.n); }
@@ -111,7 +111,7 @@ int mg_commit(psgsdf_ctx* c) {
 // every rank ends up with the refined rows of all slabs (distance, stored gradient, albedo): before the band is scattered back into the
 // dense grid for download / 2x refinement
 int gather_band_state(psgsdf_ctx* c) {
-    if (c->n_ranks == 1 || !c->inited || c->band.S == 0) return 0;
+    if (!slab_mode(c) || !c->inited || c->band.S == 0) return 0;
     int rc;
     if ((rc = comm_allgather_rows(c, c->band.dist, 1))) return rc;
     if ((rc = comm_allgather_rows(c, c->band.g[0], 3))) return rc;
@@ -129,8 +129,8 @@ int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<vo
     if (c->mbox_used + (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
     const size_t off = c->mbox_used; c->mbox_used += n;
     // multi-rank: this slab's sums go to the device shadow of the mailbox; mg_commit all-reduces them and fills the mailbox slots
-    double* dst = (c->n_ranks > 1 ? c->mbox_shadow : c->mbox_dev) + off;
-    if (c->n_ranks > 1) c->mg_segs.push_back({(unsigned)off, (unsigned)n});
+    double* dst = (slab_mode(c) ? c->mbox_shadow : c->mbox_dev) + off;
+    if (slab_mode(c)) c->mg_segs.push_back({(unsigned)off, (unsigned)n});
     if (n <= 4 && c->fold_in_next) {
         c->pending_fold.n = n; for (int i = 0; i < n; ++i) c->pending_fold.id[i] = slots[i];
         c->pending_fold.nblk = band_blocks(c); c->pending_fold.out = dst;
@@ -308,7 +308,7 @@ int build_band(psgsdf_ctx* c) {
             c->mbox_alloc = need; c->mbox_n = need - 1;      // [mbox_n] = flush marker
             c->mbox[c->mbox_n] = 0.0; c->flush_seq = 0;
         }
-        if (c->n_ranks > 1 && !c->mbox_shadow) {
+        if (slab_mode(c) && !c->mbox_shadow) {
             HIPCHK(c, hipMalloc(&c->mbox_shadow, sizeof(double) * c->mbox_alloc));
             HIPCHK(c, hipMemsetAsync(c->mbox_shadow, 0, sizeof(double) * c->mbox_alloc, c->stream));
         }

@@ -162,6 +162,9 @@ int gather_band_state(psgsdf_ctx* c);                                  // engine
 
 // ---- engine.hip
 SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg);
+// slab mode: the context is attached to a communicator (also a one-rank one: the exchanges then run as one-rank collectives, which is how
+// the RCCL path is exercised on a one-GPU box and how its overhead is measured, bench.py --force-slab)
+inline bool slab_mode(const psgsdf_ctx* c) { return c->comm != nullptr || c->n_ranks > 1; }
 inline int band_blocks(const psgsdf_ctx* c) { return (c->row1 - c->row0 + kBlock - 1) / kBlock; }
 inline double band_mean(const psgsdf_ctx* c, double sum) { return c->band.S ? sum / (double)c->band.S : 0.0; }
 inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l, float E_r = 0.f) { return E + c->reg_n * E_n + c->reg_l * E_l + c->reg_r * E_r; }   // OptimizerAux.cpp:261

@@ -40,7 +40,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
     // Multi-rank (z-slabs): the same fused kernel, reading the globally reduced sums of the previous pass from `ext` instead of its own
     // partials.  Per pass: halo rows of the records it gathers from, the pass, a 1-workgroup fold of its partials, ONE all-reduce of 7 doubles.
     // Every rank publishes the same values to its mailbox, so all ranks take the same decisions below.
-    const bool mr = c->n_ranks > 1;
+    const bool mr = slab_mode(c);
     SweepArgs ap = a;
     if (mr) {
         int rc = mg_commit(c); if (rc) return rc;      // the read-backs staged so far are delivered when the first slot of this solve is seen

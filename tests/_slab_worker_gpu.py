@@ -17,8 +17,7 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
     from psgradientsdf_amd import capi, synth
     torch.cuda.set_device(0)
     sc = synth.make_scene(N=N, F=6, W=160, H=120, model=model)
-    kw = dict(upsample=1, max_it=8, conv_threshold=1e-9) if mode == "optimize" else {}
-    st = capi.default_settings(sc.model_id, **kw)
+    st = capi.default_settings(sc.model_id)
     eng = capi.load_engine(sc, sc.K, st, 0)
     tr = None
     if transport == "rccl":
@@ -32,13 +31,13 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
         tr = GlooTransport(dist)
         eng.comm_init_ext(tr.ops, rank, world)
     eng.load_scene(sc)
+    eng.init_albedo()
+    e0 = eng.normalize_weights()
+    recs = eng.iterate(capi.ALL, n_iters)
+    if mode == "refine":          # the 2x refinement of PsOptimizer.cpp:386-409 between iterations: gather, refine, new partition
+        eng.upsample2x()
+        recs += eng.iterate(capi.ALL, 1)
     info = eng.mg_info()
-    if mode == "optimize":
-        recs, conv = eng.optimize(capi.ALL); e0 = 0.0
-    else:
-        eng.init_albedo()
-        e0 = eng.normalize_weights()
-        recs = eng.iterate(capi.ALL, n_iters)
     v = eng.download_volume()          # collective: gathers the refined rows of every slab
     np.savez(out + f".rank{rank}.npz", dist=v["dist"], rgb=v["rgb"], grad=v["grad"], poses=eng.download_poses(), light=eng.download_light(),
              e_total=[r["e_total"] for r in recs], cg=[r["cg_iters"] for r in recs], e0=e0, band=eng.download_band(),
