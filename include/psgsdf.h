@@ -285,6 +285,10 @@ int psgsdf_set_profiling(psgsdf_ctx* ctx, int enabled);
 int psgsdf_watch_kernel(psgsdf_ctx* ctx, const char* name);
 /* Builds the distance normal equations at the current state and returns, for the n_band rows:
  * diag (H_ii before damping), rhs b, and y = H*x for the supplied x (may be NULL). */
+/* the persistent PCG solve run for exactly `passes` passes, stop rule off: average kernel time over `reps` launches;
+ * shape = { workgroups, rows per thread }; stamps (may be NULL) = stage timestamps of pass 8 of two workgroups, 100 MHz ticks.
+ * PSGSDF_ERR_UNSUPPORTED where the per-pass kernels are used instead. */
+int psgsdf_debug_time_pcg_solve(psgsdf_ctx* ctx, int passes, int reps, double* ms_per_launch, int32_t shape[2], double stamps[16]);
 int psgsdf_debug_dist_system(psgsdf_ctx* ctx, float* diag, float* rhs, const float* x, float* y);
 /* timing only: average ms of `reps` back-to-back launches of the fused PCG pass on the current distance system with
  * `blocks` workgroups (0 = one row per thread) and ablation bits (see pcg.hip: k_cgf_pass); leaves the PCG state undefined */

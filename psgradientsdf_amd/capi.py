@@ -351,6 +351,11 @@ class Api:
                                                      st.ctypes.data_as(C.c_void_p) if stamps else None), "debug_time_pcg_pass")
         return (ms.value, st) if stamps else ms.value
 
+    def debug_time_pcg_solve(self, passes=16, reps=5):
+        ms = C.c_double(0); shape = (C.c_int32 * 2)(); st = (C.c_double * 16)()
+        self._check(self._fn("debug_time_pcg_solve")(self.ctx, C.c_int(passes), C.c_int(reps), C.byref(ms), shape, st), "debug_time_pcg_solve")
+        return ms.value, (shape[0], shape[1]), [x for x in st]
+
     def debug_rare_rows(self):
         r = C.c_int64(); w = C.c_int64()
         self._check(self._fn("debug_rare_rows")(self.ctx, C.byref(r), C.byref(w)), "debug_rare_rows")

@@ -23,6 +23,8 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_FOLD_IN_NEXT")) c->fold_in_next = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FUSE_ALBEDO")) c->fuse_albedo = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FUSE_PCG_INIT")) c->fuse_pcg_init = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_PCG_PERSIST")) c->pcg_persist = atoi(e) != 0;
+    if (hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cu = 0;
     c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l; c->reg_r = settings->reg_weight_rho;
     GridP& g = c->grid;
     for (int a = 0; a < 3; ++a) { g.dim[a] = grid->dim[a]; c->shift[a] = grid->shift[a]; }
@@ -33,6 +35,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     bool ok = hipStreamCreate(&c->stream) == hipSuccess
         && hipMalloc(&c->pcg_sc, sizeof(double) * (16 + 8 * (size_t)kPcgMaxBlocks)) == hipSuccess   // fs[0..1] + stage stamps of the timing hook
         && hipMalloc(&c->pcg_part, sizeof(double) * 14 * kPcgMaxBlocks) == hipSuccess
+        && hipMalloc(&c->pcg_gran, sizeof(double) * 2 * 7 * kSolveMaxBlocksHost) == hipSuccess
         && hipMalloc(&c->mg_scal, sizeof(double) * kMgScal) == hipSuccess && hipMalloc(&c->mg_ext, sizeof(double) * 8) == hipSuccess
         && hipMalloc(&c->d_need, 2 * sizeof(int)) == hipSuccess
         && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess
@@ -50,7 +53,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     free_dense(c);
     hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->led_light);
     hipFree(c->band_mem); hipFree(c->obs_mem); hipFree(c->stage);
-    hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->d_total);
+    hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->pcg_gran); hipFree(c->d_total);
     if (c->host_buf) hipHostFree(c->host_buf);
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);

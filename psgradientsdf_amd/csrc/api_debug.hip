@@ -75,6 +75,34 @@ int psgsdf_debug_time_pcg_pass(psgsdf_ctx* c, int blocks, int rows, int ablate, 
     return PSGSDF_OK;
 }
 
+// the persistent solve run for exactly `passes` passes on the current distance system (stop rule off): total kernel time and its shape
+int psgsdf_debug_time_pcg_solve(psgsdf_ctx* c, int passes, int reps, double* ms_per_launch, int32_t* shape, double* stamps /*[16] or NULL*/) {
+    if (!c || !c->inited || !ms_per_launch || !shape || passes < 1 || reps < 1) return fail(c, PSGSDF_ERR_STATE, "init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int G = 0, rows = 0;
+    if (!cgf_solve_shape(c, &G, &rows)) return fail(c, PSGSDF_ERR_UNSUPPORTED, "the persistent solve does not apply to this context");
+    shape[0] = G; shape[1] = rows;      // rows = rows per workgroup
+    SweepArgs a = make_args(c, c->reg_l != 0.f);
+    a.pcg_fuse_init = 1; a.pcg_init_blocks = band_blocks(c); a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * 7 * kSolveMaxBlocksHost;
+    hipEvent_t e0, e1; HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    float total = 0;
+    for (int r = 0; r < reps + 1; ++r) {
+        launch_sweep_dist(a, c->stream);
+        launch_assemble(a, c->stream);
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        launch_cgf_solve(a, c->pcg_sc, c->pcg_gran, G, rows, 1 << 30, c->mbox_dev, passes, c->stream);
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) total += ms;
+        if (c->mbox[3] != 1.0) return fail(c, PSGSDF_ERR_DEVICE, "persistent solve status %g", c->mbox[3]);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_per_launch = (double)total / reps;
+    if (stamps) for (int i = 0; i < 16; ++i) stamps[i] = c->mbox[8 + i];      // pass 8 of the last launch: 7 stage stamps of the first and of the last workgroup (100 MHz ticks)
+    return PSGSDF_OK;
+}
+
 // how many rows of the assembled distance system carry any of the 6 "rare" ELL columns, and how many 64-row groups
 // (wavefronts of a one-row-per-thread launch) contain such a row
 int psgsdf_debug_rare_rows(psgsdf_ctx* c, int64_t* rows, int64_t* waves) {

@@ -257,7 +257,11 @@ __global__ void __launch_bounds__(kBlock) k_assemble(SweepArgs a) {
     if (a.pcg_fuse_init) {
         __shared__ double red[kBlock / 64];
         block_part_store(bb, fpart(a.pcg_part, -1, 6), red);
-        if (blockIdx.x == 0 && threadIdx.x == 0) { a.pcg_fs[1] = 0.0; a.pcg_fs[2] = 0.0; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.pcg_fs[1] = 0.0; a.pcg_fs[2] = 0.0; a.pcg_fs[3] = 0.0; }
+        if (a.pcg_gran) {   // persistent solve: no tag of an earlier solve may survive
+            const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+            for (int q = gid; q < a.pcg_gran_n; q += gridDim.x * blockDim.x) a.pcg_gran[q] = 0.0;
+        }
     }
 }
 void launch_assemble(const SweepArgs& a, hipStream_t s) {

@@ -128,6 +128,7 @@ struct SweepArgs {
     FoldReq fold;             // n = 0: nothing pending
     AlbedoReg ar;             // ar.anb == nullptr unless "reg albedo" != 0
     double* pcg_part; double* pcg_fs;   // fused PCG state (pcg.hip)
+    double* pcg_gran; int pcg_gran_n;   // persistent solve: the tagged per-workgroup sums, zeroed by the assembly kernel when non-null
     int pcg_fuse_init;        // assembly kernel also initialises the PCG (x = 0, records of pass -1, |b|^2 partials): no k_cgf_init launch
     int pcg_init_blocks;      // workgroups that wrote the |b|^2 partials (0: the pass kernel's own grid)
     int fuse_apply;           // albedo sweep: solve the voxel's diagonal system and apply the update in the same thread (no normal equations stored)
@@ -169,7 +170,11 @@ void launch_sweep_dist(const SweepArgs& a, hipStream_t s);
 void launch_assemble(const SweepArgs& a, hipStream_t s);
 void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s);
 void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int rows, int k, int kmax, double* mb, hipStream_t s, int ablate = 0);
-void launch_cgf_sum(double* part, int G, int k, double* out, hipStream_t s);   // multi-rank: partials of pass k -> out[0..6]
+void launch_cgf_sum(double* part, int G, int k, double* out, hipStream_t s);
+// the whole solve as one persistent kernel (pcg.hip: k_cgf_solve); gran = [2][7][kSolveMaxBlocksHost] tagged per-workgroup sums, zeroed by the assembly kernel
+constexpr int kSolveThreadsHost = 512, kSolveMaxBlocksHost = 256, kSolveMaxRowsHost = 4, kSolveMbSlots = 24;      // {iters, |r|^2, |b|^2, status} + stage timestamps of the timing hook
+int cgf_solve_max_blocks(int rows);      // resident workgroups per CU of the R-rows instance (occupancy query)
+void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, int force_passes, hipStream_t s);   // multi-rank: partials of pass k -> out[0..6]
 // "reg albedo" path (albedo_reg.hip); every launch covers the whole band (single rank only)
 void launch_areg_tables(const DenseView& d, const GridP& g, const SweepArgs& a, hipStream_t s);
 void launch_areg_build(const SweepArgs& a, hipStream_t s);                       // J, res from the current albedo; sum of res -> SC_AUX0

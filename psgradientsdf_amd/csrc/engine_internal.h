@@ -64,7 +64,10 @@ struct psgsdf_ctx {
     double* acc_frame = nullptr; size_t acc_frame_n = 0;
     double* part = nullptr; int PB = 0;  // [SC_COUNT][PB] per-workgroup partials
     double* pcg_sc = nullptr; int pcg_cap = 4096;
-    double* pcg_part = nullptr;          // [2][3][kPcgMaxBlocks]
+    double* pcg_part = nullptr;          // [2][7][kPcgMaxBlocks]
+    double* pcg_gran = nullptr;          // persistent solve: [2][7][kSolveMaxBlocksHost] tagged per-workgroup sums
+    bool pcg_persist = true;             // PSGSDF_PCG_PERSIST=0: always the per-pass kernels
+    int num_cu = 0;
     int last_cg_iters = 0;
     bool want_counts = true;             // read back the accepted-update counts (debug statistic of the reference)
     double* host_buf = nullptr; size_t host_buf_n = 0;   // pinned readback
@@ -186,6 +189,7 @@ int ps_energy(psgsdf_ctx* c, double* E, int64_t* nobs);
 // ---- loop.hip
 struct LoopState { float E, E_n, E_l, E_prev; int laplacian_reg; float E_r; };
 void cgf_shape(int nblk, int* G, int* rows);
+bool cgf_solve_shape(psgsdf_ctx* c, int* G, int* rows);      // can the whole solve run as ONE persistent kernel on this context?
 int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_out, double* err_out,
               const std::function<void(const double*)>& tail = nullptr, bool gate_on_converged = true, bool* tail_ran = nullptr);
 int albedo_reg_energy(psgsdf_ctx* c, double* Er);

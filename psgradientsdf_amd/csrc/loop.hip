@@ -21,6 +21,25 @@ void cgf_shape(int nblk, int* G, int* rows) {
     *G = (per + trips - 1) / trips; *rows = r;
 }
 
+// Shape of the persistent solve (pcg.hip: k_cgf_solve): G workgroups of 512 threads, at most one per CU (all co-resident), the band dealt
+// evenly to them (<= 4 rows per thread).  Single-rank contexts only -- a slab needs the other slabs' sums every pass,
+// which is the per-pass kernels' all-reduce -- and only with 16-bit column deltas and the assembly kernel's fused initialisation.
+bool cgf_solve_shape(psgsdf_ctx* c, int* G, int* rows_per_wg) {
+    if (!c->pcg_persist || slab_mode(c) || !c->band.col16 || !c->fuse_pcg_init || c->num_cu <= 0 || band_blocks(c) > kPcgMaxBlocks) return false;
+    const int n = c->row1 - c->row0, cap = std::min(c->num_cu, kSolveMaxBlocksHost);
+    if (n <= 0) return false;
+    // as many workgroups as CUs (in multiples of 8: every XCD owns a contiguous range of rows) unless the band is so small that a workgroup
+    // would get less than one row per thread; the band is dealt evenly, in multiples of 64 rows
+    int g = std::min(cap, (n + kSolveThreadsHost - 1) / kSolveThreadsHost);
+    g = std::max(8, g / 8 * 8);
+    if (g > cap) g = cap;
+    const int per = ((n + g - 1) / g + 63) / 64 * 64;
+    const int r = (per + kSolveThreadsHost - 1) / kSolveThreadsHost;
+    if (r > kSolveMaxRowsHost || cgf_solve_max_blocks(r) < 1) return false;
+    *G = g; *rows_per_wg = per;
+    return true;
+}
+
 // Fused PCG (pcg.hip: k_cgf_pass): kernel k finishes pass k-1 and runs pass k, so a chunk of n kernels tells the host
 // about the passes up to k0+n-2; the kernel that detects convergence (or hits the cap) is also the one that finalises x.
 // `tail(gate)`, if given, enqueues what follows a finished solve (distance update + regrad) right behind every chunk of passes,
@@ -35,6 +54,27 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
     int cap = c->set.cg_max_it > 0 ? c->set.cg_max_it : 2 * S;
     if (cap > c->pcg_cap) cap = c->pcg_cap;
     int G, rows;
+    if (a.pcg_gran && cgf_solve_shape(c, &G, &rows)) {
+        // ---- the whole solve as one persistent kernel: nothing for the host to decide until it is over, so the distance update and
+        // the regrad are enqueued right behind it (gated on the device-side outcome) and the host only picks up the statistics
+        if (c->mbox_used + (size_t)kSolveMbSlots > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+        const size_t off = c->mbox_used; c->mbox_used += kSolveMbSlots;
+        volatile double* st = c->mbox + off;
+        st[3] = NAN;
+        timed(c, "pcg_solve", [&] { launch_cgf_solve(a, c->pcg_sc, c->pcg_gran, G, rows, cap, c->mbox_dev + off, 0, c->stream); });
+        if (tail && !c->profiling) { tail(c->pcg_sc + (gate_on_converged ? 2 : 1)); if (tail_ran) *tail_ran = true; }
+        const int w = wait_mapped(c, [st] { return !std::isnan(st[3]); }, "pcg_solve");
+        if (w < 0) return w;
+        if (std::isnan(st[3])) return fail(c, PSGSDF_ERR_DEVICE, "the PCG kernel published nothing");
+        if (st[3] != 1.0) return fail(c, PSGSDF_ERR_DEVICE, "the PCG kernel gave up waiting for its other workgroups (status %g): is another process holding CUs of this device?", (double)st[3]);
+        if (w == 0 && !c->pending_fold.n) { for (auto& f : c->deferred) f(); c->deferred.clear(); c->mbox_used = 0; }   // everything enqueued before the solve has landed
+        const float rhsN = (float)st[2];
+        if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }
+        const double err = sqrt((double)(float)st[1] / (double)rhsN);
+        *iters_out = (int)st[0]; *err_out = err; *success_out = err <= (double)FLT_EPSILON;
+        c->last_cg_iters = *iters_out;
+        return 0;
+    }
     cgf_shape(band_blocks(c), &G, &rows);
     if (!a.pcg_fuse_init) timed(c, "pcg_init", [&] { launch_cgf_init(a, c->pcg_sc, c->pcg_part, G, c->stream); });
     // Multi-rank (z-slabs): the same fused kernel, reading the globally reduced sums of the previous pass from `ext` instead of its own
@@ -240,6 +280,7 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
         case PSGSDF_DIST: {
             take_fold(c, a, 0u);
             if (c->fuse_pcg_init && band_blocks(c) <= kPcgMaxBlocks) { a.pcg_fuse_init = 1; a.pcg_init_blocks = band_blocks(c); }   // the assembly kernel initialises the PCG
+            { int Gs, Rs; if (a.pcg_fuse_init && cgf_solve_shape(c, &Gs, &Rs)) { a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kCgfSumsHost * kSolveMaxBlocksHost; } }   // the assembly kernel also clears the persistent solve's tags
             if ((rc = comm_halo(c, c->band.blk, 14, 1))) return rc;   // multi-rank: rows of H next to a cut take contributions from the neighbour slab's voxel blocks
             timed(c, "assemble", [&] { launch_assemble(a, c->stream); });
             int iters = 0, ok = 1; double err = 0;

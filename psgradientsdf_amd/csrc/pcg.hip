@@ -314,6 +314,234 @@ void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int ro
     else hipLaunchKernelGGL((k_cgf_pass<1, 4, false>), dim3(G), dim3(kBlock), 0, s, a, fs, part, k, kmax, mb, ablate);
 }
 
+// ------------------------------------------------------------------------------------------
+// The whole solve as ONE persistent kernel (single-rank contexts whose band fits the register file).
+//
+// A per-pass launch re-streams the 19 ELL coefficients and 9 index words of every row (152 B/row, 51 MB at the 256^3 band:
+// 9.7 of the pass's 14.3 us at the ~5.3 TB/s the L2-miss path sustains; profiles/r01_notes.md) although the matrix never
+// changes during a solve.  Here every thread loads the coefficients and column deltas of its R rows ONCE into registers
+// (28 dwords per row; 38 MB of the chip's 128 MB of VGPRs at 256^3), keeps its own {r, t, p, x} there too, and loops over
+// the passes; per pass it gathers the 18 neighbour records (16 B each, L2-resident: 5.4 MB per buffer), computes exactly what
+// k_cgf_pass computes (same recurrences, same seven sums, same fixed-order reduction, same stop rule) and meets the other
+// workgroups at a device-wide all-gather of the seven per-workgroup sums:
+//   publish : records with 16-byte write-through (sc1) stores -> every wave s_waitcnt vmcnt(0) -> __syncthreads -> seven 8-byte
+//             granules {sum with a 2-bit pass tag in its two lowest mantissa bits}, one sc1 store each: data and tag arrive
+//             together, no flag, no ordering between the seven.  (Plain stores + an agent-scope release fence measured 4.8 us
+//             for drain + write-back per pass; profiles/r02_notes.md.)
+//   wait    : thread t polls the seven granules of workgroup t (relaxed agent-scope loads) until their tags name the pass;
+//             __syncthreads; lane 0 agent-scope acquire; __syncthreads; the fixed-order sum over workgroups every workgroup
+//             computes identically -> alpha, beta, |r|^2 and the stop decision are the same everywhere, so all workgroups leave
+//             in the same pass.  The records double-buffer exactly as in k_cgf_pass; one barrier per pass covers both hazards.
+// One workgroup of 512 threads per CU at most (grid <= the CU count, so all workgroups are co-resident); logical workgroup ids
+// are remapped so that every XCD owns a contiguous range of rows (gathers stay in that XCD's L2).  Every wait is bounded:
+// a workgroup that sees nothing for ~1 s raises the abort flag and every workgroup leaves (the host reports PSGSDF_ERR_DEVICE).
+// Two mantissa bits of the double sums carry the tag: 4e-16 relative, far below the float the sums are rounded to.
+// ------------------------------------------------------------------------------------------
+constexpr int kSolveThreads = 512;            // one workgroup of 8 waves per CU: 2 waves per SIMD at <= 256 VGPRs (16 waves at 128 VGPRs spilled: 21 us per pass)
+constexpr int kSolveMaxBlocks = 256;          // one per CU
+constexpr int kSolveMaxRows = 4;              // rows per thread: R x 38 KB of coefficients in the CU's 160 KB of LDS
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+// 16-byte write-through store (sc1): the record reaches memory without a later L2 write-back, so publishing needs no release fence
+// (MI355X_MICROARCH.md "publish-large": 3.0 vs 8.2 us); the trailing s_nop keeps the assembler's hazard rules for inline VMEM
+__device__ __forceinline__ void store16_sc1(float4* p, const float4& v) {
+    const v4f_t d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+}
+__device__ __forceinline__ double gran_tag(double v, unsigned tag) { return __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(v) & ~3ull) | tag)); }
+__device__ __forceinline__ unsigned gran_tag_of(double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) & 3ull); }
+
+template <int R>
+__global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, double* fs, double* gran, int rows_per_wg, int kmax, double* mb, int force_passes) {
+    __shared__ double red[8 * kSolveThreads / 64];
+    __shared__ int s_abort;
+    const Band& b = a.b;
+    const int G = gridDim.x, tid = threadIdx.x;
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs; logical block lb gives XCD x the contiguous blocks [x G/8, (x+1) G/8)
+    const int lb = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int plane = b.Spad * 4;
+    const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)b.H, 0, kNQ * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)b.colp, 0, (kNQ - 1) / 2 * plane, 0x00020000);
+    // ---- once: the rows of this thread.  The 19 coefficients of a row live in LDS ([row slot][column][thread]: conflict-free, R x 38 KB of
+    // the CU's 160 KB), the 9 index words and the row's own state in registers.
+    float* hs = (float*)psg_dyn_smem;
+    unsigned cp[R][(kNQ - 1) / 2]; float4 me[R]; float x[R]; int row[R]; bool live[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        // the band is dealt evenly to ALL workgroups (rows_per_wg each, a multiple of 64): the last row slot of a thread is only partly used
+        const int i = a.row0 + lb * rows_per_wg + u * kSolveThreads + tid;
+        live[u] = u * kSolveThreads + tid < rows_per_wg && i < a.row1; row[u] = live[u] ? i : a.row1 - 1;
+#pragma unroll
+        for (int q = 0; q < kNQ; ++q) {
+            float hv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rH, row[u] * 4, q * plane, 0));
+            if (q == 0 && a.damping != 0.0f) hv += a.damping * hv;
+            hs[(u * kNQ + q) * kSolveThreads + tid] = hv;
+        }
+#pragma unroll
+        for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) cp[u][wd] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rC, row[u] * 4, wd * plane, 0);
+        me[u] = b.rec[1][row[u]];            // {r_0, 0, 0, inv} written by the assembly kernel
+        x[u] = 0.f;
+    }
+    // |b|^2 from the assembly kernel's per-workgroup partials (an earlier kernel: plain loads)
+    double bb;
+    { double* src[1] = {fpart(a.pcg_part, -1, 6)}; PartLoads<1> pl;   // (block_total_n assumes kBlock threads: sum here with the first kBlock threads' loads)
+      double v = 0.0;
+      for (int i = tid; i < a.pcg_init_blocks; i += kSolveThreads) v += src[0][i];
+      v = wave_sum(v);
+      if ((tid & 63) == 0) red[tid >> 6] = v;
+      __syncthreads();
+      bb = 0.0;
+#pragma unroll
+      for (int i = 0; i < kSolveThreads / 64; ++i) bb += red[i];
+      __syncthreads();
+      (void)pl; }
+    const float rhsNorm2 = (float)bb;
+    const float thr = pcg_threshold(rhsNorm2);
+    float alpha_prev = 0.f, beta = 0.f, rr_cur = rhsNorm2;
+    if (lb == 0 && tid == 0) fs[0] = bb;
+    int k = 0, status = 1;                    // status 1 = finished, 2 = a wait timed out
+    // stage timestamps of pass 8 (timing hook only: force_passes > 0), wall clock at 100 MHz, written by thread 0 of two workgroups
+#define SOLVE_STAMP(j) do { if (force_passes > 0 && k == 8 && tid == 0 && (lb == 0 || lb == G - 1)) mb[8 + (lb ? 8 : 0) + (j)] = (double)wall_clock64(); } while (0)
+    for (;; ++k) {
+        SOLVE_STAMP(0);
+        if (k > 0) {
+            // ---- meet the other workgroups: the seven sums of pass k-1 of every workgroup
+            const unsigned want = (unsigned)k & 3u;            // tag of pass k-1 = ((k-1) + 1) & 3
+            const double* gp = gran + (size_t)((k - 1) & 1) * kCgfSums * kSolveMaxBlocks;
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = 0.0;
+            if (tid == 0) s_abort = 0;
+            if (tid < G) {
+                int spins = 0; bool ok = false;
+                while (!ok) {
+                    ok = true;
+#pragma unroll
+                    for (int q = 0; q < kCgfSums; ++q) { v[q] = __hip_atomic_load(gp + (size_t)q * kSolveMaxBlocks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = ok && gran_tag_of(v[q]) == want; }
+                    if (!ok) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1 << 21) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
+                    }
+                }
+            }
+            __syncthreads();
+            SOLVE_STAMP(1);
+            if (s_abort) { if (tid == 0) __hip_atomic_store(fs + 3, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); status = 2; break; }
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            double t0, t1; wave_sum8(v, t0, t1);
+            wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
+            __syncthreads();
+            double t[kCgfSums];
+#pragma unroll
+            for (int q = 0; q < kCgfSums; ++q) { double s_ = 0; for (int i = 0; i < kSolveThreads / 64; ++i) s_ += red[q * (kSolveThreads / 64) + i]; t[q] = s_; }
+            __syncthreads();
+            const float rz_old = (float)t[5];
+            alpha_prev = rz_old / (float)t[0];
+            const double al = (double)alpha_prev;
+            const float rz_cur = (float)(t[5] - 2.0 * al * t[1] + al * al * t[2]);
+            rr_cur = (float)(t[6] - 2.0 * al * t[3] + al * al * t[4]);
+            beta = rz_cur / rz_old;
+            SOLVE_STAMP(2);
+        }
+        const bool rhs_zero = rhsNorm2 == 0.f;
+        const bool stop = force_passes > 0 ? k >= force_passes : (rhs_zero || k == kmax || (k > 0 && rr_cur < thr));
+        // ---- finish pass k-1 for the own rows; run pass k
+        const float4* __restrict__ rin = b.rec[(k + 1) & 1];
+        float4* __restrict__ rout = b.rec[k & 1];
+        double s[kCgfSums];
+#pragma unroll
+        for (int q = 0; q < kCgfSums; ++q) s[q] = 0;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            if (k > 0) x[u] = x[u] + alpha_prev * me[u].z;
+            if (stop) continue;
+            // the 18 neighbour records of the previous pass (own column from registers)
+            float4 o[kNQ - 1];
+#pragma unroll
+            for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) {
+                const int pk = (int)cp[u][wd];
+                o[2 * wd] = rin[row[u] + ((pk << 16) >> 16)];
+                o[2 * wd + 1] = rin[row[u] + (pk >> 16)];
+            }
+            double A1, A2, A3;
+            const float* hrow = hs + (size_t)u * kNQ * kSolveThreads + tid;
+            { const double hq = (double)hrow[0], iv = (double)me[u].w; A1 = hq * (iv * (double)me[u].x); A2 = hq * (iv * (double)me[u].y); A3 = hq * (double)me[u].z; }
+#pragma unroll
+            for (int q = 1; q < kNQ; ++q) {
+                const double hq = (double)hrow[q * kSolveThreads], iv = (double)o[q - 1].w;
+                A1 += hq * (iv * (double)o[q - 1].x); A2 += hq * (iv * (double)o[q - 1].y); A3 += hq * (double)o[q - 1].z;
+            }
+            const float r_i = me[u].x - alpha_prev * me[u].y;
+            const float z_i = me[u].w * r_i;
+            const float p_i = z_i + beta * me[u].z;
+            const float tt = (float)(A1 - (double)alpha_prev * A2 + (double)beta * A3);
+            me[u] = make_float4(r_i, tt, p_i, me[u].w);
+            if (live[u]) {
+                store16_sc1(rout + row[u], me[u]);
+                const double rd = (double)r_i, td = (double)tt, iv = (double)me[u].w;
+                s[0] += (double)p_i * td; s[1] += iv * rd * td; s[2] += iv * td * td; s[3] += rd * td; s[4] += td * td;
+                s[5] += rd * (double)z_i; s[6] += rd * rd;
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one row's 18 gathers in flight at a time (register budget)
+        }
+        if (stop) break;
+        SOLVE_STAMP(3);
+        // ---- publish: records first (release), then the seven tagged sums
+        double sv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sv[q] = q < kCgfSums ? s[q] : 0.0;
+        double t0, t1; wave_sum8(sv, t0, t1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
+        __syncthreads();
+        SOLVE_STAMP(4);      // (every wave drained its write-through record stores before the barrier: nothing left to release)
+        SOLVE_STAMP(5);
+        if (tid < kCgfSums) {
+            double tot = 0;
+            for (int i = 0; i < kSolveThreads / 64; ++i) tot += red[tid * (kSolveThreads / 64) + i];
+            double* gp = gran + (size_t)(k & 1) * kCgfSums * kSolveMaxBlocks + (size_t)tid * kSolveMaxBlocks + lb;
+            __hip_atomic_store(gp, gran_tag(tot, (unsigned)(k + 1) & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        SOLVE_STAMP(6);
+    }
+#undef SOLVE_STAMP
+    // ---- leave: x of the own rows; the outcome for the host and for the gated kernels behind this one
+#pragma unroll
+    for (int u = 0; u < R; ++u) if (live[u]) b.x[row[u]] = x[u];
+    if (lb == 0 && tid == 0) {
+        const bool rhs_zero = rhsNorm2 == 0.f;
+        const bool ok = status == 1 && (rhs_zero || sqrt((double)rr_cur / (double)rhsNorm2) <= (double)FLT_EPSILON);
+        int iters = 0;
+        if (!rhs_zero && k > 0) iters = (rr_cur < thr) ? k - 1 : k;      // Eigen leaves the loop before ++i when it detects convergence; k == kmax otherwise
+        fs[1] = (double)(k + 1); fs[2] = ok ? 1.0 : 0.0;
+        mb[0] = (double)iters; mb[1] = (double)rr_cur; mb[2] = (double)rhsNorm2;
+        __threadfence_system();
+        mb[3] = (double)status;                // the host watches this slot
+        __threadfence_system();
+    }
+}
+static size_t cgf_solve_lds(int rows) { return sizeof(float) * (size_t)rows * kNQ * kSolveThreads; }
+template <int R> static int cgf_solve_prepare() {      // > 64 KB of dynamic LDS has to be asked for, once per instance
+    static int per_cu = -1;
+    if (per_cu >= 0) return per_cu;
+    per_cu = 0;
+    if (hipFuncSetAttribute((const void*)k_cgf_solve<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cgf_solve_lds(R)) != hipSuccess) return per_cu;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cgf_solve<R>, kSolveThreads, cgf_solve_lds(R)) == hipSuccess) per_cu = n;
+    return per_cu;
+}
+int cgf_solve_max_blocks(int rows) {
+    return rows == 1 ? cgf_solve_prepare<1>() : rows == 2 ? cgf_solve_prepare<2>() : rows == 3 ? cgf_solve_prepare<3>() : cgf_solve_prepare<4>();
+}
+void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, int force_passes, hipStream_t s) {
+    const int rows = (rows_per_wg + kSolveThreads - 1) / kSolveThreads;
+    const size_t lds = cgf_solve_lds(rows);
+    if (rows == 1) hipLaunchKernelGGL((k_cgf_solve<1>), dim3(G), dim3(kSolveThreads), lds, s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
+    else if (rows == 2) hipLaunchKernelGGL((k_cgf_solve<2>), dim3(G), dim3(kSolveThreads), lds, s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
+    else if (rows == 3) hipLaunchKernelGGL((k_cgf_solve<3>), dim3(G), dim3(kSolveThreads), lds, s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
+    else hipLaunchKernelGGL((k_cgf_solve<4>), dim3(G), dim3(kSolveThreads), lds, s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
+}
+
 // multi-rank: fold the partials of pass k (k = -1: |b|^2 of the init) into out[0..6] for the host program's all-reduce
 __global__ void __launch_bounds__(kBlock) k_cgf_sum(double* part, int G, int k, double* __restrict__ out) {
     __shared__ double red[8 * kBlock / 64];
