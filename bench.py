@@ -31,7 +31,7 @@ from psgradientsdf_amd import capi, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def algorithmic_bytes(kernel, S, n_obs, W, H, F, laplacian=False):
+def algorithmic_bytes(kernel, S, n_obs, W, H, F, laplacian=False, pcg_passes=1.0):
     """Algorithmic HBM bytes of ONE launch: per band voxel B_v = 60 B of state
     (dist 4, grad 12, rgb 12, vis 8, 3 stencil-neighbour dists 12, 3 row lookups 12; +12 with the Laplacian),
     image taps U_img = min(48 B * n_obs, 12 B * W*H*F) and the kernel's per-voxel output."""
@@ -43,6 +43,7 @@ def algorithmic_bytes(kernel, S, n_obs, W, H, F, laplacian=False):
         "sweep_pose": S * B_v + U,
         "sweep_dist": S * B_v + U + 56 * S,
         "energy": S * B_v + U,
+        "pcg_solve": 124 * S * pcg_passes,   # the persistent solve: ONE launch runs all passes of a solve (B_cg = 124 B per band voxel per PCG iteration)
         "pcg_pass": 124 * S,    # B_cg = 124 B per band voxel per PCG iteration (block 40 + 3 nbr rows 12 + gather p 16 + scatter Ap 16 + 5 vector streams 40)
         "assemble": (56 + 80 + 12) * S,
         "derive": (4 + 12 + 24 + 36 + 12) * S,
@@ -149,7 +150,7 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_iter"] if algorithmic_bytes(k, 1, 1, 1, 1, 1) else -1)
     eng.reset_kernel_times()
     if os.environ.get("PSGSDF_NO_WATCH") != "1":   # (tools/gap_run.sh: trace without the event pairs)
-        eng.watch_kernel(dom + "/16")  # HIP events around every 16th launch of the dominant kernel (each pair breaks the back-to-back dispatch: ~6 us of stream time)
+        eng.watch_kernel(dom + ("/16" if dom == "pcg_pass" else "/4"))  # HIP events around every 16th (4th) launch of the dominant kernel (each pair breaks the back-to-back dispatch: ~6 us of stream time)
     barrier()
     coll0 = eng.comm_stats()
     t0 = time.perf_counter()
@@ -201,7 +202,7 @@ def main():
         # event pairs recorded on the launch stream around every 16th launch: the pair also reads the dispatch latency, so this is
         # ~2.5 us above the kernel duration rocprofv3 --kernel-trace reports (profiles/): the roofline fraction errs low
         avg_ms = watched[0] / max(watched[1], 1) if watched[1] else float("nan")
-        nbytes = algorithmic_bytes(dom, S, n_obs, args.width, args.height, args.frames, lap)   # per GPU (one slab)
+        nbytes = algorithmic_bytes(dom, S, n_obs, args.width, args.height, args.frames, lap, pcg_passes=cg_iters + 1.0)   # per GPU (one slab); a solve of n iterations runs n + 1 passes
         # the solve enqueues the previous solve's pass count + 2: the surplus kernels return at once (no-op launches, ~4.7 us) and are part
         # of the sampled average; `avg_working_launch_ms` removes them with the measured ratio passes / launches
         launches_per_step = kernels.get(dom, {}).get("launches_per_iter") if kernels else None
@@ -221,8 +222,8 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms,
                            "launches_timed": int(watched[1]), "avg_working_launch_ms": avg_work_ms, "working_launch_fraction": working_frac,
-                           "bytes_per_unit": "SURVEY 8d algorithmic figure (pcg_pass: 124 B per band voxel per pass; the engine's ELL storage streams 152 B)",
-                           "storage_bytes_per_launch": 152 * S if dom == "pcg_pass" else None,
+                           "bytes_per_unit": "SURVEY 8d algorithmic figure (PCG: 124 B per band voxel per pass; pcg_solve runs cg_iters + 1 passes per launch and keeps the matrix on chip: its HBM-side traffic is far below the algorithmic bytes)",
+                           "storage_bytes_per_launch": 152 * S if dom in ("pcg_pass", "pcg_solve") else None,
                            "traffic_source": traffic_src}
         # whole-iteration algorithmic bytes (SURVEY.md §8d formula) for reference
         U = min(48 * n_obs, 12 * args.width * args.height * args.frames)

@@ -100,6 +100,11 @@ int psgsdf_debug_time_pcg_solve(psgsdf_ctx* c, int passes, int reps, double* ms_
     hipEventDestroy(e0); hipEventDestroy(e1);
     *ms_per_launch = (double)total / reps;
     if (stamps) for (int i = 0; i < 16; ++i) stamps[i] = c->mbox[8 + i];      // pass 8 of the last launch: 7 stage stamps of the first and of the last workgroup (100 MHz ticks)
+    if (const char* dump = getenv("PSGSDF_SOLVE_DUMP")) {   // per-workgroup publish / gather-done / sums-seen times (tools/pcg_solve_time.py)
+        std::vector<double> h(5 * 256);
+        HIPCHK(c, hipMemcpy(h.data(), c->pcg_sc + 16, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(dump, "w")) { for (int i = 0; i < G; ++i) fprintf(f, "%d %.0f %.0f %.0f %.0f %.0f\n", i, h[i], h[256 + i], h[512 + i], h[768 + i], h[1024 + i]); fclose(f); }
+    }
     return PSGSDF_OK;
 }
 

@@ -55,6 +55,7 @@ struct Band {
     int* col;                 // [kNQ][Spad] band row of each ELL column offset (absent: the row itself)
     unsigned* colp;           // [9][Spad] the same as 16-bit deltas col - row, columns (2w+1, 2w+2) in word w: half the index bytes of a PCG pass
     int col16;                // 1 if every |col - row| fits 16 bits (then the PCG reads colp instead of col)
+    int reach;                // max |col - row| over the band: how far (in rows) a row's ELL columns reach
     // derived per voxel, refreshed whenever dist / grad change (k_derive)
     float* gfd[3];            // finite-difference gradient (Optimizer.cpp:287-364), un-normalised
     float4* vp[3];            // derived state, packed because the frame-major sweeps GATHER it per observation and are bound by L1 line

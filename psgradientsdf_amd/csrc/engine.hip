@@ -225,7 +225,7 @@ int build_band(psgsdf_ctx* c) {
         int reach = 0;
         HIPCHK(c, hipMemcpyAsync(&reach, c->d_total, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        b.col16 = reach <= 32767;
+        b.col16 = reach <= 32767; b.reach = reach;
         if (const char* e = getenv("PSGSDF_PCG_COL16")) if (atoi(e) == 0) b.col16 = 0;
     }
     if (c->areg_mem) { hipFree(c->areg_mem); c->areg_mem = nullptr; c->ar = AlbedoReg{}; }

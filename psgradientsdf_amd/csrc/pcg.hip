@@ -328,10 +328,13 @@ void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int ro
 //             granules {sum with a 2-bit pass tag in its two lowest mantissa bits}, one sc1 store each: data and tag arrive
 //             together, no flag, no ordering between the seven.  (Plain stores + an agent-scope release fence measured 4.8 us
 //             for drain + write-back per pass; profiles/r02_notes.md.)
-//   wait    : thread t polls the seven granules of workgroup t (relaxed agent-scope loads) until their tags name the pass;
-//             __syncthreads; lane 0 agent-scope acquire; __syncthreads; the fixed-order sum over workgroups every workgroup
-//             computes identically -> alpha, beta, |r|^2 and the stop decision are the same everywhere, so all workgroups leave
-//             in the same pass.  The records double-buffer exactly as in k_cgf_pass; one barrier per pass covers both hazards.
+//   wait    : in two steps.  The gathers only need the records of the few workgroups that are this one's neighbours in band order,
+//             and -- t = A1 - alpha A2 + beta A3 -- neither alpha nor beta: a few threads poll those neighbours' tags, lane 0 does an
+//             agent-scope acquire, and the gathers run while the sums of the far workgroups are still on their way.  Then thread t
+//             polls the seven granules of workgroup t until their tags name the pass, and the fixed-order sum over workgroups that
+//             every workgroup computes identically gives alpha, beta, |r|^2 and the stop decision -- the same everywhere, so all
+//             workgroups leave in the same pass.  The records double-buffer exactly as in k_cgf_pass: a workgroup writes its pass-k
+//             records only after it has seen EVERY workgroup's pass k-1 sums, i.e. after every reader of the old ones is done.
 // One workgroup of 512 threads per CU at most (grid <= the CU count, so all workgroups are co-resident); logical workgroup ids
 // are remapped so that every XCD owns a contiguous range of rows (gathers stay in that XCD's L2).  Every wait is bounded:
 // a workgroup that sees nothing for ~1 s raises the abort flag and every workgroup leaves (the host reports PSGSDF_ERR_DEVICE).
@@ -399,18 +402,72 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
     float alpha_prev = 0.f, beta = 0.f, rr_cur = rhsNorm2;
     if (lb == 0 && tid == 0) fs[0] = bb;
     int k = 0, status = 1;                    // status 1 = finished, 2 = a wait timed out
+    // The workgroups whose records this one gathers from: rows within `reach` of its own range (a handful of neighbours in band order).
+    const int first = lb * rows_per_wg, last = first + rows_per_wg - 1;                    // (relative to row0)
+    const int nlo = max(0, (first - b.reach) / rows_per_wg), nhi = min(G - 1, (last + b.reach) / rows_per_wg);
     // stage timestamps of pass 8 (timing hook only: force_passes > 0), wall clock at 100 MHz, written by thread 0 of two workgroups
-#define SOLVE_STAMP(j) do { if (force_passes > 0 && k == 8 && tid == 0 && (lb == 0 || lb == G - 1)) mb[8 + (lb ? 8 : 0) + (j)] = (double)wall_clock64(); } while (0)
+#define SOLVE_STAMP(j) do { if (force_passes > 0 && k == 8 && tid == 0 && (lb == 0 || lb == (G * 9) / 16)) mb[8 + (lb ? 8 : 0) + (j)] = (double)wall_clock64(); } while (0)
     for (;; ++k) {
         SOLVE_STAMP(0);
+        const unsigned want = (unsigned)k & 3u;            // tag of pass k-1 = ((k-1) + 1) & 3
+        const double* gp = gran + (size_t)((k - 1) & 1) * kCgfSums * kSolveMaxBlocks;
         if (k > 0) {
-            // ---- meet the other workgroups: the seven sums of pass k-1 of every workgroup
-            const unsigned want = (unsigned)k & 3u;            // tag of pass k-1 = ((k-1) + 1) & 3
-            const double* gp = gran + (size_t)((k - 1) & 1) * kCgfSums * kSolveMaxBlocks;
+            // ---- A: the records this workgroup gathers from are those of its NEIGHBOURS in band order: wait for their pass k-1 only (the tag
+            // of a workgroup's first sum is stored after its records have drained), not for the whole device
+            if (tid == 0) s_abort = 0;
+            __syncthreads();
+            if (tid <= nhi - nlo) {
+                int spins = 0;
+                while (gran_tag_of(__hip_atomic_load(gp + nlo + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
+                }
+            }
+            __syncthreads();
+            if (s_abort) { if (tid == 0) __hip_atomic_store(fs + 3, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); status = 2; break; }
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+        }
+        SOLVE_STAMP(1);
+        // ---- B: t = A p_k is linear in the gathered fields (A1 - alpha A2 + beta A3): the gathers run BEFORE alpha and beta exist, i.e.
+        // while the sums of the far workgroups are still on their way
+        const float4* __restrict__ rin = b.rec[(k + 1) & 1];
+        float4* __restrict__ rout = b.rec[k & 1];
+        double A1[R], A2[R], A3[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const float* hrow = hs + (size_t)u * kNQ * kSolveThreads + tid;
+            double a1, a2, a3;
+            { const double hq = (double)hrow[0], iv = (double)me[u].w; a1 = hq * (iv * (double)me[u].x); a2 = hq * (iv * (double)me[u].y); a3 = hq * (double)me[u].z; }
+            // the 18 neighbour records in two batches of 9 (36 registers in flight instead of 72): the second is issued before the first is consumed
+            float4 o0[9], o1[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) { const int pk = (int)cp[u][j >> 1]; o0[j] = rin[row[u] + ((j & 1) ? (pk >> 16) : ((pk << 16) >> 16))]; }
+#pragma unroll
+            for (int j = 9; j < 18; ++j) { const int pk = (int)cp[u][j >> 1]; o1[j - 9] = rin[row[u] + ((j & 1) ? (pk >> 16) : ((pk << 16) >> 16))]; }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const double hq = (double)hrow[(j + 1) * kSolveThreads], iv = (double)o0[j].w;
+                a1 += hq * (iv * (double)o0[j].x); a2 += hq * (iv * (double)o0[j].y); a3 += hq * (double)o0[j].z;
+            }
+#pragma unroll
+            for (int j = 9; j < 18; ++j) {
+                const double hq = (double)hrow[(j + 1) * kSolveThreads], iv = (double)o1[j - 9].w;
+                a1 += hq * (iv * (double)o1[j - 9].x); a2 += hq * (iv * (double)o1[j - 9].y); a3 += hq * (double)o1[j - 9].z;
+            }
+            asm volatile("" : "+v"(a1), "+v"(a2), "+v"(a3));      // the three sums exist HERE: without this the compiler sinks the consumption of the
+            A1[u] = a1; A2[u] = a2; A3[u] = a3;                    // 18 gathered records below the wait for the global sums (72 registers live across it)
+            __builtin_amdgcn_sched_barrier(0);      // one row's 18 gathers in flight at a time (register budget)
+        }
+        SOLVE_STAMP(2);
+        if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 1024 + lb] = (double)wall_clock64();            // gathers of pass 9 done
+        if (k > 0) {
+            // ---- C: the seven sums of pass k-1 of EVERY workgroup (data and tag in one granule: no fence needed for them)
+            // (requesting these granules ahead of time, next to the gathers, measured SLOWER: the sc1 loads queue in front of / behind the
+            // records and lengthen the gather stage by 1.5-2 us; profiles/r02_notes.md)
             double v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = 0.0;
-            if (tid == 0) s_abort = 0;
             if (tid < G) {
                 int spins = 0; bool ok = false;
                 while (!ok) {
@@ -418,18 +475,15 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
 #pragma unroll
                     for (int q = 0; q < kCgfSums; ++q) { v[q] = __hip_atomic_load(gp + (size_t)q * kSolveMaxBlocks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = ok && gran_tag_of(v[q]) == want; }
                     if (!ok) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1 << 21) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
                     }
                 }
             }
-            __syncthreads();
-            SOLVE_STAMP(1);
-            if (s_abort) { if (tid == 0) __hip_atomic_store(fs + 3, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); status = 2; break; }
-            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             double t0, t1; wave_sum8(v, t0, t1);
             wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
             __syncthreads();
+            if (s_abort) { if (tid == 0) __hip_atomic_store(fs + 3, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); status = 2; break; }
             double t[kCgfSums];
 #pragma unroll
             for (int q = 0; q < kCgfSums; ++q) { double s_ = 0; for (int i = 0; i < kSolveThreads / 64; ++i) s_ += red[q * (kSolveThreads / 64) + i]; t[q] = s_; }
@@ -440,13 +494,14 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             const float rz_cur = (float)(t[5] - 2.0 * al * t[1] + al * al * t[2]);
             rr_cur = (float)(t[6] - 2.0 * al * t[3] + al * al * t[4]);
             beta = rz_cur / rz_old;
-            SOLVE_STAMP(2);
+            if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 256 + lb] = (double)wall_clock64();         // ... and when it had the sums of pass 8 of all the others
+            if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 768 + lb] = (double)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // XCC_ID
         }
+        if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 512 + lb] = (double)wall_clock64();
+        SOLVE_STAMP(3);
         const bool rhs_zero = rhsNorm2 == 0.f;
         const bool stop = force_passes > 0 ? k >= force_passes : (rhs_zero || k == kmax || (k > 0 && rr_cur < thr));
-        // ---- finish pass k-1 for the own rows; run pass k
-        const float4* __restrict__ rin = b.rec[(k + 1) & 1];
-        float4* __restrict__ rout = b.rec[k & 1];
+        // ---- D: finish pass k-1 for the own rows; pass k
         double s[kCgfSums];
 #pragma unroll
         for (int q = 0; q < kCgfSums; ++q) s[q] = 0;
@@ -454,26 +509,10 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         for (int u = 0; u < R; ++u) {
             if (k > 0) x[u] = x[u] + alpha_prev * me[u].z;
             if (stop) continue;
-            // the 18 neighbour records of the previous pass (own column from registers)
-            float4 o[kNQ - 1];
-#pragma unroll
-            for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) {
-                const int pk = (int)cp[u][wd];
-                o[2 * wd] = rin[row[u] + ((pk << 16) >> 16)];
-                o[2 * wd + 1] = rin[row[u] + (pk >> 16)];
-            }
-            double A1, A2, A3;
-            const float* hrow = hs + (size_t)u * kNQ * kSolveThreads + tid;
-            { const double hq = (double)hrow[0], iv = (double)me[u].w; A1 = hq * (iv * (double)me[u].x); A2 = hq * (iv * (double)me[u].y); A3 = hq * (double)me[u].z; }
-#pragma unroll
-            for (int q = 1; q < kNQ; ++q) {
-                const double hq = (double)hrow[q * kSolveThreads], iv = (double)o[q - 1].w;
-                A1 += hq * (iv * (double)o[q - 1].x); A2 += hq * (iv * (double)o[q - 1].y); A3 += hq * (double)o[q - 1].z;
-            }
             const float r_i = me[u].x - alpha_prev * me[u].y;
             const float z_i = me[u].w * r_i;
             const float p_i = z_i + beta * me[u].z;
-            const float tt = (float)(A1 - (double)alpha_prev * A2 + (double)beta * A3);
+            const float tt = (float)(A1[u] - (double)alpha_prev * A2[u] + (double)beta * A3[u]);
             me[u] = make_float4(r_i, tt, p_i, me[u].w);
             if (live[u]) {
                 store16_sc1(rout + row[u], me[u]);
@@ -481,11 +520,10 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
                 s[0] += (double)p_i * td; s[1] += iv * rd * td; s[2] += iv * td * td; s[3] += rd * td; s[4] += td * td;
                 s[5] += rd * (double)z_i; s[6] += rd * rd;
             }
-            __builtin_amdgcn_sched_barrier(0);      // one row's 18 gathers in flight at a time (register budget)
         }
         if (stop) break;
-        SOLVE_STAMP(3);
-        // ---- publish: records first (release), then the seven tagged sums
+        SOLVE_STAMP(4);
+        // ---- E: publish: the records have to be out (write-through, drained) before the seven tagged sums
         double sv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) sv[q] = q < kCgfSums ? s[q] : 0.0;
@@ -493,16 +531,16 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
         __syncthreads();
-        SOLVE_STAMP(4);      // (every wave drained its write-through record stores before the barrier: nothing left to release)
         SOLVE_STAMP(5);
         if (tid < kCgfSums) {
             double tot = 0;
             for (int i = 0; i < kSolveThreads / 64; ++i) tot += red[tid * (kSolveThreads / 64) + i];
-            double* gp = gran + (size_t)(k & 1) * kCgfSums * kSolveMaxBlocks + (size_t)tid * kSolveMaxBlocks + lb;
-            __hip_atomic_store(gp, gran_tag(tot, (unsigned)(k + 1) & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double* gq = gran + (size_t)(k & 1) * kCgfSums * kSolveMaxBlocks + (size_t)tid * kSolveMaxBlocks + lb;
+            __hip_atomic_store(gq, gran_tag(tot, (unsigned)(k + 1) & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         SOLVE_STAMP(6);
+        if (force_passes > 0 && k == 8 && tid == 0) fs[16 + lb] = (double)wall_clock64();                 // timing hook: when every workgroup published pass 8 ...
     }
 #undef SOLVE_STAMP
     // ---- leave: x of the own rows; the outcome for the host and for the gated kernels behind this one
