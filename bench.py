@@ -215,7 +215,7 @@ def main():
         if os.path.exists(pmc) and (args.grid, args.frames, args.model, world) == (256, 50, "SH1", 1):   # the counters were collected on this configuration
             try:
                 pj = json.load(open(pmc))
-                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+                traffic = (pj.get(dom) or {}).get("hbm_bytes_per_launch")
                 traffic_src = f"static: profiles/pmc_summary.json @{pj.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 (gfx950), KiB -> bytes); not re-measured in this run"
             except Exception:
                 traffic = None

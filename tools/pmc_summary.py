@@ -8,7 +8,7 @@ KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled; WRIT
 import csv, json, re, sys
 from collections import defaultdict
 
-NAMES = {"k_cgf_pass": "pcg_pass", "k_cgf_init": "pcg_init", "k_sweep_dist": "sweep_dist", "k_sweep_pose": "sweep_pose",
+NAMES = {"k_cgf_solve": "pcg_solve", "k_cgf_pass": "pcg_pass", "k_cgf_init": "pcg_init", "k_sweep_dist": "sweep_dist", "k_sweep_pose": "sweep_pose",
          "k_sweep_light": "sweep_light", "k_sweep_albedo": "sweep_albedo", "k_energy": "energy", "k_assemble": "assemble",
          "k_derive": "derive", "k_apply_albedo": "apply_albedo", "k_apply_dist": "apply_dist"}
 
@@ -28,9 +28,13 @@ def load(path, counter):
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(set(fetch) | set(write)):
+    if not fetch[k] and not write[k]:
+        continue
     f = sum(fetch[k]) / max(len(fetch[k]), 1); w = sum(write[k]) / max(len(write[k]), 1)
     out[k] = {"launches": len(fetch[k]), "fetch_size_kib_raw": f, "write_size_kib_raw": w,
               "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
               "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes; Infinity-Cache hits are counted"}
+import os
+out["commit"] = os.environ.get("PSGSDF_COMMIT", "?")
 json.dump(out, sys.stdout, indent=1)
 print()
