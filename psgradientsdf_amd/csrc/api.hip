@@ -53,7 +53,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     free_dense(c);
     hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->led_light);
     hipFree(c->band_mem); hipFree(c->obs_mem); hipFree(c->stage);
-    hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->pcg_gran); hipFree(c->d_total);
+    hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->frame_part); hipFree(c->frame_done); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->pcg_gran); hipFree(c->d_total);
     if (c->host_buf) hipHostFree(c->host_buf);
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
@@ -151,7 +151,7 @@ static int set_keyframes_impl(psgsdf_ctx* c, int n_frames, const int32_t* frame_
     HIPCHK(c, hipMalloc(&c->frames, sizeof(FrameP) * n_frames));
     c->acc_frame_n = (size_t)n_frames * 64;
     HIPCHK(c, hipMalloc(&c->acc_frame, sizeof(double) * c->acc_frame_n));
-    HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));   // invariant: zero outside [sweep, solve]
+    HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->frame_idx, frame_idx, sizeof(int) * n_frames, hipMemcpyHostToDevice, c->stream));
     if (rgb_f32) {
         HIPCHK(c, hipMalloc(&c->img, sizeof(float) * npix * 3));

@@ -127,16 +127,16 @@ int psgsdf_debug_rare_rows(psgsdf_ctx* c, int64_t* rows, int64_t* waves) {
 int psgsdf_debug_frame_system(psgsdf_ctx* c, int block, double* H, double* b) {
     if (!c || !c->inited || !H || !b) return fail(c, PSGSDF_ERR_STATE, "init first");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
     SweepArgs a = make_args(c, 0);
     const bool led = c->set.model == PSGSDF_LED;
     int n, nb, nh;
-    if (block == PSGSDF_LIGHT) { launch_sweep_light(a, c->stream); n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4); nb = led ? 1 : c->F; nh = led ? 3 : n * (n + 1) / 2; }
-    else if (block == PSGSDF_POSE) { launch_sweep_pose(a, c->stream); n = 6; nb = c->F; nh = 21; }
+    int launched = 0;
+    if (block == PSGSDF_LIGHT) { launched = launch_sweep_light(a, c->stream); n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4); nb = led ? 1 : c->F; nh = led ? 3 : n * (n + 1) / 2; }
+    else if (block == PSGSDF_POSE) { launched = launch_sweep_pose(a, c->stream); n = 6; nb = c->F; nh = 21; }
     else return fail(c, PSGSDF_ERR_ARG, "block must be LIGHT or POSE");
+    if (!launched) HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
     std::vector<double> acc(c->acc_frame_n);
     HIPCHK(c, hipMemcpyAsync(acc.data(), c->acc_frame, sizeof(double) * c->acc_frame_n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (led && block == PSGSDF_LIGHT) {   // one global system: sum the per-frame rows
         for (int i = 0; i < 9; ++i) H[i] = 0;

@@ -82,6 +82,11 @@ struct Accum {
     double* frame;            // [F][kFrameRow] per-frame rows: H (upper triangle) | rhs | energy | n_obs
     double* part;             // [SC_COUNT][PB] per-workgroup partials of the scalar reductions
     int PB;                   // capacity (workgroups) of one partial slot
+    // frame-major sweeps: every workgroup stores ITS partial row (no floating-point atomics) and the last workgroup of a frame to arrive
+    // sums them in launch order into `frame` (sweeps.hip: frame_rows_publish): the rows are run-to-run reproducible
+    double* fpart;            // [F][fcap][kFrameRow]
+    int fcap;                 // capacity (workgroups per frame)
+    int* fdone;               // [F] arrival counters, zero outside a sweep
 };
 constexpr int kFrameRow = 64;        // doubles per frame accumulator row (SH2: 45 + 9 + 2 = 56)
 constexpr int kPcgMaxBlocks = 2048;  // workgroups of one PCG pass (grid-stride)
@@ -163,8 +168,8 @@ void launch_led_light_init(const SweepArgs& a, hipStream_t s);
 void launch_energy(const SweepArgs& a, hipStream_t s);
 void launch_sweep_albedo(const SweepArgs& a, hipStream_t s);
 void launch_apply_albedo(const SweepArgs& a, hipStream_t s);
-void launch_sweep_light(const SweepArgs& a, hipStream_t s);
-void launch_sweep_pose(const SweepArgs& a, hipStream_t s);
+int launch_sweep_light(const SweepArgs& a, hipStream_t s);    // both return the workgroups per frame they used (0: nothing was launched, the rows are untouched)
+int launch_sweep_pose(const SweepArgs& a, hipStream_t s);
 void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, hipStream_t s);   // also sums the energy columns -> e_out (nullable) and clears the rows
 void launch_solve_pose(const SweepArgs& a, FrameP* frames, double* e_out, hipStream_t s);
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s);

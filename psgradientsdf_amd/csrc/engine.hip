@@ -39,6 +39,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.im.idx32 = (size_t)c->F * c->cam.W * c->cam.H * 12 < ((size_t)1 << 32);
     a.rob.loss = c->set.loss; a.rob.lambda = c->set.lambda; a.rob.lambda_sq = c->set.lambda * c->set.lambda; a.rob.inv_lambda = 1.0f / c->set.lambda;
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
+    a.acc.fpart = c->frame_part; a.acc.fcap = c->frame_cap; a.acc.fdone = c->frame_done;
     a.fold.n = 0; a.gate = nullptr; a.fuse_apply = 0;
     a.pcg_part = c->pcg_part; a.pcg_fs = c->pcg_sc; a.pcg_fuse_init = 0; a.pcg_init_blocks = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0;
     a.ar = c->ar; a.ar.weight = c->reg_r;
@@ -293,6 +294,15 @@ int build_band(psgsdf_ctx* c) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             hipFree(d_counts);
         }
+    }
+    {   // partial rows of the frame-major sweeps: one per workgroup and frame; a sweep uses at most ceil(obs_max / (256 * 4)) workgroups per frame
+        if (c->frame_part) { hipFree(c->frame_part); c->frame_part = nullptr; }
+        if (c->frame_done) { hipFree(c->frame_done); c->frame_done = nullptr; }
+        c->frame_cap = (b.obs_max + kBlock * 4 - 1) / (kBlock * 4) + 1;
+        const int F = std::max(c->F, 1);
+        HIPCHK(c, hipMalloc(&c->frame_part, sizeof(double) * (size_t)F * c->frame_cap * kFrameRow));
+        HIPCHK(c, hipMalloc(&c->frame_done, sizeof(int) * F));
+        HIPCHK(c, hipMemsetAsync(c->frame_done, 0, sizeof(int) * F, c->stream));
     }
     if (c->part) { hipFree(c->part); c->part = nullptr; }
     c->PB = Spad / kBlock + 1;

@@ -62,6 +62,8 @@ struct psgsdf_ctx {
     bool inited = false;
     // accumulators
     double* acc_frame = nullptr; size_t acc_frame_n = 0;
+    double* frame_part = nullptr; int frame_cap = 0;   // [F][frame_cap][kFrameRow] per-workgroup partial rows of the frame-major sweeps
+    int* frame_done = nullptr;                         // [F] arrival counters
     double* part = nullptr; int PB = 0;  // [SC_COUNT][PB] per-workgroup partials
     double* pcg_sc = nullptr; int pcg_cap = 4096;
     double* pcg_part = nullptr;          // [2][7][kPcgMaxBlocks]

@@ -222,13 +222,14 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
             break;
         }
         case PSGSDF_LIGHT: case PSGSDF_POSE: {
-            int col;   // the frame accumulator is all-zero here: whoever consumed it last cleared it (sweeps.hip: frame_rows_finish)
+            int col, launched = 0;
             if (block == PSGSDF_LIGHT) {
                 take_fold(c, a, 0u);
-                timed(c, "sweep_light", [&] { launch_sweep_light(a, c->stream); });
+                timed(c, "sweep_light", [&] { launched = launch_sweep_light(a, c->stream); });
                 const int n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4), nh = led ? 3 : n * (n + 1) / 2;
                 col = nh + n;
-            } else { take_fold(c, a, 0u); timed(c, "sweep_pose", [&] { launch_sweep_pose(a, c->stream); }); col = 27; }
+            } else { take_fold(c, a, 0u); timed(c, "sweep_pose", [&] { launched = launch_sweep_pose(a, c->stream); }); col = 27; }
+            if (!launched) HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));   // no observations at all: empty rows, not the previous sweep's
             // multi-rank: every slab has summed its own observations into the per-frame rows; after the all-reduce every rank holds the
             // global normal equations and solves all F (tiny) systems itself
             if ((rc = comm_allreduce(c, c->acc_frame, c->F * kFrameRow))) return rc;
@@ -405,7 +406,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
                 have_prev = false;
                 if ((rc = finalize(prev, iter - 1))) return rc;
                 if (stop) {        // converged / diverged / aborted: nothing of this iteration has been applied
-                    if (blk == PSGSDF_LIGHT || blk == PSGSDF_POSE) launch_zero_f64(c->acc_frame, (int)c->acc_frame_n, c->stream);   // the sweep's rows stay unconsumed
+                    // (a frame-major sweep's rows stay unconsumed: nothing to clean up, the next sweep overwrites them)
                     break;
                 }
             } else {

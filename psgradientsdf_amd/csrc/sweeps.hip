@@ -177,12 +177,48 @@ void launch_apply_albedo(const SweepArgs& a, hipStream_t s) {
 // are VALU-bound per SIMD, so the grid should fill the resident workgroup slots of the chip evenly in ONE generation; a fixed 16
 // left 13 % of the pose sweep's workgroups for a second, nearly empty generation (fm_rows below).
 static int fm_rows(const SweepArgs& a, int slots_per_cu) {
-    if (const char* e = getenv("PSGSDF_FM_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 256) return v; }   // tuning knob
+    if (const char* e = getenv("PSGSDF_FM_ROWS")) { int v = atoi(e); if (v >= 4 && v <= 256) return v; }   // tuning knob (>= 4: the partial-row buffer is sized for that)
     const long long total = a.b.obs_ptr_total > 0 ? a.b.obs_ptr_total : (long long)a.b.obs_max * a.F;
     const long long slots = 256LL * slots_per_cu;                       // resident workgroups on the chip
     // every frame wastes half a chunk on average: aim at ~92 % of the slots
     long long r = (total + (long long)(0.92 * slots) * kBlock - 1) / ((long long)(0.92 * slots) * kBlock);
     return (int)std::min<long long>(std::max<long long>(r, 4), 64);
+}
+
+// Epilogue of the frame-major sweeps: every workgroup stores ITS partial row of frame f (plain stores, no floating-point atomics) and
+// takes a ticket on the frame's arrival counter; the LAST workgroup of the frame to arrive sums the frame's partial rows in launch order
+// into the final row -- reproducible from run to run, and done while the other frames' workgroups are still sweeping.
+template <int NV>
+__device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int f, const double* lds /*[kBlock/64][NV] wavefront sums*/) {
+    // Hand-off without fences (an agent-scope release fence in every workgroup's tail writes back the XCD's L2 each time: light sweep
+    // 46 -> 82 us): the row goes out with write-through (sc1) stores, the wave drains them, then takes the ticket; the last arriver reads
+    // the rows with sc1 loads (MI355X_MICROARCH.md: "sc1 payload -> vmcnt(0) -> sc1 flag", "sc1 loads may replace the acquire").
+    __shared__ int s_last;
+    double* dst = a.acc.fpart + ((size_t)f * a.acc.fcap + blockIdx.x) * kFrameRow;
+    if (threadIdx.x < NV) {                      // (NV <= 64: all in wavefront 0, whose lane 0 takes the ticket below)
+        double s = 0;
+        for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + threadIdx.x];
+        __hip_atomic_store(dst + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(a.acc.fdone + f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(a.acc.fdone + f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < NV) {
+        const double* p = a.acc.fpart + (size_t)f * a.acc.fcap * kFrameRow + threadIdx.x;
+        double s = 0;
+        for (int c = 0; c < (int)gridDim.x; c += 16) {          // 16 loads in flight, added in launch order
+            double v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = c + j < (int)gridDim.x ? __hip_atomic_load(p + (size_t)(c + j) * kFrameRow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s += v[j];
+        }
+        a.acc.frame[(size_t)f * kFrameRow + threadIdx.x] = s;
+    }
 }
 
 // light normal equations: lightJacobian PsOptimizerJa.cpp:132-143,323-371 (per frame NBxNB),
@@ -255,24 +291,19 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
         }
         acc[NH + NB] += l; acc[NH + NB + 1] += 1.0f;
     }
-    // one atomic per value per workgroup into THIS frame's row (<= S/2048 workgroups contend per address);
     // row layout: [NH H entries | NB rhs | energy | n_obs]
-    double* dst = a.acc.frame + (size_t)f * kFrameRow;
     const int w = threadIdx.x >> 6;
     wave_sums_to<NV>(acc, lds + w * NV);   // double: SH2 light blocks are ill-conditioned
     __syncthreads();
-    for (int k = threadIdx.x; k < NV; k += blockDim.x) {
-        double s = 0;
-        for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + k];
-        if (s != 0.0) atomicAdd(dst + k, s);
-    }
+    frame_rows_publish<NV>(a, f, lds);
 }
-void launch_sweep_light(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return;
+int launch_sweep_light(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return 0;
     const int rows = fm_rows(a, a.model == 1 ? 3 : 5);           // resident workgroups per CU at this kernel's register count
     const int chunk = kBlock * rows;
     dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
     PSG_LAUNCH_SWEEP(k_sweep_light, a, true, g, bl, 0, s, a, rows);
+    return (int)g.x;
 }
 
 // pose normal equations: poseJacobian PsOptimizerJa.cpp:61-115,427-475 / LedOptimizerJa.cpp:32-81,351-399
@@ -358,26 +389,22 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
         }
         acc[27] += l; acc[28] += 1.0f;
     }
-    double* dst = a.acc.frame + (size_t)f * kFrameRow;   // [21 H | 6 rhs | energy | n_obs]
     const int w = threadIdx.x >> 6;
-    wave_sums_to<NV>(acc, lds + w * NV);   // double: SH2 light blocks are ill-conditioned
+    wave_sums_to<NV>(acc, lds + w * NV);   // row layout: [21 H | 6 rhs | energy | n_obs]
     __syncthreads();
-    for (int k = threadIdx.x; k < NV; k += blockDim.x) {
-        double s = 0;
-        for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + k];
-        if (s != 0.0) atomicAdd(dst + k, s);
-    }
+    frame_rows_publish<NV>(a, f, lds);
 }
-void launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return;
+int launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
+    if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return 0;
     const int rows = fm_rows(a, 4);
     const int chunk = kBlock * rows;
     dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
     PSG_LAUNCH_SWEEP(k_sweep_pose, a, true, g, bl, 0, s, a, rows);
+    return (int)g.x;
 }
 
 // ------------------------------------------------------------------------------------------
-// small dense solves (one thread per frame): LDL^T in double, zero step on non-positive pivots
+// small dense solves: LDL^T in double, zero step on non-positive pivots
 // ------------------------------------------------------------------------------------------
 template <int N>
 __device__ void solve_spd(const double* Hin, const double* bin, double* x) {
@@ -401,10 +428,9 @@ __device__ void solve_spd(const double* Hin, const double* bin, double* x) {
     for (int i = N - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k]; x[i] = s; }
 }
 
-// The per-frame solves run as ONE workgroup (a thread takes frames tid, tid+256, ...), which lets the same kernel do
-// what used to be two more launches around every frame-major sweep: sum the energy / n_obs columns of the rows
-// (e_out, may be host-mapped) and clear the rows for the next sweep.  Invariant: the frame accumulator is all-zero
-// outside [sweep, solve].
+// The per-frame solves run as ONE workgroup (a thread takes frames tid, tid+256, ...), which lets the same kernel also sum the
+// energy / n_obs columns of the rows over the frames (e_out, may be host-mapped) in a fixed order.  The rows are final when it runs:
+// the last workgroup of every frame of the sweep has summed that frame's partial rows (frame_rows_publish).
 __device__ __forceinline__ void frame_rows_finish(const SweepArgs& a, int col_e, double* e_out, double* red) {
     __syncthreads();                                       // every thread has read the rows it solves from
     if (e_out) {
@@ -417,7 +443,6 @@ __device__ __forceinline__ void frame_rows_finish(const SweepArgs& a, int col_e,
         if (threadIdx.x == 0) { double te = 0, tn = 0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { te += red[2 * i]; tn += red[2 * i + 1]; } e_out[0] = te; e_out[1] = tn; }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < a.F * kFrameRow; i += blockDim.x) a.acc.frame[i] = 0.0;
 }
 
 // optimizeLightAll: PsOptimizer.cpp:175-203 (no damping) / LedOptimizer.cpp:134-160 (damped, one RGB vector)

@@ -158,7 +158,7 @@ def test_8bit_keyframes(built, name, mid):
         He, be = eng.debug_frame_system(blk); Ho, bo = orc.debug_frame_system(blk)
         assert relmax(He, Ho) < 2e-5 and relmax(be, bo) < 2e-5, (name, blk)
     re_, rf, ro = eng.iterate(capi.ALL, 2), engf.iterate(capi.ALL, 2), orc.iterate(capi.ALL, 2)
-    # the two engine paths sample identical floats; what remains is the summation order of the per-frame double atomics
+    # the two engine paths sample identical floats and sum them in the same fixed order
     assert np.allclose([r["e_total"] for r in re_], [r["e_total"] for r in rf], rtol=1e-4 if name == "SH2" else 1e-6) and [r["cg_iters"] for r in re_] == [r["cg_iters"] for r in rf]
     band = eng.download_band(); vs = float(sc.voxel_size)
     ve, vf, vo = eng.download_volume(), engf.download_volume(), orc.download_volume()
