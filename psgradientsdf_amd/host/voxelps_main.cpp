@@ -53,16 +53,33 @@ static int selftest_mc() {
     std::vector<float> t(24 * 24 * 24), w(t.size(), 1.f); std::vector<unsigned char> col(t.size() + 2, 128);
     for (int k = 0; k < 24; ++k) for (int j = 0; j < 24; ++j) for (int i = 0; i < 24; ++i) { float dx = i - 11.3f, dy = j - 11.7f, dz = k - 11.1f; t[(k * 24 + j) * 24 + i] = 7.2f - std::sqrt(dx * dx + dy * dy + dz * dz); }
     mc.computeIsoSurface(t.data(), w.data(), col.data(), col.data(), col.data());
-    double vol = 0, maxr = 0, minr = 1e9; auto& v = mc.vertices();
-    for (size_t f = 0; f + 2 < v.size(); f += 3) { const auto &a = v[f], &b = v[f + 1], &c = v[f + 2];
+    // closedness by the divergence theorem: the signed volume must not depend on the origin it is taken from, and the area vectors sum to 0
+    double vol = 0, vol2 = 0, area = 0, asum[3] = {0, 0, 0}, maxr = 0, minr = 1e9; auto& v = mc.vertices();
+    const double o2[3] = {40.5, -17.25, 3.125};
+    for (size_t f = 0; f + 2 < v.size(); f += 3) {
+        double a[3], b[3], c[3], a2[3], b2[3], c2[3];
+        for (int q = 0; q < 3; ++q) { a[q] = v[f][q]; b[q] = v[f + 1][q]; c[q] = v[f + 2][q]; a2[q] = a[q] - o2[q]; b2[q] = b[q] - o2[q]; c2[q] = c[q] - o2[q]; }
         vol += (a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0])) / 6.0;
+        vol2 += (a2[0] * (b2[1] * c2[2] - b2[2] * c2[1]) - a2[1] * (b2[0] * c2[2] - b2[2] * c2[0]) + a2[2] * (b2[0] * c2[1] - b2[1] * c2[0])) / 6.0;
+        double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, w2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+        double n[3] = {u[1] * w2[2] - u[2] * w2[1], u[2] * w2[0] - u[0] * w2[2], u[0] * w2[1] - u[1] * w2[0]};
+        area += 0.5 * std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]); for (int q = 0; q < 3; ++q) asum[q] += 0.5 * n[q];
         for (int q = 0; q < 3; ++q) { double r = std::sqrt(std::pow(v[f + q][0] - 11.3, 2) + std::pow(v[f + q][1] - 11.7, 2) + std::pow(v[f + q][2] - 11.1, 2)); maxr = std::max(maxr, r); minr = std::min(minr, r); } }
-    std::cout << ntri << " " << mc.num_faces() << " " << vol << " " << minr << " " << maxr << std::endl; return 0;
+    std::cout.precision(12);
+    std::cout << ntri << " " << mc.num_faces() << " " << vol << " " << minr << " " << maxr << " " << vol2 << " " << area << " " << std::sqrt(asum[0] * asum[0] + asum[1] * asum[1] + asum[2] * asum[2]) << std::endl; return 0;
+}
+// the generated 256-case table, one line per case: `case n_triangles e0 e1 e2 ...` (edge ids of the reference's numbering)
+static int selftest_mc_table() {
+    int dim[3] = {4, 4, 4}; float size[3] = {4, 4, 4}, org[3] = {0, 0, 0};
+    MarchingCubes mc(dim, size, org);
+    for (int c = 0; c < 256; ++c) { std::cout << c << " " << mc.table(c).size() / 3; for (int e : mc.table(c)) std::cout << " " << e; std::cout << "\n"; }
+    return 0;
 }
 
 int main(int argc, char* argv[]) {
     if (argc >= 3 && std::string(argv[1]) == "--selftest-png") return selftest_png(argv[2]);
     if (argc >= 2 && std::string(argv[1]) == "--selftest-mc") return selftest_mc();
+    if (argc >= 2 && std::string(argv[1]) == "--selftest-mc-table") return selftest_mc_table();
     std::string configfile;
     for (int i = 1; i < argc; ++i) { std::string a = argv[i]; if (a == "--config_file" && i + 1 < argc) configfile = argv[++i]; else if (a.rfind("--config_file=", 0) == 0) configfile = a.substr(14); }
     std::cout << "load the config file from: " << configfile << std::endl;
