@@ -22,10 +22,10 @@ void cgf_shape(int nblk, int* G, int* rows) {
 }
 
 // Shape of the persistent solve (pcg.hip: k_cgf_solve): G workgroups of 512 threads, at most one per CU (all co-resident), the band dealt
-// evenly to them (<= 4 rows per thread).  Single-rank contexts only -- a slab needs the other slabs' sums every pass,
+// evenly to them (<= 4 rows per thread).  One rank only -- a slab needs the other slabs' sums every pass,
 // which is the per-pass kernels' all-reduce -- and only with 16-bit column deltas and the assembly kernel's fused initialisation.
 bool cgf_solve_shape(psgsdf_ctx* c, int* G, int* rows_per_wg) {
-    if (!c->pcg_persist || slab_mode(c) || !c->band.col16 || !c->fuse_pcg_init || c->num_cu <= 0 || band_blocks(c) > kPcgMaxBlocks) return false;
+    if (!c->pcg_persist || c->n_ranks > 1 || !c->band.col16 || !c->fuse_pcg_init || c->num_cu <= 0 || band_blocks(c) > kPcgMaxBlocks) return false;
     const int n = c->row1 - c->row0, cap = std::min(c->num_cu, kSolveMaxBlocksHost);
     if (n <= 0) return false;
     // as many workgroups as CUs (in multiples of 8: every XCD owns a contiguous range of rows) unless the band is so small that a workgroup
@@ -58,6 +58,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         // ---- the whole solve as one persistent kernel: nothing for the host to decide until it is over, so the distance update and
         // the regrad are enqueued right behind it (gated on the device-side outcome) and the host only picks up the statistics
         if (c->mbox_used + (size_t)kSolveMbSlots > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+        { int rc = mg_commit(c); if (rc) return rc; }      // (a one-rank communicator: the read-backs staged so far are delivered below)
         const size_t off = c->mbox_used; c->mbox_used += kSolveMbSlots;
         volatile double* st = c->mbox + off;
         st[3] = NAN;
