@@ -8,7 +8,18 @@
  * fixtures for this path, and it cannot be built in this image (Eigen, Sophus, OpenCV,
  * CLI11, nlohmann/json are absent).  This restatement is pinned instead by
  * analytic known-answer tests and by the enabled form of the reference's own disabled
- * numeric-vs-analytic Jacobian diagnostic (PsOptimizerJa.cpp:293-318,514-517) in tests/.
+ * numeric-vs-analytic Jacobian diagnostic (PsOptimizerJa.cpp:293-318,514-517) in tests/
+ * (test_oracle_kat.py, test_oracle_kat2.py: distance / pose / albedo Jacobians incl. the LED
+ * pose block, the Eikonal row, the Laplacian diagonal, the assembled distance system against
+ * an explicit J^T W J, Eigen-CG semantics, SO3::exp, band membership, forward-model KATs).
+ *
+ * Where the HIP engine's arithmetic differs from this file (all far inside
+ * the parity tolerances): observation sums per voxel in float before the double reductions;
+ * block-diagonal light / pose systems solved per block by LDL^T in double instead of one global
+ * Jacobi-PCG; the distance PCG's fused recurrences (one reduction per pass); FMA contraction of
+ * the per-observation algebra; v_rcp_f32 in the Cauchy weight, __logf in the Cauchy loss; float
+ * bilinear weights; out-of-bounds reads of the reference clamped.  NOT a deviation any more:
+ * the Jacobians' second projection fx*px/pz (PsOptimizerJa.cpp:70-76) is reproduced by both.
  *
  * Arithmetic follows the reference: float32 per observation, evaluated in the reference's
  * operation order (no FMA contraction: build with -ffp-contract=off), double only where the
