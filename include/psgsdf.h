@@ -235,19 +235,21 @@ int psgsdf_upload_light(psgsdf_ctx* ctx, const float* light);
 
 /* ---- multi-GPU (z-slab partition, one context per rank, one process per GPU) -------------- */
 
-/* The reference is a single process (main_ps.cpp:41-343) and has no counterpart of this section.  The band, sorted by linear index (z
- * slowest), is cut into n_ranks contiguous row ranges of equal band count, i.e. z-slabs; a context attached to a rank computes only
- * there, and EVERY entry point above keeps its meaning: psgsdf_init / psgsdf_step / psgsdf_iterate / psgsdf_optimize / psgsdf_upsample2x /
- * psgsdf_download_volume become collective calls (all ranks must make them, in the same order) that return the same global energies,
- * counts, poses and lights on every rank.  The exchanges -- all-reduce of the per-frame light / pose rows, of the 7 sums of a PCG pass
- * and of the folded scalars; halo rows of the per-voxel blocks, the PCG records and the distances with the two z-neighbours; an
- * all-gather of the refined band before download / refinement -- are enqueued by the engine itself on its HIP stream.
+/* The reference is a single process (main_ps.cpp:41-343) and has no counterpart of this section.  The volume is cut along z into n_ranks
+ * slabs of (about) equal band count; a context attached to a rank keeps ITS slab (plus one halo plane on each inner side) on its device and
+ * computes only there, and EVERY entry point above keeps its meaning: psgsdf_upload_volume (every rank passes the whole volume and keeps its
+ * slab of it) / psgsdf_init / psgsdf_step / psgsdf_iterate / psgsdf_optimize / psgsdf_upsample2x become collective calls (all ranks make them,
+ * in the same order) that return the same global energies, counts, poses and lights on every rank; psgsdf_get_info reports the whole volume.
+ * psgsdf_download_volume writes the z-planes the rank OWNS into the caller's whole-volume arrays (the slabs tile the volume);
+ * psgsdf_download_band returns the rank's own band voxels (global linear indices).  The exchanges -- all-reduce of the per-frame light /
+ * pose rows, of the 7 sums of a PCG pass and of the folded scalars; halo rows of the per-voxel blocks, the PCG records and the distances
+ * with the two z-neighbours -- are enqueued by the engine itself on its HIP stream.  Frame fusion, normals and the tracker are single-rank.
  *
  *   rank 0:  psgsdf_comm_unique_id(id);  (hand the 128 bytes to the other ranks: file, socket, MPI_Bcast, torch.distributed ...)
  *   all   :  psgsdf_create(.., device, &ctx);  psgsdf_comm_init(ctx, id, rank, n_ranks);  then the usual call sequence.
  */
 int psgsdf_comm_unique_id(uint8_t id[128]);                       /* ncclGetUniqueId; PSGSDF_ERR_COMM if librccl cannot be loaded */
-/* RCCL communicator over xGMI for this context's device (ncclCommInitRank: blocks until all ranks have called).  Before psgsdf_init. */
+/* RCCL communicator over xGMI for this context's device (ncclCommInitRank: blocks until all ranks have called).  Before psgsdf_upload_volume. */
 int psgsdf_comm_init(psgsdf_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
 
 /* The same with a transport supplied by the caller (a host that already owns a communicator: MPI, a test harness).  All pointers are
@@ -259,15 +261,15 @@ typedef struct psgsdf_comm_ops {
     int (*allreduce_f64)(void* user, double* buf_dev, int n, void* hip_stream);                 /* in-place sum over all ranks */
     int (*sendrecv)(void* user, const psgsdf_comm_xfer* sends, int n_sends,
                     const psgsdf_comm_xfer* recvs, int n_recvs, void* hip_stream);              /* with rank-1 / rank+1; matched in list order per peer */
-    int (*allgather)(void* user, void* buf_dev, size_t bytes_per_rank, void* hip_stream);       /* in place: rank r's block lives at buf + r*bytes */
 } psgsdf_comm_ops;
 int psgsdf_comm_init_ext(psgsdf_ctx* ctx, const psgsdf_comm_ops* ops, int rank, int n_ranks);
 
 /* run every launch of this context on a caller-owned HIP stream */
 int psgsdf_set_stream(psgsdf_ctx* ctx, void* hip_stream);
-/* out = { S, Spad, row0, row1, halo, F, rank, n_ranks, need_lo, need_hi }: owned rows [row0,row1); the stencils of the owned rows read
- * the contiguous ranges [row0-need_lo,row0) and [row1,row1+need_hi) of the neighbouring slabs; halo = max(need_lo, need_hi). */
-int psgsdf_mg_info(psgsdf_ctx* ctx, int32_t out[10]);
+/* out = { S (band voxels of the whole volume), band rows this context holds, row0, row1, halo, F, rank, n_ranks, need_lo, need_hi, z0, z1 }:
+ * the context owns the global z-planes [z0, z1) = its band rows [row0, row1); the rows before / behind them are the halo planes
+ * (need_lo / need_hi rows, refreshed from the z-neighbours); halo = max(need_lo, need_hi). */
+int psgsdf_mg_info(psgsdf_ctx* ctx, int32_t out[12]);
 /* collectives + halo exchanges this context has enqueued since it was created */
 int psgsdf_comm_stats(psgsdf_ctx* ctx, int64_t* n_collectives);
 

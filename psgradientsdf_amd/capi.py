@@ -231,19 +231,21 @@ class Api:
     def download_volume(self, want_vis=False):
         i = self.info()
         n = int(i.dim[0]) * int(i.dim[1]) * int(i.dim[2])
-        dist = np.empty(n, np.float32); grad = np.empty((3, n), np.float32)
-        weight = np.empty(n, np.float32); rgb = np.empty((3, n), np.float32)
+        dist = np.full(n, np.nan, np.float32); grad = np.full((3, n), np.nan, np.float32)      # (a slab fills its own planes only)
+        weight = np.full(n, np.nan, np.float32); rgb = np.full((3, n), np.nan, np.float32)
         vis = np.empty((n, i.vis_words), np.uint64) if want_vis else None
         self._check(self._fn("download_volume")(self.ctx, dist.ctypes.data_as(C.c_void_p), grad.ctypes.data_as(C.c_void_p),
                                                  weight.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p),
                                                  vis.ctypes.data_as(C.c_void_p) if want_vis else None), "download_volume")
         return dict(dist=dist, grad=grad, weight=weight, rgb=rgb, vis=vis)
 
-    def download_band(self):
-        i = self.info()
-        b = np.empty(max(i.n_band, 1), np.int32)
+    def download_band(self, n=None):
+        """one rank: the whole band.  A slab of a multi-rank run: pass n = row1 - row0 of mg_info (its own band voxels)"""
+        if n is None:
+            n = self.info().n_band
+        b = np.empty(max(n, 1), np.int32)
         self._check(self._fn("download_band")(self.ctx, b.ctypes.data_as(C.c_void_p)), "download_band")
-        return b[: i.n_band]
+        return b[:n]
 
     def download_poses(self):
         i = self.info()
@@ -284,9 +286,12 @@ class Api:
         self._check(self._fn("set_stream")(self.ctx, C.c_void_p(stream_ptr)), "set_stream")
 
     def mg_info(self):
-        out = (C.c_int32 * 10)()
+        """engine: {S (whole volume), rows held, row0, row1, halo, F, rank, n_ranks, need_lo, need_hi, z0, z1}; the oracle's phase mirror fills
+        the first ten with its own layout ({S, Spad, ...})"""
+        out = (C.c_int32 * 12)()
         self._check(self._fn("mg_info")(self.ctx, out), "mg_info")
-        return dict(zip(["S", "Spad", "row0", "row1", "halo", "F", "rank", "n_ranks", "need_lo", "need_hi"], list(out)))
+        names = ["S", "Spad" if self._p == "orc_" else "rows", "row0", "row1", "halo", "F", "rank", "n_ranks", "need_lo", "need_hi", "z0", "z1"]
+        return dict(zip(names, list(out)))
 
     def mg_buffer(self, which):
         ptr = C.c_void_p(); n = C.c_int64()
@@ -384,12 +389,11 @@ class CommXfer(C.Structure):
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(CommXfer), C.c_int, C.POINTER(CommXfer), C.c_int, C.c_void_p)
-ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 class CommOps(C.Structure):
     """psgsdf_comm_ops: a caller-supplied transport for psgsdf_comm_init_ext"""
-    _fields_ = [("user", C.c_void_p), ("allreduce_f64", ALLREDUCE_FN), ("sendrecv", SENDRECV_FN), ("allgather", ALLGATHER_FN)]
+    _fields_ = [("user", C.c_void_p), ("allreduce_f64", ALLREDUCE_FN), ("sendrecv", SENDRECV_FN)]
 
 
 def comm_unique_id() -> bytes:

@@ -28,7 +28,9 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l; c->reg_r = settings->reg_weight_rho;
     GridP& g = c->grid;
     for (int a = 0; a < 3; ++a) { g.dim[a] = grid->dim[a]; c->shift[a] = grid->shift[a]; }
-    g.nvox = (long long)g.dim[0] * g.dim[1] * g.dim[2];
+    g.nvox = (long long)g.dim[0] * g.dim[1] * g.dim[2]; g.koff = 0;
+    for (int a = 0; a < 3; ++a) c->gdim[a] = g.dim[a];
+    c->gnvox = g.nvox; c->z0 = c->zlo = 0; c->z1 = c->zhi = g.dim[2];
     g.vs = grid->voxel_size; g.vs_inv = 1.f / g.vs; g.T = grid->truncation;
     for (int a = 0; a < 3; ++a) g.origin[a] = c->shift[a] - (float)(0.5 * (double)g.vs) * (float)g.dim[a];   // VoxelGrid.h:130
     c->cam.fx = K[0]; c->cam.fy = K[4]; c->cam.cx = K[2]; c->cam.cy = K[5];
@@ -64,22 +66,61 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     delete c;
 }
 
+// Multi-rank: where to cut the volume into z-slabs of (about) equal band count.  Every rank counts the band candidates (|d| <= sqrt(3) vs and
+// seen in some frame: OptimizerAux.cpp:249 before the keyframes are selected) of ITS share of the z-planes on the host, one all-reduce makes
+// the per-plane histogram global, and every rank takes the same cuts from its prefix sum.
+static int choose_slab(psgsdf_ctx* c, const float* dist, const uint64_t* vis_words, int wpv, int* z0, int* z1) {
+    const int nz = c->gdim[2], n = c->n_ranks;
+    const long long plane = (long long)c->gdim[0] * c->gdim[1];
+    if (nz < n) return fail(c, PSGSDF_ERR_UNSUPPORTED, "%d z-planes cannot be cut into %d slabs", nz, n);
+    std::vector<double> cnt(nz, 0.0);
+    const float lim = (float)(sqrt(3.0) * (double)c->grid.vs);
+    for (int k = c->rank; k < nz; k += n) {
+        const float* d = dist + (size_t)k * plane; const uint64_t* v = vis_words + (size_t)k * plane * wpv;
+        long long m = 0;
+        for (long long i = 0; i < plane; ++i) { if (!(fabsf(d[i]) <= lim)) continue; bool seen = false; for (int w = 0; w < wpv && !seen; ++w) seen = v[(size_t)i * wpv + w] != 0; m += seen; }
+        cnt[k] = (double)m;
+    }
+    double* d_cnt = nullptr;
+    HIPCHK(c, hipMalloc(&d_cnt, sizeof(double) * nz));
+    HIPCHK(c, hipMemcpyAsync(d_cnt, cnt.data(), sizeof(double) * nz, hipMemcpyHostToDevice, c->stream));
+    int rc = comm_allreduce(c, d_cnt, nz); if (rc) { hipFree(d_cnt); return rc; }
+    HIPCHK(c, hipMemcpyAsync(cnt.data(), d_cnt, sizeof(double) * nz, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_cnt);
+    double total = 0; for (double x : cnt) total += x;
+    if (total <= 0) return fail(c, PSGSDF_ERR_UNSUPPORTED, "the volume has no band candidates to partition");
+    // cut r = first plane at which the running count reaches r/n of the total; every slab keeps at least one plane
+    std::vector<int> cut(n + 1, 0); cut[n] = nz;
+    double run = 0; int r = 1;
+    for (int k = 0; k < nz && r < n; ++k) { run += cnt[k]; while (r < n && run >= total * r / n) { cut[r] = k + 1; ++r; } }
+    for (int q = 1; q < n; ++q) cut[q] = std::max(cut[q], cut[q - 1] + 1);
+    for (int q = n - 1; q >= 1; --q) cut[q] = std::min(cut[q], cut[q + 1] - 1);
+    *z0 = cut[c->rank]; *z1 = cut[c->rank + 1];
+    return 0;
+}
+
 int psgsdf_upload_volume(psgsdf_ctx* c, const float* dist, const float* grad_xyz, const float* weight, const float* rgb, const uint64_t* vis_words, int words_per_voxel) {
     if (!c || !dist || !grad_xyz || !weight || !rgb || !vis_words || words_per_voxel < 1) return fail(c, PSGSDF_ERR_ARG, "upload_volume: null argument");
     HIPCHK(c, hipSetDevice(c->device));
-    const long long n = c->grid.nvox;
+    // the caller hands over the WHOLE volume; a rank of a multi-rank run keeps its z-slab (+ one halo plane per inner side) of it on the device
+    int z0 = 0, z1 = c->gdim[2];
+    if (c->n_ranks > 1) { int rc = choose_slab(c, dist, vis_words, words_per_voxel, &z0, &z1); if (rc) return rc; }
+    { int rc = set_local_grid(c, z0, z1); if (rc) return rc; }
+    const long long n = c->grid.nvox, gn = c->gnvox;
+    const size_t off = (size_t)c->zlo * c->gdim[0] * c->gdim[1];          // first voxel of the local planes in the caller's arrays
     free_dense(c);
     if (c->vis_seq) { hipFree(c->vis_seq); c->vis_seq = nullptr; }
     int rc = alloc_dense(c, c->dense, n, 0, true); if (rc) return rc;
     HIPCHK(c, hipMalloc(&c->vis_seq, sizeof(uint64_t) * n * words_per_voxel));
     c->wpv_seq = words_per_voxel;
-    HIPCHK(c, hipMemcpyAsync(c->dense.dist, dist, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dense.dist, dist + off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     for (int a = 0; a < 3; ++a) {
-        HIPCHK(c, hipMemcpyAsync(c->dense.g[a], grad_xyz + (size_t)a * n, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->dense.rho[a], rgb + (size_t)a * n, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dense.g[a], grad_xyz + (size_t)a * gn + off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dense.rho[a], rgb + (size_t)a * gn + off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->dense.weight, weight, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->vis_seq, vis_words, sizeof(uint64_t) * n * words_per_voxel, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dense.weight, weight + off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->vis_seq, vis_words + off * words_per_voxel, sizeof(uint64_t) * n * words_per_voxel, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_volume = true; c->inited = false;
     return PSGSDF_OK;
@@ -87,6 +128,8 @@ int psgsdf_upload_volume(psgsdf_ctx* c, const float* dist, const float* grad_xyz
 
 int psgsdf_volume_init(psgsdf_ctx* c, int max_frames) {
     if (!c || max_frames < 1) return fail(c, PSGSDF_ERR_ARG, "volume_init: max_frames");
+    if (c->n_ranks > 1) return fail(c, PSGSDF_ERR_UNSUPPORTED, "frame fusion runs on one rank: fuse, download, then upload the volume to the ranks");
+    { int rc0 = set_local_grid(c, 0, c->gdim[2]); if (rc0) return rc0; }
     HIPCHK(c, hipSetDevice(c->device));
     const long long n = c->grid.nvox;
     free_dense(c);
@@ -105,6 +148,7 @@ int psgsdf_volume_init(psgsdf_ctx* c, int max_frames) {
 
 int psgsdf_integrate_frame(psgsdf_ctx* c, const float* rgb, const float* depth, const float* normals_xyz, int width, int height, const float pose[16], int counter, float z_min, float z_max) {
     if (!c || !c->have_volume || !c->vis_seq) return fail(c, PSGSDF_ERR_STATE, "integrate_frame: volume_init or upload_volume first");
+    if (c->n_ranks > 1) return fail(c, PSGSDF_ERR_UNSUPPORTED, "frame fusion runs on one rank");
     if (!rgb || !depth || !normals_xyz || !pose || width < 2 || height < 2 || counter < 0) return fail(c, PSGSDF_ERR_ARG, "integrate_frame: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     if (counter >= 64 * c->wpv_seq) {   // the sequence is longer than volume_init was told (the reference's vector<bool> simply grows): widen the per-voxel words
@@ -297,8 +341,8 @@ int psgsdf_upsample2x(psgsdf_ctx* c) {
 
 int psgsdf_get_info(psgsdf_ctx* c, psgsdf_info* info) {
     if (!c || !info) return PSGSDF_ERR_ARG;
-    for (int a = 0; a < 3; ++a) { info->dim[a] = c->grid.dim[a]; info->origin[a] = c->grid.origin[a]; }
-    info->voxel_size = c->grid.vs; info->n_frames = c->F; info->n_band = c->inited ? c->band.S : 0;
+    for (int a = 0; a < 3; ++a) { info->dim[a] = c->gdim[a]; info->origin[a] = c->grid.origin[a]; }     // the WHOLE volume, also on a slab
+    info->voxel_size = c->grid.vs; info->n_frames = c->F; info->n_band = c->inited ? (int)c->S_global : 0;
     info->light_stride = c->set.model == PSGSDF_LED ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4);
     info->vis_words = c->dense.KW; info->reg_weight_n = c->reg_n; info->reg_weight_l = c->reg_l;
     return PSGSDF_OK;
@@ -307,17 +351,20 @@ int psgsdf_get_info(psgsdf_ctx* c, psgsdf_info* info) {
 int psgsdf_download_volume(psgsdf_ctx* c, float* dist, float* grad_xyz, float* weight, float* rgb, uint64_t* vis_words) {
     if (!c || !c->have_volume) return fail(c, PSGSDF_ERR_STATE, "no volume");
     HIPCHK(c, hipSetDevice(c->device));
-    const long long n = c->grid.nvox;
-    if (c->inited) { int rc = gather_band_state(c); if (rc) return rc; launch_band_scatter(c->dense, c->band, c->stream); }   // multi-rank: a collective call
-    if (dist) HIPCHK(c, hipMemcpyAsync(dist, c->dense.dist, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    // The caller's arrays are those of the WHOLE volume.  A rank of a multi-rank run writes the z-planes it OWNS, [z0, z1) (psgsdf_mg_info),
+    // and leaves the rest of the arrays untouched: the slabs of all ranks tile the volume.
+    const size_t plane = (size_t)c->gdim[0] * c->gdim[1];
+    const size_t src = (size_t)(c->z0 - c->zlo) * plane, dst = (size_t)c->z0 * plane, n = (size_t)(c->z1 - c->z0) * plane, gn = (size_t)c->gnvox;
+    if (c->inited) launch_band_scatter(c->dense, c->band, c->stream);
+    if (dist) HIPCHK(c, hipMemcpyAsync(dist + dst, c->dense.dist + src, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     for (int a = 0; a < 3; ++a) {
-        if (grad_xyz) HIPCHK(c, hipMemcpyAsync(grad_xyz + (size_t)a * n, c->dense.g[a], sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
-        if (rgb) HIPCHK(c, hipMemcpyAsync(rgb + (size_t)a * n, c->dense.rho[a], sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+        if (grad_xyz) HIPCHK(c, hipMemcpyAsync(grad_xyz + (size_t)a * gn + dst, c->dense.g[a] + src, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+        if (rgb) HIPCHK(c, hipMemcpyAsync(rgb + (size_t)a * gn + dst, c->dense.rho[a] + src, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     }
-    if (weight) HIPCHK(c, hipMemcpyAsync(weight, c->dense.weight, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    if (weight) HIPCHK(c, hipMemcpyAsync(weight + dst, c->dense.weight + src, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     if (vis_words) {
         if (!c->dense.vis) return fail(c, PSGSDF_ERR_STATE, "visibility not selected yet");
-        HIPCHK(c, hipMemcpyAsync(vis_words, c->dense.vis, sizeof(uint64_t) * n * c->dense.KW, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(vis_words + dst * c->dense.KW, c->dense.vis + src * c->dense.KW, sizeof(uint64_t) * n * c->dense.KW, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PSGSDF_OK;
@@ -333,7 +380,13 @@ int psgsdf_download_vis_seq(psgsdf_ctx* c, uint64_t* out) {
 int psgsdf_download_band(psgsdf_ctx* c, int32_t* lin_idx) {
     if (!c || !c->inited || !lin_idx) return fail(c, PSGSDF_ERR_STATE, "init first");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(lin_idx, c->band.lin, sizeof(int) * c->band.S, hipMemcpyDeviceToHost));
+    // surface_points_ in the indexing of the WHOLE volume.  One rank: all n_band of them.  A slab: its own rows only (row1 - row0 of
+    // psgsdf_mg_info entries, ascending; the slabs' lists concatenated in rank order are the whole band).
+    const int n = c->row1 - c->row0;
+    if (n <= 0) return PSGSDF_OK;
+    HIPCHK(c, hipMemcpy(lin_idx, c->band.lin + c->row0, sizeof(int) * n, hipMemcpyDeviceToHost));
+    const long long shift = (long long)c->zlo * c->gdim[0] * c->gdim[1];
+    if (shift) for (int i = 0; i < n; ++i) lin_idx[i] = (int32_t)(lin_idx[i] + shift);
     return PSGSDF_OK;
 }
 

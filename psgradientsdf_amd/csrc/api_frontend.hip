@@ -58,6 +58,7 @@ extern "C" int psgsdf_estimate_normals(psgsdf_ctx* c, const float* depth, int wi
 extern "C" int psgsdf_track(psgsdf_ctx* c, const float* depth, int width, int height, float pose[16], float z_min, float z_max,
                             int num_iterations, float conv_threshold, float damping, int* iters_out, int* converged) {
     if (!c || !c->have_volume || !depth || !pose) return fail(c, PSGSDF_ERR_STATE, "track: volume first");
+    if (c->n_ranks > 1) return fail(c, PSGSDF_ERR_UNSUPPORTED, "the tracker runs on one rank");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = (size_t)width * height;
     int rc = normals_cache(c, width, height); if (rc) return rc;   // (allocates the depth staging buffer)

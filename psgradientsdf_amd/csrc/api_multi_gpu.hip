@@ -9,7 +9,7 @@ int psgsdf_comm_unique_id(uint8_t id[128]) { return id ? comm_unique_id(id) : PS
 static int attach(psgsdf_ctx* c, int rank, int n_ranks) {
     if (!c || rank < 0 || n_ranks < 1 || rank >= n_ranks) return PSGSDF_ERR_ARG;
     if (n_ranks > 1 && c->reg_r != 0.f) return fail(c, PSGSDF_ERR_UNSUPPORTED, "reg albedo is single-rank only");
-    c->rank = rank; c->n_ranks = n_ranks; c->inited = false;
+    c->rank = rank; c->n_ranks = n_ranks; c->inited = false; c->have_volume = false;      // (the slab is chosen when the volume is uploaded)
     return PSGSDF_OK;
 }
 int psgsdf_comm_init(psgsdf_ctx* c, const uint8_t id[128], int rank, int n_ranks) {
@@ -28,9 +28,10 @@ int psgsdf_set_stream(psgsdf_ctx* c, void* hip_stream) {
     c->stream = (hipStream_t)hip_stream; c->own_stream = false;
     return PSGSDF_OK;
 }
-int psgsdf_mg_info(psgsdf_ctx* c, int32_t out[10]) {
+int psgsdf_mg_info(psgsdf_ctx* c, int32_t out[12]) {
     if (!c || !c->inited) return PSGSDF_ERR_STATE;
-    out[0] = c->band.S; out[1] = c->band.Spad; out[2] = c->row0; out[3] = c->row1; out[4] = c->halo; out[5] = c->F; out[6] = c->rank; out[7] = c->n_ranks; out[8] = c->need[0]; out[9] = c->need[1];
+    out[0] = (int32_t)c->S_global; out[1] = c->band.S; out[2] = c->row0; out[3] = c->row1; out[4] = c->halo; out[5] = c->F; out[6] = c->rank; out[7] = c->n_ranks;
+    out[8] = c->need[0]; out[9] = c->need[1]; out[10] = c->z0; out[11] = c->z1;
     return PSGSDF_OK;
 }
 int psgsdf_comm_stats(psgsdf_ctx* c, int64_t* n_collectives) { if (!c || !n_collectives) return PSGSDF_ERR_ARG; *n_collectives = c->n_collectives; return PSGSDF_OK; }

@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(kBlock) k_derive(SweepArgs a, int update_grad)
         float xs[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            float xv = a.grid.origin[k] + a.grid.vs * (float)idx[k];   // VoxelGrid.h:38-40
+            float xv = a.grid.origin[k] + a.grid.vs * (float)(idx[k] + (k == 2 ? a.grid.koff : 0));   // VoxelGrid.h:38-40 (global voxel index: a slab's local planes start at koff)
             xs[k] = xv - d * gn[k];
         }
         b.vp[0][j] = make_float4(xs[0], xs[1], xs[2], b.rho[0][j]);
@@ -286,16 +286,16 @@ void launch_obs_fill(const Band& b, int F, int row0, int row1, const int* offset
 }
 // halo of a row partition: how many rows below row0 / from row1 upward the ELL columns of the owned rows reach
 // (contiguous ranges suffice because the band is sorted by linear index).  need[0] = rows below, need[1] = rows above.
-__global__ void __launch_bounds__(kBlock) k_reach(Band b, int row0, int row1, int* __restrict__ need) {
-    int i = row0 + blockIdx.x * blockDim.x + threadIdx.x;
-    int lo = 0, hi = 0;
-    if (i < row1) for (int q = 1; q < kNQ; ++q) { int c = b.col[(size_t)q * b.Spad + i]; if (c < row0) lo = max(lo, row0 - c); if (c >= row1) hi = max(hi, c - row1 + 1); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { lo = max(lo, __shfl_down(lo, o, 64)); hi = max(hi, __shfl_down(hi, o, 64)); }
-    if ((threadIdx.x & 63) == 0) { if (lo > 0) atomicMax(need, lo); if (hi > 0) atomicMax(need + 1, hi); }
+// number of band rows whose (ascending) linear index is below `target`: where a z-plane starts in the band
+__global__ void __launch_bounds__(kBlock) k_lower_bound(const int* __restrict__ lin, int S, int target, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > S) return;
+    const bool below_prev = i == 0 || lin[i - 1] < target;
+    const bool here = i == S || lin[i] >= target;
+    if (below_prev && here) *out = i;
 }
-void launch_reach(const Band& b, int row0, int row1, int* d_need, hipStream_t s) {
-    if (row1 > row0) hipLaunchKernelGGL(k_reach, dim3((row1 - row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, b, row0, row1, d_need);
+void launch_lower_bound(const int* lin, int S, int target, int* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_lower_bound, dim3((S + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, lin, S, target, out);
 }
 // fold per-workgroup partials into a few doubles.  `out` may be host-mapped pinned memory: the host then needs no
 // D2H copy (each hipMemcpyAsync costs ~10 us of GPU idle around it), only the stream synchronisation it does anyway.

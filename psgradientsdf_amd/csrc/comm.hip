@@ -3,12 +3,12 @@
 //
 //   transport "rccl" : RCCL over xGMI.  librccl is bound at run time (dlopen) the first time a communicator is asked for, so a
 //                      single-GPU process never loads it; inside a process that already maps RCCL (e.g. PyTorch) the same copy is reused.
-//   transport "ext"  : the caller supplies the three primitives (psgsdf_comm_ops): a seam for hosts that already own a
+//   transport "ext"  : the caller supplies the two primitives (psgsdf_comm_ops): a seam for hosts that already own a
 //                      communicator (MPI, a test harness).  tests/ use it to run two ranks on ONE device, which RCCL refuses.
 //
 // What moves (all latency-bound, <= 1 MiB): all-reduce of the per-frame light / pose rows, of the 7 sums of a PCG pass, of the
-// iteration's folded scalars; halo rows of `blk`, the PCG records and `dist` with the two z-neighbours; an all-gather of the refined
-// band before download / 2x refinement.
+// iteration's folded scalars; halo rows of `blk`, the PCG records and `dist` with the two z-neighbours (and, once per band, of the static
+// stencil-direction bits; before a 2x refinement, of albedo and gradient).
 #include "engine_internal.h"
 
 #include <dlfcn.h>
@@ -24,7 +24,6 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -46,7 +45,6 @@ RcclApi* rccl() {
     api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
     api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
-    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
     api.Send = (decltype(api.Send))sym("ncclSend");
     api.Recv = (decltype(api.Recv))sym("ncclRecv");
     api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
@@ -96,7 +94,7 @@ int comm_create_rccl(psgsdf_ctx* c, const uint8_t id[128], int rank, int n) {
     return PSGSDF_OK;
 }
 int comm_create_ext(psgsdf_ctx* c, const psgsdf_comm_ops* ops, int rank, int n) {
-    if (!ops || !ops->allreduce_f64 || !ops->sendrecv || !ops->allgather) return fail(c, PSGSDF_ERR_ARG, "comm_init_ext: all three primitives are required");
+    if (!ops || !ops->allreduce_f64 || !ops->sendrecv) return fail(c, PSGSDF_ERR_ARG, "comm_init_ext: both primitives are required");
     comm_destroy(c);
     Comm* cm = new Comm(); cm->rank = rank; cm->n = n; cm->ext = *ops; cm->is_ext = true;
     c->comm = cm;
@@ -143,22 +141,6 @@ int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
     for (auto& x : sends) NCCLCHK(c, r->Send(x.ptr_dev, x.bytes, ncclChar, x.peer, c->comm->nccl, c->stream));
     for (auto& x : recvs) NCCLCHK(c, r->Recv(x.ptr_dev, x.bytes, ncclChar, x.peer, c->comm->nccl, c->stream));
     NCCLCHK(c, r->GroupEnd());
-    return 0;
-}
-
-// every rank ends up with all rows of `planes` planes (4-byte elements): rank r owns rows [r*C, (r+1)*C) of each plane (C = rows per
-// slab; the padded planes hold n*C rows), so this is an in-place all-gather per plane
-int comm_allgather_rows(psgsdf_ctx* c, void* base, int planes) {
-    if (!slab_mode(c)) return 0;
-    int rc = need_comm(c); if (rc) return rc;
-    const int C = c->slab_rows;
-    if ((long long)C * c->n_ranks > c->band.Spad) return fail(c, PSGSDF_ERR_UNSUPPORTED, "band planes too short for the all-gather (%d x %d > %d)", C, c->n_ranks, c->band.Spad);
-    for (int p = 0; p < planes; ++p) {
-        char* pl = (char*)base + 4 * (size_t)c->band.Spad * p;
-        c->n_collectives++;
-        if (c->comm->is_ext) { if (c->comm->ext.allgather(c->comm->ext.user, pl, 4 * (size_t)C, c->stream)) return fail(c, PSGSDF_ERR_COMM, "ext allgather failed"); continue; }
-        NCCLCHK(c, rccl()->AllGather(pl + 4 * (size_t)C * c->rank, pl, 4 * (size_t)C, ncclChar, c->comm->nccl, c->stream));
-    }
     return 0;
 }
 

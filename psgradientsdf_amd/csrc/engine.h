@@ -31,12 +31,13 @@ struct FrameP {       // 24 floats = 96 B
 
 struct Cam { float fx, fy, cx, cy; int W, H; };
 
-struct GridP {
+struct GridP {             // the grid THIS context holds: the whole volume, or (multi-rank) its z-slab plus one halo plane on each inner side
     int dim[3];
     long long nvox;
     float vs, vs_inv;
-    float origin[3];
+    float origin[3];       // world position of voxel (0, 0, 0) of the WHOLE volume (VoxelGrid.h:130)
     float T;
+    int koff;              // global z index of local plane 0: world z of local voxel k is origin[2] + vs * (k + koff)
 };
 
 struct Robust { int loss; float lambda, lambda_sq, inv_lambda; };
@@ -155,7 +156,7 @@ void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s);
 constexpr int kObsChunk = 2048;      // rows per workgroup of the observation-list builders
 void launch_obs_count(const Band& b, int F, int row0, int row1, int* counts, hipStream_t s);       // counts[F][nch]
 void launch_obs_fill(const Band& b, int F, int row0, int row1, const int* offsets, hipStream_t s); // offsets[F][nch] -> b.obs_rows
-void launch_reach(const Band& b, int row0, int row1, int* d_need, hipStream_t s);                   // rows needed below row0 / from row1 up
+void launch_lower_bound(const int* lin, int S, int target, int* out, hipStream_t s);               // *out = number of band rows with lin < target (lin ascending)
 struct SlotList { int n; int id[8]; };
 void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, hipStream_t s);
 void launch_frame_cols(const double* frame, int F, int col, double* out, hipStream_t s);

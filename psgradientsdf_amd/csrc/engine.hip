@@ -109,14 +109,17 @@ int mg_commit(psgsdf_ctx* c) {
     c->mg_segs.clear();
     return 0;
 }
-// every rank ends up with the refined rows of all slabs (distance, stored gradient, albedo): before the band is scattered back into the
-// dense grid for download / 2x refinement
-int gather_band_state(psgsdf_ctx* c) {
-    if (!slab_mode(c) || !c->inited || c->band.S == 0) return 0;
-    int rc;
-    if ((rc = comm_allgather_rows(c, c->band.dist, 1))) return rc;
-    if ((rc = comm_allgather_rows(c, c->band.g[0], 3))) return rc;
-    return comm_allgather_rows(c, c->band.rho[0], 3);
+// This context owns the global z-planes [z0, z1) and holds them plus one halo plane on each inner side: the LOCAL grid every dense kernel
+// works on.  World coordinates stay those of the whole volume (GridP.origin is global, GridP.koff shifts the local plane index).
+int set_local_grid(psgsdf_ctx* c, int z0, int z1) {
+    if (z0 < 0 || z1 > c->gdim[2] || z1 <= z0) return fail(c, PSGSDF_ERR_ARG, "slab planes [%d, %d) of %d", z0, z1, c->gdim[2]);
+    c->z0 = z0; c->z1 = z1;
+    c->zlo = std::max(0, z0 - 1); c->zhi = std::min(c->gdim[2], z1 + 1);
+    GridP& g = c->grid;
+    g.dim[0] = c->gdim[0]; g.dim[1] = c->gdim[1]; g.dim[2] = c->zhi - c->zlo;
+    g.nvox = (long long)g.dim[0] * g.dim[1] * g.dim[2];
+    g.koff = c->zlo;
+    return 0;
 }
 // hand the pending fold to a kernel about to be launched with `a`; `writes` = bit mask of the partial slots that kernel writes
 void take_fold(psgsdf_ctx* c, SweepArgs& a, unsigned writes) {
@@ -243,33 +246,44 @@ int build_band(psgsdf_ctx* c) {
         SweepArgs at{}; at.b = b; at.ar = ar;
         launch_areg_tables(c->dense, c->grid, at, c->stream);
     }
-    // row partition: equal band count per rank = z-slabs (the band is sorted by linear index, z slowest)
+    // row partition.  The band is sorted by linear index, z slowest, so the rows of the OWN planes [z0, z1) are one contiguous range
+    // [row0, row1); the rows before it are the lower halo plane, the rows behind it the upper one (multi-rank only).
     {
-        const int C = (S + c->n_ranks - 1) / c->n_ranks;
-        c->row0 = std::min(S, c->rank * C); c->row1 = std::min(S, c->row0 + C);
-        c->halo = 0; c->need[0] = c->need[1] = 0; c->give[0] = c->give[1] = 0; c->halo_active = false; c->slab_rows = C;
+        c->row0 = 0; c->row1 = S;
+        c->halo = 0; c->need[0] = c->need[1] = 0; c->give[0] = c->give[1] = 0; c->halo_active = false;
         if (c->n_ranks > 1 && !c->comm) return fail(c, PSGSDF_ERR_COMM, "rank %d of %d has no communicator (psgsdf_comm_init)", c->rank, c->n_ranks);
         if (c->n_ranks > kMgScal / 2) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d ranks", kMgScal / 2);
-        if (c->n_ranks > 1 && c->row1 <= c->row0) return fail(c, PSGSDF_ERR_UNSUPPORTED, "rank %d of %d would own no band rows (band of %d): use fewer ranks", c->rank, c->n_ranks, S);
-        if (c->n_ranks > 1 && S > 0) {
-            HIPCHK(c, hipMemsetAsync(c->d_need, 0, 2 * sizeof(int), c->stream));
-            launch_reach(b, c->row0, c->row1, c->d_need, c->stream);
-            HIPCHK(c, hipMemcpyAsync(c->need, c->d_need, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            c->halo = std::max(c->need[0], c->need[1]);
-            if (c->halo > C) return fail(c, PSGSDF_ERR_UNSUPPORTED, "slab of %d rows is thinner than the stencil reach %d: use fewer ranks", C, c->halo);
-            // what a slab has to SEND is its neighbours' need: one tiny all-reduce of {need_lo, need_hi} per rank
-            std::vector<double> needs(2 * (size_t)c->n_ranks, 0.0);
-            needs[2 * c->rank] = c->need[0]; needs[2 * c->rank + 1] = c->need[1];
-            HIPCHK(c, hipMemcpyAsync(c->mg_scal, needs.data(), sizeof(double) * needs.size(), hipMemcpyHostToDevice, c->stream));
-            int rcc = comm_allreduce(c, c->mg_scal, (int)needs.size()); if (rcc) return rcc;
-            HIPCHK(c, hipMemcpyAsync(needs.data(), c->mg_scal, sizeof(double) * needs.size(), hipMemcpyDeviceToHost, c->stream));
+        if (c->n_ranks > 1) {
+            const long long plane = (long long)c->grid.dim[0] * c->grid.dim[1];
+            int rr[2] = {0, S};
+            if (S > 0) {
+                launch_lower_bound(b.lin, S, (int)((c->z0 - c->zlo) * plane), c->d_need, c->stream);
+                launch_lower_bound(b.lin, S, (int)((c->z1 - c->zlo) * plane), c->d_need + 1, c->stream);
+                HIPCHK(c, hipMemcpyAsync(rr, c->d_need, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
+            c->row0 = rr[0]; c->row1 = rr[1];
+            c->need[0] = c->row0; c->need[1] = S - c->row1; c->halo = std::max(c->need[0], c->need[1]);
+            // {need_lo, need_hi, own rows} of every rank in one tiny all-reduce: what a slab SENDS is its neighbours' need
+            std::vector<double> info(3 * (size_t)c->n_ranks, 0.0);
+            info[3 * c->rank] = c->need[0]; info[3 * c->rank + 1] = c->need[1]; info[3 * c->rank + 2] = c->row1 - c->row0;
+            if (info.size() > (size_t)kMgScal) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d ranks", kMgScal / 3);
+            HIPCHK(c, hipMemcpyAsync(c->mg_scal, info.data(), sizeof(double) * info.size(), hipMemcpyHostToDevice, c->stream));
+            int rcc = comm_allreduce(c, c->mg_scal, (int)info.size()); if (rcc) return rcc;
+            HIPCHK(c, hipMemcpyAsync(info.data(), c->mg_scal, sizeof(double) * info.size(), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             const int own = c->row1 - c->row0;
-            if (c->rank > 0) c->give[0] = std::min((int)needs[2 * (c->rank - 1) + 1], own);               // the lower neighbour reaches up into my first rows
-            if (c->rank < c->n_ranks - 1) c->give[1] = std::min((int)needs[2 * (c->rank + 1)], own);       // the upper neighbour reaches down into my last rows
-            for (double v : needs) if (v != 0.0) c->halo_active = true;                                   // (global: every rank takes part in an exchange or none does)
-        }
+            if (c->rank > 0) c->give[0] = std::min((int)info[3 * (c->rank - 1) + 1], own);               // the lower neighbour's upper halo plane = my first own plane
+            if (c->rank < c->n_ranks - 1) c->give[1] = std::min((int)info[3 * (c->rank + 1)], own);       // the upper neighbour's lower halo plane = my last own plane
+            c->S_global = 0;
+            for (int r = 0; r < c->n_ranks; ++r) {
+                if (info[3 * r] != 0.0 || info[3 * r + 1] != 0.0) c->halo_active = true;                 // (global: every rank takes part in an exchange or none does)
+                if (info[3 * r + 2] == 0.0) return fail(c, PSGSDF_ERR_UNSUPPORTED, "rank %d of %d owns no band rows: use fewer ranks", r, c->n_ranks);
+                c->S_global += (long long)info[3 * r + 2];
+            }
+            // the stencil-direction bits of the halo rows are static and depend on the plane BEYOND the halo: take them from their owner
+            int hrc = comm_halo(c, b.dirb, 1, 1); if (hrc) return hrc;
+        } else c->S_global = S;
     }
     // per-frame observation lists of the owned rows (counts -> host prefix -> fill)
     {

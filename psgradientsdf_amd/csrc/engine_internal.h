@@ -35,7 +35,11 @@ struct psgsdf_ctx {
     hipStream_t stream = nullptr;
     psgsdf_settings set{};
     float reg_n = 0, reg_l = 0;
-    GridP grid{};
+    GridP grid{};                        // the LOCAL grid (whole volume on one rank; z-planes [zlo, zhi) of it on a slab)
+    int gdim[3]{}; long long gnvox = 0;  // the whole volume
+    int z0 = 0, z1 = 0;                  // global z-planes this context OWNS: [z0, z1)
+    int zlo = 0, zhi = 0;                // global z-planes it HOLDS: [zlo, zhi) = own planes + one halo plane on each inner side
+    long long S_global = 0;              // band voxels of the whole volume (sum of the slabs' own rows)
     float shift[3]{};
     Cam cam{};
     // dense
@@ -92,7 +96,6 @@ struct psgsdf_ctx {
     std::vector<psge::MgSeg> mg_segs;
     int give[2] = {0, 0};                // rows the lower / upper neighbour needs of this slab
     bool halo_active = false;            // any stencil of any slab crosses a cut
-    int slab_rows = 0;                   // C = rows per slab (the last slab may be shorter)
     long long n_collectives = 0;
     float reg_r = 0.f;                   // "reg albedo" (never normalised, PsOptimizer.cpp:279)
     void* areg_mem = nullptr; AlbedoReg ar{};   // planes of the albedo regulariser, allocated with the band when reg_r != 0
@@ -161,9 +164,8 @@ int comm_create_ext(psgsdf_ctx* c, const psgsdf_comm_ops* ops, int rank, int n);
 void comm_destroy(psgsdf_ctx* c);
 int comm_allreduce(psgsdf_ctx* c, double* buf, int n);                 // in-place sum of n doubles (device), on the context's stream
 int comm_halo(psgsdf_ctx* c, void* base, int planes, int width);       // halo rows of `planes` band planes of `width` 4-byte words per row
-int comm_allgather_rows(psgsdf_ctx* c, void* base, int planes);        // every rank gets all rows of `planes` band planes (4-byte elements)
 int mg_commit(psgsdf_ctx* c);                                          // engine.hip: all-reduce + deliver the staged scalar read-backs
-int gather_band_state(psgsdf_ctx* c);                                  // engine.hip: dist / grad / albedo rows of every slab on every rank
+int set_local_grid(psgsdf_ctx* c, int z0, int z1);                     // engine.hip: this context owns global planes [z0, z1) (+ halo planes)
 
 // ---- engine.hip
 SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg);
@@ -171,7 +173,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg);
 // the RCCL path is exercised on a one-GPU box and how its overhead is measured, bench.py --force-slab)
 inline bool slab_mode(const psgsdf_ctx* c) { return c->comm != nullptr || c->n_ranks > 1; }
 inline int band_blocks(const psgsdf_ctx* c) { return (c->row1 - c->row0 + kBlock - 1) / kBlock; }
-inline double band_mean(const psgsdf_ctx* c, double sum) { return c->band.S ? sum / (double)c->band.S : 0.0; }
+inline double band_mean(const psgsdf_ctx* c, double sum) { return c->S_global ? sum / (double)c->S_global : 0.0; }   // (1/S) sum over the band of the WHOLE volume
 inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l, float E_r = 0.f) { return E + c->reg_n * E_n + c->reg_l * E_l + c->reg_r * E_r; }   // OptimizerAux.cpp:261
 int flush(psgsdf_ctx* c);
 int read_parts(psgsdf_ctx* c, const int* slots, int n, double* out);

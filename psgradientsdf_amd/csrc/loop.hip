@@ -462,23 +462,45 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
 }
 
 int do_upsample(psgsdf_ctx* c) {
-    // bring the dense grid up to date (multi-rank: with the refined rows of every slab), refine, rebuild the band
-    { int grc = gather_band_state(c); if (grc) return grc; }
+    // bring the dense grid up to date, refine, rebuild the band.  Multi-rank: every slab refines the planes it holds; the halo planes need
+    // their owners' albedo and gradient first (the distances are exchanged every iteration anyway), and of the refined halo planes only the
+    // inner one is kept: the slab [z0, z1) becomes [2 z0, 2 z1) with one halo plane on each inner side again.
+    int rc;
+    if ((rc = comm_halo(c, c->band.rho[0], 3, 1))) return rc;
+    if ((rc = comm_halo(c, c->band.g[0], 3, 1))) return rc;
     timed(c, "band_scatter", [&] { launch_band_scatter(c->dense, c->band, c->stream); });
     DenseView nd{};
     const long long nn = 8 * c->grid.nvox;
-    int rc = alloc_dense(c, nd, nn, c->dense.KW, true); if (rc) return rc;
+    if ((rc = alloc_dense(c, nd, nn, c->dense.KW, true))) return rc;
     timed(c, "upsample", [&] { launch_upsample(c->dense, nd, c->grid, c->stream); });
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_dense(c);
-    c->dense = nd;
     if (c->vis_seq) { hipFree(c->vis_seq); c->vis_seq = nullptr; }
+    const int old_zlo = c->zlo;
+    for (int a = 0; a < 3; ++a) c->gdim[a] *= 2;
+    c->gnvox *= 8;
     GridP& g = c->grid;
     g.vs *= 0.5f;
-    for (int a = 0; a < 3; ++a) g.dim[a] *= 2;
-    for (int a = 0; a < 3; ++a) g.origin[a] = c->shift[a] - (float)(0.5 * (double)g.vs) * (float)g.dim[a] - (float)(0.5 * (double)g.vs) * 1.0f;   // VoxelGrid.h:143-149
-    g.nvox = nn;
+    for (int a = 0; a < 3; ++a) g.origin[a] = c->shift[a] - (float)(0.5 * (double)g.vs) * (float)c->gdim[a] - (float)(0.5 * (double)g.vs) * 1.0f;   // VoxelGrid.h:143-149
     g.vs_inv = (float)(1.0 / (double)g.vs);
+    if ((rc = set_local_grid(c, 2 * c->z0, 2 * c->z1))) return rc;
+    if (g.nvox == nn) c->dense = nd;                                  // one rank, or a slab without halo planes: the refined grid is the local grid
+    else {                                                            // drop the outer child plane of each refined halo plane
+        const size_t plane = (size_t)g.dim[0] * g.dim[1], skip = (size_t)(c->zlo - 2 * old_zlo) * plane, n = (size_t)g.nvox;
+        DenseView td{};
+        if ((rc = alloc_dense(c, td, g.nvox, nd.KW, true))) return rc;
+        HIPCHK(c, hipMemcpyAsync(td.dist, nd.dist + skip, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(td.weight, nd.weight + skip, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+        for (int a = 0; a < 3; ++a) {
+            HIPCHK(c, hipMemcpyAsync(td.g[a], nd.g[a] + skip, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(td.rho[a], nd.rho[a] + skip, sizeof(float) * n, hipMemcpyDeviceToDevice, c->stream));
+        }
+        HIPCHK(c, hipMemcpyAsync(td.vis, nd.vis + skip * nd.KW, sizeof(uint64_t) * n * nd.KW, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(nd.dist); hipFree(nd.weight); hipFree(nd.vis); hipFree(nd.row_of);
+        for (int a = 0; a < 3; ++a) { hipFree(nd.g[a]); hipFree(nd.rho[a]); }
+        c->dense = td;
+    }
     if ((rc = build_band(c))) return rc;
     return derive(c, 0);
 }

@@ -1,5 +1,5 @@
 """A caller-supplied transport (psgsdf_comm_ops) built on a torch.distributed gloo process group: TEST INFRASTRUCTURE.  It lets two ranks
-share ONE GPU -- which RCCL refuses -- so that the engine's native multi-rank loop (halo exchanges, all-reduces, all-gather) can be
+share ONE GPU -- which RCCL refuses -- so that the engine's native multi-rank loop (halo exchanges, all-reduces) can be
 exercised on a one-GPU box.  Every primitive synchronises the device, stages through the host and blocks: correct, and slow on purpose."""
 import ctypes as C
 
@@ -21,7 +21,7 @@ class GlooTransport:
     def __init__(self, dist):
         self.dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
         self.calls = 0
-        self._f = (capi.ALLREDUCE_FN(self._allreduce), capi.SENDRECV_FN(self._sendrecv), capi.ALLGATHER_FN(self._allgather))
+        self._f = (capi.ALLREDUCE_FN(self._allreduce), capi.SENDRECV_FN(self._sendrecv))
         self.ops = capi.CommOps(None, *self._f)
 
     def _guard(self, fn):
@@ -57,14 +57,4 @@ class GlooTransport:
             for t, h in back:
                 t.copy_(h)
             torch.cuda.synchronize()
-        return self._guard(run)
-
-    def _allgather(self, user, buf, bytes_per_rank, stream):
-        def run():
-            torch.cuda.synchronize()
-            t = _alias(buf, bytes_per_rank * self.world, "|u1")
-            mine = t[self.rank * bytes_per_rank:(self.rank + 1) * bytes_per_rank].cpu()
-            parts = [torch.empty(bytes_per_rank, dtype=torch.uint8) for _ in range(self.world)]
-            self.dist.all_gather(parts, mine)
-            t.copy_(torch.cat(parts)); torch.cuda.synchronize()
         return self._guard(run)

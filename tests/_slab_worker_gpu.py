@@ -38,10 +38,11 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
         eng.upsample2x()
         recs += eng.iterate(capi.ALL, 1)
     info = eng.mg_info()
-    v = eng.download_volume()          # collective: gathers the refined rows of every slab
+    v = eng.download_volume()          # whole-volume arrays, NaN outside the z-planes this rank owns
     np.savez(out + f".rank{rank}.npz", dist=v["dist"], rgb=v["rgb"], grad=v["grad"], poses=eng.download_poses(), light=eng.download_light(),
-             e_total=[r["e_total"] for r in recs], cg=[r["cg_iters"] for r in recs], e0=e0, band=eng.download_band(),
-             info=[info["row0"], info["row1"], info["halo"], info["S"], info["need_lo"], info["need_hi"]], ncoll=eng.comm_stats(), dim=list(eng.info().dim))
+             e_total=[r["e_total"] for r in recs], cg=[r["cg_iters"] for r in recs], e0=e0, band=eng.download_band(info["row1"] - info["row0"]),
+             info=[info["row0"], info["row1"], info["halo"], info["S"], info["need_lo"], info["need_hi"], info["z0"], info["z1"], info["rows"]],
+             ncoll=eng.comm_stats(), dim=list(eng.info().dim), n_band=eng.info().n_band)
     eng.close()
     if tr is not None:
         dist.barrier(); dist.destroy_process_group()

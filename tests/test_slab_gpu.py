@@ -37,6 +37,15 @@ def run_ranks(tmp_path, model, world, transport, mode, N, n_iters, extra_env=Non
     return [np.load(out + f".rank{r}.npz") for r in range(world)]
 
 
+def stitch(res, key):
+    """the slabs tile the volume: every rank filled the z-planes it owns, NaN elsewhere"""
+    out = np.full_like(res[0][key], np.nan)
+    for got in res:
+        m = ~np.isnan(got[key]); assert not (m & ~np.isnan(out)).any(); out[m] = got[key][m]
+    assert not np.isnan(out).any()
+    return out
+
+
 @pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH2", 2, "gloo")])
 def test_native_slab_loop_matches_single_context(built, tmp_path, model, world, transport):
     N, n_iters = 40, 2
@@ -50,28 +59,40 @@ def test_native_slab_loop_matches_single_context(built, tmp_path, model, world, 
     ref.init_albedo(); e0 = ref.normalize_weights()
     recs = ref.iterate(capi.ALL, n_iters)
     band = ref.download_band(); v = ref.download_volume(); vs = float(sc.voxel_size)
-    for r, got in enumerate(res):
+    for r, got in enumerate(res):      # every rank reports the same global energies, iteration counts, poses
         assert abs(float(got["e0"]) - e0) <= 1e-6 * abs(e0)
         assert np.allclose(got["e_total"], [x["e_total"] for x in recs], rtol=2e-4 if model == "SH2" else 5e-6)
         assert np.all(np.abs(got["cg"] - np.array([x["cg_iters"] for x in recs])) <= 1)
-        # every rank downloads the WHOLE refined band (all-gather); the slabs sum their dot products in a different order than one context
-        assert np.abs(got["dist"][band] - v["dist"][band]).max() <= (1e-3 if model == "SH2" else 1e-4) * vs
-        assert np.abs(got["rgb"][:, band] - v["rgb"][:, band]).max() <= (1e-2 if model == "SH2" else 2e-4)   # SH2: float32 9x9 light blocks of cond ~2e4 (tests/test_parity_gpu.py LIGHT_RTOL) amplify the all-reduce's summation order
         assert np.abs(got["poses"] - ref.download_poses()).max() <= (2e-5 if model == "SH2" else 1e-6)
-        row0, row1, halo, S, need_lo, need_hi = got["info"]
-        assert S == len(band) and row1 - row0 <= (S + world - 1) // world
+        row0, row1, halo, S, need_lo, need_hi, z0, z1, rows = got["info"]
+        assert S == len(band) == int(got["n_band"]) and list(got["dim"]) == [N, N, N]
+        assert rows == need_lo + (row1 - row0) + need_hi and rows <= S
         if world > 1:
             assert halo > 0 and (need_lo > 0 or need_hi > 0)        # the sphere is cut through: stencils cross the cut, halos really move
+            assert rows < 0.8 * S                                     # a rank holds its slab (+ halo planes), not the whole band
             assert got["ncoll"] > 20
+            held = ~np.isnan(got["dist"])
+            assert held.sum() == (z1 - z0) * N * N and held[z0 * N * N:(z1 * N * N)].all()      # exactly its own planes came back
         else:
             assert got["ncoll"] > (40 if transport == "rccl-perpass" else 5)   # RCCL all-reduces of a one-rank communicator
+    # the slabs tile the volume and the band: stitched together they are the single-context result (the slabs sum their dot products in a
+    # different order than one context does)
+    assert np.array_equal(np.concatenate([g["band"] for g in res]), band)
+    d = stitch(res, "dist"); rgb = stitch(res, "rgb")
+    assert np.abs(d[band] - v["dist"][band]).max() <= (1e-3 if model == "SH2" else 1e-4) * vs
+    assert np.abs(rgb[:, band] - v["rgb"][:, band]).max() <= (1e-2 if model == "SH2" else 2e-4)   # SH2: float32 9x9 light blocks of cond ~2e4 (tests/test_parity_gpu.py LIGHT_RTOL) amplify the all-reduce's summation order
+    off = ~np.isin(np.arange(len(d)), band)
+    assert np.array_equal(d[off], v["dist"][off])                     # voxels outside the band are untouched
     if world > 1:
-        assert res[0]["info"][1] == res[1]["info"][0]               # contiguous slabs
+        cuts = sorted((int(g["info"][6]), int(g["info"][7])) for g in res)
+        assert cuts[0][0] == 0 and cuts[-1][1] == N and all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+        own = [int(g["info"][1] - g["info"][0]) for g in res]
+        assert max(own) <= 1.35 * min(own)                            # cut by band count (plane granularity), not by height
 
 
 def test_native_slab_refinement(built, tmp_path):
-    """two ranks through the 2x refinement (PsOptimizer.cpp:386-409): all-gather of the refined band, dense refinement and a NEW partition on
-    every rank, then another iteration -- against the single-context run of the same calls"""
+    """two ranks through the 2x refinement (PsOptimizer.cpp:386-409): halo planes refreshed, every slab refines the planes it holds, keeps the
+    inner refined halo plane, rebuilds its band -- then another iteration -- against the single-context run of the same calls"""
     res = run_ranks(tmp_path, "SH1", 2, "gloo", "refine", 24, 2)
     sc = synth.make_scene(N=24, F=6, W=160, H=120, model="SH1")
     st = capi.default_settings(capi.SH1)
@@ -81,8 +102,9 @@ def test_native_slab_refinement(built, tmp_path):
     band = ref.download_band(); v = ref.download_volume(); vs = float(ref.info().voxel_size)
     assert list(ref.info().dim) == [48, 48, 48]
     for got in res:
-        assert list(got["dim"]) == [48, 48, 48] and np.array_equal(got["band"], band)
+        assert list(got["dim"]) == [48, 48, 48] and int(got["n_band"]) == len(band)
         assert np.allclose(got["e_total"], [x["e_total"] for x in recs], rtol=1e-5)
-        d = np.abs(got["dist"][band] - v["dist"][band]) / vs
-        assert d.max() <= 1e-4, d.max()
-        assert got["info"][3] == len(band)                      # the partition was rebuilt on the refined band
+    assert np.array_equal(np.concatenate([g["band"] for g in res]), band)      # the refined slabs tile the refined band
+    d = stitch(res, "dist")
+    assert np.abs(d[band] - v["dist"][band]).max() <= 1e-4 * vs
+    assert res[0]["info"][7] == res[1]["info"][6] == 2 * (res[0]["info"][7] // 2)     # the cut doubled with the grid
