@@ -1,20 +1,20 @@
-"""Host program of the z-slab multi-GPU path.
+"""Host program of the z-slab ALGORITHM on the CPU oracle's phase mirror (`orc_mg_*`) -- TEST INFRASTRUCTURE (tests/test_slab_gloo.py).
 
-One process per GPU.  Every rank's context owns a contiguous range of band rows (= a z-slab of equal band count,
-`psgsdf_comm_init`) and exposes the phases of a Gauss-Newton iteration plus the buffers that have to be exchanged
-between them (`psgsdf_mg_*`).  This module runs the phases and does the exchanges with torch.distributed:
-backend "nccl" (= RCCL over xGMI) on the GPUs, "gloo" in the CPU tests where the same code drives the oracle.
+The HIP engine runs its slab loop natively: its C++ host (psgradientsdf_amd/csrc/comm.hip, loop.hip, engine.hip) issues every exchange on
+the engine's stream over its own RCCL communicator, and exports no phase API.  What remains here is the same algorithm spelled out phase
+by phase over torch.distributed (gloo), driving one oracle context per rank, so that the partition, the halo ranges, the fused PCG with
+globally reduced sums and the energy bookkeeping can be checked on CPU with world sizes 2-4 against the single-rank oracle.
 
-Everything between two host reads stays on the device stream: a phase folds its scalars (energies, counts) into its
-own slots of the SCAL buffer, which is all-reduced and read ONCE per iteration; the only other host reads are the PCG
-stop checks (one per chunk of passes, as on a single GPU).
+Every rank's context owns a contiguous range of band rows (= a z-slab of equal band count) and exposes the phases of a Gauss-Newton
+iteration plus the buffers that have to be exchanged between them.  A phase folds its scalars (energies, counts) into its own slots of
+the SCAL buffer, which is all-reduced and read ONCE per iteration; the only other host reads are the PCG stop checks.
 
 Exchanges per iteration (all <= 1 MiB, latency-bound):
   all-reduce : per-frame light / pose rows (F x 64 doubles, twice), the 7 sums of a PCG pass (once per pass), the
                iteration's folded scalars (once)
   halo       : the row ranges the stencils of a slab actually reach into its two z-neighbours (`need_lo`/`need_hi` of
-               psgsdf_mg_info; a chain: <= 2 xGMI links per GPU): `blk` (14 planes, once), the PCG records (16 B/row,
-               once per pass) and `dist` (once).  Slabs whose stencils do not cross the cut exchange nothing.
+               mg_info): `blk` (14 planes, once), the PCG records (16 B/row, once per pass) and `dist` (once).
+               Slabs whose stencils do not cross the cut exchange nothing.
 """
 from __future__ import annotations
 
