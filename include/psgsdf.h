@@ -37,7 +37,7 @@ enum psgsdf_status {
     PSGSDF_OK = 0,
     PSGSDF_ERR_ARG = -1,        /* bad argument / call order                               */
     PSGSDF_ERR_DEVICE = -2,     /* HIP runtime error (no device, OOM, launch failure)       */
-    PSGSDF_ERR_UNSUPPORTED = -3,/* a setting the engine does not implement (e.g. reg albedo) */
+    PSGSDF_ERR_UNSUPPORTED = -3,/* a call the engine does not implement in this mode (e.g. frame fusion on a multi-rank context) */
     PSGSDF_ERR_STATE = -4,      /* called before the required earlier call                  */
     PSGSDF_ERR_COMM = -5        /* RCCL failure / no communicator on a multi-rank context    */
 };
@@ -64,7 +64,7 @@ typedef struct psgsdf_settings {
     int32_t loss;           /* psgsdf_loss                                                    */
     float lambda;           /* robust-loss scale                                              */
     float damping;          /* LM damping: H_ii *= (1+damping)                                */
-    float reg_weight_rho;   /* "reg albedo"   (single-rank only: the multi-rank phases reject it) */
+    float reg_weight_rho;   /* "reg albedo" */
     float reg_weight_n;     /* "reg norm"     Eikonal weight                                  */
     float reg_weight_l;     /* "reg laplacian"                                                */
     int32_t max_it;         /* "max iter"                                                     */

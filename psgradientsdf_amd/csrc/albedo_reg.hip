@@ -10,6 +10,8 @@ namespace psg {
 // (Optimizer.cpp:122-136 energy, :396-460 computeAlbedoGrad, :221-245 per-voxel Jacobian, :593-647 sparse Jr).
 // No shipped configuration enables it, so this path is written for clarity, not speed: the 3S x 3S system is never
 // assembled; Jr (<= 4 entries per row: the voxel and its three stencil neighbours) is applied matrix-free.
+// Multi-rank: every kernel but the table builder covers the slab's OWN rows [row0, row1); what a row reads of a neighbouring row
+// (albedo, `back`, J, res, the CG vectors p and t) is exchanged for the halo rows by the host (loop.hip, comm_halo).
 //   unknown index = (row, channel), stored channel-major: plane[ch * Spad + row]
 //   quirk (ref_quirks): the blue self-entry of Jr sits in the GREEN column of the same voxel (Optimizer.cpp:617)
 // ------------------------------------------------------------------------------------------
@@ -40,9 +42,9 @@ __global__ void __launch_bounds__(kBlock) k_areg_build(SweepArgs a) {
 #pragma clang fp contract(off)
     __shared__ double red[kBlock / 64];
     const Band& b = a.b; const AlbedoReg& ar = a.ar;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double e = 0;
-    if (j < b.S) {
+    if (j < a.row1) {
         const float vs_inv = a.grid.vs_inv;
         const int back = ar.back[j];
         float dir[3], G[3][3];
@@ -79,7 +81,7 @@ __global__ void __launch_bounds__(kBlock) k_areg_build(SweepArgs a) {
     block_part_store(e, PART(a, SC_AUX0), red);
 }
 void launch_areg_build(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_areg_build, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_areg_build, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 // (Jr v)(row, ch) for a vector v over the unknowns
 __device__ __forceinline__ float areg_jrow(const SweepArgs& a, const float* v, int j, int ch) {
@@ -118,8 +120,8 @@ __device__ __forceinline__ float areg_jtcol(const SweepArgs& a, const float* t, 
 // rhs = b_d + weight Jr^T res ; diag = (1 + damping) (H_d + weight diag(Jr^T Jr))     (PsOptimizer.cpp:95-105)
 __global__ void __launch_bounds__(kBlock) k_areg_system(SweepArgs a) {
     const Band& b = a.b; const AlbedoReg& ar = a.ar;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= b.S) return;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.row1) return;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const size_t u = (size_t)ch * b.Spad + j;
@@ -131,24 +133,24 @@ __global__ void __launch_bounds__(kBlock) k_areg_system(SweepArgs a) {
     }
 }
 void launch_areg_system(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_areg_system, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_areg_system, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 __global__ void __launch_bounds__(kBlock) k_areg_jx(SweepArgs a, const float* __restrict__ p, float* __restrict__ t) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= a.b.S) return;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.row1) return;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) t[(size_t)ch * a.b.Spad + j] = areg_jrow(a, p, j, ch);
 }
 void launch_areg_jx(const SweepArgs& a, const float* p, float* t, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_areg_jx, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, p, t);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_areg_jx, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, p, t);
 }
 // q = H p with H = H_d + weight Jr^T Jr and H.diagonal() += damping * H.diagonal(); partial p.q
 __global__ void __launch_bounds__(kBlock) k_areg_jt(SweepArgs a, const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ q) {
     __shared__ double red[kBlock / 64];
     const Band& b = a.b; const AlbedoReg& ar = a.ar;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double pq = 0;
-    if (j < b.S) {
+    if (j < a.row1) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             const size_t u = (size_t)ch * b.Spad + j;
@@ -160,14 +162,14 @@ __global__ void __launch_bounds__(kBlock) k_areg_jt(SweepArgs a, const float* __
     block_part_store(pq, PART(a, SC_AUX0), red);
 }
 void launch_areg_jt(const SweepArgs& a, const float* p, const float* t, float* q, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_areg_jt, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, p, t, q);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_areg_jt, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, p, t, q);
 }
 __global__ void __launch_bounds__(kBlock) k_areg_cg_init(SweepArgs a) {
     __shared__ double red[kBlock / 64];
     const Band& b = a.b; const AlbedoReg& ar = a.ar;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double bb = 0, rz = 0;
-    if (j < b.S) {
+    if (j < a.row1) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             const size_t u = (size_t)ch * b.Spad + j;
@@ -181,14 +183,14 @@ __global__ void __launch_bounds__(kBlock) k_areg_cg_init(SweepArgs a) {
     block_part_store(rz, PART(a, SC_AUX1), red);
 }
 void launch_areg_cg_init(const SweepArgs& a, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_areg_cg_init, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_areg_cg_init, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 __global__ void __launch_bounds__(kBlock) k_areg_cg_update(SweepArgs a, float alpha) {
     __shared__ double red[kBlock / 64];
     const Band& b = a.b; const AlbedoReg& ar = a.ar;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double rr = 0, rz = 0;
-    if (j < b.S) {
+    if (j < a.row1) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             const size_t u = (size_t)ch * b.Spad + j;
@@ -204,12 +206,12 @@ __global__ void __launch_bounds__(kBlock) k_areg_cg_update(SweepArgs a, float al
     block_part_store(rz, PART(a, SC_AUX1), red);
 }
 void launch_areg_cg_update(const SweepArgs& a, float alpha, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_areg_cg_update, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, alpha);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_areg_cg_update, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, alpha);
 }
 __global__ void __launch_bounds__(kBlock) k_areg_cg_dir(SweepArgs a, float beta) {
     const Band& b = a.b; const AlbedoReg& ar = a.ar;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= b.S) return;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.row1) return;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const size_t u = (size_t)ch * b.Spad + j;
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(kBlock) k_areg_cg_dir(SweepArgs a, float beta)
     }
 }
 void launch_areg_cg_dir(const SweepArgs& a, float beta, hipStream_t s) {
-    if (a.b.S > 0) hipLaunchKernelGGL(k_areg_cg_dir, dim3((a.b.S + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, beta);
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_areg_cg_dir, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, beta);
 }
 // updateAlbedo (OptimizerAux.cpp:120-150) with a solved step instead of b / H
 __global__ void __launch_bounds__(kBlock) k_apply_albedo_delta(SweepArgs a, const float* __restrict__ delta) {

@@ -8,7 +8,6 @@ extern "C" {
 int psgsdf_comm_unique_id(uint8_t id[128]) { return id ? comm_unique_id(id) : PSGSDF_ERR_ARG; }
 static int attach(psgsdf_ctx* c, int rank, int n_ranks) {
     if (!c || rank < 0 || n_ranks < 1 || rank >= n_ranks) return PSGSDF_ERR_ARG;
-    if (n_ranks > 1 && c->reg_r != 0.f) return fail(c, PSGSDF_ERR_UNSUPPORTED, "reg albedo is single-rank only");
     c->rank = rank; c->n_ranks = n_ranks; c->inited = false; c->have_volume = false;      // (the slab is chosen when the volume is uploaded)
     return PSGSDF_OK;
 }

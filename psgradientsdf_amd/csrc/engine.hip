@@ -232,20 +232,6 @@ int build_band(psgsdf_ctx* c) {
         b.col16 = reach <= 32767; b.reach = reach;
         if (const char* e = getenv("PSGSDF_PCG_COL16")) if (atoi(e) == 0) b.col16 = 0;
     }
-    if (c->areg_mem) { hipFree(c->areg_mem); c->areg_mem = nullptr; c->ar = AlbedoReg{}; }
-    if (c->reg_r != 0.f) {   // "reg albedo": stencil tables + matrix-free CG vectors over the 3S unknowns
-        if (c->n_ranks > 1) return fail(c, PSGSDF_ERR_UNSUPPORTED, "reg albedo is single-rank only");
-        const size_t planes = 3 + 1 + 9 + 12 + 3 + 8 * 3;
-        HIPCHK(c, hipMalloc(&c->areg_mem, planes * 4 * (size_t)Spad));
-        HIPCHK(c, hipMemsetAsync(c->areg_mem, 0, planes * 4 * (size_t)Spad, c->stream));
-        char* q = (char*)c->areg_mem;
-        auto tk = [&](size_t n) { void* r = q; q += n * 4 * (size_t)Spad; return r; };
-        AlbedoReg& ar = c->ar;
-        ar.anb = (int*)tk(3); ar.back = (int*)tk(1); ar.anrho = (float*)tk(9); ar.J = (float*)tk(12); ar.res = (float*)tk(3);
-        ar.rhs = (float*)tk(3); ar.diag = (float*)tk(3); ar.diag0 = (float*)tk(3); ar.x = (float*)tk(3); ar.r = (float*)tk(3); ar.p = (float*)tk(3); ar.q = (float*)tk(3); ar.t = (float*)tk(3);
-        SweepArgs at{}; at.b = b; at.ar = ar;
-        launch_areg_tables(c->dense, c->grid, at, c->stream);
-    }
     // row partition.  The band is sorted by linear index, z slowest, so the rows of the OWN planes [z0, z1) are one contiguous range
     // [row0, row1); the rows before it are the lower halo plane, the rows behind it the upper one (multi-rank only).
     {
@@ -284,6 +270,21 @@ int build_band(psgsdf_ctx* c) {
             // the stencil-direction bits of the halo rows are static and depend on the plane BEYOND the halo: take them from their owner
             int hrc = comm_halo(c, b.dirb, 1, 1); if (hrc) return hrc;
         } else c->S_global = S;
+    }
+    if (c->areg_mem) { hipFree(c->areg_mem); c->areg_mem = nullptr; c->ar = AlbedoReg{}; }
+    if (c->reg_r != 0.f) {   // "reg albedo": stencil tables + matrix-free CG vectors over the 3S unknowns
+        const size_t planes = 3 + 1 + 9 + 12 + 3 + 8 * 3;
+        HIPCHK(c, hipMalloc(&c->areg_mem, planes * 4 * (size_t)Spad));
+        HIPCHK(c, hipMemsetAsync(c->areg_mem, 0, planes * 4 * (size_t)Spad, c->stream));
+        char* q = (char*)c->areg_mem;
+        auto tk = [&](size_t n) { void* r = q; q += n * 4 * (size_t)Spad; return r; };
+        AlbedoReg& ar = c->ar;
+        ar.anb = (int*)tk(3); ar.back = (int*)tk(1); ar.anrho = (float*)tk(9); ar.J = (float*)tk(12); ar.res = (float*)tk(3);
+        ar.rhs = (float*)tk(3); ar.diag = (float*)tk(3); ar.diag0 = (float*)tk(3); ar.x = (float*)tk(3); ar.r = (float*)tk(3); ar.p = (float*)tk(3); ar.q = (float*)tk(3); ar.t = (float*)tk(3);
+        SweepArgs at{}; at.b = b; at.ar = ar;
+        launch_areg_tables(c->dense, c->grid, at, c->stream);
+        // which side a halo row's stencil takes depends on the plane beyond the halo: its owner knows
+        if (int hrc = comm_halo(c, ar.back, 1, 1)) return hrc;
     }
     // per-frame observation lists of the owned rows (counts -> host prefix -> fill)
     {

@@ -1,6 +1,7 @@
 // loop.hip -- the solves and the alternation loop: launch shape and host driver of the fused PCG, the regularised albedo solve,
 // the four sub-steps (sweep + solve + update), the control flow of psgsdf_iterate / psgsdf_optimize, the 2x refinement.
 #include "engine_internal.h"
+#include <climits>
 
 namespace psge {
 
@@ -152,9 +153,10 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
 // "reg albedo": mean over the band of sum_c ||grad rho_c|| (Optimizer.cpp:122-136); also refreshes the Jacobian planes
 int albedo_reg_energy(psgsdf_ctx* c, double* Er) {
     SweepArgs a = make_args(c, 0);
+    int rc = comm_halo(c, c->band.rho[0], 3, 1); if (rc) return rc;      // multi-rank: the stencils of the rows at a cut read the neighbour slab's albedo
     launch_areg_build(a, c->stream);
     const int slots[1] = {SC_AUX0}; double s[1];
-    int rc = read_parts(c, slots, 1, s); if (rc) return rc;
+    if ((rc = read_parts(c, slots, 1, s))) return rc;
     c->er_sum = s[0]; *Er = band_mean(c, s[0]);
     return 0;
 }
@@ -163,21 +165,27 @@ int albedo_reg_energy(psgsdf_ctx* c, double* Er) {
 // configuration enables this term.  The step is left in ar.x.
 int albedo_reg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* ok_out, double* err_out) {
     const AlbedoReg& ar = a.ar;
+    // multi-rank: Jr^T reads the Jacobian rows, residuals and CG vectors of the rows across a cut -> halo exchanges (no-ops on one rank);
+    // the sums go through read_parts, i.e. one all-reduce per read-back
+    int rc = comm_halo(c, c->band.rho[0], 3, 1); if (rc) return rc;
     launch_areg_build(a, c->stream);
+    if ((rc = comm_halo(c, ar.J, 15, 1))) return rc;          // J (12 planes) and res (3 planes) are adjacent
     launch_areg_system(a, c->stream);
     launch_areg_cg_init(a, c->stream);
     const int two[2] = {SC_AUX0, SC_AUX1}, one[1] = {SC_AUX0}; double s[2];
-    int rc = read_parts(c, two, 2, s); if (rc) return rc;
+    if ((rc = read_parts(c, two, 2, s))) return rc;
     const float rhsN = (float)s[0];
     *iters_out = 0; *ok_out = 1; *err_out = 0;
     if (rhsN == 0.f) return 0;
     const float thr = fmaxf(FLT_EPSILON * FLT_EPSILON * rhsN, FLT_MIN);
     float res2 = rhsN, absNew = (float)s[1];
-    const int maxIters = c->set.cg_max_it > 0 ? c->set.cg_max_it : 6 * c->band.S;
+    const int maxIters = c->set.cg_max_it > 0 ? c->set.cg_max_it : (int)std::min<long long>(6 * c->S_global, INT_MAX);
     int i = 0;
     if (res2 >= thr) {
         while (i < maxIters) {
+            if ((rc = comm_halo(c, ar.p, 3, 1))) return rc;
             launch_areg_jx(a, ar.p, ar.t, c->stream);
+            if ((rc = comm_halo(c, ar.t, 3, 1))) return rc;
             launch_areg_jt(a, ar.p, ar.t, ar.q, c->stream);
             if ((rc = read_parts(c, one, 1, s))) return rc;
             const float alpha = absNew / (float)s[0];

@@ -16,8 +16,9 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
     import torch
     from psgradientsdf_amd import capi, synth
     torch.cuda.set_device(0)
+    model, _, opt = model.partition("+")
     sc = synth.make_scene(N=N, F=6, W=160, H=120, model=model)
-    st = capi.default_settings(sc.model_id)
+    st = capi.default_settings(sc.model_id, **({"reg_weight_rho": 0.02} if opt == "reg" else {}))      # "+reg": the albedo regulariser ("reg albedo")
     eng = capi.load_engine(sc, sc.K, st, 0)
     tr = None
     if transport == "rccl":

@@ -46,15 +46,18 @@ def stitch(res, key):
     return out
 
 
-@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH2", 2, "gloo")])
+@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH2", 2, "gloo"), ("SH1+reg", 2, "gloo")])
 def test_native_slab_loop_matches_single_context(built, tmp_path, model, world, transport):
     N, n_iters = 40, 2
     # "rccl-perpass": the PCG as the multi-rank path runs it (one kernel, one fold and one RCCL all-reduce of 7 doubles per pass) -- a one-rank
     # communicator would otherwise use the persistent single-kernel solve, which needs no exchange
     extra = {"PSGSDF_PCG_PERSIST": "0"} if transport == "rccl-perpass" else None
     res = run_ranks(tmp_path, model, world, transport.split("-")[0], "iterate", N, n_iters, extra)
+    # "+reg": with the albedo regulariser -- the matrix-free CG over 3S unknowns whose Jr / Jr^T stencils cross the cut (halo exchanges
+    # of J, res, p and t; every dot product an all-reduce)
+    model, _, opt = model.partition("+")
     sc = synth.make_scene(N=N, F=6, W=160, H=120, model=model)
-    st = capi.default_settings(sc.model_id)
+    st = capi.default_settings(sc.model_id, **({"reg_weight_rho": 0.02} if opt == "reg" else {}))
     ref = capi.load_engine(sc, sc.K, st, 0); ref.load_scene(sc)
     ref.init_albedo(); e0 = ref.normalize_weights()
     recs = ref.iterate(capi.ALL, n_iters)
@@ -70,7 +73,7 @@ def test_native_slab_loop_matches_single_context(built, tmp_path, model, world, 
         if world > 1:
             assert halo > 0 and (need_lo > 0 or need_hi > 0)        # the sphere is cut through: stencils cross the cut, halos really move
             assert rows < 0.8 * S                                     # a rank holds its slab (+ halo planes), not the whole band
-            assert got["ncoll"] > 20
+            assert got["ncoll"] > (60 if opt == "reg" else 20)        # reg: four exchanges per CG iteration of the regularised albedo solve
             held = ~np.isnan(got["dist"])
             assert held.sum() == (z1 - z0) * N * N and held[z0 * N * N:(z1 * N * N)].all()      # exactly its own planes came back
         else:
