@@ -434,37 +434,40 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         const float4* __restrict__ rin = b.rec[(k + 1) & 1];
         float4* __restrict__ rout = b.rec[k & 1];
         double A1[R], A2[R], A3[R];
+        // the 18 neighbour records of a row in two batches of 9, software-pipelined ACROSS the rows of the thread: two batches (72 registers)
+        // are in flight at any time -- batch t+2 is requested into the registers batch t has just been consumed from, so a wave's memory
+        // requests never run dry while it converts and multiplies (one row at a time did: gather stage 4.1-5.1 -> 3.5-3.8 us)
+        float4 ob[2][9];
+        auto issue = [&](int t) {
+            const int u = t >> 1, j0 = (t & 1) * 9;
 #pragma unroll
-        for (int u = 0; u < R; ++u) {
+            for (int j = 0; j < 9; ++j) { const int jj = j0 + j; const int pk = (int)cp[u][jj >> 1]; ob[t & 1][j] = rin[row[u] + ((jj & 1) ? (pk >> 16) : ((pk << 16) >> 16))]; }
+        };
+        issue(0);
+        issue(1);
+        double a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+        for (int t = 0; t < 2 * R; ++t) {
+            const int u = t >> 1, j0 = (t & 1) * 9;
             const float* hrow = hs + (size_t)u * kNQ * kSolveThreads + tid;
-            double a1, a2, a3;
-            { const double hq = (double)hrow[0], iv = (double)me[u].w; a1 = hq * (iv * (double)me[u].x); a2 = hq * (iv * (double)me[u].y); a3 = hq * (double)me[u].z; }
-            // the 18 neighbour records in two batches of 9 (36 registers in flight instead of 72): the second is issued before the first is consumed
-            float4 o0[9], o1[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) { const int pk = (int)cp[u][j >> 1]; o0[j] = rin[row[u] + ((j & 1) ? (pk >> 16) : ((pk << 16) >> 16))]; }
-#pragma unroll
-            for (int j = 9; j < 18; ++j) { const int pk = (int)cp[u][j >> 1]; o1[j - 9] = rin[row[u] + ((j & 1) ? (pk >> 16) : ((pk << 16) >> 16))]; }
+            if (!(t & 1)) { const double hq = (double)hrow[0], iv = (double)me[u].w; a1 = hq * (iv * (double)me[u].x); a2 = hq * (iv * (double)me[u].y); a3 = hq * (double)me[u].z; }
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
-                const double hq = (double)hrow[(j + 1) * kSolveThreads], iv = (double)o0[j].w;
-                a1 += hq * (iv * (double)o0[j].x); a2 += hq * (iv * (double)o0[j].y); a3 += hq * (double)o0[j].z;
+                const double hq = (double)hrow[(j0 + j + 1) * kSolveThreads], iv = (double)ob[t & 1][j].w;
+                a1 += hq * (iv * (double)ob[t & 1][j].x); a2 += hq * (iv * (double)ob[t & 1][j].y); a3 += hq * (double)ob[t & 1][j].z;
             }
-#pragma unroll
-            for (int j = 9; j < 18; ++j) {
-                const double hq = (double)hrow[(j + 1) * kSolveThreads], iv = (double)o1[j - 9].w;
-                a1 += hq * (iv * (double)o1[j - 9].x); a2 += hq * (iv * (double)o1[j - 9].y); a3 += hq * (double)o1[j - 9].z;
-            }
-            asm volatile("" : "+v"(a1), "+v"(a2), "+v"(a3));      // the three sums exist HERE: without this the compiler sinks the consumption of the
-            A1[u] = a1; A2[u] = a2; A3[u] = a3;                    // 18 gathered records below the wait for the global sums (72 registers live across it)
-            __builtin_amdgcn_sched_barrier(0);      // one row's 18 gathers in flight at a time (register budget)
+            asm volatile("" : "+v"(a1), "+v"(a2), "+v"(a3));      // the sums exist HERE: without this the compiler sinks the consumption of the
+            if (t & 1) { A1[u] = a1; A2[u] = a2; A3[u] = a3; }     // gathered records below the wait for the global sums (72 registers live across it)
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < 2 * R) issue(t + 2);
+            __builtin_amdgcn_sched_barrier(0);
         }
         SOLVE_STAMP(2);
         if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 1024 + lb] = (double)wall_clock64();            // gathers of pass 9 done
         if (k > 0) {
             // ---- C: the seven sums of pass k-1 of EVERY workgroup (data and tag in one granule: no fence needed for them)
-            // (requesting these granules ahead of time, next to the gathers, measured SLOWER: the sc1 loads queue in front of / behind the
-            // records and lengthen the gather stage by 1.5-2 us; profiles/r02_notes.md)
+            // (requesting these granules ahead of time -- in front of the gathers or behind the last batch -- measured SLOWER: the sc1 loads
+            // lengthen the gather stage by 1-2 us, and the stage is a wait for the late workgroups, not a load latency; profiles/r02_notes.md)
             double v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = 0.0;
