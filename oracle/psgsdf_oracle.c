@@ -17,8 +17,10 @@
  * the parity tolerances): observation sums per voxel in float before the double reductions;
  * block-diagonal light / pose systems solved per block by LDL^T in double instead of one global
  * Jacobi-PCG; the distance PCG's fused recurrences (one reduction per pass); FMA contraction of
- * the per-observation algebra; v_rcp_f32 in the Cauchy weight, __logf in the Cauchy loss; float
- * bilinear weights; out-of-bounds reads of the reference clamped.  NOT a deviation any more:
+ * the per-observation algebra; v_rcp_f32 in the Cauchy weight, v_log_f32 x ln2 in the Cauchy loss; float
+ * bilinear weights; the Jacobian chain image_grad * pi_grad * R^T * d(point) contracted from the right
+ * (channel-independent rows first) instead of a 3x3 product per channel; out-of-bounds reads of the
+ * reference clamped.  NOT a deviation any more:
  * the Jacobians' second projection fx*px/pz (PsOptimizerJa.cpp:70-76) is reproduced by both.
  *
  * Arithmetic follows the reference: float32 per observation, evaluated in the reference's

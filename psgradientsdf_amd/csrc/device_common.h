@@ -311,7 +311,6 @@ template <bool GRAD>
 __device__ __forceinline__ void sample_cell(const float* base, int frame, bool idx32, const Cam& cam, float m_col, float n_row, float mj_col, float nj_row, float* I, float* gu, float* gv) {
     const float m = n_row, n = m_col;  // names of Auxilary.h: m = row, n = column
     int x = (int)floorf(m), y = (int)floorf(n);
-    const float* img = base + (size_t)frame * cam.H * cam.W * 3;   // only the rare border path below uses it
     if ((x + 1) < cam.H && (y + 1) < cam.W) {
         float a00[3], a01[3], a10[3], a11[3];
         if (idx32) {
@@ -321,13 +320,14 @@ __device__ __forceinline__ void sample_cell(const float* base, int frame, bool i
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { a00[ch] = p00[ch]; a01[ch] = p00[3 + ch]; a10[ch] = p10[ch]; a11[ch] = p10[3 + ch]; }
         } else {
-            const float* p00 = img + ((size_t)x * cam.W + y) * 3;
+            const float* p00 = base + ((size_t)frame * cam.H * cam.W + (size_t)x * cam.W + y) * 3;
             const float* p10 = p00 + (size_t)cam.W * 3;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { a00[ch] = p00[ch]; a01[ch] = p00[3 + ch]; a10[ch] = p10[ch]; a11[ch] = p10[3 + ch]; }
         }
         interp_taps<GRAD>(a00, a01, a10, a11, m - (float)x, n - (float)y, nj_row - (float)x, mj_col - (float)y, I, gu, gv);
     } else {
+        const float* img = base + (size_t)frame * cam.H * cam.W * 3;   // (64-bit multiply-adds issue at quarter rate: keep them on this rare path)
         auto tex = [&](int row, int col, float* o) { const float* q = pix(img, cam, row, col); o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; };
         sample_border<GRAD>(tex, cam, x, y, nj_row, mj_col, I, gu, gv);
     }
@@ -509,17 +509,21 @@ __device__ __forceinline__ float laplacian(const Band& b, int j, float vs_inv) {
         for (uint64_t _m = (b).vis[(size_t)_w * (b).Spad + (j)]; _m; _m &= _m - 1)            \
             if (int f = 64 * _w + __builtin_ctzll(_m); f < (F))
 
-// G = image_grad(3x2) * pi_grad(2x3), PsOptimizerJa.cpp:78-90
-__device__ __forceinline__ void image_pi_grad(const Cam& cam, const Proj& pr, const float* gu, const float* gv, float* G) {
-    const float z_inv = pr.z_inv;
-    float z_inv_sq = z_inv * z_inv;
-    float p00 = cam.fx * z_inv, p02 = -cam.fx * pr.p[0] * z_inv_sq, p11 = cam.fy * z_inv, p12 = -cam.fy * pr.p[1] * z_inv_sq;
+// The chain of PsOptimizerJa.cpp:78-100 -- image_grad(3x2) * pi_grad(2x3) * R^T * d(point) -- contracted from the RIGHT: with
+//   pi_grad = [a; b],  a = (fx/z, 0, -fx x/z^2),  b = (0, fy/z, -fy y/z^2),   image_grad row of channel c = (gu_c, gv_c)
+// the row of channel c is gu_c (a R^T) + gv_c (b R^T): U = a R^T and V = b R^T are channel-independent 3-vectors, so a derivative
+// along a direction dx is gu_c (U . dx) + gv_c (V . dx).  The reference forms the 3x3 product per channel first (left to right,
+// structural zeros included); same value up to the rounding of the regrouped products, 64 instead of 87 instructions per
+// observation in the distance sweep (engine deviation 7).
+struct PiRows { float p00, p02, p11, p12; };
+__device__ __forceinline__ PiRows pi_rows(const Cam& cam, const Proj& pr) {
+    const float z_inv = pr.z_inv, z_inv_sq = z_inv * z_inv;
+    PiRows o; o.p00 = cam.fx * z_inv; o.p02 = -cam.fx * pr.p[0] * z_inv_sq; o.p11 = cam.fy * z_inv; o.p12 = -cam.fy * pr.p[1] * z_inv_sq;
+    return o;
+}
+__device__ __forceinline__ void pi_rows_world(const PiRows& pi, const float* R, float* U, float* V) {      // U = a R^T, V = b R^T
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        G[ch * 3 + 0] = gu[ch] * p00 + gv[ch] * 0.0f;
-        G[ch * 3 + 1] = gu[ch] * 0.0f + gv[ch] * p11;
-        G[ch * 3 + 2] = gu[ch] * p02 + gv[ch] * p12;
-    }
+    for (int k = 0; k < 3; ++k) { U[k] = pi.p00 * R[k * 3 + 0] + pi.p02 * R[k * 3 + 2]; V[k] = pi.p11 * R[k * 3 + 1] + pi.p12 * R[k * 3 + 2]; }
 }
 __device__ __forceinline__ int sym4(int a, int b) {   // index into the 10 upper-triangular entries
     if (a > b) { int t = a; a = b; b = t; }

@@ -82,15 +82,14 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
             const ProjJ pj = project_jac(pr, a.cam);      // distJacobian projects again, with its own in-image test (PsOptimizerJa.cpp:180-190)
             sample<true, IMG>(a.im, f, a.cam, pr.m, pr.n, pj.mj, pj.nj, I, gu, gv);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
-            float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
-            float GRt[9];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) GRt[ch * 3 + k] = (G[ch * 3 + 0] * fp.R[k * 3 + 0] + G[ch * 3 + 1] * fp.R[k * 3 + 1]) + G[ch * 3 + 2] * fp.R[k * 3 + 2];
+            float U[3], V[3]; pi_rows_world(pi_rows(a.cam, pr), fp.R, U, V);
             float J[4][3];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) mul3(GRt, dx[q], J[q]);   // dI_q
+            for (int q = 0; q < 4; ++q) {                         // dI_q = image_grad pi_grad R^T dx_q, contracted from the right (device_common.h)
+                const float sq = dot3(U, dx[q]), tq = dot3(V, dx[q]);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) J[q][ch] = gu[ch] * sq + gv[ch] * tq;
+            }
             if (!LED) {
                 // shading term rho_c * (l . dSH/dd_q): the frame's light is contracted with the (per-voxel) normal derivative ONCE per
                 // stencil slot and then scaled by the three albedos, instead of forming rho_c * l per channel first (the reference's

@@ -348,21 +348,21 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
         const ProjJ pj = project_jac(pr, a.cam);      // poseJacobian projects again, with its own in-image test (PsOptimizerJa.cpp:70-76)
         sample<true, IMG>(img, 0, a.cam, pr.m, pr.n, pj.mj, pj.nj, I, gu, gv);
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
-        float G[9]; image_pi_grad(a.cam, pr, gu, gv, G);
+        // J_c = image_grad_c pi_grad [-R^T | skew(p)] (PsOptimizerJa.cpp:78-100), contracted from the right (device_common.h pi_rows):
+        // J_c = gu_c [-U | a skew(p)] + gv_c [-V | b skew(p)] with the channel-independent rows written out (structural zeros dropped)
+        const PiRows pi = pi_rows(a.cam, pr);
+        float U[3], V[3]; pi_rows_world(pi, fp.R, U, V);
+        const float* p = pr.p;
+        const float AS[3] = {-(pi.p02 * p[1]), pi.p02 * p[0] - pi.p00 * p[2], pi.p00 * p[1]};
+        const float BS[3] = {pi.p11 * p[2] - pi.p12 * p[1], pi.p12 * p[0], -(pi.p11 * p[0])};
         float J[18];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                float s = (G[ch * 3 + 0] * fp.R[k * 3 + 0] + G[ch * 3 + 1] * fp.R[k * 3 + 1]) + G[ch * 3 + 2] * fp.R[k * 3 + 2];
-                J[ch * 6 + k] = -s;
+                J[ch * 6 + k] = -(gu[ch] * U[k] + gv[ch] * V[k]);
+                J[ch * 6 + 3 + k] = gu[ch] * AS[k] + gv[ch] * BS[k];
             }
-        const float* p = pr.p;
-        float sk[9] = {0, -p[2], p[1], p[2], 0, -p[0], -p[1], p[0], 0};
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) J[ch * 6 + 3 + k] = (G[ch * 3 + 0] * sk[0 * 3 + k] + G[ch * 3 + 1] * sk[1 * 3 + k]) + G[ch * 3 + 2] * sk[2 * 3 + k];
         if (LED) {
             float pn = norm3(p); double pd = (double)pn; float l3 = (float)(pd * pd * pd);
 #pragma unroll
