@@ -185,7 +185,7 @@ static int set_keyframes_impl(psgsdf_ctx* c, int n_frames, const int32_t* frame_
                               int width, int height, const float* poses) {
     if (!c || n_frames <= 0 || !frame_idx || (!rgb_f32 && !rgb_u8) || !poses || width <= 1 || height <= 1) return fail(c, PSGSDF_ERR_ARG, "set_keyframes: bad argument");
     if (n_frames > kMaxFramesLds) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d keyframes", kMaxFramesLds);
-    if (rgb_u8 && (size_t)n_frames * width * height >= ((size_t)1 << 30)) return fail(c, PSGSDF_ERR_UNSUPPORTED, "8-bit keyframes: at most 2^30 pixels");
+    if (rgb_u8 && ((size_t)n_frames * width * height >= ((size_t)1 << 30) || (size_t)n_frames * height >= ((size_t)1 << 24))) return fail(c, PSGSDF_ERR_UNSUPPORTED, "8-bit keyframes: at most 2^30 pixels and 2^24 image rows");
     HIPCHK(c, hipSetDevice(c->device));
     hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->acc_frame);
     c->frame_idx = nullptr; c->img = nullptr; c->img8 = nullptr; c->frames = nullptr; c->acc_frame = nullptr;

@@ -215,6 +215,10 @@ __device__ __forceinline__ void fold_pending(const SweepArgs& a, double* red /*[
 
 // frame records (pose, light) of all keyframes staged in dynamic LDS: F * 96 B (<= 60 KiB, F <= kMaxFramesLds)
 extern __shared__ __align__(16) unsigned char psg_dyn_smem[];
+// record of frame f in the LDS copy: a 24-bit multiply for the offset (v_mul_u32_u24, full rate; f * sizeof through v_mul_lo_u32 is quarter rate)
+__device__ __forceinline__ const FrameP& frame_at(const FrameP* sf, int f) {
+    return *reinterpret_cast<const FrameP*>(reinterpret_cast<const char*>(sf) + __umul24((unsigned)f, (unsigned)sizeof(FrameP)));
+}
 __device__ __forceinline__ void load_frames(FrameP* sf, const FrameP* frames, int F) {
     const float* src = (const float*)frames; float* dst = (float*)sf;
     for (int i = threadIdx.x; i < F * (int)(sizeof(FrameP) / 4); i += blockDim.x) dst[i] = src[i];
@@ -304,6 +308,13 @@ __device__ __forceinline__ void sample_border(const TEX& tex, const Cam& cam, in
         }
     }
 }
+// a * b + c with 24-bit a and a wavefront-uniform 24-bit b: v_mad_u32_u24 (full rate).  Written as inline assembly because the compiler turns
+// __umul24(a, b) + c into v_mad_u64_u32, which issues at quarter rate like v_mul_lo_u32.
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b_uniform, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(__builtin_amdgcn_readfirstlane(b_uniform)), "v"(c));
+    return r;
+}
 // float RGB images [F][H][W][3].
 // idx32: the whole stack is < 4 GiB, so a tap's byte offset fits 32 bits and the loads take the scalar-base form (one address
 // register, no 64-bit integer multiply-adds, which issue at quarter rate and made up ~10 % of a sweep's instruction slots).
@@ -314,7 +325,10 @@ __device__ __forceinline__ void sample_cell(const float* base, int frame, bool i
     if ((x + 1) < cam.H && (y + 1) < cam.W) {
         float a00[3], a01[3], a10[3], a11[3];
         if (idx32) {
-            const unsigned e = (((unsigned)frame * (unsigned)cam.H + (unsigned)x) * (unsigned)cam.W + (unsigned)y) * 3u;
+            // 24-bit multiplies (v_mad_u32_u24, full rate; 32-bit v_mul_lo_u32 / v_mad_u64_u32 issue at quarter rate and were 15 % of an
+            // energy sweep's issue cycles): F * H and 3 W are < 2^24 (engine.hip: idx32), the products fit 32 bits
+            const unsigned rowi = (__builtin_constant_p(frame) && frame == 0) ? (unsigned)x : mad24((unsigned)frame, (unsigned)cam.H, (unsigned)x);
+            const unsigned e = mad24(rowi, 3u * (unsigned)cam.W, 3u * (unsigned)y);
             const float* p00 = (const float*)((const char*)base + (size_t)(e << 2));
             const float* p10 = (const float*)((const char*)base + (size_t)((e + 3u * (unsigned)cam.W) << 2));
 #pragma unroll
@@ -355,7 +369,8 @@ __device__ __forceinline__ void sample_u8_cell(const unsigned* base, float scale
     const float m = n_row, n = m_col;
     int x = (int)floorf(m), y = (int)floorf(n);
     if ((x + 1) < cam.H && (y + 1) < cam.W) {
-        const unsigned e = ((unsigned)frame * (unsigned)cam.H + (unsigned)x) * (unsigned)cam.W + (unsigned)y;      // < 2^30 pixels (engine.hip checks)
+        const unsigned rowi = (__builtin_constant_p(frame) && frame == 0) ? (unsigned)x : mad24((unsigned)frame, (unsigned)cam.H, (unsigned)x);
+        const unsigned e = mad24(rowi, (unsigned)cam.W, (unsigned)y);      // < 2^30 pixels, < 2^24 image rows (api.hip checks)
         const unsigned* p0 = (const unsigned*)((const char*)base + (size_t)(e << 2));
         const unsigned* p1 = (const unsigned*)((const char*)base + (size_t)((e + (unsigned)cam.W) << 2));
         const unsigned t00 = p0[0], t01 = p0[1], t10 = p1[0], t11 = p1[1];

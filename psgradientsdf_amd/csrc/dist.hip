@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = 0;
         FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
-            const FrameP& fp = sf[f];
+            const FrameP& fp = frame_at(sf, f);
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], gu[3], gv[3], ren[3];

@@ -36,7 +36,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     SweepArgs a{};
     a.b = c->band; a.frames = c->frames; a.F = c->F; a.cam = c->cam; a.grid = c->grid;
     a.im.f32 = c->img; a.im.u8 = c->img8; a.im.scale = c->img_scale;
-    a.im.idx32 = (size_t)c->F * c->cam.W * c->cam.H * 12 < ((size_t)1 << 32);
+    a.im.idx32 = (size_t)c->F * c->cam.W * c->cam.H * 12 < ((size_t)1 << 32) && (size_t)c->F * c->cam.H < ((size_t)1 << 24) && 3 * (size_t)c->cam.W < ((size_t)1 << 24);   // (24-bit index multiplies, device_common.h sample_cell)
     a.rob.loss = c->set.loss; a.rob.lambda = c->set.lambda; a.rob.lambda_sq = c->set.lambda * c->set.lambda; a.rob.inv_lambda = 1.0f / c->set.lambda;
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
     a.acc.fpart = c->frame_part; a.acc.fcap = c->frame_cap; a.acc.fdone = c->frame_done;

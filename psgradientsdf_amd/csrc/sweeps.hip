@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(kBlock) k_init_albedo(SweepArgs a) {
     float xs[3] = {p0.x, p0.y, p0.z};
     int count = 0; float rho[3] = {0, 0, 0};
     FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
-        Proj pr = project(xs, sf[f], a.cam);
+        Proj pr = project(xs, frame_at(sf, f), a.cam);
         if (!pr.ok) continue;
         float I[3];
         sample<false>(a.im, f, a.cam, pr.m, pr.n, I, nullptr, nullptr);
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
         float shfd[kMaxBasis];
         if (!ModelTraits<MODEL>::LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
         FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
-            const FrameP& fp = sf[f];
+            const FrameP& fp = frame_at(sf, f);
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], ren[3];
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
         float Hd[3] = {0, 0, 0}, bd[3] = {0, 0, 0};
         float Ef = 0.f; int nobs_i = 0;
         FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
-            const FrameP& fp = sf[f];
+            const FrameP& fp = frame_at(sf, f);
             Proj pr = project(v.xs, fp, a.cam);
             if (!pr.ok) continue;
             float I[3], ren[3], J[3];
