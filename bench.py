@@ -222,7 +222,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms,
                            "launches_timed": int(watched[1]), "avg_working_launch_ms": avg_work_ms, "working_launch_fraction": working_frac,
-                           "bytes_per_unit": "SURVEY 8d algorithmic figure (PCG: 124 B per band voxel per pass; pcg_solve runs cg_iters + 1 passes per launch and keeps the matrix on chip: its HBM-side traffic is far below the algorithmic bytes)",
+                           "bytes_per_unit": "SURVEY 8d algorithmic figure (PCG: 124 B per band voxel per pass; pcg_solve runs cg_iters + 1 passes per launch and keeps the matrix on chip: its HBM-side traffic is far below the algorithmic bytes; the launch also assembles the distance system from the sweep's voxel blocks, which is NOT counted here)",
                            "storage_bytes_per_launch": 152 * S if dom in ("pcg_pass", "pcg_solve") else None,
                            "traffic_source": traffic_src}
         # whole-iteration algorithmic bytes (SURVEY.md §8d formula) for reference

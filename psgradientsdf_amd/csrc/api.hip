@@ -24,6 +24,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_FUSE_ALBEDO")) c->fuse_albedo = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FUSE_PCG_INIT")) c->fuse_pcg_init = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_PERSIST")) c->pcg_persist = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_PCG_FUSE_ASM")) c->pcg_fuse_asm = atoi(e) != 0;
     if (hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cu = 0;
     c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l; c->reg_r = settings->reg_weight_rho;
     GridP& g = c->grid;
@@ -37,7 +38,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     bool ok = hipStreamCreate(&c->stream) == hipSuccess
         && hipMalloc(&c->pcg_sc, sizeof(double) * (16 + 8 * (size_t)kPcgMaxBlocks)) == hipSuccess   // fs[0..1] + stage stamps of the timing hook
         && hipMalloc(&c->pcg_part, sizeof(double) * 14 * kPcgMaxBlocks) == hipSuccess
-        && hipMalloc(&c->pcg_gran, sizeof(double) * 2 * 7 * kSolveMaxBlocksHost) == hipSuccess
+        && hipMalloc(&c->pcg_gran, sizeof(double) * 2 * kSolveGranPlanes * kSolveMaxBlocksHost) == hipSuccess
         && hipMalloc(&c->mg_scal, sizeof(double) * kMgScal) == hipSuccess && hipMalloc(&c->mg_ext, sizeof(double) * 8) == hipSuccess
         && hipMalloc(&c->d_need, 2 * sizeof(int)) == hipSuccess
         && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess

@@ -83,7 +83,7 @@ int psgsdf_debug_time_pcg_solve(psgsdf_ctx* c, int passes, int reps, double* ms_
     if (!cgf_solve_shape(c, &G, &rows)) return fail(c, PSGSDF_ERR_UNSUPPORTED, "the persistent solve does not apply to this context");
     shape[0] = G; shape[1] = rows;      // rows = rows per workgroup
     SweepArgs a = make_args(c, c->reg_l != 0.f);
-    a.pcg_fuse_init = 1; a.pcg_init_blocks = band_blocks(c); a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * 7 * kSolveMaxBlocksHost;
+    a.pcg_fuse_init = 1; a.pcg_init_blocks = band_blocks(c); a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kSolveGranPlanes * kSolveMaxBlocksHost; a.pcg_asm = c->pcg_fuse_asm ? 1 : 0;
     hipEvent_t e0, e1; HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
     float total = 0;
     for (int r = 0; r < reps + 1; ++r) {

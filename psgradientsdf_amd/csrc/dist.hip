@@ -176,6 +176,11 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
     }
     block_part_store(E, PART(a, SC_ENERGY), red);
     block_part_store(nobs, PART(a, SC_NOBS), red);
+    if (a.pcg_asm && a.pcg_gran) {   // the persistent solve right behind this sweep assembles the system itself: no tag of an earlier solve may survive
+        if (blockIdx.x == 0 && threadIdx.x == 0) { a.pcg_fs[1] = 0.0; a.pcg_fs[2] = 0.0; a.pcg_fs[3] = 0.0; }
+        const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+        for (int q = gid; q < a.pcg_gran_n; q += gridDim.x * blockDim.x) a.pcg_gran[q] = 0.0;
+    }
 }
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;

@@ -135,6 +135,7 @@ struct SweepArgs {
     FoldReq fold;             // n = 0: nothing pending
     AlbedoReg ar;             // ar.anb == nullptr unless "reg albedo" != 0
     double* pcg_part; double* pcg_fs;   // fused PCG state (pcg.hip)
+    int pcg_asm;              // persistent solve assembles the distance system itself (no k_assemble launch in front of it)
     double* pcg_gran; int pcg_gran_n;   // persistent solve: the tagged per-workgroup sums, zeroed by the assembly kernel when non-null
     int pcg_fuse_init;        // assembly kernel also initialises the PCG (x = 0, records of pass -1, |b|^2 partials): no k_cgf_init launch
     int pcg_init_blocks;      // workgroups that wrote the |b|^2 partials (0: the pass kernel's own grid)
@@ -178,7 +179,9 @@ void launch_assemble(const SweepArgs& a, hipStream_t s);
 void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s);
 void launch_cgf_pass(const SweepArgs& a, double* fs, double* part, int G, int rows, int k, int kmax, double* mb, hipStream_t s, int ablate = 0);
 void launch_cgf_sum(double* part, int G, int k, double* out, hipStream_t s);
-// the whole solve as one persistent kernel (pcg.hip: k_cgf_solve); gran = [2][7][kSolveMaxBlocksHost] tagged per-workgroup sums, zeroed by the assembly kernel
+// the whole solve as one persistent kernel (pcg.hip: k_cgf_solve); gran = [2][kSolveGranPlanes][kSolveMaxBlocksHost] tagged per-workgroup sums (plane 7: |b|^2 of
+// the fused assembly in buffer 0, its 'records are out' flag in buffer 1), zeroed by the kernel in front (assembly kernel / distance sweep)
+constexpr int kSolveGranPlanes = 8;
 constexpr int kSolveThreadsHost = 512, kSolveMaxBlocksHost = 256, kSolveMaxRowsHost = 4, kSolveMbSlots = 24;      // {iters, |r|^2, |b|^2, status} + stage timestamps of the timing hook
 int cgf_solve_max_blocks(int rows);      // resident workgroups per CU of the R-rows instance (occupancy query)
 void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, int force_passes, hipStream_t s);   // multi-rank: partials of pass k -> out[0..6]

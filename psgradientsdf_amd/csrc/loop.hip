@@ -223,7 +223,11 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
                 take_fold(c, a, (1u << SC_ENERGY) | (1u << SC_NOBS) | (c->albedo_applied ? (1u << SC_ACCEPT) : 0u));
                 timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); });
             }
-            else { materialize_fold(c); timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); }); }   // (LED: the fused albedo sweep's sums are still pending and this sweep writes the same slots)
+            else {
+                materialize_fold(c);
+                { int Gs, Rs; if (c->pcg_fuse_asm && c->fuse_pcg_init && band_blocks(c) <= kPcgMaxBlocks && cgf_solve_shape(c, &Gs, &Rs)) { a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kSolveGranPlanes * kSolveMaxBlocksHost; a.pcg_asm = 1; } }   // the sweep clears the tags of the persistent solve behind it
+                timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); });
+            }   // (LED: the fused albedo sweep's sums are still pending and this sweep writes the same slots)
             const int slots[2] = {SC_ENERGY, SC_NOBS}; double s[2];
             if (deferred_consumer) return read_parts_deferred(c, slots, 2, [deferred_consumer](const double* v) { deferred_consumer(v[0], v[1]); });
             if ((rc = read_parts(c, slots, 2, s))) return rc;
@@ -290,9 +294,9 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
         case PSGSDF_DIST: {
             take_fold(c, a, 0u);
             if (c->fuse_pcg_init && band_blocks(c) <= kPcgMaxBlocks) { a.pcg_fuse_init = 1; a.pcg_init_blocks = band_blocks(c); }   // the assembly kernel initialises the PCG
-            { int Gs, Rs; if (a.pcg_fuse_init && cgf_solve_shape(c, &Gs, &Rs)) { a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kCgfSumsHost * kSolveMaxBlocksHost; } }   // the assembly kernel also clears the persistent solve's tags
+            { int Gs, Rs; if (a.pcg_fuse_init && cgf_solve_shape(c, &Gs, &Rs)) { a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kSolveGranPlanes * kSolveMaxBlocksHost; a.pcg_asm = c->pcg_fuse_asm ? 1 : 0; } }   // the assembly kernel also clears the persistent solve's tags
             if ((rc = comm_halo(c, c->band.blk, 14, 1))) return rc;   // multi-rank: rows of H next to a cut take contributions from the neighbour slab's voxel blocks
-            timed(c, "assemble", [&] { launch_assemble(a, c->stream); });
+            if (!a.pcg_asm) timed(c, "assemble", [&] { launch_assemble(a, c->stream); });      // (pcg_asm: the persistent solve assembles its rows itself; the distance sweep cleared its tags)
             int iters = 0, ok = 1; double err = 0;
             const bool only_on_success = !led && c->set.ref_quirks;   // PsOptimizer.cpp:168-170 (B8): SH skips the update unless the solve reports Success
             bool tail_ran = false; int tail_rc = 0;

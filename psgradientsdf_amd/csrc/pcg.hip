@@ -353,7 +353,57 @@ __device__ __forceinline__ void store16_sc1(float4* p, const float4& v) {
 __device__ __forceinline__ double gran_tag(double v, unsigned tag) { return __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(v) & ~3ull) | tag)); }
 __device__ __forceinline__ unsigned gran_tag_of(double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) & 3ull); }
 
-template <int R>
+// One ELL row of the distance system accumulated in REGISTERS: the contributions of assemble_row (dist.hip), in its order.  There the column
+// of a contribution is a run-time index into an LDS table; here every (contributor, block column) pair has at most two possible
+// columns, known at compile time, and the one the contributor's stencil direction does not select receives an exact + 0.0 -- the
+// nineteen sums are bit-identical to the LDS version's.
+__device__ __forceinline__ bool ell_valid(const int* o) {
+    const int nz = (o[0] != 0) + (o[1] != 0) + (o[2] != 0);
+    return nz <= 2 && o[0] >= -1 && o[0] <= 1 && o[1] >= -1 && o[1] <= 1 && o[2] >= -1 && o[2] <= 1;
+}
+__device__ __forceinline__ void assemble_row_regs(const SweepArgs& a, int i, double (&acc)[kNQ], double& rhs) {
+    const Band& b = a.b;
+    int jr[7]; jr[0] = i;
+#pragma unroll
+    for (int c = 1; c < 7; ++c) { const int ax = (c - 1) >> 1; const bool upper = (c - 1) & 1; jr[c] = b.nb[(size_t)(2 * ax + (upper ? 0 : 1)) * b.Spad + i]; }
+    int db[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) db[c] = b.dirb[jr[c] >= 0 ? jr[c] : i];
+    bool use[7]; use[0] = true;
+#pragma unroll
+    for (int c = 1; c < 7; ++c) { const int ax = (c - 1) >> 1; const bool upper = (c - 1) & 1; use[c] = jr[c] >= 0 && !(upper && ((db[c] >> ax) & 1)); }
+    float val[7][4], gr[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        const int sl = c == 0 ? 0 : ((c - 1) >> 1) + 1;
+        const int jrow = use[c] ? jr[c] : i;
+        gr[c] = b.blk[(size_t)(10 + sl) * b.Spad + jrow];
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) val[c][bq] = b.blk[(size_t)sym4(sl, bq) * b.Spad + jrow];
+    }
+#pragma unroll
+    for (int q = 0; q < kNQ; ++q) acc[q] = 0.0;
+    rhs = 0.0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        const int ax = c == 0 ? 0 : (c - 1) >> 1; const bool upper = c > 0 && ((c - 1) & 1);
+        int coff[3] = {0, 0, 0};
+        if (c > 0) coff[ax] = upper ? 1 : -1;
+        rhs += use[c] ? (double)gr[c] : 0.0;
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {
+            const double v = use[c] ? (double)val[c][bq] : 0.0;
+            if (bq == 0) { acc[q_of(coff)] += v; continue; }
+            const bool fwd = (db[c] >> (bq - 1)) & 1;
+            int oP[3] = {coff[0], coff[1], coff[2]}, oM[3] = {coff[0], coff[1], coff[2]};
+            oP[bq - 1] += 1; oM[bq - 1] -= 1;
+            if (ell_valid(oP)) acc[q_of(oP)] += fwd ? v : 0.0;
+            if (ell_valid(oM)) acc[q_of(oM)] += fwd ? 0.0 : v;
+        }
+    }
+}
+
+template <int R, bool ASM>
 __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, double* fs, double* gran, int rows_per_wg, int kmax, double* mb, int force_passes) {
     __shared__ double red[8 * kSolveThreads / 64];
     __shared__ int s_abort;
@@ -368,39 +418,78 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
     // the CU's 160 KB), the 9 index words and the row's own state in registers.
     float* hs = (float*)psg_dyn_smem;
     unsigned cp[R][(kNQ - 1) / 2]; float4 me[R]; float x[R]; int row[R]; bool live[R];
+    if (ASM && a.fold.n != 0 && blockIdx.x == 0) {
+        // no k_assemble in front of this kernel to fold the sums the distance sweep left pending (device_common.h fold_pending): done here,
+        // by the first 256 threads in that function's order (the same bits as in any 256-thread kernel)
+        for (int sl = 0; sl < a.fold.n; ++sl) {
+            const double* part = PART(a, a.fold.id[sl]);
+            double v = 0;
+            if (tid < kBlock) for (int i = tid; i < a.fold.nblk; i += kBlock) v += part[i];
+            v = wave_sum(v);
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = v;
+            __syncthreads();
+            if (tid == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; a.fold.out[sl] = t; }
+        }
+        __syncthreads();
+    }
+    double bb_thread = 0.0;                     // ASM: |b|^2 of this thread's rows (summed over the device with the sums of pass 0)
 #pragma unroll
     for (int u = 0; u < R; ++u) {
         // the band is dealt evenly to ALL workgroups (rows_per_wg each, a multiple of 64): the last row slot of a thread is only partly used
         const int i = a.row0 + lb * rows_per_wg + u * kSolveThreads + tid;
         live[u] = u * kSolveThreads + tid < rows_per_wg && i < a.row1; row[u] = live[u] ? i : a.row1 - 1;
+        if (ASM) {
+            // the row's matrix entries straight from the voxel blocks of the distance sweep (no k_assemble, no H in memory)
+            double acc[kNQ], rhs;
+            assemble_row_regs(a, row[u], acc, rhs);
 #pragma unroll
-        for (int q = 0; q < kNQ; ++q) {
-            float hv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rH, row[u] * 4, q * plane, 0));
-            if (q == 0 && a.damping != 0.0f) hv += a.damping * hv;
-            hs[(u * kNQ + q) * kSolveThreads + tid] = hv;
+            for (int q = 0; q < kNQ; ++q) {
+                float hv = (float)acc[q];
+                if (q == 0 && a.damping != 0.0f) hv += a.damping * hv;
+                hs[(u * kNQ + q) * kSolveThreads + tid] = hv;
+            }
+            float dg = (float)acc[0];
+            if (a.damping != 0.0f) dg += a.damping * dg;
+            const float inv = dg != 0.f ? 1.0f / dg : 1.0f;
+            const float r = (float)rhs;
+            me[u] = make_float4(r, 0.f, 0.f, inv);
+            if (live[u]) { store16_sc1(b.rec[1] + row[u], me[u]); bb_thread += (double)r * (double)r; }      // what pass 0 of the neighbours gathers
+        } else {
+#pragma unroll
+            for (int q = 0; q < kNQ; ++q) {
+                float hv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rH, row[u] * 4, q * plane, 0));
+                if (q == 0 && a.damping != 0.0f) hv += a.damping * hv;
+                hs[(u * kNQ + q) * kSolveThreads + tid] = hv;
+            }
+            me[u] = b.rec[1][row[u]];            // {r_0, 0, 0, inv} written by the assembly kernel
         }
 #pragma unroll
         for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) cp[u][wd] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rC, row[u] * 4, wd * plane, 0);
-        me[u] = b.rec[1][row[u]];            // {r_0, 0, 0, inv} written by the assembly kernel
         x[u] = 0.f;
     }
-    // |b|^2 from the assembly kernel's per-workgroup partials (an earlier kernel: plain loads)
-    double bb;
-    { double* src[1] = {fpart(a.pcg_part, -1, 6)}; PartLoads<1> pl;   // (block_total_n assumes kBlock threads: sum here with the first kBlock threads' loads)
+    // |b|^2: from the assembly kernel's per-workgroup partials (an earlier kernel: plain loads) -- or, ASM, not known before the sums of pass 0
+    double bb = 0.0;
+    if (!ASM) {
+      double* src[1] = {fpart(a.pcg_part, -1, 6)};
       double v = 0.0;
       for (int i = tid; i < a.pcg_init_blocks; i += kSolveThreads) v += src[0][i];
       v = wave_sum(v);
       if ((tid & 63) == 0) red[tid >> 6] = v;
       __syncthreads();
-      bb = 0.0;
 #pragma unroll
       for (int i = 0; i < kSolveThreads / 64; ++i) bb += red[i];
       __syncthreads();
-      (void)pl; }
-    const float rhsNorm2 = (float)bb;
-    const float thr = pcg_threshold(rhsNorm2);
+    } else {
+        // the records of this workgroup's rows are on their way: drained, then the flag the neighbours' pass 0 waits for (plane 7 of buffer 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + lb, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float rhsNorm2 = (float)bb;
+    float thr = pcg_threshold(rhsNorm2);
     float alpha_prev = 0.f, beta = 0.f, rr_cur = rhsNorm2;
-    if (lb == 0 && tid == 0) fs[0] = bb;
+    if (!ASM && lb == 0 && tid == 0) fs[0] = bb;
     int k = 0, status = 1;                    // status 1 = finished, 2 = a wait timed out
     // The workgroups whose records this one gathers from: rows within `reach` of its own range (a handful of neighbours in band order).
     const int first = lb * rows_per_wg, last = first + rows_per_wg - 1;                    // (relative to row0)
@@ -410,15 +499,23 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
     for (;; ++k) {
         SOLVE_STAMP(0);
         const unsigned want = (unsigned)k & 3u;            // tag of pass k-1 = ((k-1) + 1) & 3
-        const double* gp = gran + (size_t)((k - 1) & 1) * kCgfSums * kSolveMaxBlocks;
-        if (k > 0) {
+        const double* gp = gran + (size_t)((k - 1) & 1) * kSolveGranPlanes * kSolveMaxBlocks;
+        // (the packed column deltas are loop-invariant: given the chance, the compiler precomputes all 18 R gather addresses as 64-bit pairs
+        // ahead of the loop and spills them -- an empty asm per word keeps the three-instruction address arithmetic inside the pass)
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+#pragma unroll
+            for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) asm volatile("" : "+v"(cp[u][wd]));
+        if (k > 0 || ASM) {
             // ---- A: the records this workgroup gathers from are those of its NEIGHBOURS in band order: wait for their pass k-1 only (the tag
             // of a workgroup's first sum is stored after its records have drained), not for the whole device
             if (tid == 0) s_abort = 0;
             __syncthreads();
             if (tid <= nhi - nlo) {
                 int spins = 0;
-                while (gran_tag_of(__hip_atomic_load(gp + nlo + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != want) {
+                // (ASM, pass 0: the neighbours' assembled records -- their flag in plane 7 of buffer 1)
+                const double* wp = k > 0 ? gp + nlo + tid : gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + nlo + tid;
+                while (k > 0 ? gran_tag_of(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != want : __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0.0) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
                 }
@@ -477,6 +574,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
                     ok = true;
 #pragma unroll
                     for (int q = 0; q < kCgfSums; ++q) { v[q] = __hip_atomic_load(gp + (size_t)q * kSolveMaxBlocks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = ok && gran_tag_of(v[q]) == want; }
+                    if (ASM && k == 1) { v[7] = __hip_atomic_load(gp + (size_t)7 * kSolveMaxBlocks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = ok && gran_tag_of(v[7]) == want; }   // |b|^2 travels with the sums of pass 0
                     if (!ok) {
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
@@ -490,6 +588,12 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             double t[kCgfSums];
 #pragma unroll
             for (int q = 0; q < kCgfSums; ++q) { double s_ = 0; for (int i = 0; i < kSolveThreads / 64; ++i) s_ += red[q * (kSolveThreads / 64) + i]; t[q] = s_; }
+            if (ASM && k == 1) {
+                bb = 0.0;
+                for (int i = 0; i < kSolveThreads / 64; ++i) bb += red[7 * (kSolveThreads / 64) + i];
+                rhsNorm2 = (float)bb; thr = pcg_threshold(rhsNorm2);
+                if (lb == 0 && tid == 0) fs[0] = bb;
+            }
             __syncthreads();
             const float rz_old = (float)t[5];
             alpha_prev = rz_old / (float)t[0];
@@ -502,7 +606,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         }
         if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 512 + lb] = (double)wall_clock64();
         SOLVE_STAMP(3);
-        const bool rhs_zero = rhsNorm2 == 0.f;
+        const bool rhs_zero = (!ASM || k > 0) && rhsNorm2 == 0.f;          // (ASM: |b|^2 arrives with the sums of pass 0)
         const bool stop = force_passes > 0 ? k >= force_passes : (rhs_zero || k == kmax || (k > 0 && rr_cur < thr));
         // ---- D: finish pass k-1 for the own rows; pass k
         double s[kCgfSums];
@@ -510,7 +614,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         for (int q = 0; q < kCgfSums; ++q) s[q] = 0;
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            if (k > 0) x[u] = x[u] + alpha_prev * me[u].z;
+            if (k > 0 && !rhs_zero) x[u] = x[u] + alpha_prev * me[u].z;
             if (stop) continue;
             const float r_i = me[u].x - alpha_prev * me[u].y;
             const float z_i = me[u].w * r_i;
@@ -529,16 +633,16 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         // ---- E: publish: the records have to be out (write-through, drained) before the seven tagged sums
         double sv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sv[q] = q < kCgfSums ? s[q] : 0.0;
+        for (int q = 0; q < 8; ++q) sv[q] = q < kCgfSums ? s[q] : ((ASM && k == 0) ? bb_thread : 0.0);
         double t0, t1; wave_sum8(sv, t0, t1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
         __syncthreads();
         SOLVE_STAMP(5);
-        if (tid < kCgfSums) {
+        if (tid < kCgfSums || (ASM && k == 0 && tid == 7)) {
             double tot = 0;
             for (int i = 0; i < kSolveThreads / 64; ++i) tot += red[tid * (kSolveThreads / 64) + i];
-            double* gq = gran + (size_t)(k & 1) * kCgfSums * kSolveMaxBlocks + (size_t)tid * kSolveMaxBlocks + lb;
+            double* gq = gran + (size_t)(k & 1) * kSolveGranPlanes * kSolveMaxBlocks + (size_t)tid * kSolveMaxBlocks + lb;
             __hip_atomic_store(gq, gran_tag(tot, (unsigned)(k + 1) & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
@@ -562,25 +666,30 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
     }
 }
 static size_t cgf_solve_lds(int rows) { return sizeof(float) * (size_t)rows * kNQ * kSolveThreads; }
-template <int R> static int cgf_solve_prepare() {      // > 64 KB of dynamic LDS has to be asked for, once per instance
+template <int R, bool ASM> static int cgf_solve_prepare() {      // > 64 KB of dynamic LDS has to be asked for, once per instance
     static int per_cu = -1;
     if (per_cu >= 0) return per_cu;
     per_cu = 0;
-    if (hipFuncSetAttribute((const void*)k_cgf_solve<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cgf_solve_lds(R)) != hipSuccess) return per_cu;
+    if (hipFuncSetAttribute((const void*)k_cgf_solve<R, ASM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cgf_solve_lds(R)) != hipSuccess) return per_cu;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cgf_solve<R>, kSolveThreads, cgf_solve_lds(R)) == hipSuccess) per_cu = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cgf_solve<R, ASM>, kSolveThreads, cgf_solve_lds(R)) == hipSuccess) per_cu = n;
     return per_cu;
 }
+template <int R> static int cgf_solve_prepare_both() { return std::min(cgf_solve_prepare<R, false>(), cgf_solve_prepare<R, true>()); }
 int cgf_solve_max_blocks(int rows) {
-    return rows == 1 ? cgf_solve_prepare<1>() : rows == 2 ? cgf_solve_prepare<2>() : rows == 3 ? cgf_solve_prepare<3>() : cgf_solve_prepare<4>();
+    return rows == 1 ? cgf_solve_prepare_both<1>() : rows == 2 ? cgf_solve_prepare_both<2>() : rows == 3 ? cgf_solve_prepare_both<3>() : cgf_solve_prepare_both<4>();
+}
+template <int R>
+static void launch_cgf_solve_r(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, int force_passes, hipStream_t s) {
+    if (a.pcg_asm) hipLaunchKernelGGL((k_cgf_solve<R, true>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
+    else hipLaunchKernelGGL((k_cgf_solve<R, false>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
 }
 void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, int force_passes, hipStream_t s) {
     const int rows = (rows_per_wg + kSolveThreads - 1) / kSolveThreads;
-    const size_t lds = cgf_solve_lds(rows);
-    if (rows == 1) hipLaunchKernelGGL((k_cgf_solve<1>), dim3(G), dim3(kSolveThreads), lds, s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
-    else if (rows == 2) hipLaunchKernelGGL((k_cgf_solve<2>), dim3(G), dim3(kSolveThreads), lds, s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
-    else if (rows == 3) hipLaunchKernelGGL((k_cgf_solve<3>), dim3(G), dim3(kSolveThreads), lds, s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
-    else hipLaunchKernelGGL((k_cgf_solve<4>), dim3(G), dim3(kSolveThreads), lds, s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
+    if (rows == 1) launch_cgf_solve_r<1>(a, fs, gran, G, rows_per_wg, kmax, mb, force_passes, s);
+    else if (rows == 2) launch_cgf_solve_r<2>(a, fs, gran, G, rows_per_wg, kmax, mb, force_passes, s);
+    else if (rows == 3) launch_cgf_solve_r<3>(a, fs, gran, G, rows_per_wg, kmax, mb, force_passes, s);
+    else launch_cgf_solve_r<4>(a, fs, gran, G, rows_per_wg, kmax, mb, force_passes, s);
 }
 
 // multi-rank: fold the partials of pass k (k = -1: |b|^2 of the init) into out[0..6] for the host program's all-reduce
