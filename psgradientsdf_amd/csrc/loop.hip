@@ -294,15 +294,17 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
         case PSGSDF_DIST: {
             take_fold(c, a, 0u);
             if (c->fuse_pcg_init && band_blocks(c) <= kPcgMaxBlocks) { a.pcg_fuse_init = 1; a.pcg_init_blocks = band_blocks(c); }   // the assembly kernel initialises the PCG
-            { int Gs, Rs; if (a.pcg_fuse_init && cgf_solve_shape(c, &Gs, &Rs)) { a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kSolveGranPlanes * kSolveMaxBlocksHost; a.pcg_asm = c->pcg_fuse_asm ? 1 : 0; } }   // the assembly kernel also clears the persistent solve's tags
+            bool apply_in_solve = false;      // (the accepted count goes to the first G entries of a partial slot that holds one entry per 256 rows)
+            { int Gs, Rs; if (a.pcg_fuse_init && cgf_solve_shape(c, &Gs, &Rs)) { a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kSolveGranPlanes * kSolveMaxBlocksHost; a.pcg_asm = c->pcg_fuse_asm ? 1 : 0; apply_in_solve = a.pcg_asm && c->pcg_fuse_apply && Gs <= band_blocks(c); } }   // the assembly kernel also clears the persistent solve's tags
             if ((rc = comm_halo(c, c->band.blk, 14, 1))) return rc;   // multi-rank: rows of H next to a cut take contributions from the neighbour slab's voxel blocks
             if (!a.pcg_asm) timed(c, "assemble", [&] { launch_assemble(a, c->stream); });      // (pcg_asm: the persistent solve assembles its rows itself; the distance sweep cleared its tags)
             int iters = 0, ok = 1; double err = 0;
             const bool only_on_success = !led && c->set.ref_quirks;   // PsOptimizer.cpp:168-170 (B8): SH skips the update unless the solve reports Success
+            if (apply_in_solve) a.pcg_apply = only_on_success ? 2 : 1;      // persistent solve: the update is its epilogue
             bool tail_ran = false; int tail_rc = 0;
             auto tail = [&](const double* gate) {                     // distance update + regrad, gated on the device-side outcome of the solve
                 SweepArgs ag = a; ag.fold.n = 0; ag.gate = gate;
-                timed(c, "apply_dist", [&] { launch_apply_dist(ag, c->stream); });
+                if (!a.pcg_apply) timed(c, "apply_dist", [&] { launch_apply_dist(ag, c->stream); });      // (pcg_apply: the persistent solve has done it)
                 if (int hrc = comm_halo(c, c->band.dist, 1, 1)) tail_rc = hrc;   // multi-rank: the regrad's stencils read the neighbour slab's new distances (harmless when the gate is closed: nothing changed)
                 SweepArgs a2 = make_args(c, 0); a2.gate = gate;
                 timed(c, "derive", [&] { launch_derive(a2, 1, c->stream); });

@@ -653,6 +653,26 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
     // ---- leave: x of the own rows; the outcome for the host and for the gated kernels behind this one
 #pragma unroll
     for (int u = 0; u < R; ++u) if (live[u]) b.x[row[u]] = x[u];
+    if (a.pcg_apply) {
+        // the distance update (k_apply_dist: updateDist's accept rule, OptimizerAux.cpp:162-188) for the own rows, under the rule the host applies
+        // to the solve's outcome -- every workgroup holds the same |r|^2 and |b|^2.  The accepted count is a sum of integers: the per-workgroup
+        // counts go to the first G entries of the slot, the rest of the slot (k_apply_albedo's leftovers) is cleared.
+        const bool z0 = rhsNorm2 == 0.f;
+        const bool ok_all = status == 1 && (z0 || sqrt((double)rr_cur / (double)rhsNorm2) <= (double)FLT_EPSILON);
+        const bool apply = status == 1 && (a.pcg_apply == 1 || ok_all);
+        double cnt = 0;
+        if (apply) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) if (live[u] && (double)fabsf(x[u]) < sqrt(3.0) * (double)a.grid.vs) { b.dist[row[u]] -= x[u]; cnt += 1.0; }
+        }
+        cnt = wave_sum(cnt);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = cnt;
+        __syncthreads();
+        double* slot = PART(a, SC_ACCEPT);
+        if (tid == 0) { double t = 0; for (int i = 0; i < kSolveThreads / 64; ++i) t += red[i]; slot[lb] = t; }
+        for (int i = G + lb * kSolveThreads + tid; i < a.acc.PB; i += G * kSolveThreads) slot[i] = 0.0;
+    }
     if (lb == 0 && tid == 0) {
         const bool rhs_zero = rhsNorm2 == 0.f;
         const bool ok = status == 1 && (rhs_zero || sqrt((double)rr_cur / (double)rhsNorm2) <= (double)FLT_EPSILON);
