@@ -1,6 +1,7 @@
 """The engine's latency tricks must not change results: PCG stop test by watching the mapped mailbox vs draining the stream
 (PSGSDF_PCG_POLL), scalar folds done by the next kernel vs by a kernel of their own (PSGSDF_FOLD_IN_NEXT), albedo update applied by the sweep vs by its own kernel (PSGSDF_FUSE_ALBEDO), launch shape of the
-fused PCG pass (PSGSDF_PCG_ROWS / PSGSDF_PCG_BLOCKS).  Each variant runs in its own process (the knobs are read at create time)."""
+fused PCG pass (PSGSDF_PCG_ROWS / PSGSDF_PCG_BLOCKS), the distance step as one persistent kernel (assembly + solve + update) vs its parts
+(PSGSDF_PCG_FUSE_APPLY / PSGSDF_PCG_FUSE_ASM / PSGSDF_PCG_PERSIST).  Each variant runs in its own process (the knobs are read at create time)."""
 import json
 import os
 import subprocess
@@ -53,3 +54,14 @@ def test_pcg_launch_shape_only_changes_rounding(built):
         assert all(abs(a - b) <= 1 for a, b in zip(got["cg"], ref["cg"]))
         assert all(abs(a - b) <= 2e-5 * abs(b) for a, b in zip(got["e"], ref["e"])), (env, got["e"], ref["e"])
         assert abs(got["dsum"] - ref["dsum"]) <= 1e-5 * ref["dsum"]
+
+
+@pytest.mark.parametrize("model", ["SH1", "LED"])
+def test_distance_step_fusions_are_bitwise_neutral(built, model):
+    """The persistent solve kernel that assembles its own rows (register accumulation in assemble_row's order) and applies the distance update
+    in its epilogue must give the bits of: the same kernel with k_apply_dist behind it, with k_assemble in front of it, and of the per-pass
+    kernels (what multi-rank contexts run) -- energies, iteration counts and the optimised state, through psgsdf_optimize as well."""
+    ref = run(model, {}, full=True)
+    for env in ({"PSGSDF_PCG_FUSE_APPLY": "0"}, {"PSGSDF_PCG_FUSE_ASM": "0"}, {"PSGSDF_PCG_PERSIST": "0"}):
+        got = run(model, env, full=True)
+        assert got == ref, (env, got, ref)
