@@ -112,12 +112,13 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
                 float radius = (float)(pd * pd * pd);
                 float p5 = (float)(pd * pd * pd * pd * pd);
                 float nRp = dot3(v.nfd, Rp);
+                const float y5 = 1.0f / p5, y3 = 1.0f / radius;      // eight quotients, two divisors (device_common.h div_by: same bits)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float dm = dot3(dn[q], Rp) + dot3(v.nfd, dx[q]);
                     float tmp[3]; mulT3(fp.R, dx[q], tmp);
-                    float dm2 = -3 * dot3(pr.p, tmp) / p5;
-                    dm = dm / radius + dm2 * nRp;
+                    float dm2 = div_by(-3 * dot3(pr.p, tmp), p5, y5);
+                    dm = div_by(dm, radius, y3) + dm2 * nRp;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) J[q][ch] = J[q][ch] + (v.rho[ch] * fp.l[ch]) * dm;
                 }
