@@ -21,7 +21,7 @@ __device__ __forceinline__ void normal_jacobian(float vs_inv, const float* grad,
 // distJacobian per observation PsOptimizerJa.cpp:160-289 / LedOptimizerJa.cpp:117-218, accumulated directly
 // into the per-voxel block over {self, x-, y-, z-stencil neighbour}; regularisers Optimizer.cpp:196-218,477-590.
 template <int MODEL, int LOSS, int IMG>
-__global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
+__global__ void __launch_bounds__(kBlock, MODEL == 1 ? 3 : 4) k_sweep_dist(SweepArgs a) {      // (SH2 needs 154 VGPRs; LED landed on 130 = 3 waves per SIMD without the hint)
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
     FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
@@ -116,8 +116,9 @@ __global__ void __launch_bounds__(kBlock) k_sweep_dist(SweepArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float dm = dot3(dn[q], Rp) + dot3(v.nfd, dx[q]);
-                    float tmp[3]; mulT3(fp.R, dx[q], tmp);
-                    float dm2 = div_by(-3 * dot3(pr.p, tmp), p5, y5);
+                    // p . (R^T dx_q) regrouped as (R p) . dx_q -- R p is there already (LedOptimizerJa.cpp:176-186 forms R^T dx_q first; same value up
+                    // to the rounding of the regrouped products, 9 multiply-adds less per stencil slot: engine deviation 7)
+                    float dm2 = div_by(-3 * dot3(Rp, dx[q]), p5, y5);
                     dm = div_by(dm, radius, y3) + dm2 * nRp;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) J[q][ch] = J[q][ch] + (v.rho[ch] * fp.l[ch]) * dm;
