@@ -224,6 +224,9 @@ def main():
                            "launches_timed": int(watched[1]), "avg_working_launch_ms": avg_work_ms, "working_launch_fraction": working_frac,
                            "bytes_per_unit": "SURVEY 8d algorithmic figure (PCG: 124 B per band voxel per pass; pcg_solve runs cg_iters + 1 passes per launch and keeps the matrix on chip: its HBM-side traffic is far below the algorithmic bytes; the launch also assembles the distance system from the sweep's voxel blocks, which is NOT counted here)",
                            "storage_bytes_per_launch": 152 * S if dom in ("pcg_pass", "pcg_solve") else None,
+                           # the pcg_solve launch also assembles the system (reads the sweep's 14-float voxel blocks + 3 neighbour rows: 68 B per band voxel)
+                           # and applies the distance update (8 B): the same fraction with those algorithmic bytes counted, for reference only
+                           "frac_with_fused_steps": ((nbytes + 76 * S) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom == "pcg_solve" else None,
                            "traffic_source": traffic_src}
         # whole-iteration algorithmic bytes (SURVEY.md §8d formula) for reference
         U = min(48 * n_obs, 12 * args.width * args.height * args.frames)
