@@ -21,7 +21,7 @@ __device__ __forceinline__ void normal_jacobian(float vs_inv, const float* grad,
 // distJacobian per observation PsOptimizerJa.cpp:160-289 / LedOptimizerJa.cpp:117-218, accumulated directly
 // into the per-voxel block over {self, x-, y-, z-stencil neighbour}; regularisers Optimizer.cpp:196-218,477-590.
 template <int MODEL, int LOSS, int IMG>
-__global__ void __launch_bounds__(kBlock, MODEL == 1 ? 3 : 4) k_sweep_dist(SweepArgs a) {      // (SH2 needs 154 VGPRs; LED landed on 130 = 3 waves per SIMD without the hint)
+__global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      // 4 waves per SIMD (<= 128 VGPRs): without the hint SH2 takes 132 and LED 130
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
     FrameP* sf = reinterpret_cast<FrameP*>(psg_dyn_smem);   // F records, dynamic LDS
@@ -59,15 +59,6 @@ __global__ void __launch_bounds__(kBlock, MODEL == 1 ? 3 : 4) k_sweep_dist(Sweep
             for (int k = 0; k < 3; ++k) dx[q][k] = -d * dn[q][k];
         float shfd[kMaxBasis];
         if (!LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
-        float Dm[3][9];
-        if (NB == 9) {
-            const float* nh = v.nfd;
-            float D0[9] = {0, 1, 0, 0, nh[1], nh[2], 0, 2 * nh[0], 2 * nh[0]};
-            float D1[9] = {0, 0, 1, 0, nh[0], 0, nh[2], -2 * nh[1], 0};
-            float D2[9] = {0, 0, 0, 1, 0, nh[0], nh[1], 0, -2 * nh[2]};
-#pragma unroll
-            for (int i = 0; i < 9; ++i) { Dm[0][i] = D0[i]; Dm[1][i] = D1[i]; Dm[2][i] = D2[i]; }
-        }
         float B[10], g[4];   // <= F terms each: float accumulation (oracle: double) differs ~1e-7 relative
         float Ef = 0.f; int nobs_i = 0;
 #pragma unroll
@@ -94,15 +85,20 @@ __global__ void __launch_bounds__(kBlock, MODEL == 1 ? 3 : 4) k_sweep_dist(Sweep
                 // shading term rho_c * (l . dSH/dd_q): the frame's light is contracted with the (per-voxel) normal derivative ONCE per
                 // stencil slot and then scaled by the three albedos, instead of forming rho_c * l per channel first (the reference's
                 // order, PsOptimizerJa.cpp:225-278; same value up to the rounding of one product, a third of the instructions)
+                // SH2: l . (dSH/dn dn_q) regrouped as (l . dSH/dn) . dn_q -- the frame's light meets the 3 x 9 derivative table once per observation (14
+                // non-zero entries) instead of once per stencil slot; same value up to the rounding of the regrouped sums (engine deviation 7)
+                float lw[3] = {0.f, 0.f, 0.f};
+                if (NB == 9) {
+                    const float* nh = v.nfd;
+                    lw[0] = (fp.l[1] + fp.l[4] * nh[1]) + (fp.l[5] * nh[2] + 2 * nh[0] * (fp.l[7] + fp.l[8]));
+                    lw[1] = (fp.l[2] + fp.l[4] * nh[0]) + (fp.l[6] * nh[2] - 2 * nh[1] * fp.l[7]);
+                    lw[2] = (fp.l[3] + fp.l[5] * nh[0]) + (fp.l[6] * nh[1] - 2 * nh[2] * fp.l[8]);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float sq;
                     if (NB == 4) sq = (fp.l[1] * dn[q][0] + fp.l[2] * dn[q][1]) + fp.l[3] * dn[q][2];
-                    else {
-                        sq = 0.f;
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) sq += fp.l[i] * ((Dm[0][i] * dn[q][0] + Dm[1][i] * dn[q][1]) + Dm[2][i] * dn[q][2]);
-                    }
+                    else sq = (lw[0] * dn[q][0] + lw[1] * dn[q][1]) + lw[2] * dn[q][2];
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) J[q][ch] = J[q][ch] - v.rho[ch] * sq;
                 }
