@@ -19,7 +19,10 @@
  * Jacobi-PCG; the distance PCG's fused recurrences (one reduction per pass); FMA contraction of
  * the per-observation algebra; v_rcp_f32 in the Cauchy weight, v_log_f32 x ln2 in the Cauchy loss; float
  * bilinear weights; the Jacobian chain image_grad * pi_grad * R^T * d(point) contracted from the right
- * (channel-independent rows first) instead of a 3x3 product per channel; out-of-bounds reads of the
+ * (channel-independent rows first) instead of a 3x3 product per channel, p.(R^T dx) as (R p).dx in
+ * the LED distance Jacobian, the SH2 light contracted with dSH/dn before the stencil slots;
+ * quotients sharing a divisor via one correctly rounded reciprocal + Markstein correction (same
+ * bits); out-of-bounds reads of the
  * reference clamped.  NOT a deviation any more:
  * the Jacobians' second projection fx*px/pz (PsOptimizerJa.cpp:70-76) is reproduced by both.
  *
