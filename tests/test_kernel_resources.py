@@ -1,0 +1,58 @@
+"""Register budgets the performance of the hot kernels rests on, checked at build time (hipcc's kernel-resource-usage remarks, no GPU needed):
+the persistent distance step must not spill (the compiler once hoisted all 54 gather addresses out of the pass loop and spilled them --
+profiles/r02_notes.md section 9), and the per-observation sweeps must stay at 4 wavefronts per SIMD (<= 128 VGPRs)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "psgradientsdf_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def resources(src, tmp_path):
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c", src, "-o", str(tmp_path / "x.o"),
+                          "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res, name = {}, None
+    for ln in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", ln)
+        if m:
+            name = m.group(1); res[name] = {}
+        for key, pat in (("vgpr", r"VGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("waves", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, ln)
+            if m and name:
+                res[name][key] = int(m.group(1))
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_persistent_distance_step_does_not_spill(tmp_path):
+    res = resources("pcg.hip", tmp_path)
+    solve = {k: v for k, v in res.items() if "k_cgf_solve" in k}
+    assert len(solve) == 8                                             # R = 1..4 x {with, without the fused assembly}
+    for k, v in solve.items():
+        if "ILi4E" in k:
+            continue                                                   # 4 rows per thread (bands of 393k-524k rows): not tuned
+        assert v["scratch"] == 0 and v["vgpr"] <= 256, (k, v)
+    passk = {k: v for k, v in res.items() if "k_cgf_pass" in k and "ILi1ELi4E" in k}
+    assert passk and all(v["vgpr"] <= 128 and v["scratch"] == 0 for v in passk.values()), passk      # the per-pass kernel: 4 waves per SIMD
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_sweeps_keep_four_waves_per_simd(tmp_path):
+    dist = resources("dist.hip", tmp_path)
+    for k, v in dist.items():
+        if "k_sweep_dist" in k and "ELi1ELi0E" in k:                   # Cauchy loss, float keyframes: SH1, SH2, LED
+            assert v["vgpr"] <= 128 and v["waves"] >= 4 and v["scratch"] <= 24, (k, v)
+    sw = resources("sweeps.hip", tmp_path)
+    for k, v in sw.items():
+        if "k_sweep_pose" in k and "ELi1ELi0E" in k:
+            assert v["vgpr"] <= 128 and v["scratch"] == 0, (k, v)
+        if ("k_sweep_albedo" in k or "k_energy" in k) and "ELi1ELi0E" in k:
+            assert v["vgpr"] <= 64 and v["scratch"] == 0, (k, v)       # 8 waves per SIMD
+        if "k_sweep_light" in k and "ILi0ELi1ELi0E" in k:
+            assert v["vgpr"] <= 96 and v["scratch"] == 0, (k, v)       # SH1: 5 waves per SIMD
