@@ -115,3 +115,22 @@ def test_laplacian_and_upsample_schedule(built):
     for a, b in zip(re_, ro):
         assert abs(a["e_total"] - b["e_total"]) <= 2e-3 * abs(b["e_total"]), (a["e_total"], b["e_total"])
     assert eng.info().n_band == orc.info().n_band
+
+
+def test_zero_right_hand_side_of_the_distance_system(built):
+    """black keyframes, zero albedo, no regularisers: every residual and every Jacobian entry is zero, so the distance system is 0 x = 0.
+    Eigen's CG returns x = 0 at once (|b| = 0: zero iterations, Success) and the update is applied as a no-op that accepts every voxel.
+    The persistent solve learns |b|^2 only with the sums of its first pass -- it must come to the same end, not divide 0 by 0 into the state."""
+    sc = synth.make_scene(N=32, F=4, W=128, H=96, model="SH1")
+    sc = copy.copy(sc); sc.images = np.zeros_like(sc.images)
+    st = capi.default_settings(capi.SH1, reg_weight_n=0.0, reg_weight_l=0.0)
+    eng, orc = pair(sc, st)
+    for api in (eng, orc):
+        api.init_albedo()                                 # mean of black pixels: albedo 0
+    d0 = eng.download_volume()["dist"].copy()
+    se, so = eng.step(capi.DIST), orc.step(capi.DIST)
+    assert se["cg_iters"] == so["cg_iters"] == 0 and se["cg_converged"] == so["cg_converged"] == 1
+    assert se["applied"] == so["applied"] and se["n_accepted"] == so["n_accepted"] == eng.info().n_band
+    v = eng.download_volume()
+    assert np.array_equal(v["dist"], d0) and np.isfinite(v["grad"]).all()
+    assert np.array_equal(v["dist"], orc.download_volume()["dist"])
