@@ -134,3 +134,26 @@ def test_zero_right_hand_side_of_the_distance_system(built):
     v = eng.download_volume()
     assert np.array_equal(v["dist"], d0) and np.isfinite(v["grad"]).all()
     assert np.array_equal(v["dist"], orc.download_volume()["dist"])
+
+
+@pytest.mark.parametrize("name,mid", [("SH1", capi.SH1), ("LED", capi.LED)])
+def test_cg_iteration_cap(built, name, mid):
+    """the distance solve cut off after 3 CG iterations (`cg_max_it`): not converged.  With the reference's quirk B8 the SH optimiser then SKIPS
+    the distance update (PsOptimizer.cpp:168-170) while the LED optimiser applies it anyway (LedOptimizer.cpp:195) -- the rule the persistent
+    solve kernel applies itself in its epilogue."""
+    sc = synth.make_scene(N=32, F=6, W=128, H=96, model=name)
+    st = capi.default_settings(mid, cg_max_it=3)
+    eng, orc = pair(sc, st)
+    for api in (eng, orc):
+        api.init_albedo(); api.normalize_weights()
+    d0 = eng.download_volume()["dist"].copy()
+    se, so = eng.step(capi.DIST), orc.step(capi.DIST)
+    assert se["cg_iters"] == so["cg_iters"] == 3 and se["cg_converged"] == so["cg_converged"] == 0
+    assert se["applied"] == so["applied"] == (1 if mid == capi.LED else 0)
+    band = eng.download_band(); vs = float(sc.voxel_size)
+    ve, vo = eng.download_volume(), orc.download_volume()
+    if mid == capi.LED:
+        assert se["n_accepted"] == so["n_accepted"] > 0
+        assert np.abs(ve["dist"][band] - vo["dist"][band]).max() <= 1e-4 * vs and not np.array_equal(ve["dist"], d0)
+    else:
+        assert np.array_equal(ve["dist"], d0) and np.array_equal(vo["dist"], d0)      # nothing applied
