@@ -77,7 +77,7 @@ int psgsdf_debug_time_pcg_pass(psgsdf_ctx* c, int blocks, int rows, int ablate, 
 
 // the persistent solve run for exactly `passes` passes on the current distance system (stop rule off): total kernel time and its shape
 int psgsdf_debug_time_pcg_solve(psgsdf_ctx* c, int passes, int reps, double* ms_per_launch, int32_t* shape, double* stamps /*[16] or NULL*/) {
-    if (!c || !c->inited || !ms_per_launch || !shape || passes < 1 || reps < 1) return fail(c, PSGSDF_ERR_STATE, "init first");
+    if (!c || !c->inited || !ms_per_launch || !shape || (passes < 1 && passes != -7) || reps < 1) return fail(c, PSGSDF_ERR_STATE, "init first");      // passes = -7: fault injection, one workgroup stops publishing (the others' bounded waits must end the kernel)
     HIPCHK(c, hipSetDevice(c->device));
     int G = 0, rows = 0;
     if (!cgf_solve_shape(c, &G, &rows)) return fail(c, PSGSDF_ERR_UNSUPPORTED, "the persistent solve does not apply to this context");
@@ -95,7 +95,7 @@ int psgsdf_debug_time_pcg_solve(psgsdf_ctx* c, int passes, int reps, double* ms_
         HIPCHK(c, hipStreamSynchronize(c->stream));
         float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
         if (r > 0) total += ms;
-        if (c->mbox[3] != 1.0) return fail(c, PSGSDF_ERR_DEVICE, "persistent solve status %g", c->mbox[3]);
+        if (c->mbox[3] != 1.0) { hipEventDestroy(e0); hipEventDestroy(e1); return fail(c, PSGSDF_ERR_DEVICE, "persistent solve status %g: a workgroup gave up waiting for the others", c->mbox[3]); }
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
     *ms_per_launch = (double)total / reps;

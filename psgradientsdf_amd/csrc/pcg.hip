@@ -629,6 +629,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             }
         }
         if (stop) break;
+        if (force_passes == -7 && k == 2 && lb == 1) { status = 2; break; }      // fault injection (psgsdf_debug_time_pcg_solve(passes = -7)): this workgroup never publishes pass 2 -- every other one must give up waiting, not hang
         SOLVE_STAMP(4);
         // ---- E: publish: the records have to be out (write-through, drained) before the seven tagged sums
         double sv[8];

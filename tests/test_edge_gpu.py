@@ -157,3 +157,21 @@ def test_cg_iteration_cap(built, name, mid):
         assert np.abs(ve["dist"][band] - vo["dist"][band]).max() <= 1e-4 * vs and not np.array_equal(ve["dist"], d0)
     else:
         assert np.array_equal(ve["dist"], d0) and np.array_equal(vo["dist"], d0)      # nothing applied
+
+
+def test_persistent_solve_gives_up_instead_of_hanging(built):
+    """fault injection: one workgroup of the persistent distance-step kernel stops publishing in pass 2.  Every wait inside the kernel is
+    bounded: the others raise the abort flag, the kernel ends, the host gets PSGSDF_ERR_DEVICE (a message, not a hang) -- and the context
+    keeps working afterwards."""
+    import time
+    sc = synth.make_scene(N=48, F=6, W=160, H=120, model="SH1")
+    eng = capi.load_engine(sc, sc.K, capi.default_settings(capi.SH1), 0); eng.load_scene(sc)
+    eng.init_albedo(); eng.normalize_weights()
+    eng.debug_time_pcg_solve(passes=4, reps=1)                     # the kernel applies to this band
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="gave up waiting"):
+        eng.debug_time_pcg_solve(passes=-7, reps=1)
+    assert time.time() - t0 < 60
+    recs = eng.iterate(capi.ALL, 2)                                # the next distance step resets the abort flag
+    assert all(np.isfinite(r["e_total"]) for r in recs) and recs[1]["e_total"] < recs[0]["e_total"] * 1.01
+    assert recs[0]["cg_iters"] > 3
