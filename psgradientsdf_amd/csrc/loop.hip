@@ -99,7 +99,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         if (c->mbox_used + (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
         const size_t off = c->mbox_used; c->mbox_used += n;
         volatile double* st = c->mbox + off;
-        for (int q = 0; q < n; ++q) st[q] = NAN;       // "not published yet" (kernel q of the chunk overwrites its slot)
+        for (int q = 0; q < n; ++q) st[q] = -1.0;      // "not published yet" (kernel q of the chunk overwrites its slot with a squared norm: >= 0, or NaN)
         for (int q = 0; q < n; ++q) {
             if (mr) { int rc = comm_halo(c, c->band.rec[(k + q + 1) & 1], 1, 4); if (rc) return rc; }
             timed(c, "pcg_pass", [&] { launch_cgf_pass(ap, c->pcg_sc, c->pcg_part, G, rows, k + q, cap, c->mbox_dev + off + q, c->stream); });
@@ -116,13 +116,18 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         if (drained) { int rc = flush(c); if (rc) return rc; }
         for (int q = 0; q < n && iters < 0; ++q) {
             const int kk = k + q;
-            if (!drained && std::isnan(st[q])) {
-                const int w = wait_mapped(c, [st, q] { return !std::isnan(st[q]); }, "pcg_solve");
+            if (!drained && st[q] == -1.0) {
+                const int w = wait_mapped(c, [st, q] { return st[q] != -1.0; }, "pcg_solve");
                 if (w < 0) return w;
                 drained = w == 1;                              // nothing left that could publish
             }
-            const double v = st[q];
-            if (std::isnan(v)) return fail(c, PSGSDF_ERR_DEVICE, "PCG kernel %d published nothing", kk);
+            double v = st[q];
+            if (v == -1.0) {      // "drained" came from a stream query: before calling it a failure, drain for certain and look again
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                v = st[q];
+            }
+            if (v == -1.0) return fail(c, PSGSDF_ERR_DEVICE, "PCG kernel %d published nothing", kk);
+            if (std::isnan(v)) return fail(c, PSGSDF_ERR_DEVICE, "PCG kernel %d published NaN: the distance system (or the sums another rank contributed) contains NaN", kk);
             if (kk == 0) {
                 rhsN = (float)v;
                 if (rhsN == 0.f) { iters = 0; break; }
