@@ -67,6 +67,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         if (tail && !c->profiling) { tail(c->pcg_sc + (gate_on_converged ? 2 : 1)); if (tail_ran) *tail_ran = true; }
         const int w = wait_mapped(c, [st] { return !std::isnan(st[3]); }, "pcg_solve");
         if (w < 0) return w;
+        if (std::isnan(st[3])) HIPCHK(c, hipStreamSynchronize(c->stream));      // ("drained" came from a stream query: drain for certain before calling it a failure)
         if (std::isnan(st[3])) return fail(c, PSGSDF_ERR_DEVICE, "the PCG kernel published nothing");
         if (st[3] != 1.0) return fail(c, PSGSDF_ERR_DEVICE, "the PCG kernel gave up waiting for its other workgroups (status %g): is another process holding CUs of this device?", (double)st[3]);
         if (w == 0 && !c->pending_fold.n) { for (auto& f : c->deferred) f(); c->deferred.clear(); c->mbox_used = 0; }   // everything enqueued before the solve has landed
