@@ -349,7 +349,9 @@ __device__ __forceinline__ void sample_cell(const float* base, int frame, bool i
 template <bool GRAD>
 __device__ __forceinline__ void sample(const float* base, int frame, bool idx32, const Cam& cam, float m_col, float n_row, float mj_col, float nj_row, float* I, float* gu, float* gv) {
     sample_cell<GRAD>(base, frame, idx32, cam, m_col, n_row, mj_col, nj_row, I, gu, gv);
-    if (GRAD && (floorf(nj_row) != floorf(n_row) || floorf(mj_col) != floorf(m_col))) {   // the Jacobian's projection landed in the neighbouring cell (~1e-5 of the observations): redo the gradient there
+    // the Jacobian's projection landed in the neighbouring cell (~1e-5 of the observations): redo the gradient there -- unless that cell is
+    // outside the image (coordinate < 0: the Jacobian's own in-image test fails, its row gets weight 0, and cell -1 must not be read)
+    if (GRAD && (floorf(nj_row) != floorf(n_row) || floorf(mj_col) != floorf(m_col)) && nj_row >= 0.f && mj_col >= 0.f) {
         float Iu[3];
         sample_cell<true>(base, frame, idx32, cam, mj_col, nj_row, mj_col, nj_row, Iu, gu, gv);
     }
@@ -389,7 +391,7 @@ __device__ __forceinline__ void sample_u8_cell(const unsigned* base, float scale
 template <bool GRAD>
 __device__ __forceinline__ void sample_u8(const unsigned* base, float scale, int frame, const Cam& cam, float m_col, float n_row, float mj_col, float nj_row, float* I, float* gu, float* gv) {
     sample_u8_cell<GRAD>(base, scale, frame, cam, m_col, n_row, mj_col, nj_row, I, gu, gv);
-    if (GRAD && (floorf(nj_row) != floorf(n_row) || floorf(mj_col) != floorf(m_col))) {   // as in sample()
+    if (GRAD && (floorf(nj_row) != floorf(n_row) || floorf(mj_col) != floorf(m_col)) && nj_row >= 0.f && mj_col >= 0.f) {   // as in sample()
         float Iu[3];
         sample_u8_cell<true>(base, scale, frame, cam, mj_col, nj_row, mj_col, nj_row, Iu, gu, gv);
     }
