@@ -302,6 +302,12 @@ int psgsdf_debug_rare_rows(psgsdf_ctx* ctx, int64_t* rows, int64_t* waves);
 int psgsdf_debug_frame_system(psgsdf_ctx* ctx, int block, double* H, double* b);
 /* albedo diagonal system: H (3*n_band), b (3*n_band), channel-interleaved per row */
 int psgsdf_debug_albedo_system(psgsdf_ctx* ctx, float* H, float* b);
+/* Host <-> device hand-off statistics of this context (no reference counterpart: the reference is one host thread).
+ *   out[0] scalar read-backs validated against their check words      out[1] of those: not complete yet when the marker / status word
+ *   the host waited for had already arrived (waited for; PSGSDF_MBOX_CHECK=0 takes them as they are: the round-2 behaviour)
+ *   out[2] distance steps re-run on the per-pass kernels because the persistent solve could not get its workgroups co-resident
+ *   out[3] reserved (0) */
+int psgsdf_debug_sync_stats(psgsdf_ctx* ctx, int64_t out[4]);
 
 #ifdef __cplusplus
 }

@@ -361,6 +361,11 @@ class Api:
         self._check(self._fn("debug_time_pcg_solve")(self.ctx, C.c_int(passes), C.c_int(reps), C.byref(ms), shape, st), "debug_time_pcg_solve")
         return ms.value, (shape[0], shape[1]), [x for x in st]
 
+    def debug_sync_stats(self):
+        out = (C.c_int64 * 4)()
+        self._check(self._fn("debug_sync_stats")(self.ctx, out), "debug_sync_stats")
+        return dict(readbacks_checked=out[0], readbacks_late=out[1], persist_fallbacks=out[2])
+
     def debug_rare_rows(self):
         r = C.c_int64(); w = C.c_int64()
         self._check(self._fn("debug_rare_rows")(self.ctx, C.byref(r), C.byref(w)), "debug_rare_rows")

@@ -90,7 +90,7 @@ int psgsdf_debug_time_pcg_solve(psgsdf_ctx* c, int passes, int reps, double* ms_
         launch_sweep_dist(a, c->stream);
         launch_assemble(a, c->stream);
         HIPCHK(c, hipEventRecord(e0, c->stream));
-        launch_cgf_solve(a, c->pcg_sc, c->pcg_gran, G, rows, 1 << 30, c->mbox_dev, passes, c->stream);
+        launch_cgf_solve(a, c->pcg_sc, c->pcg_gran, G, rows, 1 << 30, c->mbox_dev, 0ull, passes, c->stream);
         HIPCHK(c, hipEventRecord(e1, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
@@ -165,6 +165,12 @@ int psgsdf_debug_albedo_system(psgsdf_ctx* c, float* H, float* b) {
     HIPCHK(c, hipMemcpyAsync(bb.data(), c->band.ab, sizeof(float) * 3 * Sp, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int j = 0; j < S; ++j) for (int ch = 0; ch < 3; ++ch) { H[3 * j + ch] = h[(size_t)ch * Sp + j]; b[3 * j + ch] = bb[(size_t)ch * Sp + j]; }
+    return PSGSDF_OK;
+}
+
+int psgsdf_debug_sync_stats(psgsdf_ctx* c, int64_t out[4]) {
+    if (!c || !out) return PSGSDF_ERR_ARG;
+    out[0] = c->mbox_checked; out[1] = c->mbox_late; out[2] = c->persist_fallbacks; out[3] = 0;
     return PSGSDF_OK;
 }
 

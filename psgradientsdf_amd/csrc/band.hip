@@ -299,19 +299,20 @@ void launch_lower_bound(const int* lin, int S, int target, int* out, hipStream_t
 }
 // fold per-workgroup partials into a few doubles.  `out` may be host-mapped pinned memory: the host then needs no
 // D2H copy (each hipMemcpyAsync costs ~10 us of GPU idle around it), only the stream synchronisation it does anyway.
-__global__ void __launch_bounds__(kBlock) k_sum_parts(const double* __restrict__ part, int PB, int nblk, SlotList slots, double* __restrict__ out) {
+__global__ void __launch_bounds__(kBlock) k_sum_parts(const double* __restrict__ part, int PB, int nblk, SlotList slots, double* __restrict__ out, unsigned long long key) {
     __shared__ double red[kBlock / 64];
     for (int s = 0; s < slots.n; ++s) {
         double t = block_total(part + (size_t)slots.id[s] * PB, nblk, red);
-        if (threadIdx.x == 0) out[s] = t;
+        if (threadIdx.x == 0) mbox_put(out, slots.n, s, t, key);
         __syncthreads();
     }
+    if (threadIdx.x == 0) mbox_commit(key);
 }
-void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(kBlock), 0, s, part, PB, nblk, slots, out);
+void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, unsigned long long key, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(kBlock), 0, s, part, PB, nblk, slots, out, key);
 }
 // sum of columns (col, col+1) over the F frame-accumulator rows -> out[0..1]
-__global__ void __launch_bounds__(kBlock) k_frame_cols(const double* __restrict__ frame, int F, int col, double* __restrict__ out) {
+__global__ void __launch_bounds__(kBlock) k_frame_cols(const double* __restrict__ frame, int F, int col, double* __restrict__ out, unsigned long long key) {
     __shared__ double red[kBlock / 64];
     double a = 0, b = 0;
     for (int f = threadIdx.x; f < F; f += blockDim.x) { a += frame[(size_t)f * kFrameRow + col]; b += frame[(size_t)f * kFrameRow + col + 1]; }
@@ -319,14 +320,14 @@ __global__ void __launch_bounds__(kBlock) k_frame_cols(const double* __restrict_
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) red[w] = a;
     __syncthreads();
-    if (threadIdx.x == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; out[0] = t; }
+    if (threadIdx.x == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; mbox_put(out, 2, 0, t, key); }
     __syncthreads();
     if (lane == 0) red[w] = b;
     __syncthreads();
-    if (threadIdx.x == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; out[1] = t; }
+    if (threadIdx.x == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; mbox_put(out, 2, 1, t, key); mbox_commit(key); }
 }
-void launch_frame_cols(const double* frame, int F, int col, double* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_frame_cols, dim3(1), dim3(kBlock), 0, s, frame, F, col, out);
+void launch_frame_cols(const double* frame, int F, int col, double* out, unsigned long long key, hipStream_t s) {
+    hipLaunchKernelGGL(k_frame_cols, dim3(1), dim3(kBlock), 0, s, frame, F, col, out, key);
 }
 // flush marker: everything queued before it has completed when the host reads `v` from the mapped slot (engine.hip: flush)
 __global__ void k_marker(double* p, double v) { *p = v; __threadfence_system(); }
@@ -335,7 +336,7 @@ __global__ void k_zero_f64(double* p, int n) { for (int i = blockIdx.x * blockDi
 // multi-rank scalar read-backs: all-reduced values from the device shadow into their (host-mapped) mailbox slots
 __global__ void k_copy_segs(const double* __restrict__ src, double* __restrict__ dst, CopySegs segs) {
     for (int q = 0; q < segs.n; ++q)
-        for (unsigned i = threadIdx.x; i < segs.len[q]; i += blockDim.x) dst[segs.off[q] + i] = src[segs.off[q] + i];
+        for (unsigned i = threadIdx.x; i < segs.len[q]; i += blockDim.x) mbox_put(dst + segs.off[q], (int)segs.len[q], (int)i, src[segs.off[q] + i], segs.key[q]);
     __threadfence_system();
 }
 void launch_copy_segs(const double* src, double* dst, const CopySegs& segs, hipStream_t s) { if (segs.n > 0) hipLaunchKernelGGL(k_copy_segs, dim3(1), dim3(64), 0, s, src, dst, segs); }

@@ -202,14 +202,24 @@ __device__ __forceinline__ double block_total(const double* part, int n, double*
     return s;
 }
 #define PART(a, slot) ((a).acc.part + (size_t)(slot) * (a).acc.PB)
+// Value i of an n-value read-back slot.  key != 0: the slot lives in the host-mapped mailbox and the value travels with its check word
+// bits(v) ^ (key + i), n doubles further on (engine.h FoldReq): the host takes the value only when the pair matches, so a read-back can
+// never be consumed before it has arrived, whatever the marker or status word the host was waiting for says.  The writing thread ends with
+// mbox_commit (system-scope release: the words leave this XCD's L2 for host memory now, not at some later write-back).
+__device__ __forceinline__ void mbox_put(double* out, int n, int i, double v, unsigned long long key) {
+    out[i] = v;
+    if (key) reinterpret_cast<unsigned long long*>(out)[n + i] = (unsigned long long)__double_as_longlong(v) ^ (key + (unsigned long long)i);
+}
+__device__ __forceinline__ void mbox_commit(unsigned long long key) { if (key) __threadfence_system(); }
 // a.fold: sum the partial slots the PREVIOUS kernel left behind (first workgroup only; all its threads must call).
 // The calling kernel must not write the folded slots itself (engine.hip: take_fold checks).
 __device__ __forceinline__ void fold_pending(const SweepArgs& a, double* red /*[kBlock/64]*/) {
     if (a.fold.n == 0 || blockIdx.x != 0 || blockIdx.y != 0) return;
     for (int s = 0; s < a.fold.n; ++s) {
         const double t = block_total(PART(a, a.fold.id[s]), a.fold.nblk, red);
-        if (threadIdx.x == 0) a.fold.out[s] = t;
+        if (threadIdx.x == 0) mbox_put(a.fold.out, a.fold.n, s, t, a.fold.key);
     }
+    if (threadIdx.x == 0) mbox_commit(a.fold.key);
     __syncthreads();
 }
 

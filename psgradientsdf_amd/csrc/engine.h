@@ -108,7 +108,10 @@ struct AlbedoReg {
 
 // a pending fold of per-workgroup partials (previous kernel's scalar reductions) that the NEXT kernel performs in its
 // first workgroup instead of a 1-workgroup kernel of its own (saves a launch + boundary per scalar read-back)
-struct FoldReq { int n; int id[4]; int nblk; double* out; };
+// `key` != 0: `out` is a slot of the host-mapped mailbox and every value is followed (n doubles further on) by its check word
+// bits(value) ^ (key + index): the host accepts a read-back only when the pair matches (engine.hip: deliver), whatever order the two
+// words reach host memory in and however they are ordered against the marker / status word it was told to wait for.
+struct FoldReq { int n; int id[4]; int nblk; double* out; unsigned long long key; };
 
 // keyframe images: float RGB [F][H][W][3] (psgsdf_set_keyframes) or RGBA8 words [F][H][W] (psgsdf_set_keyframes_u8); exactly one is set
 struct ImgSrc {
@@ -160,11 +163,11 @@ void launch_obs_count(const Band& b, int F, int row0, int row1, int* counts, hip
 void launch_obs_fill(const Band& b, int F, int row0, int row1, const int* offsets, hipStream_t s); // offsets[F][nch] -> b.obs_rows
 void launch_lower_bound(const int* lin, int S, int target, int* out, hipStream_t s);               // *out = number of band rows with lin < target (lin ascending)
 struct SlotList { int n; int id[8]; };
-void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, hipStream_t s);
-void launch_frame_cols(const double* frame, int F, int col, double* out, hipStream_t s);
+void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, unsigned long long key, hipStream_t s);   // key: FoldReq
+void launch_frame_cols(const double* frame, int F, int col, double* out, unsigned long long key, hipStream_t s);
 void launch_zero_f64(double* p, int n, hipStream_t s);
-struct CopySegs { int n; unsigned off[16]; unsigned len[16]; };
-void launch_copy_segs(const double* src, double* dst, const CopySegs& segs, hipStream_t s);   // dst[off + i] = src[off + i] for every segment
+struct CopySegs { int n; unsigned off[16]; unsigned len[16]; unsigned long long key[16]; };
+void launch_copy_segs(const double* src, double* dst, const CopySegs& segs, hipStream_t s);   // dst[off + i] = src[off + i] for every segment, + the check words (FoldReq) behind each segment
 void launch_marker(double* p, double v, hipStream_t s);
 void launch_init_albedo(const SweepArgs& a, hipStream_t s);
 void launch_led_light_init(const SweepArgs& a, hipStream_t s);
@@ -173,8 +176,8 @@ void launch_sweep_albedo(const SweepArgs& a, hipStream_t s);
 void launch_apply_albedo(const SweepArgs& a, hipStream_t s);
 int launch_sweep_light(const SweepArgs& a, hipStream_t s);    // both return the workgroups per frame they used (0: nothing was launched, the rows are untouched)
 int launch_sweep_pose(const SweepArgs& a, hipStream_t s);
-void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, hipStream_t s);   // also sums the energy columns -> e_out (nullable) and clears the rows
-void launch_solve_pose(const SweepArgs& a, FrameP* frames, double* e_out, hipStream_t s);
+void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key, hipStream_t s);   // also sums the energy columns -> e_out (nullable; e_key: FoldReq)
+void launch_solve_pose(const SweepArgs& a, FrameP* frames, double* e_out, unsigned long long e_key, hipStream_t s);
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s);
 void launch_assemble(const SweepArgs& a, hipStream_t s);
 void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s);
@@ -185,7 +188,7 @@ void launch_cgf_sum(double* part, int G, int k, double* out, hipStream_t s);
 constexpr int kSolveGranPlanes = 8;
 constexpr int kSolveThreadsHost = 512, kSolveMaxBlocksHost = 256, kSolveMaxRowsHost = 4, kSolveMbSlots = 24;      // {iters, |r|^2, |b|^2, status} + stage timestamps of the timing hook
 int cgf_solve_max_blocks(int rows);      // resident workgroups per CU of the R-rows instance (occupancy query)
-void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, int force_passes, hipStream_t s);   // multi-rank: partials of pass k -> out[0..6]
+void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, hipStream_t s);   // mb[4] = check word over mb[0..3] (FoldReq)
 // "reg albedo" path (albedo_reg.hip); every launch covers the whole band (single rank only)
 void launch_areg_tables(const DenseView& d, const GridP& g, const SweepArgs& a, hipStream_t s);
 void launch_areg_build(const SweepArgs& a, hipStream_t s);                       // J, res from the current albedo; sum of res -> SC_AUX0

@@ -61,6 +61,33 @@ int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs) {
     int rc = read_frame_energy_deferred(c, col_e, [E, nobs](double e, double n) { *E = e; *nobs = n; });
     return rc ? rc : flush(c);
 }
+// Every deferred read-back is taken from the mailbox only when its values match their check words (device_common.h mbox_put): the marker of
+// flush() and the status word of the persistent solve say that the producing kernels have RUN, not that their words have reached host
+// memory -- a read-back that is still on its way (profiles/r03_notes.md section 1: the round-2 flake) is waited for, and counted.
+int deliver(psgsdf_ctx* c) {
+    for (Deferred& d : c->deferred) {
+        if (d.key && c->mbox_check) {
+            const volatile double* v = d.src; const int n = d.n; const unsigned long long key = d.key;
+            auto whole = [v, n, key] { for (int i = 0; i < n; ++i) if ((dbits(v[i]) ^ dbits(v[n + i])) != key + (unsigned long long)i) return false; return true; };
+            c->mbox_checked++;
+            if (!whole()) {
+                c->mbox_late++;
+                const int w = wait_mapped(c, whole, "read-back");
+                if (w < 0) return w;
+                if (w == 1) { HIPCHK(c, hipStreamSynchronize(c->stream)); if (!whole()) return fail(c, PSGSDF_ERR_DEVICE, "a scalar read-back never arrived (the kernel that owed it did not run)"); }
+            }
+        }
+        d.consume(d.src);
+    }
+    c->deferred.clear(); c->mbox_used = 0;
+    return 0;
+}
+int mbox_reserve(psgsdf_ctx* c, int n, size_t* off, unsigned long long* key) {
+    if (c->mbox_used + 2 * (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+    *off = c->mbox_used; c->mbox_used += 2 * (size_t)n;
+    *key = (++c->mbox_serial << 8) | 0x80u;      // never 0; keys of different reservations differ in every index they use (n <= 64)
+    return 0;
+}
 // synchronise the stream once and run every deferred consumer in submission order
 int flush(psgsdf_ctx* c) {
     materialize_fold(c);
@@ -78,9 +105,7 @@ int flush(psgsdf_ctx* c) {
     }
     if (!synced) HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());                            // asynchronous launch failures surface here, not never
-    for (auto& f : c->deferred) f();
-    c->deferred.clear(); c->mbox_used = 0;
-    return 0;
+    return deliver(c);
 }
 // sum of per-workgroup partials of `slots`, delivered to `consume(sums)` at the next flush (no host sync here).
 // The fold itself is left pending: the next kernel that can take it (take_fold) does it in its first workgroup;
@@ -88,7 +113,7 @@ int flush(psgsdf_ctx* c) {
 void materialize_fold(psgsdf_ctx* c) {
     if (!c->pending_fold.n) return;
     SlotList sl; sl.n = c->pending_fold.n; for (int i = 0; i < sl.n; ++i) sl.id[i] = c->pending_fold.id[i];
-    launch_sum_parts(c->part, c->PB, c->pending_fold.nblk, sl, c->pending_fold.out, c->stream);
+    launch_sum_parts(c->part, c->PB, c->pending_fold.nblk, sl, c->pending_fold.out, c->pending_fold.key, c->stream);
     c->pending_fold.n = 0;
 }
 // Multi-rank: the scalar read-backs staged in the mailbox shadow since the last commit are summed over the ranks in ONE all-reduce (the
@@ -103,7 +128,7 @@ int mg_commit(psgsdf_ctx* c) {
     int rc = comm_allreduce(c, c->mbox_shadow + lo, (int)(hi - lo)); if (rc) return rc;
     for (size_t i = 0; i < c->mg_segs.size(); i += 16) {
         CopySegs cs{}; cs.n = (int)std::min<size_t>(16, c->mg_segs.size() - i);
-        for (int q = 0; q < cs.n; ++q) { cs.off[q] = c->mg_segs[i + q].off; cs.len[q] = c->mg_segs[i + q].n; }
+        for (int q = 0; q < cs.n; ++q) { cs.off[q] = c->mg_segs[i + q].off; cs.len[q] = c->mg_segs[i + q].n; cs.key[q] = c->mg_segs[i + q].key; }
         launch_copy_segs(c->mbox_shadow, c->mbox_dev, cs, c->stream);
     }
     c->mg_segs.clear();
@@ -130,37 +155,35 @@ void take_fold(psgsdf_ctx* c, SweepArgs& a, unsigned writes) {
 }
 int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<void(const double*)> consume) {
     materialize_fold(c);
-    if (c->mbox_used + (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
-    const size_t off = c->mbox_used; c->mbox_used += n;
-    // multi-rank: this slab's sums go to the device shadow of the mailbox; mg_commit all-reduces them and fills the mailbox slots
+    size_t off; unsigned long long key;
+    { int rc = mbox_reserve(c, n, &off, &key); if (rc) return rc; }
+    // multi-rank: this slab's sums go to the device shadow of the mailbox; mg_commit all-reduces them and fills the mailbox slots (values + check words)
     double* dst = (slab_mode(c) ? c->mbox_shadow : c->mbox_dev) + off;
-    if (slab_mode(c)) c->mg_segs.push_back({(unsigned)off, (unsigned)n});
+    const unsigned long long dkey = slab_mode(c) ? 0ull : key;
+    if (slab_mode(c)) c->mg_segs.push_back({(unsigned)off, (unsigned)n, key});
     if (n <= 4 && c->fold_in_next) {
         c->pending_fold.n = n; for (int i = 0; i < n; ++i) c->pending_fold.id[i] = slots[i];
-        c->pending_fold.nblk = band_blocks(c); c->pending_fold.out = dst;
+        c->pending_fold.nblk = band_blocks(c); c->pending_fold.out = dst; c->pending_fold.key = dkey;
     } else {
         SlotList sl; sl.n = n; for (int i = 0; i < n; ++i) sl.id[i] = slots[i];
-        launch_sum_parts(c->part, c->PB, band_blocks(c), sl, dst, c->stream);
+        launch_sum_parts(c->part, c->PB, band_blocks(c), sl, dst, dkey, c->stream);
     }
-    const double* src = c->mbox + off;
-    c->deferred.push_back([src, consume] { consume(src); });
+    c->deferred.push_back({c->mbox + off, n, key, std::move(consume)});
     return 0;
 }
 int read_frame_energy_deferred(psgsdf_ctx* c, int col_e, std::function<void(double, double)> consume) {
-    if (c->mbox_used + 2 > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
-    const size_t off = c->mbox_used; c->mbox_used += 2;
-    launch_frame_cols(c->acc_frame, c->F, col_e, c->mbox_dev + off, c->stream);
-    const double* src = c->mbox + off;
-    c->deferred.push_back([src, consume] { consume(src[0], src[1]); });
+    size_t off; unsigned long long key;
+    { int rc = mbox_reserve(c, 2, &off, &key); if (rc) return rc; }
+    launch_frame_cols(c->acc_frame, c->F, col_e, c->mbox_dev + off, key, c->stream);
+    c->deferred.push_back({c->mbox + off, 2, key, [consume](const double* v) { consume(v[0], v[1]); }});
     return 0;
 }
 // deferred variant without a kernel of its own: the solve kernel that follows the sweep writes the two sums to *dev_slot
-int reserve_frame_energy_deferred(psgsdf_ctx* c, std::function<void(double, double)> consume, double** dev_slot) {
-    if (c->mbox_used + 2 > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
-    const size_t off = c->mbox_used; c->mbox_used += 2;
-    *dev_slot = c->mbox_dev + off;
-    const double* src = c->mbox + off;
-    c->deferred.push_back([src, consume] { consume(src[0], src[1]); });
+int reserve_frame_energy_deferred(psgsdf_ctx* c, std::function<void(double, double)> consume, double** dev_slot, unsigned long long* key_out) {
+    size_t off; unsigned long long key;
+    { int rc = mbox_reserve(c, 2, &off, &key); if (rc) return rc; }
+    *dev_slot = c->mbox_dev + off; *key_out = key;
+    c->deferred.push_back({c->mbox + off, 2, key, [consume](const double* v) { consume(v[0], v[1]); }});
     return 0;
 }
 int ensure_host_buf(psgsdf_ctx* c, size_t n) {
@@ -189,6 +212,7 @@ int alloc_dense(psgsdf_ctx* c, DenseView& d, long long nvox, int KW, bool with_r
 
 // (re)build the band from the dense grid: flags -> scan -> compact planes -> neighbour tables
 int build_band(psgsdf_ctx* c) {
+    if (!c->deferred.empty() || c->pending_fold.n) { int rc = flush(c); if (rc) return rc; }   // (read-backs of the band that is about to be replaced)
     const long long nvox = c->grid.nvox;
     const int KW = c->dense.KW;
     if (!c->block_sums) HIPCHK(c, hipMalloc(&c->block_sums, sizeof(int) * ((nvox + 1023) / 1024 + 1)));
@@ -331,7 +355,7 @@ int build_band(psgsdf_ctx* c) {
             HIPCHK(c, hipHostMalloc(&c->mbox, sizeof(double) * need, hipHostMallocMapped));
             HIPCHK(c, hipHostGetDevicePointer((void**)&c->mbox_dev, c->mbox, 0));
             c->mbox_alloc = need; c->mbox_n = need - 1;      // [mbox_n] = flush marker
-            c->mbox[c->mbox_n] = 0.0; c->flush_seq = 0;
+            memset(c->mbox, 0, sizeof(double) * need); c->flush_seq = 0;
         }
         if (slab_mode(c) && !c->mbox_shadow) {
             HIPCHK(c, hipMalloc(&c->mbox_shadow, sizeof(double) * c->mbox_alloc));

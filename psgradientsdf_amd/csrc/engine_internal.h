@@ -25,7 +25,9 @@ namespace psge {
 constexpr int kMgScal = 64;   // doubles in the set-up exchange buffer (2 per rank: at most 32 ranks)
 struct KTime { double ms = 0; int64_t n = 0; };
 struct Comm;                  // comm.hip: RCCL communicator or caller-supplied transport
-struct MgSeg { unsigned off, n; };
+struct MgSeg { unsigned off, n; unsigned long long key; };
+// a scalar read-back waiting in the host-mapped mailbox: n values at src, their check words behind them (engine.h FoldReq; key 0: unchecked)
+struct Deferred { const double* src; int n; unsigned long long key; std::function<void(const double*)> consume; };
 }  // namespace psge
 using psge::KTime;
 using namespace psg;   // the layout structs of engine.h
@@ -83,7 +85,11 @@ struct psgsdf_ctx {
     // next host sync
     double* mbox = nullptr; double* mbox_dev = nullptr; size_t mbox_n = 0, mbox_used = 0;
     size_t mbox_alloc = 0; double flush_seq = 0;    // the last slot of the allocation is the flush marker
-    std::vector<std::function<void()>> deferred;
+    std::vector<psge::Deferred> deferred;
+    unsigned long long mbox_serial = 0;  // key generator of the read-back slots
+    bool mbox_check = true;              // PSGSDF_MBOX_CHECK=0: take read-backs on the marker's / status word's say-so (round-2 behaviour; reproduces its flake)
+    long long persist_fallbacks = 0;     // distance steps re-run on the per-pass kernels after the persistent solve gave up (loop.hip)
+    long long mbox_checked = 0, mbox_late = 0;   // read-backs validated / of those: not complete yet when the host was told everything had landed
     // cached energies
     double en_sum = 0, el_sum = 0;       // sums over the band from the last k_derive
     // row partition (multi-rank): this context owns band rows [row0, row1); halo = widest column reach
@@ -108,7 +114,7 @@ struct psgsdf_ctx {
     bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
     bool albedo_applied = false;         // the last albedo sweep already applied its update (step_begin -> step_finish)
     unsigned* img8 = nullptr; float img_scale = 0.f;   // keyframes uploaded as 8-bit RGB (psgsdf_set_keyframes_u8): RGBA8 words, c->img stays null
-    double* frame_e_slot = nullptr;      // mailbox slot the next per-frame solve writes its sweep's energy sums to
+    double* frame_e_slot = nullptr; unsigned long long frame_e_key = 0;   // mailbox slot (and its key) the next per-frame solve writes its sweep's energy sums to
     bool pcg_poll = true;                // PCG stop test by watching the mapped mailbox (PSGSDF_PCG_POLL=0: drain the stream instead)
     int need[2] = {0, 0}; int* d_need = nullptr;   // halo rows needed below row0 / from row1 up
     bool own_stream = true;
@@ -128,6 +134,7 @@ namespace psge {
 using namespace psg;
 
 int fail(psgsdf_ctx* c, int code, const char* fmt, ...);
+inline unsigned long long dbits(double v) { unsigned long long u; memcpy(&u, &v, 8); return u; }
 #define HIPCHK(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(c, PSGSDF_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
 
 template <class Fn> void timed(psgsdf_ctx* c, const char* name, Fn&& fn) {
@@ -178,11 +185,13 @@ inline int band_blocks(const psgsdf_ctx* c) { return (c->row1 - c->row0 + kBlock
 inline double band_mean(const psgsdf_ctx* c, double sum) { return c->S_global ? sum / (double)c->S_global : 0.0; }   // (1/S) sum over the band of the WHOLE volume
 inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l, float E_r = 0.f) { return E + c->reg_n * E_n + c->reg_l * E_l + c->reg_r * E_r; }   // OptimizerAux.cpp:261
 int flush(psgsdf_ctx* c);
+int mbox_reserve(psgsdf_ctx* c, int n, size_t* off, unsigned long long* key);   // n values + n check words; flushes first if the mailbox is full
+int deliver(psgsdf_ctx* c);              // validate and consume every deferred read-back (the caller knows their producers have run)
 int read_parts(psgsdf_ctx* c, const int* slots, int n, double* out);
 int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs);
 int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<void(const double*)> consume);
 int read_frame_energy_deferred(psgsdf_ctx* c, int col_e, std::function<void(double, double)> consume);
-int reserve_frame_energy_deferred(psgsdf_ctx* c, std::function<void(double, double)> consume, double** dev_slot);
+int reserve_frame_energy_deferred(psgsdf_ctx* c, std::function<void(double, double)> consume, double** dev_slot, unsigned long long* key);
 void materialize_fold(psgsdf_ctx* c);
 void take_fold(psgsdf_ctx* c, SweepArgs& a, unsigned writes);
 int ensure_host_buf(psgsdf_ctx* c, size_t n);

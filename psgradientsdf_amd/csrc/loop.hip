@@ -58,19 +58,37 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
     if (a.pcg_gran && cgf_solve_shape(c, &G, &rows)) {
         // ---- the whole solve as one persistent kernel: nothing for the host to decide until it is over, so the distance update and
         // the regrad are enqueued right behind it (gated on the device-side outcome) and the host only picks up the statistics
-        if (c->mbox_used + (size_t)kSolveMbSlots > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
+        // the fold of the distance sweep's sums that this kernel would do in its prologue has to be on the stream BEFORE anything that consumes
+        // its result: a flush (mailbox full) validates and delivers it, mg_commit (a communicator, also a one-rank one) all-reduces and copies it
+        SweepArgs as = a;
+        auto fold_now = [&] {
+            if (!as.fold.n) return;
+            SlotList sl; sl.n = as.fold.n; for (int i = 0; i < sl.n; ++i) sl.id[i] = as.fold.id[i];
+            launch_sum_parts(c->part, c->PB, as.fold.nblk, sl, as.fold.out, as.fold.key, c->stream);
+            as.fold.n = 0;
+        };
+        if (slab_mode(c)) fold_now();
+        if (c->mbox_used + (size_t)kSolveMbSlots > c->mbox_n) { fold_now(); int rc = flush(c); if (rc) return rc; }
         { int rc = mg_commit(c); if (rc) return rc; }      // (a one-rank communicator: the read-backs staged so far are delivered below)
         const size_t off = c->mbox_used; c->mbox_used += kSolveMbSlots;
         volatile double* st = c->mbox + off;
-        st[3] = NAN;
-        timed(c, "pcg_solve", [&] { launch_cgf_solve(a, c->pcg_sc, c->pcg_gran, G, rows, cap, c->mbox_dev + off, 0, c->stream); });
+        const unsigned long long key = (++c->mbox_serial << 8) | 0x80u;
+        st[3] = NAN; st[4] = 0.0;
+        timed(c, "pcg_solve", [&] { launch_cgf_solve(as, c->pcg_sc, c->pcg_gran, G, rows, cap, c->mbox_dev + off, key, 0, c->stream); });
         if (tail && !c->profiling) { tail(c->pcg_sc + (gate_on_converged ? 2 : 1)); if (tail_ran) *tail_ran = true; }
-        const int w = wait_mapped(c, [st] { return !std::isnan(st[3]); }, "pcg_solve");
+        // the four status words are taken only together with their check word (engine.h FoldReq)
+        const bool chk = c->mbox_check;
+        auto landed = [st, key, chk] {
+            const double s3 = st[3];
+            if (std::isnan(s3)) return false;
+            return !chk || (dbits(st[0]) ^ dbits(st[1]) ^ dbits(st[2]) ^ dbits(s3) ^ dbits(st[4])) == key;
+        };
+        const int w = wait_mapped(c, landed, "pcg_solve");
         if (w < 0) return w;
-        if (std::isnan(st[3])) HIPCHK(c, hipStreamSynchronize(c->stream));      // ("drained" came from a stream query: drain for certain before calling it a failure)
-        if (std::isnan(st[3])) return fail(c, PSGSDF_ERR_DEVICE, "the PCG kernel published nothing");
+        if (!landed()) HIPCHK(c, hipStreamSynchronize(c->stream));      // ("drained" came from a stream query: drain for certain before calling it a failure)
+        if (!landed()) return fail(c, PSGSDF_ERR_DEVICE, "the PCG kernel published nothing");
         if (st[3] != 1.0) return fail(c, PSGSDF_ERR_DEVICE, "the PCG kernel gave up waiting for its other workgroups (status %g): is another process holding CUs of this device?", (double)st[3]);
-        if (w == 0 && !c->pending_fold.n) { for (auto& f : c->deferred) f(); c->deferred.clear(); c->mbox_used = 0; }   // everything enqueued before the solve has landed
+        if (w == 0 && !c->pending_fold.n) { int rc = deliver(c); if (rc) return rc; }   // everything enqueued before the solve has run: its read-backs are validated and taken
         const float rhsN = (float)st[2];
         if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }
         const double err = sqrt((double)(float)st[1] / (double)rhsN);
@@ -141,10 +159,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
             else if (kk == cap) iters = cap;
         }
         if (!drained && c->pending_fold.n) { int rc = flush(c); if (rc) return rc; drained = true; }   // (cannot happen: assemble took it)
-        if (!drained) {   // every deferred read-back enqueued before the chunk has landed (in-order stream): deliver them
-            for (auto& f : c->deferred) f();
-            c->deferred.clear(); c->mbox_used = 0;
-        }
+        if (!drained) { int rc = deliver(c); if (rc) return rc; }   // every deferred read-back enqueued before the chunk has been produced (in-order stream): validate and take them
         if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }
         if (iters >= 0) break;
         k += n;
@@ -252,7 +267,7 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
             // multi-rank: every slab has summed its own observations into the per-frame rows; after the all-reduce every rank holds the
             // global normal equations and solves all F (tiny) systems itself
             if ((rc = comm_allreduce(c, c->acc_frame, c->F * kFrameRow))) return rc;
-            if (deferred_consumer) return reserve_frame_energy_deferred(c, deferred_consumer, &c->frame_e_slot);   // filled by the solve kernel
+            if (deferred_consumer) return reserve_frame_energy_deferred(c, deferred_consumer, &c->frame_e_slot, &c->frame_e_key);   // filled by the solve kernel
             if ((rc = read_frame_energy(c, col, &e_sum, &nobs))) return rc;
             break;
         }
@@ -288,13 +303,13 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
             break;
         }
         case PSGSDF_LIGHT:
-            timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->frame_e_slot, c->stream); });
-            c->frame_e_slot = nullptr;
+            timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->frame_e_slot, c->frame_e_key, c->stream); });
+            c->frame_e_slot = nullptr; c->frame_e_key = 0;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = led ? 1 : c->F;
             break;
         case PSGSDF_POSE:
-            timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->frame_e_slot, c->stream); });
-            c->frame_e_slot = nullptr;
+            timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->frame_e_slot, c->frame_e_key, c->stream); });
+            c->frame_e_slot = nullptr; c->frame_e_key = 0;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = c->F;
             break;
         case PSGSDF_DIST: {
@@ -303,7 +318,7 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
             bool apply_in_solve = false;      // (the accepted count goes to the first G entries of a partial slot that holds one entry per 256 rows)
             { int Gs, Rs; if (a.pcg_fuse_init && cgf_solve_shape(c, &Gs, &Rs)) { a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kSolveGranPlanes * kSolveMaxBlocksHost; a.pcg_asm = c->pcg_fuse_asm ? 1 : 0; apply_in_solve = a.pcg_asm && c->pcg_fuse_apply && Gs <= band_blocks(c); } }   // the assembly kernel also clears the persistent solve's tags
             if ((rc = comm_halo(c, c->band.blk, 14, 1))) return rc;   // multi-rank: rows of H next to a cut take contributions from the neighbour slab's voxel blocks
-            if (!a.pcg_asm) timed(c, "assemble", [&] { launch_assemble(a, c->stream); });      // (pcg_asm: the persistent solve assembles its rows itself; the distance sweep cleared its tags)
+            if (!a.pcg_asm) { timed(c, "assemble", [&] { launch_assemble(a, c->stream); }); a.fold.n = 0; }      // (pcg_asm: the persistent solve assembles its rows itself; the distance sweep cleared its tags)
             int iters = 0, ok = 1; double err = 0;
             const bool only_on_success = !led && c->set.ref_quirks;   // PsOptimizer.cpp:168-170 (B8): SH skips the update unless the solve reports Success
             if (apply_in_solve) a.pcg_apply = only_on_success ? 2 : 1;      // persistent solve: the update is its epilogue

@@ -404,7 +404,7 @@ __device__ __forceinline__ void assemble_row_regs(const SweepArgs& a, int i, dou
 }
 
 template <int R, bool ASM>
-__global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, double* fs, double* gran, int rows_per_wg, int kmax, double* mb, int force_passes) {
+__global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, double* fs, double* gran, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes) {
     __shared__ double red[8 * kSolveThreads / 64];
     __shared__ int s_abort;
     const Band& b = a.b;
@@ -429,8 +429,9 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             __syncthreads();
             if ((tid & 63) == 0) red[tid >> 6] = v;
             __syncthreads();
-            if (tid == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; a.fold.out[sl] = t; }
+            if (tid == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; mbox_put(a.fold.out, a.fold.n, sl, t, a.fold.key); }
         }
+        if (tid == 0) mbox_commit(a.fold.key);
         __syncthreads();
     }
     double bb_thread = 0.0;                     // ASM: |b|^2 of this thread's rows (summed over the device with the sums of pass 0)
@@ -680,9 +681,12 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         int iters = 0;
         if (!rhs_zero && k > 0) iters = (rr_cur < thr) ? k - 1 : k;      // Eigen leaves the loop before ++i when it detects convergence; k == kmax otherwise
         fs[1] = (double)(k + 1); fs[2] = ok ? 1.0 : 0.0;
-        mb[0] = (double)iters; mb[1] = (double)rr_cur; mb[2] = (double)rhsNorm2;
+        const double m0 = (double)iters, m1 = (double)rr_cur, m2 = (double)rhsNorm2, m3 = (double)status;
+        mb[0] = m0; mb[1] = m1; mb[2] = m2;
         __threadfence_system();
-        mb[3] = (double)status;                // the host watches this slot
+        mb[3] = m3;                            // the host watches this slot ...
+        // ... and takes the four words only together with their check word (engine.h FoldReq)
+        if (mb_key) reinterpret_cast<unsigned long long*>(mb)[4] = (unsigned long long)(__double_as_longlong(m0) ^ __double_as_longlong(m1) ^ __double_as_longlong(m2) ^ __double_as_longlong(m3)) ^ mb_key;
         __threadfence_system();
     }
 }
@@ -701,16 +705,16 @@ int cgf_solve_max_blocks(int rows) {
     return rows == 1 ? cgf_solve_prepare_both<1>() : rows == 2 ? cgf_solve_prepare_both<2>() : rows == 3 ? cgf_solve_prepare_both<3>() : cgf_solve_prepare_both<4>();
 }
 template <int R>
-static void launch_cgf_solve_r(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, int force_passes, hipStream_t s) {
-    if (a.pcg_asm) hipLaunchKernelGGL((k_cgf_solve<R, true>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
-    else hipLaunchKernelGGL((k_cgf_solve<R, false>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, force_passes);
+static void launch_cgf_solve_r(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, hipStream_t s) {
+    if (a.pcg_asm) hipLaunchKernelGGL((k_cgf_solve<R, true>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes);
+    else hipLaunchKernelGGL((k_cgf_solve<R, false>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes);
 }
-void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, int force_passes, hipStream_t s) {
+void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, hipStream_t s) {
     const int rows = (rows_per_wg + kSolveThreads - 1) / kSolveThreads;
-    if (rows == 1) launch_cgf_solve_r<1>(a, fs, gran, G, rows_per_wg, kmax, mb, force_passes, s);
-    else if (rows == 2) launch_cgf_solve_r<2>(a, fs, gran, G, rows_per_wg, kmax, mb, force_passes, s);
-    else if (rows == 3) launch_cgf_solve_r<3>(a, fs, gran, G, rows_per_wg, kmax, mb, force_passes, s);
-    else launch_cgf_solve_r<4>(a, fs, gran, G, rows_per_wg, kmax, mb, force_passes, s);
+    if (rows == 1) launch_cgf_solve_r<1>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s);
+    else if (rows == 2) launch_cgf_solve_r<2>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s);
+    else if (rows == 3) launch_cgf_solve_r<3>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s);
+    else launch_cgf_solve_r<4>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s);
 }
 
 // multi-rank: fold the partials of pass k (k = -1: |b|^2 of the init) into out[0..6] for the host program's all-reduce

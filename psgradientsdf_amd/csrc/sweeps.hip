@@ -432,7 +432,7 @@ __device__ void solve_spd(const double* Hin, const double* bin, double* x) {
 // The per-frame solves run as ONE workgroup (a thread takes frames tid, tid+256, ...), which lets the same kernel also sum the
 // energy / n_obs columns of the rows over the frames (e_out, may be host-mapped) in a fixed order.  The rows are final when it runs:
 // the last workgroup of every frame of the sweep has summed that frame's partial rows (frame_rows_publish).
-__device__ __forceinline__ void frame_rows_finish(const SweepArgs& a, int col_e, double* e_out, double* red) {
+__device__ __forceinline__ void frame_rows_finish(const SweepArgs& a, int col_e, double* e_out, unsigned long long e_key, double* red) {
     __syncthreads();                                       // every thread has read the rows it solves from
     if (e_out) {
         double e = 0, n = 0;
@@ -441,14 +441,14 @@ __device__ __forceinline__ void frame_rows_finish(const SweepArgs& a, int col_e,
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         if (lane == 0) { red[2 * w] = e; red[2 * w + 1] = n; }
         __syncthreads();
-        if (threadIdx.x == 0) { double te = 0, tn = 0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { te += red[2 * i]; tn += red[2 * i + 1]; } e_out[0] = te; e_out[1] = tn; }
+        if (threadIdx.x == 0) { double te = 0, tn = 0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { te += red[2 * i]; tn += red[2 * i + 1]; } mbox_put(e_out, 2, 0, te, e_key); mbox_put(e_out, 2, 1, tn, e_key); mbox_commit(e_key); }
         __syncthreads();
     }
 }
 
 // optimizeLightAll: PsOptimizer.cpp:175-203 (no damping) / LedOptimizer.cpp:134-160 (damped, one RGB vector)
 template <int MODEL>
-__global__ void __launch_bounds__(kBlock) k_solve_light(SweepArgs a, FrameP* frames, float* led_light, double* e_out) {
+__global__ void __launch_bounds__(kBlock) k_solve_light(SweepArgs a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key) {
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
     constexpr int NH = LED ? 3 : NB * (NB + 1) / 2;
@@ -490,14 +490,14 @@ __global__ void __launch_bounds__(kBlock) k_solve_light(SweepArgs a, FrameP* fra
             for (int i = 0; i < NB; ++i) frames[f].l[i] -= (float)xd[i];
         }
     }
-    frame_rows_finish(a, NH + NB, e_out, red);
+    frame_rows_finish(a, NH + NB, e_out, e_key, red);
 }
-void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, hipStream_t s) {
+void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key, hipStream_t s) {
     if (a.F <= 0) return;
     dim3 g(1), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_solve_light<0>), g, bl, 0, s, a, frames, led_light, e_out);
-    else if (a.model == 1) hipLaunchKernelGGL((k_solve_light<1>), g, bl, 0, s, a, frames, led_light, e_out);
-    else hipLaunchKernelGGL((k_solve_light<2>), g, bl, 0, s, a, frames, led_light, e_out);
+    if (a.model == 0) hipLaunchKernelGGL((k_solve_light<0>), g, bl, 0, s, a, frames, led_light, e_out, e_key);
+    else if (a.model == 1) hipLaunchKernelGGL((k_solve_light<1>), g, bl, 0, s, a, frames, led_light, e_out, e_key);
+    else hipLaunchKernelGGL((k_solve_light<2>), g, bl, 0, s, a, frames, led_light, e_out, e_key);
 }
 
 // Sophus SO3::exp(w).matrix() (quaternion exponential + Eigen toRotationMatrix)
@@ -520,7 +520,7 @@ __device__ void so3_exp(const float* w, float* R) {
     R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
 }
 // optimizePosesAll PsOptimizer.cpp:207-234 + updatePose OptimizerAux.cpp:190-205
-__global__ void __launch_bounds__(kBlock) k_solve_pose(SweepArgs a, FrameP* frames, double* e_out) {
+__global__ void __launch_bounds__(kBlock) k_solve_pose(SweepArgs a, FrameP* frames, double* e_out, unsigned long long e_key) {
     __shared__ double red[2 * kBlock / 64];
     for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
         const double* acc = a.acc.frame + (size_t)f * kFrameRow;
@@ -545,10 +545,10 @@ __global__ void __launch_bounds__(kBlock) k_solve_pose(SweepArgs a, FrameP* fram
             for (int k = 0; k < 3; ++k) frames[f].R[i * 3 + k] = (R[i * 3 + 0] * E3[0 * 3 + k] + R[i * 3 + 1] * E3[1 * 3 + k]) + R[i * 3 + 2] * E3[2 * 3 + k];
         }
     }
-    frame_rows_finish(a, 27, e_out, red);
+    frame_rows_finish(a, 27, e_out, e_key, red);
 }
-void launch_solve_pose(const SweepArgs& a, FrameP* frames, double* e_out, hipStream_t s) {
-    if (a.F > 0) hipLaunchKernelGGL(k_solve_pose, dim3(1), dim3(kBlock), 0, s, a, frames, e_out);
+void launch_solve_pose(const SweepArgs& a, FrameP* frames, double* e_out, unsigned long long e_key, hipStream_t s) {
+    if (a.F > 0) hipLaunchKernelGGL(k_solve_pose, dim3(1), dim3(kBlock), 0, s, a, frames, e_out, e_key);
 }
 
 }  // namespace psg
