@@ -110,12 +110,13 @@ int flush(psgsdf_ctx* c) {
 // sum of per-workgroup partials of `slots`, delivered to `consume(sums)` at the next flush (no host sync here).
 // The fold itself is left pending: the next kernel that can take it (take_fold) does it in its first workgroup;
 // anything else that needs the value first (flush, a kernel that writes those slots) launches k_sum_parts.
-void materialize_fold(psgsdf_ctx* c) {
-    if (!c->pending_fold.n) return;
-    SlotList sl; sl.n = c->pending_fold.n; for (int i = 0; i < sl.n; ++i) sl.id[i] = c->pending_fold.id[i];
-    launch_sum_parts(c->part, c->PB, c->pending_fold.nblk, sl, c->pending_fold.out, c->pending_fold.key, c->stream);
-    c->pending_fold.n = 0;
+void fold_by_kernel(psgsdf_ctx* c, FoldReq& f) {
+    if (!f.n) return;
+    SlotList sl; sl.n = f.n; for (int i = 0; i < sl.n; ++i) sl.id[i] = f.id[i];
+    launch_sum_parts(c->part, c->PB, f.nblk, sl, f.out, f.key, c->stream);
+    f.n = 0;
 }
+void materialize_fold(psgsdf_ctx* c) { fold_by_kernel(c, c->pending_fold); }
 // Multi-rank: the scalar read-backs staged in the mailbox shadow since the last commit are summed over the ranks in ONE all-reduce (the
 // contiguous range that spans them; slots in between belong to values that are global already -- frame-row sums, PCG status -- and are
 // not copied) and land in their mailbox slots.  Every rank runs the same control flow on the same global values, so the collectives
@@ -150,6 +151,7 @@ int set_local_grid(psgsdf_ctx* c, int z0, int z1) {
 void take_fold(psgsdf_ctx* c, SweepArgs& a, unsigned writes) {
     a.fold.n = 0;
     if (!c->pending_fold.n) return;
+    if (c->row1 <= c->row0) { materialize_fold(c); return; }      // empty band: the sweeps are not launched at all, the read-back is still owed
     for (int i = 0; i < c->pending_fold.n; ++i) if (writes & (1u << c->pending_fold.id[i])) { materialize_fold(c); return; }
     a.fold = c->pending_fold; c->pending_fold.n = 0;
 }

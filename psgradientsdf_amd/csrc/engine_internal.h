@@ -193,6 +193,7 @@ int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<vo
 int read_frame_energy_deferred(psgsdf_ctx* c, int col_e, std::function<void(double, double)> consume);
 int reserve_frame_energy_deferred(psgsdf_ctx* c, std::function<void(double, double)> consume, double** dev_slot, unsigned long long* key);
 void materialize_fold(psgsdf_ctx* c);
+void fold_by_kernel(psgsdf_ctx* c, FoldReq& f);   // the fold as a kernel of its own, now (a launch that was to take it did not happen / something consumes it first)
 void take_fold(psgsdf_ctx* c, SweepArgs& a, unsigned writes);
 int ensure_host_buf(psgsdf_ctx* c, size_t n);
 void free_dense(psgsdf_ctx* c);

@@ -61,12 +61,7 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         // the fold of the distance sweep's sums that this kernel would do in its prologue has to be on the stream BEFORE anything that consumes
         // its result: a flush (mailbox full) validates and delivers it, mg_commit (a communicator, also a one-rank one) all-reduces and copies it
         SweepArgs as = a;
-        auto fold_now = [&] {
-            if (!as.fold.n) return;
-            SlotList sl; sl.n = as.fold.n; for (int i = 0; i < sl.n; ++i) sl.id[i] = as.fold.id[i];
-            launch_sum_parts(c->part, c->PB, as.fold.nblk, sl, as.fold.out, as.fold.key, c->stream);
-            as.fold.n = 0;
-        };
+        auto fold_now = [&] { fold_by_kernel(c, as.fold); };
         if (slab_mode(c)) fold_now();
         if (c->mbox_used + (size_t)kSolveMbSlots > c->mbox_n) { fold_now(); int rc = flush(c); if (rc) return rc; }
         { int rc = mg_commit(c); if (rc) return rc; }      // (a one-rank communicator: the read-backs staged so far are delivered below)
@@ -263,7 +258,10 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
                 const int n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4), nh = led ? 3 : n * (n + 1) / 2;
                 col = nh + n;
             } else { take_fold(c, a, 0u); timed(c, "sweep_pose", [&] { launched = launch_sweep_pose(a, c->stream); }); col = 27; }
-            if (!launched) HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));   // no observations at all: empty rows, not the previous sweep's
+            if (!launched) {      // no observations at all: empty rows, not the previous sweep's -- and the fold the sweep was to take is still owed
+                HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
+                fold_by_kernel(c, a.fold);
+            }
             // multi-rank: every slab has summed its own observations into the per-frame rows; after the all-reduce every rank holds the
             // global normal equations and solves all F (tiny) systems itself
             if ((rc = comm_allreduce(c, c->acc_frame, c->F * kFrameRow))) return rc;
