@@ -267,7 +267,7 @@ class Api:
     # -- multi-GPU: attach the context to a rank (before load_scene / init); afterwards every call is collective
     def comm_init(self, rank, n_ranks, unique_id=None):
         """unique_id: the 128 bytes rank 0 got from comm_unique_id() (RCCL).  The oracle's mirror (prefix orc_) takes no id: its exchanges
-        are done by the host program psgradientsdf_amd/distributed.py over its phase API below."""
+        are done by the host program tests/_slab_runner.py over its phase API below."""
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id)) if unique_id is not None else None
         self._check(self._fn("comm_init")(self.ctx, buf, C.c_int(rank), C.c_int(n_ranks)), "comm_init")
 
@@ -281,7 +281,7 @@ class Api:
         self._check(self._fn("comm_stats")(self.ctx, C.byref(n)), "comm_stats")
         return n.value
 
-    # -- phase API of the ORACLE's multi-rank mirror (orc_mg_*), driven by psgradientsdf_amd/distributed.py in the CPU tests
+    # -- phase API of the ORACLE's multi-rank mirror (orc_mg_*), driven by tests/_slab_runner.py in the CPU tests
     def set_stream(self, stream_ptr):
         self._check(self._fn("set_stream")(self.ctx, C.c_void_p(stream_ptr)), "set_stream")
 

@@ -21,6 +21,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     c->device = device;
     if (const char* e = getenv("PSGSDF_PCG_POLL")) c->pcg_poll = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_MBOX_CHECK")) c->mbox_check = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_FAULT_SOLVE")) c->fault_solve = atoi(e);
     if (const char* e = getenv("PSGSDF_FOLD_IN_NEXT")) c->fold_in_next = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FUSE_ALBEDO")) c->fuse_albedo = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FUSE_PCG_INIT")) c->fuse_pcg_init = atoi(e) != 0;

@@ -88,6 +88,7 @@ struct psgsdf_ctx {
     std::vector<psge::Deferred> deferred;
     unsigned long long mbox_serial = 0;  // key generator of the read-back slots
     bool mbox_check = true;              // PSGSDF_MBOX_CHECK=0: take read-backs on the marker's / status word's say-so (round-2 behaviour; reproduces its flake)
+    int fault_solve = 0, solves_seen = 0;   // PSGSDF_FAULT_SOLVE=n: fault injection into the n-th persistent solve of this context
     long long persist_fallbacks = 0;     // distance steps re-run on the per-pass kernels after the persistent solve gave up (loop.hip)
     long long mbox_checked = 0, mbox_late = 0;   // read-backs validated / of those: not complete yet when the host was told everything had landed
     // cached energies
@@ -206,7 +207,7 @@ int ps_energy(psgsdf_ctx* c, double* E, int64_t* nobs);
 struct LoopState { float E, E_n, E_l, E_prev; int laplacian_reg; float E_r; };
 void cgf_shape(int nblk, int* G, int* rows);
 bool cgf_solve_shape(psgsdf_ctx* c, int* G, int* rows);      // can the whole solve run as ONE persistent kernel on this context?
-int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_out, double* err_out,
+int pcg_solve(psgsdf_ctx* c, SweepArgs& a, int* iters_out, int* success_out, double* err_out,
               const std::function<void(const double*)>& tail = nullptr, bool gate_on_converged = true, bool* tail_ran = nullptr);
 int albedo_reg_energy(psgsdf_ctx* c, double* Er);
 int albedo_reg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* ok_out, double* err_out);

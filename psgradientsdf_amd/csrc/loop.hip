@@ -47,7 +47,7 @@ bool cgf_solve_shape(psgsdf_ctx* c, int* G, int* rows_per_wg) {
 // gated on the device-side 'solve finished' flag: when the chunk converges -- the normal case -- the GPU runs it without
 // waiting for the host to notice; when it does not, the gated kernels do nothing and the tail is enqueued again behind the
 // next chunk.  *tail_ran tells the caller whether the enqueued tail is the one that took effect.
-int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_out, double* err_out,
+int pcg_solve(psgsdf_ctx* c, SweepArgs& a, int* iters_out, int* success_out, double* err_out,
               const std::function<void(const double*)>& tail, bool gate_on_converged, bool* tail_ran) {
     const int S = c->band.S;
     if (tail_ran) *tail_ran = false;
@@ -69,7 +69,8 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         volatile double* st = c->mbox + off;
         const unsigned long long key = (++c->mbox_serial << 8) | 0x80u;
         st[3] = NAN; st[4] = 0.0;
-        timed(c, "pcg_solve", [&] { launch_cgf_solve(as, c->pcg_sc, c->pcg_gran, G, rows, cap, c->mbox_dev + off, key, 0, c->stream); });
+        const int inject = (c->fault_solve > 0 && ++c->solves_seen == c->fault_solve) ? -7 : 0;      // PSGSDF_FAULT_SOLVE=n: one workgroup of the n-th solve stops publishing (tests the fallback below)
+        timed(c, "pcg_solve", [&] { launch_cgf_solve(as, c->pcg_sc, c->pcg_gran, G, rows, cap, c->mbox_dev + off, key, inject, c->stream); });
         if (tail && !c->profiling) { tail(c->pcg_sc + (gate_on_converged ? 2 : 1)); if (tail_ran) *tail_ran = true; }
         // the four status words are taken only together with their check word (engine.h FoldReq)
         const bool chk = c->mbox_check;
@@ -82,8 +83,20 @@ int pcg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* success_ou
         if (w < 0) return w;
         if (!landed()) HIPCHK(c, hipStreamSynchronize(c->stream));      // ("drained" came from a stream query: drain for certain before calling it a failure)
         if (!landed()) return fail(c, PSGSDF_ERR_DEVICE, "the PCG kernel published nothing");
-        if (st[3] != 1.0) return fail(c, PSGSDF_ERR_DEVICE, "the PCG kernel gave up waiting for its other workgroups (status %g): is another process holding CUs of this device?", (double)st[3]);
         if (w == 0 && !c->pending_fold.n) { int rc = deliver(c); if (rc) return rc; }   // everything enqueued before the solve has run: its read-backs are validated and taken
+        if (st[3] != 1.0) {
+            // The persistent kernel needs all its workgroups co-resident (no cooperative launch) and gave up waiting for some of them: something
+            // else holds CUs of this device (another process, a CU mask).  Nothing has been applied (its epilogue only acts on status 1 and it
+            // leaves both gates closed, so the tail enqueued behind it did nothing): redo this solve with the per-pass kernels, which make
+            // no residency assumption and give the same bits, and keep this context on them.
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (!c->persist_fallbacks++) fprintf(stderr, "psgsdf: the persistent distance solve could not get its %d workgroups co-resident (status %g): is another process holding CUs of this device?  Continuing with the per-pass kernels.\n", G, (double)st[3]);
+            c->pcg_persist = false;
+            a.pcg_asm = 0; a.pcg_apply = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.fold.n = 0;      // (the sweep's sums were folded by the kernel's prologue / by k_assemble)
+            timed(c, "assemble", [&] { launch_assemble(a, c->stream); });      // H, rhs, x = 0, the initial records (the attempt overwrote them) and |b|^2 in memory, status words reset
+            if (tail_ran) *tail_ran = false;
+            return pcg_solve(c, a, iters_out, success_out, err_out, tail, gate_on_converged, tail_ran);
+        }
         const float rhsN = (float)st[2];
         if (rhsN == 0.f) { *iters_out = 0; *success_out = 1; *err_out = 0; c->last_cg_iters = 0; return 0; }
         const double err = sqrt((double)(float)st[1] / (double)rhsN);

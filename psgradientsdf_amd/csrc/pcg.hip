@@ -680,7 +680,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         const bool ok = status == 1 && (rhs_zero || sqrt((double)rr_cur / (double)rhsNorm2) <= (double)FLT_EPSILON);
         int iters = 0;
         if (!rhs_zero && k > 0) iters = (rr_cur < thr) ? k - 1 : k;      // Eigen leaves the loop before ++i when it detects convergence; k == kmax otherwise
-        fs[1] = (double)(k + 1); fs[2] = ok ? 1.0 : 0.0;
+        fs[1] = status == 1 ? (double)(k + 1) : 0.0; fs[2] = ok ? 1.0 : 0.0;      // a solve that gave up leaves BOTH gates closed: nothing behind it may act on it (the host re-runs the solve, loop.hip)
         const double m0 = (double)iters, m1 = (double)rr_cur, m2 = (double)rhsNorm2, m3 = (double)status;
         mb[0] = m0; mb[1] = m1; mb[2] = m2;
         __threadfence_system();

@@ -23,7 +23,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import capi
+from psgradientsdf_amd import capi
 
 BUF_FRAME_ACC, BUF_SCAL, BUF_PCG, BUF_DIST, BUF_BLK, BUF_REC0, BUF_RHO, BUF_GRAD, BUF_REC1 = range(9)
 (PH_ENERGY, PH_INIT_ALBEDO, PH_LED_SUMS, PH_LED_SET, PH_SWEEP_ALBEDO, PH_APPLY_ALBEDO, PH_SWEEP_LIGHT, PH_SOLVE_LIGHT,

@@ -6,12 +6,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main(rank, world, port, model, out, n_iters, N, tile=False):
     import torch.distributed as dist
     from psgradientsdf_amd import capi, synth
-    from psgradientsdf_amd.distributed import SlabRunner
+    from _slab_runner import SlabRunner
     from oracle import oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

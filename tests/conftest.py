@@ -11,11 +11,13 @@ if ROOT not in sys.path:
 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
-# Collection order of the GPU suite: oracle-parity tests first, tests that launch other processes (the voxelPS binaries, bench.py,
-# torch.distributed workers) last, so that a problem in a launcher can never keep `pytest -x` from reaching the parity tests
-# (VERDICT r01, item 1).  Files not listed keep pytest's alphabetical order in between.
-_FIRST = ["test_parity_gpu.py", "test_golden.py", "test_edge_gpu.py", "test_configs_gpu.py", "test_fullsize_gpu.py", "test_integrate.py", "test_frontend.py"]
-_LAST = ["test_knobs_gpu.py", "test_host_mirror_gpu.py", "test_voxelps_gpu.py", "test_comm_gpu.py", "test_slab_gpu.py", "test_bench_gpu.py"]
+# Collection order of the GPU suite: oracle-parity tests first, then the product rows in SURVEY 8's order (configs,
+# full size, front end, the C++ host mirror, the voxelPS driver, the z-slab engine, the bench line); tests that compare the engine with
+# ITSELF (knobs, run-to-run reproducibility) come last, so that `pytest -x` can never hide a product row behind a self-comparison.
+# Files not listed keep pytest's alphabetical order in between.
+_FIRST = ["test_parity_gpu.py", "test_golden.py", "test_edge_gpu.py", "test_configs_gpu.py", "test_fullsize_gpu.py", "test_integrate.py", "test_frontend.py",
+          "test_host_mirror_gpu.py", "test_voxelps_gpu.py", "test_comm_gpu.py", "test_slab_gpu.py", "test_bench_gpu.py"]
+_LAST = ["test_repro_gpu.py", "test_knobs_gpu.py"]
 
 
 def pytest_configure(config):

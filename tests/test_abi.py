@@ -22,7 +22,7 @@ def test_oracle_mirrors_the_abi(built):
     import __graft_entry__ as g
     from oracle import oracle
     lib = oracle.lib()
-    # (the oracle's multi-rank mirror is driven through its own phase API by psgradientsdf_amd/distributed.py: no communicator entry points)
+    # (the oracle's multi-rank mirror is driven through its own phase API by tests/_slab_runner.py: no communicator entry points)
     skip = {"psgsdf_comm_unique_id", "psgsdf_comm_init_ext", "psgsdf_comm_stats", "psgsdf_kernel_times", "psgsdf_reset_kernel_times",
             "psgsdf_set_profiling", "psgsdf_watch_kernel", "psgsdf_debug_time_pcg_pass", "psgsdf_debug_time_pcg_solve", "psgsdf_debug_rare_rows", "psgsdf_debug_sync_stats"}
     for n in g._declared_symbols():

@@ -175,3 +175,32 @@ def test_persistent_solve_gives_up_instead_of_hanging(built):
     recs = eng.iterate(capi.ALL, 2)                                # the next distance step resets the abort flag
     assert all(np.isfinite(r["e_total"]) for r in recs) and recs[1]["e_total"] < recs[0]["e_total"] * 1.01
     assert recs[0]["cg_iters"] > 3
+
+
+@pytest.mark.parametrize("name,mid", [("SH1", capi.SH1), ("LED", capi.LED)])
+def test_persistent_solve_falls_back_to_the_per_pass_kernels(built, name, mid, monkeypatch, capfd):
+    """A persistent distance solve that cannot get all its workgroups co-resident (another process holding CUs; here: fault injection into the
+    2nd solve of the context, PSGSDF_FAULT_SOLVE) must not fail the optimisation: the step is re-run on the per-pass kernels, once logged, and
+    the results are those of a context that ran the per-pass kernels all along (bit for bit) -- and the oracle's, to the usual tolerance."""
+    sc = synth.make_scene(N=40, F=6, W=160, H=120, model=name)
+    st = capi.default_settings(mid)
+    monkeypatch.setenv("PSGSDF_FAULT_SOLVE", "2")
+    eng = capi.load_engine(sc, sc.K, st, 0)
+    monkeypatch.delenv("PSGSDF_FAULT_SOLVE"); monkeypatch.setenv("PSGSDF_PCG_PERSIST", "0")
+    ref = capi.load_engine(sc, sc.K, st, 0)
+    monkeypatch.delenv("PSGSDF_PCG_PERSIST")
+    from oracle import oracle
+    orc = oracle.Oracle(sc, sc.K, st)
+    for api in (eng, ref, orc):
+        api.load_scene(sc); api.init_albedo(); api.normalize_weights()
+    r_e, r_r, r_o = eng.iterate(capi.ALL, 3), ref.iterate(capi.ALL, 3), orc.iterate(capi.ALL, 3)
+    assert eng.debug_sync_stats()["persist_fallbacks"] == 1 and ref.debug_sync_stats()["persist_fallbacks"] == 0
+    assert "per-pass kernels" in capfd.readouterr().err
+    assert [r["e_total"] for r in r_e] == [r["e_total"] for r in r_r] and [r["cg_iters"] for r in r_e] == [r["cg_iters"] for r in r_r]
+    band = eng.download_band(); vs = float(sc.voxel_size)
+    ve, vr, vo = eng.download_volume(), ref.download_volume(), orc.download_volume()
+    assert np.array_equal(ve["dist"], vr["dist"]) and np.array_equal(ve["rgb"][:, band], vr["rgb"][:, band]) and np.array_equal(eng.download_poses(), ref.download_poses())
+    d = np.abs(ve["dist"][band] - vo["dist"][band]) / vs
+    assert np.quantile(d, 0.999) <= 1e-4 and d.max() <= 5e-3
+    for a, b in zip(r_e, r_o):
+        assert abs(a["e_total"] - b["e_total"]) <= 2e-4 * abs(b["e_total"])

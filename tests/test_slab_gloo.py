@@ -1,4 +1,4 @@
-"""The N>1 (z-slab) path on CPU: world_size-2/3 gloo runs of psgradientsdf_amd/distributed.py driving the oracle's
+"""The N>1 (z-slab) path on CPU: world_size-2/3 gloo runs of tests/_slab_runner.py driving the oracle's
 phase API must reproduce the single-rank oracle (same band, energies, PCG iteration counts, refined state)."""
 import os
 import socket
