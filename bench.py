@@ -2,8 +2,13 @@
 """bench.py — Gauss-Newton iterations/sec of the full photometric-stereo sweep (BASELINE.json metric).
 
 One "step" = one body of the alternation loop (albedo, light, distance, pose blocks, the four PS-energy
-evaluations and the convergence test; PsOptimizer.cpp:303-366) on the synthetic 256^3 x 50-keyframe
+evaluations and the convergence / divergence test; PsOptimizer.cpp:303-384) on the synthetic 256^3 x 50-keyframe
 scene, inputs resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+`value` is the PRODUCT loop, psgsdf_optimize -- what voxelPS calls: the host takes the stop decision after every iteration
+(VERDICT r02 item 5).  The K timed steps are iterations W+1 .. W+K of one psgsdf_optimize call, bracketed through its per-iteration
+callback (device drained + barrier on both sides).  The same scene through psgsdf_iterate (no stop decision, nothing to wait for)
+is reported next to it (`iterate_ms_per_step`).  The LED (configs[3]) and SH2 workloads ride along as `extra`.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 256] [--frames 50] [--model SH1]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -51,6 +56,149 @@ def algorithmic_bytes(kernel, S, n_obs, W, H, F, laplacian=False, pcg_passes=1.0
     return table.get(kernel)
 
 
+def timed_optimize(eng, torch, dist, steps, warmup, before_timed=None):
+    """K = `steps` iterations of ONE psgsdf_optimize call, after `warmup` untimed ones, bracketed through its per-iteration callback:
+    device drained (+ barrier over the ranks) on both sides.  Returns (elapsed seconds or None if the loop ended early, records)."""
+    import time as _t
+    mark = {}
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def on_iter(done, rec):
+        if done == warmup:
+            if before_timed:
+                before_timed()
+            sync(); mark["t0"] = _t.perf_counter()
+        elif done == warmup + steps:
+            torch.cuda.synchronize(); mark["t1"] = _t.perf_counter(); sync()
+            return True                       # abort the loop: the K timed steps are done
+        return False
+
+    recs, _ = eng.optimize(capi.ALL, cap=warmup + steps + 8, on_iter=on_iter)
+    if "t1" not in mark:
+        return None, recs
+    return mark["t1"] - mark["t0"], recs[warmup:warmup + steps]
+
+
+def measure(args, model, torch, dist, rank, world, device, slab, share, headline):
+    """one workload: scene, contexts, the timed loop; returns the fields of the JSON line for it"""
+    t_gen = time.time()
+    use_u8 = args.u8_images
+    sc = synth.make_scene(N=args.grid, F=args.frames, W=args.width, H=args.height, model=model, u8=use_u8)
+    t_gen = time.time() - t_gen
+    model_id = synth.MODELS[model]
+    st = capi.default_settings(model_id)
+    if model == "LED":   # config_basket_LED.json
+        st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0
+    if world > 1:
+        sc = synth.tile_scene(sc, world)
+
+    def context(settings):
+        eng = capi.load_engine(sc, sc.K, settings, device)
+        if slab:
+            if share:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from _gloo_transport import GlooTransport
+                eng._transport = GlooTransport(dist)
+                eng.comm_init_ext(eng._transport.ops, rank, world)
+            else:
+                ident = [capi.comm_unique_id() if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(ident, src=0)
+                eng.comm_init(rank, world, ident[0])
+        eng.load_scene(sc, u8=use_u8)
+        return eng
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- context 1: psgsdf_iterate (no stop decision): kernel breakdown, the dominant kernel, the round-2 figure
+    eng = context(st)
+    eng.init_albedo()
+    eng.normalize_weights()
+    S = eng.info().n_band // world              # per-slab band size
+    n_obs = eng.step(capi.ALBEDO)["n_obs"] // world
+    eng.iterate(capi.ALL, args.warmup)
+    kernels, dom = {}, "sweep_dist"
+    if headline and not args.no_breakdown:
+        # the dominant kernel (largest total time per iteration) from a short synchronous-event pass; THAT kernel is then timed inside the
+        # timed region with HIP events recorded on the launch stream (no host sync)
+        eng.set_profiling(True)
+        eng.reset_kernel_times()
+        nprof = 3
+        eng.iterate(capi.ALL, nprof)
+        kt = eng.kernel_times()
+        eng.set_profiling(False)
+        kernels = {k: {"ms_per_iter": v[0] / nprof, "launches_per_iter": v[1] / nprof} for k, v in kt.items()}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_iter"] if algorithmic_bytes(k, 1, 1, 1, 1, 1) else -1)
+    watch = dom + ("/16" if dom == "pcg_pass" else "/4")   # HIP events around every 16th (4th) launch (each pair breaks the back-to-back dispatch: ~6 us of stream time)
+    use_watch = headline and os.environ.get("PSGSDF_NO_WATCH") != "1"
+    timing_iterate = args.loop == "iterate"
+    eng.reset_kernel_times()
+    if use_watch and timing_iterate:
+        eng.watch_kernel(watch)
+    barrier()
+    coll0 = eng.comm_stats()
+    t0 = time.perf_counter()
+    recs_it = eng.iterate(capi.ALL, args.steps)
+    torch.cuda.synchronize()
+    t_iter = time.perf_counter() - t0
+    coll1 = eng.comm_stats()
+    barrier()
+    watched = eng.kernel_times().get(dom, (0.0, 0)) if (use_watch and timing_iterate) else (0.0, 0)
+    eng.watch_kernel("")
+    sync_stats = eng.debug_sync_stats()
+    eng.close()
+
+    # ---- context 2: psgsdf_optimize, the loop voxelPS runs (initAlbedo + weight normalisation + iterations with the stop decision)
+    st2 = capi.default_settings(model_id)
+    st2.reg_weight_n, st2.reg_weight_l, st2.damping = st.reg_weight_n, st.reg_weight_l, st.damping
+    st2.max_it, st2.conv_threshold, st2.upsample = args.warmup + args.steps + 4, 0.0, 0
+    eng2 = context(st2)
+    eng2.reset_kernel_times()
+
+    def before_timed():
+        if use_watch and not timing_iterate:
+            eng2.reset_kernel_times()
+            eng2.watch_kernel(watch)
+    t_opt, recs_opt = timed_optimize(eng2, torch, dist, args.steps, args.warmup, before_timed)
+    if use_watch and not timing_iterate:
+        watched = eng2.kernel_times().get(dom, (0.0, 0))
+        eng2.watch_kernel("")
+    s2 = eng2.debug_sync_stats()
+    for k in sync_stats:
+        sync_stats[k] += s2[k]
+    eng2.close()
+
+    def over_ranks(x):
+        if dist is None or x is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=f"cuda:{device}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+    t_iter, t_opt = over_ranks(t_iter), over_ranks(t_opt)
+
+    loop = "psgsdf_optimize"
+    if timing_iterate or t_opt is None:
+        elapsed, recs = t_iter, recs_it
+        loop = "psgsdf_iterate" + ("" if timing_iterate else f" (psgsdf_optimize left its loop after {len(recs_opt)} iterations: diverged)")
+    else:
+        elapsed, recs = t_opt, recs_opt
+    cg_iters = float(np.mean([r["cg_iters"] for r in recs]))
+    res = dict(model=model, value=world * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, loop=loop, S=int(S), n_obs=int(n_obs), cg_iters=cg_iters,
+               iterate_ms_per_step=1e3 * t_iter / args.steps, optimize_ms_per_step=(1e3 * t_opt / args.steps) if t_opt else None,
+               kernels=kernels, dom=dom, watched=watched, t_gen=t_gen, st=st, sc=sc, sync_stats=sync_stats,
+               collectives_per_step=(coll1 - coll0) / max(args.steps, 1), use_u8=use_u8)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +213,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--force-slab", action="store_true", help="attach the single rank to a one-rank RCCL communicator (overhead of the multi-rank code path)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the LED / SH2 lines")
+    ap.add_argument("--loop", default="optimize", choices=["optimize", "iterate"], help="which loop `value` times (iterate: the round-2 figure, no stop decision)")
     args = ap.parse_args()
 
     if os.environ.get("PSGSDF_FAULT_DUMP"):   # diagnostics: dump every thread's Python stack after N seconds and exit
@@ -97,103 +247,23 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     device = local_rank if world > 1 else 0
 
-    t_gen = time.time()
-    # --u8-images: keyframes quantised to 8 bits and handed over the way the reference's loader receives them (8-bit RGB + 1/255,
-    # ImageLoader.h:167-181); the oracle always gets the converted floats.  ~3 % faster than the float path (profiles/r01_notes.md, step p).
-    use_u8 = args.u8_images
-    sc = synth.make_scene(N=args.grid, F=args.frames, W=args.width, H=args.height, model=args.model, u8=use_u8)
-    t_gen = time.time() - t_gen
-    model_id = synth.MODELS[args.model]
-    st = capi.default_settings(model_id)
-    if args.model == "LED":   # config_basket_LED.json
-        st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0
-    if world > 1:
-        sc = synth.tile_scene(sc, world)
-    eng = capi.load_engine(sc, sc.K, st, device)
-    transport = None
-    if slab:
-        if share:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from _gloo_transport import GlooTransport
-            transport = GlooTransport(dist)
-            eng.comm_init_ext(transport.ops, rank, world)
-        else:
-            ident = [capi.comm_unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(ident, src=0)
-            eng.comm_init(rank, world, ident[0])
-    eng.load_scene(sc, u8=use_u8)
-    eng.init_albedo()
-    eng.normalize_weights()
-    S = eng.info().n_band // world              # per-slab band size
-    n_obs = eng.step(capi.ALBEDO)["n_obs"] // world
-    iterate = lambda k: eng.iterate(capi.ALL, k)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    iterate(args.warmup)
-    # pick the dominant kernel (largest total time per iteration) from a short synchronous-event pass, then time THAT
-    # kernel inside the timed region with HIP events recorded on the launch stream (no host sync)
-    kernels, dom = {}, "sweep_dist"
-    if not args.no_breakdown:
-        eng.set_profiling(True)
-        eng.reset_kernel_times()
-        nprof = 3
-        iterate(nprof)
-        kt = eng.kernel_times()
-        eng.set_profiling(False)
-        kernels = {k: {"ms_per_iter": v[0] / nprof, "launches_per_iter": v[1] / nprof} for k, v in kt.items()}
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_iter"] if algorithmic_bytes(k, 1, 1, 1, 1, 1) else -1)
-    eng.reset_kernel_times()
-    if os.environ.get("PSGSDF_NO_WATCH") != "1":   # (tools/gap_run.sh: trace without the event pairs)
-        eng.watch_kernel(dom + ("/16" if dom == "pcg_pass" else "/4"))  # HIP events around every 16th (4th) launch of the dominant kernel (each pair breaks the back-to-back dispatch: ~6 us of stream time)
-    barrier()
-    coll0 = eng.comm_stats()
-    t0 = time.perf_counter()
-    recs = iterate(args.steps)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    coll1 = eng.comm_stats()
-    barrier()
-    elapsed = t1 - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    watched = eng.kernel_times().get(dom, (0.0, 0))
-    eng.watch_kernel("")
-    # the loop voxelPS runs (psgsdf_optimize: stop decision after every iteration) on the same state, next to psgsdf_iterate's figure
-    opt_ms = None
-    if world == 1 and not slab:
-        st2 = capi.default_settings(model_id)
-        st2.reg_weight_n, st2.reg_weight_l, st2.damping = st.reg_weight_n, st.reg_weight_l, st.damping
-        st2.max_it, st2.conv_threshold, st2.upsample = args.steps, 0.0, 0
-        eng2 = capi.load_engine(sc, sc.K, st2, device)
-        eng2.load_scene(sc, u8=use_u8)
-        torch.cuda.synchronize(); to = time.perf_counter()      # (kernels are loaded: the first context ran them all)
-        recs2, _ = eng2.optimize(capi.ALL)              # initAlbedo + weight normalisation + up to `steps` iterations, as PsOptimizer::alternatingOptimize
-        torch.cuda.synchronize(); to = time.perf_counter() - to
-        opt_ms = 1e3 * to / max(len(recs2), 1)
-        eng2.close()
-
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = world * args.steps / elapsed
-    cg_iters = float(np.mean([r["cg_iters"] for r in recs]))
-
+    m = measure(args, args.model, torch, dist, rank, world, device, slab, share, headline=True)
+    S, n_obs, cg_iters, kernels, dom, watched, st, sc = m["S"], m["n_obs"], m["cg_iters"], m["kernels"], m["dom"], m["watched"], m["st"], m["sc"]
+    use_u8 = m["use_u8"]
     out = {
         "metric": "Gauss-Newton iterations/sec (full PS sweep), 256^3 grid x 50 frames" if (args.grid, args.frames) == (256, 50)
         else f"Gauss-Newton iterations/sec (full PS sweep), {args.grid}^3 grid x {args.frames} frames",
-        "value": value, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": m["value"], "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (8-bit RGB keyframes)" if use_u8 else "synthetic",
         "config": {"workload": f"synthetic {args.width}x{args.height} RGB-D bumpy sphere, {args.grid}^3 grid, {args.model}, {args.frames} keyframes, "
                                "albedo+light+distance+pose blocks, Cauchy IRLS, Eikonal reg (config_skorates.json settings)",
+                   "loop": m["loop"] + ": K iterations of one call, stop decision (convergence / divergence test on the host) after every iteration",
                    "band_voxels": int(S), "observations": int(n_obs), "pcg_iters_per_step": cg_iters,
                    "parallelism": "single GPU" if world == 1 else f"{world} z-slabs (one per GPU), grid {args.grid}x{args.grid}x{args.grid * world}, {args.frames * world} keyframes, native slab loop: RCCL halo exchange + all-reduce issued by the C++ host"},
+        "iterate_ms_per_step": m["iterate_ms_per_step"],      # psgsdf_iterate: the same iterations without a stop decision (round-2 `value`)
+        "iterate_value": world * 1e3 / m["iterate_ms_per_step"],
+        "optimize_ms_per_step": m["optimize_ms_per_step"],
     }
 
     if rank == 0:
@@ -221,6 +291,7 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "bytes_per_launch": nbytes, "avg_launch_ms": avg_ms,
+                           "traffic_over_algorithmic": (traffic / nbytes) if (traffic and nbytes) else None,      # < 1: the kernel keeps data on chip (pcg_solve: the matrix lives in LDS); it is then NOT bandwidth-bound and `frac` overstates how close to a limit it runs
                            "launches_timed": int(watched[1]), "avg_working_launch_ms": avg_work_ms, "working_launch_fraction": working_frac,
                            "bytes_per_unit": "SURVEY 8d algorithmic figure (PCG: 124 B per band voxel per pass; pcg_solve runs cg_iters + 1 passes per launch and keeps the matrix on chip: its HBM-side traffic is far below the algorithmic bytes; the launch also assembles the distance system from the sweep's voxel blocks, which is NOT counted here)",
                            "storage_bytes_per_launch": 152 * S if dom in ("pcg_pass", "pcg_solve") else None,
@@ -232,14 +303,16 @@ def main():
         U = min(48 * n_obs, 12 * args.width * args.height * args.frames)
         B_iter = 4 * (S * 60 + U) + 120 * S + 124 * cg_iters * S   # SURVEY §8d per-pass figure kept (the fused pass moves 144 B/row)
         if slab:
-            out["config"]["collectives_per_step"] = (coll1 - coll0) / max(args.steps, 1)
-        out["iteration"] = {"algorithmic_bytes": B_iter, "achieved_GBs": B_iter * (value / world) / 1e9,
-                            "frac_of_hbm_peak": B_iter * (value / world) / 1e9 / HBM_PEAK_GBS}
-        if opt_ms is not None:
-            out["optimize_ms_per_step"] = opt_ms      # psgsdf_optimize (host decides convergence / divergence after every iteration)
+            out["config"]["collectives_per_step"] = m["collectives_per_step"]
+        out["iteration"] = {"algorithmic_bytes": B_iter, "achieved_GBs": B_iter * (m["value"] / world) / 1e9,
+                            "frac_of_hbm_peak": B_iter * (m["value"] / world) / 1e9 / HBM_PEAK_GBS}
         if kernels:
             out["kernels"] = {k: round(v["ms_per_iter"], 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_iter"])}
-        out["setup_s"] = {"scene_generation": round(t_gen, 1)}
+            # per-kernel roofline fractions from the same synchronous-event pass (events add ~4 us per launch: fractions err low)
+            out["kernel_roofline_frac"] = {k: round(algorithmic_bytes(k, S, n_obs, args.width, args.height, args.frames, lap, pcg_passes=cg_iters + 1.0) / (v["ms_per_iter"] / max(v["launches_per_iter"], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
+                                           for k, v in kernels.items() if algorithmic_bytes(k, 1, 1, 1, 1, 1) and v["ms_per_iter"] > 0}
+        out["sync_stats"] = m["sync_stats"]      # scalar read-backs validated / found late / persistent-solve fallbacks in this run (include/psgsdf.h)
+        out["setup_s"] = {"scene_generation": round(m["t_gen"], 1)}
 
         # ---- CPU baseline: the oracle (a port of the reference's arithmetic) on the host cores, bounded sample
         if world == 1 and not slab and not args.no_cpu_baseline:
@@ -263,8 +336,20 @@ def main():
                 tc = time.perf_counter(); orc.iterate(capi.ALL, 1); tc = time.perf_counter() - tc
                 out["cpu_baseline"]["multithreaded"] = {"value": 1.0 / tc, "unit": "it/s", "cores": nthr}
                 orc.close()
+    del m, sc
+    # ---- the other shading models on the same grid / keyframe shape (BASELINE configs[3] = LED; SH2 = configs[4]'s model at the headline size)
+    if world == 1 and not slab and not args.no_extra and (args.grid, args.frames, args.model) == (256, 50, "SH1"):
+        extra = {}
+        for mod in ("LED", "SH2"):
+            e = measure(args, mod, torch, dist, rank, world, device, slab, share, headline=False)
+            extra[mod] = {"value": e["value"], "unit": "it/s", "ms_per_step": e["ms_per_step"], "loop": e["loop"], "iterate_ms_per_step": e["iterate_ms_per_step"],
+                          "band_voxels": e["S"], "observations": e["n_obs"], "pcg_iters_per_step": e["cg_iters"],
+                          "settings": "config_basket_LED.json (damping 3, reg 0.1 / 5)" if mod == "LED" else "config_skorates.json"}
+            del e
+        if rank == 0:
+            out["extra"] = extra
+    if rank == 0:
         print(json.dumps(out), file=real_stdout, flush=True)
-    eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

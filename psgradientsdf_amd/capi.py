@@ -213,10 +213,15 @@ class Api:
         self._check(self._fn("iterate")(self.ctx, C.c_int(flags), C.c_int(n), arr), "iterate")
         return [a.as_dict() for a in arr]
 
-    def optimize(self, flags, cap=256):
+    def optimize(self, flags, cap=256, on_iter=None):
+        """on_iter(iterations_done, record_dict) -> truthy aborts the loop (psgsdf_iter_cb: the host's hook for the reference's periodic dumps)"""
         arr = (IterStats * cap)()
         n, res = C.c_int(), C.c_int()
-        self._check(self._fn("optimize")(self.ctx, C.c_int(flags), arr, C.c_int(cap), C.byref(n), C.byref(res), None, None), "optimize")
+        cb = None
+        if on_iter is not None:
+            CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(IterStats))
+            cb = CB(lambda user, done, rec: 1 if on_iter(done, rec.contents.as_dict()) else 0)
+        self._check(self._fn("optimize")(self.ctx, C.c_int(flags), arr, C.c_int(cap), C.byref(n), C.byref(res), cb, None), "optimize")
         return [arr[i].as_dict() for i in range(min(n.value, cap))], bool(res.value)
 
     def upsample2x(self):
