@@ -2,9 +2,11 @@
 // computeIsoSurface :314-505, computeLutIndex :511-556, interpolate :559-579, getColor :592-608, computeTriangles :611-637,
 // savePly :659-699).  Corner / edge numbering, the inside test (tsdf > iso), the per-edge interpolation, the colour
 // look-up with its +1/+2 index offsets, the dim-2 loop bounds and the non-indexed vertices are the
-// reference's; the 256-case triangle table is NOT copied from it: it is generated here from first principles (face
-// contours -> closed loops -> fans, ambiguous faces resolved by separating the inside corners), which yields a
-// watertight triangulation of the same iso-surface (individual triangles may be fanned differently).
+// reference's, and so are the triangles: the 256 x 16 triangle table is the classic one (data: mc_tritable.inc, extracted by
+// tests/golden/make_mc_tritable.py and checked against tests/golden/mc_tritable.npy), walked in its order, so a mesh written
+// from the same volume has the reference's faces in the reference's order.  The first-principles
+// generator of round 1 (face contours -> closed loops -> fans) is kept as a cross-check of the table (generated_table():
+// same crossed edges, same orientation; tests/test_host_tools.py).
 #pragma once
 #include <array>
 #include <cmath>
@@ -19,7 +21,11 @@ class MarchingCubes {
     // corner c -> (dx,dy,dz) in the reference's numbering (computeLutIndex: bit0 = (i+1,j+1,k), bit1 = (i+1,j,k), ...)
     static constexpr int kCorner[8][3] = {{1, 1, 0}, {1, 0, 0}, {0, 0, 0}, {0, 1, 0}, {1, 1, 1}, {1, 0, 1}, {0, 0, 1}, {0, 1, 1}};
     static constexpr int kEdge[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
-    std::array<std::vector<int>, 256> tri_;   // edge triples per case
+    static constexpr signed char kTriTable[256][16] = {
+#include "mc_tritable.inc"
+    };
+    std::array<std::vector<int>, 256> tri_;   // edge triples per case (kTriTable without the -1 padding)
+    std::array<std::vector<int>, 256> gen_;   // the generated table (cross-check only)
 
     static int edge_between(int a, int b) { for (int e = 0; e < 12; ++e) if ((kEdge[e][0] == a && kEdge[e][1] == b) || (kEdge[e][0] == b && kEdge[e][1] == a)) return e; return -1; }
     void build_table() {
@@ -60,7 +66,7 @@ class MarchingCubes {
                 for (int e : loop) { int a = kEdge[e][0], b = kEdge[e][1]; if (!((cs >> a) & 1)) std::swap(a, b);   // a inside, b outside
                     for (int k = 0; k < 3; ++k) out += nrm[k] * (kCorner[b][k] - kCorner[a][k]); }
                 if (out < 0) std::reverse(loop.begin(), loop.end());
-                for (size_t q = 1; q + 1 < loop.size(); ++q) { tri_[cs].push_back(loop[0]); tri_[cs].push_back(loop[q]); tri_[cs].push_back(loop[q + 1]); }
+                for (size_t q = 1; q + 1 < loop.size(); ++q) { gen_[cs].push_back(loop[0]); gen_[cs].push_back(loop[q]); gen_[cs].push_back(loop[q + 1]); }
             }
         }
     }
@@ -87,9 +93,13 @@ public:
     MarchingCubes(const int dim[3], const float size[3], const float origin[3]) {
         for (int a = 0; a < 3; ++a) { dim_[a] = dim[a]; size_[a] = size[a]; origin_[a] = origin[a]; voxel_[a] = size[a] / dim[a]; }
         total_ = (size_t)dim[0] * dim[1] * dim[2];
-        build_table();
+        for (int cs = 0; cs < 256; ++cs) for (int i = 0; i < 16 && kTriTable[cs][i] >= 0; ++i) tri_[cs].push_back(kTriTable[cs][i]);
     }
     const std::vector<int>& table(int cs) const { return tri_[cs]; }
+    const std::vector<int>& generated_table(int cs) { if (gen_[1].empty()) build_table(); return gen_[cs]; }
+    // corner / edge geometry for the tests
+    static const int (*corners())[3] { return kCorner; }
+    static const int (*edges())[2] { return kEdge; }
 
     bool computeIsoSurface(const float* tsdf, const float* weights, const unsigned char* red, const unsigned char* green, const unsigned char* blue, float iso = 0.0f) {
         if (!tsdf || !weights || !red || !green || !blue) return false;
@@ -110,10 +120,14 @@ public:
                 for (int k = 0; k < 3; ++k) { int ia = (k == 0 ? x : k == 1 ? y : z) + kCorner[a][k], ib = (k == 0 ? x : k == 1 ? y : z) + kCorner[b][k];
                     pa[k] = ia * voxel_[k] - origin_[k]; pb[k] = ib * voxel_[k] - origin_[k]; }   // voxelToWorld, :647-651
                 interpolate(tsdf_[off[a]], tsdf_[off[b]], pa, pb, iso, ep[e]);
-                float ca[3] = {at(r_, off[a]) / 255.0f, at(g_, off[a] + 1) / 255.0f, at(b_, off[a] + 2) / 255.0f};   // getColor :598-599
-                float cb[3] = {at(r_, off[b]) / 255.0f, at(g_, off[b] + 1) / 255.0f, at(b_, off[b] + 2) / 255.0f};
-                float cv[3]; interpolate(tsdf_[off[a]], tsdf_[off[b]], ca, cb, iso, cv);
-                for (int k = 0; k < 3; ++k) ec[e][k] = (unsigned char)(cv[k] * 255.0);
+                // getColor :592-608; for edges 2, 3, 6 and 7 the reference passes the two end points to getColor in the OPPOSITE order to getVertex
+                // (:371, :383, :419, :431), which matters for the rounding of the interpolated byte
+                const bool rev = e == 2 || e == 3 || e == 6 || e == 7;
+                const size_t o1 = rev ? off[b] : off[a], o2 = rev ? off[a] : off[b];
+                float ca[3] = {at(r_, o1) / 255.0f, at(g_, o1 + 1) / 255.0f, at(b_, o1 + 2) / 255.0f};   // :598-599
+                float cb[3] = {at(r_, o2) / 255.0f, at(g_, o2 + 1) / 255.0f, at(b_, o2 + 2) / 255.0f};
+                float cv[3]; interpolate(tsdf_[o1], tsdf_[o2], ca, cb, iso, cv);
+                for (int k = 0; k < 3; ++k) ec[e][k] = (unsigned char)(cv[k] * 255.0f);   // (cVal * 255.0).cast<unsigned char>(): a float product (Eigen casts the scalar), truncated
             }
             for (size_t i = 0; i + 2 < tri_[cs].size(); i += 3) {
                 const int e0 = tri_[cs][i], e1 = tri_[cs][i + 1], e2 = tri_[cs][i + 2];

@@ -7,19 +7,21 @@
 
 using namespace psgsdf_host;
 
-// compute_centroid, main_ps.cpp:346-375
+// compute_centroid, main_ps.cpp:346-375.  A float running sum over ~1e6 pixels, in the reference's order of operations (R * p, + t, += into the
+// float accumulator; / float(counter)): the grid origin must be the reference's to the bit, not a better-rounded one.
 static void compute_centroid(const Mat3f& K, const DepthImage& depth, const Mat4f& T, float out[3]) {
-    double c[3] = {0, 0, 0}; int counter = 0;
+    float c[3] = {0.f, 0.f, 0.f}; int counter = 0;
     const float fx_inv = 1.f / K.v[0], fy_inv = 1.f / K.v[4], cx = K.v[2], cy = K.v[5];
     for (int y = 0; y < depth.rows; ++y) for (int x = 0; x < depth.cols; ++x) {
         float z = depth.data[(size_t)y * depth.cols + x];
         if (z > 0.0) {
-            float p[3] = {(float(x) - cx) * fx_inv * z, (float(y) - cy) * fy_inv * z, z};
-            for (int a = 0; a < 3; ++a) c[a] += T[a * 4] * p[0] + T[a * 4 + 1] * p[1] + T[a * 4 + 2] * p[2] + T[a * 4 + 3];
+            const float x0 = (float(x) - cx) * fx_inv, y0 = (float(y) - cy) * fy_inv;
+            const float p[3] = {x0 * z, y0 * z, z};
+            for (int a = 0; a < 3; ++a) { const float rp = (T[a * 4] * p[0] + T[a * 4 + 1] * p[1]) + T[a * 4 + 2] * p[2]; c[a] += rp + T[a * 4 + 3]; }
             ++counter;
         }
     }
-    for (int a = 0; a < 3; ++a) out[a] = (float)(c[a] / counter);
+    for (int a = 0; a < 3; ++a) out[a] = c[a] / float(counter);
 }
 // sampleKeyFrame, main_ps.cpp:392-421
 template <class A, class B, class C_, class D>
@@ -68,18 +70,37 @@ static int selftest_mc() {
     std::cout.precision(12);
     std::cout << ntri << " " << mc.num_faces() << " " << vol << " " << minr << " " << maxr << " " << vol2 << " " << area << " " << std::sqrt(asum[0] * asum[0] + asum[1] * asum[1] + asum[2] * asum[2]) << std::endl; return 0;
 }
-// the generated 256-case table, one line per case: `case n_triangles e0 e1 e2 ...` (edge ids of the reference's numbering)
-static int selftest_mc_table() {
+// the 256-case triangle table in use, one line per case: `case n_triangles e0 e1 e2 ...` (edge ids of the reference's numbering);
+// generated = true: the first-principles table of round 1 (cross-check)
+static int selftest_mc_table(bool generated) {
     int dim[3] = {4, 4, 4}; float size[3] = {4, 4, 4}, org[3] = {0, 0, 0};
     MarchingCubes mc(dim, size, org);
-    for (int c = 0; c < 256; ++c) { std::cout << c << " " << mc.table(c).size() / 3; for (int e : mc.table(c)) std::cout << " " << e; std::cout << "\n"; }
+    for (int c = 0; c < 256; ++c) { const std::vector<int>& t = generated ? mc.generated_table(c) : mc.table(c); std::cout << c << " " << t.size() / 3; for (int e : t) std::cout << " " << e; std::cout << "\n"; }
     return 0;
+}
+// a mesh of a small analytic volume, written the way the product writes it: `--selftest-mc-ply N out.ply` (an off-centre bumpy sphere in an N^3 grid
+// with a weight-0 corner region and varying colours): tests/test_host_tools.py re-derives it face by face
+static int selftest_mc_ply(int n, const char* path) {
+    int dim[3] = {n, n, n}; float size[3] = {0.5f * n, 0.5f * n, 0.5f * n}, org[3] = {0.1f, -0.2f, 0.3f};
+    MarchingCubes mc(dim, size, org);
+    std::vector<float> t((size_t)n * n * n), w(t.size(), 1.f); std::vector<unsigned char> r(t.size() + 2), g(t.size() + 2), b(t.size() + 2);
+    for (int k = 0; k < n; ++k) for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) {
+        const size_t l = ((size_t)k * n + j) * n + i;
+        const float dx = i - 0.47f * n, dy = j - 0.52f * n, dz = k - 0.45f * n;
+        t[l] = 0.31f * n + 0.6f * std::sin(0.9f * i) * std::cos(0.7f * j + 0.3f * k) - std::sqrt(dx * dx + dy * dy + dz * dz);
+        if (i + j + k < n / 2) w[l] = 0.f;
+        r[l] = (unsigned char)((37 * i + 11 * j) & 255); g[l] = (unsigned char)((5 * j + 91 * k) & 255); b[l] = (unsigned char)((17 * k + 3 * i) & 255);
+    }
+    mc.computeIsoSurface(t.data(), w.data(), r.data(), g.data(), b.data());
+    return mc.savePly(path) ? 0 : 1;
 }
 
 int main(int argc, char* argv[]) {
     if (argc >= 3 && std::string(argv[1]) == "--selftest-png") return selftest_png(argv[2]);
     if (argc >= 2 && std::string(argv[1]) == "--selftest-mc") return selftest_mc();
-    if (argc >= 2 && std::string(argv[1]) == "--selftest-mc-table") return selftest_mc_table();
+    if (argc >= 2 && std::string(argv[1]) == "--selftest-mc-table") return selftest_mc_table(false);
+    if (argc >= 2 && std::string(argv[1]) == "--selftest-mc-generated") return selftest_mc_table(true);
+    if (argc >= 4 && std::string(argv[1]) == "--selftest-mc-ply") return selftest_mc_ply(atoi(argv[2]), argv[3]);
     std::string configfile;
     for (int i = 1; i < argc; ++i) { std::string a = argv[i]; if (a == "--config_file" && i + 1 < argc) configfile = argv[++i]; else if (a.rfind("--config_file=", 0) == 0) configfile = a.substr(14); }
     std::cout << "load the config file from: " << configfile << std::endl;

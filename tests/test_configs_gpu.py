@@ -50,13 +50,23 @@ def load_sokrates():
 
 
 def centroid(K, depth, T):
-    """compute_centroid, main_ps.cpp:346-375: mean of the back-projected valid depth pixels of the first frame, in world coordinates"""
+    """compute_centroid, main_ps.cpp:346-375: mean of the back-projected valid depth pixels of the first frame, in world coordinates -- a float32
+    RUNNING sum over the pixels in row-major order (`centroid += R * p + t`), divided by float(count): the reference's bits, which decide the grid
+    origin.  (np.cumsum accumulates sequentially in the dtype asked for.)"""
+    f32 = np.float32
     H, W = depth.shape
-    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    K = np.asarray(K, f32); T = np.asarray(T, f32); depth = np.asarray(depth, f32)
+    u, v = np.meshgrid(np.arange(W, dtype=f32), np.arange(H, dtype=f32))
     ok = depth > 0
-    z = depth[ok].astype(np.float64)
-    p = np.stack([(u[ok] - K[0, 2]) / K[0, 0] * z, (v[ok] - K[1, 2]) / K[1, 1] * z, z], -1)
-    return (p @ T[:3, :3].T.astype(np.float64) + T[:3, 3].astype(np.float64)).mean(0).astype(np.float32)
+    z = depth[ok]
+    fx_inv, fy_inv = f32(1) / K[0, 0], f32(1) / K[1, 1]
+    x0 = (u[ok] - K[0, 2]) * fx_inv; y0 = (v[ok] - K[1, 2]) * fy_inv
+    p = [x0 * z, y0 * z, z]
+    out = np.zeros(3, f32)
+    for a in range(3):
+        contrib = ((T[a, 0] * p[0] + T[a, 1] * p[1]) + T[a, 2] * p[2]) + T[a, 3]
+        out[a] = np.cumsum(contrib, dtype=f32)[-1] / f32(len(z))
+    return out
 
 
 def test_config0_sokrates_frames_0_20(built):

@@ -1,5 +1,6 @@
-"""Host-side pieces of the voxelPS drop-in that need no GPU: the zlib PNG reader against PIL, the generated
-marching-cubes table, and the exit codes of the CLI contract (main_ps.cpp:72-75)."""
+"""Host-side pieces of the voxelPS drop-in that need no GPU: the zlib PNG reader against PIL, the marching-cubes table (the classic one,
+against the golden extracted from the reference, and against a first-principles generator), the mesh writer re-derived face by face,
+and the exit codes of the CLI contract (main_ps.cpp:72-75)."""
 import json
 import os
 import subprocess
@@ -33,7 +34,7 @@ def test_png_reader_matches_pil(built, tmp_path):
     assert run("--selftest-png", str(tmp_path / "missing.png")).returncode == 1
 
 
-def test_generated_marching_cubes_table(built):
+def test_marching_cubes_closed_surface(built):
     ntri, faces, vol, rmin, rmax, vol2, area, asum = map(float, run("--selftest-mc").stdout.split())
     assert ntri == 820                                   # the classic 256-case table has 820 triangles in total
     assert faces > 1500
@@ -50,19 +51,38 @@ MC_CORNER = [(1, 1, 0), (1, 0, 0), (0, 0, 0), (0, 1, 0), (1, 1, 1), (1, 0, 1), (
 MC_EDGE = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]
 
 
-def test_marching_cubes_table_uses_exactly_the_crossed_edges(built):
-    """What the reference's `edgeTable` encodes per case is which cube edges the surface crosses: those whose two corners lie on different
-    sides.  Computed here from the inside mask (not copied from the reference), it must be EXACTLY the set of edges the generated triangle
-    table uses, case by case; every triangle lives on three distinct crossed edges; inside a cell every triangle side is either shared by two
-    triangles with opposite orientation or lies on a cube face (the polygon boundary that the neighbouring cell closes); complementary cases
-    use the same edges.  The triangles themselves may be fanned differently from `triTable`."""
-    lines = run("--selftest-mc-table").stdout.strip().split("\n")
+def _table(flag):
+    lines = run(flag).stdout.strip().split("\n")
     assert len(lines) == 256
     table = {}
     for ln in lines:
         v = [int(x) for x in ln.split()]
         assert len(v) == 2 + 3 * v[1]
         table[v[0]] = np.array(v[2:], int).reshape(-1, 3)
+    return table
+
+
+def test_marching_cubes_table_is_the_references(built):
+    """the table the mesh writer walks equals `triTable` of third/mesh/MarchingCubes.cpp:31-290 for all 256 cases -- same triangles, same
+    vertex order, same triangle order (golden: tests/golden/mc_tritable.npy, extracted by tests/golden/make_mc_tritable.py)"""
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "mc_tritable.npy"))
+    table = _table("--selftest-mc-table")
+    for cs in range(256):
+        want = [int(e) for e in gold[cs] if e >= 0]
+        assert table[cs].ravel().tolist() == want, cs
+    edge = np.load(os.path.join(ROOT, "tests", "golden", "mc_edgetable.npy"))
+    for cs in range(256):       # `edgeTable` names exactly the edges whose corners lie on different sides
+        assert int(edge[cs]) == sum(1 << e for e, (a, b) in enumerate(MC_EDGE) if ((cs >> a) & 1) != ((cs >> b) & 1))
+
+
+@pytest.mark.parametrize("flag", ["--selftest-mc-table", "--selftest-mc-generated"])
+def test_marching_cubes_table_uses_exactly_the_crossed_edges(built, flag):
+    """What `edgeTable` encodes per case is which cube edges the surface crosses: those whose two corners lie on different sides.  Computed
+    here from the inside mask, it must be EXACTLY the set of edges the triangle table uses, case by case; every triangle lives on three distinct
+    crossed edges; inside a cell no triangle side is used twice in the same direction, and (generated table: always; classic table: wherever the
+    side is not shared) an unmatched side lies on a cube face -- the polygon boundary that the neighbouring cell closes.  Holds for the classic
+    table in use and for the first-principles generator of round 1 (kept as a cross-check): two independent derivations of the same surface."""
+    table = _table(flag)
     face_of_edge_pair = lambda e0, e1: any(all(MC_CORNER[c][ax] == side for e in (e0, e1) for c in MC_EDGE[e]) for ax in range(3) for side in (0, 1))
     total = 0
     for cs in range(256):
@@ -80,10 +100,74 @@ def test_marching_cubes_table_uses_exactly_the_crossed_edges(built):
             if (q, p) not in directed:
                 assert face_of_edge_pair(p, q), (cs, p, q)              # an unmatched side lies on a cube face
         assert set(table[255 - cs].ravel().tolist()) == crossed
-        # triangle count of a case: its surface polygons (closed loops of crossed edges) fanned -> crossed edges - 2 per loop
-        if crossed:
-            assert 1 <= len(tris) <= 5 or len(tris) == len(crossed) - 2
     assert total == 820
+
+
+def test_mesh_writer_face_by_face(built, tmp_path):
+    """`*_mesh.ply` as the product writes it (host/marching_cubes.hpp) against a numpy re-derivation of third/mesh/MarchingCubes.cpp:314-505,
+    559-637 driven by the GOLDEN table: same number of vertices and faces, every vertex position, every colour byte and every face index, in
+    the reference's order (non-indexed vertices, three per face; degenerate triangles dropped; cubes with a weight-0 corner skipped; colours
+    looked up at idx, idx + 1, idx + 2 -- quirk B10 -- and interpolated in getColor's own end-point order)."""
+    n = 20
+    path = str(tmp_path / "m.ply")
+    assert run("--selftest-mc-ply", str(n), path).returncode == 0
+    head, body = open(path).read().split("end_header\n")
+    nv = int([l for l in head.split("\n") if l.startswith("element vertex")][0].split()[2]); nf = int([l for l in head.split("\n") if l.startswith("element face")][0].split()[2])
+    rows = body.strip().split("\n")
+    V = np.array([[float(x) for x in r.split()] for r in rows[:nv]]); Fc = np.array([[int(x) for x in r.split()] for r in rows[nv:]])
+    assert len(Fc) == nf and nv == 3 * nf and nf > 300
+    # the same volume (selftest_mc_ply), float32 arithmetic as in C
+    f32 = np.float32
+    k, j, i = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    dx, dy, dz = i.astype(f32) - f32(0.47) * f32(n), j.astype(f32) - f32(0.52) * f32(n), k.astype(f32) - f32(0.45) * f32(n)
+    t = (f32(0.31) * f32(n) + f32(0.6) * np.sin(f32(0.9) * i.astype(f32)).astype(f32) * np.cos(f32(0.7) * j.astype(f32) + f32(0.3) * k.astype(f32)).astype(f32)
+         - np.sqrt(dx * dx + dy * dy + dz * dz).astype(f32)).astype(f32)
+    w = np.where(i + j + k < n // 2, f32(0), f32(1))
+    r = ((37 * i + 11 * j) & 255).astype(np.uint8); g = ((5 * j + 91 * k) & 255).astype(np.uint8); b = ((17 * k + 3 * i) & 255).astype(np.uint8)
+    tf, wf = t.reshape(-1), w.reshape(-1)
+    rf, gf, bf = (np.concatenate([c.reshape(-1), np.zeros(2, np.uint8)]) for c in (r, g, b))
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "mc_tritable.npy"))
+    vox = f32(0.5) * f32(n) / f32(n); org = np.array([0.1, -0.2, 0.3], f32)
+    color_rev = {2, 3, 6, 7}
+
+    def interp(t0, t1, v0, v1):
+        if abs(f32(0) - t0) < 1e-7: return v0
+        if abs(f32(0) - t1) < 1e-7: return v1
+        if abs(t0 - t1) < 1e-7: return v0
+        mu = float((f32(0) - t0) / (t1 - t0)); mu = min(max(mu, 0.0), 1.0)
+        return (v0.astype(np.float64) + mu * (v1 - v0).astype(np.float64)).astype(f32)
+    verts, cols = [], []
+    lin = lambda x, y, z: (z * n + y) * n + x
+    for z in range(n - 2):
+        for y in range(n - 2):
+            for x in range(n - 2):
+                off = [lin(x + c[0], y + c[1], z + c[2]) for c in MC_CORNER]
+                if any(wf[o] == 0 for o in off):
+                    continue
+                cs = sum(1 << c for c in range(8) if tf[off[c]] > 0)
+                if cs in (0, 255):
+                    continue
+                ep, ec = {}, {}
+                for e in {int(v) for v in gold[cs] if v >= 0}:
+                    a, bb = MC_EDGE[e]
+                    pa = (np.array([x + MC_CORNER[a][0], y + MC_CORNER[a][1], z + MC_CORNER[a][2]], f32) * vox - org).astype(f32)
+                    pb = (np.array([x + MC_CORNER[bb][0], y + MC_CORNER[bb][1], z + MC_CORNER[bb][2]], f32) * vox - org).astype(f32)
+                    ep[e] = interp(tf[off[a]], tf[off[bb]], pa, pb)
+                    o1, o2 = (off[bb], off[a]) if e in color_rev else (off[a], off[bb])
+                    c1 = np.array([rf[o1], gf[o1 + 1], bf[o1 + 2]], f32) / f32(255); c2 = np.array([rf[o2], gf[o2 + 1], bf[o2 + 2]], f32) / f32(255)
+                    ec[e] = (interp(tf[o1], tf[o2], c1, c2) * f32(255)).astype(f32).astype(np.uint8)
+                tri = [int(v) for v in gold[cs] if v >= 0]
+                for q in range(0, len(tri), 3):
+                    p = [ep[tri[q + s]] for s in range(3)]
+                    if np.array_equal(p[0], p[1]) or np.array_equal(p[0], p[2]) or np.array_equal(p[1], p[2]):
+                        continue
+                    for s in range(3):
+                        verts.append(p[s]); cols.append(ec[tri[q + s]])
+    verts, cols = np.array(verts, np.float64), np.array(cols, int)
+    assert len(verts) == nv
+    assert np.array_equal(Fc[:, 0], np.full(nf, 3)) and np.array_equal(Fc[:, 1:].ravel(), np.arange(nv))      # three fresh vertices per face, in order
+    assert np.abs(V[:, :3] - verts).max() <= 6e-6 * np.abs(verts).max() + 1e-7                                 # (the file holds 6 significant digits)
+    assert np.array_equal(V[:, 3:].astype(int), cols)
 
 
 def test_cli_contract_exit_codes(built, tmp_path):

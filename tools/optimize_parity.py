@@ -9,16 +9,19 @@ from oracle import oracle
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 max_it = int(sys.argv[3]) if len(sys.argv) > 3 else 18
+damp = float(sys.argv[4]) if len(sys.argv) > 4 else None
 for name, mid in (("SH1", capi.SH1), ("SH2", capi.SH2), ("LED", capi.LED)):
     sc = synth.make_scene(N=N, F=F, W=128, H=96, model=name)
     st = capi.default_settings(mid, upsample=1, max_it=max_it, conv_threshold=0.0)
     if mid == capi.LED:
         st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0
+    if damp is not None:
+        st.damping = damp
     eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=8)
     for api in (eng, orc):
         api.load_scene(sc); api.init_albedo(); api.normalize_weights()
     (re_, ce), (ro, co) = eng.optimize(capi.ALL), orc.optimize(capi.ALL)
-    out = dict(model=name, n_eng=len(re_), n_orc=len(ro), conv=(ce, co))
+    out = dict(model=name, damping=st.damping, n_eng=len(re_), n_orc=len(ro), conv=(ce, co), upsampled=[a["upsampled"] for a in re_])
     out["flags_equal"] = [(a["converged"], a["diverged"], a["upsampled"]) for a in re_] == [(b["converged"], b["diverged"], b["upsampled"]) for b in ro]
     out["e_total_rel"] = [abs(a["e_total"] - b["e_total"]) / abs(b["e_total"]) for a, b in zip(re_, ro)]
     out["reg_l"] = [(a["reg_weight_l"], b["reg_weight_l"]) for a, b in zip(re_, ro)][-4:]
