@@ -112,6 +112,39 @@ def test_upsample_and_optimize(built):
         assert abs(a["e_total"] - b["e_total"]) <= 1e-3 * abs(b["e_total"]), (a, b)
 
 
+@pytest.mark.parametrize("name,mid", MODELS)
+def test_optimize_matches_oracle(built, name, mid):
+    """psgsdf_optimize -- the loop voxelPS calls -- against the oracle's restatement of alternatingOptimize (PsOptimizer.cpp:239-428: albedo ->
+    light -> distance -> pose; LedOptimizer.cpp:279-478: light -> albedo -> distance -> pose) for all three shading models: initAlbedo and weight
+    normalisation inside the call, the per-iteration records with the energy after EVERY block, the converged / diverged flags that end the loop,
+    the 2x refinement at iteration 5 with its new Laplacian weight, and the state the loop leaves behind (band of the refined grid, SDF, albedo,
+    poses, light).  On these scenes both loops run 7 iterations (the one after the refinement raises the energy: the reference's divergence exit)."""
+    kw = dict(upsample=1, max_it=18, conv_threshold=0.0)
+    if mid == capi.LED:
+        kw.update(reg_weight_n=0.1, reg_weight_l=5.0, damping=3.0)      # config_basket_LED.json
+    sc, eng, orc = make_pair(name, mid, N=24, F=5, **kw)
+    (re_, ce), (ro, co) = eng.optimize(capi.ALL), orc.optimize(capi.ALL)
+    assert len(re_) == len(ro) >= 6 and ce == co
+    assert [(r["converged"], r["diverged"], r["upsampled"]) for r in re_] == [(r["converged"], r["diverged"], r["upsampled"]) for r in ro]
+    assert sum(r["upsampled"] for r in re_) == 1 and re_[5]["upsampled"] == 1
+    for a, b in zip(re_, ro):
+        assert abs(a["e_total"] - b["e_total"]) <= 1e-4 * abs(b["e_total"]), (a["e_total"], b["e_total"])
+        assert np.allclose(a["e_after"], b["e_after"], rtol=2e-4), (a["e_after"], b["e_after"])
+        assert a["cg_iters"] == b["cg_iters"]
+        assert abs(a["reg_weight_l"] - b["reg_weight_l"]) <= 1e-4 * abs(b["reg_weight_l"]) and abs(a["reg_weight_n"] - b["reg_weight_n"]) <= 1e-5 * abs(b["reg_weight_n"])
+    assert tuple(eng.info().dim) == tuple(orc.info().dim) == (48, 48, 48)
+    band = eng.download_band()
+    assert np.array_equal(band, orc.download_band())
+    vs = float(sc.voxel_size) / 2
+    ve, vo = eng.download_volume(), orc.download_volume()
+    d = np.abs(ve["dist"][band] - vo["dist"][band]) / vs
+    assert np.quantile(d, 0.999) <= 1e-4 and d.max() <= 5e-3, (np.quantile(d, 0.999), d.max())      # north star: <= 1e-4 relative SDF error
+    assert np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max() <= (2e-3 if name == "SH2" else 2e-4)
+    assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 1e-5
+    le, lo = eng.download_light(), orc.download_light()
+    assert np.abs(le - lo).max() <= 5 * LIGHT_RTOL[name] * np.abs(lo).max()
+
+
 @pytest.mark.parametrize("name,mid", [("SH1", capi.SH1), ("LED", capi.LED)])
 def test_albedo_regulariser(built, name, mid):
     """"reg albedo" != 0 (Optimizer.cpp:221-245,593-647): energy, regularised albedo step (matrix-free CG on the engine, assembled
