@@ -88,12 +88,21 @@ int mbox_reserve(psgsdf_ctx* c, int n, size_t* off, unsigned long long* key) {
     *key = (++c->mbox_serial << 8) | 0x80u;      // never 0; keys of different reservations differ in every index they use (n <= 64)
     return 0;
 }
-// synchronise the stream once and run every deferred consumer in submission order
+// wait for every deferred read-back and run its consumer, in submission order
 int flush(psgsdf_ctx* c) {
     materialize_fold(c);
     { int rc = mg_commit(c); if (rc) return rc; }
+    // With check words on every read-back the host needs no marker kernel behind them (round 2: a marker + its two kernel boundaries per
+    // flush): it watches the LAST read-back's words, then validates all of them in deliver().  Without read-backs in flight (or with
+    // PSGSDF_MBOX_CHECK=0 / PSGSDF_PCG_POLL=0 / profiling) the stream is drained the ordinary way.
     bool synced = false;
-    if (c->pcg_poll && !c->profiling && c->mbox) {
+    if (c->pcg_poll && !c->profiling && c->mbox && c->mbox_check && !c->deferred.empty() && c->deferred.back().key) {
+        const Deferred& d = c->deferred.back();
+        const volatile double* v = d.src; const int n = d.n; const unsigned long long key = d.key;
+        const int w = wait_mapped(c, [v, n, key] { for (int i = 0; i < n; ++i) if ((dbits(v[i]) ^ dbits(v[n + i])) != key + (unsigned long long)i) return false; return true; }, "flush");
+        if (w < 0) return w;
+        synced = w == 0;
+    } else if (c->pcg_poll && !c->profiling && c->mbox) {
         // a marker kernel + re-reading its mapped slot instead of hipStreamSynchronize: the runtime call itself is slower and makes the
         // next dispatch wait 5.8 us behind a system-scope fence (profiles/r01_notes.md, step p)
         const double seq = (c->flush_seq += 1.0);
