@@ -252,6 +252,19 @@ int psgsdf_comm_unique_id(uint8_t id[128]);                       /* ncclGetUniq
 /* RCCL communicator over xGMI for this context's device (ncclCommInitRank: blocks until all ranks have called).  Before psgsdf_upload_volume. */
 int psgsdf_comm_init(psgsdf_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
 
+/* Slab-local upload: a host that cannot (or should not) hold the whole volume on every rank.
+ *   1. every rank counts the band candidates of SOME z-planes (any split, e.g. plane k on rank k mod n): psgsdf_slab_plane_count on one plane's
+ *      nx*ny distances + visibility words -> its entry of a gdim[2]-long histogram, 0 for planes it did not look at;
+ *   2. psgsdf_plan_slab (collective: one all-reduce of the histogram) returns the planes [z0, z1) this rank OWNS -- the cuts
+ *      psgsdf_upload_volume would have chosen (equal band count);
+ *   3. psgsdf_upload_volume_slab with arrays that hold only the planes [max(0, z0-1), min(nz, z1+1)) (own planes + one halo plane per inner side;
+ *      grad / rgb: three consecutive blocks of that many voxels).
+ * Everything after that (psgsdf_set_keyframes, psgsdf_init, ...) is as with psgsdf_upload_volume. */
+int psgsdf_slab_plane_count(psgsdf_ctx* ctx, const float* dist_plane, const uint64_t* vis_plane, int words_per_voxel, double* count);
+int psgsdf_plan_slab(psgsdf_ctx* ctx, const double* plane_counts /* [gdim z] */, int* z0, int* z1);
+int psgsdf_upload_volume_slab(psgsdf_ctx* ctx, int z0, int z1, const float* dist, const float* grad_xyz, const float* weight,
+                              const float* rgb, const uint64_t* vis_words, int words_per_voxel);
+
 /* The same with a transport supplied by the caller (a host that already owns a communicator: MPI, a test harness).  All pointers are
  * device pointers; each primitive must be ordered after the work already enqueued on `hip_stream` and its result must be visible to
  * work enqueued on that stream afterwards (a blocking implementation may simply synchronise the stream).  Return 0 on success. */

@@ -123,6 +123,48 @@ class Api:
         a = [_fp(dist), _fp(grad), _fp(weight), _fp(rgb), _fp(vis, np.uint64)]
         self._check(self._fn("upload_volume")(self.ctx, a[0][1], a[1][1], a[2][1], a[3][1], a[4][1], C.c_int(words)), "upload_volume")
 
+    # -- slab-local upload (multi-rank): no rank touches the whole volume
+    def slab_plane_count(self, dist_plane, vis_plane, words):
+        a = [_fp(dist_plane), _fp(vis_plane, np.uint64)]; out = C.c_double()
+        self._check(self._fn("slab_plane_count")(self.ctx, a[0][1], a[1][1], C.c_int(words), C.byref(out)), "slab_plane_count")
+        return out.value
+
+    def plan_slab(self, plane_counts):
+        a = _fp(plane_counts, np.float64); z0, z1 = C.c_int(), C.c_int()
+        self._check(self._fn("plan_slab")(self.ctx, a[1], C.byref(z0), C.byref(z1)), "plan_slab")
+        return z0.value, z1.value
+
+    def upload_volume_slab(self, z0, z1, dist, grad, weight, rgb, vis, words):
+        a = [_fp(dist), _fp(grad), _fp(weight), _fp(rgb), _fp(vis, np.uint64)]
+        self._check(self._fn("upload_volume_slab")(self.ctx, C.c_int(z0), C.c_int(z1), a[0][1], a[1][1], a[2][1], a[3][1], a[4][1], C.c_int(words)), "upload_volume_slab")
+
+    def load_scene_slab(self, sc, rank, n_ranks, planes=None, u8=None):
+        """load_scene for a rank of a multi-rank run that only ever looks at ITS planes of the scene: `planes(zlo, zhi)` returns the dict of
+        per-voxel arrays (dist, grad, weight, rgb, vis) of the z-planes [zlo, zhi) -- default: slices of the whole-volume arrays of `sc`
+        (a scene generator or a file reader would produce just those planes)."""
+        nx, ny, nz = (int(x) for x in sc.dim); plane = nx * ny
+        if planes is None:
+            def planes(zlo, zhi):
+                sl = slice(zlo * plane, zhi * plane)
+                return dict(dist=sc.dist[sl], grad=sc.grad[:, sl], weight=sc.weight[sl], rgb=sc.rgb[:, sl], vis=sc.vis[sl])
+        cnt = np.zeros(nz)
+        for k in range(rank, nz, n_ranks):
+            p = planes(k, k + 1)
+            cnt[k] = self.slab_plane_count(p["dist"], p["vis"], sc.vis_words)
+        z0, z1 = self.plan_slab(cnt)
+        zlo, zhi = max(0, z0 - 1), min(nz, z1 + 1)
+        p = planes(zlo, zhi)
+        self.upload_volume_slab(z0, z1, p["dist"], p["grad"], p["weight"], p["rgb"], p["vis"], sc.vis_words)
+        has_u8 = getattr(sc, "images_u8", None) is not None
+        if u8 is None:
+            u8 = has_u8
+        if u8:
+            self.set_keyframes_u8(sc.frame_idx, sc.images_u8, sc.image_scale, sc.poses)
+        else:
+            self.set_keyframes(sc.frame_idx, sc.images, sc.poses)
+        self.init()
+        return z0, z1
+
     def set_keyframes(self, frame_idx, images, poses):
         F, H, W, _ = images.shape
         a = [_fp(frame_idx, np.int32), _fp(images), _fp(poses)]

@@ -73,25 +73,27 @@ void psgsdf_destroy(psgsdf_ctx* c) {
 // Multi-rank: where to cut the volume into z-slabs of (about) equal band count.  Every rank counts the band candidates (|d| <= sqrt(3) vs and
 // seen in some frame: OptimizerAux.cpp:249 before the keyframes are selected) of ITS share of the z-planes on the host, one all-reduce makes
 // the per-plane histogram global, and every rank takes the same cuts from its prefix sum.
-static int choose_slab(psgsdf_ctx* c, const float* dist, const uint64_t* vis_words, int wpv, int* z0, int* z1) {
-    const int nz = c->gdim[2], n = c->n_ranks;
+static double count_plane(const psgsdf_ctx* c, const float* d, const uint64_t* v, int wpv) {
     const long long plane = (long long)c->gdim[0] * c->gdim[1];
-    if (nz < n) return fail(c, PSGSDF_ERR_UNSUPPORTED, "%d z-planes cannot be cut into %d slabs", nz, n);
-    std::vector<double> cnt(nz, 0.0);
     const float lim = (float)(sqrt(3.0) * (double)c->grid.vs);
-    for (int k = c->rank; k < nz; k += n) {
-        const float* d = dist + (size_t)k * plane; const uint64_t* v = vis_words + (size_t)k * plane * wpv;
-        long long m = 0;
-        for (long long i = 0; i < plane; ++i) { if (!(fabsf(d[i]) <= lim)) continue; bool seen = false; for (int w = 0; w < wpv && !seen; ++w) seen = v[(size_t)i * wpv + w] != 0; m += seen; }
-        cnt[k] = (double)m;
+    long long m = 0;
+    for (long long i = 0; i < plane; ++i) { if (!(fabsf(d[i]) <= lim)) continue; bool seen = false; for (int w = 0; w < wpv && !seen; ++w) seen = v[(size_t)i * wpv + w] != 0; m += seen; }
+    return (double)m;
+}
+// cnt[nz]: this rank's contribution to the per-plane histogram (0 for planes another rank counted) -> the planes [z0, z1) this rank owns
+static int cut_slabs(psgsdf_ctx* c, std::vector<double>& cnt, int* z0, int* z1) {
+    const int nz = c->gdim[2], n = c->n_ranks;
+    if (nz < n) return fail(c, PSGSDF_ERR_UNSUPPORTED, "%d z-planes cannot be cut into %d slabs", nz, n);
+    if (n > 1) {
+        double* d_cnt = nullptr;
+        HIPCHK(c, hipMalloc(&d_cnt, sizeof(double) * nz));
+        int rc = 0;
+        if (hipMemcpyAsync(d_cnt, cnt.data(), sizeof(double) * nz, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "slab histogram upload");
+        if (!rc) rc = comm_allreduce(c, d_cnt, nz);
+        if (!rc && (hipMemcpyAsync(cnt.data(), d_cnt, sizeof(double) * nz, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) rc = fail(c, PSGSDF_ERR_DEVICE, "slab histogram download");
+        hipFree(d_cnt);
+        if (rc) return rc;
     }
-    double* d_cnt = nullptr;
-    HIPCHK(c, hipMalloc(&d_cnt, sizeof(double) * nz));
-    HIPCHK(c, hipMemcpyAsync(d_cnt, cnt.data(), sizeof(double) * nz, hipMemcpyHostToDevice, c->stream));
-    int rc = comm_allreduce(c, d_cnt, nz); if (rc) { hipFree(d_cnt); return rc; }
-    HIPCHK(c, hipMemcpyAsync(cnt.data(), d_cnt, sizeof(double) * nz, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipFree(d_cnt);
     double total = 0; for (double x : cnt) total += x;
     if (total <= 0) return fail(c, PSGSDF_ERR_UNSUPPORTED, "the volume has no band candidates to partition");
     // cut r = first plane at which the running count reaches r/n of the total; every slab keeps at least one plane
@@ -103,31 +105,64 @@ static int choose_slab(psgsdf_ctx* c, const float* dist, const uint64_t* vis_wor
     *z0 = cut[c->rank]; *z1 = cut[c->rank + 1];
     return 0;
 }
+static int choose_slab(psgsdf_ctx* c, const float* dist, const uint64_t* vis_words, int wpv, int* z0, int* z1) {
+    const int nz = c->gdim[2], n = c->n_ranks;
+    const long long plane = (long long)c->gdim[0] * c->gdim[1];
+    std::vector<double> cnt(nz, 0.0);
+    for (int k = c->rank; k < nz; k += n) cnt[k] = count_plane(c, dist + (size_t)k * plane, vis_words + (size_t)k * plane * wpv, wpv);
+    return cut_slabs(c, cnt, z0, z1);
+}
 
-int psgsdf_upload_volume(psgsdf_ctx* c, const float* dist, const float* grad_xyz, const float* weight, const float* rgb, const uint64_t* vis_words, int words_per_voxel) {
-    if (!c || !dist || !grad_xyz || !weight || !rgb || !vis_words || words_per_voxel < 1) return fail(c, PSGSDF_ERR_ARG, "upload_volume: null argument");
-    HIPCHK(c, hipSetDevice(c->device));
-    // the caller hands over the WHOLE volume; a rank of a multi-rank run keeps its z-slab (+ one halo plane per inner side) of it on the device
-    int z0 = 0, z1 = c->gdim[2];
-    if (c->n_ranks > 1) { int rc = choose_slab(c, dist, vis_words, words_per_voxel, &z0, &z1); if (rc) return rc; }
+// the planes [zlo, zhi) = own planes [z0, z1) + one halo plane per inner side, from arrays that hold exactly those planes (`src_n` voxels per plane set)
+static int upload_planes(psgsdf_ctx* c, int z0, int z1, size_t src_n, size_t src_off, const float* dist, const float* grad_xyz, const float* weight, const float* rgb, const uint64_t* vis_words, int words_per_voxel) {
     { int rc = set_local_grid(c, z0, z1); if (rc) return rc; }
-    const long long n = c->grid.nvox, gn = c->gnvox;
-    const size_t off = (size_t)c->zlo * c->gdim[0] * c->gdim[1];          // first voxel of the local planes in the caller's arrays
+    const long long n = c->grid.nvox;
     free_dense(c);
     if (c->vis_seq) { hipFree(c->vis_seq); c->vis_seq = nullptr; }
     int rc = alloc_dense(c, c->dense, n, 0, true); if (rc) return rc;
     HIPCHK(c, hipMalloc(&c->vis_seq, sizeof(uint64_t) * n * words_per_voxel));
     c->wpv_seq = words_per_voxel;
-    HIPCHK(c, hipMemcpyAsync(c->dense.dist, dist + off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dense.dist, dist + src_off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     for (int a = 0; a < 3; ++a) {
-        HIPCHK(c, hipMemcpyAsync(c->dense.g[a], grad_xyz + (size_t)a * gn + off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->dense.rho[a], rgb + (size_t)a * gn + off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dense.g[a], grad_xyz + (size_t)a * src_n + src_off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dense.rho[a], rgb + (size_t)a * src_n + src_off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->dense.weight, weight + off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->vis_seq, vis_words + off * words_per_voxel, sizeof(uint64_t) * n * words_per_voxel, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dense.weight, weight + src_off, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->vis_seq, vis_words + src_off * words_per_voxel, sizeof(uint64_t) * n * words_per_voxel, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_volume = true; c->inited = false;
     return PSGSDF_OK;
+}
+
+int psgsdf_upload_volume(psgsdf_ctx* c, const float* dist, const float* grad_xyz, const float* weight, const float* rgb, const uint64_t* vis_words, int words_per_voxel) {
+    if (!c || !dist || !grad_xyz || !weight || !rgb || !vis_words || words_per_voxel < 1) return fail(c, PSGSDF_ERR_ARG, "upload_volume: null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    // the caller hands over the WHOLE volume; a rank of a multi-rank run keeps its z-slab (+ one halo plane per inner side) of it on the device
+    // (a host that cannot or should not hold the whole volume on every rank uses psgsdf_plan_slab + psgsdf_upload_volume_slab instead)
+    int z0 = 0, z1 = c->gdim[2];
+    if (c->n_ranks > 1) { int rc = choose_slab(c, dist, vis_words, words_per_voxel, &z0, &z1); if (rc) return rc; }
+    const int zlo = std::max(0, z0 - 1);
+    return upload_planes(c, z0, z1, (size_t)c->gnvox, (size_t)zlo * c->gdim[0] * c->gdim[1], dist, grad_xyz, weight, rgb, vis_words, words_per_voxel);
+}
+
+// ---- slab-local upload: no rank ever touches the whole volume ----------------------------------------------
+int psgsdf_slab_plane_count(psgsdf_ctx* c, const float* dist_plane, const uint64_t* vis_plane, int words_per_voxel, double* count) {
+    if (!c || !dist_plane || !vis_plane || !count || words_per_voxel < 1) return fail(c, PSGSDF_ERR_ARG, "slab_plane_count: null argument");
+    *count = count_plane(c, dist_plane, vis_plane, words_per_voxel);
+    return PSGSDF_OK;
+}
+int psgsdf_plan_slab(psgsdf_ctx* c, const double* plane_counts, int* z0, int* z1) {
+    if (!c || !plane_counts || !z0 || !z1) return fail(c, PSGSDF_ERR_ARG, "plan_slab: null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<double> cnt(plane_counts, plane_counts + c->gdim[2]);
+    return cut_slabs(c, cnt, z0, z1);
+}
+int psgsdf_upload_volume_slab(psgsdf_ctx* c, int z0, int z1, const float* dist, const float* grad_xyz, const float* weight, const float* rgb, const uint64_t* vis_words, int words_per_voxel) {
+    if (!c || !dist || !grad_xyz || !weight || !rgb || !vis_words || words_per_voxel < 1) return fail(c, PSGSDF_ERR_ARG, "upload_volume_slab: null argument");
+    if (z0 < 0 || z1 > c->gdim[2] || z1 <= z0) return fail(c, PSGSDF_ERR_ARG, "upload_volume_slab: planes [%d, %d) of %d", z0, z1, c->gdim[2]);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int zlo = std::max(0, z0 - 1), zhi = std::min(c->gdim[2], z1 + 1);
+    return upload_planes(c, z0, z1, (size_t)(zhi - zlo) * c->gdim[0] * c->gdim[1], 0, dist, grad_xyz, weight, rgb, vis_words, words_per_voxel);
 }
 
 int psgsdf_volume_init(psgsdf_ctx* c, int max_frames) {

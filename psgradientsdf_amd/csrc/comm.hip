@@ -138,9 +138,13 @@ int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
     }
     RcclApi* r = rccl();
     NCCLCHK(c, r->GroupStart());
-    for (auto& x : sends) NCCLCHK(c, r->Send(x.ptr_dev, x.bytes, ncclChar, x.peer, c->comm->nccl, c->stream));
-    for (auto& x : recvs) NCCLCHK(c, r->Recv(x.ptr_dev, x.bytes, ncclChar, x.peer, c->comm->nccl, c->stream));
-    NCCLCHK(c, r->GroupEnd());
+    // (an error inside the bracket must not leave the group open on this thread: later collectives would be queued into it or hang)
+    ncclResult_t first = ncclSuccess;
+    for (auto& x : sends) { if (first != ncclSuccess) break; first = r->Send(x.ptr_dev, x.bytes, ncclChar, x.peer, c->comm->nccl, c->stream); }
+    for (auto& x : recvs) { if (first != ncclSuccess) break; first = r->Recv(x.ptr_dev, x.bytes, ncclChar, x.peer, c->comm->nccl, c->stream); }
+    const ncclResult_t end = r->GroupEnd();
+    if (first != ncclSuccess) return fail(c, PSGSDF_ERR_COMM, "halo exchange (ncclSend / ncclRecv): %s", r->GetErrorString ? r->GetErrorString(first) : "rccl error");
+    NCCLCHK(c, end);
     return 0;
 }
 

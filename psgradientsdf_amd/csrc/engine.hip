@@ -273,7 +273,7 @@ int build_band(psgsdf_ctx* c) {
         c->row0 = 0; c->row1 = S;
         c->halo = 0; c->need[0] = c->need[1] = 0; c->give[0] = c->give[1] = 0; c->halo_active = false;
         if (c->n_ranks > 1 && !c->comm) return fail(c, PSGSDF_ERR_COMM, "rank %d of %d has no communicator (psgsdf_comm_init)", c->rank, c->n_ranks);
-        if (c->n_ranks > kMgScal / 2) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d ranks", kMgScal / 2);
+        if (3 * c->n_ranks > kMgScal) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d ranks", kMgScal / 3);      // (the set-up exchange below carries 3 doubles per rank)
         if (c->n_ranks > 1) {
             const long long plane = (long long)c->grid.dim[0] * c->grid.dim[1];
             int rr[2] = {0, S};
@@ -288,7 +288,6 @@ int build_band(psgsdf_ctx* c) {
             // {need_lo, need_hi, own rows} of every rank in one tiny all-reduce: what a slab SENDS is its neighbours' need
             std::vector<double> info(3 * (size_t)c->n_ranks, 0.0);
             info[3 * c->rank] = c->need[0]; info[3 * c->rank + 1] = c->need[1]; info[3 * c->rank + 2] = c->row1 - c->row0;
-            if (info.size() > (size_t)kMgScal) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d ranks", kMgScal / 3);
             HIPCHK(c, hipMemcpyAsync(c->mg_scal, info.data(), sizeof(double) * info.size(), hipMemcpyHostToDevice, c->stream));
             int rcc = comm_allreduce(c, c->mg_scal, (int)info.size()); if (rcc) return rcc;
             HIPCHK(c, hipMemcpyAsync(info.data(), c->mg_scal, sizeof(double) * info.size(), hipMemcpyDeviceToHost, c->stream));

@@ -22,7 +22,7 @@
 #include <vector>
 
 namespace psge {
-constexpr int kMgScal = 64;   // doubles in the set-up exchange buffer (2 per rank: at most 32 ranks)
+constexpr int kMgScal = 96;   // doubles in the set-up exchange buffer (3 per rank: at most 32 ranks)
 struct KTime { double ms = 0; int64_t n = 0; };
 struct Comm;                  // comm.hip: RCCL communicator or caller-supplied transport
 struct MgSeg { unsigned off, n; unsigned long long key; };

@@ -31,7 +31,10 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         tr = GlooTransport(dist)
         eng.comm_init_ext(tr.ops, rank, world)
-    eng.load_scene(sc)
+    if mode == "iterate_slab":    # slab-local upload: this rank only ever hands over its own planes (+ halo) of the volume
+        eng.load_scene_slab(sc, rank, world)
+    else:
+        eng.load_scene(sc)
     eng.init_albedo()
     e0 = eng.normalize_weights()
     recs = eng.iterate(capi.ALL, n_iters)

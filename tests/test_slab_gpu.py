@@ -111,3 +111,17 @@ def test_native_slab_refinement(built, tmp_path):
     d = stitch(res, "dist")
     assert np.abs(d[band] - v["dist"][band]).max() <= 1e-4 * vs
     assert res[0]["info"][7] == res[1]["info"][6] == 2 * (res[0]["info"][7] // 2)     # the cut doubled with the grid
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_local_upload(built, tmp_path, world):
+    """psgsdf_plan_slab + psgsdf_upload_volume_slab (no rank hands over -- or ever looks at -- more than its own z-planes and one halo plane per
+    inner side; the cut negotiation is one all-reduce of a per-plane histogram that the ranks fill in turns): the same cuts, the same band rows and
+    the same bits as the whole-volume upload of psgsdf_upload_volume on every rank."""
+    res = run_ranks(tmp_path, "SH1", world, "gloo", "iterate_slab", 40, 2)
+    (tmp_path / "w").mkdir()
+    ref = run_ranks(tmp_path / "w", "SH1", world, "gloo", "iterate", 40, 2)
+    for a, b in zip(res, ref):
+        assert list(a["info"]) == list(b["info"])                       # same cuts, same row ranges, same halos
+        assert np.array_equal(a["band"], b["band"]) and np.array_equal(a["e_total"], b["e_total"]) and np.array_equal(a["cg"], b["cg"])
+        assert np.array_equal(a["dist"], b["dist"], equal_nan=True) and np.array_equal(a["rgb"], b["rgb"], equal_nan=True) and np.array_equal(a["poses"], b["poses"])
