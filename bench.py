@@ -112,14 +112,26 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
     """one workload: scene, contexts, the timed loop; returns the fields of the JSON line for it"""
     t_gen = time.time()
     use_u8 = args.u8_images
-    sc = synth.make_scene(N=args.grid, F=args.frames, W=args.width, H=args.height, model=model, u8=use_u8)
+    scene_kw = dict(N=args.grid, F=args.frames, W=args.width, H=args.height, model=model, u8=use_u8)
+    if args.strong:
+        # ONE volume for all ranks; a rank renders the keyframes (every rank needs all of them) and synthesises only the planes it is asked for:
+        # first its share of the planes for the cut negotiation, then its own slab + halo planes (capi.load_scene_slab)
+        nz = args.grid
+        sc = synth.make_scene(z_planes=(rank * nz // world, (rank + 1) * nz // world), **scene_kw)
+
+        def planes_of(zlo, zhi):
+            part = sc if tuple(sc.z_planes) == (zlo, zhi) else synth.make_scene(z_planes=(zlo, zhi), reuse=sc, **scene_kw)
+            return dict(dist=part.dist, grad=part.grad, weight=part.weight, rgb=part.rgb, vis=part.vis)
+    else:
+        sc = synth.make_scene(**scene_kw)
     t_gen = time.time() - t_gen
     model_id = synth.MODELS[model]
     st = capi.default_settings(model_id)
     if model == "LED":   # config_basket_LED.json
         st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0
-    if world > 1:
+    if world > 1 and not args.strong:
         sc = synth.tile_scene(sc, world)
+    slab_rows = []
 
     def context(settings):
         eng = capi.load_engine(sc, sc.K, settings, device)
@@ -134,7 +146,10 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
                 if world > 1:
                     dist.broadcast_object_list(ident, src=0)
                 eng.comm_init(rank, world, ident[0])
-        eng.load_scene(sc, u8=use_u8)
+        if args.strong:
+            eng.load_scene_slab(sc, rank, world, planes=planes_of, u8=use_u8)
+        else:
+            eng.load_scene(sc, u8=use_u8)
         return eng
 
     def barrier():
@@ -147,8 +162,16 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
     eng = context(st)
     eng.init_albedo()
     eng.normalize_weights()
-    S = eng.info().n_band // world              # per-slab band size
+    S = eng.info().n_band // world              # per-slab band size (weak: every slab holds one copy of the scene; strong: the mean)
     n_obs = eng.step(capi.ALBEDO)["n_obs"] // world
+    own_rows = None
+    if slab:
+        mi = eng.mg_info()
+        own_rows = [int(mi["row1"] - mi["row0"])]
+        if dist is not None:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, own_rows[0])
+            own_rows = [int(x) for x in gathered]
     eng.iterate(capi.ALL, args.warmup)
     kernels, dom = {}, "sweep_dist"
     if headline and not args.no_breakdown:
@@ -218,10 +241,10 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
     else:
         elapsed, recs = t_opt, recs_opt
     cg_iters = float(np.mean([r["cg_iters"] for r in recs]))
-    res = dict(model=model, value=world * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, loop=loop, S=int(S), n_obs=int(n_obs), cg_iters=cg_iters,
+    res = dict(model=model, value=(1 if args.strong else world) * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, loop=loop, S=int(S), n_obs=int(n_obs), cg_iters=cg_iters,
                iterate_ms_per_step=1e3 * t_iter / args.steps, optimize_ms_per_step=(1e3 * t_opt / args.steps) if t_opt else None,
                kernels=kernels, dom=dom, watched=watched, t_gen=t_gen, st=st, sc=sc, sync_stats=sync_stats,
-               collectives_per_step=(coll1 - coll0) / max(args.steps, 1), use_u8=use_u8)
+               collectives_per_step=(coll1 - coll0) / max(args.steps, 1), use_u8=use_u8, own_rows=own_rows)
     return res
 
 
@@ -240,8 +263,11 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--force-slab", action="store_true", help="attach the single rank to a one-rank RCCL communicator (overhead of the multi-rank code path)")
     ap.add_argument("--no-extra", action="store_true", help="skip the LED / SH2 lines")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: ONE volume (default BASELINE configs[4]: 512^3, SH2, 100 keyframes) cut into --gpus z-slabs; every rank synthesises and uploads only its own planes")
     ap.add_argument("--loop", default="optimize", choices=["optimize", "iterate"], help="which loop `value` times (iterate: the round-2 figure, no stop decision)")
     args = ap.parse_args()
+    if args.strong and (args.grid, args.frames, args.model) == (256, 50, "SH1"):      # nothing chosen explicitly: BASELINE configs[4]
+        args.grid, args.frames, args.model = 512, 100, "SH2"
 
     if os.environ.get("PSGSDF_FAULT_DUMP"):   # diagnostics: dump every thread's Python stack after N seconds and exit
         import faulthandler
@@ -277,18 +303,20 @@ def main():
     S, n_obs, cg_iters, kernels, dom, watched, st, sc = m["S"], m["n_obs"], m["cg_iters"], m["kernels"], m["dom"], m["watched"], m["st"], m["sc"]
     use_u8 = m["use_u8"]
     out = {
-        "metric": "Gauss-Newton iterations/sec (full PS sweep), 256^3 grid x 50 frames" if (args.grid, args.frames) == (256, 50)
+        "metric": "Gauss-Newton iterations/sec (full PS sweep), 256^3 grid x 50 frames" if (args.grid, args.frames) == (256, 50) and not args.strong
         else f"Gauss-Newton iterations/sec (full PS sweep), {args.grid}^3 grid x {args.frames} frames",
         "value": m["value"], "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (8-bit RGB keyframes)" if use_u8 else "synthetic",
         "config": {"workload": f"synthetic {args.width}x{args.height} RGB-D bumpy sphere, {args.grid}^3 grid, {args.model}, {args.frames} keyframes, "
                                "albedo+light+distance+pose blocks, Cauchy IRLS, Eikonal reg (config_skorates.json settings)",
                    "loop": m["loop"] + ": stop decision (convergence / divergence test on the host) after every iteration; the K steps span as many calls as the divergence exit makes necessary",
                    "band_voxels": int(S), "observations": int(n_obs), "pcg_iters_per_step": cg_iters,
-                   "parallelism": "single GPU" if world == 1 else f"{world} z-slabs (one per GPU), grid {args.grid}x{args.grid}x{args.grid * world}, {args.frames * world} keyframes, native slab loop: RCCL halo exchange + all-reduce issued by the C++ host"},
+                   "parallelism": "single GPU" if world == 1 else
+                   (f"strong scaling: ONE {args.grid}^3 volume with {args.frames} keyframes cut into {world} z-slabs of equal band count (one per GPU; every rank synthesises and uploads only its own planes), native slab loop: RCCL halo exchange + all-reduce issued by the C++ host" if args.strong else
+                    f"{world} z-slabs (one per GPU), grid {args.grid}x{args.grid}x{args.grid * world}, {args.frames * world} keyframes, native slab loop: RCCL halo exchange + all-reduce issued by the C++ host")},
         "iterate_ms_per_step": m["iterate_ms_per_step"],      # psgsdf_iterate: the same iterations without a stop decision (round-2 `value`)
-        "iterate_value": world * 1e3 / m["iterate_ms_per_step"],
+        "iterate_value": (1 if args.strong else world) * 1e3 / m["iterate_ms_per_step"],
         "optimize_ms_per_step": m["optimize_ms_per_step"],
     }
 
@@ -330,6 +358,7 @@ def main():
         B_iter = 4 * (S * 60 + U) + 120 * S + 124 * cg_iters * S   # SURVEY §8d per-pass figure kept (the fused pass moves 144 B/row)
         if slab:
             out["config"]["collectives_per_step"] = m["collectives_per_step"]
+            out["config"]["band_rows_per_rank"] = m["own_rows"]
         out["iteration"] = {"algorithmic_bytes": B_iter, "achieved_GBs": B_iter * (m["value"] / world) / 1e9,
                             "frac_of_hbm_peak": B_iter * (m["value"] / world) / 1e9 / HBM_PEAK_GBS}
         if kernels:
@@ -341,7 +370,7 @@ def main():
         out["setup_s"] = {"scene_generation": round(m["t_gen"], 1)}
 
         # ---- CPU baseline: the oracle (a port of the reference's arithmetic) on the host cores, bounded sample
-        if world == 1 and not slab and not args.no_cpu_baseline:
+        if world == 1 and not slab and not args.no_cpu_baseline and not args.strong:
             from oracle import oracle
             orc = oracle.Oracle(sc, sc.K, st, threads=1)
             orc.load_scene(sc)
@@ -364,7 +393,7 @@ def main():
                 orc.close()
     del m, sc
     # ---- the other shading models on the same grid / keyframe shape (BASELINE configs[3] = LED; SH2 = configs[4]'s model at the headline size)
-    if world == 1 and not slab and not args.no_extra and (args.grid, args.frames, args.model) == (256, 50, "SH1"):
+    if world == 1 and not slab and not args.no_extra and not args.strong and (args.grid, args.frames, args.model) == (256, 50, "SH1"):
         extra = {}
         for mod in ("LED", "SH2"):
             e = measure(args, mod, torch, dist, rank, world, device, slab, share, headline=False)

@@ -141,16 +141,20 @@ class Api:
     def load_scene_slab(self, sc, rank, n_ranks, planes=None, u8=None):
         """load_scene for a rank of a multi-rank run that only ever looks at ITS planes of the scene: `planes(zlo, zhi)` returns the dict of
         per-voxel arrays (dist, grad, weight, rgb, vis) of the z-planes [zlo, zhi) -- default: slices of the whole-volume arrays of `sc`
-        (a scene generator or a file reader would produce just those planes)."""
+        (a scene generator or a file reader produces just those planes).  `sc` supplies the grid, the keyframes and the poses.
+        The cut negotiation: rank r counts the band candidates of the r-th of n equal blocks of planes (any split is allowed)."""
         nx, ny, nz = (int(x) for x in sc.dim); plane = nx * ny
         if planes is None:
             def planes(zlo, zhi):
                 sl = slice(zlo * plane, zhi * plane)
                 return dict(dist=sc.dist[sl], grad=sc.grad[:, sl], weight=sc.weight[sl], rgb=sc.rgb[:, sl], vis=sc.vis[sl])
         cnt = np.zeros(nz)
-        for k in range(rank, nz, n_ranks):
-            p = planes(k, k + 1)
-            cnt[k] = self.slab_plane_count(p["dist"], p["vis"], sc.vis_words)
+        a, b = rank * nz // n_ranks, (rank + 1) * nz // n_ranks
+        if b > a:
+            p = planes(a, b)
+            for k in range(a, b):
+                sl = slice((k - a) * plane, (k - a + 1) * plane)
+                cnt[k] = self.slab_plane_count(p["dist"][sl], p["vis"][sl], sc.vis_words)
         z0, z1 = self.plan_slab(cnt)
         zlo, zhi = max(0, z0 - 1), min(nz, z1 + 1)
         p = planes(zlo, zhi)

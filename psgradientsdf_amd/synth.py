@@ -81,13 +81,17 @@ def _run_parallel(fn, jobs, workers):
 
 
 def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, noise=True,
-               perturb=True, z_mult=1, dtype=np.float32, bump=1.0, arc=360.0, u8=False, workers=None, zigzag=True):
+               perturb=True, z_mult=1, dtype=np.float32, bump=1.0, arc=360.0, u8=False, workers=None, zigzag=True, z_planes=None, reuse=None):
     """Build a scene.  N: grid edge (z edge = N*z_mult, z_mult bumpy spheres stacked along z for the
     weak-scaling bench), F keyframes of W x H pixels.
 
     u8: quantise the rendered keyframes to 8 bits the way a camera / PNG does; the scene then carries `images_u8` (uint8) with
     `image_scale` = 1/255 next to `images` = images_u8 * image_scale (float32, exactly what the reference's loader would hold), and
     everything derived from the images uses the quantised values.
+
+    z_planes = (zlo, zhi): the per-voxel arrays hold only those z-planes of the volume (a rank of a multi-rank run that never touches the whole
+    volume: capi.load_scene_slab); the planes are bit-identical to the same planes of the whole scene.  reuse: a scene of the same parameters
+    whose keyframes are taken over instead of being rendered again.
 
     Intrinsics scale with the image so the object always fills the same fraction of the frame:
     fx = fy = 525 * W/640 (TUM-like 640x480 -> 525)."""
@@ -211,10 +215,13 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         ncam = -(n @ R)                                   # R^T n_world, flipped to point into the surface
         for a in range(3):
             normals_cam[f, a][idx] = np.where(good, ncam[:, a], 0.0).astype(np.float32)
-    _run_parallel(render, range(F), workers)
-    if noise:
-        images = images + 0.005 * np.random.default_rng(1).standard_normal(images.shape)
-    images = np.clip(images, 0.0, 1.0)
+    if reuse is None:
+        _run_parallel(render, range(F), workers)
+        if noise:
+            images = images + 0.005 * np.random.default_rng(1).standard_normal(images.shape)
+        images = np.clip(images, 0.0, 1.0)
+    else:
+        images, depth, normals_cam = reuse.images.astype(np.float64), reuse.depth, reuse.normals_cam
     images_u8, image_scale = None, None
     if u8:
         images_u8 = np.rint(images * 255.0).astype(np.uint8)
@@ -225,7 +232,12 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
     ii = np.arange(N, dtype=np.float64)
     kk = np.arange(N * z_mult, dtype=np.float64)
     origin = shift - 0.5 * vs * dim.astype(np.float64)
-    nvox = int(dim.prod())
+    plane = N * N
+    chunk = max(1, (1 << 20) // plane)      # z-planes per chunk (bounds memory)
+    nz = N * z_mult
+    zlo, zhi = (0, nz) if z_planes is None else (int(z_planes[0]), int(z_planes[1]))
+    ka, kb = (zlo // chunk) * chunk, min(nz, -(-zhi // chunk) * chunk)      # the chunk-aligned planes that are computed
+    nvox = (kb - ka) * plane
     dist = np.empty(nvox, np.float32)
     grad = np.zeros((3, nvox), np.float32)
     weight = np.zeros(nvox, np.float32)
@@ -233,9 +245,6 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
     albedo_gt = np.zeros((3, nvox), np.float32)   # true albedo at the surface point of every near-surface voxel
     wpv = (F + 63) // 64
     vis = np.zeros((nvox, wpv), np.uint64)
-    # process z-planes in chunks to bound memory
-    plane = N * N
-    chunk = max(1, (1 << 20) // plane)
     rng_d = np.random.default_rng(3)
 
     def voxel_chunk(job):
@@ -256,7 +265,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
             gn = np.linalg.norm(gv, axis=-1)
             d[cand] = fv / gn
             nrm[cand] = gv / gn[:, None]
-        sl = slice(k0 * plane, k1 * plane)
+        sl = slice((k0 - ka) * plane, (k1 - ka) * plane)
         near = np.abs(d) < T
         dn = np.clip(d, -T, T)
         if perturb:
@@ -298,8 +307,14 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         jobs = []
         for k0 in starts[b0:b0 + workers]:
             k1 = min(N * z_mult, k0 + chunk)
-            jobs.append((k0, k1, rng_d.standard_normal((k1 - k0) * plane) if perturb else None))
+            pn = rng_d.standard_normal((k1 - k0) * plane) if perturb else None      # (drawn for every chunk: the planes of a partial scene are those of the whole one)
+            if k0 >= ka and k1 <= kb:
+                jobs.append((k0, k1, pn))
         _run_parallel(voxel_chunk, jobs, workers)
+    if (ka, kb) != (zlo, zhi):
+        cut = slice((zlo - ka) * plane, (zhi - ka) * plane)
+        dist, weight, vis = dist[cut].copy(), weight[cut].copy(), vis[cut].copy()
+        grad, rgb, albedo_gt = grad[:, cut].copy(), rgb[:, cut].copy(), albedo_gt[:, cut].copy()
 
     poses_used = poses.copy()
     if perturb:
@@ -322,7 +337,7 @@ def make_scene(N=64, F=8, W=160, H=120, model="SH1", seed=1234, extent=0.512, no
         poses=np.ascontiguousarray(poses_used.reshape(F, 16).astype(np.float32)),
         poses_gt=poses.reshape(F, 16).astype(np.float32),
         light_gt=np.asarray(light, np.float32), frame_idx=np.arange(F, dtype=np.int32),
-        depth=depth, normals_cam=normals_cam, R0=R0, A=A, extent=extent,
+        depth=depth, normals_cam=normals_cam, R0=R0, A=A, extent=extent, z_planes=(zlo, zhi),
     )
 
 

@@ -24,6 +24,21 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
     if transport == "rccl":
         assert world == 1
         eng.comm_init(rank, world, capi.comm_unique_id())
+    elif transport == "rccldup":      # dry run of the RCCL path with several ranks on ONE device: RCCL must refuse, the engine must report it (no hang)
+        import time
+        idf = out + ".id"
+        if rank == 0:
+            open(idf + ".tmp", "wb").write(capi.comm_unique_id()); os.replace(idf + ".tmp", idf)
+        t0 = time.time()
+        while not os.path.exists(idf) and time.time() - t0 < 60:
+            time.sleep(0.05)
+        try:
+            eng.comm_init(rank, world, open(idf, "rb").read())
+        except capi.PsgsdfError as ex:
+            print("COMM_ERROR", ex, flush=True)
+            sys.exit(3)
+        print("COMM_OK", flush=True)
+        sys.exit(0)
     else:
         import torch.distributed as dist
         from _gloo_transport import GlooTransport

@@ -57,3 +57,27 @@ def test_two_ranks_share_the_gpu(built):
     d = _one_json(outs[0][0])
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
     assert "cpu_baseline" not in d and d["config"]["collectives_per_step"] > 10
+
+
+def test_strong_scaling_mode_two_ranks_share_the_gpu(built):
+    """bench.py --strong: ONE volume cut into z-slabs of equal band count, every rank synthesising and uploading only its own planes
+    (psgsdf_plan_slab + psgsdf_upload_volume_slab); functional check with two ranks on GPU 0 through the gloo test transport"""
+    port = str(_port())
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, PSGSDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PSGSDF_FAULT_DUMP="120", GLOO_SOCKET_IFNAME="lo",
+                   RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--strong", "--steps", "3", "--warmup", "1", "--grid", "48", "--frames", "6", "--model", "SH2",
+                                       "--width", "160", "--height", "120"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
+    try:
+        outs = [p.communicate(timeout=150) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    d = _one_json(outs[0][0])
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    rows = d["config"]["band_rows_per_rank"]
+    assert len(rows) == 2 and min(rows) > 0 and max(rows) <= 1.35 * min(rows) and d["config"]["collectives_per_step"] > 10

@@ -125,3 +125,27 @@ def test_slab_local_upload(built, tmp_path, world):
         assert list(a["info"]) == list(b["info"])                       # same cuts, same row ranges, same halos
         assert np.array_equal(a["band"], b["band"]) and np.array_equal(a["e_total"], b["e_total"]) and np.array_equal(a["cg"], b["cg"])
         assert np.array_equal(a["dist"], b["dist"], equal_nan=True) and np.array_equal(a["rgb"], b["rgb"], equal_nan=True) and np.array_equal(a["poses"], b["poses"])
+
+
+def test_rccl_path_with_two_ranks_on_one_device_fails_cleanly(built, tmp_path):
+    """A dry run of the RCCL transport at N = 2 on the one-GPU box: both ranks load librccl, exchange the unique id and
+    call ncclCommInitRank for the SAME device.  RCCL refuses that; what matters here is that the bootstrap of two ranks completes and that the
+    refusal comes back through the C ABI as PSGSDF_ERR_COMM with RCCL's message on BOTH ranks within seconds -- no hang, no crash."""
+    import time
+    port = free_port(); out = str(tmp_path / "dup")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_SOCKET_IFNAME="lo")
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_slab_worker_gpu.py"), str(r), "2", str(port), "SH1", out, "1", "24", "rccldup", "iterate"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=150)
+            outs.append((p.returncode, o))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert time.time() - t0 < 150
+    for rc, o in outs:
+        assert rc == 3 and "COMM_ERROR" in o and "ncclCommInitRank" in o and "rc=-5" in o, o[-1500:]
