@@ -57,13 +57,13 @@ def algorithmic_bytes(kernel, S, n_obs, W, H, F, laplacian=False, pcg_passes=1.0
 
 
 def timed_optimize(make_engine, torch, dist, steps, warmup, before_timed=None, after_call=None):
-    """K = `steps` iterations of the product loop psgsdf_optimize, timed through its per-iteration callback.  The loop leaves on its own when
-    the energy stops falling (the reference's divergence exit, PsOptimizer.cpp:377-384; ~18 iterations on the headline scene), so the K steps
-    may span several calls, each on a FRESH context (psgsdf_optimize normalises the regulariser weights in place): the first call skips
-    `warmup` iterations, every later call its first one, and a segment runs from one callback to a later callback of the SAME call.  Every callback comes right after psgsdf_optimize has drained its stream for the
-    stop decision (the closing energy has just been read back), so its time stamp is a drained-device time stamp; the device is also
-    synchronised explicitly (+ barrier over the ranks) at the start of every segment and after its last callback.
-    Returns (elapsed seconds or None if the loop made no progress, records of the timed iterations)."""
+    """K = `steps` iterations of the product loop psgsdf_optimize, bracketed by device synchronisation (+ barrier over the ranks) on both sides.
+    The loop leaves on its own when the energy stops falling (the reference's divergence exit, PsOptimizer.cpp:377-384; ~18 iterations on the
+    headline scene), so: one UNTIMED call first (the warm-up: >= `warmup` iterations, and it tells how many iterations a call survives), then
+    as many timed calls as needed, each on a FRESH context (psgsdf_optimize normalises the regulariser weights in place), each skipping its
+    first iteration and ending ITSELF after its share of the K steps, before the divergence exit would.  The brackets are taken in a passive
+    record observer (psgsdf_set_record_observer), so the loop being timed is the callback-free one with its speculative start of the next
+    iteration.  Returns (elapsed seconds or None if the loop does not survive 3 iterations, records of the timed iterations, calls)."""
     import time as _t
 
     def sync():
@@ -72,39 +72,42 @@ def timed_optimize(make_engine, torch, dist, steps, warmup, before_timed=None, a
             dist.barrier()
             torch.cuda.synchronize()
 
-    elapsed, timed, calls, idle_calls = 0.0, [], 0, 0
-    while len(timed) < steps and idle_calls < 3:
-        skip = max(1, warmup) if calls == 0 else 1
-        need = steps - len(timed)
-        seg = {"t0": None, "t_last": None, "n": 0, "recs": []}
+    eng = make_engine()
+    recs0, _ = eng.optimize(capi.ALL, cap=warmup + steps + 8)
+    sync()
+    eng.close()
+    survive = len(recs0) - 1                      # records a call delivers before it ends on its own (the terminating iteration is not reported)
+    calls = 1
+    if survive < 3:
+        return None, recs0, calls
+    elapsed, timed = 0.0, []
+    while len(timed) < steps:
+        need = min(steps - len(timed), survive - 1)
+        seg = {"t0": None, "t1": None, "recs": []}
         eng = make_engine()
 
-        def on_iter(done, rec, seg=seg, skip=skip, need=need):
-            if done < skip:
-                return False
-            if done == skip:
-                if before_timed and calls == 0:
+        def on_record(done, rec, seg=seg, need=need, eng=eng):
+            if done == 1:
+                if before_timed and not timed:
                     before_timed(eng)
                 sync(); seg["t0"] = _t.perf_counter()
                 return False
-            seg["t_last"] = _t.perf_counter(); seg["n"] = done - skip; seg["recs"].append(rec)
-            if seg["n"] == need:
-                sync()
-                return True                   # abort the loop: the K timed steps are done
+            seg["recs"].append(rec)
+            if done == 1 + need:
+                sync(); seg["t1"] = _t.perf_counter()
+                return True                   # end the loop here: this call's share of the K timed steps is done
             return False
 
-        eng.optimize(capi.ALL, cap=warmup + steps + 8, on_iter=on_iter)
+        eng.set_record_observer(on_record)      # passive: psgsdf_optimize keeps its speculative start of the next iteration (no on_iter callback)
+        eng.optimize(capi.ALL, cap=warmup + steps + 8)
         sync()
         if after_call:
-            after_call(eng, calls)
+            after_call(eng, calls - 1)
         eng.close()
         calls += 1
-        if seg["n"] > 0:
-            elapsed += seg["t_last"] - seg["t0"]; timed += seg["recs"]; idle_calls = 0
-        else:
-            idle_calls += 1
-    if len(timed) < steps:
-        return None, timed, calls
+        if seg["t1"] is None:                   # the loop ended earlier than the untimed call did (cannot happen: same scene, same bits)
+            return None, timed, calls
+        elapsed += seg["t1"] - seg["t0"]; timed += seg["recs"]
     return elapsed, timed, calls
 
 
@@ -234,10 +237,10 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
         return float(tt.item())
     t_iter, t_opt = over_ranks(t_iter), over_ranks(t_opt)
 
-    loop = f"psgsdf_optimize ({opt_calls} call{'s' if opt_calls != 1 else ''})"
+    loop = f"psgsdf_optimize ({opt_calls - 1} timed call{'s' if opt_calls != 2 else ''} after one untimed)"
     if timing_iterate or t_opt is None:
         elapsed, recs = t_iter, recs_it
-        loop = "psgsdf_iterate" + ("" if timing_iterate else " (psgsdf_optimize made no progress on this scene)")
+        loop = "psgsdf_iterate" + ("" if timing_iterate else " (psgsdf_optimize does not survive 3 iterations on this scene)")
     else:
         elapsed, recs = t_opt, recs_opt
     cg_iters = float(np.mean([r["cg_iters"] for r in recs]))
@@ -310,7 +313,7 @@ def main():
         "dtype": "f32", "data": "synthetic (8-bit RGB keyframes)" if use_u8 else "synthetic",
         "config": {"workload": f"synthetic {args.width}x{args.height} RGB-D bumpy sphere, {args.grid}^3 grid, {args.model}, {args.frames} keyframes, "
                                "albedo+light+distance+pose blocks, Cauchy IRLS, Eikonal reg (config_skorates.json settings)",
-                   "loop": m["loop"] + ": stop decision (convergence / divergence test on the host) after every iteration; the K steps span as many calls as the divergence exit makes necessary",
+                   "loop": m["loop"] + ": stop decision (convergence / divergence test on the host) after every iteration; each timed call ends itself before the loop's own divergence exit would",
                    "band_voxels": int(S), "observations": int(n_obs), "pcg_iters_per_step": cg_iters,
                    "parallelism": "single GPU" if world == 1 else
                    (f"strong scaling: ONE {args.grid}^3 volume with {args.frames} keyframes cut into {world} z-slabs of equal band count (one per GPU; every rank synthesises and uploads only its own planes), native slab loop: RCCL halo exchange + all-reduce issued by the C++ host" if args.strong else

@@ -191,6 +191,13 @@ typedef int (*psgsdf_iter_cb)(void* user, int iter_done, const psgsdf_iter_stats
 int psgsdf_optimize(psgsdf_ctx* ctx, int flags, psgsdf_iter_stats* stats, int stats_cap,
                     int* n_done, int* result, psgsdf_iter_cb on_iter, void* user);
 
+/* A PASSIVE per-iteration observer for psgsdf_optimize (progress narration, timing): called like on_iter as soon as the record of an
+ * iteration is complete, but WITHOUT on_iter's guarantee that the context still holds the state of that iteration -- without an on_iter
+ * callback psgsdf_optimize starts the next iteration (albedo / light blocks, undoable) before the stop decision on the previous one has
+ * arrived.  The observer must not call into the context.  A non-zero return ends the loop on the iteration just reported (what the next
+ * iteration applied speculatively is undone first).  NULL removes it.  No reference counterpart. */
+int psgsdf_set_record_observer(psgsdf_ctx* ctx, psgsdf_iter_cb observer, void* user);
+
 /* Optimizer::subsampling (OptimizerAux.cpp:622-684): 2x refine of grid + band rebuild. */
 int psgsdf_upsample2x(psgsdf_ctx* ctx);
 
@@ -319,7 +326,7 @@ int psgsdf_debug_albedo_system(psgsdf_ctx* ctx, float* H, float* b);
  *   out[0] scalar read-backs validated against their check words      out[1] of those: not complete yet when the marker / status word
  *   the host waited for had already arrived (waited for; PSGSDF_MBOX_CHECK=0 takes them as they are: the round-2 behaviour)
  *   out[2] distance steps re-run on the per-pass kernels because the persistent solve could not get its workgroups co-resident
- *   out[3] reserved (0) */
+ *   out[3] 1e6 x iterations started speculatively (before the stop decision on the previous one) + those of them that were undone */
 int psgsdf_debug_sync_stats(psgsdf_ctx* ctx, int64_t out[4]);
 
 #ifdef __cplusplus

@@ -270,6 +270,16 @@ class Api:
         self._check(self._fn("optimize")(self.ctx, C.c_int(flags), arr, C.c_int(cap), C.byref(n), C.byref(res), cb, None), "optimize")
         return [arr[i].as_dict() for i in range(min(n.value, cap))], bool(res.value)
 
+    def set_record_observer(self, fn):
+        """fn(iterations_done, record_dict) -> truthy ends the loop; passive (psgsdf_set_record_observer): must not call into the engine"""
+        if fn is None:
+            self._observer = None
+            self._check(self._fn("set_record_observer")(self.ctx, None, None), "set_record_observer")
+            return
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(IterStats))
+        self._observer = CB(lambda user, done, rec: 1 if fn(done, rec.contents.as_dict()) else 0)
+        self._check(self._fn("set_record_observer")(self.ctx, self._observer, None), "set_record_observer")
+
     def upsample2x(self):
         self._check(self._fn("upsample2x")(self.ctx), "upsample2x")
 
@@ -415,7 +425,7 @@ class Api:
     def debug_sync_stats(self):
         out = (C.c_int64 * 4)()
         self._check(self._fn("debug_sync_stats")(self.ctx, out), "debug_sync_stats")
-        return dict(readbacks_checked=out[0], readbacks_late=out[1], persist_fallbacks=out[2])
+        return dict(readbacks_checked=out[0], readbacks_late=out[1], persist_fallbacks=out[2], speculative_starts=out[3] // 1000000, speculative_undos=out[3] % 1000000)
 
     def debug_rare_rows(self):
         r = C.c_int64(); w = C.c_int64()

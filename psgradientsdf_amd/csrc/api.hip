@@ -22,6 +22,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_PCG_POLL")) c->pcg_poll = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_MBOX_CHECK")) c->mbox_check = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FAULT_SOLVE")) c->fault_solve = atoi(e);
+    if (const char* e = getenv("PSGSDF_SPECULATE")) c->speculate = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FOLD_IN_NEXT")) c->fold_in_next = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FUSE_ALBEDO")) c->fuse_albedo = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FUSE_PCG_INIT")) c->fuse_pcg_init = atoi(e) != 0;
@@ -57,7 +58,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     free_dense(c);
-    hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->led_light);
+    hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->frames_undo); hipFree(c->led_light);
     hipFree(c->band_mem); hipFree(c->obs_mem); hipFree(c->stage);
     hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->frame_part); hipFree(c->frame_done); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->pcg_gran); hipFree(c->d_total);
     if (c->host_buf) hipHostFree(c->host_buf);
@@ -226,12 +227,13 @@ static int set_keyframes_impl(psgsdf_ctx* c, int n_frames, const int32_t* frame_
     if (n_frames > kMaxFramesLds) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d keyframes", kMaxFramesLds);
     if (rgb_u8 && ((size_t)n_frames * width * height >= ((size_t)1 << 30) || (size_t)n_frames * height >= ((size_t)1 << 24))) return fail(c, PSGSDF_ERR_UNSUPPORTED, "8-bit keyframes: at most 2^30 pixels and 2^24 image rows");
     HIPCHK(c, hipSetDevice(c->device));
-    hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->acc_frame);
-    c->frame_idx = nullptr; c->img = nullptr; c->img8 = nullptr; c->frames = nullptr; c->acc_frame = nullptr;
+    hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->frames_undo); hipFree(c->acc_frame);
+    c->frame_idx = nullptr; c->img = nullptr; c->img8 = nullptr; c->frames = nullptr; c->frames_undo = nullptr; c->acc_frame = nullptr;
     c->F = n_frames; c->cam.W = width; c->cam.H = height;
     const size_t npix = (size_t)n_frames * width * height;
     HIPCHK(c, hipMalloc(&c->frame_idx, sizeof(int) * n_frames));
     HIPCHK(c, hipMalloc(&c->frames, sizeof(FrameP) * n_frames));
+    HIPCHK(c, hipMalloc(&c->frames_undo, sizeof(FrameP) * n_frames + 16));
     c->acc_frame_n = (size_t)n_frames * 64;
     HIPCHK(c, hipMalloc(&c->acc_frame, sizeof(double) * c->acc_frame_n));
     HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
@@ -370,6 +372,12 @@ int psgsdf_optimize(psgsdf_ctx* c, int flags, psgsdf_iter_stats* stats, int stat
     if (c->reg_r != 0.f) { double er; if ((rc = albedo_reg_energy(c, &er))) return rc; L.E_r = (float)er; }   // PsOptimizer.cpp:279
     L.E_prev = total_energy(c, L.E, L.E_n, L.E_l, L.E_r);
     return run_loop(c, flags, L, c->set.max_it, true, stats, stats_cap, n_done, result, on_iter, user);
+}
+
+int psgsdf_set_record_observer(psgsdf_ctx* c, psgsdf_iter_cb observer, void* user) {
+    if (!c) return PSGSDF_ERR_ARG;
+    c->observer = observer; c->observer_user = user;
+    return PSGSDF_OK;
 }
 
 int psgsdf_upsample2x(psgsdf_ctx* c) {

@@ -170,7 +170,7 @@ int psgsdf_debug_albedo_system(psgsdf_ctx* c, float* H, float* b) {
 
 int psgsdf_debug_sync_stats(psgsdf_ctx* c, int64_t out[4]) {
     if (!c || !out) return PSGSDF_ERR_ARG;
-    out[0] = c->mbox_checked; out[1] = c->mbox_late; out[2] = c->persist_fallbacks; out[3] = 0;
+    out[0] = c->mbox_checked; out[1] = c->mbox_late; out[2] = c->persist_fallbacks; out[3] = c->spec_windows * 1000000LL + c->spec_undos;
     return PSGSDF_OK;
 }
 

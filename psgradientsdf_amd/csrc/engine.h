@@ -143,7 +143,7 @@ struct SweepArgs {
     double* pcg_gran; int pcg_gran_n;   // persistent solve: the tagged per-workgroup sums, zeroed by the assembly kernel when non-null
     int pcg_fuse_init;        // assembly kernel also initialises the PCG (x = 0, records of pass -1, |b|^2 partials): no k_cgf_init launch
     int pcg_init_blocks;      // workgroups that wrote the |b|^2 partials (0: the pass kernel's own grid)
-    int fuse_apply;           // albedo sweep: solve the voxel's diagonal system and apply the update in the same thread (no normal equations stored)
+    int fuse_apply;           // albedo sweep: solve the voxel's diagonal system and apply the update in the same thread (no normal equations stored); 2: and keep the old albedo for an undo
     const double* gate;       // speculative launch: the kernel does nothing unless *gate != 0 (nullptr = always run); see pcg_solve
     const double* ext;        // multi-rank PCG: the 7 globally reduced sums of the previous pass (|b|^2 in ext[0] for pass 0), else nullptr
 };
@@ -174,6 +174,7 @@ void launch_led_light_init(const SweepArgs& a, hipStream_t s);
 void launch_energy(const SweepArgs& a, hipStream_t s);
 void launch_sweep_albedo(const SweepArgs& a, hipStream_t s);
 void launch_apply_albedo(const SweepArgs& a, hipStream_t s);
+void launch_restore_albedo(const SweepArgs& a, hipStream_t s);   // undo of a speculative fused albedo update (fuse_apply == 2)
 int launch_sweep_light(const SweepArgs& a, hipStream_t s);    // both return the workgroups per frame they used (0: nothing was launched, the rows are untouched)
 int launch_sweep_pose(const SweepArgs& a, hipStream_t s);
 void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key, hipStream_t s);   // also sums the energy columns -> e_out (nullable; e_key: FoldReq)

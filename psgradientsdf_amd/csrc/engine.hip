@@ -64,24 +64,32 @@ int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs) {
 // Every deferred read-back is taken from the mailbox only when its values match their check words (device_common.h mbox_put): the marker of
 // flush() and the status word of the persistent solve say that the producing kernels have RUN, not that their words have reached host
 // memory -- a read-back that is still on its way (profiles/r03_notes.md section 1: the round-2 flake) is waited for, and counted.
-int deliver(psgsdf_ctx* c) {
-    for (Deferred& d : c->deferred) {
+bool readback_landed(const Deferred& d) {
+    const volatile double* v = d.src;
+    for (int i = 0; i < d.n; ++i) if ((dbits(v[i]) ^ dbits(v[d.n + i])) != d.key + (unsigned long long)i) return false;
+    return true;
+}
+int deliver_first(psgsdf_ctx* c, size_t count) {
+    count = std::min(count, c->deferred.size());
+    for (size_t e = 0; e < count; ++e) {
+        Deferred& d = c->deferred[e];
         if (d.key && c->mbox_check) {
-            const volatile double* v = d.src; const int n = d.n; const unsigned long long key = d.key;
-            auto whole = [v, n, key] { for (int i = 0; i < n; ++i) if ((dbits(v[i]) ^ dbits(v[n + i])) != key + (unsigned long long)i) return false; return true; };
             c->mbox_checked++;
-            if (!whole()) {
+            if (!readback_landed(d)) {
                 c->mbox_late++;
-                const int w = wait_mapped(c, whole, "read-back");
+                const Deferred* dp = &d;
+                const int w = wait_mapped(c, [dp] { return readback_landed(*dp); }, "read-back");
                 if (w < 0) return w;
-                if (w == 1) { HIPCHK(c, hipStreamSynchronize(c->stream)); if (!whole()) return fail(c, PSGSDF_ERR_DEVICE, "a scalar read-back never arrived (the kernel that owed it did not run)"); }
+                if (w == 1) { HIPCHK(c, hipStreamSynchronize(c->stream)); if (!readback_landed(d)) return fail(c, PSGSDF_ERR_DEVICE, "a scalar read-back never arrived (the kernel that owed it did not run)"); }
             }
         }
         d.consume(d.src);
     }
-    c->deferred.clear(); c->mbox_used = 0;
+    c->deferred.erase(c->deferred.begin(), c->deferred.begin() + (long)count);
+    if (c->deferred.empty()) c->mbox_used = 0;      // (slots are handed out again only when nothing is in flight)
     return 0;
 }
+int deliver(psgsdf_ctx* c) { return deliver_first(c, c->deferred.size()); }
 int mbox_reserve(psgsdf_ctx* c, int n, size_t* off, unsigned long long* key) {
     if (c->mbox_used + 2 * (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
     *off = c->mbox_used; c->mbox_used += 2 * (size_t)n;

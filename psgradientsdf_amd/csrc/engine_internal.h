@@ -88,6 +88,13 @@ struct psgsdf_ctx {
     std::vector<psge::Deferred> deferred;
     unsigned long long mbox_serial = 0;  // key generator of the read-back slots
     bool mbox_check = true;              // PSGSDF_MBOX_CHECK=0: take read-backs on the marker's / status word's say-so (round-2 behaviour; reproduces its flake)
+    // speculative start of an iteration (loop.hip run_loop): albedo / light updates applied before the stop decision of the previous iteration is
+    // known keep what they overwrite, so that the loop can still end on exactly the state the reference ends on
+    psgsdf_iter_cb observer = nullptr; void* observer_user = nullptr;   // psgsdf_set_record_observer
+    bool speculate = true;               // PSGSDF_SPECULATE=0: always wait for the decision first (round 2)
+    bool spec_undo = false, spec_albedo_saved = false, spec_light_saved = false;
+    FrameP* frames_undo = nullptr;       // device [F] + 3 floats (LED light)
+    long long spec_windows = 0, spec_undos = 0;
     int fault_solve = 0, solves_seen = 0;   // PSGSDF_FAULT_SOLVE=n: fault injection into the n-th persistent solve of this context
     long long persist_fallbacks = 0;     // distance steps re-run on the per-pass kernels after the persistent solve gave up (loop.hip)
     long long mbox_checked = 0, mbox_late = 0;   // read-backs validated / of those: not complete yet when the host was told everything had landed
@@ -188,6 +195,8 @@ inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l, fl
 int flush(psgsdf_ctx* c);
 int mbox_reserve(psgsdf_ctx* c, int n, size_t* off, unsigned long long* key);   // n values + n check words; flushes first if the mailbox is full
 int deliver(psgsdf_ctx* c);              // validate and consume every deferred read-back (the caller knows their producers have run)
+int deliver_first(psgsdf_ctx* c, size_t count);   // ... the first `count` of them
+bool readback_landed(const psge::Deferred& d);     // non-blocking: values and check words agree
 int read_parts(psgsdf_ctx* c, const int* slots, int n, double* out);
 int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs);
 int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<void(const double*)> consume);

@@ -248,7 +248,8 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
                 // without the albedo regulariser the system is diagonal: the sweep applies the update itself (may_apply = false: the caller
                 // has a stop decision pending on this sweep's input energy and nothing may be modified yet)
                 c->albedo_applied = may_apply && c->reg_r == 0.f && c->fuse_albedo;
-                a.fuse_apply = c->albedo_applied ? 1 : 0;
+                a.fuse_apply = c->albedo_applied ? (c->spec_undo ? 2 : 1) : 0;      // (2: speculative, the old albedo is kept for an undo)
+                if (c->albedo_applied && c->spec_undo) c->spec_albedo_saved = true;
                 take_fold(c, a, (1u << SC_ENERGY) | (1u << SC_NOBS) | (c->albedo_applied ? (1u << SC_ACCEPT) : 0u));
                 timed(c, "sweep_albedo", [&] { launch_sweep_albedo(a, c->stream); });
             }
@@ -314,6 +315,11 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
             break;
         }
         case PSGSDF_LIGHT:
+            if (c->spec_undo) {      // speculative light update: keep the frame records (and the LED light) it overwrites
+                HIPCHK(c, hipMemcpyAsync(c->frames_undo, c->frames, sizeof(FrameP) * c->F, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync((char*)c->frames_undo + sizeof(FrameP) * c->F, c->led_light, 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+                c->spec_light_saved = true;
+            }
             timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->frame_e_slot, c->frame_e_key, c->stream); });
             c->frame_e_slot = nullptr; c->frame_e_key = 0;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = led ? 1 : c->F;
@@ -413,6 +419,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
         done++;
         if (term) { if (result && r.converged) *result = 1; stop = true; return 0; }
         if (full && on_iter && on_iter(user, it + 1, &r)) stop = true;
+        if (full && c->observer && c->observer(c->observer_user, it + 1, &r)) stop = true;      // (passive: the state may be ahead of the record)
         return 0;
     };
     // per-iteration values that arrive through deferred read-backs (stable addresses: two alternating slots)
@@ -434,6 +441,52 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
     };
     Late* prev_late = nullptr;
     double* prev_close = nullptr;   // where the lazily delivered closing energy of `prev` will appear
+    // ---- speculative start of an iteration (psgsdf_optimize without a per-iteration callback).  The stop decision on
+    // iteration i needs the PS energy of its final state, which the FIRST sweep of iteration i+1 computes; waiting for it there leaves the GPU idle
+    // for the round trip (read-back -> host decision -> next launch) and forces the albedo update into a kernel of its own.  Instead the blocks
+    // whose updates can be undone cheaply -- albedo (the old values go to a spare plane) and light (F small records) -- are enqueued right away,
+    // updates included, and the decision is taken when the energy arrives, at the latest before the distance block.  If the loop ends there
+    // (once per optimisation) the saved albedo / light are put back: the state left behind is exactly the reference's.  A per-iteration
+    // callback (on_iter) must see the state of the iteration it is told about, so with a callback every iteration is closed first, as before.
+    const bool can_spec = full && !on_iter && c->speculate && !slab_mode(c) && c->reg_r == 0.f && !c->profiling;
+    c->spec_undo = false; c->spec_albedo_saved = false; c->spec_light_saved = false;
+    const double* close_src = nullptr;   // mailbox address of the closing energy's read-back while a speculation window is open
+    bool spec_open = false;
+    auto end_window = [&] { spec_open = false; close_src = nullptr; c->spec_undo = false; c->spec_albedo_saved = false; c->spec_light_saved = false; };
+    auto undo_window = [&]() -> int {   // the loop ends on iteration iter-1: take back what iteration `iter` has applied speculatively
+        if (c->spec_light_saved) {
+            HIPCHK(c, hipMemcpyAsync(c->frames, c->frames_undo, sizeof(FrameP) * c->F, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->led_light, (char*)c->frames_undo + sizeof(FrameP) * c->F, 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (c->spec_albedo_saved) { SweepArgs au = make_args(c, 0); launch_restore_albedo(au, c->stream); }
+        c->spec_undos++;
+        end_window();
+        return flush(c);                 // (read-backs of the abandoned iteration land in its scratch record)
+    };
+    // the closing energy of `prev` has been delivered: close the record, take the stop decision, undo if the loop ends
+    auto lazy_close = [&]() -> int {
+        apply_late(prev, *prev_late, -1);
+        close_iteration(c, L, &prev, prev_slot, (float)band_mean(c, *prev_close), full);
+        have_prev = false; prev_close = nullptr;
+        int rc = finalize(prev, iter - 1); if (rc) return rc;
+        if (spec_open) { if (stop) return undo_window(); end_window(); }
+        return 0;
+    };
+    // bring the closing energy of an open window in: non-blocking (only if it has landed) or blocking
+    auto window_poll = [&](bool block) -> int {
+        if (!spec_open || !have_prev || !prev_close) return 0;
+        if (std::isnan(*prev_close)) {
+            size_t idx = c->deferred.size();
+            for (size_t e = 0; e < c->deferred.size(); ++e) if (c->deferred[e].src == close_src) { idx = e; break; }
+            if (idx < c->deferred.size()) {
+                if (c->pending_fold.n && c->pending_fold.out == c->mbox_dev + (close_src - c->mbox)) { if (!block) return 0; materialize_fold(c); }   // (its fold is still waiting for a kernel to take it)
+                if (!block && !readback_landed(c->deferred[idx])) return 0;
+                int rc = deliver_first(c, idx + 1); if (rc) return rc;
+            }
+        }
+        if (std::isnan(*prev_close)) return block ? fail(c, PSGSDF_ERR_DEVICE, "the closing energy of iteration %d never arrived", iter - 1) : 0;
+        return lazy_close();
+    };
     while (iter < max_iters && !stop) {
         memset(&rec, 0, sizeof(rec));
         for (int q = 0; q < 4; ++q) rec.e_after[q] = NAN;
@@ -443,9 +496,11 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
             const int blk = order[q];
             if (!(flags & blk)) continue;
             psgsdf_step_stats st;
+            const bool undoable = (blk == PSGSDF_ALBEDO && !c->spec_albedo_saved && c->fuse_albedo) || (blk == PSGSDF_LIGHT && !c->spec_light_saved);
+            if (spec_open && !undoable) { int rc = window_poll(true); if (rc) return rc; if (stop) break; }   // the decision is due now (it arrived long ago: no bubble)
             const int qi = lt.n;
             lt.blk_of[qi] = blk; lt.e_in[qi] = NAN; lt.n++;
-            if (have_prev && full) {   // synchronous: this sweep's input energy closes the previous iteration (stop decision)
+            if (have_prev && full && !spec_open && !(can_spec && undoable)) {   // synchronous: this sweep's input energy closes the previous iteration (stop decision)
                 int rc = step_begin(c, blk, L.laplacian_reg, &st, nullptr, false); if (rc) return rc;   // (flushes every deferred read of the previous iteration)
                 lt.e_in[qi] = st.e_in;
                 apply_late(prev, *prev_late, -1);
@@ -457,30 +512,26 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
                     break;
                 }
             } else {
-                // no stop decision pending (psgsdf_iterate never exits early): even the closing energy of the previous
-                // iteration is delivered lazily, at the next host sync (the PCG status read of this iteration)
+                // no stop decision pending (psgsdf_iterate never exits early) or a speculation window: even the closing energy of the previous
+                // iteration is delivered lazily, at the next host sync (the PCG status read of this iteration) or when the window polls for it
+                if (have_prev && full && !spec_open) { spec_open = true; c->spec_undo = true; c->spec_albedo_saved = c->spec_light_saved = false; c->spec_windows++; }
                 double* slot_e = &lt.e_in[qi];
                 int rc = step_begin(c, blk, L.laplacian_reg, &st, [slot_e](double e_sum, double) { *slot_e = e_sum; }); if (rc) return rc;
-                if (have_prev && prev_close == nullptr) prev_close = slot_e;
+                if (have_prev && prev_close == nullptr) { prev_close = slot_e; if (spec_open && !c->deferred.empty()) close_src = c->deferred.back().src; }
             }
             int rc = step_finish(c, blk, L.laplacian_reg, &st, true); if (rc) return rc;
             if (blk == PSGSDF_ALBEDO && c->reg_r != 0.f) { double er; if ((rc = albedo_reg_energy(c, &er))) return rc; lt.alb_reg = true; lt.e_r = (float)er; }   // PsOptimizer.cpp:312 (enters L when the record closes)
             if (blk == PSGSDF_DIST) { lt.dist_ran = true; lt.cg_iters = st.cg_iters; }
-            if (have_prev && prev_close && !std::isnan(*prev_close)) {   // the lazy closing energy has arrived
-                apply_late(prev, *prev_late, -1);
-                close_iteration(c, L, &prev, prev_slot, (float)band_mean(c, *prev_close), full);
-                have_prev = false; prev_close = nullptr;
-                if ((rc = finalize(prev, iter - 1))) return rc;
-            }
+            if (spec_open) { if ((rc = window_poll(false))) return rc; }
+            else if (have_prev && prev_close && !std::isnan(*prev_close)) { if ((rc = lazy_close())) return rc; }   // the lazy closing energy has arrived
             pending = blk == PSGSDF_ALBEDO ? 0 : blk == PSGSDF_LIGHT ? 1 : blk == PSGSDF_DIST ? 2 : 3;
         }
+        if (!stop && spec_open) { int rc = window_poll(true); if (rc) return rc; }      // (an iteration of undoable blocks only)
         if (stop) break;
         if (have_prev && prev_close) {   // still open (no host sync happened during this iteration): force one
             int rc = flush(c); if (rc) return rc;
-            apply_late(prev, *prev_late, -1);
-            close_iteration(c, L, &prev, prev_slot, (float)band_mean(c, *prev_close), full);
-            have_prev = false; prev_close = nullptr;
-            if ((rc = finalize(prev, iter - 1))) return rc;
+            if ((rc = lazy_close())) return rc;
+            if (stop) break;
         }
         // deferred e_in values are raw sums (not yet divided by S) except the synchronous first one: normalise on use
         const bool last = iter + 1 >= max_iters;

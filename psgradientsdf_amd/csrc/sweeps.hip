@@ -124,6 +124,12 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
         }
         E = (double)Ef; nobs = (double)nobs_i;
         if (a.fuse_apply) {   // the system is diagonal and the voxel's albedo is read by this thread only: k_apply_albedo's arithmetic, here
+            // fuse_apply == 2: the update is SPECULATIVE (the host has not taken the stop decision this sweep's energy feeds yet, loop.hip): the old
+            // albedo goes to the (otherwise unused) aH planes, from where k_restore_albedo puts it back if the loop ends here
+            if (a.fuse_apply == 2) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) b.aH[(size_t)ch * b.Spad + j] = v.rho[ch];
+            }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 float h = Hd[ch];
@@ -164,6 +170,17 @@ __global__ void __launch_bounds__(kBlock) k_apply_albedo(SweepArgs a) {
         }
     }
     block_part_store(cnt, PART(a, SC_ACCEPT), red);
+}
+// undo of a speculative fused albedo update (k_sweep_albedo, fuse_apply == 2): the saved albedo back into rho and its packed mirror
+__global__ void __launch_bounds__(kBlock) k_restore_albedo(SweepArgs a) {
+    const Band& b = a.b;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.row1) return;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) set_rho(b, j, ch, b.aH[(size_t)ch * b.Spad + j]);
+}
+void launch_restore_albedo(const SweepArgs& a, hipStream_t s) {
+    if (a.row1 > a.row0) hipLaunchKernelGGL(k_restore_albedo, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
 }
 void launch_apply_albedo(const SweepArgs& a, hipStream_t s) {
     if (a.row1 > a.row0) hipLaunchKernelGGL(k_apply_albedo, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
