@@ -69,14 +69,14 @@ bool readback_landed(const Deferred& d) {
     for (int i = 0; i < d.n; ++i) if ((dbits(v[i]) ^ dbits(v[d.n + i])) != d.key + (unsigned long long)i) return false;
     return true;
 }
-int deliver_first(psgsdf_ctx* c, size_t count) {
+int deliver_first(psgsdf_ctx* c, size_t count, bool told_landed) {
     count = std::min(count, c->deferred.size());
     for (size_t e = 0; e < count; ++e) {
         Deferred& d = c->deferred[e];
         if (d.key && c->mbox_check) {
             c->mbox_checked++;
             if (!readback_landed(d)) {
-                c->mbox_late++;
+                if (told_landed) c->mbox_late++;      // (a speculation window WAITS here for its closing energy: not an event)
                 const Deferred* dp = &d;
                 const int w = wait_mapped(c, [dp] { return readback_landed(*dp); }, "read-back");
                 if (w < 0) return w;
@@ -89,7 +89,7 @@ int deliver_first(psgsdf_ctx* c, size_t count) {
     if (c->deferred.empty()) c->mbox_used = 0;      // (slots are handed out again only when nothing is in flight)
     return 0;
 }
-int deliver(psgsdf_ctx* c) { return deliver_first(c, c->deferred.size()); }
+int deliver(psgsdf_ctx* c) { return deliver_first(c, c->deferred.size(), true); }
 int mbox_reserve(psgsdf_ctx* c, int n, size_t* off, unsigned long long* key) {
     if (c->mbox_used + 2 * (size_t)n > c->mbox_n) { int rc = flush(c); if (rc) return rc; }
     *off = c->mbox_used; c->mbox_used += 2 * (size_t)n;

@@ -195,7 +195,7 @@ inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l, fl
 int flush(psgsdf_ctx* c);
 int mbox_reserve(psgsdf_ctx* c, int n, size_t* off, unsigned long long* key);   // n values + n check words; flushes first if the mailbox is full
 int deliver(psgsdf_ctx* c);              // validate and consume every deferred read-back (the caller knows their producers have run)
-int deliver_first(psgsdf_ctx* c, size_t count);   // ... the first `count` of them
+int deliver_first(psgsdf_ctx* c, size_t count, bool told_landed);   // ... the first `count` of them (told_landed: a marker / status word said they had arrived -- a wait is then counted as a late read-back)
 bool readback_landed(const psge::Deferred& d);     // non-blocking: values and check words agree
 int read_parts(psgsdf_ctx* c, const int* slots, int n, double* out);
 int read_frame_energy(psgsdf_ctx* c, int col_e, double* E, double* nobs);

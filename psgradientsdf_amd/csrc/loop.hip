@@ -481,7 +481,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
             if (idx < c->deferred.size()) {
                 if (c->pending_fold.n && c->pending_fold.out == c->mbox_dev + (close_src - c->mbox)) { if (!block) return 0; materialize_fold(c); }   // (its fold is still waiting for a kernel to take it)
                 if (!block && !readback_landed(c->deferred[idx])) return 0;
-                int rc = deliver_first(c, idx + 1); if (rc) return rc;
+                int rc = deliver_first(c, idx + 1, false); if (rc) return rc;
             }
         }
         if (std::isnan(*prev_close)) return block ? fail(c, PSGSDF_ERR_DEVICE, "the closing energy of iteration %d never arrived", iter - 1) : 0;
