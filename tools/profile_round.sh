@@ -5,11 +5,11 @@ set -u
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag; mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/trace -o kt -- python bench.py --no-cpu-baseline > $out/bench_traced.json 2> $out/trace.err
+rocprofv3 --kernel-trace --stats -d $out/trace -o kt -- python bench.py --no-cpu-baseline --no-extra > $out/bench_traced.json 2> $out/trace.err
 python tools/rocpd_stats.py $out/trace/kt_results.db > $out/kernel_stats.md 2>> $out/trace.err
 python tools/gap_stats.py $out/trace/kt_results.db > $out/gaps.txt 2>> $out/trace.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-breakdown > $out/pmc_$c.json 2> $out/pmc_$c.err
+  rocprofv3 --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-breakdown --no-extra > $out/pmc_$c.json 2> $out/pmc_$c.err
 done
 f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools/pmc_summary.py "$f" "$w" > $out/pmc_summary.json
