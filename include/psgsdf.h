@@ -326,8 +326,9 @@ int psgsdf_debug_albedo_system(psgsdf_ctx* ctx, float* H, float* b);
  *   out[0] scalar read-backs validated against their check words      out[1] of those: not complete yet when the marker / status word
  *   the host waited for had already arrived (waited for; PSGSDF_MBOX_CHECK=0 takes them as they are: the round-2 behaviour)
  *   out[2] distance steps re-run on the per-pass kernels because the persistent solve could not get its workgroups co-resident
- *   out[3] 1e6 x iterations started speculatively (before the stop decision on the previous one) + those of them that were undone */
-int psgsdf_debug_sync_stats(psgsdf_ctx* ctx, int64_t out[4]);
+ *   out[3] 1e6 x iterations started speculatively (before the stop decision on the previous one) + those of them that were undone
+ *   out[4] 1 if this (multi-rank) context holds the cross-rank mappings of the persistent solve, out[5] distance solves run through it, out[6..7] 0 */
+int psgsdf_debug_sync_stats(psgsdf_ctx* ctx, int64_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -423,9 +423,10 @@ class Api:
         return ms.value, (shape[0], shape[1]), [x for x in st]
 
     def debug_sync_stats(self):
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 8)()
         self._check(self._fn("debug_sync_stats")(self.ctx, out), "debug_sync_stats")
-        return dict(readbacks_checked=out[0], readbacks_late=out[1], persist_fallbacks=out[2], speculative_starts=out[3] // 1000000, speculative_undos=out[3] % 1000000)
+        return dict(readbacks_checked=out[0], readbacks_late=out[1], persist_fallbacks=out[2], speculative_starts=out[3] // 1000000, speculative_undos=out[3] % 1000000,
+                    cross_rank_ready=out[4], cross_rank_solves=out[5])
 
     def debug_rare_rows(self):
         r = C.c_int64(); w = C.c_int64()

@@ -39,7 +39,17 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     g.vs = grid->voxel_size; g.vs_inv = 1.f / g.vs; g.T = grid->truncation;
     for (int a = 0; a < 3; ++a) g.origin[a] = c->shift[a] - (float)(0.5 * (double)g.vs) * (float)g.dim[a];   // VoxelGrid.h:130
     c->cam.fx = K[0]; c->cam.fy = K[4]; c->cam.cx = K[2]; c->cam.cy = K[5];
-    bool ok = hipStreamCreate(&c->stream) == hipSuccess
+    if (const char* e = getenv("PSGSDF_XR")) c->xr_enable = atoi(e) != 0;
+    bool stream_ok;
+    if (const char* e = getenv("PSGSDF_CU_MASK")) {      // "lo:hi": the context's stream runs on CUs [lo, hi) only -- two ranks sharing ONE GPU with half the CUs each (tests of the cross-rank persistent solve)
+        int lo = 0, hi = 0;
+        if (sscanf(e, "%d:%d", &lo, &hi) != 2 || lo < 0 || hi <= lo || hi > c->num_cu) { delete c; return PSGSDF_ERR_ARG; }
+        std::vector<uint32_t> mask((size_t)(c->num_cu + 31) / 32, 0u);
+        for (int i = lo; i < hi; ++i) mask[i / 32] |= 1u << (i % 32);
+        stream_ok = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+        c->cu_mask_lo = lo; c->cu_mask_hi = hi; c->num_cu = hi - lo;
+    } else stream_ok = hipStreamCreate(&c->stream) == hipSuccess;
+    bool ok = stream_ok
         && hipMalloc(&c->pcg_sc, sizeof(double) * (16 + 8 * (size_t)kPcgMaxBlocks)) == hipSuccess   // fs[0..1] + stage stamps of the timing hook
         && hipMalloc(&c->pcg_part, sizeof(double) * 14 * kPcgMaxBlocks) == hipSuccess
         && hipMalloc(&c->pcg_gran, sizeof(double) * 2 * kSolveGranPlanes * kSolveMaxBlocksHost) == hipSuccess
@@ -65,6 +75,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    xr_release(c); hipFree(c->xr);
     comm_destroy(c);
     hipFree(c->areg_mem); hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mbox_shadow); hipFree(c->d_need);
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);

@@ -12,6 +12,7 @@
 #include "engine_internal.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>   // types and enum values only: every function is resolved with dlsym
 
 namespace psge {
@@ -145,6 +146,103 @@ int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
     const ncclResult_t end = r->GroupEnd();
     if (first != ncclSuccess) return fail(c, PSGSDF_ERR_COMM, "halo exchange (ncclSend / ncclRecv): %s", r->GetErrorString ? r->GetErrorString(first) : "rccl error");
     NCCLCHK(c, end);
+    return 0;
+}
+
+
+// ---- cross-rank persistent solve: IPC mappings ---------------------------------------------------------------------------------------
+// Every rank exports (a) its small mailbox region and (b) its band arena (the neighbours write the records of their cut-side rows into its halo rows);
+// the handles and a few numbers travel through ONE all-reduce in which every rank fills its own slice (bytes as doubles, zeros elsewhere), so the
+// exchange works over RCCL and over a caller-supplied transport alike.  All ranks agree on the outcome with a second all-reduce: either every rank
+// runs the cross-rank persistent solve or every rank stays on the per-pass kernels.
+void xr_release(psgsdf_ctx* c) {
+    for (void* p : c->xr_opened) hipIpcCloseMemHandle(p);
+    c->xr_opened.clear(); c->xr_peer.clear(); c->band_peer[0] = c->band_peer[1] = nullptr; c->xr_ready = false; c->xr_args = XrArgs{};
+}
+int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
+    xr_release(c);
+    const int R = c->n_ranks, me = c->rank;
+    if (R <= 1 || !c->comm || !c->xr_enable || !c->pcg_persist || !c->pcg_fuse_asm || R > kXrMaxRanks) return 0;
+    if (!c->xr) { HIPCHK(c, hipMalloc(&c->xr, sizeof(double) * kXrDoubles)); HIPCHK(c, hipMemsetAsync(c->xr, 0, sizeof(double) * kXrDoubles, c->stream)); }
+    constexpr int kSlice = 64 + 64 + 8;      // two IPC handles (64 bytes each, one double per byte) + {rec[0] offset, rec[1] offset, pid, ok}
+    std::vector<double> buf((size_t)R * kSlice, 0.0);
+    hipIpcMemHandle_t hx{}, hb{};
+    int Gs, Rs;
+    bool ok = cgf_solve_shape(c, &Gs, &Rs, true)      // (this slab fits the persistent kernel at all)
+        && hipIpcGetMemHandle(&hx, c->xr) == hipSuccess && hipIpcGetMemHandle(&hb, c->band_mem) == hipSuccess;
+    (void)hipGetLastError();
+    double* mine = buf.data() + (size_t)me * kSlice;
+    for (int i = 0; i < 64; ++i) { mine[i] = (double)((unsigned char*)&hx)[i]; mine[64 + i] = (double)((unsigned char*)&hb)[i]; }
+    mine[128] = (double)((char*)c->band.rec[0] - (char*)c->band_mem); mine[129] = (double)((char*)c->band.rec[1] - (char*)c->band_mem);
+    mine[130] = (double)getpid(); mine[131] = ok ? 1.0 : 0.0;
+    double* d_buf = nullptr;
+    HIPCHK(c, hipMalloc(&d_buf, sizeof(double) * buf.size()));
+    int rc = 0;
+    if (hipMemcpyAsync(d_buf, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "cross-rank set-up: upload");
+    if (!rc) rc = comm_allreduce(c, d_buf, (int)buf.size());
+    if (!rc && (hipMemcpyAsync(buf.data(), d_buf, sizeof(double) * buf.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) rc = fail(c, PSGSDF_ERR_DEVICE, "cross-rank set-up: download");
+    if (rc) { hipFree(d_buf); return rc; }
+    // map every rank's region, and the two neighbours' band arenas
+    c->xr_peer.assign(R, nullptr); c->xr_peer[me] = c->xr;
+    auto open = [&](const double* bytes) -> void* {
+        hipIpcMemHandle_t h; for (int i = 0; i < 64; ++i) ((unsigned char*)&h)[i] = (unsigned char)bytes[i];
+        void* p = nullptr;
+        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        c->xr_opened.push_back(p);
+        return p;
+    };
+    for (int r = 0; r < R && ok; ++r) {
+        const double* sl = buf.data() + (size_t)r * kSlice;
+        if (sl[131] != 1.0) { ok = false; break; }
+        if (r == me) continue;
+        if (sl[130] == (double)getpid()) { ok = false; break; }      // two ranks in ONE process: no IPC between them (the per-pass path serves that case)
+        c->xr_peer[r] = (double*)open(sl);
+        if (!c->xr_peer[r]) { ok = false; break; }
+        if (r == me - 1 || r == me + 1) { c->band_peer[r == me - 1 ? 0 : 1] = open(sl + 64); if (!c->band_peer[r == me - 1 ? 0 : 1]) { ok = false; break; } }
+    }
+    // the launch shapes of the neighbours (a function of their own row count and the CU count, the same on every rank): how many of their
+    // workgroups own rows this slab holds as halo = how many tags its cut-side workgroups wait for
+    auto shape_of = [&](int own, int* G, int* per) {
+        const int cap = std::min(c->num_cu, kSolveMaxBlocksHost);
+        int g = std::min(cap, (own + kSolveThreadsHost - 1) / kSolveThreadsHost); g = std::max(8, g / 8 * 8); if (g > cap) g = cap;
+        *G = g; *per = ((own + g - 1) / g + 63) / 64 * 64;
+    };
+    XrArgs x{}; x.rank = me; x.n_ranks = R;
+    x.need_lo = c->need[0]; x.need_hi = c->need[1]; x.give_lo = c->give[0]; x.give_hi = c->give[1];
+    if (ok) {
+        for (int r = 0; r < R; ++r) x.region[r] = c->xr_peer[r];
+        if (me > 0) {
+            const double* sl = buf.data() + (size_t)(me - 1) * kSlice;
+            const int own_p = (int)info[3 * (me - 1) + 2], need_lo_p = (int)info[3 * (me - 1)];
+            // its upper halo rows start at its row1 = need_lo_p + own_p (local band order: lower halo, own rows, upper halo)
+            for (int q = 0; q < 2; ++q) x.lo_rec[q] = (float4*)((char*)c->band_peer[0] + (size_t)sl[128 + q]) + (need_lo_p + own_p);
+            int G, per; shape_of(own_p, &G, &per);
+            const int first = std::max(0, own_p - c->need[0]) / per, last = (own_p - 1) / per;      // its workgroups that own its last need_lo(me) rows
+            x.wait_lo = c->need[0] > 0 ? last - first + 1 : 0;
+        }
+        if (me < R - 1) {
+            const double* sl = buf.data() + (size_t)(me + 1) * kSlice;
+            const int own_p = (int)info[3 * (me + 1) + 2];
+            for (int q = 0; q < 2; ++q) x.hi_rec[q] = (float4*)((char*)c->band_peer[1] + (size_t)sl[128 + q]);      // its lower halo rows are its first rows
+            int G, per; shape_of(own_p, &G, &per);
+            x.wait_hi = c->need[1] > 0 ? std::min(own_p, c->need[1]) > 0 ? (std::min(own_p, c->need[1]) - 1) / per + 1 : 0 : 0;
+        }
+        if (x.wait_lo > kXrPeerTags || x.wait_hi > kXrPeerTags) ok = false;
+        // (this rank's own cut-side workgroups must fit the neighbours' tag slots too: the same formula on their side)
+        int G, per; shape_of(c->row1 - c->row0, &G, &per);
+        if (c->give[0] > 0 && (c->give[0] - 1) / per + 1 > kXrPeerTags) ok = false;
+        if (c->give[1] > 0 && (c->row1 - c->row0 - 1) / per - std::max(0, c->row1 - c->row0 - c->give[1]) / per + 1 > kXrPeerTags) ok = false;
+    }
+    // agreement: every rank or none
+    double flag = ok ? 1.0 : 0.0;
+    rc = 0;
+    if (hipMemcpyAsync(d_buf, &flag, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "cross-rank set-up: flag");
+    if (!rc) rc = comm_allreduce(c, d_buf, 1);
+    if (!rc && (hipMemcpyAsync(&flag, d_buf, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) rc = fail(c, PSGSDF_ERR_DEVICE, "cross-rank set-up: flag");
+    hipFree(d_buf);
+    if (rc) return rc;
+    if (flag != (double)R) { xr_release(c); return 0; }
+    c->xr_args = x; c->xr_ready = true;
     return 0;
 }
 

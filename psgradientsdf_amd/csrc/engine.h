@@ -141,11 +141,27 @@ struct SweepArgs {
     int pcg_asm;              // persistent solve assembles the distance system itself (no k_assemble launch in front of it)
     int pcg_apply;            // ... and applies the distance update itself (no k_apply_dist behind it): 1 = when finished, 2 = only on Success
     double* pcg_gran; int pcg_gran_n;   // persistent solve: the tagged per-workgroup sums, zeroed by the assembly kernel when non-null
+    double* xr_clear;         // multi-rank persistent solve: this rank's cross-rank mailbox region (kXrDoubles), zeroed together with pcg_gran
     int pcg_fuse_init;        // assembly kernel also initialises the PCG (x = 0, records of pass -1, |b|^2 partials): no k_cgf_init launch
     int pcg_init_blocks;      // workgroups that wrote the |b|^2 partials (0: the pass kernel's own grid)
     int fuse_apply;           // albedo sweep: solve the voxel's diagonal system and apply the update in the same thread (no normal equations stored); 2: and keep the old albedo for an undo
     const double* gate;       // speculative launch: the kernel does nothing unless *gate != 0 (nullptr = always run); see pcg_solve
     const double* ext;        // multi-rank PCG: the 7 globally reduced sums of the previous pass (|b|^2 in ext[0] for pass 0), else nullptr
+};
+
+// Cross-rank hand-offs of the persistent distance solve on a z-slab partition (pcg.hip k_cgf_solve<.., MR = true>, comm.hip xr_setup): every rank owns one
+// small mailbox region that ALL ranks can write (IPC-mapped over xGMI), and the records of the rows next to a cut are written straight into the
+// neighbour's halo rows.  Layout of a region, in doubles:
+constexpr int kXrMaxRanks = 32;      // rank-level sums: [2 buffers][8 planes][kXrMaxRanks] tagged granules (plane 7: |b|^2 with the sums of pass 0)
+constexpr int kXrPeerTags = 64;      // 'records are out' tags of the neighbour's workgroups next to the cut: [2 sides][3 buffers (2 pass parities + prologue)][kXrPeerTags]
+constexpr int kXrRankGran = 0, kXrPtag = 2 * 8 * kXrMaxRanks, kXrAbort = kXrPtag + 2 * 3 * kXrPeerTags, kXrDoubles = kXrAbort + 8;
+struct XrArgs {
+    int rank, n_ranks;               // n_ranks == 0: single-rank solve (every field below unused)
+    double* region[kXrMaxRanks];     // every rank's mailbox region (own included)
+    float4* lo_rec[2]; float4* hi_rec[2];   // where this slab's boundary records go: first upper-halo row of the lower neighbour / first lower-halo row of the upper one (per record buffer)
+    int give_lo, give_hi;            // own rows the lower / upper neighbour holds as halo (the first give_lo / last give_hi own rows)
+    int wait_lo, wait_hi;            // workgroups of the lower / upper neighbour whose tags this slab's cut-side workgroups wait for
+    int need_lo, need_hi;            // halo rows this slab gathers from
 };
 
 // ---- launchers implemented in the kernel files (all asynchronous on `s`) ----------------------
@@ -189,7 +205,7 @@ void launch_cgf_sum(double* part, int G, int k, double* out, hipStream_t s);
 constexpr int kSolveGranPlanes = 8;
 constexpr int kSolveThreadsHost = 512, kSolveMaxBlocksHost = 256, kSolveMaxRowsHost = 4, kSolveMbSlots = 24;      // {iters, |r|^2, |b|^2, status} + stage timestamps of the timing hook
 int cgf_solve_max_blocks(int rows);      // resident workgroups per CU of the R-rows instance (occupancy query)
-void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, hipStream_t s);   // mb[4] = check word over mb[0..3] (FoldReq)
+void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, hipStream_t s, const XrArgs* xr = nullptr);   // xr: multi-rank (z-slab) solve   // mb[4] = check word over mb[0..3] (FoldReq)
 // "reg albedo" path (albedo_reg.hip); every launch covers the whole band (single rank only)
 void launch_areg_tables(const DenseView& d, const GridP& g, const SweepArgs& a, hipStream_t s);
 void launch_areg_build(const SweepArgs& a, hipStream_t s);                       // J, res from the current albedo; sum of res -> SC_AUX0

@@ -41,7 +41,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
     a.acc.fpart = c->frame_part; a.acc.fcap = c->frame_cap; a.acc.fdone = c->frame_done;
     a.fold.n = 0; a.gate = nullptr; a.fuse_apply = 0;
-    a.pcg_part = c->pcg_part; a.pcg_fs = c->pcg_sc; a.pcg_fuse_init = 0; a.pcg_init_blocks = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.pcg_asm = 0; a.pcg_apply = 0;
+    a.pcg_part = c->pcg_part; a.pcg_fs = c->pcg_sc; a.pcg_fuse_init = 0; a.pcg_init_blocks = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.pcg_asm = 0; a.pcg_apply = 0; a.xr_clear = nullptr;
     a.ar = c->ar; a.ar.weight = c->reg_r;
     a.model = c->set.model; a.quirks = c->set.ref_quirks;
     a.reg_n = c->reg_n; a.reg_l = c->reg_l;
@@ -311,6 +311,7 @@ int build_band(psgsdf_ctx* c) {
             }
             // the stencil-direction bits of the halo rows are static and depend on the plane BEYOND the halo: take them from their owner
             int hrc = comm_halo(c, b.dirb, 1, 1); if (hrc) return hrc;
+            if ((hrc = xr_setup(c, info))) return hrc;      // cross-rank persistent solve: map the neighbours' halo rows and every rank's mailbox region
         } else c->S_global = S;
     }
     if (c->areg_mem) { hipFree(c->areg_mem); c->areg_mem = nullptr; c->ar = AlbedoReg{}; }

@@ -104,6 +104,16 @@ struct psgsdf_ctx {
     int rank = 0, n_ranks = 1;
     int row0 = 0, row1 = 0, halo = 0;
     psge::Comm* comm = nullptr;          // transport of the multi-rank exchanges (comm.hip); null on a single-rank context
+    // cross-rank persistent solve (comm.hip xr_setup, pcg.hip k_cgf_solve<.., MR>): this rank's mailbox region, every rank's region and the two
+    // neighbours' band arenas mapped through IPC handles; rebuilt with every band
+    bool xr_enable = true;               // PSGSDF_XR=0: multi-rank contexts always use the per-pass kernels + RCCL all-reduce (round 2)
+    bool xr_ready = false; long long xr_solves = 0;
+    double* xr = nullptr;
+    std::vector<double*> xr_peer;        // [n_ranks] (own entry = xr)
+    void* band_peer[2] = {nullptr, nullptr};   // lower / upper neighbour's band arena
+    std::vector<void*> xr_opened;        // IPC mappings to close
+    XrArgs xr_args{};
+    int cu_mask_lo = -1, cu_mask_hi = -1;      // PSGSDF_CU_MASK=lo:hi: the context's stream only uses CUs [lo, hi) (two ranks sharing one GPU)
     double* mg_scal = nullptr;           // [kMgScal] set-up exchange (what each slab needs of its neighbours)
     double* mg_ext = nullptr;            // [8] PCG: local sums of a pass out, globally reduced sums in
     // multi-rank: deferred scalar read-backs are folded into a DEVICE shadow of the mailbox; before the host waits on the mailbox the
@@ -181,6 +191,8 @@ int comm_create_ext(psgsdf_ctx* c, const psgsdf_comm_ops* ops, int rank, int n);
 void comm_destroy(psgsdf_ctx* c);
 int comm_allreduce(psgsdf_ctx* c, double* buf, int n);                 // in-place sum of n doubles (device), on the context's stream
 int comm_halo(psgsdf_ctx* c, void* base, int planes, int width);       // halo rows of `planes` band planes of `width` 4-byte words per row
+int xr_setup(psgsdf_ctx* c, const std::vector<double>& part_info);   // comm.hip: (re)build the cross-rank mappings for the band just built (part_info: {need_lo, need_hi, own rows} of every rank)
+void xr_release(psgsdf_ctx* c);
 int mg_commit(psgsdf_ctx* c);                                          // engine.hip: all-reduce + deliver the staged scalar read-backs
 int set_local_grid(psgsdf_ctx* c, int z0, int z1);                     // engine.hip: this context owns global planes [z0, z1) (+ halo planes)
 
@@ -215,7 +227,7 @@ int ps_energy(psgsdf_ctx* c, double* E, int64_t* nobs);
 // ---- loop.hip
 struct LoopState { float E, E_n, E_l, E_prev; int laplacian_reg; float E_r; };
 void cgf_shape(int nblk, int* G, int* rows);
-bool cgf_solve_shape(psgsdf_ctx* c, int* G, int* rows);      // can the whole solve run as ONE persistent kernel on this context?
+bool cgf_solve_shape(psgsdf_ctx* c, int* G, int* rows, bool any_ranks = false);      // can the whole solve run as ONE persistent kernel on this context? (any_ranks: the shape test alone, before the cross-rank mappings exist)
 int pcg_solve(psgsdf_ctx* c, SweepArgs& a, int* iters_out, int* success_out, double* err_out,
               const std::function<void(const double*)>& tail = nullptr, bool gate_on_converged = true, bool* tail_ran = nullptr);
 int albedo_reg_energy(psgsdf_ctx* c, double* Er);

@@ -25,8 +25,9 @@ void cgf_shape(int nblk, int* G, int* rows) {
 // Shape of the persistent solve (pcg.hip: k_cgf_solve): G workgroups of 512 threads, at most one per CU (all co-resident), the band dealt
 // evenly to them (<= 4 rows per thread).  One rank only -- a slab needs the other slabs' sums every pass,
 // which is the per-pass kernels' all-reduce -- and only with 16-bit column deltas and the assembly kernel's fused initialisation.
-bool cgf_solve_shape(psgsdf_ctx* c, int* G, int* rows_per_wg) {
-    if (!c->pcg_persist || c->n_ranks > 1 || !c->band.col16 || !c->fuse_pcg_init || c->num_cu <= 0 || band_blocks(c) > kPcgMaxBlocks) return false;
+bool cgf_solve_shape(psgsdf_ctx* c, int* G, int* rows_per_wg, bool any_ranks) {
+    // (multi-rank: only with the cross-rank mappings of comm.hip xr_setup in place -- all ranks or none, agreed there)
+    if (!c->pcg_persist || (c->n_ranks > 1 && !c->xr_ready && !any_ranks) || !c->band.col16 || !c->fuse_pcg_init || c->num_cu <= 0 || band_blocks(c) > kPcgMaxBlocks) return false;
     const int n = c->row1 - c->row0, cap = std::min(c->num_cu, kSolveMaxBlocksHost);
     if (n <= 0) return false;
     // as many workgroups as CUs (in multiples of 8: every XCD owns a contiguous range of rows) unless the band is so small that a workgroup
@@ -70,7 +71,9 @@ int pcg_solve(psgsdf_ctx* c, SweepArgs& a, int* iters_out, int* success_out, dou
         const unsigned long long key = (++c->mbox_serial << 8) | 0x80u;
         st[3] = NAN; st[4] = 0.0;
         const int inject = (c->fault_solve > 0 && ++c->solves_seen == c->fault_solve) ? -7 : 0;      // PSGSDF_FAULT_SOLVE=n: one workgroup of the n-th solve stops publishing (tests the fallback below)
-        timed(c, "pcg_solve", [&] { launch_cgf_solve(as, c->pcg_sc, c->pcg_gran, G, rows, cap, c->mbox_dev + off, key, inject, c->stream); });
+        const XrArgs* xr = (c->n_ranks > 1 && c->xr_ready && as.pcg_asm) ? &c->xr_args : nullptr;
+        if (xr) c->xr_solves++;
+        timed(c, "pcg_solve", [&] { launch_cgf_solve(as, c->pcg_sc, c->pcg_gran, G, rows, cap, c->mbox_dev + off, key, inject, c->stream, xr); });
         if (tail && !c->profiling) { tail(c->pcg_sc + (gate_on_converged ? 2 : 1)); if (tail_ran) *tail_ran = true; }
         // the four status words are taken only together with their check word (engine.h FoldReq)
         const bool chk = c->mbox_check;
@@ -255,7 +258,7 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
             }
             else {
                 materialize_fold(c);
-                { int Gs, Rs; if (c->pcg_fuse_asm && c->fuse_pcg_init && band_blocks(c) <= kPcgMaxBlocks && cgf_solve_shape(c, &Gs, &Rs)) { a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kSolveGranPlanes * kSolveMaxBlocksHost; a.pcg_asm = 1; } }   // the sweep clears the tags of the persistent solve behind it
+                { int Gs, Rs; if (c->pcg_fuse_asm && c->fuse_pcg_init && band_blocks(c) <= kPcgMaxBlocks && cgf_solve_shape(c, &Gs, &Rs)) { a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kSolveGranPlanes * kSolveMaxBlocksHost; a.pcg_asm = 1; a.xr_clear = c->xr_ready ? c->xr : nullptr; } }   // the sweep clears the tags of the persistent solve behind it (and this rank's cross-rank mailbox: the halo exchange of the voxel blocks that follows orders it before any neighbour's solve)
                 timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); });
             }   // (LED: the fused albedo sweep's sums are still pending and this sweep writes the same slots)
             const int slots[2] = {SC_ENERGY, SC_NOBS}; double s[2];

@@ -350,6 +350,11 @@ __device__ __forceinline__ void store16_sc1(float4* p, const float4& v) {
     const v4f_t d = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
 }
+// the same towards another GPU's memory (a neighbour slab's halo rows, IPC-mapped over xGMI): write-through at SYSTEM scope
+__device__ __forceinline__ void store16_sys(float4* p, const float4& v) {
+    const v4f_t d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(d) : "memory");
+}
 __device__ __forceinline__ double gran_tag(double v, unsigned tag) { return __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(v) & ~3ull) | tag)); }
 __device__ __forceinline__ unsigned gran_tag_of(double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) & 3ull); }
 
@@ -403,8 +408,15 @@ __device__ __forceinline__ void assemble_row_regs(const SweepArgs& a, int i, dou
     }
 }
 
-template <int R, bool ASM>
-__global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, double* fs, double* gran, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes) {
+// MR (multi-rank, z-slabs): the same kernel on every rank's slab, meeting the other ranks in two places.  (1) The records of the rows next to a cut
+// are ALSO written into the neighbour's halo rows (system-scope write-through stores through the IPC mapping), followed -- once the wave's stores
+// have drained -- by a tag in the neighbour's mailbox region; the neighbour's workgroups whose gathers reach across the cut wait for those tags
+// next to the tags of their local neighbours.  (2) The seven sums: every workgroup first obtains the rank's sums from the local all-gather exactly
+// as on one GPU; workgroup 0 then writes them as tagged granules into EVERY rank's region, and every workgroup sums the R rank granules of its
+// own region in rank order -- the same bits on every rank, one more hop per pass instead of a kernel boundary, a fold kernel and an RCCL
+// all-reduce (loop.hip: the per-pass path stays as the fallback and as the reference of the tests).
+template <int R, bool ASM, bool MR>
+__global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, double* fs, double* gran, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, XrArgs xr) {
     __shared__ double red[8 * kSolveThreads / 64];
     __shared__ int s_abort;
     const Band& b = a.b;
@@ -414,6 +426,22 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
     const int plane = b.Spad * 4;
     const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)b.H, 0, kNQ * plane, 0x00020000);
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)b.colp, 0, (kNQ - 1) / 2 * plane, 0x00020000);
+    // MR: which of this workgroup's rows the neighbours hold as halo, and whose tags it has to wait for
+    const int own_n = a.row1 - a.row0;
+    const int wg_first = lb * rows_per_wg, wg_last = min(own_n, wg_first + rows_per_wg) - 1;      // (relative to row0)
+    const bool cut_lo = MR && xr.give_lo > 0 && wg_first < xr.give_lo && wg_first < own_n;          // owns rows of the lower neighbour's upper halo
+    const bool cut_hi = MR && xr.give_hi > 0 && wg_last >= own_n - xr.give_hi && wg_first < own_n;
+    const int hi_first_wg = MR ? max(0, own_n - xr.give_hi) / rows_per_wg : 0;                      // first workgroup that owns such rows
+    double* const xr_me = MR ? xr.region[xr.rank] : nullptr;
+    // the neighbour's mailbox slots this workgroup tags: it is the (lb)-th cut-side workgroup towards the lower neighbour, the (lb - hi_first_wg)-th towards the upper one
+    auto peer_tag = [&](int buf, double v) {
+        if (cut_lo && lb < kXrPeerTags) __hip_atomic_store(xr.region[xr.rank - 1] + kXrPtag + (1 * 3 + buf) * kXrPeerTags + lb, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);              // (side 1 of the lower rank = tags of its UPPER neighbour)
+        if (cut_hi && lb - hi_first_wg < kXrPeerTags) __hip_atomic_store(xr.region[xr.rank + 1] + kXrPtag + (0 * 3 + buf) * kXrPeerTags + (lb - hi_first_wg), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    auto push_record = [&](int buf, int rel, const float4& rec) {      // rel = row - row0
+        if (MR && rel < xr.give_lo) store16_sys(xr.lo_rec[buf] + rel, rec);
+        if (MR && rel >= own_n - xr.give_hi) store16_sys(xr.hi_rec[buf] + (rel - (own_n - xr.give_hi)), rec);
+    };
     // ---- once: the rows of this thread.  The 19 coefficients of a row live in LDS ([row slot][column][thread]: conflict-free, R x 38 KB of
     // the CU's 160 KB), the 9 index words and the row's own state in registers.
     float* hs = (float*)psg_dyn_smem;
@@ -455,7 +483,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             const float inv = dg != 0.f ? 1.0f / dg : 1.0f;
             const float r = (float)rhs;
             me[u] = make_float4(r, 0.f, 0.f, inv);
-            if (live[u]) { store16_sc1(b.rec[1] + row[u], me[u]); bb_thread += (double)r * (double)r; }      // what pass 0 of the neighbours gathers
+            if (live[u]) { store16_sc1(b.rec[1] + row[u], me[u]); push_record(1, row[u] - a.row0, me[u]); bb_thread += (double)r * (double)r; }      // what pass 0 of the neighbours gathers
         } else {
 #pragma unroll
             for (int q = 0; q < kNQ; ++q) {
@@ -485,7 +513,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         // the records of this workgroup's rows are on their way: drained, then the flag the neighbours' pass 0 waits for (plane 7 of buffer 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + lb, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) { __hip_atomic_store(gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + lb, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR) peer_tag(2, 1.0); }
     }
     float rhsNorm2 = (float)bb;
     float thr = pcg_threshold(rhsNorm2);
@@ -521,9 +549,23 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
                     if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
                 }
             }
+            if (MR) {
+                // rows within `reach` of a cut gather from halo rows: wait for the tags the neighbour slab's cut-side workgroups wrote into this rank's
+                // region after their records had drained (threads 64.. / 128..: wavefronts 1 and 2, next to the local pollers in wavefront 0)
+                const bool need_lo = xr.need_lo > 0 && wg_first < b.reach, need_hi = xr.need_hi > 0 && wg_last + b.reach >= own_n;
+                const int side = tid >= 128 ? 1 : 0, j = tid - (side ? 128 : 64);      // (kXrPeerTags = 64 slots per side: threads 64..127 / 128..191)
+                if (tid >= 64 && tid < 192 && j < (side ? xr.wait_hi : xr.wait_lo) && (side ? need_hi : need_lo)) {
+                    int spins = 0;
+                    const double* wp = xr_me + kXrPtag + (side * 3 + (k > 0 ? ((k - 1) & 1) : 2)) * kXrPeerTags + j;
+                    while (k > 0 ? gran_tag_of(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != want : __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0.0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
+                    }
+                }
+            }
             __syncthreads();
-            if (s_abort) { if (tid == 0) __hip_atomic_store(fs + 3, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); status = 2; break; }
-            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (s_abort) { if (tid == 0) { __hip_atomic_store(fs + 3, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR) for (int r = 0; r < xr.n_ranks; ++r) __hip_atomic_store(xr.region[r] + kXrAbort, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } status = 2; break; }
+            if (tid == 0) { if (MR) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }      // (MR: system scope -- the halo records came from another GPU)
             __syncthreads();
         }
         SOLVE_STAMP(1);
@@ -585,17 +627,52 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             double t0, t1; wave_sum8(v, t0, t1);
             wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
             __syncthreads();
-            if (s_abort) { if (tid == 0) __hip_atomic_store(fs + 3, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); status = 2; break; }
+            if (s_abort) { if (tid == 0) { __hip_atomic_store(fs + 3, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR) for (int r = 0; r < xr.n_ranks; ++r) __hip_atomic_store(xr.region[r] + kXrAbort, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } status = 2; break; }
             double t[kCgfSums];
 #pragma unroll
             for (int q = 0; q < kCgfSums; ++q) { double s_ = 0; for (int i = 0; i < kSolveThreads / 64; ++i) s_ += red[q * (kSolveThreads / 64) + i]; t[q] = s_; }
             if (ASM && k == 1) {
                 bb = 0.0;
                 for (int i = 0; i < kSolveThreads / 64; ++i) bb += red[7 * (kSolveThreads / 64) + i];
+            }
+            __syncthreads();
+            if (MR) {
+                // ---- C2: the sums just obtained are this RANK's (every local workgroup holds the same bits).  Workgroup 0 hands them to every rank as tagged
+                // granules; every workgroup then adds the R granules of its own region in rank order (one fixed tree: the same bits on every rank).
+                const int pb = (k - 1) & 1;
+                if (lb == 0 && tid < 8 && (tid < kCgfSums || (ASM && k == 1))) {
+                    const double mine = gran_tag(tid < kCgfSums ? t[tid] : bb, want);
+                    for (int r = 0; r < xr.n_ranks; ++r) __hip_atomic_store(xr.region[r] + kXrRankGran + (pb * 8 + tid) * kXrMaxRanks + xr.rank, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                double rv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rv[q] = 0.0;
+                if (tid < xr.n_ranks) {
+                    int spins = 0; bool ok = false;
+                    while (!ok) {
+                        ok = true;
+#pragma unroll
+                        for (int q = 0; q < kCgfSums; ++q) { rv[q] = __hip_atomic_load(xr_me + kXrRankGran + (pb * 8 + q) * kXrMaxRanks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = ok && gran_tag_of(rv[q]) == want; }
+                        if (ASM && k == 1) { rv[7] = __hip_atomic_load(xr_me + kXrRankGran + (pb * 8 + 7) * kXrMaxRanks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = ok && gran_tag_of(rv[7]) == want; }
+                        if (!ok) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
+                        }
+                    }
+                }
+                double r0, r1; wave_sum8(rv, r0, r1);
+                wave_sum8_store<kSolveThreads / 64>(r0, r1, red, tid >> 6);
+                __syncthreads();
+                if (s_abort) { if (tid == 0) { __hip_atomic_store(fs + 3, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); for (int r = 0; r < xr.n_ranks; ++r) __hip_atomic_store(xr.region[r] + kXrAbort, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } status = 2; break; }
+#pragma unroll
+                for (int q = 0; q < kCgfSums; ++q) t[q] = red[q * (kSolveThreads / 64)];      // (all R <= 32 granules sit in wavefront 0)
+                if (ASM && k == 1) bb = red[7 * (kSolveThreads / 64)];
+                __syncthreads();
+            }
+            if (ASM && k == 1) {
                 rhsNorm2 = (float)bb; thr = pcg_threshold(rhsNorm2);
                 if (lb == 0 && tid == 0) fs[0] = bb;
             }
-            __syncthreads();
             const float rz_old = (float)t[5];
             alpha_prev = rz_old / (float)t[0];
             const double al = (double)alpha_prev;
@@ -624,6 +701,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             me[u] = make_float4(r_i, tt, p_i, me[u].w);
             if (live[u]) {
                 store16_sc1(rout + row[u], me[u]);
+                push_record(k & 1, row[u] - a.row0, me[u]);
                 const double rd = (double)r_i, td = (double)tt, iv = (double)me[u].w;
                 s[0] += (double)p_i * td; s[1] += iv * rd * td; s[2] += iv * td * td; s[3] += rd * td; s[4] += td * td;
                 s[5] += rd * (double)z_i; s[6] += rd * rd;
@@ -647,6 +725,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             double* gq = gran + (size_t)(k & 1) * kSolveGranPlanes * kSolveMaxBlocks + (size_t)tid * kSolveMaxBlocks + lb;
             __hip_atomic_store(gq, gran_tag(tot, (unsigned)(k + 1) & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (MR && tid == 64) peer_tag(k & 1, gran_tag(1.0, (unsigned)(k + 1) & 3u));      // (every wave drained its stores before the barrier above: the halo records are out)
         __syncthreads();
         SOLVE_STAMP(6);
         if (force_passes > 0 && k == 8 && tid == 0) fs[16 + lb] = (double)wall_clock64();                 // timing hook: when every workgroup published pass 8 ...
@@ -691,30 +770,32 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
     }
 }
 static size_t cgf_solve_lds(int rows) { return sizeof(float) * (size_t)rows * kNQ * kSolveThreads; }
-template <int R, bool ASM> static int cgf_solve_prepare() {      // > 64 KB of dynamic LDS has to be asked for, once per instance
+template <int R, bool ASM, bool MR> static int cgf_solve_prepare() {      // > 64 KB of dynamic LDS has to be asked for, once per instance
     static int per_cu = -1;
     if (per_cu >= 0) return per_cu;
     per_cu = 0;
-    if (hipFuncSetAttribute((const void*)k_cgf_solve<R, ASM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cgf_solve_lds(R)) != hipSuccess) return per_cu;
+    if (hipFuncSetAttribute((const void*)k_cgf_solve<R, ASM, MR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cgf_solve_lds(R)) != hipSuccess) return per_cu;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cgf_solve<R, ASM>, kSolveThreads, cgf_solve_lds(R)) == hipSuccess) per_cu = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cgf_solve<R, ASM, MR>, kSolveThreads, cgf_solve_lds(R)) == hipSuccess) per_cu = n;
     return per_cu;
 }
-template <int R> static int cgf_solve_prepare_both() { return std::min(cgf_solve_prepare<R, false>(), cgf_solve_prepare<R, true>()); }
+template <int R> static int cgf_solve_prepare_both() { return std::min(std::min(cgf_solve_prepare<R, false, false>(), cgf_solve_prepare<R, true, false>()), cgf_solve_prepare<R, true, true>()); }
 int cgf_solve_max_blocks(int rows) {
     return rows == 1 ? cgf_solve_prepare_both<1>() : rows == 2 ? cgf_solve_prepare_both<2>() : rows == 3 ? cgf_solve_prepare_both<3>() : cgf_solve_prepare_both<4>();
 }
 template <int R>
-static void launch_cgf_solve_r(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, hipStream_t s) {
-    if (a.pcg_asm) hipLaunchKernelGGL((k_cgf_solve<R, true>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes);
-    else hipLaunchKernelGGL((k_cgf_solve<R, false>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes);
+static void launch_cgf_solve_r(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, hipStream_t s, const XrArgs* xr) {
+    XrArgs none{};
+    if (xr && xr->n_ranks > 1 && a.pcg_asm) hipLaunchKernelGGL((k_cgf_solve<R, true, true>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, *xr);
+    else if (a.pcg_asm) hipLaunchKernelGGL((k_cgf_solve<R, true, false>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, none);
+    else hipLaunchKernelGGL((k_cgf_solve<R, false, false>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, none);
 }
-void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, hipStream_t s) {
+void launch_cgf_solve(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, hipStream_t s, const XrArgs* xr) {
     const int rows = (rows_per_wg + kSolveThreads - 1) / kSolveThreads;
-    if (rows == 1) launch_cgf_solve_r<1>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s);
-    else if (rows == 2) launch_cgf_solve_r<2>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s);
-    else if (rows == 3) launch_cgf_solve_r<3>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s);
-    else launch_cgf_solve_r<4>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s);
+    if (rows == 1) launch_cgf_solve_r<1>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s, xr);
+    else if (rows == 2) launch_cgf_solve_r<2>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s, xr);
+    else if (rows == 3) launch_cgf_solve_r<3>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s, xr);
+    else launch_cgf_solve_r<4>(a, fs, gran, G, rows_per_wg, kmax, mb, mb_key, force_passes, s, xr);
 }
 
 // multi-rank: fold the partials of pass k (k = -1: |b|^2 of the init) into out[0..6] for the host program's all-reduce

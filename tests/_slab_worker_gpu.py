@@ -17,6 +17,8 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
     from psgradientsdf_amd import capi, synth
     torch.cuda.set_device(0)
     model, _, opt = model.partition("+")
+    if os.environ.get("SLAB_CU_MASKS"):      # two ranks on ONE GPU with disjoint halves of its CUs (the cross-rank persistent solve needs both kernels resident)
+        os.environ["PSGSDF_CU_MASK"] = os.environ["SLAB_CU_MASKS"].split(",")[rank]
     sc = synth.make_scene(N=N, F=6, W=160, H=120, model=model)
     st = capi.default_settings(sc.model_id, **({"reg_weight_rho": 0.02} if opt == "reg" else {}))      # "+reg": the albedo regulariser ("reg albedo")
     eng = capi.load_engine(sc, sc.K, st, 0)
@@ -61,7 +63,7 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
     np.savez(out + f".rank{rank}.npz", dist=v["dist"], rgb=v["rgb"], grad=v["grad"], poses=eng.download_poses(), light=eng.download_light(),
              e_total=[r["e_total"] for r in recs], cg=[r["cg_iters"] for r in recs], e0=e0, band=eng.download_band(info["row1"] - info["row0"]),
              info=[info["row0"], info["row1"], info["halo"], info["S"], info["need_lo"], info["need_hi"], info["z0"], info["z1"], info["rows"]],
-             ncoll=eng.comm_stats(), dim=list(eng.info().dim), n_band=eng.info().n_band)
+             ncoll=eng.comm_stats(), dim=list(eng.info().dim), n_band=eng.info().n_band, xr=[eng.debug_sync_stats()[k] for k in ("cross_rank_ready", "cross_rank_solves", "persist_fallbacks")])
     eng.close()
     if tr is not None:
         dist.barrier(); dist.destroy_process_group()

@@ -46,12 +46,16 @@ def stitch(res, key):
     return out
 
 
-@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH2", 2, "gloo"), ("SH1+reg", 2, "gloo")])
+@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("SH1", 2, "gloo-xr0"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH2", 2, "gloo"),
+                                                   ("SH1+reg", 2, "gloo")])
 def test_native_slab_loop_matches_single_context(built, tmp_path, model, world, transport):
     N, n_iters = 40, 2
     # "rccl-perpass": the PCG as the multi-rank path runs it (one kernel, one fold and one RCCL all-reduce of 7 doubles per pass) -- a one-rank
     # communicator would otherwise use the persistent single-kernel solve, which needs no exchange
-    extra = {"PSGSDF_PCG_PERSIST": "0"} if transport == "rccl-perpass" else None
+    # "gloo-xr0": the multi-rank PCG of round 2 (per-pass kernels, one all-reduce of 7 doubles and one halo exchange per pass); without it the ranks
+    # run the CROSS-RANK PERSISTENT solve (pcg.hip k_cgf_solve<.., MR>: halo records pushed into the neighbour's band through IPC mappings, rank-level
+    # sums through every rank's mailbox region) -- here between two / three processes sharing the one GPU
+    extra = {"PSGSDF_PCG_PERSIST": "0"} if transport == "rccl-perpass" else {"PSGSDF_XR": "0"} if transport == "gloo-xr0" else None
     res = run_ranks(tmp_path, model, world, transport.split("-")[0], "iterate", N, n_iters, extra)
     # "+reg": with the albedo regulariser -- the matrix-free CG over 3S unknowns whose Jr / Jr^T stencils cross the cut (halo exchanges
     # of J, res, p and t; every dot product an all-reduce)
@@ -73,7 +77,14 @@ def test_native_slab_loop_matches_single_context(built, tmp_path, model, world, 
         if world > 1:
             assert halo > 0 and (need_lo > 0 or need_hi > 0)        # the sphere is cut through: stencils cross the cut, halos really move
             assert rows < 0.8 * S                                     # a rank holds its slab (+ halo planes), not the whole band
-            assert got["ncoll"] > (60 if opt == "reg" else 20)        # reg: four exchanges per CG iteration of the regularised albedo solve
+            xr_ready, xr_solves, fallbacks = (int(x) for x in got["xr"])
+            if transport == "gloo-xr0":
+                assert xr_ready == 0 and xr_solves == 0 and got["ncoll"] > 40     # ~2 exchanges per PCG pass
+            else:
+                assert xr_ready == 1 and xr_solves == n_iters and fallbacks == 0   # every distance solve ran as ONE kernel per rank
+                assert got["ncoll"] > (60 if opt == "reg" else 8)                   # reg: four exchanges per CG iteration of the regularised albedo solve
+                if opt != "reg":
+                    assert got["ncoll"] < 40                                       # ... and the per-pass collectives are gone
             held = ~np.isnan(got["dist"])
             assert held.sum() == (z1 - z0) * N * N and held[z0 * N * N:(z1 * N * N)].all()      # exactly its own planes came back
         else:
@@ -149,3 +160,22 @@ def test_rccl_path_with_two_ranks_on_one_device_fails_cleanly(built, tmp_path):
     assert time.time() - t0 < 150
     for rc, o in outs:
         assert rc == 3 and "COMM_ERROR" in o and "ncclCommInitRank" in o and "rc=-5" in o, o[-1500:]
+
+
+def test_cross_rank_persistent_solve_on_disjoint_cu_halves(built, tmp_path):
+    """the persistent distance solve ACROSS ranks, developed on the one-GPU box by giving each of two ranks half the CUs
+    (PSGSDF_CU_MASK -> hipExtStreamCreateWithCUMask), so that both persistent kernels are resident while they exchange halo records and rank sums
+    through IPC-mapped memory: 96^3, two iterations, against the single-context engine to 1e-4 voxel."""
+    N, n_iters = 96, 2
+    res = run_ranks(tmp_path, "SH1", 2, "gloo", "iterate", N, n_iters, {"SLAB_CU_MASKS": "0:128,128:256"})
+    sc = synth.make_scene(N=N, F=6, W=160, H=120, model="SH1")
+    ref = capi.load_engine(sc, sc.K, capi.default_settings(capi.SH1), 0); ref.load_scene(sc)
+    ref.init_albedo(); ref.normalize_weights()
+    recs = ref.iterate(capi.ALL, n_iters)
+    band = ref.download_band(); v = ref.download_volume(); vs = float(sc.voxel_size)
+    for got in res:
+        assert [int(x) for x in got["xr"]] == [1, n_iters, 0]
+        assert np.allclose(got["e_total"], [x["e_total"] for x in recs], rtol=5e-6)
+        assert np.all(np.abs(got["cg"] - np.array([x["cg_iters"] for x in recs])) <= 1)
+    d = stitch(res, "dist")
+    assert np.abs(d[band] - v["dist"][band]).max() <= 1e-4 * vs
