@@ -56,7 +56,7 @@ def test_two_ranks_share_the_gpu(built):
     assert outs[1][0].strip() == ""                     # only rank 0 prints
     d = _one_json(outs[0][0])
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
-    assert "cpu_baseline" not in d and d["config"]["collectives_per_step"] > 10
+    assert "cpu_baseline" not in d and d["config"]["collectives_per_step"] > 3      # (cross-rank persistent solve: no per-pass collectives; ~6 exchanges per iteration remain)
 
 
 def test_strong_scaling_mode_two_ranks_share_the_gpu(built):
@@ -80,4 +80,4 @@ def test_strong_scaling_mode_two_ranks_share_the_gpu(built):
     d = _one_json(outs[0][0])
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     rows = d["config"]["band_rows_per_rank"]
-    assert len(rows) == 2 and min(rows) > 0 and max(rows) <= 1.35 * min(rows) and d["config"]["collectives_per_step"] > 10
+    assert len(rows) == 2 and min(rows) > 0 and max(rows) <= 1.35 * min(rows) and d["config"]["collectives_per_step"] > 3
