@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
                     const double* wp = xr_me + kXrPtag + (side * 3 + (k > 0 ? ((k - 1) & 1) : 2)) * kXrPeerTags + j;
                     while (k > 0 ? gran_tag_of(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != want : __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0.0) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
+                        if (++spins > (1 << 24) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
                     }
                 }
             }
@@ -656,7 +656,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
                         if (ASM && k == 1) { rv[7] = __hip_atomic_load(xr_me + kXrRankGran + (pb * 8 + 7) * kXrMaxRanks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = ok && gran_tag_of(rv[7]) == want; }
                         if (!ok) {
                             __builtin_amdgcn_s_sleep(1);
-                            if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
+                            if (++spins > (1 << 24) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
                         }
                     }
                 }
