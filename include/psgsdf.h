@@ -198,6 +198,11 @@ int psgsdf_optimize(psgsdf_ctx* ctx, int flags, psgsdf_iter_stats* stats, int st
  * iteration applied speculatively is undone first).  NULL removes it.  No reference counterpart. */
 int psgsdf_set_record_observer(psgsdf_ctx* ctx, psgsdf_iter_cb observer, void* user);
 
+/* How often psgsdf_optimize's on_iter needs the EXACT state: with period p > 1 on_iter is only invoked for iterations with iter_done % p == 0
+ * (and for the one that ended with the 2x refinement) -- voxelPS writes its meshes / point clouds every 3rd iteration (PsOptimizer.cpp:419-423) --
+ * and the iterations in between are closed speculatively like a callback-free loop's; the record observer still sees every record.  Default 1. */
+int psgsdf_set_on_iter_period(psgsdf_ctx* ctx, int period);
+
 /* Optimizer::subsampling (OptimizerAux.cpp:622-684): 2x refine of grid + band rebuild. */
 int psgsdf_upsample2x(psgsdf_ctx* ctx);
 

@@ -391,6 +391,12 @@ int psgsdf_set_record_observer(psgsdf_ctx* c, psgsdf_iter_cb observer, void* use
     return PSGSDF_OK;
 }
 
+int psgsdf_set_on_iter_period(psgsdf_ctx* c, int period) {
+    if (!c || period < 1) return PSGSDF_ERR_ARG;
+    c->on_iter_period = period;
+    return PSGSDF_OK;
+}
+
 int psgsdf_upsample2x(psgsdf_ctx* c) {
     if (!c || !c->inited) return fail(c, PSGSDF_ERR_STATE, "init first");
     HIPCHK(c, hipSetDevice(c->device));

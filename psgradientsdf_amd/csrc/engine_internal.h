@@ -91,6 +91,7 @@ struct psgsdf_ctx {
     // speculative start of an iteration (loop.hip run_loop): albedo / light updates applied before the stop decision of the previous iteration is
     // known keep what they overwrite, so that the loop can still end on exactly the state the reference ends on
     psgsdf_iter_cb observer = nullptr; void* observer_user = nullptr;   // psgsdf_set_record_observer
+    int on_iter_period = 1;              // psgsdf_set_on_iter_period
     bool speculate = true;               // PSGSDF_SPECULATE=0: always wait for the decision first (round 2)
     bool spec_undo = false, spec_albedo_saved = false, spec_light_saved = false;
     FrameP* frames_undo = nullptr;       // device [F] + 3 floats (LED light)

@@ -421,8 +421,8 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
         if (stats && done < stats_cap) stats[done] = r;
         done++;
         if (term) { if (result && r.converged) *result = 1; stop = true; return 0; }
-        if (full && on_iter && on_iter(user, it + 1, &r)) stop = true;
         if (full && c->observer && c->observer(c->observer_user, it + 1, &r)) stop = true;      // (passive: the state may be ahead of the record)
+        if (!stop && full && on_iter && ((it + 1) % c->on_iter_period == 0 || r.upsampled) && on_iter(user, it + 1, &r)) stop = true;      // (the exact-state callback, when it is due: psgsdf_set_on_iter_period)
         return 0;
     };
     // per-iteration values that arrive through deferred read-backs (stable addresses: two alternating slots)
@@ -451,7 +451,8 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
     // updates included, and the decision is taken when the energy arrives, at the latest before the distance block.  If the loop ends there
     // (once per optimisation) the saved albedo / light are put back: the state left behind is exactly the reference's.  A per-iteration
     // callback (on_iter) must see the state of the iteration it is told about, so with a callback every iteration is closed first, as before.
-    const bool can_spec = full && !on_iter && c->speculate && !slab_mode(c) && c->reg_r == 0.f && !c->profiling;
+    const bool spec_base = full && c->speculate && !slab_mode(c) && c->reg_r == 0.f && !c->profiling;
+    auto can_spec_at = [&](int it_closing) { return spec_base && (!on_iter || (it_closing + 1) % c->on_iter_period != 0); };      // (a due on_iter must see the state of the iteration it reports)
     c->spec_undo = false; c->spec_albedo_saved = false; c->spec_light_saved = false;
     const double* close_src = nullptr;   // mailbox address of the closing energy's read-back while a speculation window is open
     bool spec_open = false;
@@ -503,7 +504,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
             if (spec_open && !undoable) { int rc = window_poll(true); if (rc) return rc; if (stop) break; }   // the decision is due now (it arrived long ago: no bubble)
             const int qi = lt.n;
             lt.blk_of[qi] = blk; lt.e_in[qi] = NAN; lt.n++;
-            if (have_prev && full && !spec_open && !(can_spec && undoable)) {   // synchronous: this sweep's input energy closes the previous iteration (stop decision)
+            if (have_prev && full && !spec_open && !(can_spec_at(iter - 1) && undoable)) {   // synchronous: this sweep's input energy closes the previous iteration (stop decision)
                 int rc = step_begin(c, blk, L.laplacian_reg, &st, nullptr, false); if (rc) return rc;   // (flushes every deferred read of the previous iteration)
                 lt.e_in[qi] = st.e_in;
                 apply_late(prev, *prev_late, -1);

@@ -195,8 +195,9 @@ protected:
                 *o << "PS energy: " << E << "\t normal reg energy: " << en << "\t laplacian reg energy: " << el << "\t rho reg energy: " << er
                    << "\t total energy: " << (float)(E + en + el + er) << std::endl;
     }
-    // the per-iteration narration of PsOptimizer.cpp:304-366 and the periodic dumps of :419-423
-    int on_iter(int iter_done, const psgsdf_iter_stats* r) {
+    // the per-iteration narration of PsOptimizer.cpp:304-366: needs the record only, so it runs as the engine's PASSIVE record observer
+    // (psgsdf_set_record_observer) and the loop may already be working on the next iteration while it prints
+    int narrate(int iter_done, const psgsdf_iter_stats* r) {
         const int iter = iter_done - 1;
         const bool led = settings_->model == LED;
         const char* names[4] = {"albedo", "light", "distance", "pose"};
@@ -210,6 +211,13 @@ protected:
         }
         std::cout << "===> [" << iter << "]: relative diff " << r->rel_diff << std::endl;
         if (doc_.is_open()) doc_ << "===> [" << iter << "]: relative diff " << r->rel_diff << "\n";
+        return 0;
+    }
+    static int narrate_trampoline(void* user, int iter_done, const psgsdf_iter_stats* rec) { return static_cast<Optimizer*>(user)->narrate(iter_done, rec); }
+    // the periodic dumps of PsOptimizer.cpp:397-398,419-423 read the STATE of the iteration: the exact-state callback, due every 3rd iteration
+    // (psgsdf_set_on_iter_period(3)) and after the 2x refinement; in between the loop closes its iterations speculatively
+    int on_iter(int iter_done, const psgsdf_iter_stats* r) {
+        const int iter = iter_done - 1;
         if (r->upsampled) {   // PsOptimizer.cpp:397-398
             save_pointcloud("upsample_after_" + std::to_string(iter));
             extract_mesh("upsample_after_" + std::to_string(iter));
@@ -288,11 +296,14 @@ public:
         int flags = (albedo ? PSGSDF_ALBEDO : 0) | (light ? PSGSDF_LIGHT : 0) | (distance ? PSGSDF_DIST : 0) | (pose ? PSGSDF_POSE : 0);
         std::vector<psgsdf_iter_stats> recs(settings_->max_it + 1);
         int n_done = 0, result = 0;
+        psgsdf_set_record_observer(ctx_, &Optimizer::narrate_trampoline, this);
+        psgsdf_set_on_iter_period(ctx_, 3);
         int rc = psgsdf_optimize(ctx_, flags, recs.data(), (int)recs.size(), &n_done, &result, &Optimizer::on_iter_trampoline, this);
+        psgsdf_set_record_observer(ctx_, nullptr, nullptr);
         if (rc) return fail("psgsdf_optimize", rc);
         if (n_done > 0 && (recs[n_done - 1].converged || recs[n_done - 1].diverged)) {
             const int iter = n_done - 1;
-            on_iter(n_done, &recs[n_done - 1]);   // the callback is not invoked for the terminating iteration
+            narrate(n_done, &recs[n_done - 1]); on_iter(n_done, &recs[n_done - 1]);   // neither is invoked for the terminating iteration
             std::cout << "===> [" << iter << "]: " << (result ? "converged!" : "diverged!") << std::endl;
             doc_ << "===> [" << iter << "]: " << (result ? "converged! \n" : "diverged!\n");
             save_pointcloud("final_refined");                      // PsOptimizer.cpp:372-373,379-380
