@@ -270,6 +270,9 @@ class Api:
         self._check(self._fn("optimize")(self.ctx, C.c_int(flags), arr, C.c_int(cap), C.byref(n), C.byref(res), cb, None), "optimize")
         return [arr[i].as_dict() for i in range(min(n.value, cap))], bool(res.value)
 
+    def set_on_iter_period(self, period):
+        self._check(self._fn("set_on_iter_period")(self.ctx, C.c_int(period)), "set_on_iter_period")
+
     def set_record_observer(self, fn):
         """fn(iterations_done, record_dict) -> truthy ends the loop; passive (psgsdf_set_record_observer): must not call into the engine"""
         if fn is None:

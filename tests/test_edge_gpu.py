@@ -204,3 +204,37 @@ def test_persistent_solve_falls_back_to_the_per_pass_kernels(built, name, mid, m
     assert np.quantile(d, 0.999) <= 1e-4 and d.max() <= 5e-3
     for a, b in zip(r_e, r_o):
         assert abs(a["e_total"] - b["e_total"]) <= 2e-4 * abs(b["e_total"])
+
+
+@pytest.mark.parametrize("name,mid", [("SH1", capi.SH1), ("LED", capi.LED)])
+def test_exact_state_callback_between_speculative_iterations(built, name, mid, monkeypatch):
+    """psgsdf_set_on_iter_period(3): `on_iter` -- the callback voxelPS writes its meshes from -- is invoked for every 3rd iteration only and must see exactly
+    the state of that iteration, although the iterations in between are closed speculatively (next iteration's albedo / light already applied when the stop
+    decision arrives).  Against a run that closes every iteration first (PSGSDF_SPECULATE=0, period 1): same records, same state at every due callback,
+    same final state; the passive observer sees every record."""
+    import hashlib
+    sc = synth.make_scene(N=40, F=6, W=160, H=120, model=name)
+    st = capi.default_settings(mid, max_it=9, conv_threshold=0.0)
+
+    def run(period, speculate):
+        monkeypatch.setenv("PSGSDF_SPECULATE", "1" if speculate else "0")
+        eng = capi.load_engine(sc, sc.K, st, 0); eng.load_scene(sc)
+        seen, observed = {}, []
+
+        def on_iter(done, rec):
+            v = eng.download_volume()
+            seen[done] = (hashlib.sha1(v["dist"].tobytes()).hexdigest(), hashlib.sha1(v["rgb"].tobytes()).hexdigest(), hashlib.sha1(eng.download_light().tobytes()).hexdigest())
+            return False
+        eng.set_on_iter_period(period)
+        eng.set_record_observer(lambda done, rec: observed.append(done) and False)
+        recs, _ = eng.optimize(capi.ALL, on_iter=on_iter)
+        v = eng.download_volume()
+        stats = eng.debug_sync_stats()
+        return recs, seen, observed, (hashlib.sha1(v["dist"].tobytes()).hexdigest(), hashlib.sha1(v["rgb"].tobytes()).hexdigest()), stats
+    r0, seen0, obs0, fin0, st0 = run(1, False)
+    r3, seen3, obs3, fin3, st3 = run(3, True)
+    assert len(r0) == len(r3) >= 4 and [r["e_total"] for r in r0] == [r["e_total"] for r in r3] and [r["e_after"] for r in r0] == [r["e_after"] for r in r3]
+    assert sorted(seen3) == [d for d in sorted(seen0) if d % 3 == 0] and len(seen3) >= 1
+    assert all(seen3[d] == seen0[d] for d in seen3)
+    assert fin0 == fin3 and obs0 == obs3 == sorted(seen0)
+    assert st0["speculative_starts"] == 0 and st3["speculative_starts"] >= 2
