@@ -193,7 +193,8 @@ void launch_apply_albedo(const SweepArgs& a, hipStream_t s);
 void launch_restore_albedo(const SweepArgs& a, hipStream_t s);   // undo of a speculative fused albedo update (fuse_apply == 2)
 int launch_sweep_light(const SweepArgs& a, hipStream_t s);    // both return the workgroups per frame they used (0: nothing was launched, the rows are untouched)
 int launch_sweep_pose(const SweepArgs& a, hipStream_t s);
-void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key, hipStream_t s);   // also sums the energy columns -> e_out (nullable; e_key: FoldReq)
+void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key, float* undo, hipStream_t s);
+void launch_restore_light(int F, FrameP* frames, float* led_light, const float* undo, hipStream_t s);   // undo of a speculative light update (undo: [F][9] + [3] floats)   // also sums the energy columns -> e_out (nullable; e_key: FoldReq)
 void launch_solve_pose(const SweepArgs& a, FrameP* frames, double* e_out, unsigned long long e_key, hipStream_t s);
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s);
 void launch_assemble(const SweepArgs& a, hipStream_t s);

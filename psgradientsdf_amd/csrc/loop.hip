@@ -318,12 +318,9 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
             break;
         }
         case PSGSDF_LIGHT:
-            if (c->spec_undo) {      // speculative light update: keep the frame records (and the LED light) it overwrites
-                HIPCHK(c, hipMemcpyAsync(c->frames_undo, c->frames, sizeof(FrameP) * c->F, hipMemcpyDeviceToDevice, c->stream));
-                HIPCHK(c, hipMemcpyAsync((char*)c->frames_undo + sizeof(FrameP) * c->F, c->led_light, 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-                c->spec_light_saved = true;
-            }
-            timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->frame_e_slot, c->frame_e_key, c->stream); });
+            // (a speculative light update keeps the coefficients it overwrites: the solve kernel copies them to frames_undo first)
+            timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->frame_e_slot, c->frame_e_key, c->spec_undo ? (float*)c->frames_undo : nullptr, c->stream); });
+            if (c->spec_undo) c->spec_light_saved = true;
             c->frame_e_slot = nullptr; c->frame_e_key = 0;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = led ? 1 : c->F;
             break;
@@ -458,10 +455,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
     bool spec_open = false;
     auto end_window = [&] { spec_open = false; close_src = nullptr; c->spec_undo = false; c->spec_albedo_saved = false; c->spec_light_saved = false; };
     auto undo_window = [&]() -> int {   // the loop ends on iteration iter-1: take back what iteration `iter` has applied speculatively
-        if (c->spec_light_saved) {
-            HIPCHK(c, hipMemcpyAsync(c->frames, c->frames_undo, sizeof(FrameP) * c->F, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->led_light, (char*)c->frames_undo + sizeof(FrameP) * c->F, 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-        }
+        if (c->spec_light_saved) launch_restore_light(c->F, c->frames, c->led_light, (const float*)c->frames_undo, c->stream);
         if (c->spec_albedo_saved) { SweepArgs au = make_args(c, 0); launch_restore_albedo(au, c->stream); }
         c->spec_undos++;
         end_window();

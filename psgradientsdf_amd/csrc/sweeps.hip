@@ -465,7 +465,14 @@ __device__ __forceinline__ void frame_rows_finish(const SweepArgs& a, int col_e,
 
 // optimizeLightAll: PsOptimizer.cpp:175-203 (no damping) / LedOptimizer.cpp:134-160 (damped, one RGB vector)
 template <int MODEL>
-__global__ void __launch_bounds__(kBlock) k_solve_light(SweepArgs a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key) {
+// undo (nullable): a speculative light update (loop.hip run_loop) keeps what it overwrites -- the frames' light coefficients [F][9] and the LED light [3] behind them --
+// so that k_restore_light can put them back if the loop ends on the previous iteration
+__global__ void __launch_bounds__(kBlock) k_solve_light(SweepArgs a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key, float* undo) {
+    if (undo) {
+        for (int i = threadIdx.x; i < a.F * 9; i += blockDim.x) undo[i] = frames[i / 9].l[i % 9];
+        if (threadIdx.x < 3) undo[a.F * 9 + threadIdx.x] = led_light[threadIdx.x];
+        __syncthreads();
+    }
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
     constexpr int NH = LED ? 3 : NB * (NB + 1) / 2;
@@ -509,12 +516,17 @@ __global__ void __launch_bounds__(kBlock) k_solve_light(SweepArgs a, FrameP* fra
     }
     frame_rows_finish(a, NH + NB, e_out, e_key, red);
 }
-void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key, hipStream_t s) {
+__global__ void __launch_bounds__(kBlock) k_restore_light(int F, FrameP* frames, float* led_light, const float* undo) {
+    for (int i = threadIdx.x; i < F * 9; i += blockDim.x) frames[i / 9].l[i % 9] = undo[i];
+    if (threadIdx.x < 3) led_light[threadIdx.x] = undo[F * 9 + threadIdx.x];
+}
+void launch_restore_light(int F, FrameP* frames, float* led_light, const float* undo, hipStream_t s) { if (F > 0) hipLaunchKernelGGL(k_restore_light, dim3(1), dim3(kBlock), 0, s, F, frames, led_light, undo); }
+void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key, float* undo, hipStream_t s) {
     if (a.F <= 0) return;
     dim3 g(1), bl(kBlock);
-    if (a.model == 0) hipLaunchKernelGGL((k_solve_light<0>), g, bl, 0, s, a, frames, led_light, e_out, e_key);
-    else if (a.model == 1) hipLaunchKernelGGL((k_solve_light<1>), g, bl, 0, s, a, frames, led_light, e_out, e_key);
-    else hipLaunchKernelGGL((k_solve_light<2>), g, bl, 0, s, a, frames, led_light, e_out, e_key);
+    if (a.model == 0) hipLaunchKernelGGL((k_solve_light<0>), g, bl, 0, s, a, frames, led_light, e_out, e_key, undo);
+    else if (a.model == 1) hipLaunchKernelGGL((k_solve_light<1>), g, bl, 0, s, a, frames, led_light, e_out, e_key, undo);
+    else hipLaunchKernelGGL((k_solve_light<2>), g, bl, 0, s, a, frames, led_light, e_out, e_key, undo);
 }
 
 // Sophus SO3::exp(w).matrix() (quaternion exponential + Eigen toRotationMatrix)
