@@ -27,6 +27,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_FUSE_ALBEDO")) c->fuse_albedo = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FUSE_PCG_INIT")) c->fuse_pcg_init = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_PERSIST")) c->pcg_persist = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_PCG_XCD_LOCAL")) c->pcg_xcd_local = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_FUSE_ASM")) c->pcg_fuse_asm = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_FUSE_APPLY")) c->pcg_fuse_apply = atoi(e) != 0;
     if (hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cu = 0;

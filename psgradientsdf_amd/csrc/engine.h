@@ -139,6 +139,7 @@ struct SweepArgs {
     AlbedoReg ar;             // ar.anb == nullptr unless "reg albedo" != 0
     double* pcg_part; double* pcg_fs;   // fused PCG state (pcg.hip)
     int pcg_asm;              // persistent solve assembles the distance system itself (no k_assemble launch in front of it)
+    int pcg_xcd_local;        // ... and keeps the records of workgroups whose neighbours all run on their own XCD in that XCD's L2 (plain stores)
     int pcg_apply;            // ... and applies the distance update itself (no k_apply_dist behind it): 1 = when finished, 2 = only on Success
     double* pcg_gran; int pcg_gran_n;   // persistent solve: the tagged per-workgroup sums, zeroed by the assembly kernel when non-null
     double* xr_clear;         // multi-rank persistent solve: this rank's cross-rank mailbox region (kXrDoubles), zeroed together with pcg_gran

@@ -76,6 +76,7 @@ struct psgsdf_ctx {
     double* pcg_gran = nullptr;          // persistent solve: [2][kSolveGranPlanes][kSolveMaxBlocksHost] tagged per-workgroup sums
     bool pcg_fuse_asm = true;            // PSGSDF_PCG_FUSE_ASM=0: k_assemble in front of the persistent solve (round-2a)
     bool pcg_fuse_apply = true;          // PSGSDF_PCG_FUSE_APPLY=0: k_apply_dist behind it
+    bool pcg_xcd_local = true;           // PSGSDF_PCG_XCD_LOCAL=0: every record through memory (write-through stores)
     bool pcg_persist = true;             // PSGSDF_PCG_PERSIST=0: always the per-pass kernels
     int num_cu = 0;
     int last_cg_iters = 0;

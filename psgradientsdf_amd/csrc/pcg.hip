@@ -419,8 +419,15 @@ template <int R, bool ASM, bool MR>
 __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, double* fs, double* gran, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, XrArgs xr) {
     __shared__ double red[8 * kSolveThreads / 64];
     __shared__ int s_abort;
+    __shared__ int s_foreign;      // a neighbour workgroup (in band order) runs on another XCD
     const Band& b = a.b;
     const int G = gridDim.x, tid = threadIdx.x;
+    // The XCD this workgroup REALLY runs on (HW_REG_XCC_ID): if every workgroup that gathers from its rows sits on the same XCD, its records can stay
+    // in that XCD's L2 (plain stores) instead of going through memory with write-through stores, which drop the line and make every reader fetch it at the
+    // cross-XCD rate (MI355X_MICROARCH.md: same-XCD hand-offs 1.7x; r02 notes section 8 measured 9.5-9.6 vs 9.9-10.5 us per pass but would not rely on an
+    // ASSUMED placement).  Here the neighbours tell each other where they are: the 'records are out' flag of the prologue carries 1 + the XCD id.
+    const int my_xcc = (int)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+    bool xcd_local = false;
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs; logical block lb gives XCD x the contiguous blocks [x G/8, (x+1) G/8)
     const int lb = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int plane = b.Spad * 4;
@@ -513,7 +520,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         // the records of this workgroup's rows are on their way: drained, then the flag the neighbours' pass 0 waits for (plane 7 of buffer 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) { __hip_atomic_store(gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + lb, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR) peer_tag(2, 1.0); }
+        if (tid == 0) { __hip_atomic_store(gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + lb, (double)(1 + my_xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR) peer_tag(2, 1.0); }
     }
     float rhsNorm2 = (float)bb;
     float thr = pcg_threshold(rhsNorm2);
@@ -538,16 +545,18 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         if (k > 0 || ASM) {
             // ---- A: the records this workgroup gathers from are those of its NEIGHBOURS in band order: wait for their pass k-1 only (the tag
             // of a workgroup's first sum is stored after its records have drained), not for the whole device
-            if (tid == 0) s_abort = 0;
+            if (tid == 0) { s_abort = 0; if (ASM && k == 0) s_foreign = 0; }
             __syncthreads();
             if (tid <= nhi - nlo) {
                 int spins = 0;
                 // (ASM, pass 0: the neighbours' assembled records -- their flag in plane 7 of buffer 1)
                 const double* wp = k > 0 ? gp + nlo + tid : gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + nlo + tid;
-                while (k > 0 ? gran_tag_of(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != want : __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0.0) {
+                double seen = 0.0;
+                while (k > 0 ? gran_tag_of(seen = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != want : (seen = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0.0) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
                 }
+                if (ASM && k == 0 && (int)seen != 1 + my_xcc) s_foreign = 1;      // (the relation is symmetric: whoever gathers from this workgroup is in [nlo, nhi])
             }
             if (MR) {
                 // rows within `reach` of a cut gather from halo rows: wait for the tags the neighbour slab's cut-side workgroups wrote into this rank's
@@ -566,6 +575,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             __syncthreads();
             if (s_abort) { if (tid == 0) { __hip_atomic_store(fs + 3, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR) for (int r = 0; r < xr.n_ranks; ++r) __hip_atomic_store(xr.region[r] + kXrAbort, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } status = 2; break; }
             if (tid == 0) { if (MR) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }      // (MR: system scope -- the halo records came from another GPU)
+            if (ASM && k == 0) xcd_local = a.pcg_xcd_local && !s_foreign;
             __syncthreads();
         }
         SOLVE_STAMP(1);
@@ -700,7 +710,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             const float tt = (float)(A1[u] - (double)alpha_prev * A2[u] + (double)beta * A3[u]);
             me[u] = make_float4(r_i, tt, p_i, me[u].w);
             if (live[u]) {
-                store16_sc1(rout + row[u], me[u]);
+                if (xcd_local) rout[row[u]] = me[u]; else store16_sc1(rout + row[u], me[u]);      // (all its readers share this XCD's L2 / through memory)
                 push_record(k & 1, row[u] - a.row0, me[u]);
                 const double rd = (double)r_i, td = (double)tt, iv = (double)me[u].w;
                 s[0] += (double)p_i * td; s[1] += iv * rd * td; s[2] += iv * td * td; s[3] += rd * td; s[4] += td * td;

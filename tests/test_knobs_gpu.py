@@ -62,6 +62,6 @@ def test_distance_step_fusions_are_bitwise_neutral(built, model):
     in its epilogue must give the bits of: the same kernel with k_apply_dist behind it, with k_assemble in front of it, and of the per-pass
     kernels (what multi-rank contexts run) -- energies, iteration counts and the optimised state, through psgsdf_optimize as well."""
     ref = run(model, {}, full=True)
-    for env in ({"PSGSDF_PCG_FUSE_APPLY": "0"}, {"PSGSDF_PCG_FUSE_ASM": "0"}, {"PSGSDF_PCG_PERSIST": "0"}):
+    for env in ({"PSGSDF_PCG_FUSE_APPLY": "0"}, {"PSGSDF_PCG_FUSE_ASM": "0"}, {"PSGSDF_PCG_PERSIST": "0"}, {"PSGSDF_PCG_XCD_LOCAL": "0"}):      # XCD_LOCAL=0: every record through memory
         got = run(model, env, full=True)
         assert got == ref, (env, got, ref)

@@ -28,6 +28,7 @@ VARIANTS = {
     "fold0": {"PSGSDF_FOLD_IN_NEXT": "0"},
     "poll0": {"PSGSDF_PCG_POLL": "0"},
     "persist0": {"PSGSDF_PCG_PERSIST": "0"},
+    "xcdlocal0": {"PSGSDF_PCG_XCD_LOCAL": "0"},  # persistent solve: every record through memory instead of staying in the XCD's L2 where all its readers are
     "spec0": {"PSGSDF_SPECULATE": "0"},          # every iteration closed before the next one starts (round 2)
     "nocheck": {"PSGSDF_MBOX_CHECK": "0"},      # read-backs taken on the marker's say-so (round 2): expected to deviate now and then
 }
