@@ -238,3 +238,24 @@ def test_exact_state_callback_between_speculative_iterations(built, name, mid, m
     assert all(seen3[d] == seen0[d] for d in seen3)
     assert fin0 == fin3 and obs0 == obs3 == sorted(seen0)
     assert st0["speculative_starts"] == 0 and st3["speculative_starts"] >= 2
+
+
+@pytest.mark.parametrize("name,mid", [("SH1", capi.SH1), ("LED", capi.LED)])
+def test_speculative_start_with_block_subsets(built, name, mid, monkeypatch):
+    """the speculative start of an iteration (albedo / light with undo) under every shape the ablation flags of voxelPS can give the loop: only undoable
+    blocks (the window is closed at the end of the iteration), an undoable block followed directly by the distance block, no undoable block at all --
+    records and final state bit for bit those of the loop that closes every iteration first (PSGSDF_SPECULATE=0)."""
+    sc = synth.make_scene(N=32, F=5, W=128, H=96, model=name)
+    st = capi.default_settings(mid, max_it=6, conv_threshold=0.0)
+    for flags in (capi.ALBEDO, capi.LIGHT, capi.ALBEDO | capi.LIGHT, capi.LIGHT | capi.DIST, capi.ALBEDO | capi.POSE, capi.DIST | capi.POSE, capi.ALBEDO | capi.DIST):
+        out = []
+        for spec in ("1", "0"):
+            monkeypatch.setenv("PSGSDF_SPECULATE", spec)
+            eng = capi.load_engine(sc, sc.K, st, 0); eng.load_scene(sc)
+            recs, conv = eng.optimize(flags)
+            v = eng.download_volume()
+            out.append(([(r["e_total"], tuple(np.nan_to_num(r["e_after"], nan=-1.0)), r["cg_iters"], r["converged"], r["diverged"]) for r in recs], conv,
+                        v["dist"].tobytes(), v["rgb"].tobytes(), eng.download_poses().tobytes(), eng.download_light().tobytes(), eng.debug_sync_stats()["speculative_starts"]))
+            eng.close()
+        assert out[0][:6] == out[1][:6], flags
+        assert out[1][6] == 0
