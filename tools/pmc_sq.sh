@@ -9,7 +9,7 @@ for c in "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES" "SQ_ACTIVE_INST
          "SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_ANY SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_VMEM_TA_ADDR_FIFO_FULL SQ_ACTIVE_INST_SCA" \
          "TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-40)
-  timeout 240 rocprofv3 --pmc $c -d $out/$n -o pmc --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-breakdown > $out/$n.json 2> $out/$n.err
+  timeout 240 rocprofv3 --pmc $c -d $out/$n -o pmc --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-breakdown --no-extra > $out/$n.json 2> $out/$n.err
 done
 python - "$out" <<'PY'
 import sys, glob, csv, collections, re
