@@ -332,7 +332,9 @@ int psgsdf_debug_albedo_system(psgsdf_ctx* ctx, float* H, float* b);
  *   the host waited for had already arrived (waited for; PSGSDF_MBOX_CHECK=0 takes them as they are: the round-2 behaviour)
  *   out[2] distance steps re-run on the per-pass kernels because the persistent solve could not get its workgroups co-resident
  *   out[3] 1e6 x iterations started speculatively (before the stop decision on the previous one) + those of them that were undone
- *   out[4] 1 if this (multi-rank) context holds the cross-rank mappings of the persistent solve, out[5] distance solves run through it, out[6..7] 0 */
+ *   out[4] 1 if this (multi-rank) context holds the cross-rank mappings of the persistent solve, out[5] distance solves run through it,
+ *   out[6] memory kind the hand-off probe chose for the record planes another device writes (-1 not probed: single rank; 0 none passed: cross-rank
+ *   solve off; 1 fine-grained; 2 uncached; 3 coarse, pinned by PSGSDF_XR_MEM), out[7] 1e6 x stale records + timed-out waits the probe saw (all ranks) */
 int psgsdf_debug_sync_stats(psgsdf_ctx* ctx, int64_t out[8]);
 
 #ifdef __cplusplus

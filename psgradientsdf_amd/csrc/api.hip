@@ -68,15 +68,16 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    xr_quiesce(c);      // multi-rank: every rank closes its mappings of the others' record planes / mailbox regions before anybody frees them (collective; psgsdf_destroy is called by all ranks)
     free_dense(c);
     hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->frames_undo); hipFree(c->led_light);
-    hipFree(c->band_mem); hipFree(c->obs_mem); hipFree(c->stage);
+    hipFree(c->band_mem); hipFree(c->rec_mem); hipFree(c->obs_mem); hipFree(c->stage);
     hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->frame_part); hipFree(c->frame_done); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->pcg_gran); hipFree(c->d_total);
     if (c->host_buf) hipHostFree(c->host_buf);
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    xr_release(c); hipFree(c->xr);
+    hipFree(c->xr);
     comm_destroy(c);
     hipFree(c->areg_mem); hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mbox_shadow); hipFree(c->d_need);
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);

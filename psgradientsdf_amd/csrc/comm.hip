@@ -150,47 +150,201 @@ int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
 }
 
 
-// ---- cross-rank persistent solve: IPC mappings ---------------------------------------------------------------------------------------
-// Every rank exports (a) its small mailbox region and (b) its band arena (the neighbours write the records of their cut-side rows into its halo rows);
+// ---- cross-rank persistent solve: memory kinds, the hand-off probe, IPC mappings -------------------------------------------------------
+// Memory another device writes (or this device polls) WHILE a kernel runs must not be plain hipMalloc memory: HIP only promises visibility of
+// another device's writes to coarse-grained memory at kernel boundaries.  Two kinds are used:
+//   polled words (the mailbox region: tags, rank granules, abort flag; KB-sized)   -> hipDeviceMallocUncached (every access goes to memory)
+//   the two PCG record planes (their halo rows are written by the neighbours)      -> hipDeviceMallocFinegrained (kind 1) or uncached (kind 2)
+// Which of the two carries the hand-offs between the REAL neighbours is not assumed but probed once per context (xr_probe): the very store /
+// load / fence forms of pcg.hip k_cgf_solve<.., MR> over the real mappings, the reader holding stale copies of the payload in its caches first.
+// On one GPU (the tests) every kind passes; what the first multi-GPU run finds is reported in psgsdf_debug_sync_stats / the bench line.
+int xr_alloc(psgsdf_ctx* c, void** p, size_t bytes, bool polled) {
+    *p = nullptr;
+    const int kind = c->xr_mem_kind;
+    if (c->n_ranks <= 1 || kind <= 0 || kind == 3) { HIPCHK(c, hipMalloc(p, bytes)); return 0; }      // single rank (or the cross-rank solve is off): nobody else touches it  (3: PSGSDF_XR_MEM=coarse, round 3's allocation, for comparison)
+    const unsigned flag = (polled || kind == 2) ? hipDeviceMallocUncached : hipDeviceMallocFinegrained;
+    HIPCHK(c, hipExtMallocWithFlags(p, bytes, flag));
+    return 0;
+}
+
+namespace {
+typedef float v4f_probe_t __attribute__((ext_vector_type(4)));
+constexpr int kProbeRecs = 2048, kProbeRounds = 48, kProbeFlagDoubles = 64;
+// Two roles, one workgroup each.  OWNER (towards the lower neighbour): pull the payload into this device's caches, wait for the neighbour's
+// round flag (system-scope relaxed loads), ONE system-scope acquire fence, read the payload with plain loads and count records that do not
+// carry the round, answer.  PEER (towards the upper neighbour): write-through 16-byte stores into its payload, drain, flag, wait for the answer.
+__global__ void __launch_bounds__(256) k_xr_probe(double* myF, const float4* myP, double* loF, double* hiF, float4* hiP, int has_lo, int has_hi, double* out) {
+    __shared__ int s_to; __shared__ unsigned long long s_stale;
+    if (threadIdx.x == 0) { s_to = 0; s_stale = 0; }
+    __syncthreads();
+    if (blockIdx.x == 0 && has_lo) {
+        unsigned long long stale = 0; float sink = 0.f;
+        for (int r = 1; r <= kProbeRounds; ++r) {
+            for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) sink += myP[i].x;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(myF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (double)r) { __builtin_amdgcn_s_sleep(1); if (++spins > (1 << 21)) { s_to = 1; break; } }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            }
+            __syncthreads();
+            if (s_to) break;
+            for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { const float4 v = myP[i]; if (v.x != (float)r || v.w != (float)(r + i)) stale++; }
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(loF + 8, (double)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        atomicAdd(&s_stale, stale);
+        __syncthreads();
+        if (threadIdx.x == 0) { out[0] = (double)s_stale; out[1] = (double)s_to; out[3] = (double)sink; }
+    }
+    if (blockIdx.x == 1 && has_hi) {
+        for (int r = 1; r <= kProbeRounds; ++r) {
+            for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) {
+                const v4f_probe_t d = {(float)r, 0.f, 0.f, (float)(r + i)};
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(hiP + i), "v"(d) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(hiF, (double)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                int spins = 0;
+                while (__hip_atomic_load(myF + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (double)r) { __builtin_amdgcn_s_sleep(1); if (++spins > (1 << 21)) { s_to = 1; break; } }
+            }
+            __syncthreads();
+            if (s_to) break;
+        }
+        if (threadIdx.x == 0) out[2] = (double)s_to;
+    }
+}
+
+// all-reduce of a host vector of doubles through a scratch device buffer; every rank fills its own slice, zeros elsewhere
+int host_allreduce(psgsdf_ctx* c, std::vector<double>& buf, const char* what) {
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, sizeof(double) * buf.size()));
+    int rc = 0;
+    if (hipMemcpyAsync(d, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "%s: upload", what);
+    if (!rc) rc = comm_allreduce(c, d, (int)buf.size());
+    if (!rc && (hipMemcpyAsync(buf.data(), d, sizeof(double) * buf.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) rc = fail(c, PSGSDF_ERR_DEVICE, "%s: download", what);
+    hipFree(d);
+    return rc;
+}
+void handle_to_doubles(const hipIpcMemHandle_t& h, double* out) { for (int i = 0; i < 64; ++i) out[i] = (double)((const unsigned char*)&h)[i]; }
+void* open_handle(const double* bytes) {
+    hipIpcMemHandle_t h; for (int i = 0; i < 64; ++i) ((unsigned char*)&h)[i] = (unsigned char)bytes[i];
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+}  // namespace
+
+// Collective, once per context (the first band of a multi-rank context): choose the memory kind for the cross-rank hand-offs by trying them
+// between the real neighbours.  Leaves c->xr_mem_kind = 1 / 2 (passed on EVERY rank) or 0 (none did: the cross-rank solve stays off).
+int xr_probe(psgsdf_ctx* c) {
+    const int R = c->n_ranks, me = c->rank;
+    if (c->xr_mem_kind >= 0 || R <= 1 || !c->comm) return 0;
+    c->xr_mem_kind = 0;
+    int want = 0;                    // PSGSDF_XR_MEM=fine|uncached|coarse pins the kind (coarse: plain hipMalloc, round 3's allocation -- for comparison only)
+    if (const char* e = getenv("PSGSDF_XR_MEM")) want = !strcmp(e, "fine") ? 1 : !strcmp(e, "uncached") ? 2 : !strcmp(e, "coarse") ? 3 : 0;
+    constexpr int kSlice = 64 + 64 + 2;
+    for (int kind = 1; kind <= 2; ++kind) {
+        if (want == 1 || want == 2) { if (kind != want) continue; }
+        double* F = nullptr; float4* P = nullptr; double* out = nullptr;
+        hipIpcMemHandle_t hF{}, hP{};
+        bool ok = c->xr_enable
+            && hipExtMallocWithFlags((void**)&F, sizeof(double) * kProbeFlagDoubles, hipDeviceMallocUncached) == hipSuccess
+            && (want == 3 ? hipMalloc((void**)&P, sizeof(float4) * kProbeRecs) : hipExtMallocWithFlags((void**)&P, sizeof(float4) * kProbeRecs, kind == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached)) == hipSuccess
+            && hipMalloc((void**)&out, sizeof(double) * 4) == hipSuccess
+            && hipMemsetAsync(F, 0, sizeof(double) * kProbeFlagDoubles, c->stream) == hipSuccess && hipMemsetAsync(P, 0, sizeof(float4) * kProbeRecs, c->stream) == hipSuccess
+            && hipMemsetAsync(out, 0, sizeof(double) * 4, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess
+            && hipIpcGetMemHandle(&hF, F) == hipSuccess && hipIpcGetMemHandle(&hP, P) == hipSuccess;
+        (void)hipGetLastError();
+        std::vector<double> buf((size_t)R * kSlice, 0.0);
+        double* mine = buf.data() + (size_t)me * kSlice;
+        handle_to_doubles(hF, mine); handle_to_doubles(hP, mine + 64);
+        mine[128] = (double)getpid(); mine[129] = ok ? 1.0 : 0.0;
+        int rc = host_allreduce(c, buf, "cross-rank probe");
+        std::vector<void*> opened;
+        double *loF = nullptr, *hiF = nullptr; float4* hiP = nullptr;
+        if (!rc) {
+            for (int r = 0; r < R; ++r) if (buf[(size_t)r * kSlice + 129] != 1.0 || (r != me && buf[(size_t)r * kSlice + 128] == (double)getpid())) ok = false;      // (two ranks in ONE process: no IPC between them)
+            if (ok && me > 0) { loF = (double*)open_handle(buf.data() + (size_t)(me - 1) * kSlice); if (loF) opened.push_back(loF); else ok = false; }
+            if (ok && me < R - 1) {
+                hiF = (double*)open_handle(buf.data() + (size_t)(me + 1) * kSlice); if (hiF) opened.push_back(hiF); else ok = false;
+                hiP = ok ? (float4*)open_handle(buf.data() + (size_t)(me + 1) * kSlice + 64) : nullptr; if (hiP) opened.push_back(hiP); else ok = false;
+            }
+            // everybody mapped everything?  (this all-reduce also lines the ranks up in front of the kernels that wait for each other)
+            std::vector<double> agree(1, ok ? 1.0 : 0.0);
+            rc = host_allreduce(c, agree, "cross-rank probe");
+            ok = !rc && agree[0] == (double)R;
+        }
+        std::vector<double> res(3, 0.0);
+        if (!rc && ok) {
+            hipLaunchKernelGGL(k_xr_probe, dim3(2), dim3(256), 0, c->stream, F, (const float4*)P, loF, hiF, hiP, me > 0 ? 1 : 0, me < R - 1 ? 1 : 0, out);
+            double o[4] = {0, 0, 0, 0};
+            if (hipMemcpyAsync(o, out, sizeof(o), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "cross-rank probe: kernel");
+            res[0] = o[0]; res[1] = o[1] + o[2]; res[2] = 1.0;
+            if (!rc) rc = host_allreduce(c, res, "cross-rank probe");
+            c->xr_probe_stale += (long long)res[0]; c->xr_probe_timeouts += (long long)res[1];
+        }
+        // close before anybody frees: mappings first, then a barrier, then the allocations
+        for (void* p : opened) hipIpcCloseMemHandle(p);
+        if (!rc) { std::vector<double> bar(1, 1.0); rc = host_allreduce(c, bar, "cross-rank probe"); }
+        hipFree(F); hipFree(P); hipFree(out);
+        (void)hipGetLastError();
+        if (rc) return rc;
+        if (ok && res[2] == (double)R && res[0] == 0.0 && res[1] == 0.0) { c->xr_mem_kind = want == 3 ? 3 : kind; break; }
+        if (ok && me == 0) fprintf(stderr, "psgsdf: cross-rank hand-off probe with %s record memory: %lld stale records, %lld timed-out waits over %d ranks\n",
+                                   kind == 1 ? "fine-grained" : "uncached", (long long)res[0], (long long)res[1], R);
+        if (!ok) break;      // (no IPC between these ranks at all: another kind will not help)
+    }
+    if (c->xr_mem_kind == 0 && me == 0 && c->xr_enable) fprintf(stderr, "psgsdf: no memory kind carried the in-kernel hand-offs between the %d ranks: the distance solve uses the per-pass kernels + one all-reduce per pass\n", R);
+    return 0;
+}
+
+// Every rank exports (a) its small mailbox region and (b) its two record planes (the neighbours write the records of their cut-side rows into its halo rows);
 // the handles and a few numbers travel through ONE all-reduce in which every rank fills its own slice (bytes as doubles, zeros elsewhere), so the
 // exchange works over RCCL and over a caller-supplied transport alike.  All ranks agree on the outcome with a second all-reduce: either every rank
-// runs the cross-rank persistent solve or every rank stays on the per-pass kernels.
+// runs the cross-rank persistent solve or every rank stays on the per-pass kernels.  EVERY rank of a multi-rank context takes part in both
+// all-reduces, whatever its own knobs or state say (a rank that cannot contributes ok = 0): nobody is left waiting in a collective.
 void xr_release(psgsdf_ctx* c) {
     for (void* p : c->xr_opened) hipIpcCloseMemHandle(p);
     c->xr_opened.clear(); c->xr_peer.clear(); c->band_peer[0] = c->band_peer[1] = nullptr; c->xr_ready = false; c->xr_args = XrArgs{};
 }
+// Before rec_mem or the mailbox region are freed (band rebuild, destroy) every rank has to have closed its mappings of them: freeing memory an
+// importer still maps is undefined in HIP.  Collective over the ranks of the context; a no-op when nothing was ever exported.
+int xr_quiesce(psgsdf_ctx* c) {
+    xr_release(c);
+    if (!c->xr_mapped || !c->comm || c->n_ranks <= 1) { c->xr_mapped = false; return 0; }
+    c->xr_mapped = false;
+    std::vector<double> bar(1, 1.0);
+    return host_allreduce(c, bar, "cross-rank release");
+}
 int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     xr_release(c);
     const int R = c->n_ranks, me = c->rank;
-    if (R <= 1 || !c->comm || !c->xr_enable || !c->pcg_persist || !c->pcg_fuse_asm || R > kXrMaxRanks) return 0;
-    if (!c->xr) { HIPCHK(c, hipMalloc(&c->xr, sizeof(double) * kXrDoubles)); HIPCHK(c, hipMemsetAsync(c->xr, 0, sizeof(double) * kXrDoubles, c->stream)); }
+    if (R <= 1 || !c->comm) return 0;
+    if (R > kXrMaxRanks) return 0;                                 // (the same on every rank)
     constexpr int kSlice = 64 + 64 + 8;      // two IPC handles (64 bytes each, one double per byte) + {rec[0] offset, rec[1] offset, pid, ok}
     std::vector<double> buf((size_t)R * kSlice, 0.0);
     hipIpcMemHandle_t hx{}, hb{};
     int Gs, Rs;
-    bool ok = cgf_solve_shape(c, &Gs, &Rs, true)      // (this slab fits the persistent kernel at all)
-        && hipIpcGetMemHandle(&hx, c->xr) == hipSuccess && hipIpcGetMemHandle(&hb, c->band_mem) == hipSuccess;
+    bool ok = c->xr_enable && c->pcg_persist && c->pcg_fuse_asm && c->xr_mem_kind > 0 && c->rec_mem;
+    if (ok && !c->xr) {
+        if (xr_alloc(c, (void**)&c->xr, sizeof(double) * kXrDoubles, true) || hipMemsetAsync(c->xr, 0, sizeof(double) * kXrDoubles, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
+    }
+    ok = ok && cgf_solve_shape(c, &Gs, &Rs, true)      // (this slab fits the persistent kernel at all)
+        && hipIpcGetMemHandle(&hx, c->xr) == hipSuccess && hipIpcGetMemHandle(&hb, c->rec_mem) == hipSuccess;
     (void)hipGetLastError();
     double* mine = buf.data() + (size_t)me * kSlice;
-    for (int i = 0; i < 64; ++i) { mine[i] = (double)((unsigned char*)&hx)[i]; mine[64 + i] = (double)((unsigned char*)&hb)[i]; }
-    mine[128] = (double)((char*)c->band.rec[0] - (char*)c->band_mem); mine[129] = (double)((char*)c->band.rec[1] - (char*)c->band_mem);
+    handle_to_doubles(hx, mine); handle_to_doubles(hb, mine + 64);
+    mine[128] = (double)((char*)c->band.rec[0] - (char*)c->rec_mem); mine[129] = (double)((char*)c->band.rec[1] - (char*)c->rec_mem);
     mine[130] = (double)getpid(); mine[131] = ok ? 1.0 : 0.0;
-    double* d_buf = nullptr;
-    HIPCHK(c, hipMalloc(&d_buf, sizeof(double) * buf.size()));
-    int rc = 0;
-    if (hipMemcpyAsync(d_buf, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "cross-rank set-up: upload");
-    if (!rc) rc = comm_allreduce(c, d_buf, (int)buf.size());
-    if (!rc && (hipMemcpyAsync(buf.data(), d_buf, sizeof(double) * buf.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) rc = fail(c, PSGSDF_ERR_DEVICE, "cross-rank set-up: download");
-    if (rc) { hipFree(d_buf); return rc; }
+    int rc = host_allreduce(c, buf, "cross-rank set-up");
+    if (rc) return rc;
+    c->xr_mapped = true;             // (handles are out: a peer may map them from here on)
+    auto open = [&](const double* bytes) -> void* { void* p = open_handle(bytes); if (p) c->xr_opened.push_back(p); return p; };
     // map every rank's region, and the two neighbours' band arenas
     c->xr_peer.assign(R, nullptr); c->xr_peer[me] = c->xr;
-    auto open = [&](const double* bytes) -> void* {
-        hipIpcMemHandle_t h; for (int i = 0; i < 64; ++i) ((unsigned char*)&h)[i] = (unsigned char)bytes[i];
-        void* p = nullptr;
-        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        c->xr_opened.push_back(p);
-        return p;
-    };
     for (int r = 0; r < R && ok; ++r) {
         const double* sl = buf.data() + (size_t)r * kSlice;
         if (sl[131] != 1.0) { ok = false; break; }
@@ -233,15 +387,12 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
         if (c->give[0] > 0 && (c->give[0] - 1) / per + 1 > kXrPeerTags) ok = false;
         if (c->give[1] > 0 && (c->row1 - c->row0 - 1) / per - std::max(0, c->row1 - c->row0 - c->give[1]) / per + 1 > kXrPeerTags) ok = false;
     }
-    // agreement: every rank or none
-    double flag = ok ? 1.0 : 0.0;
-    rc = 0;
-    if (hipMemcpyAsync(d_buf, &flag, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "cross-rank set-up: flag");
-    if (!rc) rc = comm_allreduce(c, d_buf, 1);
-    if (!rc && (hipMemcpyAsync(&flag, d_buf, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) rc = fail(c, PSGSDF_ERR_DEVICE, "cross-rank set-up: flag");
-    hipFree(d_buf);
-    if (rc) return rc;
-    if (flag != (double)R) { xr_release(c); return 0; }
+    // agreement: every rank or none.  (Behind this all-reduce every rank's region has been zeroed -- at its allocation, in stream order before
+    // its contribution -- so no word of an earlier band or a raised abort flag survives into the solves of this one.)
+    if (c->xr && hipMemsetAsync(c->xr, 0, sizeof(double) * kXrDoubles, c->stream) != hipSuccess) ok = false;
+    std::vector<double> agree(1, ok ? 1.0 : 0.0);
+    if ((rc = host_allreduce(c, agree, "cross-rank set-up"))) return rc;
+    if (agree[0] != (double)R) { xr_release(c); return 0; }
     c->xr_args = x; c->xr_ready = true;
     return 0;
 }

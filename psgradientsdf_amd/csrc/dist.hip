@@ -178,7 +178,6 @@ __global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      //
         if (blockIdx.x == 0 && threadIdx.x == 0) { a.pcg_fs[1] = 0.0; a.pcg_fs[2] = 0.0; a.pcg_fs[3] = 0.0; }
         const int gid = blockIdx.x * blockDim.x + threadIdx.x;
         for (int q = gid; q < a.pcg_gran_n; q += gridDim.x * blockDim.x) a.pcg_gran[q] = 0.0;
-        if (a.xr_clear) for (int q = gid; q < kXrDoubles; q += gridDim.x * blockDim.x) a.xr_clear[q] = 0.0;
     }
 }
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s) {

@@ -142,7 +142,6 @@ struct SweepArgs {
     int pcg_xcd_local;        // ... and keeps the records of workgroups whose neighbours all run on their own XCD in that XCD's L2 (plain stores)
     int pcg_apply;            // ... and applies the distance update itself (no k_apply_dist behind it): 1 = when finished, 2 = only on Success
     double* pcg_gran; int pcg_gran_n;   // persistent solve: the tagged per-workgroup sums, zeroed by the assembly kernel when non-null
-    double* xr_clear;         // multi-rank persistent solve: this rank's cross-rank mailbox region (kXrDoubles), zeroed together with pcg_gran
     int pcg_fuse_init;        // assembly kernel also initialises the PCG (x = 0, records of pass -1, |b|^2 partials): no k_cgf_init launch
     int pcg_init_blocks;      // workgroups that wrote the |b|^2 partials (0: the pass kernel's own grid)
     int fuse_apply;           // albedo sweep: solve the voxel's diagonal system and apply the update in the same thread (no normal equations stored); 2: and keep the old albedo for an undo
@@ -152,7 +151,12 @@ struct SweepArgs {
 
 // Cross-rank hand-offs of the persistent distance solve on a z-slab partition (pcg.hip k_cgf_solve<.., MR = true>, comm.hip xr_setup): every rank owns one
 // small mailbox region that ALL ranks can write (IPC-mapped over xGMI), and the records of the rows next to a cut are written straight into the
-// neighbour's halo rows.  Layout of a region, in doubles:
+// neighbour's halo rows.  Both live in memory another device may write and this device may poll WHILE A KERNEL RUNS: the region is allocated
+// uncached, the two record planes fine-grained (comm.hip xr_alloc; plain hipMalloc memory is only coherent across devices at kernel boundaries),
+// and the hand-off forms are verified between the real neighbours before they are relied on (comm.hip xr_probe).
+// Nothing in a region is ever cleared between solves: every tag carries the solve's EPOCH next to the pass tag, so a word of an earlier solve -- or a
+// word a fast rank wrote before this rank even started its solve -- can neither be mistaken for the current one nor be wiped.
+// Layout of a region, in doubles:
 constexpr int kXrMaxRanks = 32;      // rank-level sums: [2 buffers][8 planes][kXrMaxRanks] tagged granules (plane 7: |b|^2 with the sums of pass 0)
 constexpr int kXrPeerTags = 64;      // 'records are out' tags of the neighbour's workgroups next to the cut: [2 sides][3 buffers (2 pass parities + prologue)][kXrPeerTags]
 constexpr int kXrRankGran = 0, kXrPtag = 2 * 8 * kXrMaxRanks, kXrAbort = kXrPtag + 2 * 3 * kXrPeerTags, kXrDoubles = kXrAbort + 8;
@@ -163,7 +167,9 @@ struct XrArgs {
     int give_lo, give_hi;            // own rows the lower / upper neighbour holds as halo (the first give_lo / last give_hi own rows)
     int wait_lo, wait_hi;            // workgroups of the lower / upper neighbour whose tags this slab's cut-side workgroups wait for
     int need_lo, need_hi;            // halo rows this slab gathers from
+    unsigned epoch;                  // solve counter of the context (the same on every rank), 14 bits: tags of the cross-rank words are (epoch << 2 | pass tag)
 };
+constexpr unsigned kXrEpochMask = 0x3fffu;      // (the host clears every region behind an all-rank barrier whenever the epoch wraps: loop.hip pcg_solve)
 
 // ---- launchers implemented in the kernel files (all asynchronous on `s`) ----------------------
 void launch_pack_rgb8(const uint8_t* rgb, unsigned* rgba, size_t npix, hipStream_t s);   // [npix][3] bytes -> one RGBA8 word per pixel

@@ -41,7 +41,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
     a.acc.fpart = c->frame_part; a.acc.fcap = c->frame_cap; a.acc.fdone = c->frame_done;
     a.fold.n = 0; a.gate = nullptr; a.fuse_apply = 0;
-    a.pcg_part = c->pcg_part; a.pcg_fs = c->pcg_sc; a.pcg_fuse_init = 0; a.pcg_init_blocks = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.pcg_asm = 0; a.pcg_apply = 0; a.xr_clear = nullptr; a.pcg_xcd_local = c->pcg_xcd_local ? 1 : 0;
+    a.pcg_part = c->pcg_part; a.pcg_fs = c->pcg_sc; a.pcg_fuse_init = 0; a.pcg_init_blocks = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.pcg_asm = 0; a.pcg_apply = 0; a.pcg_xcd_local = c->pcg_xcd_local ? 1 : 0;
     a.ar = c->ar; a.ar.weight = c->reg_r;
     a.model = c->set.model; a.quirks = c->set.ref_quirks;
     a.reg_n = c->reg_n; a.reg_l = c->reg_l;
@@ -232,6 +232,11 @@ int alloc_dense(psgsdf_ctx* c, DenseView& d, long long nvox, int KW, bool with_r
 // (re)build the band from the dense grid: flags -> scan -> compact planes -> neighbour tables
 int build_band(psgsdf_ctx* c) {
     if (!c->deferred.empty() || c->pending_fold.n) { int rc = flush(c); if (rc) return rc; }   // (read-backs of the band that is about to be replaced)
+    // multi-rank: the neighbours map this rank's record planes (cross-rank persistent solve); every rank closes its mappings and all ranks
+    // meet before anything is freed.  The first band of a multi-rank context also chooses the memory kind of those planes (comm.hip xr_probe).
+    { int rc = xr_quiesce(c); if (rc) return rc; }
+    if (c->n_ranks > 1 && c->comm) { int rc = xr_probe(c); if (rc) return rc; }
+    c->persist_off = false;          // a persistent solve that gave up did so on the previous band's launch shape / mappings: this band tries again
     const long long nvox = c->grid.nvox;
     const int KW = c->dense.KW;
     if (!c->block_sums) HIPCHK(c, hipMalloc(&c->block_sums, sizeof(int) * ((nvox + 1023) / 1024 + 1)));
@@ -242,18 +247,21 @@ int build_band(psgsdf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int Spad = ((S + kBlock - 1) / kBlock) * kBlock + kBlock;
     // planes (4-byte units per row): see Band
-    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 4 + 8 + 9 + 1 + 3;   // (xs, gn, nfd live in the packed planes vp: 12 instead of 9 words)
+    const size_t n4 = 1 + 1 + 3 + 3 + 6 + 6 + kNQ + 12 + 6 + 14 + kNQ + 4 + 9 + 1 + 3;   // (xs, gn, nfd live in the packed planes vp: 12 instead of 9 words; the two record planes are an allocation of their own)
     const size_t bytes = (n4 * 4 + (size_t)KW * 8) * Spad + 256;
     if (c->band_mem) { hipFree(c->band_mem); c->band_mem = nullptr; }
+    if (c->rec_mem) { hipFree(c->rec_mem); c->rec_mem = nullptr; }
     HIPCHK(c, hipMalloc(&c->band_mem, bytes));
     HIPCHK(c, hipMemsetAsync(c->band_mem, 0, bytes, c->stream));
+    { int rc = xr_alloc(c, &c->rec_mem, 2 * sizeof(float4) * (size_t)Spad, false); if (rc) return rc; }      // (fine-grained / uncached on a multi-rank context: the neighbours' kernels write its halo rows)
+    HIPCHK(c, hipMemsetAsync(c->rec_mem, 0, 2 * sizeof(float4) * (size_t)Spad, c->stream));
     c->band_bytes = bytes;
     char* p = (char*)c->band_mem;
     auto take = [&](size_t elems, size_t esz) { void* r = p; p += elems * esz * Spad; return r; };
     Band& b = c->band;
     b.S = S; b.Spad = Spad; b.KW = KW;
     b.vis = (uint64_t*)take(KW, 8);
-    b.rec[0] = (float4*)take(4, 4); b.rec[1] = (float4*)take(4, 4);
+    b.rec[0] = (float4*)c->rec_mem; b.rec[1] = b.rec[0] + Spad;
     b.lin = (int*)take(1, 4);
     b.dist = (float*)take(1, 4);
     for (int a = 0; a < 3; ++a) b.g[a] = (float*)take(1, 4);

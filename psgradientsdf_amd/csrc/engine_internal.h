@@ -59,6 +59,7 @@ struct psgsdf_ctx {
     bool have_frames = false;
     // band
     void* band_mem = nullptr; size_t band_bytes = 0;
+    void* rec_mem = nullptr;             // the two PCG record planes (Band::rec): an allocation of their own, fine-grained on a multi-rank context (the neighbours' solve kernels write its halo rows while this rank's kernel reads them)
     void* obs_mem = nullptr;
     float* stage = nullptr; size_t stage_px = 0;   // device staging of one RGB-D frame (integrate_frame)
     // front end: FALS cache (9 float planes), box-filter scratch, tracker partials
@@ -78,6 +79,7 @@ struct psgsdf_ctx {
     bool pcg_fuse_apply = true;          // PSGSDF_PCG_FUSE_APPLY=0: k_apply_dist behind it
     bool pcg_xcd_local = true;           // PSGSDF_PCG_XCD_LOCAL=0: every record through memory (write-through stores)
     bool pcg_persist = true;             // PSGSDF_PCG_PERSIST=0: always the per-pass kernels
+    bool persist_off = false;            // a persistent solve gave up on this band (bounded wait expired): per-pass kernels until the next band is built (build_band re-arms)
     int num_cu = 0;
     int last_cg_iters = 0;
     bool want_counts = true;             // read back the accepted-update counts (debug statistic of the reference)
@@ -111,6 +113,9 @@ struct psgsdf_ctx {
     bool xr_enable = true;               // PSGSDF_XR=0: multi-rank contexts always use the per-pass kernels + RCCL all-reduce (round 2)
     bool xr_ready = false; long long xr_solves = 0;
     double* xr = nullptr;
+    int xr_mem_kind = -1;                // memory kind of xr / rec_mem chosen by xr_probe: 1 fine-grained records + uncached region, 2 both uncached, 0 none passed (cross-rank solve off); -1 not probed yet
+    long long xr_probe_stale = 0, xr_probe_timeouts = 0;   // what the probe saw (all ranks, all kinds tried)
+    bool xr_mapped = false;              // peers may hold IPC mappings of xr / rec_mem: they have to be closed everywhere before either is freed (xr_quiesce)
     std::vector<double*> xr_peer;        // [n_ranks] (own entry = xr)
     void* band_peer[2] = {nullptr, nullptr};   // lower / upper neighbour's band arena
     std::vector<void*> xr_opened;        // IPC mappings to close
@@ -195,6 +200,9 @@ int comm_allreduce(psgsdf_ctx* c, double* buf, int n);                 // in-pla
 int comm_halo(psgsdf_ctx* c, void* base, int planes, int width);       // halo rows of `planes` band planes of `width` 4-byte words per row
 int xr_setup(psgsdf_ctx* c, const std::vector<double>& part_info);   // comm.hip: (re)build the cross-rank mappings for the band just built (part_info: {need_lo, need_hi, own rows} of every rank)
 void xr_release(psgsdf_ctx* c);
+int xr_quiesce(psgsdf_ctx* c);                                        // comm.hip: close this rank's mappings and wait until every rank has closed its own (before rec_mem / xr are freed)
+int xr_probe(psgsdf_ctx* c);                                          // comm.hip: once per context (collective): which memory kind carries the in-kernel hand-offs between the real neighbours
+int xr_alloc(psgsdf_ctx* c, void** p, size_t bytes, bool polled);     // comm.hip: memory another device writes while a kernel of this one reads it
 int mg_commit(psgsdf_ctx* c);                                          // engine.hip: all-reduce + deliver the staged scalar read-backs
 int set_local_grid(psgsdf_ctx* c, int z0, int z1);                     // engine.hip: this context owns global planes [z0, z1) (+ halo planes)
 

@@ -27,7 +27,7 @@ void cgf_shape(int nblk, int* G, int* rows) {
 // which is the per-pass kernels' all-reduce -- and only with 16-bit column deltas and the assembly kernel's fused initialisation.
 bool cgf_solve_shape(psgsdf_ctx* c, int* G, int* rows_per_wg, bool any_ranks) {
     // (multi-rank: only with the cross-rank mappings of comm.hip xr_setup in place -- all ranks or none, agreed there)
-    if (!c->pcg_persist || (c->n_ranks > 1 && !c->xr_ready && !any_ranks) || !c->band.col16 || !c->fuse_pcg_init || c->num_cu <= 0 || band_blocks(c) > kPcgMaxBlocks) return false;
+    if (!c->pcg_persist || c->persist_off || (c->n_ranks > 1 && !c->xr_ready && !any_ranks) || !c->band.col16 || !c->fuse_pcg_init || c->num_cu <= 0 || band_blocks(c) > kPcgMaxBlocks) return false;
     const int n = c->row1 - c->row0, cap = std::min(c->num_cu, kSolveMaxBlocksHost);
     if (n <= 0) return false;
     // as many workgroups as CUs (in multiples of 8: every XCD owns a contiguous range of rows) unless the band is so small that a workgroup
@@ -72,7 +72,18 @@ int pcg_solve(psgsdf_ctx* c, SweepArgs& a, int* iters_out, int* success_out, dou
         st[3] = NAN; st[4] = 0.0;
         const int inject = (c->fault_solve > 0 && ++c->solves_seen == c->fault_solve) ? -7 : 0;      // PSGSDF_FAULT_SOLVE=n: one workgroup of the n-th solve stops publishing (tests the fallback below)
         const XrArgs* xr = (c->n_ranks > 1 && c->xr_ready && as.pcg_asm) ? &c->xr_args : nullptr;
-        if (xr) c->xr_solves++;
+        if (xr) {
+            // the solve's epoch (the same on every rank: all ranks run the same solves) goes into every cross-rank tag, so nothing in the mailbox
+            // regions is ever cleared between solves.  When the 14-bit epoch wraps, every region is cleared once behind an all-rank barrier
+            // (a word that has sat unrewritten for 16 384 solves must not match again).
+            c->xr_solves++;
+            c->xr_args.epoch = (unsigned)(c->xr_solves & (long long)kXrEpochMask);
+            if (c->xr_args.epoch == 0) {
+                HIPCHK(c, hipMemsetAsync(c->xr, 0, sizeof(double) * kXrDoubles, c->stream));
+                HIPCHK(c, hipMemsetAsync(c->mg_ext, 0, sizeof(double), c->stream));
+                int rc = comm_allreduce(c, c->mg_ext, 1); if (rc) return rc;      // (a rank's kernel writes into another's region only behind this: every memset is ordered before its owner's contribution)
+            }
+        }
         timed(c, "pcg_solve", [&] { launch_cgf_solve(as, c->pcg_sc, c->pcg_gran, G, rows, cap, c->mbox_dev + off, key, inject, c->stream, xr); });
         if (tail && !c->profiling) { tail(c->pcg_sc + (gate_on_converged ? 2 : 1)); if (tail_ran) *tail_ran = true; }
         // the four status words are taken only together with their check word (engine.h FoldReq)
@@ -91,10 +102,14 @@ int pcg_solve(psgsdf_ctx* c, SweepArgs& a, int* iters_out, int* success_out, dou
             // The persistent kernel needs all its workgroups co-resident (no cooperative launch) and gave up waiting for some of them: something
             // else holds CUs of this device (another process, a CU mask).  Nothing has been applied (its epilogue only acts on status 1 and it
             // leaves both gates closed, so the tail enqueued behind it did nothing): redo this solve with the per-pass kernels, which make
-            // no residency assumption and give the same bits, and keep this context on them.
+            // no residency assumption and give the same bits, and keep this context on them until the next band is built.
+            // Multi-rank: the decision is the same on every rank without asking -- a rank that gives up in pass j never publishes the sums of
+            // pass j, so no rank can obtain them and finish; a rank CAN only reach its last pass when every rank has published everything that
+            // pass needs (records before sums), and the last pass itself waits for nothing.  The abort flag only shortens the others' waits.
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (!c->persist_fallbacks++) fprintf(stderr, "psgsdf: the persistent distance solve could not get its %d workgroups co-resident (status %g): is another process holding CUs of this device?  Continuing with the per-pass kernels.\n", G, (double)st[3]);
-            c->pcg_persist = false;
+            if (!c->persist_fallbacks++) fprintf(stderr, "psgsdf: the persistent distance solve gave up waiting (status %g, %d workgroups%s): %s  Continuing with the per-pass kernels.\n", (double)st[3], G, xr ? ", cross-rank" : "",
+                                                 xr ? "a neighbour rank's hand-off did not arrive in time." : "is another process holding CUs of this device?");
+            c->persist_off = true;
             a.pcg_asm = 0; a.pcg_apply = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.fold.n = 0;      // (the sweep's sums were folded by the kernel's prologue / by k_assemble)
             timed(c, "assemble", [&] { launch_assemble(a, c->stream); });      // H, rhs, x = 0, the initial records (the attempt overwrote them) and |b|^2 in memory, status words reset
             if (tail_ran) *tail_ran = false;
@@ -258,7 +273,7 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
             }
             else {
                 materialize_fold(c);
-                { int Gs, Rs; if (c->pcg_fuse_asm && c->fuse_pcg_init && band_blocks(c) <= kPcgMaxBlocks && cgf_solve_shape(c, &Gs, &Rs)) { a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kSolveGranPlanes * kSolveMaxBlocksHost; a.pcg_asm = 1; a.xr_clear = c->xr_ready ? c->xr : nullptr; } }   // the sweep clears the tags of the persistent solve behind it (and this rank's cross-rank mailbox: the halo exchange of the voxel blocks that follows orders it before any neighbour's solve)
+                { int Gs, Rs; if (c->pcg_fuse_asm && c->fuse_pcg_init && band_blocks(c) <= kPcgMaxBlocks && cgf_solve_shape(c, &Gs, &Rs)) { a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kSolveGranPlanes * kSolveMaxBlocksHost; a.pcg_asm = 1; } }   // the sweep clears the LOCAL tags of the persistent solve behind it (the cross-rank words carry the solve's epoch and are never cleared)
                 timed(c, "sweep_dist", [&] { launch_sweep_dist(a, c->stream); });
             }   // (LED: the fused albedo sweep's sums are still pending and this sweep writes the same slots)
             const int slots[2] = {SC_ENERGY, SC_NOBS}; double s[2];

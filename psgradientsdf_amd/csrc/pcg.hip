@@ -357,6 +357,10 @@ __device__ __forceinline__ void store16_sys(float4* p, const float4& v) {
 }
 __device__ __forceinline__ double gran_tag(double v, unsigned tag) { return __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(v) & ~3ull) | tag)); }
 __device__ __forceinline__ unsigned gran_tag_of(double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) & 3ull); }
+// cross-rank words (multi-rank solve): the tag is 16 bits wide, (epoch of the solve << 2 | pass tag) -- 2^-36 of the value, still far below the float the
+// sums are rounded to.  No word of an earlier solve can match, so the regions are never cleared between solves (engine.h XrArgs).
+__device__ __forceinline__ double xr_tag(double v, unsigned tag) { return __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(v) & ~0xffffull) | tag)); }
+__device__ __forceinline__ unsigned xr_tag_of(double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) & 0xffffull); }
 
 // One ELL row of the distance system accumulated in REGISTERS: the contributions of assemble_row (dist.hip), in its order.  There the column
 // of a contribution is a run-time index into an LDS table; here every (contributor, block column) pair has at most two possible
@@ -440,6 +444,8 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
     const bool cut_hi = MR && xr.give_hi > 0 && wg_last >= own_n - xr.give_hi && wg_first < own_n;
     const int hi_first_wg = MR ? max(0, own_n - xr.give_hi) / rows_per_wg : 0;                      // first workgroup that owns such rows
     double* const xr_me = MR ? xr.region[xr.rank] : nullptr;
+    const unsigned etag0 = MR ? (xr.epoch & kXrEpochMask) << 2 : 0u;      // cross-rank tags: (epoch << 2 | pass tag)
+    constexpr int kLocalSpins = MR ? (1 << 24) : (1 << 22);               // MR: a local neighbour may itself be waiting for a late RANK -- the local waits must not expire first
     // the neighbour's mailbox slots this workgroup tags: it is the (lb)-th cut-side workgroup towards the lower neighbour, the (lb - hi_first_wg)-th towards the upper one
     auto peer_tag = [&](int buf, double v) {
         if (cut_lo && lb < kXrPeerTags) __hip_atomic_store(xr.region[xr.rank - 1] + kXrPtag + (1 * 3 + buf) * kXrPeerTags + lb, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);              // (side 1 of the lower rank = tags of its UPPER neighbour)
@@ -520,7 +526,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         // the records of this workgroup's rows are on their way: drained, then the flag the neighbours' pass 0 waits for (plane 7 of buffer 1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) { __hip_atomic_store(gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + lb, (double)(1 + my_xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR) peer_tag(2, 1.0); }
+        if (tid == 0) { __hip_atomic_store(gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + lb, (double)(1 + my_xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR) peer_tag(2, xr_tag(1.0, etag0 | 1u)); }
     }
     float rhsNorm2 = (float)bb;
     float thr = pcg_threshold(rhsNorm2);
@@ -554,7 +560,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
                 double seen = 0.0;
                 while (k > 0 ? gran_tag_of(seen = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != want : (seen = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0.0) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
+                    if (++spins > kLocalSpins || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
                 }
                 if (ASM && k == 0 && (int)seen != 1 + my_xcc) s_foreign = 1;      // (the relation is symmetric: whoever gathers from this workgroup is in [nlo, nhi])
             }
@@ -566,7 +572,8 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
                 if (tid >= 64 && tid < 192 && j < (side ? xr.wait_hi : xr.wait_lo) && (side ? need_hi : need_lo)) {
                     int spins = 0;
                     const double* wp = xr_me + kXrPtag + (side * 3 + (k > 0 ? ((k - 1) & 1) : 2)) * kXrPeerTags + j;
-                    while (k > 0 ? gran_tag_of(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != want : __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0.0) {
+                    const unsigned wantx = etag0 | (k > 0 ? want : 1u);      // (prologue flag: pass tag 1 in buffer 2)
+                    while (xr_tag_of(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != wantx) {
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > (1 << 24) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
                     }
@@ -630,7 +637,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
                     if (ASM && k == 1) { v[7] = __hip_atomic_load(gp + (size_t)7 * kSolveMaxBlocks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = ok && gran_tag_of(v[7]) == want; }   // |b|^2 travels with the sums of pass 0
                     if (!ok) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1 << 22) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
+                        if (++spins > kLocalSpins || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
                     }
                 }
             }
@@ -651,7 +658,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
                 // granules; every workgroup then adds the R granules of its own region in rank order (one fixed tree: the same bits on every rank).
                 const int pb = (k - 1) & 1;
                 if (lb == 0 && tid < 8 && (tid < kCgfSums || (ASM && k == 1))) {
-                    const double mine = gran_tag(tid < kCgfSums ? t[tid] : bb, want);
+                    const double mine = xr_tag(tid < kCgfSums ? t[tid] : bb, etag0 | want);
                     for (int r = 0; r < xr.n_ranks; ++r) __hip_atomic_store(xr.region[r] + kXrRankGran + (pb * 8 + tid) * kXrMaxRanks + xr.rank, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 double rv[8];
@@ -662,8 +669,8 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
                     while (!ok) {
                         ok = true;
 #pragma unroll
-                        for (int q = 0; q < kCgfSums; ++q) { rv[q] = __hip_atomic_load(xr_me + kXrRankGran + (pb * 8 + q) * kXrMaxRanks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = ok && gran_tag_of(rv[q]) == want; }
-                        if (ASM && k == 1) { rv[7] = __hip_atomic_load(xr_me + kXrRankGran + (pb * 8 + 7) * kXrMaxRanks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = ok && gran_tag_of(rv[7]) == want; }
+                        for (int q = 0; q < kCgfSums; ++q) { rv[q] = __hip_atomic_load(xr_me + kXrRankGran + (pb * 8 + q) * kXrMaxRanks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = ok && xr_tag_of(rv[q]) == (etag0 | want); }
+                        if (ASM && k == 1) { rv[7] = __hip_atomic_load(xr_me + kXrRankGran + (pb * 8 + 7) * kXrMaxRanks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = ok && xr_tag_of(rv[7]) == (etag0 | want); }
                         if (!ok) {
                             __builtin_amdgcn_s_sleep(1);
                             if (++spins > (1 << 24) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
@@ -735,7 +742,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             double* gq = gran + (size_t)(k & 1) * kSolveGranPlanes * kSolveMaxBlocks + (size_t)tid * kSolveMaxBlocks + lb;
             __hip_atomic_store(gq, gran_tag(tot, (unsigned)(k + 1) & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (MR && tid == 64) peer_tag(k & 1, gran_tag(1.0, (unsigned)(k + 1) & 3u));      // (every wave drained its stores before the barrier above: the halo records are out)
+        if (MR && tid == 64) peer_tag(k & 1, xr_tag(1.0, etag0 | ((unsigned)(k + 1) & 3u)));      // (every wave drained its stores before the barrier above: the halo records are out)
         __syncthreads();
         SOLVE_STAMP(6);
         if (force_passes > 0 && k == 8 && tid == 0) fs[16 + lb] = (double)wall_clock64();                 // timing hook: when every workgroup published pass 8 ...

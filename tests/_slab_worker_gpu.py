@@ -63,7 +63,7 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
     np.savez(out + f".rank{rank}.npz", dist=v["dist"], rgb=v["rgb"], grad=v["grad"], poses=eng.download_poses(), light=eng.download_light(),
              e_total=[r["e_total"] for r in recs], cg=[r["cg_iters"] for r in recs], e0=e0, band=eng.download_band(info["row1"] - info["row0"]),
              info=[info["row0"], info["row1"], info["halo"], info["S"], info["need_lo"], info["need_hi"], info["z0"], info["z1"], info["rows"]],
-             ncoll=eng.comm_stats(), dim=list(eng.info().dim), n_band=eng.info().n_band, xr=[eng.debug_sync_stats()[k] for k in ("cross_rank_ready", "cross_rank_solves", "persist_fallbacks")])
+             ncoll=eng.comm_stats(), dim=list(eng.info().dim), n_band=eng.info().n_band, xr=[eng.debug_sync_stats()[k] for k in ("cross_rank_ready", "cross_rank_solves", "persist_fallbacks", "cross_rank_mem_kind", "probe_stale", "probe_timeouts")])
     eng.close()
     if tr is not None:
         dist.barrier(); dist.destroy_process_group()

@@ -46,7 +46,7 @@ def stitch(res, key):
     return out
 
 
-@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("SH1", 2, "gloo-xr0"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH2", 2, "gloo"),
+@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("SH1", 2, "gloo-xr0"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH1", 4, "gloo"), ("SH2", 2, "gloo"),
                                                    ("SH1+reg", 2, "gloo")])
 def test_native_slab_loop_matches_single_context(built, tmp_path, model, world, transport):
     N, n_iters = 40, 2
@@ -77,7 +77,9 @@ def test_native_slab_loop_matches_single_context(built, tmp_path, model, world, 
         if world > 1:
             assert halo > 0 and (need_lo > 0 or need_hi > 0)        # the sphere is cut through: stencils cross the cut, halos really move
             assert rows < 0.8 * S                                     # a rank holds its slab (+ halo planes), not the whole band
-            xr_ready, xr_solves, fallbacks = (int(x) for x in got["xr"])
+            xr_ready, xr_solves, fallbacks, mem_kind, probe_stale, probe_to = (int(x) for x in got["xr"])
+            # the hand-off probe ran between the real neighbours (here: processes sharing one GPU) and chose the memory kind of the record planes
+            assert (mem_kind == 0 if transport == "gloo-xr0" else mem_kind == 1) and probe_stale == 0 and probe_to == 0
             if transport == "gloo-xr0":
                 assert xr_ready == 0 and xr_solves == 0 and got["ncoll"] > 40     # ~2 exchanges per PCG pass
             else:
@@ -164,12 +166,20 @@ def test_rccl_path_with_two_ranks_on_one_device_fails_cleanly(built, tmp_path):
         assert rc == 3 and "COMM_ERROR" in o and "ncclCommInitRank" in o and "rc=-5" in o, o[-1500:]
 
 
-def test_cross_rank_persistent_solve_on_disjoint_cu_halves(built, tmp_path):
+@pytest.mark.parametrize("masks,memkind", [("0:128,128:256", None), ("0:64,64:128,128:192,192:256", None), ("0:128,128:256", "uncached")])
+def test_cross_rank_persistent_solve_on_disjoint_cu_halves(built, tmp_path, masks, memkind):
     """the persistent distance solve ACROSS ranks, developed on the one-GPU box by giving each of two ranks half the CUs
     (PSGSDF_CU_MASK -> hipExtStreamCreateWithCUMask), so that both persistent kernels are resident while they exchange halo records and rank sums
-    through IPC-mapped memory: 96^3, two iterations, against the single-context engine to 1e-4 voxel."""
+    through IPC-mapped memory: 96^3, two iterations, against the single-context engine to 1e-4 voxel.  Four ranks on CU quarters: a
+    rank's granules reach ranks that are not its neighbours, possibly before those have even started their solve -- the epoch tags make that harmless.
+    "uncached": the record planes in hipDeviceMallocUncached memory (what the probe falls back to if fine-grained memory does not carry the
+    hand-offs between two real devices)."""
     N, n_iters = 96, 2
-    res = run_ranks(tmp_path, "SH1", 2, "gloo", "iterate", N, n_iters, {"SLAB_CU_MASKS": "0:128,128:256"})
+    world = masks.count(",") + 1
+    env = {"SLAB_CU_MASKS": masks}
+    if memkind:
+        env["PSGSDF_XR_MEM"] = memkind
+    res = run_ranks(tmp_path, "SH1", world, "gloo", "iterate", N, n_iters, env)
     sc = synth.make_scene(N=N, F=6, W=160, H=120, model="SH1")
     ref = capi.load_engine(sc, sc.K, capi.default_settings(capi.SH1), 0); ref.load_scene(sc)
     ref.init_albedo(); ref.normalize_weights()
@@ -177,6 +187,7 @@ def test_cross_rank_persistent_solve_on_disjoint_cu_halves(built, tmp_path):
     band = ref.download_band(); v = ref.download_volume(); vs = float(sc.voxel_size)
     for got in res:
         assert int(got["xr"][0]) == 1 and int(got["xr"][1]) >= 1 and int(got["xr"][2]) <= 1      # (a fallback under host load is tolerated, see above)
+        assert int(got["xr"][3]) == (2 if memkind == "uncached" else 1) and int(got["xr"][4]) == 0 and int(got["xr"][5]) == 0
         assert np.allclose(got["e_total"], [x["e_total"] for x in recs], rtol=5e-6)
         assert np.all(np.abs(got["cg"] - np.array([x["cg_iters"] for x in recs])) <= 1)
     d = stitch(res, "dist")
