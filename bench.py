@@ -10,8 +10,12 @@ scene, inputs resident in HBM before the timed region.  Prints ONE JSON line on 
 callback (device drained + barrier on both sides).  The same scene through psgsdf_iterate (no stop decision, nothing to wait for)
 is reported next to it (`iterate_ms_per_step`).  The LED (configs[3]) and SH2 workloads ride along as `extra`.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 256] [--frames 50] [--model SH1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R] [--grid 256] [--frames 50] [--model SH1]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself, one process per device; with fewer than N devices visible it exits
+non-zero (PSGSDF_BENCH_SHARE_GPU=1: all ranks on GPU 0 over the gloo test transport -- a functional check, not a measurement).  The line never
+reports an n_gpus other than --gpus.  `value` is the MEDIAN over R repetitions of the K-step bracket (fresh contexts each), `spread` their min / max.
 
 N > 1: weak scaling over z-slabs.  The grid grows to 256 x 256 x (256*N) -- N copies of the scene stacked
 along z, each with its own 50 keyframes -- one process per GPU owns one slab and calls the SAME psgsdf_iterate: the engine's C++ host
@@ -56,14 +60,15 @@ def algorithmic_bytes(kernel, S, n_obs, W, H, F, laplacian=False, pcg_passes=1.0
     return table.get(kernel)
 
 
-def timed_optimize(make_engine, torch, dist, steps, warmup, before_timed=None, after_call=None):
-    """K = `steps` iterations of the product loop psgsdf_optimize, bracketed by device synchronisation (+ barrier over the ranks) on both sides.
-    The loop leaves on its own when the energy stops falling (the reference's divergence exit, PsOptimizer.cpp:377-384; ~18 iterations on the
-    headline scene), so: one UNTIMED call first (the warm-up: >= `warmup` iterations, and it tells how many iterations a call survives), then
-    as many timed calls as needed, each on a FRESH context (psgsdf_optimize normalises the regulariser weights in place), each skipping its
-    first iteration and ending ITSELF after its share of the K steps, before the divergence exit would.  The brackets are taken in a passive
-    record observer (psgsdf_set_record_observer), so the loop being timed is the callback-free one with its speculative start of the next
-    iteration.  Returns (elapsed seconds or None if the loop does not survive 3 iterations, records of the timed iterations, calls)."""
+def timed_optimize(make_engine, torch, dist, steps, warmup, reps=1, before_timed=None, after_call=None):
+    """`reps` repetitions of: K = `steps` iterations of the product loop psgsdf_optimize, bracketed by device synchronisation (+ barrier over the
+    ranks) on both sides.  The loop leaves on its own when the energy stops falling (the reference's divergence exit, PsOptimizer.cpp:377-384; ~18
+    iterations on the headline scene), so: one UNTIMED call first (the warm-up: >= `warmup` iterations, and it tells how many iterations a call
+    survives), then as many timed calls as needed, each on a FRESH context (psgsdf_optimize normalises the regulariser weights in place), each
+    skipping its first iteration and ending ITSELF after its share of the K steps, before the divergence exit would.  The brackets are taken in a
+    passive record observer (psgsdf_set_record_observer), so the loop being timed is the callback-free one with its speculative start of the next
+    iteration.  Returns (list of elapsed seconds per repetition -- None if the loop does not survive 3 iterations --, records of the timed
+    iterations of the first repetition, calls)."""
     import time as _t
 
     def sync():
@@ -80,39 +85,86 @@ def timed_optimize(make_engine, torch, dist, steps, warmup, before_timed=None, a
     calls = 1
     if survive < 3:
         return None, recs0, calls
-    elapsed, timed = 0.0, []
-    while len(timed) < steps:
-        need = min(steps - len(timed), survive - 1)
-        seg = {"t0": None, "t1": None, "recs": []}
-        eng = make_engine()
+    elapsed_reps, first_recs = [], []
+    for rep in range(reps):
+        elapsed, timed = 0.0, []
+        while len(timed) < steps:
+            need = min(steps - len(timed), survive - 1)
+            seg = {"t0": None, "t1": None, "recs": []}
+            eng = make_engine()
 
-        def on_record(done, rec, seg=seg, need=need, eng=eng):
-            if done == 1:
-                if before_timed and not timed:
-                    before_timed(eng)
-                sync(); seg["t0"] = _t.perf_counter()
+            def on_record(done, rec, seg=seg, need=need, eng=eng, first=(rep == 0 and not timed)):
+                if done == 1:
+                    if before_timed and first:
+                        before_timed(eng)
+                    sync(); seg["t0"] = _t.perf_counter()
+                    return False
+                seg["recs"].append(rec)
+                if done == 1 + need:
+                    sync(); seg["t1"] = _t.perf_counter()
+                    return True                   # end the loop here: this call's share of the K timed steps is done
                 return False
-            seg["recs"].append(rec)
-            if done == 1 + need:
-                sync(); seg["t1"] = _t.perf_counter()
-                return True                   # end the loop here: this call's share of the K timed steps is done
-            return False
 
-        eng.set_record_observer(on_record)      # passive: psgsdf_optimize keeps its speculative start of the next iteration (no on_iter callback)
-        eng.optimize(capi.ALL, cap=warmup + steps + 8)
-        sync()
-        if after_call:
-            after_call(eng, calls - 1)
-        eng.close()
-        calls += 1
-        if seg["t1"] is None:                   # the loop ended earlier than the untimed call did (cannot happen: same scene, same bits)
-            return None, timed, calls
-        elapsed += seg["t1"] - seg["t0"]; timed += seg["recs"]
-    return elapsed, timed, calls
+            eng.set_record_observer(on_record)      # passive: psgsdf_optimize keeps its speculative start of the next iteration (no on_iter callback)
+            eng.optimize(capi.ALL, cap=warmup + steps + 8)
+            sync()
+            if after_call:
+                after_call(eng, calls - 1)
+            eng.close()
+            calls += 1
+            if seg["t1"] is None:                   # the loop ended earlier than the untimed call did (cannot happen: same scene, same bits)
+                return None, timed, calls
+            elapsed += seg["t1"] - seg["t0"]; timed += seg["recs"]
+        elapsed_reps.append(elapsed)
+        if rep == 0:
+            first_recs = timed
+    return elapsed_reps, first_recs, calls
+
+
+def attach_comm(eng, dist, rank, world, share):
+    """attach a context to its rank: the engine's own RCCL communicator (the id travels through torch's process group), or -- all ranks sharing
+    GPU 0 -- the caller-supplied gloo transport of the tests (RCCL refuses two ranks per device)"""
+    if share:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _gloo_transport import GlooTransport
+        eng._transport = GlooTransport(dist)
+        eng.comm_init_ext(eng._transport.ops, rank, world)
+    else:
+        ident = [capi.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        eng.comm_init(rank, world, ident[0])
+
+
+def self_check(dist, rank, world, device, share):
+    """Before anything is timed on N > 1 ranks: the N-rank slab run against a single-context run of the same small scene (64^3, 8 keyframes, SH1,
+    two iterations) on this rank's own device -- e_total to 1e-5 relative.  A wrong exchange shows here, not as a fast wrong number."""
+    sc = synth.make_scene(N=64, F=8, W=160, H=120, model="SH1")
+    st = capi.default_settings(capi.SH1)
+    eng = capi.load_engine(sc, sc.K, st, device)
+    attach_comm(eng, dist, rank, world, share)
+    eng.load_scene_slab(sc, rank, world)
+    eng.init_albedo(); eng.normalize_weights()
+    e_n = [float(r["e_total"]) for r in eng.iterate(capi.ALL, 2)]
+    eng.close()
+    ref = capi.load_engine(sc, sc.K, st, device)
+    ref.load_scene(sc); ref.init_albedo(); ref.normalize_weights()
+    e_1 = [float(r["e_total"]) for r in ref.iterate(capi.ALL, 2)]
+    ref.close()
+    rel = max(abs(a - b) / abs(b) for a, b in zip(e_n, e_1))
+    worst = [None] * world
+    dist.all_gather_object(worst, rel)
+    rel = max(worst)
+    return {"scene": "64^3 x 8 keyframes, SH1, 2 iterations", "e_total_ranks": e_n, "e_total_single": e_1, "rel_diff": rel, "tol": 1e-5, "ok": bool(rel <= 1e-5)}
+
+
+STATE_STATS = ("cross_rank_ready", "cross_rank_mem_kind")      # states, not counters: never summed over contexts
 
 
 def measure(args, model, torch, dist, rank, world, device, slab, share, headline):
     """one workload: scene, contexts, the timed loop; returns the fields of the JSON line for it"""
+    reps = max(1, args.reps)
+    planes_of = None
     t_gen = time.time()
     use_u8 = args.u8_images
     scene_kw = dict(N=args.grid, F=args.frames, W=args.width, H=args.height, model=model, u8=use_u8)
@@ -133,23 +185,14 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
     if model == "LED":   # config_basket_LED.json
         st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0
     if world > 1 and not args.strong:
-        sc = synth.tile_scene(sc, world)
-    slab_rows = []
+        # weak scaling: `world` copies of the scene stacked along z, every rank building only the planes it is asked for (never the n-fold volume)
+        sc, planes_of = synth.tile_scene_lazy(sc, world)
 
     def context(settings):
         eng = capi.load_engine(sc, sc.K, settings, device)
         if slab:
-            if share:
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                from _gloo_transport import GlooTransport
-                eng._transport = GlooTransport(dist)
-                eng.comm_init_ext(eng._transport.ops, rank, world)
-            else:
-                ident = [capi.comm_unique_id() if rank == 0 else None]
-                if world > 1:
-                    dist.broadcast_object_list(ident, src=0)
-                eng.comm_init(rank, world, ident[0])
-        if args.strong:
+            attach_comm(eng, dist, rank, world, share)
+        if args.strong or world > 1:
             eng.load_scene_slab(sc, rank, world, planes=planes_of, u8=use_u8)
         else:
             eng.load_scene(sc, u8=use_u8)
@@ -224,31 +267,88 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
             e.watch_kernel("")
         s2 = e.debug_sync_stats()
         for k in sync_stats:
-            sync_stats[k] += s2[k]
-    t_opt, recs_opt, opt_calls = timed_optimize(lambda: context(st2), torch, dist, args.steps, args.warmup, before_timed, after_call)
+            sync_stats[k] = max(sync_stats[k], s2[k]) if k in STATE_STATS else sync_stats[k] + s2[k]
+    t_reps, recs_opt, opt_calls = timed_optimize(lambda: context(st2), torch, dist, args.steps, args.warmup, reps if headline else 1, before_timed, after_call)
     if use_watch and not timing_iterate:
         watched = watched_opt[0]
 
-    def over_ranks(x):
+    def over_ranks(x):      # MAX over the ranks (the contract's clock: the slowest rank)
         if dist is None or x is None:
             return x
-        tt = torch.tensor([x], dtype=torch.float64, device=f"cuda:{device}")
+        if share:           # (gloo group: CPU tensors)
+            tt = torch.tensor(list(x) if isinstance(x, (list, tuple)) else [x], dtype=torch.float64)
+        else:
+            tt = torch.tensor(list(x) if isinstance(x, (list, tuple)) else [x], dtype=torch.float64, device=f"cuda:{device}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
-    t_iter, t_opt = over_ranks(t_iter), over_ranks(t_opt)
+        return [float(v) for v in tt.tolist()] if isinstance(x, (list, tuple)) else float(tt.item())
+    t_iter, t_reps = over_ranks(t_iter), over_ranks(t_reps)
+    t_opt = float(np.median(t_reps)) if t_reps else None
+    if dist is not None:      # hand-off statistics of every rank: a fallback anywhere shows in the line
+        gathered = [None] * world
+        dist.all_gather_object(gathered, sync_stats)
+        for k in sync_stats:
+            sync_stats[k] = max(g[k] for g in gathered) if (k in STATE_STATS or k == "persist_fallbacks") else sync_stats[k]
 
-    loop = f"psgsdf_optimize ({opt_calls - 1} timed call{'s' if opt_calls != 2 else ''} after one untimed)"
+    loop = f"psgsdf_optimize ({opt_calls - 1} timed call{'s' if opt_calls != 2 else ''} on fresh contexts after one untimed, {reps if headline else 1} repetition{'s' if (reps if headline else 1) != 1 else ''} of the {args.steps}-step bracket)"
     if timing_iterate or t_opt is None:
         elapsed, recs = t_iter, recs_it
         loop = "psgsdf_iterate" + ("" if timing_iterate else " (psgsdf_optimize does not survive 3 iterations on this scene)")
     else:
         elapsed, recs = t_opt, recs_opt
     cg_iters = float(np.mean([r["cg_iters"] for r in recs]))
-    res = dict(model=model, value=(1 if args.strong else world) * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, loop=loop, S=int(S), n_obs=int(n_obs), cg_iters=cg_iters,
+    mult = 1 if args.strong else world
+    spread = None
+    if t_reps and not (timing_iterate or t_opt is None):
+        vals = [mult * args.steps / t for t in t_reps]
+        spread = {"reps": len(vals), "min": min(vals), "max": max(vals), "values": [round(v, 1) for v in vals], "statistic": "value = median over the repetitions of the K-step bracket (fresh contexts each)"}
+    res = dict(model=model, value=mult * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, spread=spread, loop=loop, S=int(S), n_obs=int(n_obs), cg_iters=cg_iters,
                iterate_ms_per_step=1e3 * t_iter / args.steps, optimize_ms_per_step=(1e3 * t_opt / args.steps) if t_opt else None,
                kernels=kernels, dom=dom, watched=watched, t_gen=t_gen, st=st, sc=sc, sync_stats=sync_stats,
                collectives_per_step=(coll1 - coll0) / max(args.steps, 1), use_u8=use_u8, own_rows=own_rows)
     return res
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per device, LOCAL_RANK = device; RANK / WORLD_SIZE / MASTER_* as
+    torch.distributed.run would set them), rank 0 inherits stdout and prints the ONE line.  Fewer than N devices -> non-zero exit, unless
+    PSGSDF_BENCH_SHARE_GPU=1 (all ranks on GPU 0 through the gloo test transport: a functional check of the code path, not a measurement)."""
+    import socket
+    import subprocess
+    import torch
+    share = os.environ.get("PSGSDF_BENCH_SHARE_GPU") == "1"
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < n and not share:
+        print(f"bench.py: --gpus {n} needs {n} devices, {ndev} visible (PSGSDF_BENCH_SHARE_GPU=1 runs the ranks on one device as a functional check; it measures nothing)", file=sys.stderr)
+        return 3
+    if share and ndev < 1:
+        print("bench.py: no GPU visible", file=sys.stderr)
+        return 3
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            bad = [p for p in procs if p.poll() not in (None, 0)]
+            if bad:                      # a rank died: the others would wait for it in a collective
+                rc = bad[0].returncode
+                break
+    finally:
+        for p in procs:                  # (exactly the processes started here, by PID)
+            if p.poll() is None:
+                if rc == 0:
+                    p.wait()
+                else:
+                    p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+    return rc or max((p.returncode or 0) for p in procs)
 
 
 def main():
@@ -256,6 +356,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step bracket (fresh contexts each): value = their median, spread = min / max")
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--frames", type=int, default=50)
     ap.add_argument("--width", type=int, default=640)
@@ -271,6 +372,14 @@ def main():
     args = ap.parse_args()
     if args.strong and (args.grid, args.frames, args.model) == (256, 50, "SH1"):      # nothing chosen explicitly: BASELINE configs[4]
         args.grid, args.frames, args.model = 512, 100, "SH2"
+
+    # ---- N ranks.  Under a launcher (torch.distributed.run: WORLD_SIZE set) this process IS one of the N ranks; without one, --gpus N > 1
+    # starts the N ranks here.  Either way the line reports --gpus ranks or nothing.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE')} ranks: refusing to print a line whose n_gpus differs from --gpus", file=sys.stderr)
+        sys.exit(2)
 
     if os.environ.get("PSGSDF_FAULT_DUMP"):   # diagnostics: dump every thread's Python stack after N seconds and exit
         import faulthandler
@@ -302,6 +411,7 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     device = local_rank if world > 1 else 0
 
+    check = self_check(dist, rank, world, device, share) if world > 1 else None
     m = measure(args, args.model, torch, dist, rank, world, device, slab, share, headline=True)
     S, n_obs, cg_iters, kernels, dom, watched, st, sc = m["S"], m["n_obs"], m["cg_iters"], m["kernels"], m["dom"], m["watched"], m["st"], m["sc"]
     use_u8 = m["use_u8"]
@@ -321,7 +431,17 @@ def main():
         "iterate_ms_per_step": m["iterate_ms_per_step"],      # psgsdf_iterate: the same iterations without a stop decision (round-2 `value`)
         "iterate_value": (1 if args.strong else world) * 1e3 / m["iterate_ms_per_step"],
         "optimize_ms_per_step": m["optimize_ms_per_step"],
+        "spread": m["spread"],
     }
+    if world > 1:
+        ss = m["sync_stats"]
+        kinds = {-1: "not probed", 0: "none (cross-rank solve off)", 1: "fine-grained", 2: "uncached", 3: "coarse (pinned)"}
+        out["multi_gpu"] = {"ranks": world, "transport": "gloo test transport, all ranks on GPU 0 (functional check only)" if share else "rccl", "rccl_ranks": 0 if share else world,
+                            "cross_rank_ready": int(ss["cross_rank_ready"]), "cross_rank_solves": int(ss["cross_rank_solves"]), "persist_fallbacks": int(ss["persist_fallbacks"]),
+                            "hand_off_memory": kinds.get(int(ss["cross_rank_mem_kind"]), "?"), "probe_stale_records": int(ss["probe_stale"]), "probe_timeouts": int(ss["probe_timeouts"]),
+                            "collectives_per_step": m["collectives_per_step"], "self_check": check}
+        # degraded: the line is not the design's N-GPU figure -- the cross-rank persistent solve is off or fell back, or the N-rank result is wrong
+        out["degraded"] = bool(not ss["cross_rank_ready"] or ss["persist_fallbacks"] > 0 or not check["ok"])
 
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live with HIP events inside the timed region
@@ -365,7 +485,16 @@ def main():
         out["iteration"] = {"algorithmic_bytes": B_iter, "achieved_GBs": B_iter * (m["value"] / world) / 1e9,
                             "frac_of_hbm_peak": B_iter * (m["value"] / world) / 1e9 / HBM_PEAK_GBS}
         if kernels:
-            out["kernels"] = {k: round(v["ms_per_iter"], 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_iter"])}
+            # A SYNCHRONOUS-event pass over psgsdf_iterate (every launch bracketed by an event pair and a host wait: ~4 us of overhead per launch, and
+            # `energy`, which the product loop folds into the next sweep, runs as a kernel of its own here): it ranks the kernels, it does not add
+            # up to ms_per_step.  The table that does is rocprofv3's (kernels_rocprof).
+            out["kernels_sync_pass"] = {k: round(v["ms_per_iter"], 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_iter"])}
+            ks = os.path.join(ROOT, "profiles", "kernel_stats_summary.json")
+            if os.path.exists(ks) and (args.grid, args.frames, args.model, world) == (256, 50, "SH1", 1):
+                try:
+                    out["kernels_rocprof"] = json.load(open(ks))      # static: rocprofv3 --kernel-trace --stats of this command at the stamped commit (us per iteration, sums to the iteration)
+                except Exception:
+                    pass
             # per-kernel roofline fractions from the same synchronous-event pass (events add ~4 us per launch: fractions err low)
             out["kernel_roofline_frac"] = {k: round(algorithmic_bytes(k, S, n_obs, args.width, args.height, args.frames, lap, pcg_passes=cg_iters + 1.0) / (v["ms_per_iter"] / max(v["launches_per_iter"], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
                                            for k, v in kernels.items() if algorithmic_bytes(k, 1, 1, 1, 1, 1) and v["ms_per_iter"] > 0}
@@ -386,6 +515,24 @@ def main():
                                    "sample": f"1 full Gauss-Newton iteration of the same {args.grid}^3 x {args.frames} scene "
                                              f"(4 blocks + 4 energy evaluations), single-threaded C oracle with indexed band lookup, {tc:.1f} s"}
             orc.close()
+            # SURVEY 8d(i) "faithful mode": the reference tests band membership with std::find over the band list (Optimizer.cpp:470 and eight more
+            # sites), O(S) per test.  Measured on a 64^3 crop (8 keyframes, 320x240) with the oracle's look-ups switched to that linear scan, the
+            # excess over the indexed run extrapolated by its law: excess ~ (membership tests ~ N_obs) x (scan length ~ S).
+            scf = synth.make_scene(N=64, F=8, W=320, H=240, model=args.model)
+            tf = []
+            for faithful in (False, True):
+                orc = oracle.Oracle(scf, scf.K, st, threads=1)
+                orc.load_scene(scf); orc.init_albedo(); orc.normalize_weights()
+                orc.set_faithful(faithful)
+                t0 = time.perf_counter(); orc.iterate(capi.ALL, 1); tf.append(time.perf_counter() - t0)
+                if not faithful:
+                    Sf, nof = int(orc.info().n_band), int(orc.step(capi.ALBEDO)["n_obs"])
+                orc.close()
+            excess = max(tf[1] - tf[0], 0.0) * (float(n_obs) * float(S)) / (float(nof) * float(Sf))
+            out["cpu_baseline"]["faithful"] = {"value": 1.0 / (tc + excess), "unit": "it/s", "cores": 1, "kind": "port, std::find membership (extrapolated)",
+                                               "sample": f"64^3 x 8-keyframe crop (band {Sf}, {nof} observations): 1 iteration indexed {tf[0]:.2f} s, with linear std::find-style membership {tf[1]:.2f} s; "
+                                                         f"the excess scaled by (N_obs x S) = ({n_obs} x {S}) / ({nof} x {Sf}) and added to the indexed full-size iteration ({tc:.1f} s): {tc + excess:.0f} s per iteration -- an EXTRAPOLATION, not a measurement at full size"}
+            del scf
             # the same port with its sweeps spread over the host's cores (OpenMP): informative only, `value` stays the one-core figure
             nthr = min(64, os.cpu_count() or 1)
             if nthr > 1:

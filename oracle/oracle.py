@@ -36,6 +36,10 @@ class Oracle(capi.Api):
         self._lib.orc_set_solver_mode(self.ctx, C.c_int(solver_mode))
         self._lib.orc_set_threads(self.ctx, C.c_int(threads))
 
+    def set_faithful(self, on=True):
+        """band membership as the reference does it (std::find over surface_points_, O(S) per test) instead of the row_of table: same results"""
+        self._lib.orc_set_faithful(self.ctx, C.c_int(1 if on else 0))
+
     def set_solver_mode(self, mode):
         self._lib.orc_set_solver_mode(self.ctx, C.c_int(mode))
 

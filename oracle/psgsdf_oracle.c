@@ -87,6 +87,8 @@ typedef struct orc_ctx {
     float *cg_x, *cg_r, *cg_t, *cg_p, *cg_inv; double* cg_sc;
     void* mg_sys; /* dist_sys* of the current solve */
     int solver_mode; /* 0 = direct per-block solves, 1 = Eigen-style global Jacobi-PCG */
+    int faithful;    /* 1 = band membership as the reference does it: std::find over surface_points_ (Optimizer.cpp:470), O(S) per look-up */
+    long long n_find; /* look-ups made through band_find (both modes) */
     int threads;
     char err[256];
     /* last dist system (debug) */
@@ -226,6 +228,16 @@ static int get_intensity(const orc_ctx* c, int lin, int f, const float R[9], con
     return 1;
 }
 
+/* Band row of linear index ln, or -1.  Indexed mode (default): the row_of table.  Faithful mode (orc_set_faithful): what the
+ * reference does at every one of its membership tests -- std::find(surface_points_.begin(), surface_points_.end(), lin_idx), a linear
+ * scan of the ascending band list (Optimizer.cpp:470,520,565,574,628; PsOptimizerJa.cpp:523,541; LedOptimizerJa.cpp:444,462).  Same
+ * result, O(S) per look-up: the reference's dominant cost. */
+static inline int band_find(const orc_ctx* c, size_t ln) {
+    if (!c->faithful) return c->row_of[ln];
+    const int* b = c->band; const int S = c->S, key = (int)ln;
+    for (int i = 0; i < S; ++i) if (b[i] == key) return i;
+    return -1;
+}
 /* Optimizer.cpp:462-474 ifValidDirection(idx, +1, pos): bound test is `>` (B2), membership by
  * linear index (std::find over surface_points_ == row_of lookup). */
 static inline int valid_forward(const orc_ctx* c, int lin, const int idx[3], int pos) {
@@ -233,7 +245,7 @@ static inline int valid_forward(const orc_ctx* c, int lin, const int idx[3], int
     size_t stride = pos == 0 ? 1 : (pos == 1 ? (size_t)c->dim[0] : (size_t)c->dim[0] * c->dim[1]);
     size_t ln = (size_t)lin + stride;
     if (ln >= c->nvox) return 0;
-    return c->row_of[ln] >= 0;
+    return band_find(c, ln) >= 0;
 }
 static inline float dist_at(const orc_ctx* c, long lin, float fallback) {
     if (lin < 0 || (size_t)lin >= c->nvox) return fallback; /* reference reads out of bounds here (UB) */
@@ -623,7 +635,7 @@ static int step_albedo_reg(orc_ctx* c, const float* Hd, const float* bd, float* 
         for (int ch = 0; ch < 3; ++ch) {
             int col[4]; float e[4]; int m = 0;
             col[m] = 3 * j + ((ch == 2 && c->set.ref_quirks) ? 1 : ch); e[m] = J[0][ch]; m++;
-            for (int a = 0; a < 3; ++a) { int r = (nb[a] != (long)c->band[j]) ? c->row_of[nb[a]] : -1; if (r >= 0) { col[m] = 3 * r + ch; e[m] = J[a + 1][ch]; m++; } }
+            for (int a = 0; a < 3; ++a) { int r = (nb[a] != (long)c->band[j]) ? band_find(c, (size_t)nb[a]) : -1; if (r >= 0) { col[m] = 3 * r + ch; e[m] = J[a + 1][ch]; m++; } }
             for (int p = 0; p < m; ++p) { rhs[col[p]] += (double)c->reg_r * (double)e[p] * (double)res[ch];
                 for (int q = 0; q < m; ++q) { coo[nc].key = (long long)col[p] * n + col[q]; coo[nc].v = (double)c->reg_r * (double)e[p] * (double)e[q]; nc++; } }
         }
@@ -957,7 +969,7 @@ static void dist_system(const orc_ctx* c, int normal_reg, int laplacian_reg, dis
         cols[0] = j;
         for (int a = 0; a < 3; ++a) {
             long ln = (long)lin + (long)dir[a] * stride[a];
-            cols[a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? c->row_of[ln] : -1;
+            cols[a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? band_find(c, (size_t)ln) : -1;
         }
         for (int f = 0; f < c->F; ++f) {
             if (!vis_bit(c, lin, f)) continue;
@@ -1007,7 +1019,7 @@ static void dist_assemble(const orc_ctx* c, dist_sys* s) {
         if (j >= c->row0 && j < c->row1) continue;
         int lin = c->band[j]; int idx[3]; line2idx(c, lin, idx);
         s->cols[4 * j] = j;
-        for (int a = 0; a < 3; ++a) { float dir = valid_forward(c, lin, idx, a) ? 1.0f : -1.0f; long ln = (long)lin + (long)dir * stride[a]; s->cols[4 * j + a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? c->row_of[ln] : -1; }
+        for (int a = 0; a < 3; ++a) { float dir = valid_forward(c, lin, idx, a) ? 1.0f : -1.0f; long ln = (long)lin + (long)dir * stride[a]; s->cols[4 * j + a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? band_find(c, (size_t)ln) : -1; }
     }
     size_t ncoo = 0; coo_t* coo = (coo_t*)malloc(sizeof(coo_t) * 16 * (size_t)(S + 1));
     double* rhs = (double*)calloc(S + 1, sizeof(double));
@@ -1177,7 +1189,7 @@ static void mg_setup(orc_ctx* c) {
             if ((ox != 0) + (oy != 0) + (oz != 0) > 2) continue;
             long ln = (long)c->band[i] + ox * st[0] + oy * st[1] + oz * st[2];
             if (ln < 0 || (size_t)ln >= c->nvox) continue;
-            int r = c->row_of[ln]; if (r < 0) continue;
+            int r = band_find(c, (size_t)ln); if (r < 0) continue;
             if (r < c->row0 && c->row0 - r > c->need[0]) c->need[0] = c->row0 - r;
             if (r >= c->row1 && r - c->row1 + 1 > c->need[1]) c->need[1] = r - c->row1 + 1;
         }
@@ -1418,6 +1430,8 @@ void orc_destroy(orc_ctx* c) {
 const char* orc_last_error(const orc_ctx* c) { return c ? c->err : "null context"; }
 const char* orc_version(void) { return "psgsdf-oracle cpu (test infrastructure)"; }
 int orc_set_solver_mode(orc_ctx* c, int mode) { c->solver_mode = mode; return 0; }
+/* 1: every band-membership test is the reference's std::find over the band list (SURVEY 8d(i) "faithful mode"; same results, O(S) per test) */
+int orc_set_faithful(orc_ctx* c, int on) { c->faithful = on; return 0; }
 int orc_set_threads(orc_ctx* c, int n) { c->threads = n > 0 ? n : 1; return 0; }
 
 static float* dupf(const float* p, size_t n) { float* q = (float*)malloc(sizeof(float) * n); memcpy(q, p, sizeof(float) * n); return q; }
@@ -1842,7 +1856,7 @@ int orc_probe_dist_jacobian(orc_ctx* c, int j, int f, float J[12], int rows[4]) 
     if (!dist_jacobian(c, lin, f, R, t, Jb, dir)) return 0;
     long stride[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
     rows[0] = j;
-    for (int a = 0; a < 3; ++a) { long ln = (long)lin + (long)dir[a] * stride[a]; rows[a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? c->row_of[ln] : -1; }
+    for (int a = 0; a < 3; ++a) { long ln = (long)lin + (long)dir[a] * stride[a]; rows[a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? band_find(c, (size_t)ln) : -1; }
     for (int k = 0; k < 4; ++k) for (int ch = 0; ch < 3; ++ch) J[k * 3 + ch] = Jb[k][ch];
     return 1;
 }
@@ -1860,7 +1874,7 @@ int orc_probe_eikonal(orc_ctx* c, int j, float Jr[4], float* res, int rows[4]) {
     eikonal_row(c, lin, Jr, res, dir);
     long stride[3] = {1, c->dim[0], (long)c->dim[0] * c->dim[1]};
     rows[0] = j;
-    for (int a = 0; a < 3; ++a) { long ln = (long)lin + (long)dir[a] * stride[a]; rows[a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? c->row_of[ln] : -1; }
+    for (int a = 0; a < 3; ++a) { long ln = (long)lin + (long)dir[a] * stride[a]; rows[a + 1] = (ln >= 0 && (size_t)ln < c->nvox) ? band_find(c, (size_t)ln) : -1; }
     return 1;
 }
 /* Laplacian residual of band row j (Optimizer.cpp:368-393) and the only Jacobian entry the reference emits (B3): the diagonal -6 / vs^2 */

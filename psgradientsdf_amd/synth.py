@@ -379,3 +379,52 @@ def tile_scene(sc, n):
              images_u8=None if getattr(sc, 'images_u8', None) is None else np.ascontiguousarray(np.tile(sc.images_u8, (n, 1, 1, 1))), poses=poses.reshape(n * F, 16), poses_gt=poses_gt.reshape(n * F, 16),
              light_gt=np.asarray(light, np.float32), frame_idx=np.arange(F * n, dtype=np.int32))
     return Scene(**d)
+
+
+def tile_scene_lazy(sc, n):
+    """tile_scene without ever materialising the n-fold volume: returns (scene, planes) where `scene` carries the grid, the n*F keyframes, poses
+    and lights of the tiled scene but NO per-voxel arrays, and `planes(zlo, zhi)` builds the per-voxel arrays of the z-planes [zlo, zhi) of the
+    tiled volume on demand (capi.load_scene_slab: a rank only ever holds its own slab).  Same bits as tile_scene(sc, n) restricted to the planes."""
+    if n == 1:
+        return sc, None
+    F = sc.F
+    nz = int(sc.dim[2])
+    plane = int(sc.dim[0]) * int(sc.dim[1])
+    wpv = (F * n + 63) // 64
+    poses = np.tile(sc.poses.reshape(1, F, 16), (n, 1, 1)).astype(np.float32)
+    poses_gt = np.tile(sc.poses_gt.reshape(1, F, 16), (n, 1, 1)).astype(np.float32)
+    vs = float(sc.voxel_size)
+    for c in range(n):
+        dz = np.float32(vs * nz * (c - 0.5 * (n - 1)))
+        poses[c, :, 11] += dz
+        poses_gt[c, :, 11] += dz
+    light = sc.light_gt if sc.model == "LED" else np.tile(sc.light_gt, (n, 1))
+    d = {k: v for k, v in sc.__dict__.items() if k not in ("dist", "grad", "weight", "rgb", "albedo_gt", "vis")}
+    d.update(F=F * n, dim=np.array([sc.dim[0], sc.dim[1], nz * n], np.int32), vis_words=wpv,
+             images=np.ascontiguousarray(np.tile(sc.images, (n, 1, 1, 1))),
+             images_u8=None if getattr(sc, 'images_u8', None) is None else np.ascontiguousarray(np.tile(sc.images_u8, (n, 1, 1, 1))),
+             poses=poses.reshape(n * F, 16), poses_gt=poses_gt.reshape(n * F, 16),
+             light_gt=np.asarray(light, np.float32), frame_idx=np.arange(F * n, dtype=np.int32))
+    tiled = Scene(**d)
+
+    def planes(zlo, zhi):
+        dist, grad, weight, rgb, vis = [], [], [], [], []
+        k = zlo
+        while k < zhi:
+            c, kz = divmod(k, nz)
+            k1 = min(zhi, (c + 1) * nz)                 # the part of [zlo, zhi) that lies in copy c
+            sl = slice(kz * plane, (kz + k1 - k) * plane)
+            dist.append(sc.dist[sl]); grad.append(sc.grad[:, sl]); weight.append(sc.weight[sl]); rgb.append(sc.rgb[:, sl])
+            v = np.zeros(((k1 - k) * plane, wpv), np.uint64)
+            src = sc.vis[sl]
+            near = np.nonzero((src != 0).any(axis=1))[0]
+            for f in range(F):
+                g = c * F + f
+                rows = near[((src[near, f >> 6] >> np.uint64(f & 63)) & np.uint64(1)).astype(bool)]
+                v[rows, g >> 6] |= np.uint64(1) << np.uint64(g & 63)
+            vis.append(v)
+            k = k1
+        return dict(dist=np.ascontiguousarray(np.concatenate(dist)), grad=np.ascontiguousarray(np.concatenate(grad, axis=1)),
+                    weight=np.ascontiguousarray(np.concatenate(weight)), rgb=np.ascontiguousarray(np.concatenate(rgb, axis=1)),
+                    vis=np.ascontiguousarray(np.concatenate(vis)))
+    return tiled, planes

@@ -36,27 +36,38 @@ def test_single_gpu_line(built):
 
 
 def test_two_ranks_share_the_gpu(built):
-    """two ranks started the way torch.distributed.run would start them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment; the
-    driver itself covers the launcher at N > 1), both on GPU 0"""
-    port = str(_port())
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, PSGSDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PSGSDF_FAULT_DUMP="90", GLOO_SOCKET_IFNAME="lo",
-                   RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid", "64", "--frames", "8"],
-                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
-    try:
-        outs = [p.communicate(timeout=120) for p in procs]
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-    for p, (o, e) in zip(procs, outs):
-        assert p.returncode == 0, e[-3000:]
-    assert outs[1][0].strip() == ""                     # only rank 0 prints
-    d = _one_json(outs[0][0])
+    """`python bench.py --gpus 2` WITHOUT a launcher starts its two ranks itself; here both on GPU 0 through the gloo test
+    transport (PSGSDF_BENCH_SHARE_GPU=1).  The line carries the multi-GPU block: ranks, cross-rank solves, fallbacks, the hand-off memory the
+    probe chose, collectives per step and the pre-timing self-check (2 ranks vs 1 context, e_total to 1e-5)."""
+    env = dict(os.environ, PSGSDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PSGSDF_FAULT_DUMP="150", GLOO_SOCKET_IFNAME="lo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reps", "2", "--grid", "64", "--frames", "8"],
+                       capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json(r.stdout)                             # only rank 0 prints
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
     assert "cpu_baseline" not in d and d["config"]["collectives_per_step"] > 3      # (cross-rank persistent solve: no per-pass collectives; ~6 exchanges per iteration remain)
+    mg = d["multi_gpu"]
+    assert mg["ranks"] == 2 and mg["rccl_ranks"] == 0 and mg["cross_rank_ready"] == 1 and mg["cross_rank_solves"] > 0 and mg["persist_fallbacks"] <= 1
+    assert mg["hand_off_memory"] == "fine-grained" and mg["probe_stale_records"] == 0 and mg["probe_timeouts"] == 0
+    assert mg["self_check"]["ok"] and mg["self_check"]["rel_diff"] <= 1e-5
+    assert d["degraded"] == (mg["persist_fallbacks"] > 0)
+    assert d["spread"]["reps"] == 2 and d["spread"]["min"] <= d["value"] <= d["spread"]["max"]
+
+
+def test_more_ranks_than_devices_is_refused(built):
+    """`--gpus 2` on the one-GPU box without PSGSDF_BENCH_SHARE_GPU: non-zero exit and no line -- never an n_gpus other than --gpus -- and the
+    same when a launcher's WORLD_SIZE disagrees with --gpus"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PSGSDF_BENCH_SHARE_GPU")}
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "48", "--frames", "6"],
+                           capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+        assert r.returncode != 0 and r.stdout.strip() == "" and "needs 2 devices" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "48", "--frames", "6"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and r.stdout.strip() == "" and "WORLD_SIZE" in r.stderr
 
 
 def test_strong_scaling_mode_two_ranks_share_the_gpu(built):
