@@ -101,6 +101,8 @@ typedef struct psgsdf_iter_stats {
     int32_t diverged;       /* E_total > E_prev                                                */
     int32_t upsampled;      /* this iteration ended with the 2x refine                         */
     double e_r;             /* un-weighted albedo-gradient energy (Optimizer.cpp:122-136) after the albedo step; 0 unless "reg albedo" */
+    double e_n_in, e_l_in;  /* e_n / e_l as they stood BEFORE this iteration's dist step: what the reference's log lines of the blocks in front of it
+                             * add to the PS energy (getTotalEnergy(E, E_n, E_l, E_r), PsOptimizer.cpp:311-331 -- E_n changes at :342 only) */
 } psgsdf_iter_stats;
 
 /* sizes the caller needs for downloads */

@@ -1706,6 +1706,7 @@ static void iterate_once(orc_ctx* c, int flags, int laplacian_reg, float* E, flo
     int order[4] = {led ? PSGSDF_LIGHT : PSGSDF_ALBEDO, led ? PSGSDF_ALBEDO : PSGSDF_LIGHT, PSGSDF_DIST, PSGSDF_POSE};
     for (int q = 0; q < 4; ++q) rec->e_after[q] = NAN;
     rec->cg_iters = 0;
+    rec->e_n_in = *E_n; rec->e_l_in = *E_l;   /* in force until this iteration's distance block (PsOptimizer.cpp:342-343) */
     for (int q = 0; q < 4; ++q) {
         int blk = order[q];
         if (!(flags & blk)) continue;

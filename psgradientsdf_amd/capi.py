@@ -44,7 +44,7 @@ class IterStats(C.Structure):
     _fields_ = [("e_after", C.c_double * 4), ("e_n", C.c_double), ("e_l", C.c_double), ("e_total", C.c_double),
                 ("rel_diff", C.c_double), ("reg_weight_n", C.c_float), ("reg_weight_l", C.c_float),
                 ("cg_iters", C.c_int32), ("converged", C.c_int32), ("diverged", C.c_int32), ("upsampled", C.c_int32),
-                ("e_r", C.c_double)]
+                ("e_r", C.c_double), ("e_n_in", C.c_double), ("e_l_in", C.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

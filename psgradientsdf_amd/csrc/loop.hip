@@ -441,6 +441,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
     struct Late { double e_in[4]; int blk_of[4]; int n; bool dist_ran; int cg_iters; bool alb_reg; float e_r; } late[2];
     int li = 0;
     auto apply_late = [&](psgsdf_iter_stats& r, const Late& lt, int first_slot_pending) {
+        r.e_n_in = L.E_n; r.e_l_in = L.E_l;      // (records are closed in order: L still holds what was in force before this iteration's distance block)
         // e_in of sweep q is the energy AFTER the block that ran before it in the same iteration
         int pend = first_slot_pending;
         for (int q = 0; q < lt.n; ++q) {

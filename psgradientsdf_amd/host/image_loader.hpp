@@ -116,13 +116,21 @@ public:
 // [1/4 1/2 1/4], BORDER_REFLECT_101; cv::mean(FM).val[0] = mean of channel 0, which is BLUE in the reference's BGR images.
 inline float modifiedLaplacian(const ImageRGB& img) {
     const int H = img.rows, W = img.cols; const int ch = 2;   // blue
-    auto at = [&](int y, int x) { y = y < 0 ? -y : (y >= H ? 2 * H - 2 - y : y); x = x < 0 ? -x : (x >= W ? 2 * W - 2 - x : x); return img.data[((size_t)y * W + x) * 3 + ch]; };
-    const float M[3] = {-1, 2, -1}, G[3] = {0.25f, 0.5f, 0.25f};
+    auto rx = [&](int x) { return x < 0 ? -x : (x >= W ? 2 * W - 2 - x : x); };
+    auto ry = [&](int y) { return y < 0 ? -y : (y >= H ? 2 * H - 2 - y : y); };
+    // separable like cv::sepFilter2D: the row kernel first (float), then the column kernel over the row results
+    std::vector<float> rowM((size_t)W * H), rowG((size_t)W * H);
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+        const float a = img.data[((size_t)y * W + rx(x - 1)) * 3 + ch], b = img.data[((size_t)y * W + x) * 3 + ch], c = img.data[((size_t)y * W + rx(x + 1)) * 3 + ch];
+        rowM[(size_t)y * W + x] = (-a + 2.0f * b) - c;
+        rowG[(size_t)y * W + x] = (0.25f * a + 0.5f * b) + 0.25f * c;
+    }
     double sum = 0;
     for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
-        float lx = 0, ly = 0;
-        for (int j = -1; j <= 1; ++j) for (int i = -1; i <= 1; ++i) { float v = at(y + j, x + i); lx += M[i + 1] * G[j + 1] * v; ly += G[i + 1] * M[j + 1] * v; }
-        sum += std::fabs(lx) + std::fabs(ly);
+        const size_t u = (size_t)ry(y - 1) * W + x, m = (size_t)y * W + x, d = (size_t)ry(y + 1) * W + x;
+        const float lx = (0.25f * rowM[u] + 0.5f * rowM[m]) + 0.25f * rowM[d];      // Lx = sepFilter2D(src, M, G): M along x, G along y
+        const float ly = (-rowG[u] + 2.0f * rowG[m]) - rowG[d];                      // Ly = sepFilter2D(src, G, M)
+        sum += (double)(std::fabs(lx) + std::fabs(ly));
     }
     return (float)(sum / ((double)W * H));
 }

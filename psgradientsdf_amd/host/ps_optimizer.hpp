@@ -188,8 +188,9 @@ protected:
     static int on_iter_trampoline(void* user, int iter_done, const psgsdf_iter_stats* rec) { return static_cast<Optimizer*>(user)->on_iter(iter_done, rec); }
 
     // getTotalEnergy's log line, OptimizerAux.cpp:259-269
-    void log_energy(double E, const psgsdf_iter_stats* r) {
-        double en = r->reg_weight_n * r->e_n, el = r->reg_weight_l * r->e_l, er = settings_->reg_weight_rho * r->e_r;
+    void log_energy(double E, const psgsdf_iter_stats* r, bool before_dist = false) {
+        // (the blocks in front of the distance block are logged with the regulariser energies of the previous iteration: E_n / E_l only change at PsOptimizer.cpp:342-343)
+        double en = r->reg_weight_n * (before_dist ? r->e_n_in : r->e_n), el = r->reg_weight_l * (before_dist ? r->e_l_in : r->e_l), er = settings_->reg_weight_rho * r->e_r;
         for (std::ostream* o : {static_cast<std::ostream*>(&std::cout), static_cast<std::ostream*>(&doc_)})
             if (o == &std::cout || doc_.is_open())
                 *o << "PS energy: " << E << "\t normal reg energy: " << en << "\t laplacian reg energy: " << el << "\t rho reg energy: " << er
@@ -207,7 +208,7 @@ protected:
             if (std::isnan(r->e_after[s])) continue;
             std::cout << "===> [" << iter << "]: after " << names[s] << " optimization: ";
             if (doc_.is_open()) doc_ << "===> [" << iter << "]: after " << names[s] << " optimization: \n";
-            log_energy(r->e_after[s], r);
+            log_energy(r->e_after[s], r, s < 2);
         }
         std::cout << "===> [" << iter << "]: relative diff " << r->rel_diff << std::endl;
         if (doc_.is_open()) doc_ << "===> [" << iter << "]: relative diff " << r->rel_diff << "\n";
@@ -218,9 +219,19 @@ protected:
     // (psgsdf_set_on_iter_period(3)) and after the 2x refinement; in between the loop closes its iterations speculatively
     int on_iter(int iter_done, const psgsdf_iter_stats* r) {
         const int iter = iter_done - 1;
-        if (r->upsampled) {   // PsOptimizer.cpp:397-398
+        if (r->upsampled) {   // PsOptimizer.cpp:397-405
             save_pointcloud("upsample_after_" + std::to_string(iter));
             extract_mesh("upsample_after_" + std::to_string(iter));
+            // the log line behind the refinement: the iteration's last PS energy and Eikonal term with the Laplacian energy of the REFINED grid under
+            // its re-normalised weight (PsOptimizer.cpp:400-405: E_l = getLaplacianEnergy(); reg_weight_l *= E / E_l; getTotalEnergy(...))
+            double e4[4] = {0, 0, 0, 0}; psgsdf_info info{};
+            if (!psgsdf_energy(ctx_, e4) && !psgsdf_get_info(ctx_, &info)) {
+                double E = 0; for (int q = 0; q < 4; ++q) if (!std::isnan(r->e_after[q])) E = r->e_after[q];      // (slot order albedo, light, dist, pose: the last enabled block is the last one run)
+                psgsdf_iter_stats t = *r; t.e_l = e4[2]; t.reg_weight_l = info.reg_weight_l;
+                std::cout << "===> [" << iter << "]: after pose optimization: ";
+                if (doc_.is_open()) doc_ << "===> [" << iter << "]: after pose optimization: \n";
+                log_energy(E, &t);
+            }
         }
         if (iter_done % 3 == 0) {
             savePoses("after_poses_opt_" + std::to_string(iter_done));
@@ -303,7 +314,7 @@ public:
         if (rc) return fail("psgsdf_optimize", rc);
         if (n_done > 0 && (recs[n_done - 1].converged || recs[n_done - 1].diverged)) {
             const int iter = n_done - 1;
-            narrate(n_done, &recs[n_done - 1]); on_iter(n_done, &recs[n_done - 1]);   // neither is invoked for the terminating iteration
+            narrate(n_done, &recs[n_done - 1]);   // (the observer is not invoked for the terminating iteration.  Narration only: the reference returns at PsOptimizer.cpp:368-384, before ++iter and the iter % 3 dumps of :419-423 -- no after_iter_<k> files for it)
             std::cout << "===> [" << iter << "]: " << (result ? "converged!" : "diverged!") << std::endl;
             doc_ << "===> [" << iter << "]: " << (result ? "converged! \n" : "diverged!\n");
             save_pointcloud("final_refined");                      // PsOptimizer.cpp:372-373,379-380

@@ -95,7 +95,24 @@ static int selftest_mc_ply(int n, const char* path) {
     return mc.savePly(path) ? 0 : 1;
 }
 
+// the focus measure of one colour PNG as the keyframe selector computes it (SharpDetector.h:22-37), and the keyframe sub-sampling of
+// main_ps.cpp:392-421 on the index list 0..n-1: tests/test_host_tools.py compares both with numpy / scipy restatements (no GPU needed)
+static int selftest_lapm(const char* path) {
+    ImageLoader* l = new MultiviewLoader("");
+    ImageRGB c; if (!l->load_color(path, c)) { std::cout << "FAIL" << std::endl; return 1; }
+    std::cout.precision(9); std::cout << modifiedLaplacian(c) << std::endl; delete l; return 0;
+}
+static int selftest_sample(int n, int max_num) {
+    std::vector<int> frames(n), poses(n), images(n); std::vector<std::string> stamps(n);
+    for (int i = 0; i < n; ++i) { frames[i] = 3 * i + 1; poses[i] = i; images[i] = -i; stamps[i] = std::to_string(i); }
+    if ((int)frames.size() > max_num) sampleKeyFrame(frames, stamps, images, poses, max_num);      // (the call site's guard, main_ps.cpp:312)
+    for (size_t i = 0; i < frames.size(); ++i) std::cout << frames[i] << ":" << stamps[i] << ":" << images[i] << ":" << poses[i] << (i + 1 < frames.size() ? " " : "\n");
+    return 0;
+}
+
 int main(int argc, char* argv[]) {
+    if (argc >= 3 && std::string(argv[1]) == "--selftest-lapm") return selftest_lapm(argv[2]);
+    if (argc >= 4 && std::string(argv[1]) == "--selftest-sample") return selftest_sample(atoi(argv[2]), atoi(argv[3]));
     if (argc >= 3 && std::string(argv[1]) == "--selftest-png") return selftest_png(argv[2]);
     if (argc >= 2 && std::string(argv[1]) == "--selftest-mc") return selftest_mc();
     if (argc >= 2 && std::string(argv[1]) == "--selftest-mc-table") return selftest_mc_table(false);

@@ -179,3 +179,64 @@ def test_cli_contract_exit_codes(built, tmp_path):
     r = run("--config_file", str(cfg))
     assert r.returncode == 1 and "No intrinsics file found" in r.stderr
     assert os.path.exists(tmp_path / "saved_config.json")   # ConfigLoader.h:161-165 writes it before anything else can fail
+
+
+def lapm_numpy(rgb_u8):
+    """modifiedLaplacian (SharpDetector.h:22-37) restated with scipy: the image is the loader's float colour image (byte / 255, ImageLoader.h:181);
+    Lx = sepFilter2D(src, kernelX = M = [-1 2 -1], kernelY = G), Ly = sepFilter2D(src, G, M) with G = getGaussianKernel(3, -1) = [1/4 1/2 1/4]
+    (OpenCV's fixed table for ksize 3) and OpenCV's default border BORDER_REFLECT_101 (= scipy 'mirror': the edge pixel is not repeated);
+    cv::mean(|Lx| + |Ly|).val[0] is the mean of CHANNEL 0, which is blue in the reference's BGR images."""
+    from scipy import ndimage
+    b = rgb_u8[..., 2].astype(np.float32) * np.float32(1.0 / 255.0)
+    M = np.array([-1, 2, -1], np.float32); G = np.array([0.25, 0.5, 0.25], np.float32)
+    lx = ndimage.correlate1d(ndimage.correlate1d(b, M, axis=1, mode="mirror"), G, axis=0, mode="mirror")
+    ly = ndimage.correlate1d(ndimage.correlate1d(b, G, axis=1, mode="mirror"), M, axis=0, mode="mirror")
+    return float((np.abs(lx).astype(np.float64) + np.abs(ly).astype(np.float64)).mean())
+
+
+def sample_keyframes_numpy(n, max_num):
+    """sampleKeyFrame (main_ps.cpp:392-421) behind its call-site guard `keyframes.size() > 40` (:312): max_num - 1 picks at a FLOAT running index
+    (idx += step in float32, truncated), then the last frame"""
+    idx = list(range(n))
+    if not n > max_num or n < max_num:
+        return idx
+    m = max_num - 1
+    step = np.float32(n) / np.float32(m)
+    out, pos = [], np.float32(0)
+    for _ in range(m):
+        out.append(idx[int(pos)]); pos = np.float32(pos + step)
+    return out + [idx[-1]]
+
+
+def test_focus_measure_against_scipy(built, tmp_path):
+    """the keyframe selector's focus measure (no test at all) on random, smooth and real images, incl. sizes whose borders matter"""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:48, 0:64]
+    cases = {"noise.png": rng.integers(0, 256, (48, 64, 3), dtype=np.uint8),
+             "smooth.png": np.stack([(127 + 100 * np.sin(0.2 * xx + 0.1 * yy)), (127 + 100 * np.cos(0.15 * yy)), (127 + 120 * np.sin(0.31 * xx) * np.cos(0.27 * yy))], -1).astype(np.uint8),
+             "tiny.png": rng.integers(0, 256, (3, 4, 3), dtype=np.uint8),
+             "flat.png": np.full((20, 30, 3), 77, np.uint8)}
+    for name, arr in cases.items():
+        path = str(tmp_path / name); Image.fromarray(arr).save(path)
+        got = float(run("--selftest-lapm", path).stdout)
+        want = lapm_numpy(arr)
+        assert abs(got - want) <= 2e-6 * max(1.0, want), (name, got, want)      # (float32 products summed in a different order)
+    assert float(run("--selftest-lapm", str(tmp_path / "flat.png")).stdout) == 0.0
+    arr = np.asarray(Image.open(os.path.join(GOLD, "color000003.png")).convert("RGB"))
+    assert abs(float(run("--selftest-lapm", os.path.join(GOLD, "color000003.png")).stdout) - lapm_numpy(arr)) <= 2e-6
+    # the red and green channels do not enter: only channel 0 of the reference's BGR image
+    arr2 = cases["noise.png"].copy(); arr2[..., :2] = 0
+    Image.fromarray(arr2).save(str(tmp_path / "blue_only.png"))
+    assert float(run("--selftest-lapm", str(tmp_path / "blue_only.png")).stdout) == float(run("--selftest-lapm", str(tmp_path / "noise.png")).stdout)
+
+
+@pytest.mark.parametrize("n,max_num", [(41, 40), (46, 40), (97, 40), (40, 40), (12, 40), (151, 40), (9, 4), (1000, 40)])
+def test_keyframe_sampling_against_numpy(built, n, max_num):
+    """sampleKeyFrame on n selected frames: the four parallel lists (frame index, stamp, image, pose) stay aligned, the float stepping and the
+    forced last frame are the reference's"""
+    rows = [x.split(":") for x in run("--selftest-sample", str(n), str(max_num)).stdout.split()]
+    want = sample_keyframes_numpy(n, max_num)
+    assert [int(r[3]) for r in rows] == want
+    assert all(int(r[0]) == 3 * int(r[3]) + 1 and int(r[1]) == int(r[3]) and int(r[2]) == -int(r[3]) for r in rows)
+    assert len(rows) == (max_num if n > max_num else n) and int(rows[-1][3]) == n - 1
