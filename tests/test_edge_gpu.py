@@ -201,7 +201,7 @@ def test_persistent_solve_falls_back_to_the_per_pass_kernels(built, name, mid, m
     ve, vr, vo = eng.download_volume(), ref.download_volume(), orc.download_volume()
     assert np.array_equal(ve["dist"], vr["dist"]) and np.array_equal(ve["rgb"][:, band], vr["rgb"][:, band]) and np.array_equal(eng.download_poses(), ref.download_poses())
     d = np.abs(ve["dist"][band] - vo["dist"][band]) / vs
-    assert np.quantile(d, 0.999) <= 1e-4 and d.max() <= 5e-3
+    assert d.max() <= 1e-4, (np.quantile(d, 0.999), d.max())      # three iterations, no refinement: every band voxel (tests/test_parity_gpu.py OPT_MAX_VS)
     for a, b in zip(r_e, r_o):
         assert abs(a["e_total"] - b["e_total"]) <= 2e-4 * abs(b["e_total"])
 

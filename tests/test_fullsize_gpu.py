@@ -5,6 +5,7 @@ reproducibility, and agreement with the oracle on a random SAMPLE of observation
 import numpy as np
 import pytest
 
+from conftest import sdf_margin
 from psgradientsdf_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
@@ -62,7 +63,7 @@ def test_headline_size_sample_against_oracle(built, big_scene):
     assert abs(ee[0] - eo[0]) <= 1e-5 * eo[0] and abs(ee[1] - eo[1]) <= 1e-6 * eo[1]
 
 
-def test_config1_against_the_oracle(built):
+def test_config1_against_the_oracle(built, margins):
     """BASELINE.json configs[1]: synthetic 640x480 RGB-D, 128^3 grid, SH1, 30 keyframes -- one full Gauss-Newton iteration
     against the oracle (8 host threads), tolerance of the north star: <= 1e-4 relative SDF error."""
     from oracle import oracle
@@ -78,15 +79,18 @@ def test_config1_against_the_oracle(built):
     band = eng.download_band()
     ve, vo = eng.download_volume(), orc.download_volume()
     vs = float(sc.voxel_size)
-    d = np.abs(ve["dist"][band] - vo["dist"][band]) / vs
-    assert d.max() <= 1e-4, d.max()
-    assert np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max() <= 1e-4
-    assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 1e-5
-    assert np.abs(eng.download_light() - orc.download_light()).max() <= 1e-4 * np.abs(orc.download_light()).max()
+    m = sdf_margin(ve["dist"], vo["dist"], band, vs)
+    got = {"e_total_rel": abs(re_["e_total"] - ro["e_total"]) / abs(ro["e_total"]), "rgb": float(np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max()),
+           "pose": float(np.abs(eng.download_poses() - orc.download_poses()).max()), "light_rel": float(np.abs(eng.download_light() - orc.download_light()).max() / np.abs(orc.download_light()).max())}
+    margins(sdf=m, achieved=got, tolerance={"max_vs": 1e-4, "e_total_rel": 1e-4, "rgb": 1e-4, "pose": 1e-5, "light_rel": 1e-4})
+    assert m["max_vs"] <= 1e-4, m
+    assert got["rgb"] <= 1e-4
+    assert got["pose"] <= 1e-5
+    assert got["light_rel"] <= 1e-4
 
 
 @pytest.mark.parametrize("model,N,F,iters", [("SH1", 96, 20, 12), ("LED", 64, 12, 12), ("SH2", 64, 12, 8)])
-def test_long_run_stays_within_the_north_star_tolerance(built, model, N, F, iters):
+def test_long_run_stays_within_the_north_star_tolerance(built, margins, model, N, F, iters):
     """engine vs oracle over a whole optimisation's worth of iterations (rounding differences are amplified by the discrete accept
     rules, so a handful of voxels wander; tools/long_parity.py prints the growth): norm-wise relative SDF error <= 1e-4 and
     99.9 % of the band within 1e-4 voxel"""
@@ -100,14 +104,13 @@ def test_long_run_stays_within_the_north_star_tolerance(built, model, N, F, iter
         api.load_scene(sc); api.init_albedo(); api.normalize_weights()
     re_, ro = eng.iterate(capi.ALL, iters), orc.iterate(capi.ALL, iters)
     band = eng.download_band(); vs = float(sc.voxel_size)
-    de, do = eng.download_volume()["dist"][band].astype(np.float64), orc.download_volume()["dist"][band].astype(np.float64)
-    rel = np.linalg.norm(de - do) / np.linalg.norm(do)
-    d = np.abs(de - do) / vs
-    assert rel <= 1e-4 and np.quantile(d, 0.999) <= 1e-4, (rel, np.quantile(d, 0.999), d.max())
+    m = sdf_margin(eng.download_volume()["dist"], orc.download_volume()["dist"], band, vs)
+    margins(sdf=m, iterations=iters, e_total_rel=abs(re_[-1]["e_total"] - ro[-1]["e_total"]) / abs(ro[-1]["e_total"]), tolerance={"rel": 1e-4, "q999_vs": 1e-4, "e_total_rel": 5e-4})
+    assert m["rel"] <= 1e-4 and m["q999_vs"] <= 1e-4, m
     assert abs(re_[-1]["e_total"] - ro[-1]["e_total"]) <= 5e-4 * abs(ro[-1]["e_total"])
 
 
-def test_headline_size_against_the_oracle(built, big_scene):
+def test_headline_size_against_the_oracle(built, margins, big_scene):
     """256^3 x 50 keyframes 640x480: two full Gauss-Newton iterations, every band voxel against the oracle (64 host threads)"""
     from oracle import oracle
     sc = big_scene
@@ -121,7 +124,10 @@ def test_headline_size_against_the_oracle(built, big_scene):
         assert abs(a["e_total"] - b["e_total"]) <= 1e-4 * abs(b["e_total"]) and abs(a["cg_iters"] - b["cg_iters"]) <= 1
     band = eng.download_band(); vs = float(sc.voxel_size)
     ve, vo = eng.download_volume(), orc.download_volume()
-    d = np.abs(ve["dist"][band] - vo["dist"][band]) / vs
-    assert d.max() <= 1e-4, (d.max(), np.quantile(d, 0.999))
-    assert np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max() <= 1e-4
-    assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 1e-5
+    m = sdf_margin(ve["dist"], vo["dist"], band, vs)
+    got = {"e_total_rel": max(abs(a["e_total"] - b["e_total"]) / abs(b["e_total"]) for a, b in zip(re_, ro)), "rgb": float(np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max()),
+           "pose": float(np.abs(eng.download_poses() - orc.download_poses()).max())}
+    margins(sdf=m, achieved=got, tolerance={"max_vs": 1e-4, "e_total_rel": 1e-4, "rgb": 1e-4, "pose": 1e-5})
+    assert m["max_vs"] <= 1e-4, m
+    assert got["rgb"] <= 1e-4
+    assert got["pose"] <= 1e-5

@@ -7,6 +7,7 @@ Tolerances (north_star: <= 1e-4 relative SDF error, denominator = voxel size):
 import numpy as np
 import pytest
 
+from conftest import sdf_margin
 from psgradientsdf_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
@@ -15,7 +16,11 @@ MODELS = [("SH1", capi.SH1), ("SH2", capi.SH2), ("LED", capi.LED)]
 # The reference stores the per-frame light normal equations in float32 (Eigen::SparseMatrix<float>), so the light
 # step is only determined to cond(H_f) * eps_f32.  SH1 blocks have cond ~1e2, SH2 9x9 blocks ~2e4 on these scenes
 # (printed by the diagnosis in profiles/r01_notes.md): 2e4 * 6e-8 * a small factor.
-LIGHT_RTOL = {"SH1": 1e-4, "SH2": 5e-3, "LED": 1e-4}
+LIGHT_RTOL = {"SH1": 1e-4, "SH2": 1e-3, "LED": 1e-4}      # (achieved on the driver box, profiles/r04_parity_margins.json: SH1 2e-6, SH2 2.6e-4 per sub-step / 1.0e-3 after seven iterations, LED 0)
+# Every band voxel, not a quantile: round 3 allowed single voxels up to 5e-3 voxel here; the recorded margins (profiles/r04_parity_margins.json) show the
+# maximum at 1e-6 .. 5e-5 voxel after three iterations and after seven iterations THROUGH the 2x refinement alike, so the maximum itself is held to the
+# north star's 1e-4.  (Only whole optimisations of 12 iterations let a handful of voxels wander further: tests/test_fullsize_gpu.py)
+OPT_MAX_VS = 1e-4
 
 
 def make_pair(model_name, model_id, N=48, F=6, **kw):
@@ -47,23 +52,27 @@ def test_band_and_init(built, name, mid):
 
 
 @pytest.mark.parametrize("name,mid", MODELS)
-def test_normal_equations(built, name, mid):
+def test_normal_equations(built, margins, name, mid):
     sc, eng, orc = make_pair(name, mid, reg_weight_l=2.0)
     for api in (eng, orc):
         api.init_albedo(); api.normalize_weights()
+    got = {}
     He, be = eng.debug_albedo_system(); Ho, bo = orc.debug_albedo_system()
-    assert relmax(He, Ho) < 2e-5 and relmax(be, bo) < 2e-5
-    for blk in (capi.LIGHT, capi.POSE):
+    got["albedo_H"], got["albedo_b"] = relmax(He, Ho), relmax(be, bo)
+    for blk, nm in ((capi.LIGHT, "light"), (capi.POSE, "pose")):
         He, be = eng.debug_frame_system(blk); Ho, bo = orc.debug_frame_system(blk)
-        assert relmax(He, Ho) < 2e-5 and relmax(be, bo) < 2e-5, (name, blk)
+        got[nm + "_H"], got[nm + "_b"] = relmax(He, Ho), relmax(be, bo)
     x = np.random.default_rng(0).standard_normal(eng.info().n_band).astype(np.float32)
     de, re_, ye = eng.debug_dist_system(x); do, ro, yo = orc.debug_dist_system(x)
-    assert relmax(de, do) < 2e-5 and relmax(re_, ro) < 2e-5 and relmax(ye, yo) < 2e-5
+    got["dist_diag"], got["dist_rhs"], got["dist_matvec"] = relmax(de, do), relmax(re_, ro), relmax(ye, yo)
+    margins(achieved=got, tolerance=2e-5)
+    assert all(v < 2e-5 for v in got.values()), got
 
 
 @pytest.mark.parametrize("name,mid", MODELS)
-def test_substeps(built, name, mid):
+def test_substeps(built, margins, name, mid):
     sc, eng, orc = make_pair(name, mid)
+    worst = {"dist_vs": 0.0, "rgb": 0.0, "grad": 0.0, "pose": 0.0, "light_rel": 0.0, "e_in_rel": 0.0}
     for api in (eng, orc):
         api.init_albedo(); api.normalize_weights()
     vs = float(sc.voxel_size)
@@ -78,15 +87,20 @@ def test_substeps(built, name, mid):
         if blk == capi.DIST:
             assert abs(se["cg_iters"] - so["cg_iters"]) <= 1 and se["cg_converged"] == so["cg_converged"]
         ve, vo = eng.download_volume(), orc.download_volume()
-        assert np.abs(ve["dist"][band] - vo["dist"][band]).max() <= 1e-4 * vs, blk
-        assert np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max() <= 1e-4, blk
-        assert np.abs(ve["grad"][:, band] - vo["grad"][:, band]).max() <= 2e-4, blk
-        assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 1e-5, blk
-        assert relmax(eng.download_light(), orc.download_light()) <= LIGHT_RTOL[name], blk
+        got = {"dist_vs": float(np.abs(ve["dist"][band] - vo["dist"][band]).max() / vs), "rgb": float(np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max()),
+               "grad": float(np.abs(ve["grad"][:, band] - vo["grad"][:, band]).max()), "pose": float(np.abs(eng.download_poses() - orc.download_poses()).max()),
+               "light_rel": relmax(eng.download_light(), orc.download_light()), "e_in_rel": float(abs(se["e_in"] - so["e_in"]) / abs(so["e_in"]))}
+        worst = {k: max(worst[k], got[k]) for k in worst}
+        assert got["dist_vs"] <= 1e-4, blk
+        assert got["rgb"] <= 1e-4, blk
+        assert got["grad"] <= 2e-4, blk
+        assert got["pose"] <= 1e-5, blk
+        assert got["light_rel"] <= LIGHT_RTOL[name], blk
+    margins(achieved=worst, tolerance={"dist_vs": 1e-4, "rgb": 1e-4, "grad": 2e-4, "pose": 1e-5, "light_rel": LIGHT_RTOL[name], "e_in_rel": 2e-4 if name == "SH2" else 2e-5})
 
 
 @pytest.mark.parametrize("name,mid", MODELS)
-def test_iterations(built, name, mid):
+def test_iterations(built, margins, name, mid):
     sc, eng, orc = make_pair(name, mid)
     for api in (eng, orc):
         api.init_albedo(); api.normalize_weights()
@@ -97,8 +111,9 @@ def test_iterations(built, name, mid):
         assert np.allclose(a["e_after"], b["e_after"], rtol=2e-4), (a, b)
         assert abs(a["e_total"] - b["e_total"]) <= 2e-4 * abs(b["e_total"])
     ve, vo = eng.download_volume(), orc.download_volume()
-    d = np.abs(ve["dist"][band] - vo["dist"][band]) / vs
-    assert np.quantile(d, 0.999) <= 1e-4 and d.max() <= 5e-3, (np.quantile(d, 0.999), d.max())
+    m = sdf_margin(ve["dist"], vo["dist"], band, vs)
+    margins(sdf=m, e_total_rel=max(abs(a["e_total"] - b["e_total"]) / abs(b["e_total"]) for a, b in zip(re_, ro)), tolerance={"q999_vs": 1e-4, "max_vs": 1e-4, "e_total_rel": 2e-4})
+    assert m["q999_vs"] <= 1e-4 and m["max_vs"] <= 1e-4, m      # three iterations: EVERY band voxel inside the north star's tolerance
 
 
 def test_upsample_and_optimize(built):
@@ -113,7 +128,7 @@ def test_upsample_and_optimize(built):
 
 
 @pytest.mark.parametrize("name,mid", MODELS)
-def test_optimize_matches_oracle(built, name, mid):
+def test_optimize_matches_oracle(built, margins, name, mid):
     """psgsdf_optimize -- the loop voxelPS calls -- against the oracle's restatement of alternatingOptimize (PsOptimizer.cpp:239-428: albedo ->
     light -> distance -> pose; LedOptimizer.cpp:279-478: light -> albedo -> distance -> pose) for all three shading models: initAlbedo and weight
     normalisation inside the call, the per-iteration records with the energy after EVERY block, the converged / diverged flags that end the loop,
@@ -137,12 +152,15 @@ def test_optimize_matches_oracle(built, name, mid):
     assert np.array_equal(band, orc.download_band())
     vs = float(sc.voxel_size) / 2
     ve, vo = eng.download_volume(), orc.download_volume()
-    d = np.abs(ve["dist"][band] - vo["dist"][band]) / vs
-    assert np.quantile(d, 0.999) <= 1e-4 and d.max() <= 5e-3, (np.quantile(d, 0.999), d.max())      # north star: <= 1e-4 relative SDF error
-    assert np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max() <= (2e-3 if name == "SH2" else 2e-4)
-    assert np.abs(eng.download_poses() - orc.download_poses()).max() <= 1e-5
+    m = sdf_margin(ve["dist"], vo["dist"], band, vs)
     le, lo = eng.download_light(), orc.download_light()
-    assert np.abs(le - lo).max() <= 5 * LIGHT_RTOL[name] * np.abs(lo).max()
+    got = {"rgb": float(np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max()), "pose": float(np.abs(eng.download_poses() - orc.download_poses()).max()),
+           "light_rel": float(np.abs(le - lo).max() / np.abs(lo).max()), "e_total_rel": max(abs(a["e_total"] - b["e_total"]) / abs(b["e_total"]) for a, b in zip(re_, ro))}
+    margins(sdf=m, achieved=got, iterations=len(re_), tolerance={"q999_vs": 1e-4, "max_vs": OPT_MAX_VS, "rgb": 2e-3 if name == "SH2" else 2e-4, "pose": 1e-5, "light_rel": 5 * LIGHT_RTOL[name], "e_total_rel": 1e-4})
+    assert m["q999_vs"] <= 1e-4 and m["max_vs"] <= OPT_MAX_VS, m      # north star: <= 1e-4 relative SDF error
+    assert got["rgb"] <= (2e-3 if name == "SH2" else 2e-4)
+    assert got["pose"] <= 1e-5
+    assert got["light_rel"] <= 5 * LIGHT_RTOL[name]
 
 
 SCHEDULE_CASES = [("SH1", capi.SH1, 12, dict(damping=10.0, reg_weight_n=10.0)), ("SH2", capi.SH2, 16, dict(damping=1.0, reg_weight_n=0.1)),
@@ -203,7 +221,7 @@ def test_albedo_regulariser(built, name, mid):
 
 
 @pytest.mark.parametrize("name,mid", MODELS)
-def test_8bit_keyframes(built, name, mid):
+def test_8bit_keyframes(built, margins, name, mid):
     """psgsdf_set_keyframes_u8 (the reference loader's 8-bit RGB + its conversion factor, ImageLoader.h:167-181): the engine samples
     RGBA8 words, the oracle the converted floats -- same tolerances as the float path, and the engine's two paths agree to rounding noise"""
     from oracle import oracle
@@ -230,5 +248,6 @@ def test_8bit_keyframes(built, name, mid):
     assert np.abs(eng.download_poses() - engf.download_poses()).max() <= noise
     for a, b in zip(re_, ro):
         assert abs(a["e_total"] - b["e_total"]) <= 2e-4 * abs(b["e_total"])
-    d = np.abs(ve["dist"][band] - vo["dist"][band]) / vs
-    assert np.quantile(d, 0.999) <= 1e-4 and d.max() <= 5e-3
+    m = sdf_margin(ve["dist"], vo["dist"], band, vs)
+    margins(sdf=m, tolerance={"q999_vs": 1e-4, "max_vs": 1e-4})
+    assert m["q999_vs"] <= 1e-4 and m["max_vs"] <= 1e-4, m

@@ -48,7 +48,7 @@ def stitch(res, key):
 
 @pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("SH1", 2, "gloo-xr0"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH1", 4, "gloo"), ("SH2", 2, "gloo"),
                                                    ("SH1+reg", 2, "gloo")])
-def test_native_slab_loop_matches_single_context(built, tmp_path, model, world, transport):
+def test_native_slab_loop_matches_single_context(built, margins, tmp_path, model, world, transport):
     N, n_iters = 40, 2
     # "rccl-perpass": the PCG as the multi-rank path runs it (one kernel, one fold and one RCCL all-reduce of 7 doubles per pass) -- a one-rank
     # communicator would otherwise use the persistent single-kernel solve, which needs no exchange
@@ -97,7 +97,11 @@ def test_native_slab_loop_matches_single_context(built, tmp_path, model, world, 
     # different order than one context does)
     assert np.array_equal(np.concatenate([g["band"] for g in res]), band)
     d = stitch(res, "dist"); rgb = stitch(res, "rgb")
-    assert np.abs(d[band] - v["dist"][band]).max() <= (1e-3 if model == "SH2" else 1e-4) * vs
+    margins(slab_vs_single={"dist_max_vs": float(np.abs(d[band] - v["dist"][band]).max() / vs), "rgb_max": float(np.abs(rgb[:, band] - v["rgb"][:, band]).max()),
+                            "e_total_rel": float(max(np.abs(np.array(g["e_total"]) / np.array([x["e_total"] for x in recs]) - 1).max() for g in res)),
+                            "pose_max": float(max(np.abs(g["poses"] - ref.download_poses()).max() for g in res))},
+            tolerance={"dist_max_vs": 1e-4, "rgb_max": 1e-2 if model == "SH2" else 2e-4, "e_total_rel": 2e-4 if model == "SH2" else 5e-6, "pose_max": 2e-5 if model == "SH2" else 1e-6})
+    assert np.abs(d[band] - v["dist"][band]).max() <= 1e-4 * vs      # (SH2 too: 2.6e-5 achieved, profiles/r04_parity_margins.json)
     assert np.abs(rgb[:, band] - v["rgb"][:, band]).max() <= (1e-2 if model == "SH2" else 2e-4)   # SH2: float32 9x9 light blocks of cond ~2e4 (tests/test_parity_gpu.py LIGHT_RTOL) amplify the all-reduce's summation order
     off = ~np.isin(np.arange(len(d)), band)
     assert np.array_equal(d[off], v["dist"][off])                     # voxels outside the band are untouched
