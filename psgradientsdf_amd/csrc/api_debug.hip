@@ -101,9 +101,9 @@ int psgsdf_debug_time_pcg_solve(psgsdf_ctx* c, int passes, int reps, double* ms_
     *ms_per_launch = (double)total / reps;
     if (stamps) for (int i = 0; i < 16; ++i) stamps[i] = c->mbox[8 + i];      // pass 8 of the last launch: 7 stage stamps of the first and of the last workgroup (100 MHz ticks)
     if (const char* dump = getenv("PSGSDF_SOLVE_DUMP")) {   // per-workgroup publish / gather-done / sums-seen times (tools/pcg_solve_time.py)
-        std::vector<double> h(5 * 256);
+        std::vector<double> h(8 * 256);      // columns: workgroup, publish(8), sums seen(9), =, XCC, gathers done(9), publish(9), neighbour tags seen(9), prefetch valid(9)
         HIPCHK(c, hipMemcpy(h.data(), c->pcg_sc + 16, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
-        if (FILE* f = fopen(dump, "w")) { for (int i = 0; i < G; ++i) fprintf(f, "%d %.0f %.0f %.0f %.0f %.0f\n", i, h[i], h[256 + i], h[512 + i], h[768 + i], h[1024 + i]); fclose(f); }
+        if (FILE* f = fopen(dump, "w")) { for (int i = 0; i < G; ++i) fprintf(f, "%d %.0f %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n", i, h[i], h[256 + i], h[512 + i], h[768 + i], h[1024 + i], h[1280 + i], h[1536 + i], h[1792 + i]); fclose(f); }
     }
     return PSGSDF_OK;
 }

@@ -369,7 +369,7 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
             const double* sl = buf.data() + (size_t)(me - 1) * kSlice;
             const int own_p = (int)info[3 * (me - 1) + 2], need_lo_p = (int)info[3 * (me - 1)];
             // its upper halo rows start at its row1 = need_lo_p + own_p (local band order: lower halo, own rows, upper halo)
-            for (int q = 0; q < 2; ++q) x.lo_rec[q] = (float4*)((char*)c->band_peer[0] + (size_t)sl[128 + q]) + (need_lo_p + own_p);
+            for (int q = 0; q < 2; ++q) { x.lo_base[q] = (float4*)((char*)c->band_peer[0] + (size_t)sl[128 + q]); x.lo_rec[q] = x.lo_base[q] + (need_lo_p + own_p); }
             int G, per; shape_of(own_p, &G, &per);
             const int first = std::max(0, own_p - c->need[0]) / per, last = (own_p - 1) / per;      // its workgroups that own its last need_lo(me) rows
             x.wait_lo = c->need[0] > 0 ? last - first + 1 : 0;

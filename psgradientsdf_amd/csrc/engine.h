@@ -139,6 +139,7 @@ struct SweepArgs {
     AlbedoReg ar;             // ar.anb == nullptr unless "reg albedo" != 0
     double* pcg_part; double* pcg_fs;   // fused PCG state (pcg.hip)
     int pcg_asm;              // persistent solve assembles the distance system itself (no k_assemble launch in front of it)
+    int pcg_pipe;             // ... and runs the pipelined recurrences (pcg.hip k_cgp_solve: the sums of a pass travel while the next pass gathers)
     int pcg_xcd_local;        // ... and keeps the records of workgroups whose neighbours all run on their own XCD in that XCD's L2 (plain stores)
     int pcg_apply;            // ... and applies the distance update itself (no k_apply_dist behind it): 1 = when finished, 2 = only on Success
     double* pcg_gran; int pcg_gran_n;   // persistent solve: the tagged per-workgroup sums, zeroed by the assembly kernel when non-null
@@ -164,6 +165,7 @@ struct XrArgs {
     int rank, n_ranks;               // n_ranks == 0: single-rank solve (every field below unused)
     double* region[kXrMaxRanks];     // every rank's mailbox region (own included)
     float4* lo_rec[2]; float4* hi_rec[2];   // where this slab's boundary records go: first upper-halo row of the lower neighbour / first lower-halo row of the upper one (per record buffer)
+    float4* lo_base[2];                     // row 0 of the lower neighbour's record planes (k_cgp_solve stores ONE double per row at the head of a plane: row index counted in doubles)
     int give_lo, give_hi;            // own rows the lower / upper neighbour holds as halo (the first give_lo / last give_hi own rows)
     int wait_lo, wait_hi;            // workgroups of the lower / upper neighbour whose tags this slab's cut-side workgroups wait for
     int need_lo, need_hi;            // halo rows this slab gathers from

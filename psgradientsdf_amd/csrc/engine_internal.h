@@ -76,6 +76,9 @@ struct psgsdf_ctx {
     double* pcg_part = nullptr;          // [2][7][kPcgMaxBlocks]
     double* pcg_gran = nullptr;          // persistent solve: [2][kSolveGranPlanes][kSolveMaxBlocksHost] tagged per-workgroup sums
     bool pcg_fuse_asm = true;            // PSGSDF_PCG_FUSE_ASM=0: k_assemble in front of the persistent solve (round-2a)
+    int pcg_ablate = 0;                  // PSGSDF_PCG_ABLATE: timing ablations of the pipelined solve (wrong results; tools only)
+    bool pcg_prefetch = true;            // PSGSDF_PCG_PREFETCH=0: pipelined solve: the sums of a pass are only fetched after its gathers (not behind the last gather batch)
+    bool pcg_pipeline = true;            // PSGSDF_PCG_PIPELINE=0: the persistent solve with round 2's recurrences (k_cgf_solve: a pass waits for its own reduction)
     bool pcg_fuse_apply = true;          // PSGSDF_PCG_FUSE_APPLY=0: k_apply_dist behind it
     bool pcg_xcd_local = true;           // PSGSDF_PCG_XCD_LOCAL=0: every record through memory (write-through stores)
     bool pcg_persist = true;             // PSGSDF_PCG_PERSIST=0: always the per-pass kernels

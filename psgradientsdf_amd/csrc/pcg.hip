@@ -786,7 +786,359 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
         __threadfence_system();
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// The persistent solve, PIPELINED (round 4): the same matrix-in-LDS kernel, the same hand-offs, but with the recurrences of
+// Ghysels & Vanroose's pipelined CG so that a pass no longer waits for its own reduction.
+//
+// In k_cgf_solve the seven sums of pass k contain t_k = A p_k, i.e. they can only be published AFTER the gathers of pass k, and the next pass can
+// only start after they have gone round the device: per pass  tags ~0.9 + gathers ~4.2 + sums ~2.7 + finish ~1.1 = 9.5 us (tools/pcg_solve_time.py),
+// the 2.7 us being a pure wait for the slowest workgroup's publish to arrive.  Here a pass publishes, at its END, the next search-direction input
+// m_{k+1} = M^-1 w_{k+1} AND the three sums of the NEXT pass -- gamma = r.u, delta = w.u, |r|^2 with u = M^-1 r, w = A u carried by recurrence --
+// none of which involves the matrix-vector product n_{k+1} = A m_{k+1} that the next pass gathers for.  The all-gather of the sums therefore runs
+// concurrently with the neighbour hand-off and the gathers, and is complete when they are:
+//     per pass  tags + gathers + finish   (~6 us: profiles/r04_notes.md)
+// Recurrences (Jacobi M = diag, so q = M^-1 s and m = M^-1 w need no extra vectors), Eigen's x0 = 0:
+//     r_0 = b, u_0 = M^-1 b, w_0 = A u_0 (one extra gather round in front);   pass k:  n = A (M^-1 w)   ||   gamma, delta, |r|^2 over the device
+//     beta = gamma / gamma_old (0 in pass 0), alpha = gamma / (delta - beta gamma / alpha_old)
+//     z = n + beta z;  s = w + beta s;  p = u + beta p;  x += alpha p;  r -= alpha s;  w -= alpha z;  u = M^-1 r
+// In exact arithmetic the iterates ARE Eigen::ConjugateGradient's (alpha equals r.z / p.Ap); in float they differ from it -- and from k_cgf_pass,
+// which keeps the round-1 recurrences for bands that do not fit the LDS and as the fallback -- at rounding level (deviation 3;
+// measured margins in profiles/r04_parity_margins.json).  Stop rule, iteration count and info() are Eigen's: |r_k|^2 of the recursively updated
+// residual against max(eps^2 |b|^2, FLT_MIN), checked before update k + 1.  Gather rounds per solve: iterations + 2 (w_0, and the round that is in
+// flight when the stop is detected) instead of iterations + 1.
+// What travels: ONE float per row (m) instead of a 16-byte record, three tagged sums instead of seven (+ |b|^2 = the |r|^2 of pass 0).
+// ------------------------------------------------------------------------------------------
+constexpr int kCgpSums = 3;
+constexpr int kCgpMaxRows = 4;                // row slots per thread the pipelined kernel supports
+#ifndef PSG_CGP_DEPTH
+#define PSG_CGP_DEPTH 2
+#endif
+constexpr int kCgpDepth = PSG_CGP_DEPTH;      // gather batches (of 9 doubles) in flight per thread
+__device__ __forceinline__ void store8_sc1(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store8_sys(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
+
+template <int R, bool MR>
+__global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, double* fs, double* gran, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, XrArgs xr) {
+    __shared__ double red[8 * kSolveThreads / 64];
+    __shared__ int s_abort;
+    __shared__ int s_foreign;
+    const Band& b = a.b;
+    const int G = gridDim.x, tid = threadIdx.x;
+    const int my_xcc = (int)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+    bool xcd_local = false;
+    const int lb = (G % 8 == 0) ? (int)(blockIdx.x % 8) * (G / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int plane = b.Spad * 4;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)b.colp, 0, (kNQ - 1) / 2 * plane, 0x00020000);
+    double* const recd[2] = {(double*)b.rec[0], (double*)b.rec[1]};      // m_k lives in recd[k & 1] (u_0 of the prologue in recd[1]): the first Spad doubles of a record plane
+    const int own_n = a.row1 - a.row0;
+    const int wg_first = lb * rows_per_wg, wg_last = min(own_n, wg_first + rows_per_wg) - 1;
+    const bool cut_lo = MR && xr.give_lo > 0 && wg_first < xr.give_lo && wg_first < own_n;
+    const bool cut_hi = MR && xr.give_hi > 0 && wg_last >= own_n - xr.give_hi && wg_first < own_n;
+    const int hi_first_wg = MR ? max(0, own_n - xr.give_hi) / rows_per_wg : 0;
+    double* const xr_me = MR ? xr.region[xr.rank] : nullptr;
+    const unsigned etag0 = MR ? (xr.epoch & kXrEpochMask) << 2 : 0u;
+    constexpr int kLocalSpins = MR ? (1 << 24) : (1 << 22);
+    auto peer_tag = [&](int buf, double v) {
+        if (cut_lo && lb < kXrPeerTags) __hip_atomic_store(xr.region[xr.rank - 1] + kXrPtag + (1 * 3 + buf) * kXrPeerTags + lb, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (cut_hi && lb - hi_first_wg < kXrPeerTags) __hip_atomic_store(xr.region[xr.rank + 1] + kXrPtag + (0 * 3 + buf) * kXrPeerTags + (lb - hi_first_wg), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    // the neighbour slab's halo row of the same band row.  (xr.lo_rec / hi_rec point at the first halo RECORD, 16 bytes per row: the same row counted in doubles)
+    const int lo_row0 = MR && xr.lo_rec[0] ? (int)(xr.lo_rec[0] - xr.lo_base[0]) : 0;
+    auto push_record = [&](int buf, int rel, double v) {
+        if (MR && rel < xr.give_lo) store8_sys((double*)xr.lo_base[buf] + lo_row0 + rel, v);
+        if (MR && rel >= own_n - xr.give_hi) store8_sys((double*)xr.hi_rec[buf] + (rel - (own_n - xr.give_hi)), v);
+    };
+    auto raise_abort = [&] {
+        __hip_atomic_store(fs + 3, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MR) for (int r = 0; r < xr.n_ranks; ++r) __hip_atomic_store(xr.region[r] + kXrAbort, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    float* hs = (float*)psg_dyn_smem;
+    unsigned cp[R][(kNQ - 1) / 2]; int row[R]; bool live[R];
+    double x[R], r[R], w[R], z[R], sv[R], pv[R]; float inv[R];      // every vector of the recurrences in double: see "precision" above
+    if (a.fold.n != 0 && blockIdx.x == 0) {      // the sums the distance sweep left pending (device_common.h fold_pending), in that function's order
+        for (int sl = 0; sl < a.fold.n; ++sl) {
+            const double* part = PART(a, a.fold.id[sl]);
+            double v = 0;
+            if (tid < kBlock) for (int i = tid; i < a.fold.nblk; i += kBlock) v += part[i];
+            v = wave_sum(v);
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = v;
+            __syncthreads();
+            if (tid == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; mbox_put(a.fold.out, a.fold.n, sl, t, a.fold.key); }
+        }
+        if (tid == 0) mbox_commit(a.fold.key);
+        __syncthreads();
+    }
+    // ---- once: assemble the rows of this thread (coefficients -> LDS), r_0 = b, u_0 = M^-1 b out for the neighbours
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int i = a.row0 + lb * rows_per_wg + u * kSolveThreads + tid;
+        live[u] = u * kSolveThreads + tid < rows_per_wg && i < a.row1; row[u] = live[u] ? i : a.row1 - 1;
+        double acc[kNQ], rhs;
+        assemble_row_regs(a, row[u], acc, rhs);
+#pragma unroll
+        for (int q = 0; q < kNQ; ++q) {
+            float hv = (float)acc[q];
+            if (q == 0 && a.damping != 0.0f) hv += a.damping * hv;
+            hs[(u * kNQ + q) * kSolveThreads + tid] = hv;
+        }
+        float dg = (float)acc[0];
+        if (a.damping != 0.0f) dg += a.damping * dg;
+        inv[u] = dg != 0.f ? 1.0f / dg : 1.0f;
+        r[u] = live[u] ? (double)(float)rhs : 0.0;      // (b is the float vector the reference solves for)
+        x[u] = 0.0; z[u] = 0.0; sv[u] = 0.0; pv[u] = 0.0; w[u] = 0.0;
+        if (live[u]) { const double u0 = (double)inv[u] * r[u]; store8_sc1(recd[1] + row[u], u0); push_record(1, row[u] - a.row0, u0); }
+#pragma unroll
+        for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) cp[u][wd] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rC, row[u] * 4, wd * plane, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) { __hip_atomic_store(gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + lb, (double)(1 + my_xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR) peer_tag(2, xr_tag(1.0, etag0 | 1u)); }
+    float rhsNorm2 = 0.f, thr = 0.f, rr_cur = 0.f;
+    double gamma_old = 0.0, alpha = 0.0;
+    int k = -1, status = 1;                   // k = -1: the extra round w_0 = A u_0
+    const int first = lb * rows_per_wg, last = first + rows_per_wg - 1;
+    const int nlo = max(0, (first - b.reach) / rows_per_wg), nhi = min(G - 1, (last + b.reach) / rows_per_wg);
+    const bool need_lo = MR && xr.need_lo > 0 && wg_first < b.reach, need_hi = MR && xr.need_hi > 0 && wg_last + b.reach >= own_n;
+#define SOLVE_STAMP(j) do { if (force_passes > 0 && k == 8 && tid == 0 && (lb == 0 || lb == (G * 9) / 16)) mb[8 + (lb ? 8 : 0) + (j)] = (double)wall_clock64(); } while (0)
+    for (;; ++k) {
+        SOLVE_STAMP(0);
+        const unsigned want = (unsigned)(k + 1) & 3u;      // tag of the sums published for pass k (k >= 0)
+        const double* gp = gran + (size_t)(k & 1) * kSolveGranPlanes * kSolveMaxBlocks;
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+#pragma unroll
+            for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) asm volatile("" : "+v"(cp[u][wd]));
+        // ---- A: the values this workgroup gathers are those of its neighbours in band order: their tag (the first sum of pass k, stored after
+        // their m_k had drained; k = -1: the prologue's flag)
+        if (tid == 0) { s_abort = 0; if (k < 0) s_foreign = 0; }
+        __syncthreads();
+        if (tid <= nhi - nlo && !((a.pcg_xcd_local >> 3) & 2)) {
+            int spins = 0;
+            const double* wp = k >= 0 ? gp + nlo + tid : gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + nlo + tid;
+            double seen = 0.0;
+            while (k >= 0 ? gran_tag_of(seen = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != want : (seen = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0.0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kLocalSpins || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
+            }
+            if (k < 0 && (int)seen != 1 + my_xcc) s_foreign = 1;
+        }
+        if (MR) {
+            const int side = tid >= 128 ? 1 : 0, j = tid - (side ? 128 : 64);
+            if (tid >= 64 && tid < 192 && j < (side ? xr.wait_hi : xr.wait_lo) && (side ? need_hi : need_lo)) {
+                int spins = 0;
+                const double* wp = xr_me + kXrPtag + (side * 3 + (k >= 0 ? (k & 1) : 2)) * kXrPeerTags + j;
+                const unsigned wantx = etag0 | (k >= 0 ? want : 1u);
+                while (xr_tag_of(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != wantx) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 24) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
+                }
+            }
+        }
+        __syncthreads();
+        if (s_abort) { if (tid == 0) raise_abort(); status = 2; break; }
+        if (tid == 0) { if (MR) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+        if (k < 0) xcd_local = (a.pcg_xcd_local & 1) && !s_foreign;
+        __syncthreads();
+        SOLVE_STAMP(1);
+        if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 1536 + lb] = (double)wall_clock64();      // ... neighbours' tags of pass 9 seen
+        // ---- B: n = A m (k = -1: w_0 = A u_0): 18 four-byte gathers per row in two batches of 9, software-pipelined across the rows of the thread
+        const double* __restrict__ rin = recd[k >= 0 ? (k & 1) : 1];
+        const int abl = (a.pcg_xcd_local >> 3) & 3;      // timing ablations (tools/pcg_variants.py; never set in production): 1 = every gather reads the row's own element, 2 = no neighbour-tag wait
+        double nres[R];
+        double ob[kCgpDepth][9];
+        auto issue = [&](int t) {
+            const int u = t >> 1, j0 = (t & 1) * 9;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) { const int jj = j0 + j; const int pk = (int)cp[u][jj >> 1]; ob[t % kCgpDepth][j] = rin[row[u] + ((abl & 1) ? 0 : ((jj & 1) ? (pk >> 16) : ((pk << 16) >> 16)))]; }
+        };
+        // The sums of pass k were published when m_k was: by the time the last gather batch is on its way they have normally arrived, but FETCHING
+        // them is a memory round trip of its own (agent-scope loads past the XCD's L2: ~1.5 us if issued only after the gathers).  So they are
+        // requested right behind the last batch and checked in stage C; only a late workgroup's granules are polled for again there.
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.0;
+        auto prefetch_sums = [&] {
+            if (k >= 0 && (a.pcg_xcd_local & 2) && tid < G) {
+#pragma unroll
+                for (int q = 0; q < kCgpSums; ++q) v[q] = __hip_atomic_load(gp + (size_t)q * kSolveMaxBlocks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < kCgpDepth && t < 2 * R; ++t) issue(t);
+        if (2 * R - 1 - kCgpDepth < 0) { __builtin_amdgcn_sched_barrier(0); prefetch_sums(); __builtin_amdgcn_sched_barrier(0); }
+        double acc = 0;
+#pragma unroll
+        for (int t = 0; t < 2 * R; ++t) {
+            const int u = t >> 1, j0 = (t & 1) * 9;
+            const float* hrow = hs + (size_t)u * kNQ * kSolveThreads + tid;
+            if (!(t & 1)) { const double mine = (double)inv[u] * (k >= 0 ? w[u] : r[u]); acc = (double)hrow[0] * mine; }      // (the row's own m: what it published)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) acc += (double)hrow[(j0 + j + 1) * kSolveThreads] * ob[t % kCgpDepth][j];
+            asm volatile("" : "+v"(acc));
+            if (t & 1) nres[u] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + kCgpDepth < 2 * R) issue(t + kCgpDepth);
+            if (t == 2 * R - 1 - kCgpDepth) prefetch_sums();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        SOLVE_STAMP(2);
+        if (force_passes > 0 && k == 9 && tid == 0) { fs[16 + 1024 + lb] = (double)wall_clock64(); fs[16 + 768 + lb] = (double)my_xcc; fs[16 + 1792 + lb] = (double)(gran_tag_of(v[0]) == want && gran_tag_of(v[1]) == want && gran_tag_of(v[2]) == want); }      // timing hook (PSGSDF_SOLVE_DUMP): gathers of pass 9 done; was the prefetch of this thread's granules valid?
+        double beta = 0.0;
+        bool stop = false;
+        if (k >= 0) {
+            // ---- C: the three sums for pass k of EVERY workgroup (published at the end of pass k - 1: normally all here by now)
+            auto poll3 = [&](const double* base, bool prefetched) {      // this thread's three granules at base[q * kSolveMaxBlocks] until they carry the pass's tag
+                int spins = 0;
+                bool ok = prefetched && gran_tag_of(v[0]) == want && gran_tag_of(v[1]) == want && gran_tag_of(v[2]) == want;
+                while (!ok) {
+                    if (spins) __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kLocalSpins || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
+                    ok = true;
+#pragma unroll
+                    for (int q = 0; q < kCgpSums; ++q) { v[q] = __hip_atomic_load(base + (size_t)q * kSolveMaxBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = ok && gran_tag_of(v[q]) == want; }
+                }
+            };
+            if (tid < G) poll3(gp + tid, (a.pcg_xcd_local & 2) != 0);
+            double t0, t1; wave_sum8(v, t0, t1);
+            wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
+            __syncthreads();
+            if (s_abort) { if (tid == 0) raise_abort(); status = 2; break; }
+            double t[kCgpSums];
+#pragma unroll
+            for (int q = 0; q < kCgpSums; ++q) { double s_ = 0; for (int i = 0; i < kSolveThreads / 64; ++i) s_ += red[q * (kSolveThreads / 64) + i]; t[q] = s_; }
+            __syncthreads();
+            if (MR) {
+                // ---- C2: this RANK's sums -> every rank's region (workgroup 0), then the R rank granules of the own region in rank order
+                const int pb = k & 1;
+                if (lb == 0 && tid < kCgpSums) {
+                    const double mine = xr_tag(t[tid], etag0 | want);
+                    for (int rk = 0; rk < xr.n_ranks; ++rk) __hip_atomic_store(xr.region[rk] + kXrRankGran + (pb * 8 + tid) * kXrMaxRanks + xr.rank, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                double rv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rv[q] = 0.0;
+                if (tid < xr.n_ranks) {
+                    int spins = 0; bool ok = false;
+                    while (!ok) {
+                        ok = true;
+#pragma unroll
+                        for (int q = 0; q < kCgpSums; ++q) { rv[q] = __hip_atomic_load(xr_me + kXrRankGran + (pb * 8 + q) * kXrMaxRanks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = ok && xr_tag_of(rv[q]) == (etag0 | want); }
+                        if (!ok) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1 << 24) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
+                        }
+                    }
+                }
+                double r0, r1; wave_sum8(rv, r0, r1);
+                wave_sum8_store<kSolveThreads / 64>(r0, r1, red, tid >> 6);
+                __syncthreads();
+                if (s_abort) { if (tid == 0) raise_abort(); status = 2; break; }
+#pragma unroll
+                for (int q = 0; q < kCgpSums; ++q) t[q] = red[q * (kSolveThreads / 64)];      // (all <= 32 rank granules sit in wavefront 0)
+                __syncthreads();
+            }
+            if (k == 0) { rhsNorm2 = (float)t[2]; thr = pcg_threshold(rhsNorm2); if (lb == 0 && tid == 0) fs[0] = t[2]; }
+            rr_cur = (float)t[2];
+            const bool rhs_zero = rhsNorm2 == 0.f;
+            stop = force_passes > 0 ? k >= force_passes : (rhs_zero || k == kmax || (k > 0 && rr_cur < thr));
+            if (!stop) {
+                // alpha = gamma / (delta - beta gamma / alpha_old): the reference's alpha = r.z / p.Ap without the product that is still being gathered
+                beta = k > 0 ? t[0] / gamma_old : 0.0;
+                alpha = t[0] / (k > 0 ? t[1] - beta * t[0] / alpha : t[1]);
+                gamma_old = t[0];
+            }
+        }
+        SOLVE_STAMP(3);
+        if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 256 + lb] = fs[16 + 512 + lb] = (double)wall_clock64();      // ... the sums of pass 9 of all the others seen
+        if (stop) break;
+        if (force_passes == -7 && k == 2 && lb == 1) { status = 2; break; }      // fault injection: this workgroup never publishes pass 3
+        // ---- D: the update (k = -1: w_0 = n), the three sums and m for the next pass
+        double s[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s[q] = 0.0;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            double ui = (double)inv[u] * r[u];
+            if (k < 0) w[u] = nres[u];
+            else {
+                z[u] = nres[u] + beta * z[u];
+                sv[u] = w[u] + beta * sv[u];
+                pv[u] = ui + beta * pv[u];
+                x[u] = x[u] + alpha * pv[u];
+                r[u] = r[u] - alpha * sv[u];
+                w[u] = w[u] - alpha * z[u];
+                ui = (double)inv[u] * r[u];
+            }
+            const double mnext = (double)inv[u] * w[u];
+            if (live[u]) {
+                s[0] += r[u] * ui; s[1] += w[u] * ui; s[2] += r[u] * r[u];
+                double* dst = recd[(k + 1) & 1] + row[u];
+                // readers on this XCD hit the line in its L2 if it is DIRTY there (a plain store: the per-pass acquire only drops clean lines); readers
+                // on another XCD need it in memory (write-through store).  A workgroup with neighbours on both sides does both.
+                if (!xcd_local) store8_sc1(dst, mnext);
+                *dst = mnext;
+                push_record((k + 1) & 1, row[u] - a.row0, mnext);
+            }
+        }
+        SOLVE_STAMP(4);
+        // ---- E: publish: m has to be out (drained) before the tagged sums
+        double t0, t1; wave_sum8(s, t0, t1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
+        __syncthreads();
+        SOLVE_STAMP(5);
+        if (tid < kCgpSums) {
+            double tot = 0;
+            for (int i = 0; i < kSolveThreads / 64; ++i) tot += red[tid * (kSolveThreads / 64) + i];
+            double* gq = gran + (size_t)((k + 1) & 1) * kSolveGranPlanes * kSolveMaxBlocks + (size_t)tid * kSolveMaxBlocks + lb;
+            __hip_atomic_store(gq, gran_tag(tot, (unsigned)(k + 2) & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (MR && tid == 64) peer_tag((k + 1) & 1, xr_tag(1.0, etag0 | ((unsigned)(k + 2) & 3u)));
+        __syncthreads();
+        SOLVE_STAMP(6);
+        if (force_passes > 0 && k == 8 && tid == 0) fs[16 + lb] = (double)wall_clock64();      // ... published at the end of pass 8 (m_9 and the sums of pass 9)
+        if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 1280 + lb] = (double)wall_clock64();  // ... and at the end of pass 9
+    }
+#undef SOLVE_STAMP
+    // ---- leave: x of the own rows; the distance update; the outcome for the host and for the gated kernels behind this one
+    float xf[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) { xf[u] = (float)x[u]; if (live[u]) b.x[row[u]] = xf[u]; }
+    if (a.pcg_apply) {
+        const bool z0 = rhsNorm2 == 0.f;
+        const bool ok_all = status == 1 && (z0 || sqrt((double)rr_cur / (double)rhsNorm2) <= (double)FLT_EPSILON);
+        const bool apply = status == 1 && (a.pcg_apply == 1 || ok_all);
+        double cnt = 0;
+        if (apply) {
+#pragma unroll
+            for (int u = 0; u < R; ++u) if (live[u] && (double)fabsf(xf[u]) < sqrt(3.0) * (double)a.grid.vs) { b.dist[row[u]] -= xf[u]; cnt += 1.0; }
+        }
+        cnt = wave_sum(cnt);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = cnt;
+        __syncthreads();
+        double* slot = PART(a, SC_ACCEPT);
+        if (tid == 0) { double t = 0; for (int i = 0; i < kSolveThreads / 64; ++i) t += red[i]; slot[lb] = t; }
+        for (int i = G + lb * kSolveThreads + tid; i < a.acc.PB; i += G * kSolveThreads) slot[i] = 0.0;
+    }
+    if (lb == 0 && tid == 0) {
+        const bool rhs_zero = rhsNorm2 == 0.f;
+        const bool ok = status == 1 && (rhs_zero || sqrt((double)rr_cur / (double)rhsNorm2) <= (double)FLT_EPSILON);
+        int iters = 0;
+        if (!rhs_zero && k > 0) iters = (rr_cur < thr) ? k - 1 : k;
+        fs[1] = status == 1 ? (double)(k + 1) : 0.0; fs[2] = ok ? 1.0 : 0.0;
+        const double m0 = (double)iters, m1 = (double)rr_cur, m2 = (double)rhsNorm2, m3 = (double)status;
+        mb[0] = m0; mb[1] = m1; mb[2] = m2;
+        __threadfence_system();
+        mb[3] = m3;
+        if (mb_key) reinterpret_cast<unsigned long long*>(mb)[4] = (unsigned long long)(__double_as_longlong(m0) ^ __double_as_longlong(m1) ^ __double_as_longlong(m2) ^ __double_as_longlong(m3)) ^ mb_key;
+        __threadfence_system();
+    }
+}
 static size_t cgf_solve_lds(int rows) { return sizeof(float) * (size_t)rows * kNQ * kSolveThreads; }
+static size_t cgp_solve_lds(int rows) { return cgf_solve_lds(rows); }
 template <int R, bool ASM, bool MR> static int cgf_solve_prepare() {      // > 64 KB of dynamic LDS has to be asked for, once per instance
     static int per_cu = -1;
     if (per_cu >= 0) return per_cu;
@@ -796,13 +1148,31 @@ template <int R, bool ASM, bool MR> static int cgf_solve_prepare() {      // > 6
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cgf_solve<R, ASM, MR>, kSolveThreads, cgf_solve_lds(R)) == hipSuccess) per_cu = n;
     return per_cu;
 }
-template <int R> static int cgf_solve_prepare_both() { return std::min(std::min(cgf_solve_prepare<R, false, false>(), cgf_solve_prepare<R, true, false>()), cgf_solve_prepare<R, true, true>()); }
+template <int R, bool MR> static int cgp_solve_prepare() {
+    static int per_cu = -1;
+    if (per_cu >= 0) return per_cu;
+    per_cu = 0;
+    if (hipFuncSetAttribute((const void*)k_cgp_solve<R, MR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cgp_solve_lds(R)) != hipSuccess) return per_cu;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cgp_solve<R, MR>, kSolveThreads, cgp_solve_lds(R)) == hipSuccess) per_cu = n;
+    return per_cu;
+}
+template <int R> static int cgf_solve_prepare_both() {
+    const int classic = std::min(std::min(cgf_solve_prepare<R, false, false>(), cgf_solve_prepare<R, true, false>()), cgf_solve_prepare<R, true, true>());
+    if (R > kCgpMaxRows) return classic;
+    return std::min(classic, std::min(cgp_solve_prepare<R, false>(), cgp_solve_prepare<R, true>()));
+}
 int cgf_solve_max_blocks(int rows) {
     return rows == 1 ? cgf_solve_prepare_both<1>() : rows == 2 ? cgf_solve_prepare_both<2>() : rows == 3 ? cgf_solve_prepare_both<3>() : cgf_solve_prepare_both<4>();
 }
 template <int R>
 static void launch_cgf_solve_r(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, hipStream_t s, const XrArgs* xr) {
     XrArgs none{};
+    if (a.pcg_asm && a.pcg_pipe && R <= kCgpMaxRows) {      // the pipelined recurrences (always with the fused assembly)
+        if (xr && xr->n_ranks > 1) hipLaunchKernelGGL((k_cgp_solve<R, true>), dim3(G), dim3(kSolveThreads), cgp_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, *xr);
+        else hipLaunchKernelGGL((k_cgp_solve<R, false>), dim3(G), dim3(kSolveThreads), cgp_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, none);
+        return;
+    }
     if (xr && xr->n_ranks > 1 && a.pcg_asm) hipLaunchKernelGGL((k_cgf_solve<R, true, true>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, *xr);
     else if (a.pcg_asm) hipLaunchKernelGGL((k_cgf_solve<R, true, false>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, none);
     else hipLaunchKernelGGL((k_cgf_solve<R, false, false>), dim3(G), dim3(kSolveThreads), cgf_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, none);

@@ -196,10 +196,12 @@ def test_persistent_solve_falls_back_to_the_per_pass_kernels(built, name, mid, m
     r_e, r_r, r_o = eng.iterate(capi.ALL, 3), ref.iterate(capi.ALL, 3), orc.iterate(capi.ALL, 3)
     assert eng.debug_sync_stats()["persist_fallbacks"] == 1 and ref.debug_sync_stats()["persist_fallbacks"] == 0
     assert "per-pass kernels" in capfd.readouterr().err
-    assert [r["e_total"] for r in r_e] == [r["e_total"] for r in r_r] and [r["cg_iters"] for r in r_e] == [r["cg_iters"] for r in r_r]
+    # the solve that fell back and every solve of `ref` ran the per-pass kernels (Eigen's recurrences in float), the other solves of `eng` the
+    # pipelined ones in double: rounding-level differences only
+    assert np.allclose([r["e_total"] for r in r_e], [r["e_total"] for r in r_r], rtol=2e-6) and all(abs(a["cg_iters"] - b["cg_iters"]) <= 1 for a, b in zip(r_e, r_r))
     band = eng.download_band(); vs = float(sc.voxel_size)
     ve, vr, vo = eng.download_volume(), ref.download_volume(), orc.download_volume()
-    assert np.array_equal(ve["dist"], vr["dist"]) and np.array_equal(ve["rgb"][:, band], vr["rgb"][:, band]) and np.array_equal(eng.download_poses(), ref.download_poses())
+    assert np.abs(ve["dist"][band] - vr["dist"][band]).max() <= 5e-5 * vs and np.abs(ve["rgb"][:, band] - vr["rgb"][:, band]).max() <= 5e-5 and np.abs(eng.download_poses() - ref.download_poses()).max() <= 1e-6
     d = np.abs(ve["dist"][band] - vo["dist"][band]) / vs
     assert d.max() <= 1e-4, (np.quantile(d, 0.999), d.max())      # three iterations, no refinement: every band voxel (tests/test_parity_gpu.py OPT_MAX_VS)
     for a, b in zip(r_e, r_o):

@@ -59,9 +59,19 @@ def test_pcg_launch_shape_only_changes_rounding(built):
 @pytest.mark.parametrize("model", ["SH1", "LED"])
 def test_distance_step_fusions_are_bitwise_neutral(built, model):
     """The persistent solve kernel that assembles its own rows (register accumulation in assemble_row's order) and applies the distance update
-    in its epilogue must give the bits of: the same kernel with k_apply_dist behind it, with k_assemble in front of it, and of the per-pass
-    kernels (what multi-rank contexts run) -- energies, iteration counts and the optimised state, through psgsdf_optimize as well."""
+    in its epilogue must give the bits of the same kernel with k_apply_dist behind it, with every value through memory instead of the XCD's L2, and
+    with the sums fetched after instead of behind the gathers -- energies, iteration counts and the optimised state, through psgsdf_optimize too.
+    The CLASSIC recurrences (round 2's persistent kernel, the same with k_assemble in front, the per-pass kernels that multi-rank fallbacks and
+    512^3 bands run) agree with each other to the bit as well; between the two families -- pipelined recurrences in double vs Eigen's in float --
+    only rounding differs: same iteration counts (+-1), energies to 2e-5."""
     ref = run(model, {}, full=True)
-    for env in ({"PSGSDF_PCG_FUSE_APPLY": "0"}, {"PSGSDF_PCG_FUSE_ASM": "0"}, {"PSGSDF_PCG_PERSIST": "0"}, {"PSGSDF_PCG_XCD_LOCAL": "0"}):      # XCD_LOCAL=0: every record through memory
+    for env in ({"PSGSDF_PCG_FUSE_APPLY": "0"}, {"PSGSDF_PCG_XCD_LOCAL": "0"}, {"PSGSDF_PCG_PREFETCH": "0"}):
         got = run(model, env, full=True)
         assert got == ref, (env, got, ref)
+    classic = run(model, {"PSGSDF_PCG_PIPELINE": "0"}, full=True)
+    for env in ({"PSGSDF_PCG_FUSE_ASM": "0"}, {"PSGSDF_PCG_PERSIST": "0"}, {"PSGSDF_PCG_PIPELINE": "0", "PSGSDF_PCG_XCD_LOCAL": "0"}):
+        got = run(model, env, full=True)
+        assert got == classic, (env, got, classic)
+    assert all(abs(a - b) <= 1 for a, b in zip(classic["cg"], ref["cg"])) and classic["n2"] == ref["n2"]
+    assert all(abs(a - b) <= 2e-5 * abs(b) for a, b in zip(classic["e"] + classic["e2"], ref["e"] + ref["e2"])), (classic["e"], ref["e"])
+    assert abs(classic["dsum"] - ref["dsum"]) <= 1e-5 * ref["dsum"] and abs(classic["psum"] - ref["psum"]) <= 1e-6 * ref["psum"]
