@@ -202,31 +202,7 @@ __global__ void __launch_bounds__(kBlock) k_derive(SweepArgs a, int update_grad)
     const Band& b = a.b;
     int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
     double en = 0, el = 0;
-    if (j < a.row1) {
-        float n[3], dir[3];
-        fd_grad(b, j, a.grid.vs_inv, n, dir);
-        float g[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { b.gfd[k][j] = n[k]; if (update_grad) b.g[k][j] = n[k]; g[k] = update_grad ? n[k] : b.g[k][j]; }
-        float gn[3]; normalized3(g, gn);
-        float nn[3]; normalized3(n, nn);
-        long long lin = b.lin[j];
-        int nxy = a.grid.dim[0] * a.grid.dim[1];
-        int kz = (int)(lin / nxy); int rest = (int)(lin - (long long)kz * nxy); int jy = rest / a.grid.dim[0]; int ix = rest - jy * a.grid.dim[0];
-        int idx[3] = {ix, jy, kz};
-        float d = b.dist[j];
-        float xs[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float xv = a.grid.origin[k] + a.grid.vs * (float)(idx[k] + (k == 2 ? a.grid.koff : 0));   // VoxelGrid.h:38-40 (global voxel index: a slab's local planes start at koff)
-            xs[k] = xv - d * gn[k];
-        }
-        b.vp[0][j] = make_float4(xs[0], xs[1], xs[2], b.rho[0][j]);
-        b.vp[1][j] = make_float4(gn[0], gn[1], gn[2], b.rho[1][j]);
-        b.vp[2][j] = make_float4(nn[0], nn[1], nn[2], b.rho[2][j]);
-        float e = norm3(n) - 1; en = (double)(e * e);
-        float l = laplacian(b, j, a.grid.vs_inv); el = (double)(l * l);
-    }
+    if (j < a.row1) derive_row(a, j, update_grad, en, el);
     block_part_store(en, PART(a, SC_EN), red);
     block_part_store(el, PART(a, SC_EL), red);
 }

@@ -527,6 +527,37 @@ __device__ __forceinline__ float laplacian(const Band& b, int j, float vs_inv) {
     return (dd[0] + dd[1] + dd[2]) * vs_inv * vs_inv;
 }
 
+// One band row of k_derive: FD gradient (Optimizer.cpp:287-364), optional updateGrad (OptimizerAux.cpp:152-160), the packed per-voxel record the
+// sweeps read (surface point, the two normalised gradients, albedo) and the row's Eikonal / Laplacian energy terms (Optimizer.cpp:86-119).
+// Shared by k_derive (band.hip) and by the epilogue of the persistent distance solve (pcg.hip: the regrad behind the solve's last hand-off).
+__device__ __forceinline__ void derive_row(const SweepArgs& a, int j, int update_grad, double& en, double& el) {
+#pragma clang fp contract(off)
+    const Band& b = a.b;
+    float n[3], dir[3];
+    fd_grad(b, j, a.grid.vs_inv, n, dir);
+    float g[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { b.gfd[k][j] = n[k]; if (update_grad) b.g[k][j] = n[k]; g[k] = update_grad ? n[k] : b.g[k][j]; }
+    float gn[3]; normalized3(g, gn);
+    float nn[3]; normalized3(n, nn);
+    long long lin = b.lin[j];
+    int nxy = a.grid.dim[0] * a.grid.dim[1];
+    int kz = (int)(lin / nxy); int rest = (int)(lin - (long long)kz * nxy); int jy = rest / a.grid.dim[0]; int ix = rest - jy * a.grid.dim[0];
+    int idx[3] = {ix, jy, kz};
+    float d = b.dist[j];
+    float xs[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float xv = a.grid.origin[k] + a.grid.vs * (float)(idx[k] + (k == 2 ? a.grid.koff : 0));   // VoxelGrid.h:38-40 (global voxel index: a slab's local planes start at koff)
+        xs[k] = xv - d * gn[k];
+    }
+    b.vp[0][j] = make_float4(xs[0], xs[1], xs[2], b.rho[0][j]);
+    b.vp[1][j] = make_float4(gn[0], gn[1], gn[2], b.rho[1][j]);
+    b.vp[2][j] = make_float4(nn[0], nn[1], nn[2], b.rho[2][j]);
+    float e = norm3(n) - 1; en = (double)(e * e);
+    float l = laplacian(b, j, a.grid.vs_inv); el = (double)(l * l);
+}
+
 // ------------------------------------------------------------------------------------------
 // voxel-major sweeps: one thread per band voxel, iterating the set bits of its visibility mask
 // ------------------------------------------------------------------------------------------

@@ -1122,6 +1122,9 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
         double* slot = PART(a, SC_ACCEPT);
         if (tid == 0) { double t = 0; for (int i = 0; i < kSolveThreads / 64; ++i) t += red[i]; slot[lb] = t; }
         for (int i = G + lb * kSolveThreads + tid; i < a.acc.PB; i += G * kSolveThreads) slot[i] = 0.0;
+        // (Measured and rejected, profiles/r04_notes.md: the regrad -- k_derive -- in this epilogue behind one more neighbour hand-off.  Same bits, no
+        // launch, but 2 648 vs 2 680 it/s: with one workgroup of eight waves per CU the dependent loads of three rows per thread take longer than the
+        // 13 us the stand-alone kernel needs at full occupancy.)
     }
     if (lb == 0 && tid == 0) {
         const bool rhs_zero = rhsNorm2 == 0.f;
