@@ -287,9 +287,15 @@ typedef struct psgsdf_comm_ops {
     void* user;
     int (*allreduce_f64)(void* user, double* buf_dev, int n, void* hip_stream);                 /* in-place sum over all ranks */
     int (*sendrecv)(void* user, const psgsdf_comm_xfer* sends, int n_sends,
-                    const psgsdf_comm_xfer* recvs, int n_recvs, void* hip_stream);              /* with rank-1 / rank+1; matched in list order per peer */
+                    const psgsdf_comm_xfer* recvs, int n_recvs, void* hip_stream);              /* peers: rank-1 / rank+1 (any rank in psgsdf_rebalance_slabs); matched in list order per peer */
 } psgsdf_comm_ops;
 int psgsdf_comm_init_ext(psgsdf_ctx* ctx, const psgsdf_comm_ops* ops, int rank, int n_ranks);
+
+/* A volume fused slab-parallel (psgsdf_volume_init / psgsdf_integrate_frame on a multi-rank context: every rank fuses every frame into the z-planes it
+ * holds, VolumetricGradSdf.cpp:78-134 touches each voxel independently; the slabs are cut by HEIGHT because the band does not exist yet) is re-cut
+ * into slabs of equal band-candidate count -- the partition psgsdf_upload_volume chooses -- and the planes move to their new ranks.  Collective;
+ * a no-op on one rank.  Uses the transport's sendrecv with ANY rank as peer, not only the z-neighbours.  No reference counterpart. */
+int psgsdf_rebalance_slabs(psgsdf_ctx* ctx);
 
 /* run every launch of this context on a caller-owned HIP stream */
 int psgsdf_set_stream(psgsdf_ctx* ctx, void* hip_stream);

@@ -134,6 +134,10 @@ class Api:
         self._check(self._fn("plan_slab")(self.ctx, a[1], C.byref(z0), C.byref(z1)), "plan_slab")
         return z0.value, z1.value
 
+    def rebalance_slabs(self):
+        """re-cut a slab-parallel fused volume into slabs of equal band-candidate count and move the planes (collective)"""
+        self._check(self._fn("rebalance_slabs")(self.ctx), "rebalance_slabs")
+
     def upload_volume_slab(self, z0, z1, dist, grad, weight, rgb, vis, words):
         a = [_fp(dist), _fp(grad), _fp(weight), _fp(rgb), _fp(vis, np.uint64)]
         self._check(self._fn("upload_volume_slab")(self.ctx, C.c_int(z0), C.c_int(z1), a[0][1], a[1][1], a[2][1], a[3][1], a[4][1], C.c_int(words)), "upload_volume_slab")
@@ -228,7 +232,7 @@ class Api:
     def download_vis_seq(self, words):
         i = self.info()
         n = int(i.dim[0]) * int(i.dim[1]) * int(i.dim[2])
-        out = np.empty((n, words), np.uint64)
+        out = np.zeros((n, words), np.uint64)      # (a slab fills the planes it owns)
         f = self._fn("download_vis_seq")
         rc = f(self.ctx, out.ctypes.data_as(C.c_void_p))
         if rc < 0:

@@ -184,8 +184,10 @@ int psgsdf_upload_volume_slab(psgsdf_ctx* c, int z0, int z1, const float* dist, 
 
 int psgsdf_volume_init(psgsdf_ctx* c, int max_frames) {
     if (!c || max_frames < 1) return fail(c, PSGSDF_ERR_ARG, "volume_init: max_frames");
-    if (c->n_ranks > 1) return fail(c, PSGSDF_ERR_UNSUPPORTED, "frame fusion runs on one rank: fuse, download, then upload the volume to the ranks");
-    { int rc0 = set_local_grid(c, 0, c->gdim[2]); if (rc0) return rc0; }
+    // multi-rank: fusion is slab-parallel (VolumetricGradSdf.cpp:78-134 touches every voxel independently).  The band does not exist yet, so the
+    // volume is cut into slabs of equal HEIGHT; psgsdf_rebalance_slabs moves planes to slabs of equal band count once the frames are fused.
+    if (c->n_ranks > 1 && c->gdim[2] < c->n_ranks) return fail(c, PSGSDF_ERR_UNSUPPORTED, "%d z-planes cannot be cut into %d slabs", c->gdim[2], c->n_ranks);
+    { int rc0 = c->n_ranks > 1 ? set_local_grid(c, (int)((long long)c->rank * c->gdim[2] / c->n_ranks), (int)((long long)(c->rank + 1) * c->gdim[2] / c->n_ranks)) : set_local_grid(c, 0, c->gdim[2]); if (rc0) return rc0; }
     HIPCHK(c, hipSetDevice(c->device));
     const long long n = c->grid.nvox;
     free_dense(c);
@@ -202,10 +204,82 @@ int psgsdf_volume_init(psgsdf_ctx* c, int max_frames) {
     return PSGSDF_OK;
 }
 
+// Re-cut a slab-parallel volume (psgsdf_volume_init cut it by height) into slabs of equal band-candidate count -- the partition every other entry
+// point works on (psgsdf_upload_volume: choose_slab) -- and move the planes: every rank counts the candidates of the planes it owns, one all-reduce
+// makes the histogram global, all ranks take the same cuts, and each plane travels from its old owner to every rank that holds it under the new
+// cut (own planes + one halo plane per inner side).  Collective.
+int psgsdf_rebalance_slabs(psgsdf_ctx* c) {
+    if (!c || !c->have_volume || !c->vis_seq) return fail(c, PSGSDF_ERR_STATE, "rebalance_slabs: volume first");
+    if (c->n_ranks <= 1) return PSGSDF_OK;
+    if (!c->comm) return fail(c, PSGSDF_ERR_COMM, "rank %d of %d has no communicator (psgsdf_comm_init)", c->rank, c->n_ranks);
+    HIPCHK(c, hipSetDevice(c->device));
+    const int R = c->n_ranks, nz = c->gdim[2], wpv = c->wpv_seq;
+    const size_t plane = (size_t)c->gdim[0] * c->gdim[1];
+    // band candidates of the planes this rank owns (|d| <= sqrt(3) vs and seen by some frame: OptimizerAux.cpp:249 before the keyframes are selected)
+    const int oz0 = c->z0, oz1 = c->z1, ozlo = c->zlo;
+    std::vector<float> hd((size_t)(oz1 - oz0) * plane); std::vector<uint64_t> hv((size_t)(oz1 - oz0) * plane * wpv);
+    HIPCHK(c, hipMemcpyAsync(hd.data(), c->dense.dist + (size_t)(oz0 - ozlo) * plane, sizeof(float) * hd.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hv.data(), c->vis_seq + (size_t)(oz0 - ozlo) * plane * wpv, sizeof(uint64_t) * hv.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<double> cnt(nz, 0.0);
+    for (int k = oz0; k < oz1; ++k) cnt[k] = count_plane(c, hd.data() + (size_t)(k - oz0) * plane, hv.data() + (size_t)(k - oz0) * plane * wpv, wpv);
+    int nz0 = 0, nz1 = nz;
+    { int rc = cut_slabs(c, cnt, &nz0, &nz1); if (rc) return rc; }
+    // every rank's old and new planes
+    std::vector<double> cuts((size_t)4 * R, 0.0);
+    cuts[4 * c->rank] = oz0; cuts[4 * c->rank + 1] = oz1; cuts[4 * c->rank + 2] = nz0; cuts[4 * c->rank + 3] = nz1;
+    { int rc = host_allreduce(c, cuts, "rebalance_slabs"); if (rc) return rc; }
+    // the new local grid and its arrays
+    DenseView od = c->dense; uint64_t* ovis = c->vis_seq;
+    c->dense = DenseView{}; c->vis_seq = nullptr;
+    { int rc = set_local_grid(c, nz0, nz1); if (rc) return rc; }
+    const int nzlo = c->zlo, nzhi = c->zhi;
+    const long long n = c->grid.nvox;
+    DenseView nd{};
+    int rc = alloc_dense(c, nd, n, 0, true); if (rc) return rc;
+    uint64_t* nvis = nullptr;
+    HIPCHK(c, hipMalloc(&nvis, sizeof(uint64_t) * n * wpv));
+    float* oarr[8] = {od.dist, od.g[0], od.g[1], od.g[2], od.rho[0], od.rho[1], od.rho[2], od.weight};
+    float* narr[8] = {nd.dist, nd.g[0], nd.g[1], nd.g[2], nd.rho[0], nd.rho[1], nd.rho[2], nd.weight};
+    std::vector<psgsdf_comm_xfer> sends, recvs;
+    for (int peer = 0; peer < R; ++peer) {
+        const int pz0 = (int)cuts[4 * peer], pz1 = (int)cuts[4 * peer + 1], pn0 = (int)cuts[4 * peer + 2], pn1 = (int)cuts[4 * peer + 3];
+        const int pnlo = std::max(0, pn0 - 1), pnhi = std::min(nz, pn1 + 1);
+        // what I own (old cut) and `peer` holds (new cut): I send (or copy, if I am the peer)
+        const int s0 = std::max(oz0, pnlo), s1 = std::min(oz1, pnhi);
+        if (s1 > s0) {
+            const size_t so = (size_t)(s0 - ozlo) * plane, cntv = (size_t)(s1 - s0) * plane;
+            if (peer == c->rank) {
+                const size_t dn = (size_t)(s0 - nzlo) * plane;
+                for (int q = 0; q < 8; ++q) HIPCHK(c, hipMemcpyAsync(narr[q] + dn, oarr[q] + so, sizeof(float) * cntv, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(nvis + dn * wpv, ovis + so * wpv, sizeof(uint64_t) * cntv * wpv, hipMemcpyDeviceToDevice, c->stream));
+            } else {
+                for (int q = 0; q < 8; ++q) sends.push_back({oarr[q] + so, sizeof(float) * cntv, peer});
+                sends.push_back({ovis + so * wpv, sizeof(uint64_t) * cntv * wpv, peer});
+            }
+        }
+        // what `peer` owns (old cut) and I hold (new cut): I receive
+        if (peer != c->rank) {
+            const int r0 = std::max(pz0, nzlo), r1 = std::min(pz1, nzhi);
+            if (r1 > r0) {
+                const size_t dn = (size_t)(r0 - nzlo) * plane, cntv = (size_t)(r1 - r0) * plane;
+                for (int q = 0; q < 8; ++q) recvs.push_back({narr[q] + dn, sizeof(float) * cntv, peer});
+                recvs.push_back({nvis + dn * wpv, sizeof(uint64_t) * cntv * wpv, peer});
+            }
+        }
+    }
+    rc = comm_xfer(c, sends, recvs);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "rebalance_slabs: exchange");
+    for (int q = 0; q < 8; ++q) hipFree(oarr[q]);
+    hipFree(od.vis); hipFree(od.row_of); hipFree(ovis); hipFree(c->block_sums); c->block_sums = nullptr;
+    c->dense = nd; c->vis_seq = nvis;
+    c->inited = false;
+    return rc;
+}
+
 int psgsdf_integrate_frame(psgsdf_ctx* c, const float* rgb, const float* depth, const float* normals_xyz, int width, int height, const float pose[16], int counter, float z_min, float z_max) {
     if (!c || !c->have_volume || !c->vis_seq) return fail(c, PSGSDF_ERR_STATE, "integrate_frame: volume_init or upload_volume first");
-    if (c->n_ranks > 1) return fail(c, PSGSDF_ERR_UNSUPPORTED, "frame fusion runs on one rank");
-    if (!rgb || !depth || !normals_xyz || !pose || width < 2 || height < 2 || counter < 0) return fail(c, PSGSDF_ERR_ARG, "integrate_frame: bad argument");
+    if (!rgb || !depth || !normals_xyz || !pose || width < 2 || height < 2 || counter < 0) return fail(c, PSGSDF_ERR_ARG, "integrate_frame: bad argument");      // (multi-rank: every rank fuses the frame into the planes it holds, halo planes included -- no exchange)
     HIPCHK(c, hipSetDevice(c->device));
     if (counter >= 64 * c->wpv_seq) {   // the sequence is longer than volume_init was told (the reference's vector<bool> simply grows): widen the per-voxel words
         const long long n = c->grid.nvox;
@@ -442,7 +516,9 @@ int psgsdf_download_volume(psgsdf_ctx* c, float* dist, float* grad_xyz, float* w
 int psgsdf_download_vis_seq(psgsdf_ctx* c, uint64_t* out) {
     if (!c || !c->vis_seq || !out) return PSGSDF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(out, c->vis_seq, sizeof(uint64_t) * c->grid.nvox * c->wpv_seq, hipMemcpyDeviceToHost));
+    // (the caller's array is the whole volume's; a slab writes the planes it owns, like psgsdf_download_volume)
+    const size_t plane = (size_t)c->gdim[0] * c->gdim[1] * c->wpv_seq;
+    HIPCHK(c, hipMemcpy(out + (size_t)c->z0 * plane, c->vis_seq + (size_t)(c->z0 - c->zlo) * plane, sizeof(uint64_t) * (size_t)(c->z1 - c->z0) * plane, hipMemcpyDeviceToHost));
     return c->wpv_seq;
 }
 

@@ -58,7 +58,7 @@ extern "C" int psgsdf_estimate_normals(psgsdf_ctx* c, const float* depth, int wi
 extern "C" int psgsdf_track(psgsdf_ctx* c, const float* depth, int width, int height, float pose[16], float z_min, float z_max,
                             int num_iterations, float conv_threshold, float damping, int* iters_out, int* converged) {
     if (!c || !c->have_volume || !depth || !pose) return fail(c, PSGSDF_ERR_STATE, "track: volume first");
-    if (c->n_ranks > 1) return fail(c, PSGSDF_ERR_UNSUPPORTED, "the tracker runs on one rank");
+    if (c->n_ranks > 1 && !c->comm) return fail(c, PSGSDF_ERR_COMM, "rank %d of %d has no communicator (psgsdf_comm_init)", c->rank, c->n_ranks);
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = (size_t)width * height;
     int rc = normals_cache(c, width, height); if (rc) return rc;   // (allocates the depth staging buffer)
@@ -71,11 +71,13 @@ extern "C" int psgsdf_track(psgsdf_ctx* c, const float* depth, int width, int he
     for (; k < num_iterations; ++k) {
         FrameP fp{};
         for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) fp.R[i * 3 + j] = pose[i * 4 + j]; fp.t[i] = pose[i * 4 + 3]; }
-        timed(c, "track", [&] { launch_track(c->dense, c->grid, cam, fp, c->ndepth, z_min, z_max, c->track_part, nblk, c->stream); });
+        // (z-slabs: every rank sums the pixels whose nearest voxel lies in a plane it OWNS; the 29 sums are all-reduced below, every rank solves the same 6x6)
+        timed(c, "track", [&] { launch_track(c->dense, c->grid, cam, fp, c->ndepth, z_min, z_max, c->track_part, nblk, c->gdim[2], c->z0, c->z1, c->stream); });
         HIPCHK(c, hipMemcpyAsync(c->track_host, c->track_part, sizeof(double) * nblk * 29, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         double acc[29] = {0};
         for (int b = 0; b < nblk; ++b) for (int q = 0; q < 29; ++q) acc[q] += c->track_host[(size_t)b * 29 + q];
+        if (c->n_ranks > 1) { std::vector<double> all(acc, acc + 29); int arc = host_allreduce(c, all, "tracker"); if (arc) return arc; for (int q = 0; q < 29; ++q) acc[q] = all[q]; }
         if (acc[28] == 0) break;
         // xi = damping * H.llt().solve(g): 6x6 LDL^T in double on the host
         double Hd[36], gd[6], L[36] = {0}, D[6], y[6], xd[6]; int q = 0;

@@ -28,8 +28,9 @@ int psgsdf_set_stream(psgsdf_ctx* c, void* hip_stream) {
     return PSGSDF_OK;
 }
 int psgsdf_mg_info(psgsdf_ctx* c, int32_t out[12]) {
-    if (!c || !c->inited) return PSGSDF_ERR_STATE;
-    out[0] = (int32_t)c->S_global; out[1] = c->band.S; out[2] = c->row0; out[3] = c->row1; out[4] = c->halo; out[5] = c->F; out[6] = c->rank; out[7] = c->n_ranks;
+    if (!c || !(c->inited || c->have_volume)) return PSGSDF_ERR_STATE;
+    if (!c->inited) { for (int i = 0; i < 6; ++i) out[i] = 0; out[5] = c->F; }      // (a volume without a band yet: the planes only)
+    else { out[0] = (int32_t)c->S_global; out[1] = c->band.S; out[2] = c->row0; out[3] = c->row1; out[4] = c->halo; out[5] = c->F; } out[6] = c->rank; out[7] = c->n_ranks;
     out[8] = c->need[0]; out[9] = c->need[1]; out[10] = c->z0; out[11] = c->z1;
     return PSGSDF_OK;
 }

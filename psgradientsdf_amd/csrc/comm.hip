@@ -131,7 +131,13 @@ int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
         if (c->give[1]) sends.push_back({pl + rowb * (c->row1 - c->give[1]), rowb * c->give[1], c->rank + 1});
         if (c->need[1]) recvs.push_back({pl + rowb * c->row1, rowb * c->need[1], c->rank + 1});
     }
+    return comm_xfer(c, sends, recvs);
+}
+// grouped point-to-point transfers of device memory, ordered on the context's stream (halo rows with the z-neighbours; whole planes between any two
+// ranks when the slabs are re-cut, api.hip psgsdf_rebalance_slabs); matched in list order per peer
+int comm_xfer(psgsdf_ctx* c, const std::vector<psgsdf_comm_xfer>& sends, const std::vector<psgsdf_comm_xfer>& recvs) {
     if (sends.empty() && recvs.empty()) return 0;
+    int rc = need_comm(c); if (rc) return rc;
     c->n_collectives++;
     if (c->comm->is_ext) {
         if (c->comm->ext.sendrecv(c->comm->ext.user, sends.data(), (int)sends.size(), recvs.data(), (int)recvs.size(), c->stream)) return fail(c, PSGSDF_ERR_COMM, "ext sendrecv failed");
@@ -144,7 +150,7 @@ int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
     for (auto& x : sends) { if (first != ncclSuccess) break; first = r->Send(x.ptr_dev, x.bytes, ncclChar, x.peer, c->comm->nccl, c->stream); }
     for (auto& x : recvs) { if (first != ncclSuccess) break; first = r->Recv(x.ptr_dev, x.bytes, ncclChar, x.peer, c->comm->nccl, c->stream); }
     const ncclResult_t end = r->GroupEnd();
-    if (first != ncclSuccess) return fail(c, PSGSDF_ERR_COMM, "halo exchange (ncclSend / ncclRecv): %s", r->GetErrorString ? r->GetErrorString(first) : "rccl error");
+    if (first != ncclSuccess) return fail(c, PSGSDF_ERR_COMM, "point-to-point exchange (ncclSend / ncclRecv): %s", r->GetErrorString ? r->GetErrorString(first) : "rccl error");
     NCCLCHK(c, end);
     return 0;
 }
@@ -217,7 +223,8 @@ __global__ void __launch_bounds__(256) k_xr_probe(double* myF, const float4* myP
     }
 }
 
-// all-reduce of a host vector of doubles through a scratch device buffer; every rank fills its own slice, zeros elsewhere
+}  // namespace
+// all-reduce (sum over the ranks) of a host vector of doubles through a scratch device buffer
 int host_allreduce(psgsdf_ctx* c, std::vector<double>& buf, const char* what) {
     double* d = nullptr;
     HIPCHK(c, hipMalloc(&d, sizeof(double) * buf.size()));
@@ -228,6 +235,7 @@ int host_allreduce(psgsdf_ctx* c, std::vector<double>& buf, const char* what) {
     hipFree(d);
     return rc;
 }
+namespace {
 void handle_to_doubles(const hipIpcMemHandle_t& h, double* out) { for (int i = 0; i < 64; ++i) out[i] = (double)((const unsigned char*)&h)[i]; }
 void* open_handle(const double* bytes) {
     hipIpcMemHandle_t h; for (int i = 0; i < 64; ++i) ((unsigned char*)&h)[i] = (unsigned char)bytes[i];

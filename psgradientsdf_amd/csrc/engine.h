@@ -231,7 +231,7 @@ void launch_apply_dist(const SweepArgs& a, hipStream_t s);
 void launch_upsample(const DenseView& src, const DenseView& dst, const GridP& g_old, hipStream_t s);
 void launch_fill_f32(float* p, float v, long long n, hipStream_t s);
 void launch_normals(const float* depth, const float* cache, int W, int H, int r, double* tmp, float* out, hipStream_t s);
-void launch_track(const DenseView& d, const GridP& g, const Cam& cam, const FrameP& fp, const float* depth, float z_min, float z_max, double* part, int nblk, hipStream_t s);
+void launch_track(const DenseView& d, const GridP& g, const Cam& cam, const FrameP& fp, const float* depth, float z_min, float z_max, double* part, int nblk, int gdimz, int zown0, int zown1, hipStream_t s);
 void launch_integrate(const DenseView& d, uint64_t* vis_seq, int wpv_seq, const GridP& g, const Cam& cam, const FrameP& fp,
                       const float* rgb, const float* depth, const float* normals, int counter, float z_min, float z_max, hipStream_t s);
 

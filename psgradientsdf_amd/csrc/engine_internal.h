@@ -201,6 +201,8 @@ int comm_create_ext(psgsdf_ctx* c, const psgsdf_comm_ops* ops, int rank, int n);
 void comm_destroy(psgsdf_ctx* c);
 int comm_allreduce(psgsdf_ctx* c, double* buf, int n);                 // in-place sum of n doubles (device), on the context's stream
 int comm_halo(psgsdf_ctx* c, void* base, int planes, int width);       // halo rows of `planes` band planes of `width` 4-byte words per row
+int comm_xfer(psgsdf_ctx* c, const std::vector<psgsdf_comm_xfer>& sends, const std::vector<psgsdf_comm_xfer>& recvs);   // grouped send / recv of device memory with any ranks
+int host_allreduce(psgsdf_ctx* c, std::vector<double>& buf, const char* what);   // comm.hip: sum over the ranks of a HOST vector (set-up exchanges, the tracker's 6x6 system); synchronous
 int xr_setup(psgsdf_ctx* c, const std::vector<double>& part_info);   // comm.hip: (re)build the cross-rank mappings for the band just built (part_info: {need_lo, need_hi, own rows} of every rank)
 void xr_release(psgsdf_ctx* c);
 int xr_quiesce(psgsdf_ctx* c);                                        // comm.hip: close this rank's mappings and wait until every rank has closed its own (before rec_mem / xr are freed)

@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(kBlock) k_integrate(DenseView d, uint64_t* __r
     const long long nxy = (long long)g.dim[0] * g.dim[1];
     for (long long lin = blockIdx.x * (long long)blockDim.x + threadIdx.x; lin < g.nvox; lin += (long long)gridDim.x * blockDim.x) {
         int k = (int)(lin / nxy); int rest = (int)(lin - (long long)k * nxy); int j = rest / g.dim[0]; int i = rest - j * g.dim[0];
-        float xv[3] = {g.origin[0] + g.vs * (float)i, g.origin[1] + g.vs * (float)j, g.origin[2] + g.vs * (float)k};
+        float xv[3] = {g.origin[0] + g.vs * (float)i, g.origin[1] + g.vs * (float)j, g.origin[2] + g.vs * (float)(k + g.koff)};      // (a z-slab's local plane k is plane k + koff of the volume)
         float tmp[3] = {xv[0] - fp.t[0], xv[1] - fp.t[1], xv[2] - fp.t[2]}, p[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) p[a] = (fp.R[0 * 3 + a] * tmp[0] + fp.R[1 * 3 + a] * tmp[1]) + fp.R[2 * 3 + a] * tmp[2];
@@ -101,7 +101,9 @@ void launch_normals(const float* depth, const float* cache, int W, int H, int r,
     hipLaunchKernelGGL(k_normals_v, dim3(grid), dim3(kBlock), 0, s, (const double*)tmp, cache, W, H, r, out);
 }
 // one Gauss-Newton pass of the tracker: H (21) | g (6) | E | count per workgroup -> partial rows part[blockIdx][29]
-__global__ void __launch_bounds__(kBlock) k_track(DenseView d, GridP g, Cam cam, FrameP fp, const float* __restrict__ depth, float z_min, float z_max, double* __restrict__ part) {
+// gdimz, zown0, zown1: z-slabs -- the volume's plane count and the planes THIS context owns; a pixel is counted by the rank that owns the plane of its
+// nearest voxel (the ranks' sums are all-reduced by the host), the bounds test is the whole volume's
+__global__ void __launch_bounds__(kBlock) k_track(DenseView d, GridP g, Cam cam, FrameP fp, const float* __restrict__ depth, float z_min, float z_max, double* __restrict__ part, int gdimz, int zown0, int zown1) {
 #pragma clang fp contract(off)
     __shared__ double lds[(kBlock / 64) * 29];
     const float fx_inv = 1.f / cam.fx, fy_inv = 1.f / cam.fy;
@@ -120,9 +122,10 @@ __global__ void __launch_bounds__(kBlock) k_track(DenseView d, GridP g, Cam cam,
         float fi[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) fi[a] = (pw[a] - g.origin[a]) / g.vs;
-        if (fi[0] <= 0 || fi[1] <= 0 || fi[2] <= 0 || fi[0] >= (g.dim[0] - 1) || fi[1] >= (g.dim[1] - 1) || fi[2] >= (g.dim[2] - 1)) continue;
+        if (fi[0] <= 0 || fi[1] <= 0 || fi[2] <= 0 || fi[0] >= (g.dim[0] - 1) || fi[1] >= (g.dim[1] - 1) || fi[2] >= (gdimz - 1)) continue;
         const int im = (int)(fi[0] + 0.5), jm = (int)(fi[1] + 0.5), km = (int)(fi[2] + 0.5);
-        const long long I = (long long)im + (long long)jm * g.dim[0] + (long long)km * g.dim[0] * g.dim[1];
+        if (km < zown0 || km >= zown1) continue;
+        const long long I = (long long)im + (long long)jm * g.dim[0] + (long long)(km - g.koff) * g.dim[0] * g.dim[1];
         if (!(d.weight[I] > 0)) continue;
         float gr[3] = {d.g[0][I], d.g[1][I], d.g[2][I]}, gn[3]; normalized3(gr, gn);
         int idx[3] = {(int)(fi[0] + 0.5f), (int)(fi[1] + 0.5f), (int)(fi[2] + 0.5f)};
@@ -146,8 +149,8 @@ __global__ void __launch_bounds__(kBlock) k_track(DenseView d, GridP g, Cam cam,
     __syncthreads();
     for (int k = threadIdx.x; k < 29; k += blockDim.x) { double s_ = 0; for (int i = 0; i < kBlock / 64; ++i) s_ += lds[i * 29 + k]; part[(size_t)blockIdx.x * 29 + k] = s_; }
 }
-void launch_track(const DenseView& d, const GridP& g, const Cam& cam, const FrameP& fp, const float* depth, float z_min, float z_max, double* part, int nblk, hipStream_t s) {
-    hipLaunchKernelGGL(k_track, dim3(nblk), dim3(kBlock), 0, s, d, g, cam, fp, depth, z_min, z_max, part);
+void launch_track(const DenseView& d, const GridP& g, const Cam& cam, const FrameP& fp, const float* depth, float z_min, float z_max, double* part, int nblk, int gdimz, int zown0, int zown1, hipStream_t s) {
+    hipLaunchKernelGGL(k_track, dim3(nblk), dim3(kBlock), 0, s, d, g, cam, fp, depth, z_min, z_max, part, gdimz, zown0, zown1);
 }
 __global__ void k_fill_f32(float* p, float v, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;

@@ -48,7 +48,19 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         tr = GlooTransport(dist)
         eng.comm_init_ext(tr.ops, rank, world)
-    if mode == "iterate_slab":    # slab-local upload: this rank only ever hands over its own planes (+ halo) of the volume
+    track = None
+    if mode.startswith("fuse"):   # slab-parallel front end: every rank fuses every frame into the planes it holds, tracks one frame against its slab
+        eng.volume_init(sc.F)
+        for f in range(sc.F):
+            eng.integrate_frame(sc.images[f], sc.depth[f], eng.estimate_normals(sc.depth[f]), sc.poses_gt[f], f, z_min=0.05, z_max=10.0)
+        P, iters, conv = eng.track(sc.depth[1], sc.poses_gt[0], z_min=0.05, z_max=10.0, num_iterations=3)
+        track = np.concatenate([P.reshape(-1), [iters, conv]])
+        cut_before = eng.mg_info() if world > 1 else None
+        if mode == "fuse_rebalance":
+            eng.rebalance_slabs()
+        fused = eng.download_volume(); fused_vis = eng.download_vis_seq(1)
+        eng.set_keyframes(np.arange(sc.F, dtype=np.int32), sc.images, sc.poses); eng.init()
+    elif mode == "iterate_slab":    # slab-local upload: this rank only ever hands over its own planes (+ halo) of the volume
         eng.load_scene_slab(sc, rank, world)
     else:
         eng.load_scene(sc)
@@ -63,6 +75,8 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
     np.savez(out + f".rank{rank}.npz", dist=v["dist"], rgb=v["rgb"], grad=v["grad"], poses=eng.download_poses(), light=eng.download_light(),
              e_total=[r["e_total"] for r in recs], cg=[r["cg_iters"] for r in recs], e0=e0, band=eng.download_band(info["row1"] - info["row0"]),
              info=[info["row0"], info["row1"], info["halo"], info["S"], info["need_lo"], info["need_hi"], info["z0"], info["z1"], info["rows"]],
+             track=track if track is not None else np.zeros(0), fused_weight=fused["weight"] if mode.startswith("fuse") else np.zeros(0), fused_dist=fused["dist"] if mode.startswith("fuse") else np.zeros(0),
+             fused_vis=fused_vis if mode.startswith("fuse") else np.zeros(0), cut_before=[cut_before["z0"], cut_before["z1"]] if mode.startswith("fuse") and world > 1 else [0, 0],
              ncoll=eng.comm_stats(), dim=list(eng.info().dim), n_band=eng.info().n_band, xr=[eng.debug_sync_stats()[k] for k in ("cross_rank_ready", "cross_rank_solves", "persist_fallbacks", "cross_rank_mem_kind", "probe_stale", "probe_timeouts")])
     eng.close()
     if tr is not None:
