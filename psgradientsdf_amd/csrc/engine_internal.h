@@ -140,6 +140,8 @@ struct psgsdf_ctx {
     bool fuse_pcg_init = true;           // PSGSDF_FUSE_PCG_INIT=0: separate k_cgf_init launch
     bool fuse_albedo = true;             // PSGSDF_FUSE_ALBEDO=0: separate k_apply_albedo launch
     bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
+    bool fm_solve = true;                // PSGSDF_FM_SOLVE=0: k_solve_light / k_solve_pose as kernels of their own behind the frame-major sweeps
+    bool fm_solved = false;              // the sweep just launched solves its frames itself (step_begin -> step_finish)
     bool albedo_applied = false;         // the last albedo sweep already applied its update (step_begin -> step_finish)
     unsigned* img8 = nullptr; float img_scale = 0.f;   // keyframes uploaded as 8-bit RGB (psgsdf_set_keyframes_u8): RGBA8 words, c->img stays null
     double* frame_e_slot = nullptr; unsigned long long frame_e_key = 0;   // mailbox slot (and its key) the next per-frame solve writes its sweep's energy sums to

@@ -284,16 +284,32 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
         }
         case PSGSDF_LIGHT: case PSGSDF_POSE: {
             int col, launched = 0;
+            // The per-frame solve in the sweep's own epilogue (sweeps.hip frame_rows_publish: the last workgroup of a frame solves it, the last frame
+            // sums the energy columns into the mailbox): no k_solve_light / k_solve_pose launch.  Only where step_finish is certain to follow (the
+            // deferred path: no stop decision hangs on this sweep's input energy), on one rank (a slab all-reduces the rows first), and not for the
+            // LED light, which is ONE vector over all frames.
+            const bool fuse = deferred_consumer && c->fm_solve && !slab_mode(c) && !c->profiling && (block == PSGSDF_POSE || !led) && c->row1 > c->row0 && c->band.obs_max > 0;
+            double* fm_slot = nullptr; unsigned long long fm_key = 0;
+            if (fuse) {      // (the mailbox slot first: reserving may flush, and a flush must not find the pending fold already handed to `a`)
+                if ((rc = reserve_frame_energy_deferred(c, deferred_consumer, &fm_slot, &fm_key))) return rc;
+                a.fm_solve = 1; a.fm_frames = c->frames; a.fm_e_out = fm_slot; a.fm_e_key = fm_key;
+                a.fm_undo = (block == PSGSDF_LIGHT && c->spec_undo) ? (float*)c->frames_undo : nullptr;
+            }
             if (block == PSGSDF_LIGHT) {
                 take_fold(c, a, 0u);
                 timed(c, "sweep_light", [&] { launched = launch_sweep_light(a, c->stream); });
                 const int n = led ? 3 : (c->set.model == PSGSDF_SH2 ? 9 : 4), nh = led ? 3 : n * (n + 1) / 2;
                 col = nh + n;
             } else { take_fold(c, a, 0u); timed(c, "sweep_pose", [&] { launched = launch_sweep_pose(a, c->stream); }); col = 27; }
+            if (fuse) {
+                if (launched) { c->fm_solved = true; return 0; }
+                c->frame_e_slot = fm_slot; c->frame_e_key = fm_key;      // (nothing was launched: the solve kernel of step_finish fills the slot)
+            }
             if (!launched) {      // no observations at all: empty rows, not the previous sweep's -- and the fold the sweep was to take is still owed
                 HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
                 fold_by_kernel(c, a.fold);
             }
+            if (fuse) return 0;
             // multi-rank: every slab has summed its own observations into the per-frame rows; after the all-reduce every rank holds the
             // global normal equations and solves all F (tiny) systems itself
             if ((rc = comm_allreduce(c, c->acc_frame, c->F * kFrameRow))) return rc;
@@ -334,13 +350,15 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
         }
         case PSGSDF_LIGHT:
             // (a speculative light update keeps the coefficients it overwrites: the solve kernel copies them to frames_undo first)
-            timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->frame_e_slot, c->frame_e_key, c->spec_undo ? (float*)c->frames_undo : nullptr, c->stream); });
+            if (c->fm_solved) c->fm_solved = false;      // (the sweep's last workgroups solved their frames: step_begin)
+            else timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->frame_e_slot, c->frame_e_key, c->spec_undo ? (float*)c->frames_undo : nullptr, c->stream); });
             if (c->spec_undo) c->spec_light_saved = true;
             c->frame_e_slot = nullptr; c->frame_e_key = 0;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = led ? 1 : c->F;
             break;
         case PSGSDF_POSE:
-            timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->frame_e_slot, c->frame_e_key, c->stream); });
+            if (c->fm_solved) c->fm_solved = false;
+            else timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->frame_e_slot, c->frame_e_key, c->stream); });
             c->frame_e_slot = nullptr; c->frame_e_key = 0;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = c->F;
             break;

@@ -202,11 +202,56 @@ static int fm_rows(const SweepArgs& a, int slots_per_cu) {
     return (int)std::min<long long>(std::max<long long>(r, 4), 64);
 }
 
+// small dense solves and SO3::exp (defined below)
+template <int N> __device__ void solve_spd(const double* Hin, const double* bin, double* x);
+__device__ void so3_exp(const float* w, float* R);
+
+// One frame's light step (optimizeLightAll, PsOptimizer.cpp:175-203: no damping; SH models: NB x NB per frame) from its final row `acc`, and one
+// frame's pose step (optimizePosesAll PsOptimizer.cpp:207-234 + updatePose OptimizerAux.cpp:190-205).  Shared by the one-workgroup solve kernels
+// below and by the sweeps' own epilogue (fm_solve: the last workgroup of a frame to arrive solves that frame at once -- no solve launch).
+template <int NB>
+__device__ __forceinline__ void frame_solve_light_sh(FrameP* frames, int f, const double* acc, float* undo) {
+    constexpr int NH = NB * (NB + 1) / 2;
+    if (undo) for (int i = 0; i < 9; ++i) undo[f * 9 + i] = frames[f].l[i];      // (a speculative update keeps what it overwrites: loop.hip run_loop)
+    double Hd[NB * NB], bd[NB], xd[NB];
+    int q = 0;
+    for (int i = 0; i < NB; ++i) for (int k = i; k < NB; ++k) { double v = (double)(float)acc[q++]; Hd[i * NB + k] = v; Hd[k * NB + i] = v; }
+    for (int i = 0; i < NB; ++i) bd[i] = (double)(float)acc[NH + i];
+    solve_spd<NB>(Hd, bd, xd);
+    for (int i = 0; i < NB; ++i) frames[f].l[i] -= (float)xd[i];
+}
+__device__ __forceinline__ void frame_solve_pose(const SweepArgs& a, FrameP* frames, int f, const double* acc) {
+    double Hd[36], bd[6], xd[6];
+    int q = 0;
+    for (int i = 0; i < 6; ++i) for (int k = i; k < 6; ++k) {
+        float v = (float)acc[q++];
+        if (i == k && a.damping != 0.0f) v += a.damping * v;
+        Hd[i * 6 + k] = (double)v; Hd[k * 6 + i] = (double)v;
+    }
+    for (int i = 0; i < 6; ++i) bd[i] = (double)(float)acc[21 + i];
+    solve_spd<6>(Hd, bd, xd);
+    float xi[6];
+    for (int i = 0; i < 6; ++i) xi[i] = (float)xd[i];
+    float R[9], t[3];
+    for (int i = 0; i < 9; ++i) R[i] = frames[f].R[i];
+    for (int i = 0; i < 3; ++i) t[i] = frames[f].t[i];
+    float mw[3] = {-xi[3], -xi[4], -xi[5]}, E3[9];
+    so3_exp(mw, E3);
+    for (int i = 0; i < 3; ++i) {
+        frames[f].t[i] = t[i] - xi[i];
+        for (int k = 0; k < 3; ++k) frames[f].R[i * 3 + k] = (R[i * 3 + 0] * E3[0 * 3 + k] + R[i * 3 + 1] * E3[1 * 3 + k]) + R[i * 3 + 2] * E3[2 * 3 + k];
+    }
+}
+
 // Epilogue of the frame-major sweeps: every workgroup stores ITS partial row of frame f (plain stores, no floating-point atomics) and
 // takes a ticket on the frame's arrival counter; the LAST workgroup of the frame to arrive sums the frame's partial rows in launch order
 // into the final row -- reproducible from run to run, and done while the other frames' workgroups are still sweeping.
-template <int NV>
-__device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int f, const double* lds /*[kBlock/64][NV] wavefront sums*/) {
+// fm_solve (single rank, the deferred path of the alternation loop): that last workgroup also SOLVES the frame -- KIND 0: the SH light block
+// (the LED light is one vector over all frames: k_solve_light keeps it), KIND 1: the pose block -- and takes a second ticket on the sweep's
+// frame counter; the last FRAME to finish sums the energy / n_obs columns of all rows in frame order into the mailbox (what the solve kernels'
+// frame_rows_finish does).  The frame's record is only read by the frame's own workgroups, all of which have finished; same arithmetic, same bits.
+template <int NV, int KIND, int MODEL>
+__device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int f, double* lds /*[kBlock/64][NV] wavefront sums*/) {
     // Hand-off without fences (an agent-scope release fence in every workgroup's tail writes back the XCD's L2 each time: light sweep
     // 46 -> 82 us): the row goes out with write-through (sc1) stores, the wave drains them, then takes the ticket; the last arriver reads
     // the rows with sc1 loads (MI355X_MICROARCH.md: "sc1 payload -> vmcnt(0) -> sc1 flag", "sc1 loads may replace the acquire").
@@ -224,6 +269,7 @@ __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int f, co
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x == 0) __hip_atomic_store(a.acc.fdone + f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool solve = a.fm_solve != 0;
     if (threadIdx.x < NV) {
         const double* p = a.acc.fpart + (size_t)f * a.acc.fcap * kFrameRow + threadIdx.x;
         double s = 0;
@@ -234,7 +280,35 @@ __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int f, co
 #pragma unroll
             for (int j = 0; j < 16; ++j) s += v[j];
         }
-        a.acc.frame[(size_t)f * kFrameRow + threadIdx.x] = s;
+        if (solve) { __hip_atomic_store(a.acc.frame + (size_t)f * kFrameRow + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); lds[threadIdx.x] = s; }      // (the last frame's workgroup reads the energy columns of every row)
+        else a.acc.frame[(size_t)f * kFrameRow + threadIdx.x] = s;
+    }
+    if (!solve) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (KIND == 0) { if (!ModelTraits<MODEL>::LED) frame_solve_light_sh<ModelTraits<MODEL>::NB == 3 ? 4 : ModelTraits<MODEL>::NB>(a.fm_frames, f, lds, a.fm_undo); }
+        else frame_solve_pose(a, a.fm_frames, f, lds);
+    }
+    if (threadIdx.x < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(a.acc.fdone + a.F, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.y - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(a.acc.fdone + a.F, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.fm_e_out) {      // energy / n_obs over the frames, in frame_rows_finish's order (one 256-thread workgroup, threads striding the frames)
+        constexpr int col_e = NV - 2;
+        double e = 0, n = 0;
+        for (int ff = threadIdx.x; ff < a.F; ff += blockDim.x) {
+            e += __hip_atomic_load(a.acc.frame + (size_t)ff * kFrameRow + col_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n += __hip_atomic_load(a.acc.frame + (size_t)ff * kFrameRow + col_e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        e = wave_sum(e); n = wave_sum(n);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) { lds[2 * w] = e; lds[2 * w + 1] = n; }
+        __syncthreads();
+        if (threadIdx.x == 0) { double te = 0, tn = 0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { te += lds[2 * i]; tn += lds[2 * i + 1]; } mbox_put(a.fm_e_out, 2, 0, te, a.fm_e_key); mbox_put(a.fm_e_out, 2, 1, tn, a.fm_e_key); mbox_commit(a.fm_e_key); }
     }
 }
 
@@ -312,7 +386,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
     const int w = threadIdx.x >> 6;
     wave_sums_to<NV>(acc, lds + w * NV);   // double: SH2 light blocks are ill-conditioned
     __syncthreads();
-    frame_rows_publish<NV>(a, f, lds);
+    frame_rows_publish<NV, 0, MODEL>(a, f, lds);
 }
 int launch_sweep_light(const SweepArgs& a, hipStream_t s) {
     if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return 0;
@@ -410,7 +484,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
     const int w = threadIdx.x >> 6;
     wave_sums_to<NV>(acc, lds + w * NV);   // row layout: [21 H | 6 rhs | energy | n_obs]
     __syncthreads();
-    frame_rows_publish<NV>(a, f, lds);
+    frame_rows_publish<NV, 1, MODEL>(a, f, lds);
 }
 int launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
     if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return 0;
@@ -504,15 +578,7 @@ __global__ void __launch_bounds__(kBlock) k_solve_light(SweepArgs a, FrameP* fra
             for (int ch = 0; ch < 3; ++ch) { const float nl = frames[f].l[ch] - dl[ch]; frames[f].l[ch] = nl; if (f == 0) led_light[ch] = nl; }
         }
     } else {
-        for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
-            const double* acc = a.acc.frame + (size_t)f * kFrameRow;
-            double Hd[NB * NB], bd[NB], xd[NB];
-            int q = 0;
-            for (int i = 0; i < NB; ++i) for (int k = i; k < NB; ++k) { double v = (double)(float)acc[q++]; Hd[i * NB + k] = v; Hd[k * NB + i] = v; }
-            for (int i = 0; i < NB; ++i) bd[i] = (double)(float)acc[NH + i];
-            solve_spd<NB>(Hd, bd, xd);
-            for (int i = 0; i < NB; ++i) frames[f].l[i] -= (float)xd[i];
-        }
+        for (int f = threadIdx.x; f < a.F; f += blockDim.x) frame_solve_light_sh<NB>(frames, f, a.acc.frame + (size_t)f * kFrameRow, nullptr);      // (undo: copied above)
     }
     frame_rows_finish(a, NH + NB, e_out, e_key, red);
 }
@@ -551,29 +617,7 @@ __device__ void so3_exp(const float* w, float* R) {
 // optimizePosesAll PsOptimizer.cpp:207-234 + updatePose OptimizerAux.cpp:190-205
 __global__ void __launch_bounds__(kBlock) k_solve_pose(SweepArgs a, FrameP* frames, double* e_out, unsigned long long e_key) {
     __shared__ double red[2 * kBlock / 64];
-    for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
-        const double* acc = a.acc.frame + (size_t)f * kFrameRow;
-        double Hd[36], bd[6], xd[6];
-        int q = 0;
-        for (int i = 0; i < 6; ++i) for (int k = i; k < 6; ++k) {
-            float v = (float)acc[q++];
-            if (i == k && a.damping != 0.0f) v += a.damping * v;
-            Hd[i * 6 + k] = (double)v; Hd[k * 6 + i] = (double)v;
-        }
-        for (int i = 0; i < 6; ++i) bd[i] = (double)(float)acc[21 + i];
-        solve_spd<6>(Hd, bd, xd);
-        float xi[6];
-        for (int i = 0; i < 6; ++i) xi[i] = (float)xd[i];
-        float R[9], t[3];
-        for (int i = 0; i < 9; ++i) R[i] = frames[f].R[i];
-        for (int i = 0; i < 3; ++i) t[i] = frames[f].t[i];
-        float mw[3] = {-xi[3], -xi[4], -xi[5]}, E3[9];
-        so3_exp(mw, E3);
-        for (int i = 0; i < 3; ++i) {
-            frames[f].t[i] = t[i] - xi[i];
-            for (int k = 0; k < 3; ++k) frames[f].R[i * 3 + k] = (R[i * 3 + 0] * E3[0 * 3 + k] + R[i * 3 + 1] * E3[1 * 3 + k]) + R[i * 3 + 2] * E3[2 * 3 + k];
-        }
-    }
+    for (int f = threadIdx.x; f < a.F; f += blockDim.x) frame_solve_pose(a, frames, f, a.acc.frame + (size_t)f * kFrameRow);
     frame_rows_finish(a, 27, e_out, e_key, red);
 }
 void launch_solve_pose(const SweepArgs& a, FrameP* frames, double* e_out, unsigned long long e_key, hipStream_t s) {

@@ -41,7 +41,8 @@ def run(model, env, full=False):
 def test_host_side_knobs_are_bitwise_neutral(built, model):
     ref = run(model, {}, full=True)
     for env in ({"PSGSDF_PCG_POLL": "0"}, {"PSGSDF_FOLD_IN_NEXT": "0"}, {"PSGSDF_PCG_POLL": "0", "PSGSDF_FOLD_IN_NEXT": "0"},
-                {"PSGSDF_FUSE_ALBEDO": "0"}, {"PSGSDF_SPECULATE": "0"}, {"PSGSDF_SPECULATE": "0", "PSGSDF_FUSE_ALBEDO": "0"}):
+                {"PSGSDF_FUSE_ALBEDO": "0"}, {"PSGSDF_SPECULATE": "0"}, {"PSGSDF_SPECULATE": "0", "PSGSDF_FUSE_ALBEDO": "0"},
+                {"PSGSDF_FM_SOLVE": "0"}, {"PSGSDF_FM_SOLVE": "0", "PSGSDF_SPECULATE": "0"}):      # FM_SOLVE=0: the per-frame light / pose solves as kernels of their own instead of in the sweeps' last workgroups
         got = run(model, env, full=True)
         assert got == ref, (env, got, ref)
 

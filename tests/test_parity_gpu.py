@@ -243,7 +243,7 @@ def test_8bit_keyframes(built, margins, name, mid):
     assert np.allclose([r["e_total"] for r in re_], [r["e_total"] for r in rf], rtol=1e-4 if name == "SH2" else 1e-6) and [r["cg_iters"] for r in re_] == [r["cg_iters"] for r in rf]
     band = eng.download_band(); vs = float(sc.voxel_size)
     ve, vf, vo = eng.download_volume(), engf.download_volume(), orc.download_volume()
-    noise = 2e-4 if name == "SH2" else 1e-6        # SH2: the ill-conditioned light step amplifies it (LIGHT_RTOL above)
+    noise = 2e-4 if name == "SH2" else 5e-6        # the two template instances contract different multiply-adds into FMAs (measured: dist 9e-8 voxel, albedo 2.6e-6); SH2: the ill-conditioned light step amplifies it (LIGHT_RTOL above)
     assert np.abs(ve["dist"][band] - vf["dist"][band]).max() <= 10 * noise * vs and np.abs(ve["rgb"][:, band] - vf["rgb"][:, band]).max() <= noise
     assert np.abs(eng.download_poses() - engf.download_poses()).max() <= noise
     for a, b in zip(re_, ro):
