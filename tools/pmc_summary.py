@@ -8,7 +8,7 @@ KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled; WRIT
 import csv, json, re, sys
 from collections import defaultdict
 
-NAMES = {"k_cgf_solve": "pcg_solve", "k_cgf_pass": "pcg_pass", "k_cgf_init": "pcg_init", "k_sweep_dist": "sweep_dist", "k_sweep_pose": "sweep_pose",
+NAMES = {"k_cgf_solve": "pcg_solve", "k_cgp_solve": "pcg_solve", "k_cgf_pass": "pcg_pass", "k_cgf_init": "pcg_init", "k_sweep_dist": "sweep_dist", "k_sweep_pose": "sweep_pose",
          "k_sweep_light": "sweep_light", "k_sweep_albedo": "sweep_albedo", "k_energy": "energy", "k_assemble": "assemble",
          "k_derive": "derive", "k_apply_albedo": "apply_albedo", "k_apply_dist": "apply_dist"}
 

@@ -31,7 +31,27 @@ def main(path, out=None):
     print(txt)
     if out:
         open(out, "w").write(txt + "\n")
+    return agg
+
+
+def per_iteration(agg, json_out, commit):
+    """us per Gauss-Newton iteration of every kernel of the product loop (bench.py `kernels_rocprof`): total time / launches of the solve kernel,
+    which runs exactly once per iteration"""
+    import json
+    solves = sum(a[0] for k, a in agg.items() if k.startswith(("k_cgp_solve", "k_cgf_solve")))
+    if not solves:
+        return
+    loop = ("k_cgp_solve", "k_cgf_solve", "k_sweep_", "k_derive", "k_solve_", "k_energy", "k_apply_", "k_sum_parts", "k_restore_", "k_frame_cols", "k_marker")
+    # a kernel of the loop runs once per iteration (the traced runs also hold the loops' openings and closings: a few extra sweeps, energy evaluations
+    # and undo kernels per psgsdf_optimize call, listed with their launch counts)
+    per = {k: {"avg_us": round(a[1] / a[0], 2), "launches": a[0]} for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]) if k.startswith(loop)}
+    once = sum(v["avg_us"] for k, v in per.items() if v["launches"] >= solves)
+    json.dump({"source": "rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline --no-extra` (tools/profile_round.sh)", "commit": commit, "iterations_traced": solves,
+               "kernels": per, "us_per_iteration": round(once, 1), "note": "us_per_iteration = sum of the average durations of the kernels that run once per iteration (launches >= iterations_traced)"}, open(json_out, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    import os
+    agg = main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    if len(sys.argv) > 3:
+        per_iteration(agg, sys.argv[3], os.environ.get("PSGSDF_COMMIT", "?"))
