@@ -200,11 +200,12 @@ __global__ void __launch_bounds__(kBlock) k_derive(SweepArgs a, int update_grad)
     __shared__ double red[kBlock / 64];
     if (a.gate && *a.gate == 0.0) return;       // launched speculatively behind a PCG chunk that did not finish the solve
     const Band& b = a.b;
-    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int bid = vm_bid(a);
+    int j = a.row0 + bid * blockDim.x + threadIdx.x;
     double en = 0, el = 0;
     if (j < a.row1) derive_row(a, j, update_grad, en, el);
-    block_part_store(en, PART(a, SC_EN), red);
-    block_part_store(el, PART(a, SC_EL), red);
+    block_part_store(en, PART(a, SC_EN), red, bid);
+    block_part_store(el, PART(a, SC_EL), red, bid);
 }
 void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s) {
     if (a.row1 > a.row0) hipLaunchKernelGGL(k_derive, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, update_grad);

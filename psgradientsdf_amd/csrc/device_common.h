@@ -176,7 +176,7 @@ __device__ __forceinline__ float wave_sumf(float v) {
 // workgroups hitting one address serialise at ~12 ns each, which made trivial kernels take 30 us).
 // All threads of the block must call; red is __shared__ double[kBlock/64].  The partials are summed by the
 // consumer (host, or the next PCG kernel) in a fixed order, so results are run-to-run deterministic.
-__device__ __forceinline__ void block_part_store(double v, double* part_slot, double* red) {
+__device__ __forceinline__ void block_part_store(double v, double* part_slot, double* red, int bid = -1) {
     v = wave_sum(v);
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
@@ -185,7 +185,7 @@ __device__ __forceinline__ void block_part_store(double v, double* part_slot, do
     if (threadIdx.x == 0) {
         double s = 0;
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
-        part_slot[blockIdx.x] = s;
+        part_slot[bid >= 0 ? bid : (int)blockIdx.x] = s;
     }
 }
 // sum of n partials, identical in every thread of every block (fixed order)
@@ -200,6 +200,36 @@ __device__ __forceinline__ double block_total(const double* part, int n, double*
     double s = 0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
     return s;
+}
+// Workgroups are dealt to the 8 XCDs round-robin in dispatch order (physical id mod 8).  xcd_remap turns the physical id into a LOGICAL one such that
+// XCD x works on the contiguous logical range [x G/8, (x+1) G/8): neighbouring band rows (and the image regions they project to) then meet in ONE L2
+// instead of in all eight.  A bijection on [0, G) for any G; the logical id replaces blockIdx everywhere (rows AND partial-sum slots), so results do
+// not depend on the mapping.
+__device__ __forceinline__ unsigned xcd_remap(unsigned pid, unsigned G) {
+    const unsigned x = pid & 7u, s = pid >> 3, q = G >> 3, rem = G & 7u;
+    return x * q + (x < rem ? x : rem) + s;
+}
+// frame-major grids (chunks, F): logical ids run chunk-major, so an XCD owns a range of CHUNKS (= of band rows: the observation lists ascend) of every frame
+__device__ __forceinline__ void fm_ids(const SweepArgs& a, int& cx, int& f) {
+    cx = blockIdx.x; f = blockIdx.y;
+    if (a.xcd_map & 1) {
+        const unsigned L = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+        cx = (int)(L / gridDim.y); f = (int)(L - (unsigned)cx * gridDim.y);
+    }
+}
+// voxel-major grids: the logical workgroup id (rows bid * blockDim.x ..., partial-sum slot bid)
+// striped variant: XCD x owns the stripes x, x + 8, ... of T consecutive logical ids (locality within a stripe, load spread over the whole range);
+// the ids behind the last complete round of 8 stripes keep their physical order
+__device__ __forceinline__ unsigned xcd_remap_striped(unsigned pid, unsigned G, unsigned T) {
+    const unsigned Gc = G / (8u * T) * (8u * T);
+    if (pid >= Gc) return pid;
+    const unsigned x = pid & 7u, s = pid >> 3;
+    return ((s / T) * 8u + x) * T + s % T;
+}
+__device__ __forceinline__ int vm_bid(const SweepArgs& a, int bit = 2) {
+    if (!(a.xcd_map & bit)) return (int)blockIdx.x;
+    const unsigned T = (unsigned)a.xcd_map >> 8;
+    return T ? (int)xcd_remap_striped(blockIdx.x, gridDim.x, T) : (int)xcd_remap(blockIdx.x, gridDim.x);
 }
 #define PART(a, slot) ((a).acc.part + (size_t)(slot) * (a).acc.PB)
 // Value i of an n-value read-back slot.  key != 0: the slot lives in the host-mapped mailbox and the value travels with its check word

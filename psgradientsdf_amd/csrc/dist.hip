@@ -28,7 +28,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      //
     __shared__ double red[kBlock / 64];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
-    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int bid = vm_bid(a, 4);
+    int j = a.row0 + bid * blockDim.x + threadIdx.x;
     double E = 0, nobs = 0;
     if (j < a.row1) {
         Vox v; load_vox(b, j, v);
@@ -172,8 +173,8 @@ __global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      //
 #pragma unroll
         for (int p = 0; p < 4; ++p) b.blk[(size_t)(10 + p) * b.Spad + j] = exists[p] ? g[p] : 0.f;
     }
-    block_part_store(E, PART(a, SC_ENERGY), red);
-    block_part_store(nobs, PART(a, SC_NOBS), red);
+    block_part_store(E, PART(a, SC_ENERGY), red, bid);
+    block_part_store(nobs, PART(a, SC_NOBS), red, bid);
     if (a.pcg_asm && a.pcg_gran) {   // the persistent solve right behind this sweep assembles the system itself: no tag of an earlier solve may survive
         if (blockIdx.x == 0 && threadIdx.x == 0) { a.pcg_fs[1] = 0.0; a.pcg_fs[2] = 0.0; a.pcg_fs[3] = 0.0; }
         const int gid = blockIdx.x * blockDim.x + threadIdx.x;

@@ -146,6 +146,7 @@ struct SweepArgs {
     int pcg_fuse_init;        // assembly kernel also initialises the PCG (x = 0, records of pass -1, |b|^2 partials): no k_cgf_init launch
     int pcg_init_blocks;      // workgroups that wrote the |b|^2 partials (0: the pass kernel's own grid)
     int fuse_apply;           // albedo sweep: solve the voxel's diagonal system and apply the update in the same thread (no normal equations stored); 2: and keep the old albedo for an undo
+    int xcd_map;              // workgroup -> work mapping that gives every XCD (physical workgroup id mod 8) one contiguous range of band rows / observation chunks: its L2 then holds an eighth of the band (device_common.h xcd_remap)
     int fm_solve;             // frame-major sweeps: the last workgroup of a frame solves the frame's light (SH) / pose block, the last frame sums the energy columns (sweeps.hip frame_rows_publish): no solve launch
     FrameP* fm_frames; float* fm_undo; double* fm_e_out; unsigned long long fm_e_key;
     const double* gate;       // speculative launch: the kernel does nothing unless *gate != 0 (nullptr = always run); see pcg_solve

@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
     __shared__ double red[kBlock / 64];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
-    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int bid = vm_bid(a);
+    int j = a.row0 + bid * blockDim.x + threadIdx.x;
     double E = 0, nobs = 0, sI[3] = {0, 0, 0}, sR[3] = {0, 0, 0};
     float Ef = 0.f;
     if (j < a.row1) {
@@ -70,11 +71,11 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
     E = (double)Ef;
     if (LED_INIT) {
         // 6 sums: observed rgb into SC_AUX0.., rendered into SC_EN/SC_EL/SC_ACCEPT slots (scratch use at init only)
-        block_part_store(sI[0], PART(a, SC_AUX0), red); block_part_store(sI[1], PART(a, SC_AUX1), red); block_part_store(sI[2], PART(a, SC_AUX2), red);
-        block_part_store(sR[0], PART(a, SC_EN), red); block_part_store(sR[1], PART(a, SC_EL), red); block_part_store(sR[2], PART(a, SC_ACCEPT), red);
+        block_part_store(sI[0], PART(a, SC_AUX0), red, bid); block_part_store(sI[1], PART(a, SC_AUX1), red, bid); block_part_store(sI[2], PART(a, SC_AUX2), red, bid);
+        block_part_store(sR[0], PART(a, SC_EN), red, bid); block_part_store(sR[1], PART(a, SC_EL), red, bid); block_part_store(sR[2], PART(a, SC_ACCEPT), red, bid);
     } else {
-        block_part_store(E, PART(a, SC_ENERGY), red);
-        block_part_store(nobs, PART(a, SC_NOBS), red);
+        block_part_store(E, PART(a, SC_ENERGY), red, bid);
+        block_part_store(nobs, PART(a, SC_NOBS), red, bid);
     }
 }
 void launch_energy(const SweepArgs& a, hipStream_t s) {
@@ -96,7 +97,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
     __shared__ double red[kBlock / 64];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
-    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int bid = vm_bid(a);
+    int j = a.row0 + bid * blockDim.x + threadIdx.x;
     double E = 0, nobs = 0, cnt = 0;
     if (j < a.row1) {
         Vox v; load_vox(b, j, v);
@@ -143,9 +145,9 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
             for (int ch = 0; ch < 3; ++ch) { b.aH[(size_t)ch * b.Spad + j] = Hd[ch]; b.ab[(size_t)ch * b.Spad + j] = bd[ch]; }
         }
     }
-    block_part_store(E, PART(a, SC_ENERGY), red);
-    block_part_store(nobs, PART(a, SC_NOBS), red);
-    if (a.fuse_apply) block_part_store(cnt, PART(a, SC_ACCEPT), red);
+    block_part_store(E, PART(a, SC_ENERGY), red, bid);
+    block_part_store(nobs, PART(a, SC_NOBS), red, bid);
+    if (a.fuse_apply) block_part_store(cnt, PART(a, SC_ACCEPT), red, bid);
 }
 void launch_sweep_albedo(const SweepArgs& a, hipStream_t s) {
     if (a.row1 <= a.row0) return;
@@ -251,12 +253,12 @@ __device__ __forceinline__ void frame_solve_pose(const SweepArgs& a, FrameP* fra
 // frame counter; the last FRAME to finish sums the energy / n_obs columns of all rows in frame order into the mailbox (what the solve kernels'
 // frame_rows_finish does).  The frame's record is only read by the frame's own workgroups, all of which have finished; same arithmetic, same bits.
 template <int NV, int KIND, int MODEL>
-__device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int f, double* lds /*[kBlock/64][NV] wavefront sums*/) {
+__device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, int f, double* lds /*[kBlock/64][NV] wavefront sums*/) {
     // Hand-off without fences (an agent-scope release fence in every workgroup's tail writes back the XCD's L2 each time: light sweep
     // 46 -> 82 us): the row goes out with write-through (sc1) stores, the wave drains them, then takes the ticket; the last arriver reads
     // the rows with sc1 loads (MI355X_MICROARCH.md: "sc1 payload -> vmcnt(0) -> sc1 flag", "sc1 loads may replace the acquire").
     __shared__ int s_last;
-    double* dst = a.acc.fpart + ((size_t)f * a.acc.fcap + blockIdx.x) * kFrameRow;
+    double* dst = a.acc.fpart + ((size_t)f * a.acc.fcap + cx) * kFrameRow;
     if (threadIdx.x < NV) {                      // (NV <= 64: all in wavefront 0, whose lane 0 takes the ticket below)
         double s = 0;
         for (int i = 0; i < kBlock / 64; ++i) s += lds[i * NV + threadIdx.x];
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
     constexpr int NV = NH + NB + 2;   // + energy, n_obs
     __shared__ FrameP sfp;
     __shared__ double lds[(kBlock / 64) * NV];
-    const int f = blockIdx.y;
+    int cx, f; fm_ids(a, cx, f);
     if (threadIdx.x < (int)(sizeof(FrameP) / 4)) ((float*)&sfp)[threadIdx.x] = ((const float*)(a.frames + f))[threadIdx.x];
     __syncthreads();
     const Band& b = a.b;
@@ -338,7 +340,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
     // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
     // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
     // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
-    int e = beg + blockIdx.x * (kBlock * rows) + threadIdx.x;
+    int e = beg + cx * (kBlock * rows) + threadIdx.x;
     int j_cur = e < end ? b.obs_rows[e] : -1;
     int j_nxt = (rows > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
     Vox vn;
@@ -386,7 +388,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
     const int w = threadIdx.x >> 6;
     wave_sums_to<NV>(acc, lds + w * NV);   // double: SH2 light blocks are ill-conditioned
     __syncthreads();
-    frame_rows_publish<NV, 0, MODEL>(a, f, lds);
+    frame_rows_publish<NV, 0, MODEL>(a, cx, f, lds);
 }
 int launch_sweep_light(const SweepArgs& a, hipStream_t s) {
     if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return 0;
@@ -406,7 +408,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
     constexpr int NV = 21 + 6 + 2;
     __shared__ FrameP sfp;
     __shared__ double lds[(kBlock / 64) * NV];
-    const int f = blockIdx.y;
+    int cx, f; fm_ids(a, cx, f);
     if (threadIdx.x < (int)(sizeof(FrameP) / 4)) ((float*)&sfp)[threadIdx.x] = ((const float*)(a.frames + f))[threadIdx.x];
     __syncthreads();
     const Band& b = a.b;
@@ -421,7 +423,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
     // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
     // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
     // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
-    int e = beg + blockIdx.x * (kBlock * rows) + threadIdx.x;
+    int e = beg + cx * (kBlock * rows) + threadIdx.x;
     int j_cur = e < end ? b.obs_rows[e] : -1;
     int j_nxt = (rows > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
     Vox vn;
@@ -484,7 +486,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
     const int w = threadIdx.x >> 6;
     wave_sums_to<NV>(acc, lds + w * NV);   // row layout: [21 H | 6 rhs | energy | n_obs]
     __syncthreads();
-    frame_rows_publish<NV, 1, MODEL>(a, f, lds);
+    frame_rows_publish<NV, 1, MODEL>(a, cx, f, lds);
 }
 int launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
     if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return 0;
