@@ -18,7 +18,7 @@ SH1, SH2, LED = 0, 1, 2
 L2, CAUCHY, HUBER, TUKEY, TRUNC_L2 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ENGINE_LIB = os.path.join(_HERE, "csrc", "libpsgsdf.so")
+ENGINE_LIB = os.environ.get("PSGSDF_ENGINE_LIB") or os.path.join(_HERE, "csrc", "libpsgsdf.so")      # (the override is for A/B runs of two BUILDS on one box: tools/)
 
 
 class GridDesc(C.Structure):
