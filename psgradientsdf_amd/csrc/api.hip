@@ -34,7 +34,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_FM_SOLVE")) c->fm_solve = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XCD_MAP")) c->xcd_map = atoi(e);
     if (const char* e = getenv("PSGSDF_XCD_STRIPE")) c->xcd_map = (c->xcd_map & 255) | (atoi(e) << 8);
-    if (const char* e = getenv("PSGSDF_PCG_ABLATE")) c->pcg_ablate = atoi(e) & 15;
+    if (const char* e = getenv("PSGSDF_PCG_ABLATE")) c->pcg_ablate = atoi(e) & 7;
     if (const char* e = getenv("PSGSDF_PCG_FUSE_APPLY")) c->pcg_fuse_apply = atoi(e) != 0;
     if (hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cu = 0;
     c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l; c->reg_r = settings->reg_weight_rho;
@@ -62,7 +62,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
         && hipMalloc(&c->pcg_gran, sizeof(double) * 2 * kSolveGranPlanes * kSolveMaxBlocksHost) == hipSuccess
         && hipMalloc(&c->mg_scal, sizeof(double) * kMgScal) == hipSuccess && hipMalloc(&c->mg_ext, sizeof(double) * 8) == hipSuccess
         && hipMalloc(&c->d_need, 2 * sizeof(int)) == hipSuccess
-        && hipMalloc(&c->d_total, 2 * sizeof(int)) == hipSuccess
+        && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess
         && hipMalloc(&c->led_light, sizeof(float) * 3) == hipSuccess
         && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     if (!ok) { delete c; return PSGSDF_ERR_DEVICE; }

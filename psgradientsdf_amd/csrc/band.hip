@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(kBlock) k_band_nb(DenseView d, GridP grid, Ban
         if (!(q & 1) && r >= 0) fwd |= 1 << (q >> 1);
     }
     b.dirb[j] = fwd;
-    int dl[kNQ], far = 0, far_xy = 0;
+    int dl[kNQ], far = 0;
     for (int q = 0; q < kNQ; ++q) {
         int o[3]; q_offset(q, o);
         long long ln = lin + o[0] * stride[0] + o[1] * stride[1] + o[2] * stride[2];
@@ -139,13 +139,12 @@ __global__ void __launch_bounds__(kBlock) k_band_nb(DenseView d, GridP grid, Ban
         b.col[(size_t)q * b.Spad + j] = r >= 0 ? r : j;   // absent column: coefficient is 0, point at self so gathers stay in range
         dl[q] = r >= 0 ? r - j : 0;
         far = max(far, abs(dl[q]));
-        if (o[2] == 0) far_xy = max(far_xy, abs(dl[q]));   // columns inside the row's own z-plane
     }
     for (int w = 0; w < (kNQ - 1) / 2; ++w)
         b.colp[(size_t)w * b.Spad + j] = ((unsigned)dl[2 * w + 1] & 0xffffu) | ((unsigned)dl[2 * w + 2] << 16);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { far = max(far, __shfl_down(far, o, 64)); far_xy = max(far_xy, __shfl_down(far_xy, o, 64)); }
-    if ((threadIdx.x & 63) == 0 && far > 0) { atomicMax(reach, far); atomicMax(reach + 1, far_xy); }
+    for (int o = 32; o > 0; o >>= 1) far = max(far, __shfl_down(far, o, 64));
+    if ((threadIdx.x & 63) == 0 && far > 0) atomicMax(reach, far);
 }
 void launch_band_fill(const DenseView& d, const GridP& grid, Band b, int* d_reach, hipStream_t s) {
     int g1 = (int)min((grid.nvox + kBlock - 1) / kBlock, (long long)256 * 16);

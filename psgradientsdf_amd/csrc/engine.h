@@ -57,7 +57,6 @@ struct Band {
     unsigned* colp;           // [9][Spad] the same as 16-bit deltas col - row, columns (2w+1, 2w+2) in word w: half the index bytes of a PCG pass
     int col16;                // 1 if every |col - row| fits 16 bits (then the PCG reads colp instead of col)
     int reach;                // max |col - row| over the band: how far (in rows) a row's ELL columns reach
-    int reach_xy;             // the same over the columns without a z offset (rows of the row's own z-plane)
     // derived per voxel, refreshed whenever dist / grad change (k_derive)
     float* gfd[3];            // finite-difference gradient (Optimizer.cpp:287-364), un-normalised
     float4* vp[3];            // derived state, packed because the frame-major sweeps GATHER it per observation and are bound by L1 line
@@ -184,7 +183,7 @@ void launch_band_flags(const float* dist, const uint64_t* vis_key, int KW, float
 // exclusive scan of flags -> row_of (-1 where flag==0); returns total through d_total (device int)
 void launch_band_scan(int* flags_inout_rowof, long long nvox, int* block_sums, int* d_total, hipStream_t s);
 struct DenseView { float* dist; float* g[3]; float* weight; float* rho[3]; uint64_t* vis; int KW; int* row_of; };
-void launch_band_fill(const DenseView& d, const GridP& grid, Band b, int* d_reach, hipStream_t s);   // d_reach[0] = max |col - row|, d_reach[1] = the same over the in-plane columns (atomicMax; zero both first)
+void launch_band_fill(const DenseView& d, const GridP& grid, Band b, int* d_reach, hipStream_t s);   // *d_reach = max |col - row| (atomicMax; zero it first)
 void launch_band_scatter(const DenseView& d, Band b, hipStream_t s);
 void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s);
 constexpr int kObsChunk = 2048;      // rows per workgroup of the observation-list builders

@@ -276,13 +276,13 @@ int build_band(psgsdf_ctx* c) {
     b.hx = (int*)take(1, 4);
     b.rhs = (float*)take(1, 4); b.x = (float*)take(1, 4); b.t = (float*)take(1, 4);
     if ((size_t)(p - (char*)c->band_mem) > bytes) return fail(c, PSGSDF_ERR_DEVICE, "band arena overrun: %zu > %zu bytes", (size_t)(p - (char*)c->band_mem), bytes);
-    HIPCHK(c, hipMemsetAsync(c->d_total, 0, 2 * sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_total, 0, sizeof(int), c->stream));
     timed(c, "band_fill", [&] { launch_band_fill(c->dense, c->grid, b, c->d_total, c->stream); });
     {   // 16-bit column deltas are usable if the widest reach of any ELL column fits (PSGSDF_PCG_COL16=0 forces the 32-bit table)
-        int reach[2] = {0, 0};
-        HIPCHK(c, hipMemcpyAsync(reach, c->d_total, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        int reach = 0;
+        HIPCHK(c, hipMemcpyAsync(&reach, c->d_total, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        b.col16 = reach[0] <= 32767; b.reach = reach[0]; b.reach_xy = reach[1];
+        b.col16 = reach <= 32767; b.reach = reach;
         if (const char* e = getenv("PSGSDF_PCG_COL16")) if (atoi(e) == 0) b.col16 = 0;
     }
     // row partition.  The band is sorted by linear index, z slowest, so the rows of the OWN planes [z0, z1) are one contiguous range

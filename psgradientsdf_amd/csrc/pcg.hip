@@ -811,13 +811,8 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
 // ------------------------------------------------------------------------------------------
 constexpr int kCgpSums = 3;
 constexpr int kCgpMaxRows = 4;                // row slots per thread the pipelined kernel supports
-constexpr int kCgpLdsRows = 3;                // up to this many row slots the workgroup's own m lives in LDS too (two buffers of rows * 512 + 2 * kCgpHalo doubles next to the matrix: 145 KB at 3)
-constexpr int kCgpHalo = 128;                 // ... with at most this many rows of the neighbouring workgroups on either side (Band::reach_xy)
 #ifndef PSG_CGP_DEPTH
 #define PSG_CGP_DEPTH 2
-#endif
-#ifndef PSG_CGP_GDEPTH
-#define PSG_CGP_GDEPTH 3
 #endif
 constexpr int kCgpDepth = PSG_CGP_DEPTH;      // gather batches (of 9 doubles) in flight per thread
 __device__ __forceinline__ void store8_sc1(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
@@ -859,17 +854,6 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
         if (MR) for (int r = 0; r < xr.n_ranks; ++r) __hip_atomic_store(xr.region[r] + kXrAbort, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
     float* hs = (float*)psg_dyn_smem;
-    // The workgroup's own m also lives in LDS (two buffers, by local row, with `hal` rows of the neighbouring workgroups on either side): a workgroup
-    // holds about one z-plane of the band, so the 8 columns WITHOUT a z offset (77 % of a row's off-diagonal mass) are rows of the same workgroup or
-    // within reach_xy of it -- and a gather instruction costs the texture addresser its cycles whatever it hits (dropping those 24 of the 54 gathers
-    // per thread: 8.0 -> 7.2 us per pass).  Per pass 2 * hal threads fetch the halo rows' m from memory once, everybody reads the in-plane columns
-    // from LDS and gathers only the 10 columns with a z offset.  Same values, same order of the row's sum: same bits.
-    constexpr bool kLdsM = R <= kCgpLdsRows;
-    constexpr unsigned kInPlane = (1u << 0) | (1u << 1) | (1u << 2) | (1u << 3) | (1u << 6) | (1u << 7) | (1u << 12) | (1u << 13);      // jj = q - 1 of the columns without a z offset (q_offset)
-    const int hal = b.reach_xy;
-    const bool use_lds = kLdsM && hal <= kCgpHalo && !((a.pcg_xcd_local >> 3) & 8);
-    constexpr int kMlStride = kCgpLdsRows * kSolveThreads + 2 * kCgpHalo;
-    double* const ml = (double*)(hs + (size_t)R * kNQ * kSolveThreads);      // [2][kMlStride]: halo below | own rows by local index | halo above
     unsigned cp[R][(kNQ - 1) / 2]; int row[R]; bool live[R];
     double x[R], r[R], w[R], z[R], sv[R], pv[R]; float inv[R];      // every vector of the recurrences in double: see "precision" above
     if (a.fold.n != 0 && blockIdx.x == 0) {      // the sums the distance sweep left pending (device_common.h fold_pending), in that function's order
@@ -904,16 +888,11 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
         inv[u] = dg != 0.f ? 1.0f / dg : 1.0f;
         r[u] = live[u] ? (double)(float)rhs : 0.0;      // (b is the float vector the reference solves for)
         x[u] = 0.0; z[u] = 0.0; sv[u] = 0.0; pv[u] = 0.0; w[u] = 0.0;
-        if (live[u]) { const double u0 = (double)inv[u] * r[u]; store8_sc1(recd[1] + row[u], u0); push_record(1, row[u] - a.row0, u0); if (use_lds) ml[kMlStride + hal + u * kSolveThreads + tid] = u0; }
+        if (live[u]) { const double u0 = (double)inv[u] * r[u]; store8_sc1(recd[1] + row[u], u0); push_record(1, row[u] - a.row0, u0); }
 #pragma unroll
         for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) cp[u][wd] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rC, row[u] * 4, wd * plane, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int u = 0; u < R; ++u) if (!live[u]) {      // (a dead lane gathers its clamped row's own element: always valid, in memory and in the LDS copy)
-#pragma unroll
-        for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) cp[u][wd] = 0u;
-    }
     __syncthreads();
     if (tid == 0) { __hip_atomic_store(gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + lb, (double)(1 + my_xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR) peer_tag(2, xr_tag(1.0, etag0 | 1u)); }
     float rhsNorm2 = 0.f, thr = 0.f, rr_cur = 0.f;
@@ -966,9 +945,19 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
         if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 1536 + lb] = (double)wall_clock64();      // ... neighbours' tags of pass 9 seen
         // ---- B: n = A m (k = -1: w_0 = A u_0): 18 four-byte gathers per row in two batches of 9, software-pipelined across the rows of the thread
         const double* __restrict__ rin = recd[k >= 0 ? (k & 1) : 1];
-        double* const lin = ml + (size_t)(k >= 0 ? (k & 1) : 1) * kMlStride + hal;      // (index = local row, -hal .. live rows + hal)
-        const int abl = (a.pcg_xcd_local >> 3) & 7;      // timing ablations (tools/pcg_variants.py; never set in production): 1 = every gather reads the row's own element, 2 = no neighbour-tag wait, 4 = in-plane columns not fetched at all; (8 = the LDS copy of m is not used)
+        const int abl = (a.pcg_xcd_local >> 3) & 7;      // timing ablations (tools/pcg_variants.py; never set in production): 1 = every gather reads the row's own element, 2 = no neighbour-tag wait, 4 = the 8 in-plane columns are not fetched
         double nres[R];
+        double ob[kCgpDepth][9];
+        auto issue = [&](int t) {
+            const int u = t >> 1, j0 = (t & 1) * 9;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int jj = j0 + j; const int pk = (int)cp[u][jj >> 1];
+                constexpr unsigned kInPlane = (1u << 0) | (1u << 1) | (1u << 2) | (1u << 3) | (1u << 6) | (1u << 7) | (1u << 12) | (1u << 13);      // columns without a z offset (q_offset: q = jj + 1)
+                if ((abl & 4) && ((kInPlane >> jj) & 1u)) { ob[t % kCgpDepth][j] = 0.0; continue; }      // ablation 4: the in-plane columns are not gathered at all
+                ob[t % kCgpDepth][j] = rin[row[u] + ((abl & 1) ? 0 : ((jj & 1) ? (pk >> 16) : ((pk << 16) >> 16)))];
+            }
+        };
         // The sums of pass k were published when m_k was: by the time the last gather batch is on its way they have normally arrived, but FETCHING
         // them is a memory round trip of its own (agent-scope loads past the XCD's L2: ~1.5 us if issued only after the gathers).  So they are
         // requested right behind the last batch and checked in stage C; only a late workgroup's granules are polled for again there.
@@ -980,58 +969,6 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
 #pragma unroll
                 for (int q = 0; q < kCgpSums; ++q) v[q] = __hip_atomic_load(gp + (size_t)q * kSolveMaxBlocks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        };
-        auto delta = [&](int u, int jj) { const int pk = (int)cp[u][jj >> 1]; return (abl & 1) ? 0 : ((jj & 1) ? (pk >> 16) : ((pk << 16) >> 16)); };
-        if (use_lds) {
-            // halo rows of m_k -> LDS (2 * hal threads, one row each), the z-column gathers of the first two row slots on their way meanwhile
-            const int wg_live = min(rows_per_wg, own_n - wg_first);
-            double hv = 0.0; int hslot = 0;
-            if (tid < 2 * hal) {
-                const int rel = tid < hal ? tid - hal : wg_live + (tid - hal);
-                hslot = rel;
-                hv = rin[min(max(a.row0 + wg_first + rel, 0), b.S - 1)];
-            }
-            double og[PSG_CGP_GDEPTH][10];
-            auto issue_g = [&](int u) {
-                int gi = 0;
-#pragma unroll
-                for (int jj = 0; jj < kNQ - 1; ++jj) if (!((kInPlane >> jj) & 1u)) og[u % PSG_CGP_GDEPTH][gi++] = rin[row[u] + delta(u, jj)];
-            };
-#pragma unroll
-            for (int u = 0; u < PSG_CGP_GDEPTH && u < R; ++u) issue_g(u);
-            if (R <= PSG_CGP_GDEPTH) { __builtin_amdgcn_sched_barrier(0); prefetch_sums(); }
-            __builtin_amdgcn_sched_barrier(0);
-            if (tid < 2 * hal) lin[hslot] = hv;
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < R; ++u) {
-                const float* hrow = hs + (size_t)u * kNQ * kSolveThreads + tid;
-                double ol[8];
-                int li = 0;
-#pragma unroll
-                for (int jj = 0; jj < kNQ - 1; ++jj) if ((kInPlane >> jj) & 1u) { ol[li] = (abl & 4) ? 0.0 : lin[u * kSolveThreads + tid + delta(u, jj)]; ++li; }
-                const double mine = (double)inv[u] * (k >= 0 ? w[u] : r[u]);      // (the row's own m: what it published)
-                double acc = (double)hrow[0] * mine;
-                int gi = 0; li = 0;
-#pragma unroll
-                for (int jj = 0; jj < kNQ - 1; ++jj) {
-                    const double val = ((kInPlane >> jj) & 1u) ? ol[li++] : og[u % PSG_CGP_GDEPTH][gi++];
-                    acc += (double)hrow[(jj + 1) * kSolveThreads] * val;
-                    if (jj == 8) asm volatile("" : "+v"(acc));
-                }
-                asm volatile("" : "+v"(acc));
-                nres[u] = acc;
-                __builtin_amdgcn_sched_barrier(0);
-                if (u + PSG_CGP_GDEPTH < R) issue_g(u + PSG_CGP_GDEPTH);
-                if (u == R - 1 - PSG_CGP_GDEPTH) prefetch_sums();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-        double ob[kCgpDepth][9];
-        auto issue = [&](int t) {
-            const int u = t >> 1, j0 = (t & 1) * 9;
-#pragma unroll
-            for (int j = 0; j < 9; ++j) { const int jj = j0 + j; ob[t % kCgpDepth][j] = ((abl & 4) && ((kInPlane >> jj) & 1u)) ? 0.0 : rin[row[u] + delta(u, jj)]; }
         };
 #pragma unroll
         for (int t = 0; t < kCgpDepth && t < 2 * R; ++t) issue(t);
@@ -1050,7 +987,6 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
             if (t + kCgpDepth < 2 * R) issue(t + kCgpDepth);
             if (t == 2 * R - 1 - kCgpDepth) prefetch_sums();
             __builtin_amdgcn_sched_barrier(0);
-        }
         }
         SOLVE_STAMP(2);
         if (force_passes > 0 && k == 9 && tid == 0) { fs[16 + 1024 + lb] = (double)wall_clock64(); fs[16 + 768 + lb] = (double)my_xcc; fs[16 + 1792 + lb] = (double)(gran_tag_of(v[0]) == want && gran_tag_of(v[1]) == want && gran_tag_of(v[2]) == want); }      // timing hook (PSGSDF_SOLVE_DUMP): gathers of pass 9 done; was the prefetch of this thread's granules valid?
@@ -1148,7 +1084,6 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                 // on another XCD need it in memory (write-through store).  A workgroup with neighbours on both sides does both.
                 if (!xcd_local) store8_sc1(dst, mnext);
                 *dst = mnext;
-                if (use_lds) ml[(size_t)((k + 1) & 1) * kMlStride + hal + u * kSolveThreads + tid] = mnext;
                 push_record((k + 1) & 1, row[u] - a.row0, mnext);
             }
         }
@@ -1211,7 +1146,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
     }
 }
 static size_t cgf_solve_lds(int rows) { return sizeof(float) * (size_t)rows * kNQ * kSolveThreads; }
-static size_t cgp_solve_lds(int rows) { return cgf_solve_lds(rows) + (rows <= kCgpLdsRows ? 2 * sizeof(double) * (size_t)(kCgpLdsRows * kSolveThreads + 2 * kCgpHalo) : 0); }
+static size_t cgp_solve_lds(int rows) { return cgf_solve_lds(rows); }
 template <int R, bool ASM, bool MR> static int cgf_solve_prepare() {      // > 64 KB of dynamic LDS has to be asked for, once per instance
     static int per_cu = -1;
     if (per_cu >= 0) return per_cu;
