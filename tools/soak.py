@@ -27,12 +27,18 @@ VARIANTS = {
     "default": {},
     "fold0": {"PSGSDF_FOLD_IN_NEXT": "0"},
     "poll0": {"PSGSDF_PCG_POLL": "0"},
-    "persist0": {"PSGSDF_PCG_PERSIST": "0"},
+    "persist0": {"PSGSDF_PCG_PERSIST": "0"},     # per-pass kernels: the CLASSIC recurrences (family "classic": bit-identical among themselves, rounding-level apart from the pipelined default)
+    "pipeline0": {"PSGSDF_PCG_PIPELINE": "0"},   # persistent kernel with the classic recurrences (same family as persist0)
+    "prefetch0": {"PSGSDF_PCG_PREFETCH": "0"},   # pipelined solve: sums requested after the last gather batch
+    "fmsolve0": {"PSGSDF_FM_SOLVE": "0"},        # light / pose solves as kernels of their own
+    "xcdmap0": {"PSGSDF_XCD_MAP": "0"},          # physical workgroup ids (no XCD-contiguous mapping)
+    "xcdmap7": {"PSGSDF_XCD_MAP": "7"},          # ... also for the distance sweep
     "xcdlocal0": {"PSGSDF_PCG_XCD_LOCAL": "0"},  # persistent solve: every record through memory instead of staying in the XCD's L2 where all its readers are
     "spec0": {"PSGSDF_SPECULATE": "0"},          # every iteration closed before the next one starts (round 2)
     "nocheck": {"PSGSDF_MBOX_CHECK": "0"},      # read-backs taken on the marker's say-so (round 2): expected to deviate now and then
 }
 KNOB_NAMES = sorted({k for v in VARIANTS.values() for k in v})
+FAMILY = {"persist0": "classic", "pipeline0": "classic"}      # which distance-solve recurrences a variant runs (default: pipelined)
 
 
 def _hash(a):
@@ -84,7 +90,7 @@ def analyse(runs):
     report = []
     groups = {}
     for r in runs:
-        groups.setdefault((r["model"], r["mode"]), []).append(r)
+        groups.setdefault((r["model"], r["mode"], FAMILY.get(r["variant"], "pipelined")), []).append(r)
     bad_total = 0
     for key, rs in sorted(groups.items()):
         # majority vector, checkpoint by checkpoint (the vectors can differ in length when the iteration count differs: compare by label)
@@ -113,7 +119,7 @@ def analyse(runs):
         late = Counter(); checked = Counter()
         for r in rs:
             late[r["variant"]] += (r.get("sync") or {}).get("readbacks_late", 0); checked[r["variant"]] += (r.get("sync") or {}).get("readbacks_checked", 0)
-        report.append(dict(model=key[0], mode=key[1], runs=len(rs), distinct_results=len(whole), deviating=len(bad), runs_per_variant=dict(by_variant), deviating_per_variant=dict(dev_by_variant),
+        report.append(dict(model=key[0], mode=key[1], family=key[2], runs=len(rs), distinct_results=len(whole), deviating=len(bad), runs_per_variant=dict(by_variant), deviating_per_variant=dict(dev_by_variant),
                            readbacks_checked=dict(checked), readbacks_late=dict(late), deviations=bad[:40]))
     return report, bad_total
 
