@@ -32,6 +32,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_PCG_PIPELINE")) c->pcg_pipeline = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_PREFETCH")) c->pcg_prefetch = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FM_SOLVE")) c->fm_solve = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_SPECULATE_MR")) c->speculate_mr = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XCD_MAP")) c->xcd_map = atoi(e);
     if (const char* e = getenv("PSGSDF_XCD_STRIPE")) c->xcd_map = (c->xcd_map & 255) | (atoi(e) << 8);
     if (const char* e = getenv("PSGSDF_PCG_ABLATE")) c->pcg_ablate = atoi(e) & 7;

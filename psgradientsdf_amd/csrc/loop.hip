@@ -482,11 +482,16 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
     // updates included, and the decision is taken when the energy arrives, at the latest before the distance block.  If the loop ends there
     // (once per optimisation) the saved albedo / light are put back: the state left behind is exactly the reference's.  A per-iteration
     // callback (on_iter) must see the state of the iteration it is told about, so with a callback every iteration is closed first, as before.
-    const bool spec_base = full && c->speculate && !slab_mode(c) && c->reg_r == 0.f && !c->profiling;
+    // Multi-rank (round 4): the same window, with two rules that keep the ranks' collectives in step -- the closing energy is a sum over the slabs,
+    // so the staged read-backs are committed (mg_commit: ONE all-reduce on the stream) right behind the first speculative sweep instead of at the next
+    // host wait, and the window is only ever closed at the same program point on every rank (the blocking poll in front of the first block that
+    // cannot be undone): no "has it landed yet?" polls, whose answer could differ from rank to rank and with it the order of the collectives.
+    const bool mr_spec = slab_mode(c);
+    const bool spec_base = full && c->speculate && (!mr_spec || c->speculate_mr) && c->reg_r == 0.f && !c->profiling;
     auto can_spec_at = [&](int it_closing) { return spec_base && (!on_iter || (it_closing + 1) % c->on_iter_period != 0); };      // (a due on_iter must see the state of the iteration it reports)
     c->spec_undo = false; c->spec_albedo_saved = false; c->spec_light_saved = false;
     const double* close_src = nullptr;   // mailbox address of the closing energy's read-back while a speculation window is open
-    bool spec_open = false;
+    bool spec_open = false, mr_committed = false;
     auto end_window = [&] { spec_open = false; close_src = nullptr; c->spec_undo = false; c->spec_albedo_saved = false; c->spec_light_saved = false; };
     auto undo_window = [&]() -> int {   // the loop ends on iteration iter-1: take back what iteration `iter` has applied speculatively
         if (c->spec_light_saved) launch_restore_light(c->F, c->frames, c->led_light, (const float*)c->frames_undo, c->stream);
@@ -507,6 +512,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
     // bring the closing energy of an open window in: non-blocking (only if it has landed) or blocking
     auto window_poll = [&](bool block) -> int {
         if (!spec_open || !have_prev || !prev_close) return 0;
+        if (mr_spec) { if (!block) return 0; materialize_fold(c); int rc = mg_commit(c); if (rc) return rc; }
         if (std::isnan(*prev_close)) {
             size_t idx = c->deferred.size();
             for (size_t e = 0; e < c->deferred.size(); ++e) if (c->deferred[e].src == close_src) { idx = e; break; }
@@ -546,7 +552,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
             } else {
                 // no stop decision pending (psgsdf_iterate never exits early) or a speculation window: even the closing energy of the previous
                 // iteration is delivered lazily, at the next host sync (the PCG status read of this iteration) or when the window polls for it
-                if (have_prev && full && !spec_open) { spec_open = true; c->spec_undo = true; c->spec_albedo_saved = c->spec_light_saved = false; c->spec_windows++; }
+                if (have_prev && full && !spec_open) { spec_open = true; mr_committed = false; c->spec_undo = true; c->spec_albedo_saved = c->spec_light_saved = false; c->spec_windows++; }
                 double* slot_e = &lt.e_in[qi];
                 int rc = step_begin(c, blk, L.laplacian_reg, &st, [slot_e](double e_sum, double) { *slot_e = e_sum; }); if (rc) return rc;
                 if (have_prev && prev_close == nullptr) { prev_close = slot_e; if (spec_open && !c->deferred.empty()) close_src = c->deferred.back().src; }
@@ -554,6 +560,7 @@ int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, p
             int rc = step_finish(c, blk, L.laplacian_reg, &st, true); if (rc) return rc;
             if (blk == PSGSDF_ALBEDO && c->reg_r != 0.f) { double er; if ((rc = albedo_reg_energy(c, &er))) return rc; lt.alb_reg = true; lt.e_r = (float)er; }   // PsOptimizer.cpp:312 (enters L when the record closes)
             if (blk == PSGSDF_DIST) { lt.dist_ran = true; lt.cg_iters = st.cg_iters; }
+            if (spec_open && mr_spec && !mr_committed && prev_close && std::isnan(*prev_close)) { mr_committed = true; materialize_fold(c); if ((rc = mg_commit(c))) return rc; }   // the closing energy starts travelling now (once per window)
             if (spec_open) { if ((rc = window_poll(false))) return rc; }
             else if (have_prev && prev_close && !std::isnan(*prev_close)) { if ((rc = lazy_close())) return rc; }   // the lazy closing energy has arrived
             pending = blk == PSGSDF_ALBEDO ? 0 : blk == PSGSDF_LIGHT ? 1 : blk == PSGSDF_DIST ? 2 : 3;

@@ -19,8 +19,13 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
     model, _, opt = model.partition("+")
     if os.environ.get("SLAB_CU_MASKS"):      # two ranks on ONE GPU with disjoint halves of its CUs (the cross-rank persistent solve needs both kernels resident)
         os.environ["PSGSDF_CU_MASK"] = os.environ["SLAB_CU_MASKS"].split(",")[rank]
-    sc = synth.make_scene(N=N, F=6, W=160, H=120, model=model)
-    st = capi.default_settings(sc.model_id, **({"reg_weight_rho": 0.02} if opt == "reg" else {}))      # "+reg": the albedo regulariser ("reg albedo")
+    sc = synth.make_scene(N=N, F=5 if mode == "optimize" else 6, W=160, H=120, model=model)
+    kw = {"reg_weight_rho": 0.02} if opt == "reg" else {}      # "+reg": the albedo regulariser ("reg albedo")
+    if mode == "optimize":
+        kw.update(upsample=1, max_it=n_iters, conv_threshold=0.0, damping=10.0)      # through the 2x refinement after iteration 5 (tests/test_parity_gpu.py test_optimize_matches_oracle's recipe)
+        if model == "LED":
+            kw.update(reg_weight_n=0.1, reg_weight_l=5.0)
+    st = capi.default_settings(sc.model_id, **kw)
     eng = capi.load_engine(sc, sc.K, st, 0)
     tr = None
     if transport == "rccl":
@@ -66,7 +71,11 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
         eng.load_scene(sc)
     eng.init_albedo()
     e0 = eng.normalize_weights()
-    recs = eng.iterate(capi.ALL, n_iters)
+    conv = -1
+    if mode == "optimize":        # the product loop with its stop decisions (and, on multi-rank contexts too, the speculative start of the next iteration)
+        recs, conv = eng.optimize(capi.ALL)
+    else:
+        recs = eng.iterate(capi.ALL, n_iters)
     if mode == "refine":          # the 2x refinement of PsOptimizer.cpp:386-409 between iterations: gather, refine, new partition
         eng.upsample2x()
         recs += eng.iterate(capi.ALL, 1)
@@ -77,6 +86,7 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
              info=[info["row0"], info["row1"], info["halo"], info["S"], info["need_lo"], info["need_hi"], info["z0"], info["z1"], info["rows"]],
              track=track if track is not None else np.zeros(0), fused_weight=fused["weight"] if mode.startswith("fuse") else np.zeros(0), fused_dist=fused["dist"] if mode.startswith("fuse") else np.zeros(0),
              fused_vis=fused_vis if mode.startswith("fuse") else np.zeros(0), cut_before=[cut_before["z0"], cut_before["z1"]] if mode.startswith("fuse") and world > 1 else [0, 0],
+             conv=conv, spec=[eng.debug_sync_stats()[k] for k in ("speculative_starts", "speculative_undos")], upsampled=[int(r["upsampled"]) for r in recs],
              ncoll=eng.comm_stats(), dim=list(eng.info().dim), n_band=eng.info().n_band, xr=[eng.debug_sync_stats()[k] for k in ("cross_rank_ready", "cross_rank_solves", "persist_fallbacks", "cross_rank_mem_kind", "probe_stale", "probe_timeouts")])
     eng.close()
     if tr is not None:

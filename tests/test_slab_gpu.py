@@ -132,6 +132,34 @@ def test_native_slab_refinement(built, tmp_path):
     assert res[0]["info"][7] == res[1]["info"][6] == 2 * (res[0]["info"][7] // 2)     # the cut doubled with the grid
 
 
+@pytest.mark.parametrize("model,world", [("SH1", 2), ("LED", 3)])
+def test_slab_optimize_with_speculative_start(built, tmp_path, model, world):
+    """psgsdf_optimize on slabs: the stop decision of every iteration is taken while the next iteration's albedo / light sweeps already run (the
+    closing energy is all-reduced right behind the first of them; the window closes at the same program point on every rank) -- bit for bit what the
+    loop that decides first produces (PSGSDF_SPECULATE_MR=0), and the single context's result to the slab tolerances, through the 2x refinement."""
+    N, cap = 24, 18
+    res = run_ranks(tmp_path, model, world, "gloo", "optimize", N, cap)
+    (tmp_path / "decide_first").mkdir()
+    res0 = run_ranks(tmp_path / "decide_first", model, world, "gloo", "optimize", N, cap, {"PSGSDF_SPECULATE_MR": "0"})
+    for a, b in zip(res, res0):
+        assert int(a["spec"][0]) >= 3 and int(b["spec"][0]) == 0                 # windows were opened / none
+        for key in ("dist", "rgb", "poses", "light", "e_total", "cg", "upsampled"):
+            assert np.array_equal(a[key], b[key], equal_nan=True), key
+    sc = synth.make_scene(N=N, F=5, W=160, H=120, model=model)
+    st = capi.default_settings(sc.model_id, upsample=1, max_it=cap, conv_threshold=0.0, damping=10.0, **({"reg_weight_n": 0.1, "reg_weight_l": 5.0} if model == "LED" else {}))
+    ref = capi.load_engine(sc, sc.K, st, 0); ref.load_scene(sc)
+    ref.init_albedo(); ref.normalize_weights()
+    recs, conv = ref.optimize(capi.ALL)
+    band = ref.download_band(); v = ref.download_volume(); vs = float(ref.info().voxel_size)
+    for got in res:
+        assert len(got["e_total"]) == len(recs) and int(got["conv"]) == int(conv)
+        assert list(got["upsampled"]) == [int(r["upsampled"]) for r in recs] and sum(got["upsampled"]) == 1      # the refinement after iteration 5 happened on the slabs too
+        assert np.allclose(got["e_total"], [x["e_total"] for x in recs], rtol=2e-5)
+    assert np.array_equal(np.concatenate([g["band"] for g in res]), band)
+    d = stitch(res, "dist")
+    assert np.abs(d[band] - v["dist"][band]).max() <= 1e-4 * vs
+
+
 @pytest.mark.parametrize("world,mode", [(2, "fuse"), (3, "fuse_rebalance")])
 def test_slab_parallel_front_end(built, tmp_path, world, mode):
     """SURVEY 8f row 1 "trivially z-slab parallel" (VERDICT r03 item 7): psgsdf_volume_init / psgsdf_integrate_frame / psgsdf_track on contexts attached
