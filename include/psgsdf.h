@@ -339,6 +339,7 @@ int psgsdf_debug_albedo_system(psgsdf_ctx* ctx, float* H, float* b);
  *   out[0] scalar read-backs validated against their check words      out[1] of those: not complete yet when the marker / status word
  *   the host waited for had already arrived (waited for; PSGSDF_MBOX_CHECK=0 takes them as they are: the round-2 behaviour)
  *   out[2] distance steps re-run on the per-pass kernels because the persistent solve could not get its workgroups co-resident
+ *          (+ 1e6 if the float keyframes of psgsdf_set_keyframes turned out to be 8-bit data and are held as RGBA8 words)
  *   out[3] 1e6 x iterations started speculatively (before the stop decision on the previous one) + those of them that were undone
  *   out[4] 1 if this (multi-rank) context holds the cross-rank mappings of the persistent solve, out[5] distance solves run through it,
  *   out[6] memory kind the hand-off probe chose for the record planes another device writes (-1 not probed: single rank; 0 none passed: cross-rank

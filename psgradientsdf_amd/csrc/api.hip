@@ -32,6 +32,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_PCG_PIPELINE")) c->pcg_pipeline = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_PREFETCH")) c->pcg_prefetch = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FM_SOLVE")) c->fm_solve = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_IMG_COMPACT")) c->img_compact = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_SPECULATE_MR")) c->speculate_mr = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XCD_MAP")) c->xcd_map = atoi(e);
     if (const char* e = getenv("PSGSDF_XCD_STRIPE")) c->xcd_map = (c->xcd_map & 255) | (atoi(e) << 8);
@@ -335,6 +336,20 @@ static int set_keyframes_impl(psgsdf_ctx* c, int n_frames, const int32_t* frame_
     if (rgb_f32) {
         HIPCHK(c, hipMalloc(&c->img, sizeof(float) * npix * 3));
         HIPCHK(c, hipMemcpyAsync(c->img, rgb_f32, sizeof(float) * npix * 3, hipMemcpyHostToDevice, c->stream));
+        // Keyframes that came out of 8-bit files (the reference's loader: imread + convertTo(CV_32FC3, 1.0f / 255.0f)) are kept as RGBA8 words: the
+        // samplers give back the SAME floats (device_common.h unpack_rgb8), with two tap loads per observation instead of four and a third of the bytes.
+        c->img_compacted = false;
+        if (c->img_compact && npix < ((size_t)1 << 30) && (size_t)n_frames * height < ((size_t)1 << 24)) {
+            const float scale = 1.0f / 255.0f;
+            HIPCHK(c, hipMalloc(&c->img8, sizeof(unsigned) * npix));
+            HIPCHK(c, hipMemsetAsync(c->d_total, 0, sizeof(int), c->stream));
+            launch_try_pack_f32(c->img, c->img8, npix, scale, c->d_total, c->stream);
+            int bad = 1;
+            HIPCHK(c, hipMemcpyAsync(&bad, c->d_total, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (bad) { hipFree(c->img8); c->img8 = nullptr; }
+            else { hipFree(c->img); c->img = nullptr; c->img_scale = scale; c->img_compacted = true; }
+        }
     } else {
         uint8_t* tmp = nullptr;
         HIPCHK(c, hipMalloc(&c->img8, sizeof(unsigned) * npix));

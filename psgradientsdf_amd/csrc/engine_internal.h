@@ -140,6 +140,8 @@ struct psgsdf_ctx {
     bool fuse_pcg_init = true;           // PSGSDF_FUSE_PCG_INIT=0: separate k_cgf_init launch
     bool fuse_albedo = true;             // PSGSDF_FUSE_ALBEDO=0: separate k_apply_albedo launch
     bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
+    bool img_compact = true;             // PSGSDF_IMG_COMPACT=0: float keyframes stay float even when every value is (float)byte / 255
+    bool img_compacted = false;          // the float keyframes of this context are held as RGBA8 words
     bool speculate_mr = true;            // PSGSDF_SPECULATE_MR=0: no speculative start of the next iteration on multi-rank contexts (round 3's loop)
     int xcd_map = 3;                     // PSGSDF_XCD_MAP: XCD-contiguous logical workgroup ids in bit 0 the frame-major sweeps, bit 1 k_sweep_albedo / k_energy / k_derive, bit 2 k_sweep_dist (off: 68 -> 76 us, its VALU-bound workgroups want the round-robin's load mix); PSGSDF_XCD_STRIPE=T: stripes of T ids instead of eighths
     bool fm_solve = true;                // PSGSDF_FM_SOLVE=0: k_solve_light / k_solve_pose as kernels of their own behind the frame-major sweeps

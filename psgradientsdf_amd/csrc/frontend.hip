@@ -165,6 +165,28 @@ __global__ void __launch_bounds__(kBlock) k_pack_rgb8(const uint8_t* __restrict_
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x)
         rgba[i] = (unsigned)rgb[3 * i] | ((unsigned)rgb[3 * i + 1] << 8) | ((unsigned)rgb[3 * i + 2] << 16);
 }
+// float keyframes that ARE 8-bit data -- every channel equal to RN((float)b * scale) for a byte b, which is what the reference's loader produces from a
+// PNG (ImageLoader.h:181 convertTo(CV_32FC3, 1.0f / 255.0f)) -- can be kept as RGBA8 words: the sampler's (float)b * scale gives back the same floats.
+// *fail becomes non-zero if any channel is not such a value (the words are then not used).
+__global__ void __launch_bounds__(kBlock) k_try_pack_f32(const float* __restrict__ rgb, unsigned* __restrict__ rgba, size_t npix, float scale, float inv_scale, int* __restrict__ fail) {
+    bool bad = false;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned w = 0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float v = rgb[3 * i + ch];
+            const float bf = rintf(v * inv_scale);
+            const bool ok = bf >= 0.f && bf <= 255.f && __fmul_rn(bf, scale) == v;
+            bad = bad || !ok;
+            w |= (ok ? (unsigned)bf : 0u) << (8 * ch);
+        }
+        rgba[i] = w;
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(fail, 1);
+}
+void launch_try_pack_f32(const float* rgb, unsigned* rgba, size_t npix, float scale, int* fail, hipStream_t s) {
+    if (npix) hipLaunchKernelGGL(k_try_pack_f32, dim3((unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, 65535)), dim3(kBlock), 0, s, rgb, rgba, npix, scale, 1.0f / scale, fail);
+}
 void launch_pack_rgb8(const uint8_t* rgb, unsigned* rgba, size_t npix, hipStream_t s) {
     if (npix) hipLaunchKernelGGL(k_pack_rgb8, dim3((unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, 65535)), dim3(kBlock), 0, s, rgb, rgba, npix);
 }

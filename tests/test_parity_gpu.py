@@ -41,6 +41,7 @@ def relmax(a, b):
 @pytest.mark.parametrize("name,mid", MODELS)
 def test_band_and_init(built, name, mid):
     sc, eng, orc = make_pair(name, mid)
+    assert eng.debug_sync_stats()["keyframes_compacted"] == 0      # (rendered floats, not 8-bit data: kept as they are)
     assert np.array_equal(eng.download_band(), orc.download_band())
     assert np.allclose(eng.download_light(), orc.download_light(), rtol=1e-6, atol=1e-7)
     eng.init_albedo(); orc.init_albedo()
@@ -229,10 +230,21 @@ def test_8bit_keyframes(built, margins, name, mid):
     assert sc.images_u8.dtype == np.uint8 and np.array_equal(sc.images, sc.images_u8.astype(np.float32) * sc.image_scale)
     st = capi.default_settings(mid)
     eng = capi.load_engine(sc, sc.K, st, 0); eng.load_scene(sc, u8=True)
-    engf = capi.load_engine(sc, sc.K, st, 0); engf.load_scene(sc, u8=False)
+    import os
+    os.environ["PSGSDF_IMG_COMPACT"] = "0"          # (read by psgsdf_create) the float keyframes stay float: the engine's float-image instance
+    try:
+        engf = capi.load_engine(sc, sc.K, st, 0)
+    finally:
+        del os.environ["PSGSDF_IMG_COMPACT"]
+    engf.load_scene(sc, u8=False)
+    # default: float keyframes that ARE 8-bit data (what the reference's loader hands its optimiser: ImageLoader.h:181) are recognised and held as RGBA8
+    # words -- the very same run as the 8-bit entry point, bit for bit
+    engc = capi.load_engine(sc, sc.K, st, 0); engc.load_scene(sc, u8=False)
+    assert engc.debug_sync_stats()["keyframes_compacted"] == 1 and engf.debug_sync_stats()["keyframes_compacted"] == 0 and eng.debug_sync_stats()["keyframes_compacted"] == 0
     orc = oracle.Oracle(sc, sc.K, st, threads=4); orc.load_scene(sc, u8=True)
-    for api in (eng, engf, orc):
+    for api in (eng, engf, engc, orc):
         api.init_albedo(); api.normalize_weights()
+    rc_ = engc.iterate(capi.ALL, 2)
     He, be = eng.debug_albedo_system(); Ho, bo = orc.debug_albedo_system()
     assert relmax(He, Ho) < 2e-5 and relmax(be, bo) < 2e-5
     for blk in (capi.LIGHT, capi.POSE):
@@ -243,6 +255,8 @@ def test_8bit_keyframes(built, margins, name, mid):
     assert np.allclose([r["e_total"] for r in re_], [r["e_total"] for r in rf], rtol=1e-4 if name == "SH2" else 1e-6) and [r["cg_iters"] for r in re_] == [r["cg_iters"] for r in rf]
     band = eng.download_band(); vs = float(sc.voxel_size)
     ve, vf, vo = eng.download_volume(), engf.download_volume(), orc.download_volume()
+    vc = engc.download_volume()
+    assert [r["e_total"] for r in rc_] == [r["e_total"] for r in re_] and np.array_equal(vc["dist"], ve["dist"]) and np.array_equal(vc["rgb"], ve["rgb"]) and np.array_equal(engc.download_poses(), eng.download_poses())
     noise = 2e-4 if name == "SH2" else 5e-6        # the two template instances contract different multiply-adds into FMAs (measured: dist 9e-8 voxel, albedo 2.6e-6); SH2: the ill-conditioned light step amplifies it (LIGHT_RTOL above)
     assert np.abs(ve["dist"][band] - vf["dist"][band]).max() <= 10 * noise * vs and np.abs(ve["rgb"][:, band] - vf["rgb"][:, band]).max() <= noise
     assert np.abs(eng.download_poses() - engf.download_poses()).max() <= noise
