@@ -13,6 +13,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools/pmc_summary.py "$f" "$w" > $out/pmc_summary.json
+cp $out/pmc_summary.json profiles/pmc_summary.json; cp $out/kernel_stats_summary.json profiles/kernel_stats_summary.json      # (the line below quotes them; copy them into profiles/ at home too)
 python bench.py > $out/bench.json 2> $out/bench.err
 find $out/trace -name "*.db" -delete; rm -rf $out/pmc_*/    # keep the summaries only (the databases are tens of MB)
 head -20 $out/kernel_stats.md; cat $out/pmc_summary.json | head -30; cut -c 1-300 $out/bench.json
