@@ -337,8 +337,14 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     hipIpcMemHandle_t hx{}, hb{};
     int Gs, Rs;
     bool ok = c->xr_enable && c->pcg_persist && c->pcg_fuse_asm && c->xr_mem_kind > 0 && c->rec_mem;
+    // the region: the solve's fixed words + the frame rows' exchange area (engine.h XfTable) for this many ranks and keyframes.  (Every peer closed
+    // its mapping of the old region in xr_quiesce at the top of build_band: it may be replaced here.)
+    const size_t frows = (size_t)2 * R * std::max(c->F, 1);
+    const size_t want = (size_t)kXrDoubles + frows * kFrameRow + frows;
+    if (ok && c->xr && c->xr_doubles < want) { hipFree(c->xr); c->xr = nullptr; c->xr_doubles = 0; }
     if (ok && !c->xr) {
-        if (xr_alloc(c, (void**)&c->xr, sizeof(double) * kXrDoubles, true) || hipMemsetAsync(c->xr, 0, sizeof(double) * kXrDoubles, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
+        if (xr_alloc(c, (void**)&c->xr, sizeof(double) * want, true) || hipMemsetAsync(c->xr, 0, sizeof(double) * want, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
+        else c->xr_doubles = want;
     }
     ok = ok && cgf_solve_shape(c, &Gs, &Rs, true)      // (this slab fits the persistent kernel at all)
         && hipIpcGetMemHandle(&hx, c->xr) == hipSuccess && hipIpcGetMemHandle(&hb, c->rec_mem) == hipSuccess;
@@ -397,7 +403,14 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     }
     // agreement: every rank or none.  (Behind this all-reduce every rank's region has been zeroed -- at its allocation, in stream order before
     // its contribution -- so no word of an earlier band or a raised abort flag survives into the solves of this one.)
-    if (c->xr && hipMemsetAsync(c->xr, 0, sizeof(double) * kXrDoubles, c->stream) != hipSuccess) ok = false;
+    if (c->xr && hipMemsetAsync(c->xr, 0, sizeof(double) * c->xr_doubles, c->stream) != hipSuccess) ok = false;
+    if (ok) {      // the frame rows' exchange table (the flags carry the exchange's number, which only grows: the zeroed region matches none)
+        XfTable t{}; t.n_ranks = R; t.rank = me; t.F = std::max(c->F, 1); t.pay = kXrDoubles; t.flg = (long long)kXrDoubles + (long long)frows * kFrameRow;
+        for (int r = 0; r < R; ++r) t.region[r] = c->xr_peer[r];
+        if (!c->xf_table && hipMalloc(&c->xf_table, sizeof(XfTable)) != hipSuccess) ok = false;
+        if (ok && hipMemcpyAsync(c->xf_table, &t, sizeof(t), hipMemcpyHostToDevice, c->stream) != hipSuccess) ok = false;
+        if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
+    }
     std::vector<double> agree(1, ok ? 1.0 : 0.0);
     if ((rc = host_allreduce(c, agree, "cross-rank set-up"))) return rc;
     if (agree[0] != (double)R) { xr_release(c); return 0; }

@@ -120,6 +120,7 @@ struct ImgSrc {
     bool idx32;                        // f32: the stack is < 4 GiB, tap offsets fit 32 bits (device_common.h: sample)
 };
 
+struct XfTable;
 struct SweepArgs {
     Band b;
     const FrameP* frames;     // [F]
@@ -146,6 +147,8 @@ struct SweepArgs {
     int pcg_fuse_init;        // assembly kernel also initialises the PCG (x = 0, records of pass -1, |b|^2 partials): no k_cgf_init launch
     int pcg_init_blocks;      // workgroups that wrote the |b|^2 partials (0: the pass kernel's own grid)
     int fuse_apply;           // albedo sweep: solve the voxel's diagonal system and apply the update in the same thread (no normal equations stored); 2: and keep the old albedo for an undo
+    const XfTable* xf;        // multi-rank: the frame rows travel through the ranks' mailbox regions (nullptr: single rank / RCCL all-reduce path)
+    long long xf_epoch;       // number of this exchange (flag value; its parity selects the buffer)
     int xcd_map;              // workgroup -> work mapping that gives every XCD (physical workgroup id mod 8) one contiguous range of band rows / observation chunks: its L2 then holds an eighth of the band (device_common.h xcd_remap)
     int fm_solve;             // frame-major sweeps: the last workgroup of a frame solves the frame's light (SH) / pose block, the last frame sums the energy columns (sweeps.hip frame_rows_publish): no solve launch
     FrameP* fm_frames; float* fm_undo; double* fm_e_out; unsigned long long fm_e_key;
@@ -173,6 +176,16 @@ struct XrArgs {
     int wait_lo, wait_hi;            // workgroups of the lower / upper neighbour whose tags this slab's cut-side workgroups wait for
     int need_lo, need_hi;            // halo rows this slab gathers from
     unsigned epoch;                  // solve counter of the context (the same on every rank), 14 bits: tags of the cross-rank words are (epoch << 2 | pass tag)
+};
+// Cross-rank exchange of the frame-major sweeps' per-frame rows (sweeps.hip frame_rows_publish, multi-rank): behind the fixed words of a rank's
+// mailbox region sit, for two alternating sweeps, R x F payload rows of kFrameRow doubles and R x F flags.  The last workgroup of frame f on rank r
+// stores ITS slab's final row into [buf][r][f] of EVERY rank's region (system-scope write-through stores), drains them, then sets the flags to the
+// sweep's number; it then waits for the R flags of frame f in its OWN region and adds the R rows in rank order -- every rank holds the same global
+// row without a collective, and solves the frame on the spot as a single-rank context does.
+struct XfTable {
+    int n_ranks, rank, F, pad;
+    long long pay, flg;              // offsets (doubles) of the payload rows / the flags inside a region
+    double* region[32];              // (= kXrMaxRanks) every rank's mailbox region, own included
 };
 constexpr unsigned kXrEpochMask = 0x3fffu;      // (the host clears every region behind an all-rank barrier whenever the epoch wraps: loop.hip pcg_solve)
 

@@ -41,7 +41,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
     a.acc.fpart = c->frame_part; a.acc.fcap = c->frame_cap; a.acc.fdone = c->frame_done;
     a.fold.n = 0; a.gate = nullptr; a.fuse_apply = 0;
-    a.xcd_map = c->xcd_map;
+    a.xcd_map = c->xcd_map; a.xf = nullptr; a.xf_epoch = 0;
     a.fm_solve = 0; a.fm_frames = nullptr; a.fm_undo = nullptr; a.fm_e_out = nullptr; a.fm_e_key = 0;
     a.pcg_part = c->pcg_part; a.pcg_fs = c->pcg_sc; a.pcg_fuse_init = 0; a.pcg_init_blocks = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.pcg_asm = 0; a.pcg_pipe = c->pcg_pipeline ? 1 : 0; a.pcg_apply = 0; a.pcg_xcd_local = (c->pcg_xcd_local ? 1 : 0) | (c->pcg_prefetch ? 2 : 0) | (c->pcg_ablate << 3);
     a.ar = c->ar; a.ar.weight = c->reg_r;
@@ -89,6 +89,7 @@ int deliver_first(psgsdf_ctx* c, size_t count, bool told_landed) {
     }
     c->deferred.erase(c->deferred.begin(), c->deferred.begin() + (long)count);
     if (c->deferred.empty()) c->mbox_used = 0;      // (slots are handed out again only when nothing is in flight)
+    if (c->xf_timeout) { c->xf_timeout = false; return fail(c, PSGSDF_ERR_DEVICE, "a rank's per-frame rows never arrived in the in-sweep exchange (rank %d of %d)", c->rank, c->n_ranks); }
     return 0;
 }
 int deliver(psgsdf_ctx* c) { return deliver_first(c, c->deferred.size(), true); }
@@ -362,6 +363,14 @@ int build_band(psgsdf_ctx* c) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
             hipFree(d_counts);
         }
+    }
+    // a slab without a single observation launches no frame-major sweep and could not deliver its rows to the other ranks from inside one (loop.hip
+    // step_begin: the in-sweep exchange): every rank has to know
+    c->any_empty_slab = false;
+    if (c->n_ranks > 1 && c->comm) {
+        std::vector<double> e(1, (c->row1 <= c->row0 || b.obs_max <= 0) ? 1.0 : 0.0);
+        if (int hrc = host_allreduce(c, e, "empty slabs")) return hrc;
+        c->any_empty_slab = e[0] != 0.0;
     }
     {   // partial rows of the frame-major sweeps: one per workgroup and frame; a sweep uses at most ceil(obs_max / (256 * 4)) workgroups per frame
         if (c->frame_part) { hipFree(c->frame_part); c->frame_part = nullptr; }

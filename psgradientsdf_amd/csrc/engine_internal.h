@@ -140,6 +140,12 @@ struct psgsdf_ctx {
     bool fuse_pcg_init = true;           // PSGSDF_FUSE_PCG_INIT=0: separate k_cgf_init launch
     bool fuse_albedo = true;             // PSGSDF_FUSE_ALBEDO=0: separate k_apply_albedo launch
     bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
+    bool xf_enable = true;               // PSGSDF_XF=0: multi-rank frame rows through an RCCL all-reduce + solve kernels (round 3)
+    XfTable* xf_table = nullptr;         // device copy of the exchange table (valid while xr_ready)
+    long long xf_epoch = 0;              // exchanges so far (the same on every rank)
+    size_t xr_doubles = 0;               // size of this rank's mailbox region
+    bool any_empty_slab = false;         // some rank's slab has no observation at all (agreed at band build)
+    bool xf_timeout = false;             // a frame row came back NaN: a rank's row never arrived
     bool img_compact = true;             // PSGSDF_IMG_COMPACT=0: float keyframes stay float even when every value is (float)byte / 255
     bool img_compacted = false;          // the float keyframes of this context are held as RGBA8 words
     bool speculate_mr = true;            // PSGSDF_SPECULATE_MR=0: no speculative start of the next iteration on multi-rank contexts (round 3's loop)

@@ -252,6 +252,7 @@ __device__ __forceinline__ void frame_solve_pose(const SweepArgs& a, FrameP* fra
 // (the LED light is one vector over all frames: k_solve_light keeps it), KIND 1: the pose block -- and takes a second ticket on the sweep's
 // frame counter; the last FRAME to finish sums the energy / n_obs columns of all rows in frame order into the mailbox (what the solve kernels'
 // frame_rows_finish does).  The frame's record is only read by the frame's own workgroups, all of which have finished; same arithmetic, same bits.
+__device__ __forceinline__ void store8_sys_row(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
 template <int NV, int KIND, int MODEL>
 __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, int f, double* lds /*[kBlock/64][NV] wavefront sums*/) {
     // Hand-off without fences (an agent-scope release fence in every workgroup's tail writes back the XCD's L2 each time: light sweep
@@ -281,6 +282,28 @@ __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, i
             for (int j = 0; j < 16; ++j) v[j] = c + j < (int)gridDim.x ? __hip_atomic_load(p + (size_t)(c + j) * kFrameRow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) s += v[j];
+        }
+        if (solve && a.xf) {
+            // multi-rank: `s` is this SLAB's row of frame f.  It goes into every rank's mailbox region (engine.h XfTable), the R rows of the frame come
+            // back out of the own region and are added in rank order: the global row, the same bits on every rank, no collective and no launch.
+            const XfTable& t = *a.xf;
+            const int Rk = t.n_ranks, buf = (int)(a.xf_epoch & 1);
+            const double tag = (double)a.xf_epoch;
+            const long long slot = ((long long)buf * Rk + t.rank) * t.F + f;
+            for (int r = 0; r < Rk; ++r) store8_sys_row(t.region[r] + t.pay + slot * kFrameRow + threadIdx.x, s);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (NV <= 64: the whole row sits in wavefront 0)
+            if (threadIdx.x == 0) for (int r = 0; r < Rk; ++r) __hip_atomic_store(t.region[r] + t.flg + slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            double* const mine = t.region[t.rank];
+            bool late = false;
+            for (int r = 0; r < Rk && !late; ++r) {
+                const double* fp = mine + t.flg + ((long long)buf * Rk + r) * t.F + f;
+                int spins = 0;
+                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > (1 << 24)) { late = true; break; } }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            double tot = 0.0;
+            for (int r = 0; r < Rk; ++r) tot += __hip_atomic_load(mine + t.pay + (((long long)buf * Rk + r) * t.F + f) * kFrameRow + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            s = late ? __builtin_nan("") : tot;      // (a rank that never delivers: the host sees the NaN energy and reports PSGSDF_ERR_DEVICE, engine.hip deliver_first)
         }
         if (solve) { __hip_atomic_store(a.acc.frame + (size_t)f * kFrameRow + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); lds[threadIdx.x] = s; }      // (the last frame's workgroup reads the energy columns of every row)
         else a.acc.frame[(size_t)f * kFrameRow + threadIdx.x] = s;

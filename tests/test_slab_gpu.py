@@ -46,7 +46,7 @@ def stitch(res, key):
     return out
 
 
-@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("SH1", 2, "gloo-xr0"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH1", 4, "gloo"), ("SH2", 2, "gloo"),
+@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("SH1", 2, "gloo-xr0"), ("SH1", 3, "gloo-xf0"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH1", 4, "gloo"), ("SH2", 2, "gloo"),
                                                    ("SH1+reg", 2, "gloo")])
 def test_native_slab_loop_matches_single_context(built, margins, tmp_path, model, world, transport):
     N, n_iters = 40, 2
@@ -55,7 +55,8 @@ def test_native_slab_loop_matches_single_context(built, margins, tmp_path, model
     # "gloo-xr0": the multi-rank PCG of round 2 (per-pass kernels, one all-reduce of 7 doubles and one halo exchange per pass); without it the ranks
     # run the CROSS-RANK PERSISTENT solve (pcg.hip k_cgf_solve<.., MR>: halo records pushed into the neighbour's band through IPC mappings, rank-level
     # sums through every rank's mailbox region) -- here between two / three processes sharing the one GPU
-    extra = {"PSGSDF_PCG_PERSIST": "0"} if transport == "rccl-perpass" else {"PSGSDF_XR": "0"} if transport == "gloo-xr0" else None
+    # "gloo-xf0": the per-frame light / pose rows through an all-reduce and the solve kernels (round 3); without it they meet inside the sweeps
+    extra = {"PSGSDF_PCG_PERSIST": "0"} if transport == "rccl-perpass" else {"PSGSDF_XR": "0"} if transport == "gloo-xr0" else {"PSGSDF_XF": "0"} if transport == "gloo-xf0" else None
     res = run_ranks(tmp_path, model, world, transport.split("-")[0], "iterate", N, n_iters, extra)
     # "+reg": with the albedo regulariser -- the matrix-free CG over 3S unknowns whose Jr / Jr^T stencils cross the cut (halo exchanges
     # of J, res, p and t; every dot product an all-reduce)
@@ -86,13 +87,13 @@ def test_native_slab_loop_matches_single_context(built, margins, tmp_path, model
                 # the distance solves ran as ONE kernel per rank (a rank that cannot wait any longer for the others -- a badly loaded host -- makes
                 # ALL ranks fall back to the per-pass kernels together; that is correct behaviour too, so it is tolerated here and counted)
                 assert xr_ready == 1 and xr_solves >= 1 and fallbacks <= 1
-                assert got["ncoll"] > (60 if opt == "reg" else 8)                   # reg: four exchanges per CG iteration of the regularised albedo solve
+                assert got["ncoll"] > (60 if opt == "reg" else 4)                   # reg: four exchanges per CG iteration of the regularised albedo solve
                 if opt != "reg" and fallbacks == 0:
                     assert xr_solves == n_iters and got["ncoll"] < 40               # ... and the per-pass collectives are gone
             held = ~np.isnan(got["dist"])
             assert held.sum() == (z1 - z0) * N * N and held[z0 * N * N:(z1 * N * N)].all()      # exactly its own planes came back
         else:
-            assert got["ncoll"] > (40 if transport == "rccl-perpass" else 5)   # RCCL all-reduces of a one-rank communicator
+            assert got["ncoll"] > (30 if transport == "rccl-perpass" else 3)   # RCCL all-reduces of a one-rank communicator (the per-frame rows need none: solved inside the sweeps)
     # the slabs tile the volume and the band: stitched together they are the single-context result (the slabs sum their dot products in a
     # different order than one context does)
     assert np.array_equal(np.concatenate([g["band"] for g in res]), band)
