@@ -33,6 +33,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_PCG_PREFETCH")) c->pcg_prefetch = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FM_SOLVE")) c->fm_solve = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XF")) c->xf_enable = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_XS")) c->xs_enable = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_IMG_COMPACT")) c->img_compact = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_SPECULATE_MR")) c->speculate_mr = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XCD_MAP")) c->xcd_map = atoi(e);

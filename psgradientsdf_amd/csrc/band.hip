@@ -276,17 +276,18 @@ void launch_lower_bound(const int* lin, int S, int target, int* out, hipStream_t
 }
 // fold per-workgroup partials into a few doubles.  `out` may be host-mapped pinned memory: the host then needs no
 // D2H copy (each hipMemcpyAsync costs ~10 us of GPU idle around it), only the stream synchronisation it does anyway.
-__global__ void __launch_bounds__(kBlock) k_sum_parts(const double* __restrict__ part, int PB, int nblk, SlotList slots, double* __restrict__ out, unsigned long long key) {
+__global__ void __launch_bounds__(kBlock) k_sum_parts(const double* __restrict__ part, int PB, int nblk, SlotList slots, double* __restrict__ out, unsigned long long key, const XfTable* xf, long long xf_epoch) {
     __shared__ double red[kBlock / 64];
-    for (int s = 0; s < slots.n; ++s) {
-        double t = block_total(part + (size_t)slots.id[s] * PB, nblk, red);
-        if (threadIdx.x == 0) mbox_put(out, slots.n, s, t, key);
-        __syncthreads();
+    double t[8];
+    for (int s = 0; s < slots.n; ++s) { t[s] = block_total(part + (size_t)slots.id[s] * PB, nblk, red); __syncthreads(); }
+    if (threadIdx.x == 0) {
+        if (xf) fold_exchange(xf, xf_epoch, slots.n, t);      // multi-rank: the sums over all slabs (device_common.h)
+        for (int s = 0; s < slots.n; ++s) mbox_put(out, slots.n, s, t[s], key);
+        mbox_commit(key);
     }
-    if (threadIdx.x == 0) mbox_commit(key);
 }
-void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, unsigned long long key, hipStream_t s) {
-    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(kBlock), 0, s, part, PB, nblk, slots, out, key);
+void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, unsigned long long key, hipStream_t s, const XfTable* xf, long long xf_epoch) {
+    hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(kBlock), 0, s, part, PB, nblk, slots, out, key, xf, xf_epoch);
 }
 // sum of columns (col, col+1) over the F frame-accumulator rows -> out[0..1]
 __global__ void __launch_bounds__(kBlock) k_frame_cols(const double* __restrict__ frame, int F, int col, double* __restrict__ out, unsigned long long key) {

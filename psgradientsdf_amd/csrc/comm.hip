@@ -340,7 +340,7 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     // the region: the solve's fixed words + the frame rows' exchange area (engine.h XfTable) for this many ranks and keyframes.  (Every peer closed
     // its mapping of the old region in xr_quiesce at the top of build_band: it may be replaced here.)
     const size_t frows = (size_t)2 * R * std::max(c->F, 1);
-    const size_t want = (size_t)kXrDoubles + frows * kFrameRow + frows;
+    const size_t want = (size_t)kXrDoubles + frows * kFrameRow + frows + (size_t)2 * R * 8 + (size_t)2 * R;
     if (ok && c->xr && c->xr_doubles < want) { hipFree(c->xr); c->xr = nullptr; c->xr_doubles = 0; }
     if (ok && !c->xr) {
         if (xr_alloc(c, (void**)&c->xr, sizeof(double) * want, true) || hipMemsetAsync(c->xr, 0, sizeof(double) * want, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
@@ -405,7 +405,7 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     // its contribution -- so no word of an earlier band or a raised abort flag survives into the solves of this one.)
     if (c->xr && hipMemsetAsync(c->xr, 0, sizeof(double) * c->xr_doubles, c->stream) != hipSuccess) ok = false;
     if (ok) {      // the frame rows' exchange table (the flags carry the exchange's number, which only grows: the zeroed region matches none)
-        XfTable t{}; t.n_ranks = R; t.rank = me; t.F = std::max(c->F, 1); t.pay = kXrDoubles; t.flg = (long long)kXrDoubles + (long long)frows * kFrameRow;
+        XfTable t{}; t.n_ranks = R; t.rank = me; t.F = std::max(c->F, 1); t.pay = kXrDoubles; t.flg = (long long)kXrDoubles + (long long)frows * kFrameRow; t.spay = t.flg + (long long)frows; t.sflg = t.spay + (long long)2 * R * 8;
         for (int r = 0; r < R; ++r) t.region[r] = c->xr_peer[r];
         if (!c->xf_table && hipMalloc(&c->xf_table, sizeof(XfTable)) != hipSuccess) ok = false;
         if (ok && hipMemcpyAsync(c->xf_table, &t, sizeof(t), hipMemcpyHostToDevice, c->stream) != hipSuccess) ok = false;

@@ -241,15 +241,43 @@ __device__ __forceinline__ void mbox_put(double* out, int n, int i, double v, un
     if (key) reinterpret_cast<unsigned long long*>(out)[n + i] = (unsigned long long)__double_as_longlong(v) ^ (key + (unsigned long long)i);
 }
 __device__ __forceinline__ void mbox_commit(unsigned long long key) { if (key) __threadfence_system(); }
+// 8-byte write-through store at system scope: the word reaches memory (another device's view) without a later write-back
+__device__ __forceinline__ void store8_system(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
+// Multi-rank fold (ONE thread): this slab's n <= 8 sums go into slot [parity][rank] of EVERY rank's mailbox region (payload, drained, then a flag
+// carrying the fold's number), the R ranks' sums come back out of the own region and are added in rank order -- the same bits on every rank.
+// A rank that never delivers (bounded wait) turns the sums into NaN; the host reports it.
+__device__ __forceinline__ void fold_exchange(const XfTable* xf, long long epoch, int n, double* t) {
+    const XfTable& x = *xf;
+    const int Rk = x.n_ranks, buf = (int)(epoch & 1);
+    const double tag = (double)epoch;
+    const long long slot = (long long)buf * Rk + x.rank;
+    for (int r = 0; r < Rk; ++r) for (int s = 0; s < n; ++s) store8_system(x.region[r] + x.spay + slot * 8 + s, t[s]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int r = 0; r < Rk; ++r) __hip_atomic_store(x.region[r] + x.sflg + slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    double* const mine = x.region[x.rank];
+    bool late = false;
+    for (int r = 0; r < Rk && !late; ++r) {
+        int spins = 0;
+        while (__hip_atomic_load(mine + x.sflg + (long long)buf * Rk + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > (1 << 24)) { late = true; break; } }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    for (int s = 0; s < n; ++s) {
+        double tot = 0.0;
+        for (int r = 0; r < Rk; ++r) tot += __hip_atomic_load(mine + x.spay + ((long long)buf * Rk + r) * 8 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        t[s] = late ? __builtin_nan("") : tot;
+    }
+}
 // a.fold: sum the partial slots the PREVIOUS kernel left behind (first workgroup only; all its threads must call).
 // The calling kernel must not write the folded slots itself (engine.hip: take_fold checks).
 __device__ __forceinline__ void fold_pending(const SweepArgs& a, double* red /*[kBlock/64]*/) {
     if (a.fold.n == 0 || blockIdx.x != 0 || blockIdx.y != 0) return;
-    for (int s = 0; s < a.fold.n; ++s) {
-        const double t = block_total(PART(a, a.fold.id[s]), a.fold.nblk, red);
-        if (threadIdx.x == 0) mbox_put(a.fold.out, a.fold.n, s, t, a.fold.key);
+    double t[4];
+    for (int s = 0; s < a.fold.n; ++s) t[s] = block_total(PART(a, a.fold.id[s]), a.fold.nblk, red);
+    if (threadIdx.x == 0) {
+        if (a.fold.xf) fold_exchange(a.fold.xf, a.fold.xf_epoch, a.fold.n, t);
+        for (int s = 0; s < a.fold.n; ++s) mbox_put(a.fold.out, a.fold.n, s, t[s], a.fold.key);
+        mbox_commit(a.fold.key);
     }
-    if (threadIdx.x == 0) mbox_commit(a.fold.key);
     __syncthreads();
 }
 

@@ -111,7 +111,10 @@ struct AlbedoReg {
 // `key` != 0: `out` is a slot of the host-mapped mailbox and every value is followed (n doubles further on) by its check word
 // bits(value) ^ (key + index): the host accepts a read-back only when the pair matches (engine.hip: deliver), whatever order the two
 // words reach host memory in and however they are ordered against the marker / status word it was told to wait for.
-struct FoldReq { int n; int id[4]; int nblk; double* out; unsigned long long key; };
+struct XfTable;
+// xf != nullptr (multi-rank): the folded sums are this SLAB's; the folding thread exchanges them with the other ranks through the mailbox regions
+// (device_common.h fold_exchange) and delivers the sums over all slabs -- no all-reduce, no staging: the read-back is global at its source.
+struct FoldReq { int n; int id[4]; int nblk; double* out; unsigned long long key; const XfTable* xf; long long xf_epoch; };
 
 // keyframe images: float RGB [F][H][W][3] (psgsdf_set_keyframes) or RGBA8 words [F][H][W] (psgsdf_set_keyframes_u8); exactly one is set
 struct ImgSrc {
@@ -120,7 +123,6 @@ struct ImgSrc {
     bool idx32;                        // f32: the stack is < 4 GiB, tap offsets fit 32 bits (device_common.h: sample)
 };
 
-struct XfTable;
 struct SweepArgs {
     Band b;
     const FrameP* frames;     // [F]
@@ -185,6 +187,7 @@ struct XrArgs {
 struct XfTable {
     int n_ranks, rank, F, pad;
     long long pay, flg;              // offsets (doubles) of the payload rows / the flags inside a region
+    long long spay, sflg;            // scalar folds (FoldReq::xf): [2 buffers][R ranks][8 values] and [2][R] flags
     double* region[32];              // (= kXrMaxRanks) every rank's mailbox region, own included
 };
 constexpr unsigned kXrEpochMask = 0x3fffu;      // (the host clears every region behind an all-rank barrier whenever the epoch wraps: loop.hip pcg_solve)
@@ -205,7 +208,7 @@ void launch_obs_count(const Band& b, int F, int row0, int row1, int* counts, hip
 void launch_obs_fill(const Band& b, int F, int row0, int row1, const int* offsets, hipStream_t s); // offsets[F][nch] -> b.obs_rows
 void launch_lower_bound(const int* lin, int S, int target, int* out, hipStream_t s);               // *out = number of band rows with lin < target (lin ascending)
 struct SlotList { int n; int id[8]; };
-void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, unsigned long long key, hipStream_t s);   // key: FoldReq
+void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, unsigned long long key, hipStream_t s, const XfTable* xf = nullptr, long long xf_epoch = 0);   // key: FoldReq
 void launch_frame_cols(const double* frame, int F, int col, double* out, unsigned long long key, hipStream_t s);
 void launch_zero_f64(double* p, int n, hipStream_t s);
 struct CopySegs { int n; unsigned off[16]; unsigned len[16]; unsigned long long key[16]; };

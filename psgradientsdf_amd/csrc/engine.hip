@@ -133,7 +133,7 @@ int flush(psgsdf_ctx* c) {
 void fold_by_kernel(psgsdf_ctx* c, FoldReq& f) {
     if (!f.n) return;
     SlotList sl; sl.n = f.n; for (int i = 0; i < sl.n; ++i) sl.id[i] = f.id[i];
-    launch_sum_parts(c->part, c->PB, f.nblk, sl, f.out, f.key, c->stream);
+    launch_sum_parts(c->part, c->PB, f.nblk, sl, f.out, f.key, c->stream, f.xf, f.xf_epoch);
     f.n = 0;
 }
 void materialize_fold(psgsdf_ctx* c) { fold_by_kernel(c, c->pending_fold); }
@@ -180,17 +180,24 @@ int read_parts_deferred(psgsdf_ctx* c, const int* slots, int n, std::function<vo
     size_t off; unsigned long long key;
     { int rc = mbox_reserve(c, n, &off, &key); if (rc) return rc; }
     // multi-rank: this slab's sums go to the device shadow of the mailbox; mg_commit all-reduces them and fills the mailbox slots (values + check words)
-    double* dst = (slab_mode(c) ? c->mbox_shadow : c->mbox_dev) + off;
-    const unsigned long long dkey = slab_mode(c) ? 0ull : key;
-    if (slab_mode(c)) c->mg_segs.push_back({(unsigned)off, (unsigned)n, key});
+    // multi-rank, where the ranks' mailbox regions are mapped (round 4): the folding thread itself exchanges the slab's sums with the other ranks
+    // (device_common.h fold_exchange) and writes the GLOBAL sums straight into the mailbox, check words and all -- as a single-rank context does
+    const bool xs = xs_active(c) && n <= 8;
+    const bool staged = slab_mode(c) && !xs;
+    double* dst = (staged ? c->mbox_shadow : c->mbox_dev) + off;
+    const unsigned long long dkey = staged ? 0ull : key;
+    if (staged) c->mg_segs.push_back({(unsigned)off, (unsigned)n, key});
+    const XfTable* xf = xs ? c->xf_table : nullptr;
+    const long long ep = xs ? ++c->xs_epoch : 0;
     if (n <= 4 && c->fold_in_next) {
         c->pending_fold.n = n; for (int i = 0; i < n; ++i) c->pending_fold.id[i] = slots[i];
-        c->pending_fold.nblk = band_blocks(c); c->pending_fold.out = dst; c->pending_fold.key = dkey;
+        c->pending_fold.nblk = band_blocks(c); c->pending_fold.out = dst; c->pending_fold.key = dkey; c->pending_fold.xf = xf; c->pending_fold.xf_epoch = ep;
     } else {
         SlotList sl; sl.n = n; for (int i = 0; i < n; ++i) sl.id[i] = slots[i];
-        launch_sum_parts(c->part, c->PB, band_blocks(c), sl, dst, dkey, c->stream);
+        launch_sum_parts(c->part, c->PB, band_blocks(c), sl, dst, dkey, c->stream, xf, ep);
     }
-    c->deferred.push_back({c->mbox + off, n, key, std::move(consume)});
+    if (xs) c->deferred.push_back({c->mbox + off, n, key, [c, consume](const double* v) { if (std::isnan(v[0])) c->xf_timeout = true; consume(v); }});      // (NaN: a rank's sums never arrived, fold_exchange)
+    else c->deferred.push_back({c->mbox + off, n, key, std::move(consume)});
     return 0;
 }
 int read_frame_energy_deferred(psgsdf_ctx* c, int col_e, std::function<void(double, double)> consume) {

@@ -140,6 +140,8 @@ struct psgsdf_ctx {
     bool fuse_pcg_init = true;           // PSGSDF_FUSE_PCG_INIT=0: separate k_cgf_init launch
     bool fuse_albedo = true;             // PSGSDF_FUSE_ALBEDO=0: separate k_apply_albedo launch
     bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
+    bool xs_enable = true;               // PSGSDF_XS=0: multi-rank scalar read-backs staged in the mailbox shadow and all-reduced over RCCL (round 3)
+    long long xs_epoch = 0;              // scalar folds exchanged so far (the same on every rank)
     bool xf_enable = true;               // PSGSDF_XF=0: multi-rank frame rows through an RCCL all-reduce + solve kernels (round 3)
     XfTable* xf_table = nullptr;         // device copy of the exchange table (valid while xr_ready)
     long long xf_epoch = 0;              // exchanges so far (the same on every rank)
@@ -228,6 +230,8 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg);
 // slab mode: the context is attached to a communicator (also a one-rank one: the exchanges then run as one-rank collectives, which is how
 // the RCCL path is exercised on a one-GPU box and how its overhead is measured, bench.py --force-slab)
 inline bool slab_mode(const psgsdf_ctx* c) { return c->comm != nullptr || c->n_ranks > 1; }
+// the scalar folds exchange their sums between the ranks themselves (device_common.h fold_exchange): no staging, no all-reduce
+inline bool xs_active(const psgsdf_ctx* c) { return c->n_ranks > 1 && c->xs_enable && c->xr_ready && c->xf_table != nullptr; }
 inline int band_blocks(const psgsdf_ctx* c) { return (c->row1 - c->row0 + kBlock - 1) / kBlock; }
 inline double band_mean(const psgsdf_ctx* c, double sum) { return c->S_global ? sum / (double)c->S_global : 0.0; }   // (1/S) sum over the band of the WHOLE volume
 inline float total_energy(const psgsdf_ctx* c, float E, float E_n, float E_l, float E_r = 0.f) { return E + c->reg_n * E_n + c->reg_l * E_l + c->reg_r * E_r; }   // OptimizerAux.cpp:261

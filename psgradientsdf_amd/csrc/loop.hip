@@ -63,7 +63,7 @@ int pcg_solve(psgsdf_ctx* c, SweepArgs& a, int* iters_out, int* success_out, dou
         // its result: a flush (mailbox full) validates and delivers it, mg_commit (a communicator, also a one-rank one) all-reduces and copies it
         SweepArgs as = a;
         auto fold_now = [&] { fold_by_kernel(c, as.fold); };
-        if (slab_mode(c)) fold_now();
+        if (slab_mode(c) && !xs_active(c)) fold_now();      // (with the in-kernel exchange of the folds the solve's own prologue does it, as on one rank)
         if (c->mbox_used + (size_t)kSolveMbSlots > c->mbox_n) { fold_now(); int rc = flush(c); if (rc) return rc; }
         { int rc = mg_commit(c); if (rc) return rc; }      // (a one-rank communicator: the read-backs staged so far are delivered below)
         const size_t off = c->mbox_used; c->mbox_used += kSolveMbSlots;

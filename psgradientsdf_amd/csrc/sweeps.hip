@@ -252,7 +252,6 @@ __device__ __forceinline__ void frame_solve_pose(const SweepArgs& a, FrameP* fra
 // (the LED light is one vector over all frames: k_solve_light keeps it), KIND 1: the pose block -- and takes a second ticket on the sweep's
 // frame counter; the last FRAME to finish sums the energy / n_obs columns of all rows in frame order into the mailbox (what the solve kernels'
 // frame_rows_finish does).  The frame's record is only read by the frame's own workgroups, all of which have finished; same arithmetic, same bits.
-__device__ __forceinline__ void store8_sys_row(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
 template <int NV, int KIND, int MODEL>
 __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, int f, double* lds /*[kBlock/64][NV] wavefront sums*/) {
     // Hand-off without fences (an agent-scope release fence in every workgroup's tail writes back the XCD's L2 each time: light sweep
@@ -290,7 +289,7 @@ __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, i
             const int Rk = t.n_ranks, buf = (int)(a.xf_epoch & 1);
             const double tag = (double)a.xf_epoch;
             const long long slot = ((long long)buf * Rk + t.rank) * t.F + f;
-            for (int r = 0; r < Rk; ++r) store8_sys_row(t.region[r] + t.pay + slot * kFrameRow + threadIdx.x, s);
+            for (int r = 0; r < Rk; ++r) store8_system(t.region[r] + t.pay + slot * kFrameRow + threadIdx.x, s);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (NV <= 64: the whole row sits in wavefront 0)
             if (threadIdx.x == 0) for (int r = 0; r < Rk; ++r) __hip_atomic_store(t.region[r] + t.flg + slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             double* const mine = t.region[t.rank];

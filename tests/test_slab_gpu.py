@@ -46,7 +46,7 @@ def stitch(res, key):
     return out
 
 
-@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("SH1", 2, "gloo-xr0"), ("SH1", 3, "gloo-xf0"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH1", 4, "gloo"), ("SH2", 2, "gloo"),
+@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("SH1", 2, "gloo-xr0"), ("SH1", 3, "gloo-xf0"), ("LED", 2, "gloo-xs0"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH1", 4, "gloo"), ("SH2", 2, "gloo"),
                                                    ("SH1+reg", 2, "gloo")])
 def test_native_slab_loop_matches_single_context(built, margins, tmp_path, model, world, transport):
     N, n_iters = 40, 2
@@ -56,7 +56,7 @@ def test_native_slab_loop_matches_single_context(built, margins, tmp_path, model
     # run the CROSS-RANK PERSISTENT solve (pcg.hip k_cgf_solve<.., MR>: halo records pushed into the neighbour's band through IPC mappings, rank-level
     # sums through every rank's mailbox region) -- here between two / three processes sharing the one GPU
     # "gloo-xf0": the per-frame light / pose rows through an all-reduce and the solve kernels (round 3); without it they meet inside the sweeps
-    extra = {"PSGSDF_PCG_PERSIST": "0"} if transport == "rccl-perpass" else {"PSGSDF_XR": "0"} if transport == "gloo-xr0" else {"PSGSDF_XF": "0"} if transport == "gloo-xf0" else None
+    extra = {"PSGSDF_PCG_PERSIST": "0"} if transport == "rccl-perpass" else {"PSGSDF_XR": "0"} if transport == "gloo-xr0" else {"PSGSDF_XF": "0"} if transport == "gloo-xf0" else {"PSGSDF_XS": "0"} if transport == "gloo-xs0" else None      # "gloo-xs0": scalar read-backs staged and all-reduced (round 3) instead of exchanged by the folding thread
     res = run_ranks(tmp_path, model, world, transport.split("-")[0], "iterate", N, n_iters, extra)
     # "+reg": with the albedo regulariser -- the matrix-free CG over 3S unknowns whose Jr / Jr^T stencils cross the cut (halo exchanges
     # of J, res, p and t; every dot product an all-reduce)
