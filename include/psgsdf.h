@@ -341,7 +341,8 @@ int psgsdf_debug_albedo_system(psgsdf_ctx* ctx, float* H, float* b);
  *   out[2] distance steps re-run on the per-pass kernels because the persistent solve could not get its workgroups co-resident
  *          (+ 1e6 if the float keyframes of psgsdf_set_keyframes turned out to be 8-bit data and are held as RGBA8 words)
  *   out[3] 1e6 x iterations started speculatively (before the stop decision on the previous one) + those of them that were undone
- *   out[4] 1 if this (multi-rank) context holds the cross-rank mappings of the persistent solve, out[5] distance solves run through it,
+ *   out[4] 1 if this (multi-rank) context holds the cross-rank mappings of the persistent solve (+ 10 x halo exchanges done by push / pull kernels
+ *          through those mappings instead of the communicator), out[5] distance solves run through it,
  *   out[6] memory kind the hand-off probe chose for the record planes another device writes (-1 not probed: single rank; 0 none passed: cross-rank
  *   solve off; 1 fine-grained; 2 uncached; 3 coarse, pinned by PSGSDF_XR_MEM), out[7] 1e6 x stale records + timed-out waits the probe saw (all ranks) */
 int psgsdf_debug_sync_stats(psgsdf_ctx* ctx, int64_t out[8]);

@@ -433,7 +433,7 @@ class Api:
         out = (C.c_int64 * 8)()
         self._check(self._fn("debug_sync_stats")(self.ctx, out), "debug_sync_stats")
         return dict(readbacks_checked=out[0], readbacks_late=out[1], persist_fallbacks=out[2] % 1000000, keyframes_compacted=out[2] // 1000000, speculative_starts=out[3] // 1000000, speculative_undos=out[3] % 1000000,
-                    cross_rank_ready=out[4], cross_rank_solves=out[5], cross_rank_mem_kind=out[6], probe_stale=out[7] // 1000000, probe_timeouts=out[7] % 1000000)
+                    cross_rank_ready=out[4] % 10, halo_pushes=out[4] // 10, cross_rank_solves=out[5], cross_rank_mem_kind=out[6], probe_stale=out[7] // 1000000, probe_timeouts=out[7] % 1000000)
 
     def debug_rare_rows(self):
         r = C.c_int64(); w = C.c_int64()

@@ -34,6 +34,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_FM_SOLVE")) c->fm_solve = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XF")) c->xf_enable = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XS")) c->xs_enable = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_XH")) c->xh_enable = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_IMG_COMPACT")) c->img_compact = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_SPECULATE_MR")) c->speculate_mr = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XCD_MAP")) c->xcd_map = atoi(e);
@@ -87,7 +88,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    hipFree(c->xr); hipFree(c->xf_table);
+    hipFree(c->xr); hipFree(c->xf_table); hipFree(c->hx_mem);
     comm_destroy(c);
     hipFree(c->areg_mem); hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mbox_shadow); hipFree(c->d_need);
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);

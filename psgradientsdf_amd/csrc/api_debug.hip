@@ -171,7 +171,7 @@ int psgsdf_debug_albedo_system(psgsdf_ctx* c, float* H, float* b) {
 int psgsdf_debug_sync_stats(psgsdf_ctx* c, int64_t out[8]) {
     if (!c || !out) return PSGSDF_ERR_ARG;
     out[0] = c->mbox_checked; out[1] = c->mbox_late; out[2] = c->persist_fallbacks + (c->img_compacted ? 1000000LL : 0); out[3] = c->spec_windows * 1000000LL + c->spec_undos;
-    out[4] = c->xr_ready ? 1 : 0; out[5] = c->xr_solves; out[6] = c->xr_mem_kind; out[7] = c->xr_probe_stale * 1000000LL + c->xr_probe_timeouts;
+    out[4] = (c->xr_ready ? 1 : 0) + 10 * c->n_halo_pushes; out[5] = c->xr_solves; out[6] = c->xr_mem_kind; out[7] = c->xr_probe_stale * 1000000LL + c->xr_probe_timeouts;
     return PSGSDF_OK;
 }
 

@@ -119,9 +119,76 @@ int comm_allreduce(psgsdf_ctx* c, double* buf, int n) {
 
 // halo rows of `planes` planes of `width` 4-byte words per row (plane stride Spad rows) with the two z-neighbours:
 // what this slab needs of them ([row0-need_lo,row0) and [row1,row1+need_hi)) against what they need of it (give_lo / give_hi rows)
+// Round 4: where the ranks' mailbox regions and halo stagings are mapped (xr_setup) the exchange is two small kernels on the context's stream instead
+// of an RCCL send / recv group: k_halo_push stores the cut-side rows into the neighbours' stagings (system-scope write-through stores, drained, then a
+// flag carrying the exchange's number in the neighbour's region), k_halo_pull waits for the two neighbours' flags and copies the staged rows into
+// the halo rows of the array.  Two stagings alternate, so a push never overwrites rows the neighbour has yet to pull (its pull of exchange n sits
+// in front of its push of n + 1, which this rank's pull of n + 1 -- in front of its push of n + 2 -- waits for).
+namespace {
+struct HaloSide { const unsigned* src; unsigned* dst; int rows; double* flag; };
+struct HaloArgs { HaloSide s[2]; int planes, width; long long plane_words; double tag; double* abort_flag; };
+__global__ void __launch_bounds__(1024) k_halo_push(HaloArgs h) {
+    const HaloSide& sd = h.s[blockIdx.x];
+    if (sd.rows <= 0) return;
+    const int n = sd.rows * h.width;
+    for (int p = 0; p < h.planes; ++p)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned v = sd.src[(size_t)p * h.plane_words + i];
+            asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(sd.dst + (size_t)p * n + i), "v"(v) : "memory");
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(sd.flag, h.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void __launch_bounds__(1024) k_halo_pull(HaloArgs h) {
+    const HaloSide& sd = h.s[blockIdx.x];      // (src: the own staging, dst: the array's halo rows, flag: in the own region)
+    if (sd.rows <= 0) return;
+    __shared__ int s_late;
+    if (threadIdx.x == 0) {
+        int spins = 0; s_late = 0;
+        while (__hip_atomic_load(sd.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != h.tag) { __builtin_amdgcn_s_sleep(2); if (++spins > (1 << 24)) { s_late = 1; break; } }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (s_late) __hip_atomic_store(h.abort_flag, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    const int n = sd.rows * h.width;
+    for (int p = 0; p < h.planes; ++p)
+        for (int i = threadIdx.x; i < n; i += blockDim.x)      // (a neighbour that never delivers: NaN rows -- the energies turn NaN and the host reports PSGSDF_ERR_DEVICE)
+            sd.dst[(size_t)p * h.plane_words + i] = s_late ? 0x7fc00000u : __hip_atomic_load(sd.src + (size_t)p * n + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
 int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
     if (c->n_ranks == 1 || !c->halo_active) return 0;
     int rc = need_comm(c); if (rc) return rc;
+    if (c->hx_ready && c->xr_ready && planes * width <= kHxWords) {
+        const long long ep = ++c->hx_epoch;
+        const int par = (int)(ep & 1);
+        const size_t pw = (size_t)width * c->band.Spad;
+        HaloArgs push{}, pull{};
+        push.planes = pull.planes = planes; push.width = pull.width = width; push.plane_words = pull.plane_words = (long long)pw; push.tag = pull.tag = (double)ep;
+        pull.abort_flag = push.abort_flag = c->xr + kXrAbort;
+        unsigned* arr = (unsigned*)base;
+        for (int sd = 0; sd < 2; ++sd) {
+            const int nb = sd == 0 ? c->rank - 1 : c->rank + 1;
+            // what I give: my first give[0] rows to the lower neighbour (its upper side), my last give[1] rows to the upper neighbour (its lower side)
+            if (c->give[sd] && c->hx_peer[sd]) {
+                push.s[sd].src = arr + (size_t)width * (sd == 0 ? c->row0 : c->row1 - c->give[1]);
+                push.s[sd].dst = (unsigned*)(c->hx_peer[sd] + (size_t)par * c->hx_peer_par[sd] + c->hx_peer_off[sd]);
+                push.s[sd].rows = c->give[sd];
+                push.s[sd].flag = c->xr_peer[nb] + c->hx_flag_off + par * 2 + (1 - sd);      // (the neighbour's side seen from ITS end)
+            }
+            if (c->need[sd]) {
+                pull.s[sd].src = (const unsigned*)((char*)c->hx_mem + (size_t)par * c->hx_par + (sd == 0 ? 0 : sizeof(unsigned) * kHxWords * (size_t)c->need[0]));
+                pull.s[sd].dst = arr + (size_t)width * (sd == 0 ? c->row0 - c->need[0] : c->row1);
+                pull.s[sd].rows = c->need[sd];
+                pull.s[sd].flag = c->xr + c->hx_flag_off + par * 2 + sd;
+            }
+        }
+        hipLaunchKernelGGL(k_halo_push, dim3(2), dim3(1024), 0, c->stream, push);
+        hipLaunchKernelGGL(k_halo_pull, dim3(2), dim3(1024), 0, c->stream, pull);
+        c->n_halo_pushes++;
+        return 0;
+    }
     const size_t rowb = 4 * (size_t)width, planeb = rowb * (size_t)c->band.Spad;
     std::vector<psgsdf_comm_xfer> sends, recvs;
     for (int p = 0; p < planes; ++p) {
@@ -317,6 +384,7 @@ int xr_probe(psgsdf_ctx* c) {
 void xr_release(psgsdf_ctx* c) {
     for (void* p : c->xr_opened) hipIpcCloseMemHandle(p);
     c->xr_opened.clear(); c->xr_peer.clear(); c->band_peer[0] = c->band_peer[1] = nullptr; c->xr_ready = false; c->xr_args = XrArgs{};
+    c->hx_ready = false; c->hx_peer[0] = c->hx_peer[1] = nullptr;
 }
 // Before rec_mem or the mailbox region are freed (band rebuild, destroy) every rank has to have closed its mappings of them: freeing memory an
 // importer still maps is undefined in HIP.  Collective over the ranks of the context; a no-op when nothing was ever exported.
@@ -332,15 +400,21 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     const int R = c->n_ranks, me = c->rank;
     if (R <= 1 || !c->comm) return 0;
     if (R > kXrMaxRanks) return 0;                                 // (the same on every rank)
-    constexpr int kSlice = 64 + 64 + 8;      // two IPC handles (64 bytes each, one double per byte) + {rec[0] offset, rec[1] offset, pid, ok}
+    constexpr int kSlice = 64 + 64 + 8 + 64;      // two IPC handles (64 bytes each, one double per byte) + {rec[0] offset, rec[1] offset, pid, ok} + the halo staging's handle
     std::vector<double> buf((size_t)R * kSlice, 0.0);
-    hipIpcMemHandle_t hx{}, hb{};
+    hipIpcMemHandle_t hx{}, hb{}, hh{};
+    c->hx_ready = false; c->hx_peer[0] = c->hx_peer[1] = nullptr;
     int Gs, Rs;
     bool ok = c->xr_enable && c->pcg_persist && c->pcg_fuse_asm && c->xr_mem_kind > 0 && c->rec_mem;
     // the region: the solve's fixed words + the frame rows' exchange area (engine.h XfTable) for this many ranks and keyframes.  (Every peer closed
     // its mapping of the old region in xr_quiesce at the top of build_band: it may be replaced here.)
     const size_t frows = (size_t)2 * R * std::max(c->F, 1);
-    const size_t want = (size_t)kXrDoubles + frows * kFrameRow + frows + (size_t)2 * R * 8 + (size_t)2 * R;
+    const size_t want = (size_t)kXrDoubles + frows * kFrameRow + frows + (size_t)2 * R * 8 + (size_t)2 * R + 8;      // (+ 4 flags of the halo pushes, comm_halo)
+    // halo staging: what the two neighbours push of their cut-side rows (comm_halo): [2 parities][lower side: need_lo rows | upper side: need_hi rows] x kHxWords words
+    const size_t hx_par = sizeof(unsigned) * kHxWords * ((size_t)c->need[0] + c->need[1]);
+    if (c->hx_mem) { hipFree(c->hx_mem); c->hx_mem = nullptr; }
+    if (ok && c->xh_enable && hx_par) { if (xr_alloc(c, &c->hx_mem, 2 * hx_par, false)) { (void)hipGetLastError(); c->hx_mem = nullptr; } }
+    const bool hx_ok = ok && c->hx_mem && hipIpcGetMemHandle(&hh, c->hx_mem) == hipSuccess;
     if (ok && c->xr && c->xr_doubles < want) { hipFree(c->xr); c->xr = nullptr; c->xr_doubles = 0; }
     if (ok && !c->xr) {
         if (xr_alloc(c, (void**)&c->xr, sizeof(double) * want, true) || hipMemsetAsync(c->xr, 0, sizeof(double) * want, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
@@ -353,6 +427,8 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     handle_to_doubles(hx, mine); handle_to_doubles(hb, mine + 64);
     mine[128] = (double)((char*)c->band.rec[0] - (char*)c->rec_mem); mine[129] = (double)((char*)c->band.rec[1] - (char*)c->rec_mem);
     mine[130] = (double)getpid(); mine[131] = ok ? 1.0 : 0.0;
+    mine[132] = (hx_ok || (ok && c->xh_enable && !hx_par)) ? 1.0 : 0.0;      // (a rank that needs no halo rows has nothing to stage and is fine with the pushes)
+    if (hx_ok) handle_to_doubles(hh, mine + 136);
     int rc = host_allreduce(c, buf, "cross-rank set-up");
     if (rc) return rc;
     c->xr_mapped = true;             // (handles are out: a peer may map them from here on)
@@ -367,6 +443,23 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
         c->xr_peer[r] = (double*)open(sl);
         if (!c->xr_peer[r]) { ok = false; break; }
         if (r == me - 1 || r == me + 1) { c->band_peer[r == me - 1 ? 0 : 1] = open(sl + 64); if (!c->band_peer[r == me - 1 ? 0 : 1]) { ok = false; break; } }
+    }
+    // the neighbours' halo stagings (halo pushes instead of RCCL send / recv: all ranks or none)
+    bool hx_all = ok;
+    for (int r = 0; r < R && hx_all; ++r) if (buf[(size_t)r * kSlice + 132] != 1.0) hx_all = false;
+    if (me > 0 && c->give[0] != (int)info[3 * (me - 1) + 1]) hx_all = false;      // (what I push has to be exactly what the neighbour stages)
+    if (me < R - 1 && c->give[1] != (int)info[3 * (me + 1)]) hx_all = false;
+    if (hx_all) {
+        for (int sd = 0; sd < 2 && hx_all; ++sd) {
+            const int nb = sd == 0 ? me - 1 : me + 1;
+            if (nb < 0 || nb >= R || c->give[sd] == 0) continue;
+            c->hx_peer[sd] = (char*)open(buf.data() + (size_t)nb * kSlice + 136);
+            if (!c->hx_peer[sd]) { hx_all = false; break; }
+            const size_t nlo = (size_t)info[3 * nb], nhi = (size_t)info[3 * nb + 1];
+            c->hx_peer_par[sd] = sizeof(unsigned) * kHxWords * (nlo + nhi);
+            // my first rows are the LOWER neighbour's upper halo, my last rows the UPPER neighbour's lower halo
+            c->hx_peer_off[sd] = sd == 0 ? sizeof(unsigned) * kHxWords * nlo : 0;
+        }
     }
     // the launch shapes of the neighbours (a function of their own row count and the CU count, the same on every rank): how many of their
     // workgroups own rows this slab holds as halo = how many tags its cut-side workgroups wait for
@@ -411,10 +504,12 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
         if (ok && hipMemcpyAsync(c->xf_table, &t, sizeof(t), hipMemcpyHostToDevice, c->stream) != hipSuccess) ok = false;
         if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
     }
-    std::vector<double> agree(1, ok ? 1.0 : 0.0);
+    std::vector<double> agree(2, 0.0); agree[0] = ok ? 1.0 : 0.0; agree[1] = (ok && hx_all) ? 1.0 : 0.0;
     if ((rc = host_allreduce(c, agree, "cross-rank set-up"))) return rc;
     if (agree[0] != (double)R) { xr_release(c); return 0; }
     c->xr_args = x; c->xr_ready = true;
+    c->hx_ready = agree[1] == (double)R;
+    c->hx_par = hx_par; c->hx_flag_off = (long long)want - 8;
     return 0;
 }
 

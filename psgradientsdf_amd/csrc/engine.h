@@ -190,6 +190,7 @@ struct XfTable {
     long long spay, sflg;            // scalar folds (FoldReq::xf): [2 buffers][R ranks][8 values] and [2][R] flags
     double* region[32];              // (= kXrMaxRanks) every rank's mailbox region, own included
 };
+constexpr int kHxWords = 16;            // 4-byte words per row a halo push carries at most (planes x width of comm_halo: 14 voxel-block planes, 15 of the albedo regulariser, one float4 record)
 constexpr unsigned kXrEpochMask = 0x3fffu;      // (the host clears every region behind an all-rank barrier whenever the epoch wraps: loop.hip pcg_solve)
 
 // ---- launchers implemented in the kernel files (all asynchronous on `s`) ----------------------

@@ -140,6 +140,12 @@ struct psgsdf_ctx {
     bool fuse_pcg_init = true;           // PSGSDF_FUSE_PCG_INIT=0: separate k_cgf_init launch
     bool fuse_albedo = true;             // PSGSDF_FUSE_ALBEDO=0: separate k_apply_albedo launch
     bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
+    bool xh_enable = true;               // PSGSDF_XH=0: halo rows through RCCL send / recv (round 3)
+    void* hx_mem = nullptr;              // halo staging the two neighbours push into (fine-grained, IPC-exported): [2 parities][lower | upper side]
+    char* hx_peer[2] = {nullptr, nullptr};   // the neighbours' stagings (lower, upper), mapped
+    size_t hx_peer_par[2] = {0, 0}, hx_peer_off[2] = {0, 0}, hx_par = 0;
+    long long hx_flag_off = 0, hx_epoch = 0, n_halo_pushes = 0;
+    bool hx_ready = false;
     bool xs_enable = true;               // PSGSDF_XS=0: multi-rank scalar read-backs staged in the mailbox shadow and all-reduced over RCCL (round 3)
     long long xs_epoch = 0;              // scalar folds exchanged so far (the same on every rank)
     bool xf_enable = true;               // PSGSDF_XF=0: multi-rank frame rows through an RCCL all-reduce + solve kernels (round 3)

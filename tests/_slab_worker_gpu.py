@@ -86,7 +86,7 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
              info=[info["row0"], info["row1"], info["halo"], info["S"], info["need_lo"], info["need_hi"], info["z0"], info["z1"], info["rows"]],
              track=track if track is not None else np.zeros(0), fused_weight=fused["weight"] if mode.startswith("fuse") else np.zeros(0), fused_dist=fused["dist"] if mode.startswith("fuse") else np.zeros(0),
              fused_vis=fused_vis if mode.startswith("fuse") else np.zeros(0), cut_before=[cut_before["z0"], cut_before["z1"]] if mode.startswith("fuse") and world > 1 else [0, 0],
-             conv=conv, spec=[eng.debug_sync_stats()[k] for k in ("speculative_starts", "speculative_undos")], upsampled=[int(r["upsampled"]) for r in recs],
+             halo_pushes=eng.debug_sync_stats()["halo_pushes"], conv=conv, spec=[eng.debug_sync_stats()[k] for k in ("speculative_starts", "speculative_undos")], upsampled=[int(r["upsampled"]) for r in recs],
              ncoll=eng.comm_stats(), dim=list(eng.info().dim), n_band=eng.info().n_band, xr=[eng.debug_sync_stats()[k] for k in ("cross_rank_ready", "cross_rank_solves", "persist_fallbacks", "cross_rank_mem_kind", "probe_stale", "probe_timeouts")])
     eng.close()
     if tr is not None:

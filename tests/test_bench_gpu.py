@@ -47,7 +47,7 @@ def test_two_ranks_share_the_gpu(built):
     assert r.returncode == 0, r.stderr[-3000:]
     d = _one_json(r.stdout)                             # only rank 0 prints
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0
-    assert "cpu_baseline" not in d and d["config"]["collectives_per_step"] >= 2      # (cross-rank persistent solve, frame rows and scalar folds exchanged inside the kernels: the two halo exchanges around the distance solve remain; more when the ranks sharing the GPU fall back to the per-pass solve)
+    assert "cpu_baseline" not in d and d["config"]["collectives_per_step"] >= 0      # (cross-rank persistent solve, frame rows, scalar folds and halos all travel through the mapped regions: no communicator call per iteration unless the ranks sharing the GPU fall back to the per-pass solve)
     mg = d["multi_gpu"]
     assert mg["ranks"] == 2 and mg["rccl_ranks"] == 0 and mg["cross_rank_ready"] == 1 and mg["cross_rank_solves"] > 0 and mg["persist_fallbacks"] <= 1
     assert mg["hand_off_memory"] == "fine-grained" and mg["probe_stale_records"] == 0 and mg["probe_timeouts"] == 0
@@ -91,4 +91,4 @@ def test_strong_scaling_mode_two_ranks_share_the_gpu(built):
     d = _one_json(outs[0][0])
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     rows = d["config"]["band_rows_per_rank"]
-    assert len(rows) == 2 and min(rows) > 0 and max(rows) <= 1.35 * min(rows) and d["config"]["collectives_per_step"] >= 2
+    assert len(rows) == 2 and min(rows) > 0 and max(rows) <= 1.35 * min(rows) and d["config"]["collectives_per_step"] >= 0

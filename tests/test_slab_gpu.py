@@ -46,7 +46,7 @@ def stitch(res, key):
     return out
 
 
-@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("SH1", 2, "gloo-xr0"), ("SH1", 3, "gloo-xf0"), ("LED", 2, "gloo-xs0"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH1", 4, "gloo"), ("SH2", 2, "gloo"),
+@pytest.mark.parametrize("model,world,transport", [("SH1", 1, "rccl"), ("SH1", 1, "rccl-perpass"), ("SH1", 2, "gloo"), ("SH1", 2, "gloo-xr0"), ("SH1", 3, "gloo-xf0"), ("LED", 2, "gloo-xs0"), ("SH1", 3, "gloo-xh0"), ("LED", 2, "gloo"), ("SH1", 3, "gloo"), ("SH1", 4, "gloo"), ("SH2", 2, "gloo"),
                                                    ("SH1+reg", 2, "gloo")])
 def test_native_slab_loop_matches_single_context(built, margins, tmp_path, model, world, transport):
     N, n_iters = 40, 2
@@ -56,7 +56,7 @@ def test_native_slab_loop_matches_single_context(built, margins, tmp_path, model
     # run the CROSS-RANK PERSISTENT solve (pcg.hip k_cgf_solve<.., MR>: halo records pushed into the neighbour's band through IPC mappings, rank-level
     # sums through every rank's mailbox region) -- here between two / three processes sharing the one GPU
     # "gloo-xf0": the per-frame light / pose rows through an all-reduce and the solve kernels (round 3); without it they meet inside the sweeps
-    extra = {"PSGSDF_PCG_PERSIST": "0"} if transport == "rccl-perpass" else {"PSGSDF_XR": "0"} if transport == "gloo-xr0" else {"PSGSDF_XF": "0"} if transport == "gloo-xf0" else {"PSGSDF_XS": "0"} if transport == "gloo-xs0" else None      # "gloo-xs0": scalar read-backs staged and all-reduced (round 3) instead of exchanged by the folding thread
+    extra = {"PSGSDF_PCG_PERSIST": "0"} if transport == "rccl-perpass" else {"PSGSDF_XR": "0"} if transport == "gloo-xr0" else {"PSGSDF_XF": "0"} if transport == "gloo-xf0" else {"PSGSDF_XS": "0"} if transport == "gloo-xs0" else {"PSGSDF_XH": "0"} if transport == "gloo-xh0" else None      # "gloo-xs0": scalar read-backs staged and all-reduced (round 3) instead of exchanged by the folding thread
     res = run_ranks(tmp_path, model, world, transport.split("-")[0], "iterate", N, n_iters, extra)
     # "+reg": with the albedo regulariser -- the matrix-free CG over 3S unknowns whose Jr / Jr^T stencils cross the cut (halo exchanges
     # of J, res, p and t; every dot product an all-reduce)
@@ -87,7 +87,11 @@ def test_native_slab_loop_matches_single_context(built, margins, tmp_path, model
                 # the distance solves ran as ONE kernel per rank (a rank that cannot wait any longer for the others -- a badly loaded host -- makes
                 # ALL ranks fall back to the per-pass kernels together; that is correct behaviour too, so it is tolerated here and counted)
                 assert xr_ready == 1 and xr_solves >= 1 and fallbacks <= 1
-                assert got["ncoll"] > (60 if opt == "reg" else 4)                   # reg: four exchanges per CG iteration of the regularised albedo solve
+                # (frame rows, scalar folds and halo rows all travel through the mapped regions: what is left for the communicator is set-up traffic;
+                #  "gloo-xf0/xs0/xh0" switch one of the three back to it)
+                assert got["ncoll"] > (4 if transport in ("gloo-xf0", "gloo-xs0", "gloo-xh0") else 0) and int(got["halo_pushes"]) > (0 if transport != "gloo-xh0" else -1)
+                if transport == "gloo-xh0":
+                    assert int(got["halo_pushes"]) == 0
                 if opt != "reg" and fallbacks == 0:
                     assert xr_solves == n_iters and got["ncoll"] < 40               # ... and the per-pass collectives are gone
             held = ~np.isnan(got["dist"])
