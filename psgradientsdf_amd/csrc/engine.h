@@ -149,6 +149,7 @@ struct SweepArgs {
     int pcg_fuse_init;        // assembly kernel also initialises the PCG (x = 0, records of pass -1, |b|^2 partials): no k_cgf_init launch
     int pcg_init_blocks;      // workgroups that wrote the |b|^2 partials (0: the pass kernel's own grid)
     int fuse_apply;           // albedo sweep: solve the voxel's diagonal system and apply the update in the same thread (no normal equations stored); 2: and keep the old albedo for an undo
+    float* fm_led_light;      // fm_solve, LED: the light vector [3] next to the frames' copies (updated by the sweep's last workgroup)
     const XfTable* xf;        // multi-rank: the frame rows travel through the ranks' mailbox regions (nullptr: single rank / RCCL all-reduce path)
     long long xf_epoch;       // number of this exchange (flag value; its parity selects the buffer)
     int xcd_map;              // workgroup -> work mapping that gives every XCD (physical workgroup id mod 8) one contiguous range of band rows / observation chunks: its L2 then holds an eighth of the band (device_common.h xcd_remap)

@@ -41,7 +41,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
     a.acc.fpart = c->frame_part; a.acc.fcap = c->frame_cap; a.acc.fdone = c->frame_done;
     a.fold.n = 0; a.gate = nullptr; a.fuse_apply = 0;
-    a.xcd_map = c->xcd_map; a.xf = nullptr; a.xf_epoch = 0;
+    a.xcd_map = c->xcd_map; a.xf = nullptr; a.xf_epoch = 0; a.fm_led_light = nullptr;
     a.fm_solve = 0; a.fm_frames = nullptr; a.fm_undo = nullptr; a.fm_e_out = nullptr; a.fm_e_key = 0;
     a.pcg_part = c->pcg_part; a.pcg_fs = c->pcg_sc; a.pcg_fuse_init = 0; a.pcg_init_blocks = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.pcg_asm = 0; a.pcg_pipe = c->pcg_pipeline ? 1 : 0; a.pcg_apply = 0; a.pcg_xcd_local = (c->pcg_xcd_local ? 1 : 0) | (c->pcg_prefetch ? 2 : 0) | (c->pcg_ablate << 3);
     a.ar = c->ar; a.ar.weight = c->reg_r;

@@ -159,6 +159,7 @@ struct psgsdf_ctx {
     bool speculate_mr = true;            // PSGSDF_SPECULATE_MR=0: no speculative start of the next iteration on multi-rank contexts (round 3's loop)
     int xcd_map = 3;                     // PSGSDF_XCD_MAP: XCD-contiguous logical workgroup ids in bit 0 the frame-major sweeps, bit 1 k_sweep_albedo / k_energy / k_derive, bit 2 k_sweep_dist (off: 68 -> 76 us, its VALU-bound workgroups want the round-robin's load mix); PSGSDF_XCD_STRIPE=T: stripes of T ids instead of eighths
     bool fm_solve = true;                // PSGSDF_FM_SOLVE=0: k_solve_light / k_solve_pose as kernels of their own behind the frame-major sweeps
+    bool fm_solve_led = true;            // ... also the LED light vector (by the sweep's very last workgroup); PSGSDF_FM_SOLVE=2 keeps k_solve_light for it
     bool fm_solved = false;              // the sweep just launched solves its frames itself (step_begin -> step_finish)
     bool albedo_applied = false;         // the last albedo sweep already applied its update (step_begin -> step_finish)
     unsigned* img8 = nullptr; float img_scale = 0.f;   // keyframes uploaded as 8-bit RGB (psgsdf_set_keyframes_u8): RGBA8 words, c->img stays null

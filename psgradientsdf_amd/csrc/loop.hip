@@ -292,11 +292,11 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
             // cross-rank persistent solve is set up), so the same epilogue serves -- no RCCL all-reduce of the rows, no solve launch.  A one-rank
             // communicator has nothing to exchange.  (An empty slab still has to deliver its -- zero -- rows: it keeps the all-reduce path, on every rank.)
             const bool xf = c->n_ranks > 1 && c->xf_enable && c->xr_ready && c->xf_table && !c->any_empty_slab;
-            const bool fuse = deferred_consumer && c->fm_solve && (!slab_mode(c) || c->n_ranks == 1 || xf) && !c->profiling && (block == PSGSDF_POSE || !led) && c->row1 > c->row0 && c->band.obs_max > 0;
+            const bool fuse = deferred_consumer && c->fm_solve && (!slab_mode(c) || c->n_ranks == 1 || xf) && !c->profiling && (block == PSGSDF_POSE || !led || c->fm_solve_led) && c->row1 > c->row0 && c->band.obs_max > 0;
             double* fm_slot = nullptr; unsigned long long fm_key = 0;
             if (fuse) {      // (the mailbox slot first: reserving may flush, and a flush must not find the pending fold already handed to `a`)
                 if ((rc = reserve_frame_energy_deferred(c, xf ? std::function<void(double, double)>([c, deferred_consumer](double e, double n) { if (std::isnan(e)) c->xf_timeout = true; deferred_consumer(e, n); }) : deferred_consumer, &fm_slot, &fm_key))) return rc;
-                a.fm_solve = 1; a.fm_frames = c->frames; a.fm_e_out = fm_slot; a.fm_e_key = fm_key;
+                a.fm_solve = 1; a.fm_frames = c->frames; a.fm_led_light = c->led_light; a.fm_e_out = fm_slot; a.fm_e_key = fm_key;
                 if (xf) { a.xf = c->xf_table; a.xf_epoch = ++c->xf_epoch; }
                 a.fm_undo = (block == PSGSDF_LIGHT && c->spec_undo) ? (float*)c->frames_undo : nullptr;
             }

@@ -320,6 +320,35 @@ __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, i
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x == 0) __hip_atomic_store(a.acc.fdone + a.F, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (KIND == 0 && ModelTraits<MODEL>::LED) {
+        // LED: ONE light vector over all frames (LedOptimizer.cpp:128-160): this workgroup is the last of the whole sweep, every frame's final row is
+        // in place and no workgroup reads a frame record any more -- k_solve_light's arithmetic (sums over the frames in frame order, three
+        // scalar equations, every frame's copy updated), thread 0 solving, all threads updating
+        constexpr int NHL = 3;
+        __shared__ float s_dl[3];
+        if (a.fm_undo) {
+            for (int i = threadIdx.x; i < a.F * 9; i += blockDim.x) a.fm_undo[i] = a.fm_frames[i / 9].l[i % 9];
+            if (threadIdx.x < 3) a.fm_undo[a.F * 9 + threadIdx.x] = a.fm_led_light[threadIdx.x];
+        }
+        __shared__ double srow[6 * kMaxFramesLds];      // the six columns staged by all threads at once (summed straight from memory: 2 x F dependent loads per thread)
+        for (int i = threadIdx.x; i < 6 * a.F; i += blockDim.x) { const int ff = i / 6, c6 = i % 6; srow[c6 * kMaxFramesLds + ff] = __hip_atomic_load(a.acc.frame + (size_t)ff * kFrameRow + (c6 < 3 ? c6 : NHL + c6 - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int ch = threadIdx.x;
+            double hs = 0, bs = 0;
+            for (int ff = 0; ff < a.F; ++ff) { hs += srow[ch * kMaxFramesLds + ff]; bs += srow[(3 + ch) * kMaxFramesLds + ff]; }
+            float h = (float)hs; const float bb = (float)bs;
+            if (a.damping != 0.0f) h += a.damping * h;
+            double Hd[1] = {(double)h}, bd[1] = {(double)bb}, xd[1];
+            solve_spd<1>(Hd, bd, xd);
+            s_dl[ch] = (float)xd[0];
+        }
+        __syncthreads();
+        for (int ff = threadIdx.x; ff < a.F; ff += blockDim.x) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { const float nl = a.fm_frames[ff].l[ch] - s_dl[ch]; a.fm_frames[ff].l[ch] = nl; if (ff == 0) a.fm_led_light[ch] = nl; }
+        }
+    }
     if (a.fm_e_out) {      // energy / n_obs over the frames, in frame_rows_finish's order (one 256-thread workgroup, threads striding the frames)
         constexpr int col_e = NV - 2;
         double e = 0, n = 0;
