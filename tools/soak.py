@@ -31,6 +31,7 @@ VARIANTS = {
     "pipeline0": {"PSGSDF_PCG_PIPELINE": "0"},   # persistent kernel with the classic recurrences (same family as persist0)
     "prefetch0": {"PSGSDF_PCG_PREFETCH": "0"},   # pipelined solve: sums requested after the last gather batch
     "fmsolve0": {"PSGSDF_FM_SOLVE": "0"},        # light / pose solves as kernels of their own
+    "fmsolve2": {"PSGSDF_FM_SOLVE": "2"},        # ... only the LED light vector
     "xcdmap0": {"PSGSDF_XCD_MAP": "0"},          # physical workgroup ids (no XCD-contiguous mapping)
     "xcdmap7": {"PSGSDF_XCD_MAP": "7"},          # ... also for the distance sweep
     "xcdlocal0": {"PSGSDF_PCG_XCD_LOCAL": "0"},  # persistent solve: every record through memory instead of staying in the XCD's L2 where all its readers are
