@@ -35,6 +35,8 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_XF")) c->xf_enable = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XS")) c->xs_enable = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XH")) c->xh_enable = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_XWAIT_LOG2")) { const int l = atoi(e); if (l >= 8 && l <= 30) c->xwait_spins = 1 << l; }
+    if (const char* e = getenv("PSGSDF_FAULT_HALO")) c->fault_halo = atoll(e);
     if (const char* e = getenv("PSGSDF_IMG_COMPACT")) c->img_compact = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_SPECULATE_MR")) c->speculate_mr = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XCD_MAP")) c->xcd_map = atoi(e);

@@ -126,7 +126,7 @@ int comm_allreduce(psgsdf_ctx* c, double* buf, int n) {
 // in front of its push of n + 1, which this rank's pull of n + 1 -- in front of its push of n + 2 -- waits for).
 namespace {
 struct HaloSide { const unsigned* src; unsigned* dst; int rows; double* flag; };
-struct HaloArgs { HaloSide s[2]; int planes, width; long long plane_words; double tag; double* abort_flag; };
+struct HaloArgs { HaloSide s[2]; int planes, width; long long plane_words; double tag; double* abort_flag; int spin_max; };
 __global__ void __launch_bounds__(1024) k_halo_push(HaloArgs h) {
     const HaloSide& sd = h.s[blockIdx.x];
     if (sd.rows <= 0) return;
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(1024) k_halo_pull(HaloArgs h) {
     __shared__ int s_late;
     if (threadIdx.x == 0) {
         int spins = 0; s_late = 0;
-        while (__hip_atomic_load(sd.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != h.tag) { __builtin_amdgcn_s_sleep(2); if (++spins > (1 << 24)) { s_late = 1; break; } }
+        while (__hip_atomic_load(sd.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != h.tag) { __builtin_amdgcn_s_sleep(2); if (++spins > h.spin_max) { s_late = 1; break; } }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         if (s_late) __hip_atomic_store(h.abort_flag, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -166,7 +166,7 @@ int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
         const size_t pw = (size_t)width * c->band.Spad;
         HaloArgs push{}, pull{};
         push.planes = pull.planes = planes; push.width = pull.width = width; push.plane_words = pull.plane_words = (long long)pw; push.tag = pull.tag = (double)ep;
-        pull.abort_flag = push.abort_flag = c->xr + kXrAbort;
+        pull.abort_flag = push.abort_flag = c->xr + kXrAbort; pull.spin_max = push.spin_max = c->xwait_spins;
         unsigned* arr = (unsigned*)base;
         for (int sd = 0; sd < 2; ++sd) {
             const int nb = sd == 0 ? c->rank - 1 : c->rank + 1;
@@ -184,7 +184,8 @@ int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
                 pull.s[sd].flag = c->xr + c->hx_flag_off + par * 2 + sd;
             }
         }
-        hipLaunchKernelGGL(k_halo_push, dim3(2), dim3(1024), 0, c->stream, push);
+        if (!(c->fault_halo > 0 && ep == c->fault_halo))      // PSGSDF_FAULT_HALO=n: this rank's n-th exchange pushes nothing (the neighbours' bounded waits: tests)
+            hipLaunchKernelGGL(k_halo_push, dim3(2), dim3(1024), 0, c->stream, push);
         hipLaunchKernelGGL(k_halo_pull, dim3(2), dim3(1024), 0, c->stream, pull);
         c->n_halo_pushes++;
         return 0;
@@ -498,7 +499,7 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     // its contribution -- so no word of an earlier band or a raised abort flag survives into the solves of this one.)
     if (c->xr && hipMemsetAsync(c->xr, 0, sizeof(double) * c->xr_doubles, c->stream) != hipSuccess) ok = false;
     if (ok) {      // the frame rows' exchange table (the flags carry the exchange's number, which only grows: the zeroed region matches none)
-        XfTable t{}; t.n_ranks = R; t.rank = me; t.F = std::max(c->F, 1); t.pay = kXrDoubles; t.flg = (long long)kXrDoubles + (long long)frows * kFrameRow; t.spay = t.flg + (long long)frows; t.sflg = t.spay + (long long)2 * R * 8;
+        XfTable t{}; t.n_ranks = R; t.rank = me; t.F = std::max(c->F, 1); t.spin_max = c->xwait_spins; t.pay = kXrDoubles; t.flg = (long long)kXrDoubles + (long long)frows * kFrameRow; t.spay = t.flg + (long long)frows; t.sflg = t.spay + (long long)2 * R * 8;
         for (int r = 0; r < R; ++r) t.region[r] = c->xr_peer[r];
         if (!c->xf_table && hipMalloc(&c->xf_table, sizeof(XfTable)) != hipSuccess) ok = false;
         if (ok && hipMemcpyAsync(c->xf_table, &t, sizeof(t), hipMemcpyHostToDevice, c->stream) != hipSuccess) ok = false;

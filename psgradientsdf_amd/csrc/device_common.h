@@ -258,7 +258,7 @@ __device__ __forceinline__ void fold_exchange(const XfTable* xf, long long epoch
     bool late = false;
     for (int r = 0; r < Rk && !late; ++r) {
         int spins = 0;
-        while (__hip_atomic_load(mine + x.sflg + (long long)buf * Rk + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > (1 << 24)) { late = true; break; } }
+        while (__hip_atomic_load(mine + x.sflg + (long long)buf * Rk + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > x.spin_max) { late = true; break; } }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     for (int s = 0; s < n; ++s) {

@@ -186,7 +186,7 @@ struct XrArgs {
 // sweep's number; it then waits for the R flags of frame f in its OWN region and adds the R rows in rank order -- every rank holds the same global
 // row without a collective, and solves the frame on the spot as a single-rank context does.
 struct XfTable {
-    int n_ranks, rank, F, pad;
+    int n_ranks, rank, F, spin_max;  // spin_max: polls a wait inside a kernel may take before the peer counts as lost (2^24; PSGSDF_XWAIT_LOG2 for the failure tests)
     long long pay, flg;              // offsets (doubles) of the payload rows / the flags inside a region
     long long spay, sflg;            // scalar folds (FoldReq::xf): [2 buffers][R ranks][8 values] and [2][R] flags
     double* region[32];              // (= kXrMaxRanks) every rank's mailbox region, own included

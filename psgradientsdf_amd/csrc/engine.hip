@@ -89,7 +89,7 @@ int deliver_first(psgsdf_ctx* c, size_t count, bool told_landed) {
     }
     c->deferred.erase(c->deferred.begin(), c->deferred.begin() + (long)count);
     if (c->deferred.empty()) c->mbox_used = 0;      // (slots are handed out again only when nothing is in flight)
-    if (c->xf_timeout) { c->xf_timeout = false; return fail(c, PSGSDF_ERR_DEVICE, "a rank's per-frame rows never arrived in the in-sweep exchange (rank %d of %d)", c->rank, c->n_ranks); }
+    if (c->xf_timeout) { c->xf_timeout = false; return fail(c, PSGSDF_ERR_DEVICE, "rank %d of %d: NaN came back from an exchange between the ranks' kernels -- a peer's rows or sums never arrived within the bounded wait (or the state itself is NaN)", c->rank, c->n_ranks); }
     return 0;
 }
 int deliver(psgsdf_ctx* c) { return deliver_first(c, c->deferred.size(), true); }

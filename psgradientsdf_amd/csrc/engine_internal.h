@@ -140,6 +140,8 @@ struct psgsdf_ctx {
     bool fuse_pcg_init = true;           // PSGSDF_FUSE_PCG_INIT=0: separate k_cgf_init launch
     bool fuse_albedo = true;             // PSGSDF_FUSE_ALBEDO=0: separate k_apply_albedo launch
     bool fold_in_next = true;            // PSGSDF_FOLD_IN_NEXT=0: always a k_sum_parts launch
+    int xwait_spins = 1 << 24;           // polls of a wait inside a kernel for a peer's flag (PSGSDF_XWAIT_LOG2)
+    long long fault_halo = 0;            // PSGSDF_FAULT_HALO
     bool xh_enable = true;               // PSGSDF_XH=0: halo rows through RCCL send / recv (round 3)
     void* hx_mem = nullptr;              // halo staging the two neighbours push into (fine-grained, IPC-exported): [2 parities][lower | upper side]
     char* hx_peer[2] = {nullptr, nullptr};   // the neighbours' stagings (lower, upper), mapped

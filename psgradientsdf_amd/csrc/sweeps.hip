@@ -297,7 +297,7 @@ __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, i
             for (int r = 0; r < Rk && !late; ++r) {
                 const double* fp = mine + t.flg + ((long long)buf * Rk + r) * t.F + f;
                 int spins = 0;
-                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > (1 << 24)) { late = true; break; } }
+                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > t.spin_max) { late = true; break; } }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
             double tot = 0.0;

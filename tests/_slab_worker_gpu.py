@@ -19,6 +19,8 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
     model, _, opt = model.partition("+")
     if os.environ.get("SLAB_CU_MASKS"):      # two ranks on ONE GPU with disjoint halves of its CUs (the cross-rank persistent solve needs both kernels resident)
         os.environ["PSGSDF_CU_MASK"] = os.environ["SLAB_CU_MASKS"].split(",")[rank]
+    if os.environ.get("SLAB_FAULT_HALO") and rank == 1:      # this rank's n-th halo exchange pushes nothing (the neighbours' waits are bounded: tests)
+        os.environ["PSGSDF_FAULT_HALO"] = os.environ["SLAB_FAULT_HALO"]
     sc = synth.make_scene(N=N, F=5 if mode == "optimize" else 6, W=160, H=120, model=model)
     kw = {"reg_weight_rho": 0.02} if opt == "reg" else {}      # "+reg": the albedo regulariser ("reg albedo")
     if mode == "optimize":
