@@ -90,7 +90,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    hipFree(c->xr); hipFree(c->xf_table); hipFree(c->hx_mem);
+    hipFree(c->xr); hipFree(c->xf_table); hipFree(c->hx_mem); hipFree(c->vm_order);
     comm_destroy(c);
     hipFree(c->areg_mem); hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mbox_shadow); hipFree(c->d_need);
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);

@@ -230,6 +230,23 @@ __global__ void __launch_bounds__(kBlock) k_obs_count(Band b, int F, int row0, i
     __syncthreads();
     if (threadIdx.x == 0) { int s = 0; for (int i = 0; i < kBlock / 64; ++i) s += red[i]; counts[f * nch + blockIdx.x] = s; }
 }
+// work of a voxel-major block of kBlock rows = sum over its wavefronts of the LONGEST lane (a lane visits its visible frames one by one and the
+// wavefront lasts as long as its busiest lane): what the distance sweep's dispatch order is sorted by (engine.hip build_band)
+__global__ void __launch_bounds__(kBlock) k_block_work(Band b, int row0, int row1, int* __restrict__ work) {
+    __shared__ int red[kBlock / 64];
+    const int j = row0 + blockIdx.x * kBlock + threadIdx.x;
+    int n = 0;
+    if (j < row1) for (int w = 0; w < b.KW; ++w) n += __popcll(b.vis[(size_t)w * b.Spad + j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n = max(n, __shfl_down(n, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) { int s = 0; for (int i = 0; i < kBlock / 64; ++i) s += red[i]; work[blockIdx.x] = s; }
+}
+void launch_block_work(const Band& b, int row0, int row1, int* work, hipStream_t s) {
+    const int nb = (row1 - row0 + kBlock - 1) / kBlock;
+    if (nb > 0) hipLaunchKernelGGL(k_block_work, dim3(nb), dim3(kBlock), 0, s, b, row0, row1, work);
+}
 void launch_obs_count(const Band& b, int F, int row0, int row1, int* counts, hipStream_t s) {
     int nch = (row1 - row0 + kObsChunk - 1) / kObsChunk;
     if (nch > 0 && F > 0) hipLaunchKernelGGL(k_obs_count, dim3(nch, F), dim3(kBlock), 0, s, b, F, row0, row1, counts);

@@ -226,7 +226,9 @@ __device__ __forceinline__ unsigned xcd_remap_striped(unsigned pid, unsigned G, 
     const unsigned x = pid & 7u, s = pid >> 3;
     return ((s / T) * 8u + x) * T + s % T;
 }
-__device__ __forceinline__ int vm_bid(const SweepArgs& a, int bit = 2) {
+__device__ __forceinline__ int vm_bid(const SweepArgs& a, int bit = 2, bool per_obs = false) {
+    if (bit == 4 && (a.xcd_map & 32) && a.vm_order) return a.vm_order[blockIdx.x];      // distance sweep: heaviest blocks first (longest-processing-time order: a shorter tail)
+    if (per_obs && (a.xcd_map & 64) && a.vm_order) return a.vm_order[blockIdx.x];       // (the other per-observation voxel-major kernels: albedo sweep, energy)
     if (!(a.xcd_map & bit)) return (int)blockIdx.x;
     const unsigned T = (unsigned)a.xcd_map >> 8;
     return T ? (int)xcd_remap_striped(blockIdx.x, gridDim.x, T) : (int)xcd_remap(blockIdx.x, gridDim.x);

@@ -149,6 +149,7 @@ struct SweepArgs {
     int pcg_fuse_init;        // assembly kernel also initialises the PCG (x = 0, records of pass -1, |b|^2 partials): no k_cgf_init launch
     int pcg_init_blocks;      // workgroups that wrote the |b|^2 partials (0: the pass kernel's own grid)
     int fuse_apply;           // albedo sweep: solve the voxel's diagonal system and apply the update in the same thread (no normal equations stored); 2: and keep the old albedo for an undo
+    const int* vm_order;      // voxel-major dispatch order of the distance sweep: physical workgroup -> logical block, heaviest first (nullptr: identity)
     float* fm_led_light;      // fm_solve, LED: the light vector [3] next to the frames' copies (updated by the sweep's last workgroup)
     const XfTable* xf;        // multi-rank: the frame rows travel through the ranks' mailbox regions (nullptr: single rank / RCCL all-reduce path)
     long long xf_epoch;       // number of this exchange (flag value; its parity selects the buffer)
@@ -207,6 +208,7 @@ void launch_band_scatter(const DenseView& d, Band b, hipStream_t s);
 void launch_derive(const SweepArgs& a, int update_grad, hipStream_t s);
 constexpr int kObsChunk = 2048;      // rows per workgroup of the observation-list builders
 void launch_obs_count(const Band& b, int F, int row0, int row1, int* counts, hipStream_t s);       // counts[F][nch]
+void launch_block_work(const Band& b, int row0, int row1, int* work, hipStream_t s);   // work[block of kBlock owned rows] = sum over its wavefronts of the busiest lane's visible frames
 void launch_obs_fill(const Band& b, int F, int row0, int row1, const int* offsets, hipStream_t s); // offsets[F][nch] -> b.obs_rows
 void launch_lower_bound(const int* lin, int S, int target, int* out, hipStream_t s);               // *out = number of band rows with lin < target (lin ascending)
 struct SlotList { int n; int id[8]; };

@@ -41,7 +41,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.acc.frame = c->acc_frame; a.acc.part = c->part; a.acc.PB = c->PB;
     a.acc.fpart = c->frame_part; a.acc.fcap = c->frame_cap; a.acc.fdone = c->frame_done;
     a.fold.n = 0; a.gate = nullptr; a.fuse_apply = 0;
-    a.xcd_map = c->xcd_map; a.xf = nullptr; a.xf_epoch = 0; a.fm_led_light = nullptr;
+    a.xcd_map = c->xcd_map; a.xf = nullptr; a.xf_epoch = 0; a.fm_led_light = nullptr; a.vm_order = c->vm_order;
     a.fm_solve = 0; a.fm_frames = nullptr; a.fm_undo = nullptr; a.fm_e_out = nullptr; a.fm_e_key = 0;
     a.pcg_part = c->pcg_part; a.pcg_fs = c->pcg_sc; a.pcg_fuse_init = 0; a.pcg_init_blocks = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.pcg_asm = 0; a.pcg_pipe = c->pcg_pipeline ? 1 : 0; a.pcg_apply = 0; a.pcg_xcd_local = (c->pcg_xcd_local ? 1 : 0) | (c->pcg_prefetch ? 2 : 0) | (c->pcg_ablate << 3);
     a.ar = c->ar; a.ar.weight = c->reg_r;
@@ -369,6 +369,25 @@ int build_band(psgsdf_ctx* c) {
             launch_obs_fill(b, F, c->row0, c->row1, d_counts, c->stream);
             HIPCHK(c, hipStreamSynchronize(c->stream));
             hipFree(d_counts);
+        }
+    }
+    {   // dispatch order of the voxel-major distance sweep: blocks sorted by their work, heaviest first (the sweep needs 1.3 generations of resident
+        // workgroups: what is dispatched last should be short).  Logical ids carry rows and partial-sum slots: results do not depend on the order.
+        if (c->vm_order) { hipFree(c->vm_order); c->vm_order = nullptr; }
+        const int nb = (c->row1 - c->row0 + kBlock - 1) / kBlock;
+        if (nb > 1) {
+            int* d_work = nullptr;
+            HIPCHK(c, hipMalloc(&d_work, sizeof(int) * nb));
+            launch_block_work(b, c->row0, c->row1, d_work, c->stream);
+            std::vector<int> work(nb), order(nb);
+            HIPCHK(c, hipMemcpyAsync(work.data(), d_work, sizeof(int) * nb, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int i = 0; i < nb; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return work[x] > work[y]; });
+            HIPCHK(c, hipMalloc(&c->vm_order, sizeof(int) * nb));
+            HIPCHK(c, hipMemcpyAsync(c->vm_order, order.data(), sizeof(int) * nb, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(d_work);
         }
     }
     // a slab without a single observation launches no frame-major sweep and could not deliver its rows to the other ranks from inside one (loop.hip

@@ -159,7 +159,8 @@ struct psgsdf_ctx {
     bool img_compact = true;             // PSGSDF_IMG_COMPACT=0: float keyframes stay float even when every value is (float)byte / 255
     bool img_compacted = false;          // the float keyframes of this context are held as RGBA8 words
     bool speculate_mr = true;            // PSGSDF_SPECULATE_MR=0: no speculative start of the next iteration on multi-rank contexts (round 3's loop)
-    int xcd_map = 3;                     // PSGSDF_XCD_MAP: XCD-contiguous logical workgroup ids in bit 0 the frame-major sweeps, bit 1 k_sweep_albedo / k_energy / k_derive, bit 2 k_sweep_dist (off: 68 -> 76 us, its VALU-bound workgroups want the round-robin's load mix); PSGSDF_XCD_STRIPE=T: stripes of T ids instead of eighths
+    int* vm_order = nullptr;             // distance sweep: physical workgroup -> logical block, heaviest first (build_band)
+    int xcd_map = 35;                    // PSGSDF_XCD_MAP: logical workgroup ids -- bit 0 frame-major sweeps XCD-contiguous, bit 1 k_sweep_albedo / k_energy / k_derive XCD-contiguous, bit 2 k_sweep_dist XCD-contiguous (off: 68 -> 76 us), bit 5 (32) k_sweep_dist heaviest block first (70 -> 62 us), bit 6 (64) albedo / energy heaviest first (no gain); PSGSDF_XCD_STRIPE=T: stripes of T ids instead of eighths
     bool fm_solve = true;                // PSGSDF_FM_SOLVE=0: k_solve_light / k_solve_pose as kernels of their own behind the frame-major sweeps
     bool fm_solve_led = true;            // ... also the LED light vector (by the sweep's very last workgroup); PSGSDF_FM_SOLVE=2 keeps k_solve_light for it
     bool fm_solved = false;              // the sweep just launched solves its frames itself (step_begin -> step_finish)

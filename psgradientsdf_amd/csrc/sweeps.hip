@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
     __shared__ double red[kBlock / 64];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
-    const int bid = vm_bid(a);
+    const int bid = vm_bid(a, 2, true);
     int j = a.row0 + bid * blockDim.x + threadIdx.x;
     double E = 0, nobs = 0, sI[3] = {0, 0, 0}, sR[3] = {0, 0, 0};
     float Ef = 0.f;
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
     __shared__ double red[kBlock / 64];
     load_frames(sf, a.frames, a.F);
     const Band& b = a.b;
-    const int bid = vm_bid(a);
+    const int bid = vm_bid(a, 2, true);
     int j = a.row0 + bid * blockDim.x + threadIdx.x;
     double E = 0, nobs = 0, cnt = 0;
     if (j < a.row1) {

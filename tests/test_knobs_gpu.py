@@ -42,7 +42,7 @@ def test_host_side_knobs_are_bitwise_neutral(built, model):
     ref = run(model, {}, full=True)
     for env in ({"PSGSDF_PCG_POLL": "0"}, {"PSGSDF_FOLD_IN_NEXT": "0"}, {"PSGSDF_PCG_POLL": "0", "PSGSDF_FOLD_IN_NEXT": "0"},
                 {"PSGSDF_FUSE_ALBEDO": "0"}, {"PSGSDF_SPECULATE": "0"}, {"PSGSDF_SPECULATE": "0", "PSGSDF_FUSE_ALBEDO": "0"},
-                {"PSGSDF_XCD_MAP": "0"}, {"PSGSDF_XCD_MAP": "7"}, {"PSGSDF_XCD_MAP": "7", "PSGSDF_XCD_STRIPE": "4"},   # which workgroup does which rows: logical ids carry rows AND partial-sum slots
+                {"PSGSDF_XCD_MAP": "0"}, {"PSGSDF_XCD_MAP": "3"}, {"PSGSDF_XCD_MAP": "99"}, {"PSGSDF_XCD_MAP": "7"}, {"PSGSDF_XCD_MAP": "7", "PSGSDF_XCD_STRIPE": "4"},   # which workgroup does which rows: logical ids carry rows AND partial-sum slots
                 {"PSGSDF_FM_SOLVE": "2"}, {"PSGSDF_FM_SOLVE": "2", "PSGSDF_SPECULATE": "0"},      # 2: only the LED light vector keeps its solve kernel
                 {"PSGSDF_FM_SOLVE": "0"}, {"PSGSDF_FM_SOLVE": "0", "PSGSDF_SPECULATE": "0"}):      # FM_SOLVE=0: the per-frame light / pose solves as kernels of their own instead of in the sweeps' last workgroups
         got = run(model, env, full=True)

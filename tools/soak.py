@@ -34,6 +34,7 @@ VARIANTS = {
     "fmsolve2": {"PSGSDF_FM_SOLVE": "2"},        # ... only the LED light vector
     "xcdmap0": {"PSGSDF_XCD_MAP": "0"},          # physical workgroup ids (no XCD-contiguous mapping)
     "xcdmap7": {"PSGSDF_XCD_MAP": "7"},          # ... also for the distance sweep
+    "xcdmap99": {"PSGSDF_XCD_MAP": "99"},        # heaviest-first dispatch for every per-observation voxel-major kernel
     "xcdlocal0": {"PSGSDF_PCG_XCD_LOCAL": "0"},  # persistent solve: every record through memory instead of staying in the XCD's L2 where all its readers are
     "spec0": {"PSGSDF_SPECULATE": "0"},          # every iteration closed before the next one starts (round 2)
     "nocheck": {"PSGSDF_MBOX_CHECK": "0"},      # read-backs taken on the marker's say-so (round 2): expected to deviate now and then
