@@ -51,6 +51,10 @@ class IterStats(C.Structure):
         d["e_after"] = list(self.e_after)
         return d
 
+    def __getitem__(self, k):      # (a record reads like its dict: the passive observer hands out struct copies, not dicts -- it runs between two launches)
+        v = getattr(self, k)
+        return list(v) if k == "e_after" else v
+
 
 class Info(C.Structure):
     _fields_ = [("dim", C.c_int32 * 3), ("voxel_size", C.c_float), ("origin", C.c_float * 3), ("n_frames", C.c_int32),
@@ -278,13 +282,13 @@ class Api:
         self._check(self._fn("set_on_iter_period")(self.ctx, C.c_int(period)), "set_on_iter_period")
 
     def set_record_observer(self, fn):
-        """fn(iterations_done, record_dict) -> truthy ends the loop; passive (psgsdf_set_record_observer): must not call into the engine"""
+        """fn(iterations_done, record) -> truthy ends the loop (record: an IterStats copy, rec["e_total"] / rec.as_dict()); passive (psgsdf_set_record_observer): must not call into the engine"""
         if fn is None:
             self._observer = None
             self._check(self._fn("set_record_observer")(self.ctx, None, None), "set_record_observer")
             return
         CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(IterStats))
-        self._observer = CB(lambda user, done, rec: 1 if fn(done, rec.contents.as_dict()) else 0)
+        self._observer = CB(lambda user, done, rec: 1 if fn(done, IterStats.from_buffer_copy(rec.contents)) else 0)      # (a 120-byte copy, fields read on demand: the callback sits on the loop's critical path)
         self._check(self._fn("set_record_observer")(self.ctx, self._observer, None), "set_record_observer")
 
     def upsample2x(self):
