@@ -167,7 +167,7 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
     planes_of = None
     t_gen = time.time()
     use_u8 = args.u8_images
-    scene_kw = dict(N=args.grid, F=args.frames, W=args.width, H=args.height, model=model, u8=use_u8)
+    scene_kw = dict(N=args.grid, F=args.frames, W=args.width, H=args.height, model=model, u8=use_u8 or getattr(args, "u8_scene", False))      # (u8_scene: keyframes quantised to 8 bits but handed over as FLOATS, as the reference's loader does)
     if args.strong:
         # ONE volume for all ranks; a rank renders the keyframes (every rank needs all of them) and synthesises only the planes it is asked for:
         # first its share of the planes for the cut negotiation, then its own slab + halo planes (capi.load_scene_slab)
@@ -553,6 +553,14 @@ def main():
                           "band_voxels": e["S"], "observations": e["n_obs"], "pcg_iters_per_step": e["cg_iters"],
                           "settings": "config_basket_LED.json (damping 3, reg 0.1 / 5)" if mod == "LED" else "config_skorates.json"}
             del e
+        # the headline scene with keyframes that are 8-bit data handed over as floats -- what the reference's main() gives its optimiser after
+        # imread + convertTo(CV_32FC3, 1/255): the engine recognises them and samples RGBA8 words (same floats, half the tap instructions)
+        args.u8_scene = True
+        e = measure(args, "SH1", torch, dist, rank, world, device, slab, share, headline=False)
+        args.u8_scene = False
+        extra["SH1_png_like_float_keyframes"] = {"value": e["value"], "unit": "it/s", "ms_per_step": e["ms_per_step"],
+                                                 "note": "keyframes quantised to 8 bits, passed through psgsdf_set_keyframes (float); held as RGBA8 words (PSGSDF_IMG_COMPACT)"}
+        del e
         if rank == 0:
             out["extra"] = extra
     if rank == 0:
