@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main(rank, world, port, model, out, n_iters, N, transport, mode):
-    faulthandler.dump_traceback_later(110, exit=True)
+    faulthandler.dump_traceback_later(int(os.environ.get("SLAB_WORKER_TIMEOUT", "110")), exit=True)
     import torch
     from psgradientsdf_amd import capi, synth
     torch.cuda.set_device(0)
@@ -21,7 +21,9 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
         os.environ["PSGSDF_CU_MASK"] = os.environ["SLAB_CU_MASKS"].split(",")[rank]
     if os.environ.get("SLAB_FAULT_HALO") and rank == 1:      # this rank's n-th halo exchange pushes nothing (the neighbours' waits are bounded: tests)
         os.environ["PSGSDF_FAULT_HALO"] = os.environ["SLAB_FAULT_HALO"]
-    sc = synth.make_scene(N=N, F=5 if mode == "optimize" else 6, W=160, H=120, model=model)
+    # SLAB_FRAMES=F[:W:H]: another keyframe count (> 64: two visibility words per voxel) / image size than the default scene of these tests
+    fr = [int(x) for x in os.environ.get("SLAB_FRAMES", "").split(":") if x]
+    sc = synth.make_scene(N=N, F=fr[0] if fr else (5 if mode == "optimize" else 6), W=fr[1] if len(fr) > 1 else 160, H=fr[2] if len(fr) > 2 else 120, model=model)
     kw = {"reg_weight_rho": 0.02} if opt == "reg" else {}      # "+reg": the albedo regulariser ("reg albedo")
     if mode == "optimize":
         kw.update(upsample=1, max_it=n_iters, conv_threshold=0.0, damping=10.0)      # through the 2x refinement after iteration 5 (tests/test_parity_gpu.py test_optimize_matches_oracle's recipe)

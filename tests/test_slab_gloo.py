@@ -17,10 +17,12 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("model,world", [("SH1", 2), ("LED", 2), ("SH2", 3)])
-def test_slab_runs_match_single_rank(built, tmp_path, model, world):
+# world 8 = the machine BASELINE.json names (8 x MI355X): seven inner cut planes, band-count cuts over eight slabs, rank-order sums over eight
+# contributions; at 32^3 the slabs are 2-6 planes thick, i.e. some are thinner than the three planes a stencil spans
+@pytest.mark.parametrize("model,world,N", [("SH1", 2, 32), ("LED", 2, 32), ("SH2", 3, 32), ("SH1", 8, 32), ("SH2", 8, 48), ("LED", 8, 40)])
+def test_slab_runs_match_single_rank(built, tmp_path, model, world, N):
     from oracle import oracle
-    N, n_iters = 32, 2
+    n_iters = 2
     port = free_port()
     out = str(tmp_path / "slab")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_slab_worker.py"), str(r), str(world), str(port), model, out, str(n_iters), str(N)],

@@ -21,14 +21,14 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def run_ranks(tmp_path, model, world, transport, mode, N, n_iters, extra_env=None):
+def run_ranks(tmp_path, model, world, transport, mode, N, n_iters, extra_env=None, timeout=150):
     port = free_port(); out = str(tmp_path / "slab")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SLAB_WORKER_TIMEOUT=str(timeout - 40), **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_slab_worker_gpu.py"), str(r), str(world), str(port), model, out, str(n_iters), str(N), transport, mode],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
     try:
         for p in procs:
-            o, _ = p.communicate(timeout=150)
+            o, _ = p.communicate(timeout=timeout)
             assert p.returncode == 0, o[-3000:]
     finally:
         for p in procs:      # a rank that is still alive here would keep the GPU (and the next test) busy
@@ -301,3 +301,57 @@ def test_cross_rank_persistent_solve_on_disjoint_cu_halves(built, tmp_path, mask
         assert np.all(np.abs(got["cg"] - np.array([x["cg_iters"] for x in recs])) <= 1)
     d = stitch(res, "dist")
     assert np.abs(d[band] - v["dist"][band]).max() <= 1e-4 * vs
+
+
+EIGHTHS = ",".join(f"{32 * i}:{32 * i + 32}" for i in range(8))
+
+
+@pytest.mark.parametrize("model,N,frames,mode", [("SH1", 96, None, "iterate"), ("SH2", 64, "70:96:72", "iterate"), ("LED", 64, None, "iterate"), ("SH1", 24, None, "iterate"), ("SH1", 24, None, "optimize")])
+def test_eight_ranks_on_cu_eighths(built, margins, tmp_path, model, N, frames, mode):
+    """WORLD SIZE 8 -- the machine BASELINE.json names -- rehearsed on the one-GPU box: eight processes, each confined to an eighth
+    of the CUs (PSGSDF_CU_MASK=0:32, 32:64, ...), so that the eight persistent solve kernels are resident together while they exchange halo records,
+    rank granules, frame rows and scalar folds through IPC-mapped memory.  Seven inner cut planes, band-count cuts over eight slabs, rank-order sums
+    over eight granules, the hand-off probe over seven neighbour pairs.  SH2 with 70 keyframes: TWO visibility words per voxel in slab mode
+    (configs[4]'s layout); N = 24: slabs of one or two planes -- thinner than the three planes a stencil spans, a rank's two halo planes belong to
+    ranks that are its neighbours' neighbours' neighbours in the band; "optimize": the product loop through the 2x refinement with the speculative
+    start.  All against the single context: every band voxel within 1e-4 voxel, cross-rank solves on every rank, NO fallback."""
+    n_iters = 18 if mode == "optimize" else 2
+    env = {"SLAB_CU_MASKS": EIGHTHS}
+    if frames:
+        env["SLAB_FRAMES"] = frames
+    res = run_ranks(tmp_path, model, 8, "gloo", mode, N, n_iters, env, timeout=280)
+    fr = [int(x) for x in frames.split(":")] if frames else []
+    sc = synth.make_scene(N=N, F=fr[0] if fr else (5 if mode == "optimize" else 6), W=fr[1] if fr else 160, H=fr[2] if fr else 120, model=model)
+    kw = dict(upsample=1, max_it=n_iters, conv_threshold=0.0, damping=10.0) if mode == "optimize" else {}
+    st = capi.default_settings(sc.model_id, **kw)
+    ref = capi.load_engine(sc, sc.K, st, 0); ref.load_scene(sc)
+    ref.init_albedo(); e0 = ref.normalize_weights()
+    if mode == "optimize":
+        recs, conv = ref.optimize(capi.ALL)
+    else:
+        recs = ref.iterate(capi.ALL, n_iters)
+    band = ref.download_band(); v = ref.download_volume(); vs = float(ref.info().voxel_size)
+    if frames:
+        assert sc.vis_words == 2
+    planes = []
+    for got in res:
+        xr_ready, xr_solves, fallbacks, mem_kind, probe_stale, probe_to = (int(x) for x in got["xr"])
+        assert xr_ready == 1 and xr_solves >= 1 and fallbacks == 0, (xr_ready, xr_solves, fallbacks)
+        assert mem_kind == 1 and probe_stale == 0 and probe_to == 0
+        assert len(got["e_total"]) == len(recs)
+        assert np.allclose(got["e_total"], [x["e_total"] for x in recs], rtol=2e-4 if model == "SH2" else 2e-5 if mode == "optimize" else 5e-6)
+        assert np.all(np.abs(got["cg"] - np.array([x["cg_iters"] for x in recs])) <= 1)
+        assert np.abs(got["poses"] - ref.download_poses()).max() <= (2e-5 if model == "SH2" else 2e-6)
+        planes.append(int(got["info"][7]) - int(got["info"][6]))
+    cuts = [(int(g["info"][6]), int(g["info"][7])) for g in res]
+    nz = int(ref.info().dim[2])
+    assert cuts[0][0] == 0 and cuts[-1][1] == nz and all(cuts[i][1] == cuts[i + 1][0] for i in range(7)) and min(planes) >= 1
+    if N == 24 and mode == "iterate":
+        assert min(planes) <= 2, planes              # a slab thinner than a stencil
+    assert np.array_equal(np.concatenate([g["band"] for g in res]), band)
+    d = stitch(res, "dist"); rgb = stitch(res, "rgb")
+    m = {"dist_max_vs": float(np.abs(d[band] - v["dist"][band]).max() / vs), "rgb_max": float(np.abs(rgb[:, band] - v["rgb"][:, band]).max()), "planes_per_rank": planes,
+         "band_rows_per_rank": [int(g["info"][1] - g["info"][0]) for g in res], "cross_rank_solves": [int(g["xr"][1]) for g in res]}
+    margins(eight_ranks_vs_single=m, tolerance={"dist_max_vs": 1e-4})
+    assert m["dist_max_vs"] <= 1e-4
+    assert m["rgb_max"] <= (1e-2 if model == "SH2" else 2e-4)
