@@ -17,10 +17,12 @@ is reported next to it (`iterate_ms_per_step`).  The LED (configs[3]) and SH2 wo
 non-zero (PSGSDF_BENCH_SHARE_GPU=1: all ranks on GPU 0 over the gloo test transport -- a functional check, not a measurement).  The line never
 reports an n_gpus other than --gpus.  `value` is the MEDIAN over R repetitions of the K-step bracket (fresh contexts each), `spread` their min / max.
 
-N > 1: weak scaling over z-slabs.  The grid grows to 256 x 256 x (256*N) -- N copies of the scene stacked
-along z, each with its own 50 keyframes -- one process per GPU owns one slab and calls the SAME psgsdf_iterate: the engine's C++ host
-exchanges halos / all-reduces over its own RCCL communicator (comm.hip).  Python only launches the ranks, hands the RCCL id around and
-takes the time.  value = N * it/s of the whole job (256^3 x 50-frame equivalents per second).
+N > 1: `value` = STRONG scaling of the metric's own problem -- the ONE 256^3 volume with its 50 keyframes cut into N z-slabs of equal
+band count, one process per GPU, every rank synthesising and uploading only its own planes -- it/s of that one job (`scaling: "strong"`).  The
+same line carries, as `extra`, the weak-scaling run (`extra.weak`: N copies of the scene stacked along z, 50*N keyframes, N x it/s -- round 4's
+default, `--weak` makes it `value` again) and BASELINE configs[4] (`extra.configs4_strong`: 512^3, SH2, 100 keyframes cut into N slabs; `--strong`
+alone makes it `value`), each with its own pre-timing self-check and `degraded` flag.  The engine's C++ host runs the slab loop natively; Python only
+launches the ranks, hands the RCCL id around and takes the time.
 """
 from __future__ import annotations
 
@@ -136,11 +138,13 @@ def attach_comm(eng, dist, rank, world, share):
         eng.comm_init(rank, world, ident[0])
 
 
-def self_check(dist, rank, world, device, share):
-    """Before anything is timed on N > 1 ranks: the N-rank slab run against a single-context run of the same small scene (64^3, 8 keyframes, SH1,
-    two iterations) on this rank's own device -- e_total to 1e-5 relative.  A wrong exchange shows here, not as a fast wrong number."""
-    sc = synth.make_scene(N=64, F=8, W=160, H=120, model="SH1")
-    st = capi.default_settings(capi.SH1)
+def self_check(dist, rank, world, device, share, model="SH1", F=8):
+    """Before anything is timed on N > 1 ranks: the N-rank slab run against a single-context run of the same small scene (64^3, two iterations;
+    SH1 with 8 keyframes for the 256^3 workloads, SH2 with 70 keyframes -- two visibility words per voxel -- for configs[4]) on this rank's own
+    device -- e_total to 1e-5 relative (SH2: 2e-4, the float32 9x9 light blocks).  A wrong exchange shows here, not as a fast wrong number."""
+    sc = synth.make_scene(N=64, F=F, W=160 if F <= 16 else 96, H=120 if F <= 16 else 72, model=model)
+    st = capi.default_settings(synth.MODELS[model])
+    tol = 2e-4 if model == "SH2" else 1e-5
     eng = capi.load_engine(sc, sc.K, st, device)
     attach_comm(eng, dist, rank, world, share)
     eng.load_scene_slab(sc, rank, world)
@@ -155,7 +159,7 @@ def self_check(dist, rank, world, device, share):
     worst = [None] * world
     dist.all_gather_object(worst, rel)
     rel = max(worst)
-    return {"scene": "64^3 x 8 keyframes, SH1, 2 iterations", "e_total_ranks": e_n, "e_total_single": e_1, "rel_diff": rel, "tol": 1e-5, "ok": bool(rel <= 1e-5)}
+    return {"scene": f"64^3 x {F} keyframes, {model}, 2 iterations", "e_total_ranks": e_n, "e_total_single": e_1, "rel_diff": rel, "tol": tol, "ok": bool(rel <= tol)}
 
 
 STATE_STATS = ("cross_rank_ready", "cross_rank_mem_kind")      # states, not counters: never summed over contexts
@@ -220,6 +224,7 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
             own_rows = [int(x) for x in gathered]
     eng.iterate(capi.ALL, args.warmup)
     kernels, dom = {}, "sweep_dist"
+    nprof = 0
     if headline and not args.no_breakdown:
         # the dominant kernel (largest total time per iteration) from a short synchronous-event pass; THAT kernel is then timed inside the
         # timed region with HIP events recorded on the launch stream (no host sync)
@@ -304,8 +309,46 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
     res = dict(model=model, value=mult * args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps, spread=spread, loop=loop, S=int(S), n_obs=int(n_obs), cg_iters=cg_iters,
                iterate_ms_per_step=1e3 * t_iter / args.steps, optimize_ms_per_step=(1e3 * t_opt / args.steps) if t_opt else None,
                kernels=kernels, dom=dom, watched=watched, t_gen=t_gen, st=st, sc=sc, sync_stats=sync_stats,
-               collectives_per_step=(coll1 - coll0) / max(args.steps, 1), use_u8=use_u8, own_rows=own_rows)
+               collectives_per_step=(coll1 - coll0) / max(args.steps, 1), use_u8=use_u8, own_rows=own_rows,
+               e_iter=[float(r["e_total"]) for r in recs_it], iter_calls=[args.warmup, nprof, args.steps], scene_kw=scene_kw)
     return res
+
+
+def full_size_check(m, args, model, torch, dist, rank, world, device):
+    """The N-rank run of the PRIMARY workload against ONE context on the same scene at its full size: rank 0 synthesises the whole volume, replays
+    the psgsdf_iterate calls of the measurement (same split) on its own device and compares every e_total of the timed iterations with what the N
+    ranks reported (they all hold the same global energies).  After the timed region; the other ranks wait at the broadcast."""
+    res = [None]
+    if rank == 0:
+        sc = synth.make_scene(**m["scene_kw"])
+        eng = capi.load_engine(sc, sc.K, m["st"], device)
+        eng.load_scene(sc, u8=m["use_u8"])
+        eng.init_albedo(); eng.normalize_weights(); eng.step(capi.ALBEDO)
+        recs = []
+        for n in m["iter_calls"]:
+            recs = eng.iterate(capi.ALL, n) if n > 0 else recs
+        eng.close()
+        e1 = [float(r["e_total"]) for r in recs]
+        rel = max(abs(a - b) / abs(b) for a, b in zip(m["e_iter"], e1))
+        res = [{"scene": f"the measured one ({args.grid}^3 x {args.frames} keyframes, {model}), e_total of the {len(e1)} timed psgsdf_iterate iterations, {world} ranks vs one context on rank 0's device",
+                "rel_diff": rel, "tol": 1e-4, "ok": bool(rel <= 1e-4), "e_total_last_ranks": m["e_iter"][-1], "e_total_last_single": e1[-1]}]
+    dist.broadcast_object_list(res, src=0)
+    return res[0]
+
+
+def multi_gpu_block(m, check, world, share):
+    """the multi-GPU fields of one workload + its `degraded` flag (the cross-rank persistent solve is off or fell back, or a self-check failed)"""
+    ss = m["sync_stats"]
+    kinds = {-1: "not probed", 0: "none (cross-rank solve off)", 1: "fine-grained", 2: "uncached", 3: "coarse (pinned)"}
+    blk = {"ranks": world, "transport": "gloo test transport, all ranks on GPU 0 (functional check only)" if share else "rccl", "rccl_ranks": 0 if share else world,
+           "cross_rank_ready": int(ss["cross_rank_ready"]), "cross_rank_solves": int(ss["cross_rank_solves"]), "persist_fallbacks": int(ss["persist_fallbacks"]),
+           "hand_off_memory": kinds.get(int(ss["cross_rank_mem_kind"]), "?"), "probe_stale_records": int(ss["probe_stale"]), "probe_timeouts": int(ss["probe_timeouts"]),
+           "collectives_per_step": m["collectives_per_step"], "halo_exchanges_by_push_kernels": int(ss.get("halo_pushes", 0)),
+           "band_rows_per_rank": m["own_rows"],
+           "exchange": "inside the kernels through IPC-mapped peer memory (distance solve, per-frame rows, scalar folds, halo rows); collectives_per_step counts what still went through the communicator",
+           "self_check": check}
+    checks_ok = all(c["ok"] for c in (check if isinstance(check, list) else [check]) if c)
+    return blk, bool(not ss["cross_rank_ready"] or ss["persist_fallbacks"] > 0 or not checks_ok)
 
 
 def spawn_ranks(n):
@@ -368,10 +411,16 @@ def main():
     ap.add_argument("--force-slab", action="store_true", help="attach the single rank to a one-rank RCCL communicator (overhead of the multi-rank code path)")
     ap.add_argument("--no-extra", action="store_true", help="skip the LED / SH2 lines")
     ap.add_argument("--strong", action="store_true", help="strong scaling: ONE volume (default BASELINE configs[4]: 512^3, SH2, 100 keyframes) cut into --gpus z-slabs; every rank synthesises and uploads only its own planes")
+    ap.add_argument("--weak", action="store_true", help="N > 1: `value` = the weak-scaling run (N copies of the scene stacked along z, N x it/s: round 4's default) instead of the strong scaling of the one scene")
+    ap.add_argument("--configs4", default="512:100", help="grid:keyframes of the BASELINE configs[4] extra of the N > 1 line (SH2; tests pass a small one)")
     ap.add_argument("--loop", default="optimize", choices=["optimize", "iterate"], help="which loop `value` times (iterate: the round-2 figure, no stop decision)")
     args = ap.parse_args()
-    if args.strong and (args.grid, args.frames, args.model) == (256, 50, "SH1"):      # nothing chosen explicitly: BASELINE configs[4]
-        args.grid, args.frames, args.model = 512, 100, "SH2"
+    c4 = [int(x) for x in args.configs4.split(":")]
+    if args.strong and (args.grid, args.frames, args.model) == (256, 50, "SH1"):      # --strong and nothing chosen explicitly: BASELINE configs[4] is `value`
+        args.grid, args.frames, args.model = c4[0], c4[1], "SH2"
+    explicit_strong = args.strong
+    if args.gpus > 1 and not args.weak:      # the N > 1 line is the strong scaling of the metric's own problem
+        args.strong = True
 
     # ---- N ranks.  Under a launcher (torch.distributed.run: WORLD_SIZE set) this process IS one of the N ranks; without one, --gpus N > 1
     # starts the N ranks here.  Either way the line reports --gpus ranks or nothing.
@@ -404,6 +453,10 @@ def main():
         if share:
             local_rank = 0
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            # the ranks' persistent solve kernels wait for each other: on ONE device they are only resident together if each rank keeps to its
+            # own share of the CUs (PSGSDF_CU_MASK: the context's stream is created with that mask)
+            ncu = torch.cuda.get_device_properties(0).multi_processor_count
+            os.environ.setdefault("PSGSDF_CU_MASK", f"{rank * (ncu // world)}:{(rank + 1) * (ncu // world)}")
         torch.cuda.set_device(local_rank)
         if share:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -411,15 +464,18 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     device = local_rank if world > 1 else 0
 
-    check = self_check(dist, rank, world, device, share) if world > 1 else None
+    check = self_check(dist, rank, world, device, share, *(("SH2", 70) if args.model == "SH2" else ("SH1", 8))) if world > 1 else None
     m = measure(args, args.model, torch, dist, rank, world, device, slab, share, headline=True)
+    if world > 1 and args.strong and os.environ.get("PSGSDF_BENCH_NO_FULL_CHECK") != "1":
+        check = [check, full_size_check(m, args, args.model, torch, dist, rank, world, device)]
     S, n_obs, cg_iters, kernels, dom, watched, st, sc = m["S"], m["n_obs"], m["cg_iters"], m["kernels"], m["dom"], m["watched"], m["st"], m["sc"]
     use_u8 = m["use_u8"]
     out = {
-        "metric": "Gauss-Newton iterations/sec (full PS sweep), 256^3 grid x 50 frames" if (args.grid, args.frames) == (256, 50) and not args.strong
+        "metric": "Gauss-Newton iterations/sec (full PS sweep), 256^3 grid x 50 frames" if (args.grid, args.frames) == (256, 50)
         else f"Gauss-Newton iterations/sec (full PS sweep), {args.grid}^3 grid x {args.frames} frames",
         "value": m["value"], "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+        # (one GPU: the strong and the weak run are the same run; the N > 1 line is the strong scaling of this scene unless --weak)
+        "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (8-bit RGB keyframes)" if use_u8 else "synthetic",
         "config": {"workload": f"synthetic {args.width}x{args.height} RGB-D bumpy sphere, {args.grid}^3 grid, {args.model}, {args.frames} keyframes, "
                                "albedo+light+distance+pose blocks, Cauchy IRLS, Eikonal reg (config_skorates.json settings)",
@@ -434,16 +490,8 @@ def main():
         "spread": m["spread"],
     }
     if world > 1:
-        ss = m["sync_stats"]
-        kinds = {-1: "not probed", 0: "none (cross-rank solve off)", 1: "fine-grained", 2: "uncached", 3: "coarse (pinned)"}
-        out["multi_gpu"] = {"ranks": world, "transport": "gloo test transport, all ranks on GPU 0 (functional check only)" if share else "rccl", "rccl_ranks": 0 if share else world,
-                            "cross_rank_ready": int(ss["cross_rank_ready"]), "cross_rank_solves": int(ss["cross_rank_solves"]), "persist_fallbacks": int(ss["persist_fallbacks"]),
-                            "hand_off_memory": kinds.get(int(ss["cross_rank_mem_kind"]), "?"), "probe_stale_records": int(ss["probe_stale"]), "probe_timeouts": int(ss["probe_timeouts"]),
-                            "collectives_per_step": m["collectives_per_step"], "halo_exchanges_by_push_kernels": int(ss.get("halo_pushes", 0)),
-                            "exchange": "inside the kernels through IPC-mapped peer memory (distance solve, per-frame rows, scalar folds, halo rows); collectives_per_step counts what still went through the communicator",
-                            "self_check": check}
         # degraded: the line is not the design's N-GPU figure -- the cross-rank persistent solve is off or fell back, or the N-rank result is wrong
-        out["degraded"] = bool(not ss["cross_rank_ready"] or ss["persist_fallbacks"] > 0 or not check["ok"])
+        out["multi_gpu"], out["degraded"] = multi_gpu_block(m, check, world, share)
 
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live with HIP events inside the timed region
@@ -560,6 +608,29 @@ def main():
         args.u8_scene = False
         extra["SH1_png_like_float_keyframes"] = {"value": e["value"], "unit": "it/s", "ms_per_step": e["ms_per_step"],
                                                  "note": "keyframes quantised to 8 bits, passed through psgsdf_set_keyframes (float); held as RGBA8 words (PSGSDF_IMG_COMPACT)"}
+        del e
+        if rank == 0:
+            out["extra"] = extra
+    if world > 1 and not args.no_extra and not explicit_strong and not args.weak:
+        # ---- the other two N-rank workloads ride along, each with its own self-check and `degraded`
+        import copy
+        extra = {}
+        wk = copy.copy(args); wk.strong = False; wk.weak = True
+        e = measure(wk, args.model, torch, dist, rank, world, device, slab, share, headline=False)
+        blk, deg = multi_gpu_block(e, check[0] if isinstance(check, list) else check, world, share)
+        extra["weak"] = {"value": e["value"], "unit": "it/s", "ms_per_step": e["ms_per_step"], "scaling": "weak",
+                         "workload": f"{world} copies of the {args.grid}^3 scene stacked along z (grid {args.grid}x{args.grid}x{args.grid * world}), {args.frames * world} keyframes, one slab per GPU; value = {world} x it/s of the whole job ({args.grid}^3 x {args.frames}-frame equivalents per second)",
+                         "loop": e["loop"], "band_voxels_per_rank": e["S"], "pcg_iters_per_step": e["cg_iters"], "multi_gpu": blk, "degraded": deg}
+        del e
+        c4a = copy.copy(args); c4a.strong = True; c4a.grid, c4a.frames = c4[0], c4[1]
+        if (c4a.width, c4a.height) == (640, 480) and c4[0] < 256:      # (a small stand-in of the tests: small images too)
+            c4a.width, c4a.height = 96, 72
+        chk4 = self_check(dist, rank, world, device, share, "SH2", 70)
+        e = measure(c4a, "SH2", torch, dist, rank, world, device, slab, share, headline=False)
+        blk, deg = multi_gpu_block(e, chk4, world, share)
+        extra["configs4_strong"] = {"value": e["value"], "unit": "it/s", "ms_per_step": e["ms_per_step"], "scaling": "strong",
+                                    "workload": f"BASELINE configs[4]: ONE {c4[0]}^3 volume, SH2, {c4[1]} keyframes ({(c4[1] + 63) // 64} visibility word{'s' if c4[1] > 64 else ''} per voxel) cut into {world} z-slabs of equal band count",
+                                    "loop": e["loop"], "band_voxels_per_rank": e["S"], "pcg_iters_per_step": e["cg_iters"], "multi_gpu": blk, "degraded": deg}
         del e
         if rank == 0:
             out["extra"] = extra

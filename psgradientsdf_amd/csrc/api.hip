@@ -81,16 +81,24 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    xr_quiesce(c);      // multi-rank: every rank closes its mappings of the others' record planes / mailbox regions before anybody frees them (collective; psgsdf_destroy is called by all ranks)
+    // multi-rank: this rank closes its mappings of the others' record planes / mailbox regions (telling their owners) and frees what IT exported
+    // only once every rank that mapped it has reported the same -- bounded, and no collective: a rank that failed, left early or destroys its
+    // contexts in another order cannot hang this call.  If a peer never reports, the exported allocations are leaked instead of freed.
+    double qt = 15.0; if (const char* e = getenv("PSGSDF_DESTROY_TIMEOUT_S")) qt = atof(e);
+    if (xr_quiesce(c, qt)) {
+        c->leak_exported = true;
+        fprintf(stderr, "psgsdf: rank %d: a peer did not close its mappings of this rank's exchange memory within %.0f s (failed or still running?): that memory is leaked, not freed\n", c->rank, qt);
+    }
     free_dense(c);
     hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->frames_undo); hipFree(c->led_light);
-    hipFree(c->band_mem); hipFree(c->rec_mem); hipFree(c->obs_mem); hipFree(c->stage);
+    hipFree(c->band_mem); if (!c->leak_exported) hipFree(c->rec_mem); hipFree(c->obs_mem); hipFree(c->stage);
     hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->frame_part); hipFree(c->frame_done); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->pcg_gran); hipFree(c->d_total);
     if (c->host_buf) hipHostFree(c->host_buf);
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
     for (auto& pr : c->watch_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    hipFree(c->xr); hipFree(c->xf_table); hipFree(c->hx_mem); hipFree(c->vm_order);
+    if (!c->leak_exported) { hipFree(c->xr); hipFree(c->hx_mem); }
+    hipFree(c->xf_table); hipFree(c->vm_order);
     comm_destroy(c);
     hipFree(c->areg_mem); hipFree(c->mg_scal); hipFree(c->mg_ext); hipFree(c->mbox_shadow); hipFree(c->d_need);
     if (c->stream && c->own_stream) hipStreamDestroy(c->stream);

@@ -11,6 +11,7 @@
 // stencil-direction bits; before a 2x refinement, of albedo and gradient).
 #include "engine_internal.h"
 
+#include <chrono>
 #include <dlfcn.h>
 #include <unistd.h>
 #include <rccl/rccl.h>   // types and enum values only: every function is resolved with dlsym
@@ -129,7 +130,10 @@ struct HaloSide { const unsigned* src; unsigned* dst; int rows; double* flag; };
 struct HaloArgs { HaloSide s[2]; int planes, width; long long plane_words; double tag; double* abort_flag; int spin_max; };
 __global__ void __launch_bounds__(1024) k_halo_push(HaloArgs h) {
     const HaloSide& sd = h.s[blockIdx.x];
-    if (sd.rows <= 0) return;
+    if (!sd.flag) return;                      // (no neighbour on this side)
+    // a side with 0 rows still FLAGS: the neighbour's pull of exchange n + 1 is what orders its push of n + 2 behind this rank's pull of n, and
+    // that only holds if every pull waits for every existing neighbour -- whether or not rows travel in that direction (need[] is the
+    // band-row count of the adjacent plane and can be 0 on one side of a cut only)
     const int n = sd.rows * h.width;
     for (int p = 0; p < h.planes; ++p)
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -142,13 +146,13 @@ __global__ void __launch_bounds__(1024) k_halo_push(HaloArgs h) {
 }
 __global__ void __launch_bounds__(1024) k_halo_pull(HaloArgs h) {
     const HaloSide& sd = h.s[blockIdx.x];      // (src: the own staging, dst: the array's halo rows, flag: in the own region)
-    if (sd.rows <= 0) return;
+    if (!sd.flag) return;                      // (no neighbour on this side; with one, the wait happens even for 0 rows: see k_halo_push)
     __shared__ int s_late;
     if (threadIdx.x == 0) {
         int spins = 0; s_late = 0;
         while (__hip_atomic_load(sd.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != h.tag) { __builtin_amdgcn_s_sleep(2); if (++spins > h.spin_max) { s_late = 1; break; } }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        if (s_late) __hip_atomic_store(h.abort_flag, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (s_late) __hip_atomic_store(h.abort_flag, h.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (the "late" word of the halo pulls, NOT the solve's abort flag: a late pull hands on NaN rows, it does not disarm later solves -- ADVICE r04)
     }
     __syncthreads();
     const int n = sd.rows * h.width;
@@ -166,23 +170,24 @@ int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
         const size_t pw = (size_t)width * c->band.Spad;
         HaloArgs push{}, pull{};
         push.planes = pull.planes = planes; push.width = pull.width = width; push.plane_words = pull.plane_words = (long long)pw; push.tag = pull.tag = (double)ep;
-        pull.abort_flag = push.abort_flag = c->xr + kXrAbort; pull.spin_max = push.spin_max = c->xwait_spins;
+        pull.abort_flag = push.abort_flag = c->xr + kXrLate + 2; pull.spin_max = push.spin_max = c->xwait_spins;
         unsigned* arr = (unsigned*)base;
         for (int sd = 0; sd < 2; ++sd) {
             const int nb = sd == 0 ? c->rank - 1 : c->rank + 1;
             // what I give: my first give[0] rows to the lower neighbour (its upper side), my last give[1] rows to the upper neighbour (its lower side)
+            if (nb < 0 || nb >= c->n_ranks) continue;
             if (c->give[sd] && c->hx_peer[sd]) {
                 push.s[sd].src = arr + (size_t)width * (sd == 0 ? c->row0 : c->row1 - c->give[1]);
                 push.s[sd].dst = (unsigned*)(c->hx_peer[sd] + (size_t)par * c->hx_peer_par[sd] + c->hx_peer_off[sd]);
                 push.s[sd].rows = c->give[sd];
-                push.s[sd].flag = c->xr_peer[nb] + c->hx_flag_off + par * 2 + (1 - sd);      // (the neighbour's side seen from ITS end)
             }
+            push.s[sd].flag = c->xr_peer[nb] + c->hx_flag_off + par * 2 + (1 - sd);      // (the neighbour's side seen from ITS end)
             if (c->need[sd]) {
                 pull.s[sd].src = (const unsigned*)((char*)c->hx_mem + (size_t)par * c->hx_par + (sd == 0 ? 0 : sizeof(unsigned) * kHxWords * (size_t)c->need[0]));
                 pull.s[sd].dst = arr + (size_t)width * (sd == 0 ? c->row0 - c->need[0] : c->row1);
                 pull.s[sd].rows = c->need[sd];
-                pull.s[sd].flag = c->xr + c->hx_flag_off + par * 2 + sd;
             }
+            pull.s[sd].flag = c->xr + c->hx_flag_off + par * 2 + sd;
         }
         if (!(c->fault_halo > 0 && ep == c->fault_halo))      // PSGSDF_FAULT_HALO=n: this rank's n-th exchange pushes nothing (the neighbours' bounded waits: tests)
             hipLaunchKernelGGL(k_halo_push, dim3(2), dim3(1024), 0, c->stream, push);
@@ -382,19 +387,50 @@ int xr_probe(psgsdf_ctx* c) {
 // exchange works over RCCL and over a caller-supplied transport alike.  All ranks agree on the outcome with a second all-reduce: either every rank
 // runs the cross-rank persistent solve or every rank stays on the per-pass kernels.  EVERY rank of a multi-rank context takes part in both
 // all-reduces, whatever its own knobs or state say (a rank that cannot contributes ok = 0): nobody is left waiting in a collective.
+namespace {
+// the nonce words of up to 32 mapped regions, read the way the exchange kernels read and write them (system scope, through the mappings)
+struct NonceArgs { const double* src[32]; int n; };
+__global__ void k_xr_nonces(NonceArgs a, double* out) { if ((int)threadIdx.x < a.n) out[threadIdx.x] = a.src[threadIdx.x] ? __hip_atomic_load(a.src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0; }
+__global__ void k_xr_closed(double* slot, double serial) { __hip_atomic_store(slot, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+}  // namespace
+// Closing this rank's mappings of the peers' memory.  Every peer whose region is mapped is TOLD so first: one system-scope store of the set-up's
+// serial number into slot [closed_off + my rank] of ITS region (a one-thread kernel on the context's stream -- the same kind of store every
+// in-kernel exchange uses), drained before the mappings go.  The owner of a region reads these slots before it frees what it exported
+// (xr_quiesce): the release protocol needs no collective.
 void xr_release(psgsdf_ctx* c) {
+    bool told = false;
+    if (c->xr_closed_off > 0 && c->stream)
+        for (size_t r = 0; r < c->xr_peer.size(); ++r)
+            if ((int)r != c->rank && c->xr_peer[r]) { hipLaunchKernelGGL(k_xr_closed, dim3(1), dim3(1), 0, c->stream, c->xr_peer[r] + c->xr_closed_off + c->rank, (double)c->xr_serial); told = true; }
+    if (told) { (void)hipStreamSynchronize(c->stream); (void)hipGetLastError(); }
     for (void* p : c->xr_opened) hipIpcCloseMemHandle(p);
     c->xr_opened.clear(); c->xr_peer.clear(); c->band_peer[0] = c->band_peer[1] = nullptr; c->xr_ready = false; c->xr_args = XrArgs{};
     c->hx_ready = false; c->hx_peer[0] = c->hx_peer[1] = nullptr;
 }
-// Before rec_mem or the mailbox region are freed (band rebuild, destroy) every rank has to have closed its mappings of them: freeing memory an
-// importer still maps is undefined in HIP.  Collective over the ranks of the context; a no-op when nothing was ever exported.
-int xr_quiesce(psgsdf_ctx* c) {
+// Before rec_mem, the halo staging or the mailbox region are freed (band rebuild, destroy) every rank that mapped them has to have closed its
+// mappings: freeing memory an importer still maps is undefined in HIP.  NOT a collective (a barrier here hung every
+// healthy rank inside psgsdf_destroy as soon as one rank had failed, had already gone, or destroyed its contexts in another order): this rank
+// closes its own mappings (telling their owners, xr_release) and then watches the "closed" slots of ITS region until every rank that opened it
+// at the last set-up (xr_openers, agreed there) has written that set-up's serial number -- for at most `timeout_s` seconds.
+//   returns 0 : nobody maps this rank's memory any more (or nobody ever did)
+//           1 : a peer never reported: the caller must NOT free xr / rec_mem / hx_mem (psgsdf_destroy leaks them, logged once; build_band fails)
+int xr_quiesce(psgsdf_ctx* c, double timeout_s) {
     xr_release(c);
-    if (!c->xr_mapped || !c->comm || c->n_ranks <= 1) { c->xr_mapped = false; return 0; }
-    c->xr_mapped = false;
-    std::vector<double> bar(1, 1.0);
-    return host_allreduce(c, bar, "cross-rank release");
+    const unsigned long long openers = c->xr_openers;
+    const bool was_mapped = c->xr_mapped;
+    c->xr_mapped = false; c->xr_openers = 0;
+    if (!was_mapped || !openers || !c->xr || c->xr_closed_off <= 0 || c->n_ranks <= 1) return 0;
+    const int R = c->n_ranks;
+    std::vector<double> slots(R, 0.0);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        if (hipMemcpy(slots.data(), c->xr + c->xr_closed_off, sizeof(double) * R, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        bool all = true;
+        for (int r = 0; r < R && all; ++r) if (r != c->rank && ((openers >> r) & 1ull) && slots[r] != (double)c->xr_serial) all = false;
+        if (all) return 0;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return 1;
+        usleep(200);
+    }
 }
 int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     xr_release(c);
@@ -410,7 +446,7 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     // the region: the solve's fixed words + the frame rows' exchange area (engine.h XfTable) for this many ranks and keyframes.  (Every peer closed
     // its mapping of the old region in xr_quiesce at the top of build_band: it may be replaced here.)
     const size_t frows = (size_t)2 * R * std::max(c->F, 1);
-    const size_t want = (size_t)kXrDoubles + frows * kFrameRow + frows + (size_t)2 * R * 8 + (size_t)2 * R + 8;      // (+ 4 flags of the halo pushes, comm_halo)
+    const size_t want = (size_t)kXrDoubles + frows * kFrameRow + frows + (size_t)2 * R * 8 + (size_t)2 * R + 8 + (size_t)R;      // (+ 4 flags of the halo pushes, comm_halo; + one "closed" slot per rank, xr_release / xr_quiesce)
     // halo staging: what the two neighbours push of their cut-side rows (comm_halo): [2 parities][lower side: need_lo rows | upper side: need_hi rows] x kHxWords words
     const size_t hx_par = sizeof(unsigned) * kHxWords * ((size_t)c->need[0] + c->need[1]);
     if (c->hx_mem) { hipFree(c->hx_mem); c->hx_mem = nullptr; }
@@ -424,15 +460,31 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     ok = ok && cgf_solve_shape(c, &Gs, &Rs, true)      // (this slab fits the persistent kernel at all)
         && hipIpcGetMemHandle(&hx, c->xr) == hipSuccess && hipIpcGetMemHandle(&hb, c->rec_mem) == hipSuccess;
     (void)hipGetLastError();
+    // The region is zeroed HERE -- every peer closed its mapping of it before this band was built (xr_quiesce), nobody writes into it until the
+    // agreement at the end of this function -- and then stamped with a nonce no other region of this run carries (pid, allocation counter): the
+    // peers read it back THROUGH THEIR MAPPING before they rely on it.  (Round 5: with eight processes creating and destroying contexts in turn,
+    // a rank was seen to sweep into a region nobody polled -- every peer timed out waiting for ITS flags while it saw all of theirs.  A mapping
+    // that does not show the owner's nonce is not the owner's memory.)
+    static unsigned nonce_counter = 0;
+    const double nonce = (double)(getpid() % 1000000) * 4096.0 + (double)(++nonce_counter % 4096u) + 0.5;
+    if (c->xr) {
+        if (hipMemsetAsync(c->xr, 0, sizeof(double) * c->xr_doubles, c->stream) != hipSuccess
+            || hipMemcpyAsync(c->xr + kXrNonce, &nonce, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess
+            || hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
+        (void)hipGetLastError();
+    }
     double* mine = buf.data() + (size_t)me * kSlice;
     handle_to_doubles(hx, mine); handle_to_doubles(hb, mine + 64);
     mine[128] = (double)((char*)c->band.rec[0] - (char*)c->rec_mem); mine[129] = (double)((char*)c->band.rec[1] - (char*)c->rec_mem);
-    mine[130] = (double)getpid(); mine[131] = ok ? 1.0 : 0.0;
+    mine[130] = (double)getpid(); mine[131] = ok ? 1.0 : 0.0; mine[133] = nonce;
     mine[132] = (hx_ok || (ok && c->xh_enable && !hx_par)) ? 1.0 : 0.0;      // (a rank that needs no halo rows has nothing to stage and is fine with the pushes)
     if (hx_ok) handle_to_doubles(hh, mine + 136);
+    c->xr_serial += 1;               // (the same on every rank: set-ups are collective)
+    c->xr_closed_off = (long long)want - R;
     int rc = host_allreduce(c, buf, "cross-rank set-up");
     if (rc) return rc;
     c->xr_mapped = true;             // (handles are out: a peer may map them from here on)
+    c->xr_openers = ~0ull;           // (until the agreement below says who did)
     auto open = [&](const double* bytes) -> void* { void* p = open_handle(bytes); if (p) c->xr_opened.push_back(p); return p; };
     // map every rank's region, and the two neighbours' band arenas
     c->xr_peer.assign(R, nullptr); c->xr_peer[me] = c->xr;
@@ -444,6 +496,21 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
         c->xr_peer[r] = (double*)open(sl);
         if (!c->xr_peer[r]) { ok = false; break; }
         if (r == me - 1 || r == me + 1) { c->band_peer[r == me - 1 ? 0 : 1] = open(sl + 64); if (!c->band_peer[r == me - 1 ? 0 : 1]) { ok = false; break; } }
+    }
+    // is every mapping the owner's LIVE region?  (its nonce, read through the mapping by a kernel)
+    if (ok) {
+        NonceArgs na{}; na.n = R;
+        for (int r = 0; r < R; ++r) na.src[r] = c->xr_peer[r] ? c->xr_peer[r] + kXrNonce : nullptr;
+        double got[32] = {0};
+        hipLaunchKernelGGL(k_xr_nonces, dim3(1), dim3(32), 0, c->stream, na, c->mg_scal);
+        if (hipMemcpyAsync(got, c->mg_scal, sizeof(double) * R, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+        for (int r = 0; r < R && ok; ++r) {
+            const double want_nonce = buf[(size_t)r * kSlice + 133];
+            if (got[r] != want_nonce) {
+                fprintf(stderr, "psgsdf: rank %d: the mapping of rank %d's exchange region does not show that rank's memory (nonce %.1f, expected %.1f): in-kernel exchanges off for this band\n", me, r, got[r], want_nonce);
+                c->xr_stale_maps++; ok = false;
+            }
+        }
     }
     // the neighbours' halo stagings (halo pushes instead of RCCL send / recv: all ranks or none)
     bool hx_all = ok;
@@ -495,9 +562,8 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
         if (c->give[0] > 0 && (c->give[0] - 1) / per + 1 > kXrPeerTags) ok = false;
         if (c->give[1] > 0 && (c->row1 - c->row0 - 1) / per - std::max(0, c->row1 - c->row0 - c->give[1]) / per + 1 > kXrPeerTags) ok = false;
     }
-    // agreement: every rank or none.  (Behind this all-reduce every rank's region has been zeroed -- at its allocation, in stream order before
-    // its contribution -- so no word of an earlier band or a raised abort flag survives into the solves of this one.)
-    if (c->xr && hipMemsetAsync(c->xr, 0, sizeof(double) * c->xr_doubles, c->stream) != hipSuccess) ok = false;
+    // agreement: every rank or none.  (Every rank's region was zeroed above, before its handle went out: no word of an earlier band or a raised
+    // abort flag survives into the solves of this one.)
     if (ok) {      // the frame rows' exchange table (the flags carry the exchange's number, which only grows: the zeroed region matches none)
         XfTable t{}; t.n_ranks = R; t.rank = me; t.F = std::max(c->F, 1); t.spin_max = c->xwait_spins; t.pay = kXrDoubles; t.flg = (long long)kXrDoubles + (long long)frows * kFrameRow; t.spay = t.flg + (long long)frows; t.sflg = t.spay + (long long)2 * R * 8;
         for (int r = 0; r < R; ++r) t.region[r] = c->xr_peer[r];
@@ -505,12 +571,15 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
         if (ok && hipMemcpyAsync(c->xf_table, &t, sizeof(t), hipMemcpyHostToDevice, c->stream) != hipSuccess) ok = false;
         if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = false;
     }
-    std::vector<double> agree(2, 0.0); agree[0] = ok ? 1.0 : 0.0; agree[1] = (ok && hx_all) ? 1.0 : 0.0;
+    // ... and who holds a mapping of whose memory: entry 2 + r collects one bit per rank that opened rank r's region (R <= 32: exact in a double)
+    std::vector<double> agree(2 + (size_t)R, 0.0); agree[0] = ok ? 1.0 : 0.0; agree[1] = (ok && hx_all) ? 1.0 : 0.0;
+    for (int r = 0; r < R && r < (int)c->xr_peer.size(); ++r) if (r != me && c->xr_peer[r]) agree[2 + r] = (double)(1ull << me);
     if ((rc = host_allreduce(c, agree, "cross-rank set-up"))) return rc;
-    if (agree[0] != (double)R) { xr_release(c); return 0; }
+    c->xr_openers = (unsigned long long)agree[2 + me];
+    if (agree[0] != (double)R) { xr_release(c); return 0; }      // (xr_release tells the owners: their xr_quiesce will not wait for this rank)
     c->xr_args = x; c->xr_ready = true;
     c->hx_ready = agree[1] == (double)R;
-    c->hx_par = hx_par; c->hx_flag_off = (long long)want - 8;
+    c->hx_par = hx_par; c->hx_flag_off = (long long)want - 8 - R;
     return 0;
 }
 

@@ -268,6 +268,7 @@ __device__ __forceinline__ void fold_exchange(const XfTable* xf, long long epoch
         for (int r = 0; r < Rk; ++r) tot += __hip_atomic_load(mine + x.spay + ((long long)buf * Rk + r) * 8 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         t[s] = late ? __builtin_nan("") : tot;
     }
+    if (late) __hip_atomic_store(mine + kXrLate + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (out of band: the host tells a lost peer from a NaN state, engine.hip deliver_first)
 }
 // a.fold: sum the partial slots the PREVIOUS kernel left behind (first workgroup only; all its threads must call).
 // The calling kernel must not write the folded slots itself (engine.hip: take_fold checks).

@@ -171,6 +171,11 @@ struct SweepArgs {
 constexpr int kXrMaxRanks = 32;      // rank-level sums: [2 buffers][8 planes][kXrMaxRanks] tagged granules (plane 7: |b|^2 with the sums of pass 0)
 constexpr int kXrPeerTags = 64;      // 'records are out' tags of the neighbour's workgroups next to the cut: [2 sides][3 buffers (2 pass parities + prologue)][kXrPeerTags]
 constexpr int kXrRankGran = 0, kXrPtag = 2 * 8 * kXrMaxRanks, kXrAbort = kXrPtag + 2 * 3 * kXrPeerTags, kXrDoubles = kXrAbort + 8;
+// kXrAbort + 0: the persistent solve's abort flag (raised in every rank's region; cleared with the region at the next band).  kXrLate + 0 / 1 / 2: the
+// number of the last frame-row exchange / scalar fold / halo pull of THIS rank whose bounded wait for a peer expired (0: none) -- the NaN such an
+// exchange hands on says "something is wrong", these words say what (lateness signalled out of band, not through the payload alone)
+constexpr int kXrLate = kXrAbort + 1;
+constexpr int kXrNonce = kXrAbort + 7;   // stamped by the owner at every set-up, read back by every peer through its mapping (comm.hip xr_setup)
 struct XrArgs {
     int rank, n_ranks;               // n_ranks == 0: single-rank solve (every field below unused)
     double* region[kXrMaxRanks];     // every rank's mailbox region (own included)

@@ -89,7 +89,16 @@ int deliver_first(psgsdf_ctx* c, size_t count, bool told_landed) {
     }
     c->deferred.erase(c->deferred.begin(), c->deferred.begin() + (long)count);
     if (c->deferred.empty()) c->mbox_used = 0;      // (slots are handed out again only when nothing is in flight)
-    if (c->xf_timeout) { c->xf_timeout = false; return fail(c, PSGSDF_ERR_DEVICE, "rank %d of %d: NaN came back from an exchange between the ranks' kernels -- a peer's rows or sums never arrived within the bounded wait (or the state itself is NaN)", c->rank, c->n_ranks); }
+    if (c->xf_timeout) {
+        c->xf_timeout = false;
+        // which bounded wait expired is on record in this rank's region (kXrLate: written by the kernel whose wait expired); none: the NaN is the state's own
+        double late[4] = {0, 0, 0, 0};
+        if (c->xr) { (void)hipStreamSynchronize(c->stream); if (hipMemcpy(late, c->xr + kXrLate, sizeof(late), hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError(); }
+        if (late[0] == 0 && late[1] == 0 && late[2] == 0)
+            return fail(c, PSGSDF_ERR_DEVICE, "rank %d of %d: NaN came back from an exchange between the ranks' kernels, and no bounded wait of this rank expired: a peer handed on NaN (its wait expired, or the state itself is NaN)", c->rank, c->n_ranks);
+        return fail(c, PSGSDF_ERR_DEVICE, "rank %d of %d: NaN came back from an exchange between the ranks' kernels -- a peer's contribution never arrived within the bounded wait (2^%d polls): frame rows of exchange %.0f (missing: rank %d's row of frame %d), scalar fold %.0f, halo pull %.0f (0 = not that one)",
+                    c->rank, c->n_ranks, (int)log2((double)c->xwait_spins), late[0], (int)late[3] / 1000, (int)late[3] % 1000, late[1], late[2]);
+    }
     return 0;
 }
 int deliver(psgsdf_ctx* c) { return deliver_first(c, c->deferred.size(), true); }
@@ -242,9 +251,9 @@ int alloc_dense(psgsdf_ctx* c, DenseView& d, long long nvox, int KW, bool with_r
 // (re)build the band from the dense grid: flags -> scan -> compact planes -> neighbour tables
 int build_band(psgsdf_ctx* c) {
     if (!c->deferred.empty() || c->pending_fold.n) { int rc = flush(c); if (rc) return rc; }   // (read-backs of the band that is about to be replaced)
-    // multi-rank: the neighbours map this rank's record planes (cross-rank persistent solve); every rank closes its mappings and all ranks
-    // meet before anything is freed.  The first band of a multi-rank context also chooses the memory kind of those planes (comm.hip xr_probe).
-    { int rc = xr_quiesce(c); if (rc) return rc; }
+    // multi-rank: the neighbours map this rank's record planes (cross-rank persistent solve); every rank closes its mappings and tells the
+    // owners, and nothing is freed before every rank that mapped THIS rank's planes has said so (comm.hip xr_quiesce: flags, no collective).  The first band of a multi-rank context also chooses the memory kind of those planes (comm.hip xr_probe).
+    if (xr_quiesce(c, 120.0)) return fail(c, PSGSDF_ERR_COMM, "band rebuild: a rank never closed its mappings of this rank's record planes (lost or failed peer?)");
     if (c->n_ranks > 1 && c->comm) { int rc = xr_probe(c); if (rc) return rc; }
     c->persist_off = false;          // a persistent solve that gave up did so on the previous band's launch shape / mappings: this band tries again
     const long long nvox = c->grid.nvox;

@@ -119,6 +119,10 @@ struct psgsdf_ctx {
     int xr_mem_kind = -1;                // memory kind of xr / rec_mem chosen by xr_probe: 1 fine-grained records + uncached region, 2 both uncached, 0 none passed (cross-rank solve off); -1 not probed yet
     long long xr_probe_stale = 0, xr_probe_timeouts = 0;   // what the probe saw (all ranks, all kinds tried)
     bool xr_mapped = false;              // peers may hold IPC mappings of xr / rec_mem: they have to be closed everywhere before either is freed (xr_quiesce)
+    unsigned long long xr_openers = 0;   // bit r: rank r opened this rank's region at the last set-up (agreed there); xr_quiesce waits for exactly those
+    long long xr_serial = 0, xr_closed_off = 0;   // number of the last set-up (the same on every rank) and where the R "closed" slots of a region sit
+    long long xr_stale_maps = 0;         // mappings that did not show their owner's nonce (xr_setup)
+    bool leak_exported = false;          // a peer never reported its mappings closed: xr / rec_mem / hx_mem are never freed by this context
     std::vector<double*> xr_peer;        // [n_ranks] (own entry = xr)
     void* band_peer[2] = {nullptr, nullptr};   // lower / upper neighbour's band arena
     std::vector<void*> xr_opened;        // IPC mappings to close
@@ -229,7 +233,7 @@ int comm_xfer(psgsdf_ctx* c, const std::vector<psgsdf_comm_xfer>& sends, const s
 int host_allreduce(psgsdf_ctx* c, std::vector<double>& buf, const char* what);   // comm.hip: sum over the ranks of a HOST vector (set-up exchanges, the tracker's 6x6 system); synchronous
 int xr_setup(psgsdf_ctx* c, const std::vector<double>& part_info);   // comm.hip: (re)build the cross-rank mappings for the band just built (part_info: {need_lo, need_hi, own rows} of every rank)
 void xr_release(psgsdf_ctx* c);
-int xr_quiesce(psgsdf_ctx* c);                                        // comm.hip: close this rank's mappings and wait until every rank has closed its own (before rec_mem / xr are freed)
+int xr_quiesce(psgsdf_ctx* c, double timeout_s);                      // comm.hip: close this rank's mappings and wait (bounded, no collective) until every rank that mapped this rank's memory has closed its own; 1 = a peer never reported (do not free rec_mem / xr / hx_mem)
 int xr_probe(psgsdf_ctx* c);                                          // comm.hip: once per context (collective): which memory kind carries the in-kernel hand-offs between the real neighbours
 int xr_alloc(psgsdf_ctx* c, void** p, size_t bytes, bool polled);     // comm.hip: memory another device writes while a kernel of this one reads it
 int mg_commit(psgsdf_ctx* c);                                          // engine.hip: all-reduce + deliver the staged scalar read-backs

@@ -211,14 +211,16 @@ __device__ void so3_exp(const float* w, float* R);
 // One frame's light step (optimizeLightAll, PsOptimizer.cpp:175-203: no damping; SH models: NB x NB per frame) from its final row `acc`, and one
 // frame's pose step (optimizePosesAll PsOptimizer.cpp:207-234 + updatePose OptimizerAux.cpp:190-205).  Shared by the one-workgroup solve kernels
 // below and by the sweeps' own epilogue (fm_solve: the last workgroup of a frame to arrive solves that frame at once -- no solve launch).
+// (a row element: LDS in a frame's own last workgroup, memory -- written by other threads of the workgroup a barrier ago -- in the multi-rank tail)
+__device__ __forceinline__ double ldrow(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int NB>
 __device__ __forceinline__ void frame_solve_light_sh(FrameP* frames, int f, const double* acc, float* undo) {
     constexpr int NH = NB * (NB + 1) / 2;
     if (undo) for (int i = 0; i < 9; ++i) undo[f * 9 + i] = frames[f].l[i];      // (a speculative update keeps what it overwrites: loop.hip run_loop)
     double Hd[NB * NB], bd[NB], xd[NB];
     int q = 0;
-    for (int i = 0; i < NB; ++i) for (int k = i; k < NB; ++k) { double v = (double)(float)acc[q++]; Hd[i * NB + k] = v; Hd[k * NB + i] = v; }
-    for (int i = 0; i < NB; ++i) bd[i] = (double)(float)acc[NH + i];
+    for (int i = 0; i < NB; ++i) for (int k = i; k < NB; ++k) { double v = (double)(float)ldrow(acc + q++); Hd[i * NB + k] = v; Hd[k * NB + i] = v; }
+    for (int i = 0; i < NB; ++i) bd[i] = (double)(float)ldrow(acc + NH + i);
     solve_spd<NB>(Hd, bd, xd);
     for (int i = 0; i < NB; ++i) frames[f].l[i] -= (float)xd[i];
 }
@@ -226,11 +228,11 @@ __device__ __forceinline__ void frame_solve_pose(const SweepArgs& a, FrameP* fra
     double Hd[36], bd[6], xd[6];
     int q = 0;
     for (int i = 0; i < 6; ++i) for (int k = i; k < 6; ++k) {
-        float v = (float)acc[q++];
+        float v = (float)ldrow(acc + q++);
         if (i == k && a.damping != 0.0f) v += a.damping * v;
         Hd[i * 6 + k] = (double)v; Hd[k * 6 + i] = (double)v;
     }
-    for (int i = 0; i < 6; ++i) bd[i] = (double)(float)acc[21 + i];
+    for (int i = 0; i < 6; ++i) bd[i] = (double)(float)ldrow(acc + 21 + i);
     solve_spd<6>(Hd, bd, xd);
     float xi[6];
     for (int i = 0; i < 6; ++i) xi[i] = (float)xd[i];
@@ -283,33 +285,26 @@ __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, i
             for (int j = 0; j < 16; ++j) s += v[j];
         }
         if (solve && a.xf) {
-            // multi-rank: `s` is this SLAB's row of frame f.  It goes into every rank's mailbox region (engine.h XfTable), the R rows of the frame come
-            // back out of the own region and are added in rank order: the global row, the same bits on every rank, no collective and no launch.
+            // multi-rank: `s` is this SLAB's row of frame f.  It goes into every rank's mailbox region (engine.h XfTable) behind a flag carrying the
+            // exchange's number -- and this workgroup is DONE with the frame.  The R rows of a frame are added (rank order) and the frame solved by the
+            // sweep's LAST workgroup below: ONE workgroup per rank ever waits for another rank, whatever the frame count and however few workgroups
+            // the rank's CUs hold.  (Round 4 let the last workgroup of EVERY frame wait for the other ranks' rows: up to F waiting workgroups that keep
+            // their CU slots -- and under the XCD-contiguous ids all of an empty frame's last arrivals sit on one XCD.  Eight ranks on 32 CUs each
+            // with 32 keyframes dead-locked there: each rank's sweep stuck behind its own waiters, every one of them waiting for a frame of another
+            // rank's stuck sweep; 400 keyframes on eight whole GPUs would have done the same.  profiles/r05_notes.md section 1.)
             const XfTable& t = *a.xf;
             const int Rk = t.n_ranks, buf = (int)(a.xf_epoch & 1);
-            const double tag = (double)a.xf_epoch;
             const long long slot = ((long long)buf * Rk + t.rank) * t.F + f;
             for (int r = 0; r < Rk; ++r) store8_system(t.region[r] + t.pay + slot * kFrameRow + threadIdx.x, s);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (NV <= 64: the whole row sits in wavefront 0)
-            if (threadIdx.x == 0) for (int r = 0; r < Rk; ++r) __hip_atomic_store(t.region[r] + t.flg + slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            double* const mine = t.region[t.rank];
-            bool late = false;
-            for (int r = 0; r < Rk && !late; ++r) {
-                const double* fp = mine + t.flg + ((long long)buf * Rk + r) * t.F + f;
-                int spins = 0;
-                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > t.spin_max) { late = true; break; } }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-            double tot = 0.0;
-            for (int r = 0; r < Rk; ++r) tot += __hip_atomic_load(mine + t.pay + (((long long)buf * Rk + r) * t.F + f) * kFrameRow + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            s = late ? __builtin_nan("") : tot;      // (a rank that never delivers: the host sees the NaN energy and reports PSGSDF_ERR_DEVICE, engine.hip deliver_first)
+            if (threadIdx.x == 0) for (int r = 0; r < Rk; ++r) __hip_atomic_store(t.region[r] + t.flg + slot, (double)a.xf_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        if (solve) { __hip_atomic_store(a.acc.frame + (size_t)f * kFrameRow + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); lds[threadIdx.x] = s; }      // (the last frame's workgroup reads the energy columns of every row)
+        else if (solve) { __hip_atomic_store(a.acc.frame + (size_t)f * kFrameRow + threadIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); lds[threadIdx.x] = s; }      // (the last frame's workgroup reads the energy columns of every row)
         else a.acc.frame[(size_t)f * kFrameRow + threadIdx.x] = s;
     }
     if (!solve) return;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !a.xf) {
         if (KIND == 0) { if (!ModelTraits<MODEL>::LED) frame_solve_light_sh<ModelTraits<MODEL>::NB == 3 ? 4 : ModelTraits<MODEL>::NB>(a.fm_frames, f, lds, a.fm_undo); }
         else frame_solve_pose(a, a.fm_frames, f, lds);
     }
@@ -320,6 +315,40 @@ __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, i
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x == 0) __hip_atomic_store(a.acc.fdone + a.F, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.xf) {
+        // multi-rank tail: every frame of THIS slab is out.  Element (f, l) of the global rows: wait for the R flags of frame f (bounded), add the
+        // R slabs' values in rank order -- the same bits on every rank -- and put the row where the solves read it; then one lane per frame solves.
+        const XfTable& t = *a.xf;
+        const int Rk = t.n_ranks, buf = (int)(a.xf_epoch & 1);
+        const double tag = (double)a.xf_epoch;
+        double* const mine = t.region[t.rank];
+        for (int i = threadIdx.x; i < a.F * NV; i += blockDim.x) {
+            const int ff = i / NV, l = i - ff * NV;
+            bool late = false; int late_rank = -1;
+            for (int r = 0; r < Rk && !late; ++r) {
+                const double* fp = mine + t.flg + ((long long)buf * Rk + r) * t.F + ff;
+                int spins = 0;
+                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > t.spin_max) { late = true; late_rank = r; break; } }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            double tot = 0.0;
+            for (int r = 0; r < Rk; ++r) tot += __hip_atomic_load(mine + t.pay + (((long long)buf * Rk + r) * t.F + ff) * kFrameRow + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (late) {      // (a rank that never delivers: the host sees the NaN energy and reports PSGSDF_ERR_DEVICE -- and what was missing: engine.hip deliver_first)
+                tot = __builtin_nan("");
+                __hip_atomic_store(mine + kXrLate, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(mine + kXrLate + 3, (double)(late_rank * 1000 + ff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __hip_atomic_store(a.acc.frame + (size_t)ff * kFrameRow + l, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int ff = threadIdx.x; ff < a.F; ff += blockDim.x) {
+            const double* row = a.acc.frame + (size_t)ff * kFrameRow;
+            if (KIND == 0) { if (!ModelTraits<MODEL>::LED) frame_solve_light_sh<ModelTraits<MODEL>::NB == 3 ? 4 : ModelTraits<MODEL>::NB>(a.fm_frames, ff, row, a.fm_undo); }
+            else frame_solve_pose(a, a.fm_frames, ff, row);
+        }
+        __syncthreads();
+    }
     if (KIND == 0 && ModelTraits<MODEL>::LED) {
         // LED: ONE light vector over all frames (LedOptimizer.cpp:128-160): this workgroup is the last of the whole sweep, every frame's final row is
         // in place and no workgroup reads a frame record any more -- k_solve_light's arithmetic (sums over the frames in frame order, three

@@ -306,7 +306,7 @@ def test_cross_rank_persistent_solve_on_disjoint_cu_halves(built, tmp_path, mask
 EIGHTHS = ",".join(f"{32 * i}:{32 * i + 32}" for i in range(8))
 
 
-@pytest.mark.parametrize("model,N,frames,mode", [("SH1", 96, None, "iterate"), ("SH2", 64, "70:96:72", "iterate"), ("LED", 64, None, "iterate"), ("SH1", 24, None, "iterate"), ("SH1", 24, None, "optimize")])
+@pytest.mark.parametrize("model,N,frames,mode", [("SH1", 96, None, "iterate"), ("SH2", 64, "70:96:72", "iterate"), ("LED", 64, None, "iterate"), ("SH1", 24, None, "iterate"), ("SH1", 16, None, "iterate"), ("SH1", 24, None, "optimize")])
 def test_eight_ranks_on_cu_eighths(built, margins, tmp_path, model, N, frames, mode):
     """WORLD SIZE 8 -- the machine BASELINE.json names -- rehearsed on the one-GPU box: eight processes, each confined to an eighth
     of the CUs (PSGSDF_CU_MASK=0:32, 32:64, ...), so that the eight persistent solve kernels are resident together while they exchange halo records,
@@ -346,8 +346,8 @@ def test_eight_ranks_on_cu_eighths(built, margins, tmp_path, model, N, frames, m
     cuts = [(int(g["info"][6]), int(g["info"][7])) for g in res]
     nz = int(ref.info().dim[2])
     assert cuts[0][0] == 0 and cuts[-1][1] == nz and all(cuts[i][1] == cuts[i + 1][0] for i in range(7)) and min(planes) >= 1
-    if N == 24 and mode == "iterate":
-        assert min(planes) <= 2, planes              # a slab thinner than a stencil
+    if N <= 24 and mode == "iterate":
+        assert min(planes) <= (1 if N == 16 else 2), planes              # slabs thinner than a stencil (N = 16: ONE plane -- both halo planes of its neighbours are this rank's only plane)
     assert np.array_equal(np.concatenate([g["band"] for g in res]), band)
     d = stitch(res, "dist"); rgb = stitch(res, "rgb")
     m = {"dist_max_vs": float(np.abs(d[band] - v["dist"][band]).max() / vs), "rgb_max": float(np.abs(rgb[:, band] - v["rgb"][:, band]).max()), "planes_per_rank": planes,
