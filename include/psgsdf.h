@@ -249,7 +249,11 @@ int psgsdf_upload_light(psgsdf_ctx* ctx, const float* light);
 
 /* ---- multi-GPU (z-slab partition, one context per rank, one process per GPU) -------------- */
 
-/* The reference is a single process (main_ps.cpp:41-343) and has no counterpart of this section.  The volume is cut along z into n_ranks
+/* psgsdf_destroy on a multi-rank context is NOT a collective: a rank closes its mappings of the other ranks' exchange memory, tells their owners, and
+ * frees what it exported itself once every rank that mapped it has reported the same -- or after PSGSDF_DESTROY_TIMEOUT_S (15 s), in which case that
+ * memory is leaked rather than freed under a peer that may still be writing to it.  Ranks may fail, leave early or destroy their contexts in any order.
+ *
+ * The reference is a single process (main_ps.cpp:41-343) and has no counterpart of this section.  The volume is cut along z into n_ranks
  * slabs of (about) equal band count; a context attached to a rank keeps ITS slab (plus one halo plane on each inner side) on its device and
  * computes only there, and EVERY entry point above keeps its meaning: psgsdf_upload_volume (every rank passes the whole volume and keeps its
  * slab of it) / psgsdf_init / psgsdf_step / psgsdf_iterate / psgsdf_optimize / psgsdf_upsample2x become collective calls (all ranks make them,
@@ -346,6 +350,28 @@ int psgsdf_debug_albedo_system(psgsdf_ctx* ctx, float* H, float* b);
  *   out[6] memory kind the hand-off probe chose for the record planes another device writes (-1 not probed: single rank; 0 none passed: cross-rank
  *   solve off; 1 fine-grained; 2 uncached; 3 coarse, pinned by PSGSDF_XR_MEM), out[7] 1e6 x stale records + timed-out waits the probe saw (all ranks) */
 int psgsdf_debug_sync_stats(psgsdf_ctx* ctx, int64_t out[8]);
+
+/* ---- tuning knobs ------------------------------------------------------------------------- */
+
+/* The engine reads the following environment variables when a context is created (a few, marked *, when they are used).  All of them only choose
+ * between equivalent execution strategies -- results agree to rounding, most bit for bit (tests/test_knobs_gpu.py) -- and none is needed in
+ * normal operation.  psgsdf_get_tuning reports what was set and what it resolved to.
+ *   PSGSDF_PCG_POLL, PSGSDF_SPECULATE, PSGSDF_SPECULATE_MR, PSGSDF_FOLD_IN_NEXT, PSGSDF_FUSE_ALBEDO, PSGSDF_FUSE_PCG_INIT        (0 / 1) host-side scheduling
+ *   PSGSDF_PCG_PERSIST, PSGSDF_PCG_PIPELINE, PSGSDF_PCG_PREFETCH, PSGSDF_PCG_FUSE_ASM, PSGSDF_PCG_FUSE_APPLY, PSGSDF_PCG_XCD_LOCAL,
+ *   PSGSDF_PCG_COL16*, PSGSDF_PCG_ROWS*, PSGSDF_PCG_BLOCKS*                                                                        distance solve
+ *   PSGSDF_FM_SOLVE, PSGSDF_FM_ROWS*, PSGSDF_IMG_COMPACT, PSGSDF_XCD_MAP, PSGSDF_XCD_STRIPE                                        sweeps
+ *   PSGSDF_XR, PSGSDF_XF, PSGSDF_XS, PSGSDF_XH (0: that exchange through the communicator instead of IPC-mapped memory), PSGSDF_XR_MEM* (fine | uncached |
+ *   coarse), PSGSDF_XWAIT_LOG2 (log2 of the polls an in-kernel wait for another rank may take), PSGSDF_CU_MASK (lo:hi)              multi-rank
+ *   PSGSDF_WAIT_TIMEOUT_S*, PSGSDF_DESTROY_TIMEOUT_S*, PSGSDF_SOLVE_DUMP*                                                           host waits / diagnostics
+ * DESIGN.md section 4 has the table with defaults and measured effects.
+ * NOT in libpsgsdf.so: PSGSDF_FAULT_SOLVE, PSGSDF_FAULT_HALO (fault injection), PSGSDF_PCG_ABLATE (timing ablations: results are WRONG),
+ * PSGSDF_MBOX_CHECK=0 (re-opens a race fixed in round 3).  They exist only in the development build libpsgsdf_dev.so (-DPSGSDF_DEV) the tests and
+ * tools load; the product library ignores them and says so under "ignored_dev_only".
+ *
+ * psgsdf_get_tuning writes one JSON object {"build": .., "env": {variables that were set, verbatim}, "ignored_dev_only": {..}, "effective": {the
+ * switches as resolved, defaults included}} into `json` (at most cap - 1 characters + terminator; json may be NULL) and returns the length the whole
+ * text needs, or a negative status. */
+int psgsdf_get_tuning(psgsdf_ctx* ctx, char* json, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,46 @@ class Oracle(capi.Api):
         self._lib.orc_set_solver_mode(self.ctx, C.c_int(solver_mode))
         self._lib.orc_set_threads(self.ctx, C.c_int(threads))
 
+    # ---- the oracle's multi-rank PHASE MIRROR (orc_mg_*): the slab algorithm spelled out phase by phase for the host program tests/_slab_runner.py
+    # (gloo, CPU).  The engine has no such API -- its C++ host runs the slab loop itself -- so these bindings live here, not in the product's capi.
+    def comm_init(self, rank, n_ranks, unique_id=None):
+        """attach this oracle context to a rank (no communicator: the exchanges are done by the host program over the phase API below)"""
+        self._check(self._fn("comm_init")(self.ctx, None, C.c_int(rank), C.c_int(n_ranks)), "comm_init")
+
+    def mg_info(self):
+        """{S, Spad, row0, row1, halo, F, rank, n_ranks, need_lo, need_hi, -, -} in the mirror's own layout (rows = band rows, not z-planes)"""
+        out = (C.c_int32 * 12)()
+        self._check(self._fn("mg_info")(self.ctx, out), "mg_info")
+        return dict(zip(["S", "Spad", "row0", "row1", "halo", "F", "rank", "n_ranks", "need_lo", "need_hi", "z0", "z1"], list(out)))
+
+    def mg_buffer(self, which):
+        ptr = C.c_void_p(); n = C.c_int64()
+        self._check(self._fn("mg_buffer")(self.ctx, C.c_int(which), C.byref(ptr), C.byref(n)), "mg_buffer")
+        return ptr.value, n.value
+
+    def mg_phase(self, phase, arg=0):
+        self._check(self._fn("mg_phase")(self.ctx, C.c_int(phase), C.c_int(arg)), f"mg_phase({phase})")
+
+    def mg_pcg_status(self, k0, n):
+        it = C.c_int32(); err = C.c_double()
+        self._check(self._fn("mg_pcg_status")(self.ctx, C.c_int(k0), C.c_int(n), C.byref(it), C.byref(err)), "mg_pcg_status")
+        return it.value, err.value
+
+    def mg_fold_base(self, base):
+        self._check(self._fn("mg_fold_base")(self.ctx, C.c_int(base)), "mg_fold_base")
+
+    def mg_set_reg_sums(self, en_sum, el_sum):
+        self._check(self._fn("mg_set_reg_sums")(self.ctx, C.c_double(en_sum), C.c_double(el_sum)), "mg_set_reg_sums")
+
+    def mg_set_weights(self, reg_n, reg_l):
+        self._check(self._fn("mg_set_weights")(self.ctx, C.c_float(reg_n), C.c_float(reg_l)), "mg_set_weights")
+
+    def mg_pack_state(self):
+        self._check(self._fn("mg_pack_state")(self.ctx), "mg_pack_state")
+
+    def mg_unpack_state(self):
+        self._check(self._fn("mg_unpack_state")(self.ctx), "mg_unpack_state")
+
     def set_faithful(self, on=True):
         """band membership as the reference does it (std::find over surface_points_, O(S) per test) instead of the row_of table: same results"""
         self._lib.orc_set_faithful(self.ctx, C.c_int(1 if on else 0))

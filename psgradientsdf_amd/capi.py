@@ -2,9 +2,9 @@
 
 This is host-side plumbing for tests and bench.py (the reference is C++; the C++ mirror of its
 PsOptimizer/LedOptimizer interface lives in psgradientsdf_amd/host/).  `Api` is generic over
-(shared library, symbol prefix) because the test oracle exports the same functions under `orc_`;
-the product only ever instantiates it through `load_engine()`, which binds `libpsgsdf.so` and
-raises if the HIP library is missing — there is no CPU fallback.
+(shared library, symbol prefix) so that a test harness can bind another implementation of the
+same C ABI; the product only ever instantiates it through `load_engine()`, which binds
+`libpsgsdf.so` and raises if the HIP library is missing — there is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -19,6 +19,8 @@ L2, CAUCHY, HUBER, TUKEY, TRUNC_L2 = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ENGINE_LIB = os.environ.get("PSGSDF_ENGINE_LIB") or os.path.join(_HERE, "csrc", "libpsgsdf.so")      # (the override is for A/B runs of two BUILDS on one box: tools/)
+# the development build (-DPSGSDF_DEV): the same engine plus the fault-injection / ablation knobs the product library does not contain; tests and tools only
+ENGINE_LIB_DEV = os.path.join(_HERE, "csrc", "libpsgsdf_dev.so")
 
 
 class GridDesc(C.Structure):
@@ -83,7 +85,8 @@ class PsgsdfError(RuntimeError):
 
 
 class Api:
-    """One context of either the HIP engine (prefix psgsdf_) or the test oracle (prefix orc_)."""
+    """One context behind the C ABI of include/psgsdf.h.  (The binding is generic over (library, symbol prefix): the test oracle exports the same
+    entry points under another prefix and subclasses this in oracle/oracle.py; the product only instantiates it through load_engine.)"""
 
     def __init__(self, lib: C.CDLL, prefix: str, grid: GridDesc, K, settings: Settings, device: int = 0):
         self._lib, self._p = lib, prefix
@@ -338,8 +341,7 @@ class Api:
 
     # -- multi-GPU: attach the context to a rank (before load_scene / init); afterwards every call is collective
     def comm_init(self, rank, n_ranks, unique_id=None):
-        """unique_id: the 128 bytes rank 0 got from comm_unique_id() (RCCL).  The oracle's mirror (prefix orc_) takes no id: its exchanges
-        are done by the host program tests/_slab_runner.py over its phase API below."""
+        """unique_id: the 128 bytes rank 0 got from comm_unique_id() (RCCL)"""
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id)) if unique_id is not None else None
         self._check(self._fn("comm_init")(self.ctx, buf, C.c_int(rank), C.c_int(n_ranks)), "comm_init")
 
@@ -353,45 +355,27 @@ class Api:
         self._check(self._fn("comm_stats")(self.ctx, C.byref(n)), "comm_stats")
         return n.value
 
-    # -- phase API of the ORACLE's multi-rank mirror (orc_mg_*), driven by tests/_slab_runner.py in the CPU tests
     def set_stream(self, stream_ptr):
         self._check(self._fn("set_stream")(self.ctx, C.c_void_p(stream_ptr)), "set_stream")
 
     def mg_info(self):
-        """engine: {S (whole volume), rows held, row0, row1, halo, F, rank, n_ranks, need_lo, need_hi, z0, z1}; the oracle's phase mirror fills
-        the first ten with its own layout ({S, Spad, ...})"""
+        """{S (whole volume), rows held, row0, row1, halo, F, rank, n_ranks, need_lo, need_hi, z0, z1} of a context attached to a rank"""
         out = (C.c_int32 * 12)()
         self._check(self._fn("mg_info")(self.ctx, out), "mg_info")
-        names = ["S", "Spad" if self._p == "orc_" else "rows", "row0", "row1", "halo", "F", "rank", "n_ranks", "need_lo", "need_hi", "z0", "z1"]
-        return dict(zip(names, list(out)))
+        return dict(zip(self._MG_INFO_NAMES, list(out)))
 
-    def mg_buffer(self, which):
-        ptr = C.c_void_p(); n = C.c_int64()
-        self._check(self._fn("mg_buffer")(self.ctx, C.c_int(which), C.byref(ptr), C.byref(n)), "mg_buffer")
-        return ptr.value, n.value
+    _MG_INFO_NAMES = ["S", "rows", "row0", "row1", "halo", "F", "rank", "n_ranks", "need_lo", "need_hi", "z0", "z1"]
 
-    def mg_phase(self, phase, arg=0):
-        self._check(self._fn("mg_phase")(self.ctx, C.c_int(phase), C.c_int(arg)), f"mg_phase({phase})")
-
-    def mg_pcg_status(self, k0, n):
-        it = C.c_int32(); err = C.c_double()
-        self._check(self._fn("mg_pcg_status")(self.ctx, C.c_int(k0), C.c_int(n), C.byref(it), C.byref(err)), "mg_pcg_status")
-        return it.value, err.value
-
-    def mg_fold_base(self, base):
-        self._check(self._fn("mg_fold_base")(self.ctx, C.c_int(base)), "mg_fold_base")
-
-    def mg_set_reg_sums(self, en_sum, el_sum):
-        self._check(self._fn("mg_set_reg_sums")(self.ctx, C.c_double(en_sum), C.c_double(el_sum)), "mg_set_reg_sums")
-
-    def mg_set_weights(self, reg_n, reg_l):
-        self._check(self._fn("mg_set_weights")(self.ctx, C.c_float(reg_n), C.c_float(reg_l)), "mg_set_weights")
-
-    def mg_pack_state(self):
-        self._check(self._fn("mg_pack_state")(self.ctx), "mg_pack_state")
-
-    def mg_unpack_state(self):
-        self._check(self._fn("mg_unpack_state")(self.ctx), "mg_unpack_state")
+    def get_tuning(self):
+        """psgsdf_get_tuning: which environment knobs were set when the context was created, which dev-only ones this build ignores, what they resolved to"""
+        import json
+        f = getattr(self._lib, self._p + "get_tuning"); f.restype = C.c_int
+        n = f(self.ctx, None, C.c_size_t(0))
+        if n < 0:
+            self._check(n, "get_tuning")
+        buf = C.create_string_buffer(n + 1)
+        f(self.ctx, buf, C.c_size_t(n + 1))
+        return json.loads(buf.value.decode())
 
     # -- measurement
     def set_profiling(self, on):
@@ -493,19 +477,19 @@ def grid_of(sc) -> GridDesc:
     return g
 
 
-_engine_lib = None
+_engine_lib = {}
 
 
-def engine_lib() -> C.CDLL:
-    """dlopen the HIP engine; raises (no fallback) if it has not been built."""
-    global _engine_lib
-    if _engine_lib is None:
-        if not os.path.exists(ENGINE_LIB):
-            raise PsgsdfError(f"HIP engine {ENGINE_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-        _engine_lib = C.CDLL(ENGINE_LIB)
-    return _engine_lib
+def engine_lib(dev: bool = False) -> C.CDLL:
+    """dlopen the HIP engine; raises (no fallback) if it has not been built.  dev: the development build with the fault-injection knobs (tests / tools)."""
+    path = ENGINE_LIB_DEV if dev else ENGINE_LIB
+    if path not in _engine_lib:
+        if not os.path.exists(path):
+            raise PsgsdfError(f"HIP engine {path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _engine_lib[path] = C.CDLL(path)
+    return _engine_lib[path]
 
 
-def load_engine(sc_or_grid, K, settings: Settings, device: int = 0) -> Api:
+def load_engine(sc_or_grid, K, settings: Settings, device: int = 0, dev: bool = False) -> Api:
     grid = sc_or_grid if isinstance(sc_or_grid, GridDesc) else grid_of(sc_or_grid)
-    return Api(engine_lib(), "psgsdf_", grid, K, settings, device)
+    return Api(engine_lib(dev or os.environ.get("PSGSDF_USE_DEV_LIB") == "1"), "psgsdf_", grid, K, settings, device)

@@ -8,7 +8,22 @@ using namespace psge;
 // ============================================================================================
 extern "C" {
 
-const char* psgsdf_version(void) { return "psgsdf-hip gfx950 r1"; }
+#ifdef PSGSDF_DEV
+const char* psgsdf_version(void) { return "psgsdf-hip gfx950 r5 dev (fault-injection and ablation knobs compiled in: libpsgsdf_dev.so, tests and tools only)"; }
+#else
+const char* psgsdf_version(void) { return "psgsdf-hip gfx950 r5"; }
+#endif
+
+// Every environment variable the engine reads (include/psgsdf.h lists them with their meaning).  The values are snapshotted when a context is created;
+// psgsdf_get_tuning reports the snapshot and what it resolved to.  kDevKnobs exist only in the development build: they inject faults or make results
+// WRONG on purpose and are compiled out of libpsgsdf.so.
+static const char* const kKnobs[] = {
+    "PSGSDF_PCG_POLL", "PSGSDF_SPECULATE", "PSGSDF_FOLD_IN_NEXT", "PSGSDF_FUSE_ALBEDO", "PSGSDF_FUSE_PCG_INIT", "PSGSDF_PCG_PERSIST", "PSGSDF_PCG_XCD_LOCAL",
+    "PSGSDF_PCG_FUSE_ASM", "PSGSDF_PCG_FUSE_APPLY", "PSGSDF_PCG_PIPELINE", "PSGSDF_PCG_PREFETCH", "PSGSDF_PCG_COL16", "PSGSDF_PCG_ROWS", "PSGSDF_PCG_BLOCKS",
+    "PSGSDF_FM_SOLVE", "PSGSDF_FM_ROWS", "PSGSDF_IMG_COMPACT", "PSGSDF_XCD_MAP", "PSGSDF_XCD_STRIPE",
+    "PSGSDF_XR", "PSGSDF_XF", "PSGSDF_XS", "PSGSDF_XH", "PSGSDF_XR_MEM", "PSGSDF_XWAIT_LOG2", "PSGSDF_SPECULATE_MR", "PSGSDF_CU_MASK",
+    "PSGSDF_WAIT_TIMEOUT_S", "PSGSDF_DESTROY_TIMEOUT_S", "PSGSDF_SOLVE_DUMP"};
+static const char* const kDevKnobs[] = {"PSGSDF_PCG_ABLATE", "PSGSDF_FAULT_SOLVE", "PSGSDF_FAULT_HALO", "PSGSDF_MBOX_CHECK"};
 const char* psgsdf_last_error(const psgsdf_ctx* c) { return c ? c->err : "null context"; }
 
 int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_settings* settings, int device, psgsdf_ctx** out) {
@@ -20,8 +35,6 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     psgsdf_ctx* c = new psgsdf_ctx();
     c->device = device;
     if (const char* e = getenv("PSGSDF_PCG_POLL")) c->pcg_poll = atoi(e) != 0;
-    if (const char* e = getenv("PSGSDF_MBOX_CHECK")) c->mbox_check = atoi(e) != 0;
-    if (const char* e = getenv("PSGSDF_FAULT_SOLVE")) c->fault_solve = atoi(e);
     if (const char* e = getenv("PSGSDF_SPECULATE")) c->speculate = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FOLD_IN_NEXT")) c->fold_in_next = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FUSE_ALBEDO")) c->fuse_albedo = atoi(e) != 0;
@@ -36,12 +49,24 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_XS")) c->xs_enable = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XH")) c->xh_enable = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XWAIT_LOG2")) { const int l = atoi(e); if (l >= 8 && l <= 30) c->xwait_spins = 1 << l; }
-    if (const char* e = getenv("PSGSDF_FAULT_HALO")) c->fault_halo = atoll(e);
     if (const char* e = getenv("PSGSDF_IMG_COMPACT")) c->img_compact = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_SPECULATE_MR")) c->speculate_mr = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XCD_MAP")) c->xcd_map = atoi(e);
     if (const char* e = getenv("PSGSDF_XCD_STRIPE")) c->xcd_map = (c->xcd_map & 255) | (atoi(e) << 8);
+#ifdef PSGSDF_DEV      // fault injection / ablation / the round-2 race: development build only (libpsgsdf_dev.so)
     if (const char* e = getenv("PSGSDF_PCG_ABLATE")) c->pcg_ablate = atoi(e) & 7;
+    if (const char* e = getenv("PSGSDF_MBOX_CHECK")) c->mbox_check = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_FAULT_SOLVE")) c->fault_solve = atoi(e);
+    if (const char* e = getenv("PSGSDF_FAULT_HALO")) c->fault_halo = atoll(e);
+#endif
+    for (const char* k : kKnobs) if (const char* e = getenv(k)) c->tuning_env.emplace_back(k, e);
+    for (const char* k : kDevKnobs) if (const char* e = getenv(k)) {
+#ifdef PSGSDF_DEV
+        c->tuning_env.emplace_back(k, e);
+#else
+        c->tuning_ignored.emplace_back(k, e);      // (set, but this build does not know it: reported, never silently honoured)
+#endif
+    }
     if (const char* e = getenv("PSGSDF_PCG_FUSE_APPLY")) c->pcg_fuse_apply = atoi(e) != 0;
     if (hipDeviceGetAttribute(&c->num_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->num_cu = 0;
     c->set = *settings; c->reg_n = settings->reg_weight_n; c->reg_l = settings->reg_weight_l; c->reg_r = settings->reg_weight_rho;

@@ -175,4 +175,30 @@ int psgsdf_debug_sync_stats(psgsdf_ctx* c, int64_t out[8]) {
     return PSGSDF_OK;
 }
 
+// Which tuning knobs are in force on this context: one JSON object -- "build", "env" (every supported PSGSDF_* variable that was set when the context
+// was created, verbatim), "ignored_dev_only" (fault-injection / ablation variables that were set but are compiled out of this build) and "effective"
+// (what the switches resolved to, defaults included).  Returns the length the text needs (excluding the terminator); writes at most cap - 1 characters.
+int psgsdf_get_tuning(psgsdf_ctx* c, char* json, size_t cap) {
+    if (!c) return PSGSDF_ERR_ARG;
+    std::string o = "{\"build\": \"";
+    o += psgsdf_version(); o += "\", \"env\": {";
+    auto esc = [](const std::string& v) { std::string r; for (char ch : v) { if (ch == '"' || ch == '\\') r += '\\'; if ((unsigned char)ch >= 0x20) r += ch; } return r; };
+    bool first = true;
+    for (auto& kv : c->tuning_env) { o += (first ? "\"" : ", \"") + kv.first + "\": \"" + esc(kv.second) + "\""; first = false; }
+    o += "}, \"ignored_dev_only\": {"; first = true;
+    for (auto& kv : c->tuning_ignored) { o += (first ? "\"" : ", \"") + kv.first + "\": \"" + esc(kv.second) + "\""; first = false; }
+    o += "}, \"effective\": {";
+    char buf[1024];
+    snprintf(buf, sizeof(buf), "\"pcg_poll\": %d, \"speculate\": %d, \"speculate_mr\": %d, \"fold_in_next\": %d, \"fuse_albedo\": %d, \"fuse_pcg_init\": %d, \"pcg_persist\": %d, \"pcg_pipeline\": %d, "
+             "\"pcg_prefetch\": %d, \"pcg_fuse_asm\": %d, \"pcg_fuse_apply\": %d, \"pcg_xcd_local\": %d, \"fm_solve\": %d, \"fm_solve_led\": %d, \"img_compact\": %d, \"xcd_map\": %d, "
+             "\"xr\": %d, \"xf\": %d, \"xs\": %d, \"xh\": %d, \"xr_mem_kind\": %d, \"xwait_log2\": %d, \"cu_mask\": [%d, %d], \"mbox_check\": %d, \"pcg_ablate\": %d, \"fault_solve\": %d, \"fault_halo\": %lld",
+             (int)c->pcg_poll, (int)c->speculate, (int)c->speculate_mr, (int)c->fold_in_next, (int)c->fuse_albedo, (int)c->fuse_pcg_init, (int)c->pcg_persist, (int)c->pcg_pipeline,
+             (int)c->pcg_prefetch, (int)c->pcg_fuse_asm, (int)c->pcg_fuse_apply, (int)c->pcg_xcd_local, (int)c->fm_solve, (int)c->fm_solve_led, (int)c->img_compact, c->xcd_map,
+             (int)c->xr_enable, (int)c->xf_enable, (int)c->xs_enable, (int)c->xh_enable, c->xr_mem_kind, (int)lround(log2((double)c->xwait_spins)), c->cu_mask_lo, c->cu_mask_hi,
+             (int)c->mbox_check, c->pcg_ablate, c->fault_solve, c->fault_halo);
+    o += buf; o += "}}";
+    if (json && cap) { const size_t n = std::min(cap - 1, o.size()); memcpy(json, o.data(), n); json[n] = 0; }
+    return (int)o.size();
+}
+
 }  // extern "C"

@@ -127,7 +127,7 @@ int comm_allreduce(psgsdf_ctx* c, double* buf, int n) {
 // in front of its push of n + 1, which this rank's pull of n + 1 -- in front of its push of n + 2 -- waits for).
 namespace {
 struct HaloSide { const unsigned* src; unsigned* dst; int rows; double* flag; };
-struct HaloArgs { HaloSide s[2]; int planes, width; long long plane_words; double tag; double* abort_flag; int spin_max; };
+struct HaloArgs { HaloSide s[2]; int planes, width; long long plane_words; double tag; double* abort_flag; double* host_late; int spin_max; };
 __global__ void __launch_bounds__(1024) k_halo_push(HaloArgs h) {
     const HaloSide& sd = h.s[blockIdx.x];
     if (!sd.flag) return;                      // (no neighbour on this side)
@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(1024) k_halo_pull(HaloArgs h) {
         int spins = 0; s_late = 0;
         while (__hip_atomic_load(sd.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != h.tag) { __builtin_amdgcn_s_sleep(2); if (++spins > h.spin_max) { s_late = 1; break; } }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (s_late && h.host_late) __hip_atomic_store(h.host_late, h.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (host-mapped: engine.hip deliver_first turns it into PSGSDF_ERR_DEVICE)
         if (s_late) __hip_atomic_store(h.abort_flag, h.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (the "late" word of the halo pulls, NOT the solve's abort flag: a late pull hands on NaN rows, it does not disarm later solves -- ADVICE r04)
     }
     __syncthreads();
@@ -170,7 +171,8 @@ int comm_halo(psgsdf_ctx* c, void* base, int planes, int width) {
         const size_t pw = (size_t)width * c->band.Spad;
         HaloArgs push{}, pull{};
         push.planes = pull.planes = planes; push.width = pull.width = width; push.plane_words = pull.plane_words = (long long)pw; push.tag = pull.tag = (double)ep;
-        pull.abort_flag = push.abort_flag = c->xr + kXrLate + 2; pull.spin_max = push.spin_max = c->xwait_spins;
+        pull.abort_flag = push.abort_flag = c->xr + kXrLate + 2;
+        pull.host_late = push.host_late = c->mbox_dev ? c->mbox_dev + c->mbox_n + 1 : nullptr; pull.spin_max = push.spin_max = c->xwait_spins;
         unsigned* arr = (unsigned*)base;
         for (int sd = 0; sd < 2; ++sd) {
             const int nb = sd == 0 ? c->rank - 1 : c->rank + 1;

@@ -89,6 +89,13 @@ int deliver_first(psgsdf_ctx* c, size_t count, bool told_landed) {
     }
     c->deferred.erase(c->deferred.begin(), c->deferred.begin() + (long)count);
     if (c->deferred.empty()) c->mbox_used = 0;      // (slots are handed out again only when nothing is in flight)
+    // a halo pull whose bounded wait expired hands on NaN rows -- which the distance solve may swallow (a CG on NaN sums never reports Success and the
+    // reference's B8 rule then simply skips the update): the pull says so in a host-mapped word of its own, and the host looks at it here
+    if (c->mbox && c->mbox_n && ((volatile double*)c->mbox)[c->mbox_n + 1] != 0.0) {
+        const double ep = ((volatile double*)c->mbox)[c->mbox_n + 1];
+        ((volatile double*)c->mbox)[c->mbox_n + 1] = 0.0;
+        return fail(c, PSGSDF_ERR_DEVICE, "rank %d of %d: halo pull %.0f gave up -- a neighbour's halo rows never arrived within the bounded wait (2^%d polls); the halo rows were filled with NaN", c->rank, c->n_ranks, ep, (int)log2((double)c->xwait_spins));
+    }
     if (c->xf_timeout) {
         c->xf_timeout = false;
         // which bounded wait expired is on record in this rank's region (kXrLate: written by the kernel whose wait expired); none: the NaN is the state's own
@@ -427,7 +434,7 @@ int build_band(psgsdf_ctx* c) {
             c->mbox = nullptr; c->mbox_n = 0; c->mbox_alloc = 0;
             HIPCHK(c, hipHostMalloc(&c->mbox, sizeof(double) * need, hipHostMallocMapped));
             HIPCHK(c, hipHostGetDevicePointer((void**)&c->mbox_dev, c->mbox, 0));
-            c->mbox_alloc = need; c->mbox_n = need - 1;      // [mbox_n] = flush marker
+            c->mbox_alloc = need; c->mbox_n = need - 2;      // [mbox_n] = flush marker, [mbox_n + 1] = the "a halo pull gave up" word (comm.hip k_halo_pull)
             memset(c->mbox, 0, sizeof(double) * need); c->flush_seq = 0;
         }
         if (slab_mode(c) && !c->mbox_shadow) {

@@ -183,6 +183,7 @@ struct psgsdf_ctx {
     std::string watch;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> watch_pool;
     size_t watch_used = 0; int watch_every = 1; size_t watch_seen = 0;
+    std::vector<std::pair<std::string, std::string>> tuning_env, tuning_ignored;   // environment knobs as they stood when the context was created / dev-only ones this build ignores (psgsdf_get_tuning)
     char err[512] = {0};
 };
 

@@ -21,6 +21,8 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
         os.environ["PSGSDF_CU_MASK"] = os.environ["SLAB_CU_MASKS"].split(",")[rank]
     if os.environ.get("SLAB_FAULT_HALO") and rank == 1:      # this rank's n-th halo exchange pushes nothing (the neighbours' waits are bounded: tests)
         os.environ["PSGSDF_FAULT_HALO"] = os.environ["SLAB_FAULT_HALO"]
+    if os.environ.get("SLAB_FAULT_HALO"):                    # (fault injection exists in the development build only: every rank of such a run loads it)
+        os.environ["PSGSDF_USE_DEV_LIB"] = "1"
     # SLAB_FRAMES=F[:W:H]: another keyframe count (> 64: two visibility words per voxel) / image size than the default scene of these tests
     fr = [int(x) for x in os.environ.get("SLAB_FRAMES", "").split(":") if x]
     sc = synth.make_scene(N=N, F=fr[0] if fr else (5 if mode == "optimize" else 6), W=fr[1] if len(fr) > 1 else 160, H=fr[2] if len(fr) > 2 else 120, model=model)

@@ -25,11 +25,31 @@ def test_oracle_mirrors_the_abi(built):
     # (the oracle's multi-rank mirror is driven through its own phase API by tests/_slab_runner.py: no communicator entry points)
     skip = {"psgsdf_comm_unique_id", "psgsdf_comm_init_ext", "psgsdf_comm_stats", "psgsdf_kernel_times", "psgsdf_reset_kernel_times",
             "psgsdf_set_profiling", "psgsdf_watch_kernel", "psgsdf_debug_time_pcg_pass", "psgsdf_debug_time_pcg_solve", "psgsdf_debug_rare_rows", "psgsdf_debug_sync_stats",
-            "psgsdf_slab_plane_count", "psgsdf_plan_slab", "psgsdf_upload_volume_slab", "psgsdf_rebalance_slabs", "psgsdf_set_record_observer", "psgsdf_set_on_iter_period"}
+            "psgsdf_slab_plane_count", "psgsdf_plan_slab", "psgsdf_upload_volume_slab", "psgsdf_rebalance_slabs", "psgsdf_set_record_observer", "psgsdf_set_on_iter_period", "psgsdf_get_tuning"}
     for n in g._declared_symbols():
         if n in skip:
             continue
         assert hasattr(lib, n.replace("psgsdf_", "orc_")), n
+
+
+def test_dangerous_knobs_are_not_in_the_product_library(built):
+    """the fault-injection / ablation / "skip the check words" environment variables are compiled into libpsgsdf_dev.so only; the
+    product library does not even contain their names as knobs it honours (they appear once, in the list of variables it reports as IGNORED)."""
+    import os
+    prod = open(capi.ENGINE_LIB, "rb").read(); dev = open(capi.ENGINE_LIB_DEV, "rb").read()
+    lib = ctypes.CDLL(capi.ENGINE_LIB); lib.psgsdf_version.restype = ctypes.c_char_p
+    devlib = ctypes.CDLL(capi.ENGINE_LIB_DEV); devlib.psgsdf_version.restype = ctypes.c_char_p
+    assert b"dev" not in lib.psgsdf_version() and b"dev" in devlib.psgsdf_version()
+    for n in g_names():
+        assert hasattr(devlib, n), n
+    for k in (b"PSGSDF_FAULT_SOLVE", b"PSGSDF_FAULT_HALO", b"PSGSDF_PCG_ABLATE", b"PSGSDF_MBOX_CHECK"):
+        assert prod.count(k) == 1 and dev.count(k) >= 1, k      # (one occurrence: the kDevKnobs name table behind "ignored_dev_only")
+    assert os.path.getsize(capi.ENGINE_LIB_DEV) > 0
+
+
+def g_names():
+    import __graft_entry__ as g
+    return g._declared_symbols()
 
 
 def test_comm_entry_points_fail_cleanly_without_a_gpu(built):
@@ -61,7 +81,7 @@ def test_bad_arguments_are_status_codes(built):
 
 def test_no_cpu_fallback_without_library(monkeypatch, tmp_path):
     monkeypatch.setattr(capi, "ENGINE_LIB", str(tmp_path / "missing.so"))
-    monkeypatch.setattr(capi, "_engine_lib", None)
+    monkeypatch.setattr(capi, "_engine_lib", {})
     with pytest.raises(capi.PsgsdfError):
         capi.engine_lib()
 

@@ -185,9 +185,15 @@ def test_persistent_solve_falls_back_to_the_per_pass_kernels(built, name, mid, m
     sc = synth.make_scene(N=40, F=6, W=160, H=120, model=name)
     st = capi.default_settings(mid)
     monkeypatch.setenv("PSGSDF_FAULT_SOLVE", "2")
-    eng = capi.load_engine(sc, sc.K, st, 0)
+    eng = capi.load_engine(sc, sc.K, st, 0, dev=True)      # (fault injection exists in the development build only)
+    prod = capi.load_engine(sc, sc.K, st, 0)
+    tp, td = prod.get_tuning(), eng.get_tuning()
+    assert td["env"]["PSGSDF_FAULT_SOLVE"] == "2" and td["effective"]["fault_solve"] == 2 and "dev" in td["build"]
+    assert tp["ignored_dev_only"] == {"PSGSDF_FAULT_SOLVE": "2"} and tp["effective"]["fault_solve"] == 0 and "PSGSDF_FAULT_SOLVE" not in tp["env"]      # the product library says it ignores it
+    prod.close()
     monkeypatch.delenv("PSGSDF_FAULT_SOLVE"); monkeypatch.setenv("PSGSDF_PCG_PERSIST", "0")
     ref = capi.load_engine(sc, sc.K, st, 0)
+    assert ref.get_tuning()["env"] == {"PSGSDF_PCG_PERSIST": "0"} and ref.get_tuning()["effective"]["pcg_persist"] == 0
     monkeypatch.delenv("PSGSDF_PCG_PERSIST")
     from oracle import oracle
     orc = oracle.Oracle(sc, sc.K, st)

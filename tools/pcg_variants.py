@@ -10,7 +10,8 @@ for spec in (sys.argv[1:] or [""]):
     kv = dict(x.split("=") for x in spec.split(",") if x)
     for k, v in kv.items():
         os.environ[k] = v
-    eng = capi.load_engine(sc, sc.K, st, 0); eng.load_scene(sc); eng.init_albedo(); eng.normalize_weights()
+    eng = capi.load_engine(sc, sc.K, st, 0, dev="PSGSDF_PCG_ABLATE" in kv)      # (the ablations exist in the development build only)
+    eng.load_scene(sc); eng.init_albedo(); eng.normalize_weights()
     t16 = [eng.debug_time_pcg_solve(passes=16, reps=4)[0] for _ in range(8)]
     t48 = [eng.debug_time_pcg_solve(passes=48, reps=4)[0] for _ in range(8)]
     recs = eng.iterate(capi.ALL, 6)

@@ -37,7 +37,7 @@ VARIANTS = {
     "xcdmap99": {"PSGSDF_XCD_MAP": "99"},        # heaviest-first dispatch for every per-observation voxel-major kernel
     "xcdlocal0": {"PSGSDF_PCG_XCD_LOCAL": "0"},  # persistent solve: every record through memory instead of staying in the XCD's L2 where all its readers are
     "spec0": {"PSGSDF_SPECULATE": "0"},          # every iteration closed before the next one starts (round 2)
-    "nocheck": {"PSGSDF_MBOX_CHECK": "0"},      # read-backs taken on the marker's say-so (round 2): expected to deviate now and then
+    "nocheck": {"PSGSDF_MBOX_CHECK": "0", "PSGSDF_USE_DEV_LIB": "1"},      # read-backs taken on the marker's say-so (round 2): expected to deviate now and then
 }
 KNOB_NAMES = sorted({k for v in VARIANTS.values() for k in v})
 FAMILY = {"persist0": "classic", "pipeline0": "classic"}      # which distance-solve recurrences a variant runs (default: pipelined)
