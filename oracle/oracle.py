@@ -12,12 +12,14 @@ from psgradientsdf_amd import capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_HERE, "libpsgsdf_oracle.so")
+LIB_FMA = os.path.join(_HERE, "libpsgsdf_oracle_fma.so")      # the same source with FMA contraction: a second float build (oracle/Makefile), a yardstick for drift
 _lib = None
+_lib_fma = None
 
 
 def build(force=False):
     src = os.path.join(_HERE, "psgsdf_oracle.c")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+    if force or not os.path.exists(LIB) or not os.path.exists(LIB_FMA) or os.path.getmtime(LIB) < os.path.getmtime(src) or os.path.getmtime(LIB_FMA) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
 
 
@@ -29,10 +31,19 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def lib_fma() -> C.CDLL:
+    global _lib_fma
+    if _lib_fma is None:
+        build()
+        _lib_fma = C.CDLL(LIB_FMA)
+    return _lib_fma
+
+
 class Oracle(capi.Api):
-    def __init__(self, sc_or_grid, K, settings, solver_mode=0, threads=1):
+    def __init__(self, sc_or_grid, K, settings, solver_mode=0, threads=1, fma=False):
+        """fma: the FMA-contracted build of the same source (a second float build: the drift yardstick of the whole-run tests, never the checker)"""
         grid = sc_or_grid if isinstance(sc_or_grid, capi.GridDesc) else capi.grid_of(sc_or_grid)
-        super().__init__(lib(), "orc_", grid, K, settings, 0)
+        super().__init__(lib_fma() if fma else lib(), "orc_", grid, K, settings, 0)
         self._lib.orc_set_solver_mode(self.ctx, C.c_int(solver_mode))
         self._lib.orc_set_threads(self.ctx, C.c_int(threads))
 

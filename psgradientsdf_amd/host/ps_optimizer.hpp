@@ -13,6 +13,7 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <fstream>
@@ -25,6 +26,32 @@
 #include "marching_cubes.hpp"
 
 namespace psgsdf_host {
+
+// Wall-clock per stage of a voxelPS run (`voxelPS --timing <file.json>`: VERDICT r04 item 4 -- the Gauss-Newton iterations are milliseconds, the
+// decode / fusion / dump stages around them are what a user waits for).  Scopes nest: a stage's time includes the stages opened inside it.
+struct StageClock {
+    std::vector<std::pair<std::string, double>> acc; std::vector<long long> calls;
+    size_t slot(const std::string& n) { for (size_t i = 0; i < acc.size(); ++i) if (acc[i].first == n) return i; acc.emplace_back(n, 0.0); calls.push_back(0); return acc.size() - 1; }
+    struct Scope {
+        StageClock& c; size_t i; std::chrono::steady_clock::time_point t0;
+        Scope(StageClock& c_, const std::string& n) : c(c_), i(c_.slot(n)), t0(std::chrono::steady_clock::now()) {}
+        ~Scope() { c.acc[i].second += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); c.calls[i] += 1; }
+    };
+    static StageClock& get() { static StageClock c; return c; }
+    double of(const std::string& n) { return acc[slot(n)].second; }
+    bool write_json(const std::string& path, const std::string& extra = "") {
+        std::ofstream f(path.c_str()); if (!f.is_open()) return false;
+        f << "{\"stages_s\": {";
+        for (size_t i = 0; i < acc.size(); ++i) f << (i ? ", " : "") << "\"" << acc[i].first << "\": " << acc[i].second;
+        f << "}, \"calls\": {";
+        for (size_t i = 0; i < acc.size(); ++i) f << (i ? ", " : "") << "\"" << acc[i].first << "\": " << calls[i];
+        f << "}" << extra << "}\n";
+        return true;
+    }
+};
+#define PSG_STAGE_CAT2(a, b) a##b
+#define PSG_STAGE_CAT(a, b) PSG_STAGE_CAT2(a, b)
+#define PSG_STAGE(name) ::psgsdf_host::StageClock::Scope PSG_STAGE_CAT(psg_stage_, __LINE__)(::psgsdf_host::StageClock::get(), name)
 
 using Mat4f = std::array<float, 16>;                 // row-major camera->world
 struct Mat3f { float v[9]; };                        // row-major intrinsics
@@ -118,6 +145,7 @@ struct VolumetricGradSdf {
     void increase_counter() { ++counter_; }
     // VolumetricGradSdf::update (VolumetricGradSdf.cpp:51-138): FALS normals + fusion, both on the device
     bool update(const ImageRGB& color, const std::vector<float>& depth, const Mat4f& pose) {
+        PSG_STAGE("fuse: FALS normals + integration (device, incl. transfers)");
         std::vector<float> nrm((size_t)3 * color.rows * color.cols);
         if (psgsdf_estimate_normals(ctx, depth.data(), color.cols, color.rows, nrm.data())) return false;
         return psgsdf_integrate_frame(ctx, color.data.data(), depth.data(), nrm.data(), color.cols, color.rows, pose.data(), (int)counter_, z_min_, z_max_) == 0;
@@ -127,10 +155,11 @@ struct VolumetricGradSdf {
         dist.resize(n); grad.resize(3 * n); weight.resize(n); rgb.resize(3 * n);
         return psgsdf_download_volume(ctx, dist.data(), grad.data(), weight.data(), rgb.data(), nullptr) == 0;
     }
-    bool extract_mesh(const std::string& filename) { return sync_host() && write_mesh(filename, grid_dim_, voxel_size_, dist, weight, rgb); }
-    bool saveSDF(const std::string& filename) { return sync_host() && write_sdf(filename, grid_dim_, voxel_size_, dist); }
+    bool extract_mesh(const std::string& filename) { PSG_STAGE("dump: mesh (marching cubes + PLY)"); return sync_host() && write_mesh(filename, grid_dim_, voxel_size_, dist, weight, rgb); }
+    bool saveSDF(const std::string& filename) { PSG_STAGE("dump: sdf"); return sync_host() && write_sdf(filename, grid_dim_, voxel_size_, dist); }
     // extract_pc, VolumetricGradSdf.cpp:320-376: x y z nx ny nz r g b of every voxel with |d| < sqrt(3) vs and weight > 0
     bool extract_pc(const std::string& filename) {
+        PSG_STAGE("dump: point cloud");
         if (!sync_host()) return false;
         const size_t n = num_voxels(); std::vector<size_t> sel;
         for (size_t lin = 0; lin < n; ++lin) if (weight[lin] > 0 && std::fabs(dist[lin]) < std::sqrt(3) * voxel_size_) sel.push_back(lin);
@@ -159,6 +188,7 @@ public:
     void set_pose(const Mat4f& p) { pose_ = p; }
     Mat4f pose() const { return pose_; }
     bool optimize(const std::vector<float>& depth, int cols, int rows) {
+        PSG_STAGE("track: frame-to-model (device)");
         int iters = 0, conv = 0;
         if (psgsdf_track(tSDF_->ctx, depth.data(), cols, rows, pose_.data(), tSDF_->z_min_, tSDF_->z_max_, num_iterations_, conv_threshold_, damping_, &iters, &conv)) return false;
         if (conv) std::cout << "... Convergence after " << iters << " iterations!" << std::endl;
@@ -254,6 +284,7 @@ public:
     // PsOptimizer::init / LedOptimizer::init (PsOptimizer.cpp:25-42): with zero keyframes (the constructor-time
     // call of the reference) this is a no-op; with keyframes it creates the device context and uploads everything.
     virtual void init() {
+        PSG_STAGE("optimiser init: keyframe upload + band");
         num_frames_ = frame_idx_.size();
         num_voxels_ = tSDF_->num_voxels();
         if (num_frames_ == 0) return;
@@ -299,6 +330,7 @@ public:
 
     // alternatingOptimize (PsOptimizer.cpp:239-428 / LedOptimizer.cpp:279-478): true = converged
     virtual bool alternatingOptimize(bool light, bool albedo, bool distance, bool pose) {
+        PSG_STAGE("alternatingOptimize: total (incl. its dumps)");
         if (!ctx_) return false;
         doc_.open((save_path_ + "optimizer_doc.txt").c_str());
         std::cout << "albation study settings: \n" << "light: " << light << "\n" << "albedo: " << albedo << "\n" << "distance: " << distance << "\n" << "pose: " << pose << std::endl;
@@ -331,6 +363,7 @@ public:
 
     // copy the refined state back into tSDF_ / poses_ (the reference mutates them in place)
     bool sync_back() {
+        PSG_STAGE("sync back: refined volume to host");
         psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
         size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
         for (int a = 0; a < 3; ++a) tSDF_->grid_dim_[a] = info.dim[a];
@@ -348,6 +381,7 @@ public:
 
     // savePoses, OptimizerAux.cpp:580-599: "stamp tx ty tz qx qy qz qw" with Eigen's matrix->quaternion conversion
     bool savePoses(std::string filename) {
+        PSG_STAGE("dump: poses");
         std::vector<float> P(num_frames_ * 16);
         if (psgsdf_download_poses(ctx_, P.data())) return false;
         std::ofstream posefile((save_path_ + filename + ".txt").c_str());
@@ -372,6 +406,7 @@ public:
 
     // save_pointcloud, OptimizerAux.cpp:456-511 (grid-local coordinates: vox2float, origin not added)
     bool save_pointcloud(std::string filename) {
+        PSG_STAGE("dump: point cloud");
         psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
         size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
         std::vector<float> d(n), g(3 * n), rgb(3 * n); std::vector<int32_t> band(info.n_band);
@@ -398,6 +433,7 @@ public:
 
     // extract_mesh / saveSDF, OptimizerAux.cpp:278-363,513-577
     bool extract_mesh(std::string filename) {
+        PSG_STAGE("dump: mesh (marching cubes + PLY)");
         psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
         size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
         std::vector<float> d(n), w(n), rgb(3 * n);
@@ -407,6 +443,7 @@ public:
         return ok;
     }
     bool saveSDF(std::string filename) {
+        PSG_STAGE("dump: sdf");
         psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
         size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
         std::vector<float> d(n);

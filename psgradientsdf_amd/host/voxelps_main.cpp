@@ -118,8 +118,10 @@ int main(int argc, char* argv[]) {
     if (argc >= 2 && std::string(argv[1]) == "--selftest-mc-table") return selftest_mc_table(false);
     if (argc >= 2 && std::string(argv[1]) == "--selftest-mc-generated") return selftest_mc_table(true);
     if (argc >= 4 && std::string(argv[1]) == "--selftest-mc-ply") return selftest_mc_ply(atoi(argv[2]), argv[3]);
-    std::string configfile;
-    for (int i = 1; i < argc; ++i) { std::string a = argv[i]; if (a == "--config_file" && i + 1 < argc) configfile = argv[++i]; else if (a.rfind("--config_file=", 0) == 0) configfile = a.substr(14); }
+    std::string configfile, timing_file;      // --timing <file.json>: wall-clock per stage (no reference counterpart; the reference's outputs are unchanged)
+    for (int i = 1; i < argc; ++i) { std::string a = argv[i]; if (a == "--config_file" && i + 1 < argc) configfile = argv[++i]; else if (a.rfind("--config_file=", 0) == 0) configfile = a.substr(14);
+        else if (a == "--timing" && i + 1 < argc) timing_file = argv[++i]; }
+    const auto t_main0 = std::chrono::steady_clock::now();
     std::cout << "load the config file from: " << configfile << std::endl;
     JsonObject config;
     if (!config.load(configfile)) { std::cout << "can't load config file!" << std::endl << "fail to load the config file!" << std::endl; return 1; }
@@ -193,7 +195,7 @@ int main(int argc, char* argv[]) {
     Mat4f cur_pose = I4;
     for (size_t i = first; i <= last; ++i) {
         std::cout << "Working on frame: " << i << std::endl;
-        if (!loader->load_next(color, depth)) { std::cerr << " -> Frame " << i << " could not be loaded!" << std::endl; break; }
+        { PSG_STAGE("decode: PNG colour + depth (host)"); if (!loader->load_next(color, depth)) { std::cerr << " -> Frame " << i << " could not be loaded!" << std::endl; break; } }
         if (GT_pose && i >= poses.size()) break;
         if (i == first) {
             float centroid[3]; compute_centroid(K, depth, poses[0], centroid);
@@ -219,7 +221,8 @@ int main(int argc, char* argv[]) {
             else { bool conv = pOpt->optimize(depth.data, depth.cols, depth.rows); cur_pose = pOpt->pose(); if (conv) integrated = tSDF->update(color, depth.data, cur_pose); }
             if (!integrated && tSDF->last_error()[0]) { std::cerr << " -> Frame " << i << " could not be fused: " << tSDF->last_error() << std::endl; return 1; }   // a frame that is not in the volume must not become a keyframe
             if (integrated) {
-                if (sharpDetector(color, sharp_thr) || dist_to_last_keyframe > 5) {
+                bool sharp; { PSG_STAGE("keyframe selection: focus measure (host)"); sharp = sharpDetector(color, sharp_thr); }
+                if (sharp || dist_to_last_keyframe > 5) {
                     dist_to_last_keyframe = 0;
                     keyframes.push_back((int)(i - first)); key_stamps.push_back(loader->rgb_timestamp()); key_poses.push_back(cur_pose);
                     key_images.push_back(std::make_shared<ImageRGB>(color));
@@ -241,5 +244,11 @@ int main(int argc, char* argv[]) {
     vOpt->init();
     vOpt->alternatingOptimize(light, albedo, distance, pose);
     delete vOpt; delete pOpt; delete tSDF; delete loader; delete opt_set_;
+    if (!timing_file.empty()) {
+        char extra[256];
+        snprintf(extra, sizeof(extra), ", \"total_s\": %.6f, \"frames\": %zu, \"keyframes\": %zu", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main0).count(),
+                 (size_t)(last == (size_t)-1 ? 0 : last - first + 1), keyframes.size());
+        StageClock::get().write_json(timing_file, extra);
+    }
     return 0;
 }
