@@ -216,7 +216,8 @@ int psgsdf_upsample2x(psgsdf_ctx* ctx);
 int psgsdf_volume_init(psgsdf_ctx* ctx, int max_frames);
 /* VolumetricGradSdf::update (VolumetricGradSdf.cpp:51-138): fuse one RGB-D frame into the volume.
  * rgb: H*W*3 float RGB; depth: H*W metres (0 = invalid); normals_xyz: 3 planes of H*W, camera-frame, inward
- * pointing unit normals (what NormalEstimator::compute returns, NormalEstimator.h:150-176); pose: 4x4 row-major
+ * pointing unit normals (what NormalEstimator::compute returns, NormalEstimator.h:150-176) -- or NULL: the engine
+ * estimates them itself from `depth` on the device, as VolumetricGradSdf::update does (:59-61); pose: 4x4 row-major
  * camera->world; counter: index of this frame in the sequence (the visibility bit it sets, Sdf.h increase_counter). */
 int psgsdf_integrate_frame(psgsdf_ctx* ctx, const float* rgb, const float* depth, const float* normals_xyz,
                            int width, int height, const float pose[16], int counter, float z_min, float z_max);
@@ -246,6 +247,26 @@ int psgsdf_download_poses(psgsdf_ctx* ctx, float* poses);
 /* light_: n_frames * light_stride (SH) or 3 floats (LED) */
 int psgsdf_download_light(psgsdf_ctx* ctx, float* light);
 int psgsdf_upload_light(psgsdf_ctx* ctx, const float* light);
+
+/* ---- the writers' geometry, extracted on the device ---------------------- */
+
+/* What the reference writes every third iteration (PsOptimizer.cpp:419-423) is computed from the dense state: a mesh by marching cubes and a point
+ * cloud of the band.  These calls do that on the device and hand back compact arrays in engine-owned pinned host memory, valid until the next
+ * extraction call on the context; the host only formats text.  Single-rank contexts.
+ *
+ * psgsdf_extract_mesh: Optimizer::extract_mesh (OptimizerAux.cpp:278-363) = crop box of |d| <= sqrt(3) vs, tsdf = -dist, 8-bit colours, then
+ *   MarchingCubes::computeIsoSurface / computeTriangles (third/mesh/MarchingCubes.cpp:314-637): cells in (z, y, x) order, faces in the classic
+ *   table's order, degenerate faces dropped, non-indexed vertices.  xyz: n_vertices * 3 floats in grid-local coordinates (three consecutive
+ *   vertices = one face), rgb: n_vertices * 3 bytes.  The same floats and bytes as the host-side pass (host/marching_cubes.hpp), so *_mesh.ply
+ *   comes out byte for byte.
+ * psgsdf_extract_pointcloud: which = 0: Optimizer::save_pointcloud (OptimizerAux.cpp:456-511): the band voxels (ascending) with |d| < sqrt(3) vs;
+ *   which = 1: VolumetricGradSdf::extract_pc (VolumetricGradSdf.cpp:320-376): every voxel with weight > 0 and |d| < sqrt(3) vs.
+ *   xyz_nxyz: n_points * 6 floats (x - d g^ in grid-local coordinates, then g^), rgb: n_points * 3 ints = int(255 * colour), as the reference prints them.
+ * psgsdf_extract_sdf: the block Optimizer::saveSDF / VolumetricGradSdf::saveSDF write (OptimizerAux.cpp:513-577): lo = first voxel of the crop box,
+ *   dim = its extent, neg_dist = dim[0] * dim[1] * dim[2] values of -dist, x fastest.  dim = 0 if no voxel lies within sqrt(3) vs of the surface. */
+int psgsdf_extract_mesh(psgsdf_ctx* ctx, const float** xyz, const uint8_t** rgb, int64_t* n_vertices);
+int psgsdf_extract_pointcloud(psgsdf_ctx* ctx, int which, const float** xyz_nxyz, const int32_t** rgb, int64_t* n_points);
+int psgsdf_extract_sdf(psgsdf_ctx* ctx, int32_t lo[3], int32_t dim[3], const float** neg_dist);
 
 /* ---- multi-GPU (z-slab partition, one context per rank, one process per GPU) -------------- */
 

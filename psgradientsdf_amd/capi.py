@@ -314,6 +314,32 @@ class Api:
                                                  vis.ctypes.data_as(C.c_void_p) if want_vis else None), "download_volume")
         return dict(dist=dist, grad=grad, weight=weight, rgb=rgb, vis=vis)
 
+    # -- the writers' geometry, extracted on the device (valid until the next extraction: copied here)
+    def extract_mesh(self):
+        """(xyz [n_vertices, 3] float32 grid-local, rgb [n_vertices, 3] uint8): three consecutive vertices are one face (psgsdf_extract_mesh)"""
+        xyz = C.POINTER(C.c_float)(); rgb = C.POINTER(C.c_uint8)(); n = C.c_int64()
+        self._check(self._fn("extract_mesh")(self.ctx, C.byref(xyz), C.byref(rgb), C.byref(n)), "extract_mesh")
+        if n.value == 0:
+            return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint8)
+        return np.ctypeslib.as_array(xyz, shape=(n.value, 3)).copy(), np.ctypeslib.as_array(rgb, shape=(n.value, 3)).copy()
+
+    def extract_pointcloud(self, which=0):
+        """(xyz_nxyz [n, 6] float32, rgb [n, 3] int32); which = 0: the band voxels, 1: every fused voxel (psgsdf_extract_pointcloud)"""
+        pn = C.POINTER(C.c_float)(); col = C.POINTER(C.c_int32)(); n = C.c_int64()
+        self._check(self._fn("extract_pointcloud")(self.ctx, C.c_int(which), C.byref(pn), C.byref(col), C.byref(n)), "extract_pointcloud")
+        if n.value == 0:
+            return np.zeros((0, 6), np.float32), np.zeros((0, 3), np.int32)
+        return np.ctypeslib.as_array(pn, shape=(n.value, 6)).copy(), np.ctypeslib.as_array(col, shape=(n.value, 3)).copy()
+
+    def extract_sdf(self):
+        """(lo [3], dim [3], -dist block [dim2, dim1, dim0]) of the crop box |d| <= sqrt(3) vs (psgsdf_extract_sdf)"""
+        lo = (C.c_int32 * 3)(); dim = (C.c_int32 * 3)(); v = C.POINTER(C.c_float)()
+        self._check(self._fn("extract_sdf")(self.ctx, lo, dim, C.byref(v)), "extract_sdf")
+        d = list(dim)
+        if d[0] == 0:
+            return list(lo), d, np.zeros((0, 0, 0), np.float32)
+        return list(lo), d, np.ctypeslib.as_array(v, shape=(d[2], d[1], d[0])).copy()
+
     def download_band(self, n=None):
         """one rank: the whole band.  A slab of a multi-rank run: pass n = row1 - row0 of mg_info (its own band voxels)"""
         if n is None:

@@ -118,6 +118,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->frames_undo); hipFree(c->led_light);
     hipFree(c->band_mem); if (!c->leak_exported) hipFree(c->rec_mem); hipFree(c->obs_mem); hipFree(c->stage);
     hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->frame_part); hipFree(c->frame_done); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->pcg_gran); hipFree(c->d_total);
+    for (void* p : c->xo_host) if (p) hipHostFree(p);
     if (c->host_buf) hipHostFree(c->host_buf);
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
@@ -322,7 +323,7 @@ int psgsdf_rebalance_slabs(psgsdf_ctx* c) {
 
 int psgsdf_integrate_frame(psgsdf_ctx* c, const float* rgb, const float* depth, const float* normals_xyz, int width, int height, const float pose[16], int counter, float z_min, float z_max) {
     if (!c || !c->have_volume || !c->vis_seq) return fail(c, PSGSDF_ERR_STATE, "integrate_frame: volume_init or upload_volume first");
-    if (!rgb || !depth || !normals_xyz || !pose || width < 2 || height < 2 || counter < 0) return fail(c, PSGSDF_ERR_ARG, "integrate_frame: bad argument");      // (multi-rank: every rank fuses the frame into the planes it holds, halo planes included -- no exchange)
+    if (!rgb || !depth || !pose || width < 2 || height < 2 || counter < 0) return fail(c, PSGSDF_ERR_ARG, "integrate_frame: bad argument");      // (multi-rank: every rank fuses the frame into the planes it holds, halo planes included -- no exchange)
     HIPCHK(c, hipSetDevice(c->device));
     if (counter >= 64 * c->wpv_seq) {   // the sequence is longer than volume_init was told (the reference's vector<bool> simply grows): widen the per-voxel words
         const long long n = c->grid.nvox;
@@ -343,7 +344,10 @@ int psgsdf_integrate_frame(psgsdf_ctx* c, const float* rgb, const float* depth, 
     float* d_rgb = c->stage; float* d_depth = c->stage + 3 * npx; float* d_nrm = c->stage + 4 * npx;
     HIPCHK(c, hipMemcpyAsync(d_rgb, rgb, sizeof(float) * 3 * npx, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_depth, depth, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_nrm, normals_xyz, sizeof(float) * 3 * npx, hipMemcpyHostToDevice, c->stream));
+    if (normals_xyz) HIPCHK(c, hipMemcpyAsync(d_nrm, normals_xyz, sizeof(float) * 3 * npx, hipMemcpyHostToDevice, c->stream));
+    else {      // normals_xyz == NULL: NormalEstimator::compute on the depth map that is on the device already (what VolumetricGradSdf::update does, VolumetricGradSdf.cpp:59-61) -- no 3-plane round trip through the host
+        int nrc = frontend_normals_dev(c, d_depth, width, height, d_nrm); if (nrc) return nrc;
+    }
     Cam cam = c->cam; cam.W = width; cam.H = height;
     FrameP fp{};
     for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) fp.R[i * 3 + j] = pose[i * 4 + j]; fp.t[i] = pose[i * 4 + 3]; }

@@ -42,6 +42,15 @@ int normals_cache(psgsdf_ctx* c, int W, int H) {
 }
 }  // namespace
 
+// FALS normals of a depth map that is on the device already, into 3 device planes (psgsdf_integrate_frame with normals_xyz == NULL)
+namespace psge {
+int frontend_normals_dev(psgsdf_ctx* c, const float* d_depth, int width, int height, float* d_normals) {
+    int rc = normals_cache(c, width, height); if (rc) return rc;
+    timed(c, "normals", [&] { launch_normals(d_depth, c->ncache, width, height, 5, c->ntmp, d_normals, c->stream); });
+    return 0;
+}
+}  // namespace psge
+
 extern "C" int psgsdf_estimate_normals(psgsdf_ctx* c, const float* depth, int width, int height, float* normals_xyz) {
     if (!c || !depth || !normals_xyz || width < 2 || height < 2) return fail(c, PSGSDF_ERR_ARG, "estimate_normals: bad argument");
     HIPCHK(c, hipSetDevice(c->device));

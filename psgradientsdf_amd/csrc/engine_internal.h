@@ -121,6 +121,7 @@ struct psgsdf_ctx {
     bool xr_mapped = false;              // peers may hold IPC mappings of xr / rec_mem: they have to be closed everywhere before either is freed (xr_quiesce)
     unsigned long long xr_openers = 0;   // bit r: rank r opened this rank's region at the last set-up (agreed there); xr_quiesce waits for exactly those
     long long xr_serial = 0, xr_closed_off = 0;   // number of the last set-up (the same on every rank) and where the R "closed" slots of a region sit
+    void* xo_host[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; size_t xo_bytes[5] = {0, 0, 0, 0, 0};   // pinned host results of the extraction calls (extract.hip): mesh xyz / rgb, point cloud xyz+n / rgb, sdf block; valid until the next extraction
     long long xr_stale_maps = 0;         // mappings that did not show their owner's nonce (xr_setup)
     bool leak_exported = false;          // a peer never reported its mappings closed: xr / rec_mem / hx_mem are never freed by this context
     std::vector<double*> xr_peer;        // [n_ranks] (own entry = xr)
@@ -240,6 +241,7 @@ int xr_alloc(psgsdf_ctx* c, void** p, size_t bytes, bool polled);     // comm.hi
 int mg_commit(psgsdf_ctx* c);                                          // engine.hip: all-reduce + deliver the staged scalar read-backs
 int set_local_grid(psgsdf_ctx* c, int z0, int z1);                     // engine.hip: this context owns global planes [z0, z1) (+ halo planes)
 
+int frontend_normals_dev(psgsdf_ctx* c, const float* d_depth, int width, int height, float* d_normals);   // api_frontend.hip: FALS normals, device to device
 // ---- engine.hip
 SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg);
 // slab mode: the context is attached to a communicator (also a one-rank one: the exchanges then run as one-rank collectives, which is how

@@ -2,6 +2,8 @@
 // intrinsics (9 floats), depth PNG16 * unit -> float metres, colour PNG8 -> float RGB / 255 (the reference keeps BGR, the
 // engine wants RGB), TUM-format pose file "stamp tx ty tz qx qy qz qw".
 #pragma once
+#include <deque>
+#include <future>
 #include <iomanip>
 #include <sstream>
 
@@ -51,6 +53,10 @@ public:
     }
     virtual bool load_next(ImageRGB& color, DepthImage& depth) = 0;
     virtual void reset_counter() {}
+    // The two halves of load_next: naming the next frame's files (cheap, sequential, sets the time stamps) and decoding them (expensive, touches no
+    // loader state: safe on worker threads).  FramePrefetcher below decodes several frames ahead of the fusion.
+    virtual bool next_names(std::string& depth_fn, std::string& rgb_fn) = 0;
+    bool decode(const std::string& depth_fn, const std::string& rgb_fn, ImageRGB& color, DepthImage& depth) { return load_depth(depth_fn, depth) && load_color(rgb_fn, color); }
     // ImageLoader.h:228-258 (Eigen::Quaternionf::toRotationMatrix)
     bool load_pose(const std::string& filename, std::vector<Mat4f>& poses) {
         std::ifstream file((path_ + filename).c_str());
@@ -73,13 +79,16 @@ class SynthLoader : public ImageLoader {
     size_t counter = 1;
 public:
     explicit SynthLoader(const std::string& path) : ImageLoader(1.f / 1000, path) {}
-    bool load_next(ImageRGB& color, DepthImage& depth) override {
+    bool next_names(std::string& depth_fn, std::string& rgb_fn) override {
         std::stringstream ss; ss << std::setfill('0') << std::setw(3) << counter;
         timestamp_rgb_ = ss.str(); timestamp_depth_ = timestamp_rgb_;
-        const std::string fn = timestamp_rgb_ + ".png";
-        if (!load_depth("depth/" + fn, depth)) return false;
-        if (!load_color("rgb/" + fn, color)) return false;
+        depth_fn = "depth/" + timestamp_rgb_ + ".png"; rgb_fn = "rgb/" + timestamp_rgb_ + ".png";
         ++counter; return true;
+    }
+    bool load_next(ImageRGB& color, DepthImage& depth) override {
+        std::string d, r; next_names(d, r);
+        if (!load_depth(d, depth) || !load_color(r, color)) { --counter; return false; }      // (the reference only counts a frame it could load)
+        return true;
     }
     void reset_counter() override { counter = 1; }
 };
@@ -88,13 +97,16 @@ class MultiviewLoader : public ImageLoader {
     size_t counter = 1;
 public:
     explicit MultiviewLoader(const std::string& path) : ImageLoader(1.f / 1000, path) {}
-    bool load_next(ImageRGB& color, DepthImage& depth) override {
+    bool next_names(std::string& depth_fn, std::string& rgb_fn) override {
         std::stringstream ss; ss << std::setfill('0') << std::setw(6) << counter;
         timestamp_rgb_ = ss.str(); timestamp_depth_ = timestamp_rgb_;
-        const std::string fn = timestamp_rgb_ + ".png";
-        if (!load_depth("depth" + fn, depth)) return false;
-        if (!load_color("color" + fn, color)) return false;
+        depth_fn = "depth" + timestamp_rgb_ + ".png"; rgb_fn = "color" + timestamp_rgb_ + ".png";
         ++counter; return true;
+    }
+    bool load_next(ImageRGB& color, DepthImage& depth) override {
+        std::string d, r; next_names(d, r);
+        if (!load_depth(d, depth) || !load_color(r, color)) { --counter; return false; }
+        return true;
     }
     void reset_counter() override { counter = 1; }
 };
@@ -103,12 +115,48 @@ class TumrgbdLoader : public ImageLoader {
     std::ifstream assoc_;
 public:
     explicit TumrgbdLoader(const std::string& path) : ImageLoader(1.f / 5000, path) { assoc_.open(path_ + "associated.txt"); }
-    bool load_next(ImageRGB& color, DepthImage& depth) override {
-        std::string line = "#", rgb_fn, depth_fn;
+    bool next_names(std::string& depth_fn, std::string& rgb_fn) override {
+        std::string line = "#";
         while (line.empty() || line.at(0) == '#') if (!std::getline(assoc_, line)) return false;
         std::istringstream ss(line); ss >> timestamp_rgb_ >> rgb_fn >> timestamp_depth_ >> depth_fn;
-        if (!load_depth(depth_fn, depth)) return false;
-        return load_color(rgb_fn, color);
+        return true;
+    }
+    bool load_next(ImageRGB& color, DepthImage& depth) override {
+        std::string d, r;
+        if (!next_names(d, r)) return false;
+        if (!load_depth(d, depth)) return false;
+        return load_color(r, color);
+    }
+};
+
+// Decodes the PNGs of the next few frames on worker threads while the current frame is being fused / tracked (a 1139 x 1709
+// colour + depth pair takes ~50 ms of single-threaded inflate + unfilter; the fusion of a frame takes a few ms).  Frames come out in sequence order
+// with their time stamps; a frame that cannot be read ends the sequence there, exactly as load_next would have.
+class FramePrefetcher {
+public:
+    struct Frame { bool ok = false; ImageRGB color; DepthImage depth; std::string rgb_stamp, depth_stamp; };
+private:
+    ImageLoader* l_; size_t window_; bool exhausted_ = false;
+    std::deque<std::future<std::shared_ptr<Frame>>> q_;
+    void fill() {
+        while (!exhausted_ && q_.size() < window_) {
+            std::string d, r;
+            if (!l_->next_names(d, r)) { exhausted_ = true; break; }
+            const std::string rs = l_->rgb_timestamp(), ds = l_->depth_timestamp();
+            ImageLoader* l = l_;
+            q_.push_back(std::async(std::launch::async, [l, d, r, rs, ds] { auto f = std::make_shared<Frame>(); f->rgb_stamp = rs; f->depth_stamp = ds; f->ok = l->decode(d, r, f->color, f->depth); return f; }));
+        }
+    }
+public:
+    FramePrefetcher(ImageLoader* l, size_t window) : l_(l), window_(std::max<size_t>(1, window)) {}
+    // the next frame of the sequence, or null when the files are exhausted / unreadable
+    std::shared_ptr<Frame> next() {
+        fill();
+        if (q_.empty()) return nullptr;
+        auto f = q_.front().get(); q_.pop_front();
+        if (!f->ok) { exhausted_ = true; q_.clear(); return nullptr; }
+        fill();
+        return f;
     }
 };
 

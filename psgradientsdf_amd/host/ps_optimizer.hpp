@@ -15,6 +15,13 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdint>
 #include <fstream>
 #include <iostream>
@@ -30,12 +37,12 @@ namespace psgsdf_host {
 // Wall-clock per stage of a voxelPS run (`voxelPS --timing <file.json>`: VERDICT r04 item 4 -- the Gauss-Newton iterations are milliseconds, the
 // decode / fusion / dump stages around them are what a user waits for).  Scopes nest: a stage's time includes the stages opened inside it.
 struct StageClock {
-    std::vector<std::pair<std::string, double>> acc; std::vector<long long> calls;
-    size_t slot(const std::string& n) { for (size_t i = 0; i < acc.size(); ++i) if (acc[i].first == n) return i; acc.emplace_back(n, 0.0); calls.push_back(0); return acc.size() - 1; }
+    std::vector<std::pair<std::string, double>> acc; std::vector<long long> calls; std::mutex mu;      // (the background writer thread books its stages too)
+    size_t slot(const std::string& n) { std::lock_guard<std::mutex> g(mu); for (size_t i = 0; i < acc.size(); ++i) if (acc[i].first == n) return i; acc.emplace_back(n, 0.0); calls.push_back(0); return acc.size() - 1; }
     struct Scope {
         StageClock& c; size_t i; std::chrono::steady_clock::time_point t0;
         Scope(StageClock& c_, const std::string& n) : c(c_), i(c_.slot(n)), t0(std::chrono::steady_clock::now()) {}
-        ~Scope() { c.acc[i].second += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); c.calls[i] += 1; }
+        ~Scope() { const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> g(c.mu); c.acc[i].second += dt; c.calls[i] += 1; }
     };
     static StageClock& get() { static StageClock c; return c; }
     double of(const std::string& n) { return acc[slot(n)].second; }
@@ -71,6 +78,79 @@ struct OptimizerSettings {                           // OptimizerSettings.h:24-5
     bool upsample = false;
     ModelType model = SH1;
     LossFunction loss = CAUCHY;
+};
+
+// ---- the ASCII writers -----------------------------------------------------------------------------------------------------------------
+// The reference prints every number through `ostream << float`, i.e. printf's %g with six significant digits, one std::endl (= a flush) per line;
+// its files are tens of MB of that.  Same characters here, from snprintf into per-thread buffers (the lines of a file are formatted in parallel
+// chunks and written in order), on a background thread, so that the optimisation goes on while a dump is being formatted.
+inline bool& host_writers() { static bool v = false; return v; }      // voxelPS --host-writers: round 4's path (dense download, host marching cubes, iostream): the cross-check
+struct TextOut {
+    std::string s;
+    void f(float v) { char t[40]; const int n = snprintf(t, sizeof t, "%g", (double)v); s.append(t, (size_t)n); }
+    void i(long long v) { char t[24]; const int n = snprintf(t, sizeof t, "%lld", v); s.append(t, (size_t)n); }
+    void c(char ch) { s.push_back(ch); }
+};
+// n lines, line(out, i) appends line i; formatted on up to 16 threads, written in order
+template <class Fn>
+inline bool write_lines(FILE* f, size_t n, size_t approx_line_bytes, Fn line) {
+    unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (n < 50000) T = 1;
+    std::vector<TextOut> parts(T);
+    auto work = [&](unsigned t) { const size_t a = n * t / T, b = n * (t + 1) / T; parts[t].s.reserve((b - a) * approx_line_bytes); for (size_t q = a; q < b; ++q) line(parts[t], q); };
+    if (T == 1) work(0);
+    else { std::vector<std::thread> th; for (unsigned t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+    for (auto& p : parts) if (!p.s.empty() && fwrite(p.s.data(), 1, p.s.size(), f) != p.s.size()) return false;
+    return true;
+}
+// MarchingCubes::savePly (third/mesh/MarchingCubes.cpp:659-699) from non-indexed vertices: 3 per face
+inline bool write_mesh_ply(const std::string& file, const float* xyz, const uint8_t* rgb, size_t nv) {
+    if (nv == 0) return false;
+    FILE* f = fopen(file.c_str(), "wb"); if (!f) return false;
+    fprintf(f, "ply\nformat ascii 1.0\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
+               "element face %d\nproperty list uchar int vertex_indices\nend_header\n", nv, (int)(nv / 3));
+    bool ok = write_lines(f, nv, 40, [&](TextOut& o, size_t i) { o.f(xyz[3 * i]); o.c(' '); o.f(xyz[3 * i + 1]); o.c(' '); o.f(xyz[3 * i + 2]); o.c(' '); o.i(rgb[3 * i]); o.c(' '); o.i(rgb[3 * i + 1]); o.c(' '); o.i(rgb[3 * i + 2]); o.c('\n'); });
+    ok = ok && write_lines(f, nv / 3, 24, [&](TextOut& o, size_t q) { o.c('3'); o.c(' '); o.i((long long)(3 * q)); o.c(' '); o.i((long long)(3 * q + 1)); o.c(' '); o.i((long long)(3 * q + 2)); o.c('\n'); });
+    return fclose(f) == 0 && ok;
+}
+// save_pointcloud / extract_pc (OptimizerAux.cpp:456-511, VolumetricGradSdf.cpp:320-376): x y z nx ny nz r g b
+inline bool write_pointcloud_ply(const std::string& file, const float* pn, const int32_t* col, size_t n) {
+    FILE* f = fopen(file.c_str(), "wb"); if (!f) return false;
+    fprintf(f, "ply\nformat ascii 1.0\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+               "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n", n);
+    const bool ok = write_lines(f, n, 80, [&](TextOut& o, size_t i) { for (int k = 0; k < 6; ++k) { o.f(pn[6 * i + k]); o.c(' '); } o.i(col[3 * i]); o.c(' '); o.i(col[3 * i + 1]); o.c(' '); o.i(col[3 * i + 2]); o.c('\n'); });
+    return fclose(f) == 0 && ok;
+}
+// saveSDF (OptimizerAux.cpp:513-577): dims, the box's first voxel in metres, the voxel size, then -dist, x fastest
+inline bool write_sdf_block(const std::string& file, const int lo[3], const int dim[3], float vs, const float* v) {
+    FILE* f = fopen(file.c_str(), "wb"); if (!f) return false;
+    TextOut h; h.i(dim[0]); h.c(' '); h.i(dim[1]); h.c(' '); h.i(dim[2]); h.c('\n'); h.f(lo[0] * vs); h.c(' '); h.f(lo[1] * vs); h.c(' '); h.f(lo[2] * vs); h.c('\n'); h.f(vs); h.c('\n');
+    bool ok = fwrite(h.s.data(), 1, h.s.size(), f) == h.s.size();
+    ok = ok && write_lines(f, (size_t)dim[0] * dim[1] * dim[2], 12, [&](TextOut& o, size_t i) { o.f(v[i]); o.c('\n'); });
+    return fclose(f) == 0 && ok;
+}
+// One background thread that formats and writes the dumps in the order they were issued; drain() before anything that must see the files.
+class DumpQueue {
+    std::thread th_; std::mutex m_; std::condition_variable cv_, idle_; std::deque<std::function<void()>> q_; bool stop_ = false, busy_ = false;
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            { std::unique_lock<std::mutex> l(m_); cv_.wait(l, [&] { return stop_ || !q_.empty(); }); if (q_.empty()) return; job = std::move(q_.front()); q_.pop_front(); busy_ = true; }
+            { PSG_STAGE("background: format + write the dump files"); job(); }
+            { std::lock_guard<std::mutex> l(m_); busy_ = false; }
+            idle_.notify_all();
+        }
+    }
+public:
+    static DumpQueue& get() { static DumpQueue q; return q; }
+    void push(std::function<void()> job) {
+        if (host_writers()) { job(); return; }
+        std::lock_guard<std::mutex> l(m_);
+        if (!th_.joinable()) th_ = std::thread([this] { run(); });
+        q_.push_back(std::move(job)); cv_.notify_one();
+    }
+    void drain() { PSG_STAGE("wait for the background writer"); std::unique_lock<std::mutex> l(m_); idle_.wait(l, [&] { return q_.empty() && !busy_; }); }
+    ~DumpQueue() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
 };
 
 struct DepthImage;
@@ -146,20 +226,55 @@ struct VolumetricGradSdf {
     // VolumetricGradSdf::update (VolumetricGradSdf.cpp:51-138): FALS normals + fusion, both on the device
     bool update(const ImageRGB& color, const std::vector<float>& depth, const Mat4f& pose) {
         PSG_STAGE("fuse: FALS normals + integration (device, incl. transfers)");
-        std::vector<float> nrm((size_t)3 * color.rows * color.cols);
-        if (psgsdf_estimate_normals(ctx, depth.data(), color.cols, color.rows, nrm.data())) return false;
-        return psgsdf_integrate_frame(ctx, color.data.data(), depth.data(), nrm.data(), color.cols, color.rows, pose.data(), (int)counter_, z_min_, z_max_) == 0;
+        if (host_writers()) {      // (round 4's path: the normals come back to the host and go up again)
+            std::vector<float> nrm((size_t)3 * color.rows * color.cols);
+            if (psgsdf_estimate_normals(ctx, depth.data(), color.cols, color.rows, nrm.data())) return false;
+            return psgsdf_integrate_frame(ctx, color.data.data(), depth.data(), nrm.data(), color.cols, color.rows, pose.data(), (int)counter_, z_min_, z_max_) == 0;
+        }
+        return psgsdf_integrate_frame(ctx, color.data.data(), depth.data(), nullptr, color.cols, color.rows, pose.data(), (int)counter_, z_min_, z_max_) == 0;      // NULL: FALS normals on the device
     }
     bool sync_host() {
         const size_t n = num_voxels();
         dist.resize(n); grad.resize(3 * n); weight.resize(n); rgb.resize(3 * n);
         return psgsdf_download_volume(ctx, dist.data(), grad.data(), weight.data(), rgb.data(), nullptr) == 0;
     }
-    bool extract_mesh(const std::string& filename) { PSG_STAGE("dump: mesh (marching cubes + PLY)"); return sync_host() && write_mesh(filename, grid_dim_, voxel_size_, dist, weight, rgb); }
-    bool saveSDF(const std::string& filename) { PSG_STAGE("dump: sdf"); return sync_host() && write_sdf(filename, grid_dim_, voxel_size_, dist); }
+    bool extract_mesh(const std::string& filename) {
+        PSG_STAGE("dump: mesh (marching cubes + PLY)");
+        if (ctx && !host_writers()) return device_mesh(ctx, filename);
+        return sync_host() && write_mesh(filename, grid_dim_, voxel_size_, dist, weight, rgb);
+    }
+    bool saveSDF(const std::string& filename) {
+        PSG_STAGE("dump: sdf");
+        if (ctx && !host_writers()) return device_sdf(ctx, filename, voxel_size_);
+        return sync_host() && write_sdf(filename, grid_dim_, voxel_size_, dist);
+    }
+    // the device-side extraction (include/psgsdf.h psgsdf_extract_*): compact arrays come back, a copy of them goes to the background writer
+    static bool device_mesh(psgsdf_ctx* ctx, const std::string& file) {
+        const float* xyz = nullptr; const uint8_t* rgb = nullptr; int64_t nv = 0;
+        if (psgsdf_extract_mesh(ctx, &xyz, &rgb, &nv) || nv == 0) return false;
+        auto vx = std::make_shared<std::vector<float>>(xyz, xyz + 3 * nv); auto vc = std::make_shared<std::vector<uint8_t>>(rgb, rgb + 3 * nv);
+        DumpQueue::get().push([=] { if (!write_mesh_ply(file, vx->data(), vc->data(), (size_t)nv)) std::cout << "couldn't save mesh " << file << std::endl; });
+        return true;
+    }
+    static bool device_pointcloud(psgsdf_ctx* ctx, int which, const std::string& file) {
+        const float* pn = nullptr; const int32_t* col = nullptr; int64_t n = 0;
+        if (psgsdf_extract_pointcloud(ctx, which, &pn, &col, &n)) return false;
+        auto vp = std::make_shared<std::vector<float>>(pn, pn + 6 * n); auto vc = std::make_shared<std::vector<int32_t>>(col, col + 3 * n);
+        DumpQueue::get().push([=] { if (!write_pointcloud_ply(file, vp->data(), vc->data(), (size_t)n)) std::cout << " can't save point cloud!" << std::endl; });
+        return true;
+    }
+    static bool device_sdf(psgsdf_ctx* ctx, const std::string& file, float vs) {
+        int32_t lo[3], dim[3]; const float* v = nullptr;
+        if (psgsdf_extract_sdf(ctx, lo, dim, &v) || !v) return false;
+        auto vv = std::make_shared<std::vector<float>>(v, v + (size_t)dim[0] * dim[1] * dim[2]);
+        const std::array<int, 3> l{lo[0], lo[1], lo[2]}, d{dim[0], dim[1], dim[2]};
+        DumpQueue::get().push([=] { write_sdf_block(file, l.data(), d.data(), vs, vv->data()); });
+        return true;
+    }
     // extract_pc, VolumetricGradSdf.cpp:320-376: x y z nx ny nz r g b of every voxel with |d| < sqrt(3) vs and weight > 0
     bool extract_pc(const std::string& filename) {
         PSG_STAGE("dump: point cloud");
+        if (ctx && !host_writers()) return device_pointcloud(ctx, 1, filename);
         if (!sync_host()) return false;
         const size_t n = num_voxels(); std::vector<size_t> sel;
         for (size_t lin = 0; lin < n; ++lin) if (weight[lin] > 0 && std::fabs(dist[lin]) < std::sqrt(3) * voxel_size_) sel.push_back(lin);
@@ -358,6 +473,7 @@ public:
         settings_->reg_weight_n = info.reg_weight_n; settings_->reg_weight_l = info.reg_weight_l;
         sync_back();
         doc_.close();
+        DumpQueue::get().drain();      // the reference has written its files when alternatingOptimize returns
         return result != 0;
     }
 
@@ -407,6 +523,7 @@ public:
     // save_pointcloud, OptimizerAux.cpp:456-511 (grid-local coordinates: vox2float, origin not added)
     bool save_pointcloud(std::string filename) {
         PSG_STAGE("dump: point cloud");
+        if (!host_writers()) return VolumetricGradSdf::device_pointcloud(ctx_, 0, save_path_ + filename + "_pointcloud.ply");
         psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
         size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
         std::vector<float> d(n), g(3 * n), rgb(3 * n); std::vector<int32_t> band(info.n_band);
@@ -434,6 +551,11 @@ public:
     // extract_mesh / saveSDF, OptimizerAux.cpp:278-363,513-577
     bool extract_mesh(std::string filename) {
         PSG_STAGE("dump: mesh (marching cubes + PLY)");
+        if (!host_writers()) {
+            const bool ok = VolumetricGradSdf::device_mesh(ctx_, save_path_ + filename + "_mesh.ply");
+            if (!ok) std::cout << "couldn't save mesh " << save_path_ << filename << std::endl;
+            return ok;
+        }
         psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
         size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
         std::vector<float> d(n), w(n), rgb(3 * n);
@@ -444,6 +566,7 @@ public:
     }
     bool saveSDF(std::string filename) {
         PSG_STAGE("dump: sdf");
+        if (!host_writers()) { psgsdf_info i2{}; psgsdf_get_info(ctx_, &i2); return VolumetricGradSdf::device_sdf(ctx_, save_path_ + filename, i2.voxel_size); }
         psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
         size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
         std::vector<float> d(n);

@@ -120,7 +120,8 @@ int main(int argc, char* argv[]) {
     if (argc >= 4 && std::string(argv[1]) == "--selftest-mc-ply") return selftest_mc_ply(atoi(argv[2]), argv[3]);
     std::string configfile, timing_file;      // --timing <file.json>: wall-clock per stage (no reference counterpart; the reference's outputs are unchanged)
     for (int i = 1; i < argc; ++i) { std::string a = argv[i]; if (a == "--config_file" && i + 1 < argc) configfile = argv[++i]; else if (a.rfind("--config_file=", 0) == 0) configfile = a.substr(14);
-        else if (a == "--timing" && i + 1 < argc) timing_file = argv[++i]; }
+        else if (a == "--timing" && i + 1 < argc) timing_file = argv[++i];
+        else if (a == "--host-writers") host_writers() = true; }      // round 4's dump path (dense download, host marching cubes, iostream) and frame path (serial decode, normals through the host): the cross-check of the device / threaded one
     const auto t_main0 = std::chrono::steady_clock::now();
     std::cout << "load the config file from: " << configfile << std::endl;
     JsonObject config;
@@ -191,11 +192,21 @@ int main(int argc, char* argv[]) {
     int dist_to_last_keyframe = 0; bool GT_pose = false;
     if (!loader->load_pose(pose_file, poses)) { std::cout << "GT poses is not avalible!" << std::endl; poses.push_back(I4); }
     else { std::cout << poses.size() << " GT poses are loaded." << std::endl; GT_pose = true; }
-    for (size_t i = 0; i < first; ++i) loader->load_next(color, depth);
+    { std::string d, r; for (size_t i = 0; i < first; ++i) if (host_writers()) loader->load_next(color, depth); else loader->next_names(d, r); }      // (frames in front of "first" are skipped; the reference decodes them, nothing reads them)
     Mat4f cur_pose = I4;
+    FramePrefetcher prefetch(loader, host_writers() ? 1 : std::min<size_t>(8, std::max(2u, std::thread::hardware_concurrency() / 2)));
+    std::string stamp_rgb, stamp_depth;
     for (size_t i = first; i <= last; ++i) {
         std::cout << "Working on frame: " << i << std::endl;
-        { PSG_STAGE("decode: PNG colour + depth (host)"); if (!loader->load_next(color, depth)) { std::cerr << " -> Frame " << i << " could not be loaded!" << std::endl; break; } }
+        {
+            PSG_STAGE("decode: PNG colour + depth (host; wait for the prefetched frame)");
+            if (host_writers()) { if (!loader->load_next(color, depth)) { std::cerr << " -> Frame " << i << " could not be loaded!" << std::endl; break; } stamp_rgb = loader->rgb_timestamp(); stamp_depth = loader->depth_timestamp(); }
+            else {
+                auto fr = prefetch.next();
+                if (!fr) { std::cerr << " -> Frame " << i << " could not be loaded!" << std::endl; break; }
+                color = std::move(fr->color); depth = std::move(fr->depth); stamp_rgb = fr->rgb_stamp; stamp_depth = fr->depth_stamp;
+            }
+        }
         if (GT_pose && i >= poses.size()) break;
         if (i == first) {
             float centroid[3]; compute_centroid(K, depth, poses[0], centroid);
@@ -212,7 +223,7 @@ int main(int argc, char* argv[]) {
             if (opt_set_->model == LED) vOpt = new LedOptimizer(tSDF, voxel_size, K, output, opt_set_); else vOpt = new PsOptimizer(tSDF, voxel_size, K, output, opt_set_);
             if (!tSDF->update(color, depth.data, poses[0])) { std::cerr << " -> Frame " << i << " could not be fused: " << tSDF->last_error() << std::endl; return 1; }
             cur_pose = poses[0];
-            key_stamps.push_back(loader->rgb_timestamp());
+            key_stamps.push_back(stamp_rgb);
             key_images.push_back(std::make_shared<ImageRGB>(color));
         } else {
             tSDF->increase_counter();
@@ -224,13 +235,13 @@ int main(int argc, char* argv[]) {
                 bool sharp; { PSG_STAGE("keyframe selection: focus measure (host)"); sharp = sharpDetector(color, sharp_thr); }
                 if (sharp || dist_to_last_keyframe > 5) {
                     dist_to_last_keyframe = 0;
-                    keyframes.push_back((int)(i - first)); key_stamps.push_back(loader->rgb_timestamp()); key_poses.push_back(cur_pose);
+                    keyframes.push_back((int)(i - first)); key_stamps.push_back(stamp_rgb); key_poses.push_back(cur_pose);
                     key_images.push_back(std::make_shared<ImageRGB>(color));
                 } else ++dist_to_last_keyframe;
             }
         }
         float q[4]; quat_of(cur_pose, q);
-        pose_out << loader->depth_timestamp() << " " << cur_pose[3] << " " << cur_pose[7] << " " << cur_pose[11] << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << "\n";
+        pose_out << stamp_depth << " " << cur_pose[3] << " " << cur_pose[7] << " " << cur_pose[11] << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << "\n";
     }
     pose_out.close();
     if (!vOpt) { std::cerr << "no frame was processed" << std::endl; return 1; }
@@ -243,6 +254,7 @@ int main(int argc, char* argv[]) {
     vOpt->setImages(key_images); vOpt->setKeyframes(keyframes); vOpt->setKeytimestamps(key_stamps); vOpt->setPoses(key_poses);
     vOpt->init();
     vOpt->alternatingOptimize(light, albedo, distance, pose);
+    DumpQueue::get().drain();
     delete vOpt; delete pOpt; delete tSDF; delete loader; delete opt_set_;
     if (!timing_file.empty()) {
         char extra[256];
