@@ -194,7 +194,9 @@ int main(int argc, char* argv[]) {
     else { std::cout << poses.size() << " GT poses are loaded." << std::endl; GT_pose = true; }
     { std::string d, r; for (size_t i = 0; i < first; ++i) if (host_writers()) loader->load_next(color, depth); else loader->next_names(d, r); }      // (frames in front of "first" are skipped; the reference decodes them, nothing reads them)
     Mat4f cur_pose = I4;
-    FramePrefetcher prefetch(loader, host_writers() ? 1 : std::min<size_t>(8, std::max(2u, std::thread::hardware_concurrency() / 2)));
+    size_t window = host_writers() ? 1 : std::min<size_t>(4, std::max(2u, std::thread::hardware_concurrency() / 2));
+    if (const char* e = getenv("VOXELPS_PREFETCH")) window = (size_t)std::max(1, atoi(e));      // (frames decoded ahead of the fusion)
+    FramePrefetcher prefetch(loader, window);
     std::string stamp_rgb, stamp_depth;
     for (size_t i = first; i <= last; ++i) {
         std::cout << "Working on frame: " << i << std::endl;

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DATA = {"native_4": ("tests/golden/sokrates_native_4", 3), "frames_21": ("tests/golden/sokrates_21", 20)}
 
 
-def run(exe, name, reps):
+def run(exe, name, reps, extra_flags=()):
     inp, last = DATA[name]
     best = None
     for rep in range(reps):
@@ -23,7 +23,7 @@ def run(exe, name, reps):
                    "upsample": False, "--light": True, "--albedo": True, "--distance": True, "--pose": True}      # config_skorates.json
             json.dump(cfg, open(out + "config.json", "w"))
             t0 = time.time()
-            r = subprocess.run([exe, "--config_file", out + "config.json", "--timing", out + "timing.json"], capture_output=True, text=True, timeout=900)
+            r = subprocess.run([exe, "--config_file", out + "config.json", "--timing", out + "timing.json"] + list(extra_flags), capture_output=True, text=True, timeout=900)
             wall = time.time() - t0
             if r.returncode != 0:
                 return {"error": r.stdout[-500:] + r.stderr[-500:]}
@@ -34,12 +34,10 @@ def run(exe, name, reps):
             if best is None or t["total_s"] < best["total_s"]:
                 best = t
     s = best["stages_s"]
-    dumps = sum(v for k, v in s.items() if k.startswith("dump:"))
-    opt_total = s.get("alternatingOptimize: total (incl. its dumps)", 0.0)
-    init_dumps = dumps - sum(0 for _ in ())      # (all dumps; those inside alternatingOptimize are part of opt_total too)
-    best["summary_s"] = {"decode": s.get("decode: PNG colour + depth (host)", 0.0), "fuse": s.get("fuse: FALS normals + integration (device, incl. transfers)", 0.0),
-                         "focus_measure": s.get("keyframe selection: focus measure (host)", 0.0), "dumps_all": dumps,
-                         "optimise_without_dumps": None, "total": best["total_s"]}
+    get = lambda pre: sum(v for k, v in s.items() if k.startswith(pre))
+    best["summary_s"] = {"decode (main thread)": get("decode:"), "fuse": get("fuse:"), "focus_measure": get("keyframe selection"), "dumps (main thread)": get("dump:"),
+                         "background writer (overlapped)": get("background:"), "waiting for the writer": get("wait for the background"),
+                         "alternatingOptimize incl. its dumps": get("alternatingOptimize"), "total": best["total_s"]}
     return best
 
 
@@ -49,10 +47,11 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "voxelps_e2e.json"))
     ap.add_argument("--label", default="run")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--host-writers", action="store_true", help="round 4's path: dense downloads, host marching cubes, iostream, serial decode")
     a = ap.parse_args()
     res = {"label": a.label, "exe": os.path.relpath(a.exe, ROOT)}
     for name in DATA:
-        res[name] = run(a.exe, name, a.reps)
+        res[name] = run(a.exe, name, a.reps, ["--host-writers"] if a.host_writers else [])
         print(name, json.dumps(res[name]), flush=True)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     old = json.load(open(a.out)) if os.path.exists(a.out) else {}
