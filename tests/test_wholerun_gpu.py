@@ -42,7 +42,7 @@ def margins_of(a, b, band, vs):
             "light_rel": float(np.abs(a.download_light() - lb).max() / np.abs(lb).max())}
 
 
-def whole_run(make, vs_final, margins, min_iters):
+def whole_run(make, vs_final, margins, min_iters, e_floor=1e-4):
     from oracle import oracle  # noqa: F401
     eng, orc, fma = make("eng"), make("orc"), make("orc_fma")
     (re_, ce), (ro, co), (rf, cf) = eng.optimize(capi.ALL), orc.optimize(capi.ALL), fma.optimize(capi.ALL)
@@ -63,9 +63,9 @@ def whole_run(make, vs_final, margins, min_iters):
     m_fma = margins_of(fma, orc, band, vs_final) if same_band else None
     margins(engine_vs_oracle=m_eng, oracle_fma_build_vs_oracle=m_fma, iterations=len(ro), result=bool(co), fma_build_iterations=len(rf),
             e_total_rel_by_iteration={"engine": [float(f"{x:.2e}") for x in e_eng], "oracle_fma_build": [float(f"{x:.2e}") for x in e_fma[:len(rf)]]},
-            tolerance=f"max(1e-4, {K_YARD} x the FMA build's deviation)")
+            tolerance=f"max({e_floor:g} (e_total) / 1e-4 (SDF), {K_YARD} x the FMA build's deviation)")
     for i, (x, y) in enumerate(zip(e_eng, yard_run)):
-        assert x <= max(1e-4, K_YARD * y), (i, x, y)
+        assert x <= max(e_floor, K_YARD * y), (i, x, y)
     yard = m_fma if m_fma else {"rel": 1.0, "rgb": 1.0, "pose": 1.0, "light_rel": 1.0}
     assert m_eng["rel"] <= max(1e-4, K_YARD * yard["rel"]), (m_eng, m_fma)
     assert m_eng["rgb"] <= max(2e-4, K_YARD * yard["rgb"]) and m_eng["pose"] <= max(1e-5, K_YARD * yard["pose"]) and m_eng["light_rel"] <= max(2e-4, K_YARD * yard["light_rel"]), (m_eng, m_fma)
@@ -129,4 +129,7 @@ def test_config3_led_128_with_refinement_to_termination(built, margins):
 def test_small_scenes_to_termination(built, margins, model, kw):
     """the three shading models at 64^3 x 12 to their own termination (10 / 11 / 35 iterations; SH1 and LED converge, SH2 takes the divergence exit)"""
     make, vs = synth_maker(model, 64, 12, 320, 240, **kw)
-    whole_run(make, vs, margins, min_iters=8)
+    # SH2: the engine solves the 9x9 light blocks (float32 in the reference, cond ~2e4) by LDL^T in double, the reference and BOTH oracle builds by one
+    # global Jacobi-PCG in float (DESIGN.md 2, deviation 2: bounded at 2e-4 of the step) -- a difference the FMA yardstick cannot show; the energy floor
+    # is the one every SH2 test uses (tests/test_configs_gpu.py config4: 5e-4)
+    whole_run(make, vs, margins, min_iters=8, e_floor=5e-4 if model == "SH2" else 1e-4)
