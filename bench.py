@@ -253,6 +253,17 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
     watched = eng.kernel_times().get(dom, (0.0, 0)) if (use_watch and timing_iterate) else (0.0, 0)
     eng.watch_kernel("")
     sync_stats = eng.debug_sync_stats()
+    solve_model = None
+    if headline and dom == "pcg_solve" and not slab:
+        # what the dominant kernel's time is made of, measured live: the same launch forced to 16 and to 48 passes (stop rule off) -> time per pass
+        # and the fixed part (assembly of the system from the sweep's voxel blocks, first records, distance update, launch ramp)
+        try:
+            t16 = min(eng.debug_time_pcg_solve(passes=16, reps=4)[0] for _ in range(3)); t48 = min(eng.debug_time_pcg_solve(passes=48, reps=4)[0] for _ in range(3))
+            per = (t48 - t16) / 32.0
+            solve_model = {"us_per_pass": 1e3 * per, "fixed_us": 1e3 * (t16 - 16.0 * per), "solve_16_passes_us": 1e3 * t16, "solve_48_passes_us": 1e3 * t48}
+        except capi.PsgsdfError:
+            solve_model = None
+    tuning = eng.get_tuning()
     eng.close()
 
     # ---- context 2: psgsdf_optimize, the loop voxelPS runs (initAlbedo + weight normalisation + iterations with the stop decision)
@@ -310,7 +321,7 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
                iterate_ms_per_step=1e3 * t_iter / args.steps, optimize_ms_per_step=(1e3 * t_opt / args.steps) if t_opt else None,
                kernels=kernels, dom=dom, watched=watched, t_gen=t_gen, st=st, sc=sc, sync_stats=sync_stats,
                collectives_per_step=(coll1 - coll0) / max(args.steps, 1), use_u8=use_u8, own_rows=own_rows,
-               e_iter=[float(r["e_total"]) for r in recs_it], iter_calls=[args.warmup, nprof, args.steps], scene_kw=scene_kw)
+               e_iter=[float(r["e_total"]) for r in recs_it], iter_calls=[args.warmup, nprof, args.steps], scene_kw=scene_kw, solve_model=solve_model, tuning=tuning)
     return res
 
 
@@ -349,6 +360,36 @@ def multi_gpu_block(m, check, world, share):
            "self_check": check}
     checks_ok = all(c["ok"] for c in (check if isinstance(check, list) else [check]) if c)
     return blk, bool(not ss["cross_rank_ready"] or ss["persist_fallbacks"] > 0 or not checks_ok)
+
+
+def voxelps_e2e():
+    import subprocess, tempfile
+    exe = os.path.join(ROOT, "psgradientsdf_amd", "host", "voxelPS"); data = os.path.join(ROOT, "tests", "golden", "sokrates_21")
+    if not (os.path.exists(exe) and os.path.isdir(data)):
+        return {"skipped": "voxelPS or tests/golden/sokrates_21 not present"}
+    res = {"workload": "voxelPS --config_file: config_skorates.json settings (128^3 at 4 mm, SH1, max iter 100, 5e-3) on the reference's demo frames 0-20 (sub-sampled 3x: 380 x 570), 21 keyframes, run to convergence; whole process"}
+    for label, flags in (("round5", []), ("round4_path", ["--host-writers"])):
+        best = None
+        for _ in range(2):
+            with tempfile.TemporaryDirectory() as td:
+                out = td + "/"
+                cfg = {"input": data + "/", "output": out, "pose filename": "pose.txt", "datatype": "multiview", "first": 0, "last": 20, "voxel size": 0.004, "truncation factor": 5, "zmin": 0.5, "zmax": 3.5,
+                       "sharpness threshold": 0.0, "model type": "SH1", "loss function": "cauchy", "reg albedo": 0.0, "reg norm": 10.0, "reg laplacian": 0.0, "max iter": 100, "damping": 1.0,
+                       "converge threshold": 5e-3, "lambda": 0.2, "upsample": False, "--light": True, "--albedo": True, "--distance": True, "--pose": True}
+                json.dump(cfg, open(out + "config.json", "w"))
+                r = subprocess.run([exe, "--config_file", out + "config.json", "--timing", out + "timing.json"] + flags, capture_output=True, text=True, timeout=300)
+                if r.returncode != 0:
+                    return {"error": (r.stdout[-200:] + r.stderr[-200:])}
+                t = json.load(open(out + "timing.json"))
+                t["iterations"] = r.stdout.count("relative diff"); t["output_bytes"] = sum(os.path.getsize(out + f) for f in os.listdir(out) if f.endswith((".ply", ".sdf", ".txt")))
+                if best is None or t["total_s"] < best["total_s"]:
+                    best = t
+        st = best["stages_s"]; grp = lambda pre: round(sum(v for k, v in st.items() if k.startswith(pre)), 4)
+        res[label] = {"total_s": round(best["total_s"], 4), "gauss_newton_iterations": best["iterations"], "output_MB": round(best["output_bytes"] / 1e6, 1),
+                      "stages_s": {"decode (main thread)": grp("decode:"), "fusion": grp("fuse:"), "focus measure": grp("keyframe selection"), "dumps (main thread)": grp("dump:"),
+                                   "background writer (overlapped)": grp("background:"), "waiting for the writer": grp("wait for the background"), "alternatingOptimize incl. its dumps": grp("alternatingOptimize")}}
+    res["speedup"] = round(res["round4_path"]["total_s"] / res["round5"]["total_s"], 2)
+    return res
 
 
 def spawn_ranks(n):
@@ -507,13 +548,20 @@ def main():
         noop_ms = 0.0047
         avg_work_ms = (avg_ms - (1.0 - working_frac) * noop_ms) / working_frac if working_frac > 0 else avg_ms
         achieved = nbytes / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pj = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        # (the archived rocprofv3 summaries carry the hash of the engine sources they were collected on: the line says whether the sources have changed since)
+        try:
+            src_hash = open(os.path.join(ROOT, "psgradientsdf_amd", "csrc", ".build_hash")).read().strip()[:12]
+        except OSError:
+            src_hash = None
+        stale = lambda j: None if not (j and j.get("source_hash") and src_hash) else bool(j["source_hash"] != src_hash)
         if os.path.exists(pmc) and (args.grid, args.frames, args.model, world) == (256, 50, "SH1", 1):   # the counters were collected on this configuration
             try:
                 pj = json.load(open(pmc))
                 traffic = (pj.get(dom) or {}).get("hbm_bytes_per_launch")
-                traffic_src = f"static: profiles/pmc_summary.json @{pj.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 (gfx950), KiB -> bytes); not re-measured in this run"
+                traffic_src = (f"static: profiles/pmc_summary.json @{pj.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 (gfx950), KiB -> bytes); "
+                               f"not re-measured in this run; engine sources changed since it was collected: {stale(pj)}")
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -526,6 +574,22 @@ def main():
                            # and applies the distance update (8 B): the same fraction with those algorithmic bytes counted, for reference only
                            "frac_with_fused_steps": ((nbytes + 76 * S) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if dom == "pcg_solve" else None,
                            "traffic_source": traffic_src}
+        if dom == "pcg_solve":
+            # SURVEY 8d prices this kernel against HBM (`bound`, `frac` above: the contract's figure), but HBM is not what bounds it: the matrix lives in LDS
+            # and the counters see 0.13 x the algorithmic bytes.  A pass is a chain of device-wide hand-offs (tag wait -> gathers of the neighbours' values
+            # -> publish); the floor below is that chain at its shortest, the decomposition next to it is measured in this run.
+            sm = m.get("solve_model")
+            passes = cg_iters + 2.0                                      # cg_iters + 1 passes, + the prologue's gather round w_0 = A u_0
+            hand_off_us = 3.0                                            # one device-wide hand-off through memory on MI355X (profiles/r04_notes.md section 4, tools/mapped_visibility.hip)
+            fixed_floor_us = 76.0 * S / (HBM_PEAK_GBS * 1e3) + 2.0       # the fused assembly + update stream 76 B per band voxel once; + the launch ramp
+            floor_us = fixed_floor_us + passes * hand_off_us
+            out["roofline"].update({
+                "bound_observed": "device-wide hand-off latency (one tag wait + gather round + publish per PCG pass across 256 workgroups; the matrix is LDS-resident, HBM traffic is 0.13 x the algorithmic bytes)",
+                "passes": passes, "us_per_pass": sm["us_per_pass"] if sm else None, "fixed_us": sm["fixed_us"] if sm else None,
+                "floor_model": {"formula": "fixed_floor + passes x hand_off", "hand_off_us": hand_off_us, "fixed_floor_us": fixed_floor_us, "floor_us": floor_us,
+                                "measured_us": 1e3 * avg_ms, "frac_of_floor": floor_us / (1e3 * avg_ms) if avg_ms == avg_ms else None,
+                                "measured_decomposition_us": ({"fixed (assembly, first records, update, launch)": sm["fixed_us"], "passes": passes * sm["us_per_pass"]} if sm else None),
+                                "note": "a pass costs 2.6 hand-offs' worth: the tag wait of the slowest neighbour, 18 gathers per row in two batches, the publish (profiles/r04_notes.md section 4: five variants measured against it)"}})
         # whole-iteration algorithmic bytes (SURVEY.md §8d formula) for reference
         U = min(48 * n_obs, 12 * args.width * args.height * args.frames)
         B_iter = 4 * (S * 60 + U) + 120 * S + 124 * cg_iters * S   # SURVEY §8d per-pass figure kept (the fused pass moves 144 B/row)
@@ -534,6 +598,11 @@ def main():
             out["config"]["band_rows_per_rank"] = m["own_rows"]
         out["iteration"] = {"algorithmic_bytes": B_iter, "achieved_GBs": B_iter * (m["value"] / world) / 1e9,
                             "frac_of_hbm_peak": B_iter * (m["value"] / world) / 1e9 / HBM_PEAK_GBS}
+        if pj:      # the same fraction from the COUNTERS (archived passes): what really crosses the HBM interface per iteration -- nothing on this path is bandwidth-bound
+            per_iter = ("pcg_solve", "sweep_dist", "sweep_pose", "sweep_light", "sweep_albedo", "derive")
+            cb = sum((pj.get(k) or {}).get("hbm_bytes_per_launch", 0.0) for k in per_iter)
+            out["iteration"].update({"counter_bytes": cb, "counter_frac_of_hbm_peak": cb * (m["value"] / world) / 1e9 / HBM_PEAK_GBS,
+                                     "counter_source": f"static: profiles/pmc_summary.json @{pj.get('commit', '?')}, kernels {', '.join(per_iter)}; sources changed since: {stale(pj)}"})
         if kernels:
             # A SYNCHRONOUS-event pass over psgsdf_iterate (every launch bracketed by an event pair and a host wait: ~4 us of overhead per launch, and
             # `energy`, which the product loop folds into the next sweep, runs as a kernel of its own here): it ranks the kernels, it does not add
@@ -543,12 +612,14 @@ def main():
             if os.path.exists(ks) and (args.grid, args.frames, args.model, world) == (256, 50, "SH1", 1):
                 try:
                     out["kernels_rocprof"] = json.load(open(ks))      # static: rocprofv3 --kernel-trace --stats of this command at the stamped commit (us per iteration, sums to the iteration)
+                    out["kernels_rocprof"]["engine_sources_changed_since"] = stale(out["kernels_rocprof"])
                 except Exception:
                     pass
             # per-kernel roofline fractions from the same synchronous-event pass (events add ~4 us per launch: fractions err low)
             out["kernel_roofline_frac"] = {k: round(algorithmic_bytes(k, S, n_obs, args.width, args.height, args.frames, lap, pcg_passes=cg_iters + 1.0) / (v["ms_per_iter"] / max(v["launches_per_iter"], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
                                            for k, v in kernels.items() if algorithmic_bytes(k, 1, 1, 1, 1, 1) and v["ms_per_iter"] > 0}
         out["sync_stats"] = m["sync_stats"]      # scalar read-backs validated / found late / persistent-solve fallbacks in this run (include/psgsdf.h)
+        out["tuning"] = {"build": m["tuning"]["build"], "env": m["tuning"]["env"], "ignored_dev_only": m["tuning"]["ignored_dev_only"]}      # psgsdf_get_tuning: every PSGSDF_* knob that was in force
         out["setup_s"] = {"scene_generation": round(m["t_gen"], 1)}
 
         # ---- CPU baseline: the oracle (a port of the reference's arithmetic) on the host cores, bounded sample
@@ -609,6 +680,13 @@ def main():
         extra["SH1_png_like_float_keyframes"] = {"value": e["value"], "unit": "it/s", "ms_per_step": e["ms_per_step"],
                                                  "note": "keyframes quantised to 8 bits, passed through psgsdf_set_keyframes (float); held as RGBA8 words (PSGSDF_IMG_COMPACT)"}
         del e
+        # ---- the drop-in end to end: `voxelPS --config_file` with config_skorates.json's settings on the reference's demo frames
+        # (tests/golden/sokrates_21), wall-clock of the whole process and its stages; "round4_path" = the same binary with --host-writers (dense
+        # downloads, host marching cubes, iostream text, serial PNG decode): the files are byte for byte the same (tests/test_extract_gpu.py)
+        try:
+            extra["voxelps_e2e"] = voxelps_e2e()
+        except Exception as ex:      # (never let the side measurement take the line down)
+            extra["voxelps_e2e"] = {"error": repr(ex)[:300]}
         if rank == 0:
             out["extra"] = extra
     if world > 1 and not args.no_extra and not explicit_strong and not args.weak:

@@ -36,5 +36,9 @@ for k in sorted(set(fetch) | set(write)):
               "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes; Infinity-Cache hits are counted"}
 import os
 out["commit"] = os.environ.get("PSGSDF_COMMIT", "?")
+try:
+    out["source_hash"] = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "psgradientsdf_amd", "csrc", ".build_hash")).read().strip()[:12]
+except OSError:
+    out["source_hash"] = None
 json.dump(out, sys.stdout, indent=1)
 print()

@@ -46,7 +46,12 @@ def per_iteration(agg, json_out, commit):
     # and undo kernels per psgsdf_optimize call, listed with their launch counts)
     per = {k: {"avg_us": round(a[1] / a[0], 2), "launches": a[0]} for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]) if k.startswith(loop)}
     once = sum(v["avg_us"] for k, v in per.items() if v["launches"] >= solves)
-    json.dump({"source": "rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline --no-extra` (tools/profile_round.sh)", "commit": commit, "iterations_traced": solves,
+    import os
+    try:
+        src_hash = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "psgradientsdf_amd", "csrc", ".build_hash")).read().strip()[:12]
+    except OSError:
+        src_hash = None
+    json.dump({"source": "rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline --no-extra` (tools/profile_round.sh)", "commit": commit, "source_hash": src_hash, "iterations_traced": solves,
                "kernels": per, "us_per_iteration": round(once, 1), "note": "us_per_iteration = sum of the average durations of the kernels that run once per iteration (launches >= iterations_traced)"}, open(json_out, "w"), indent=1)
 
 
