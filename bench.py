@@ -454,8 +454,12 @@ def main():
     ap.add_argument("--strong", action="store_true", help="strong scaling: ONE volume (default BASELINE configs[4]: 512^3, SH2, 100 keyframes) cut into --gpus z-slabs; every rank synthesises and uploads only its own planes")
     ap.add_argument("--weak", action="store_true", help="N > 1: `value` = the weak-scaling run (N copies of the scene stacked along z, N x it/s: round 4's default) instead of the strong scaling of the one scene")
     ap.add_argument("--configs4", default="512:100", help="grid:keyframes of the BASELINE configs[4] extra of the N > 1 line (SH2; tests pass a small one)")
+    ap.add_argument("--probe-only", action="store_true", help="no measurement: the first-contact probe of a multi-GPU node (tools/first_contact.py: communicator, one collective, the in-kernel hand-off forms per memory kind between every neighbour pair, two iterations with every in-kernel exchange against one context), one JSON line, every phase under a wall-clock bound")
     ap.add_argument("--loop", default="optimize", choices=["optimize", "iterate"], help="which loop `value` times (iterate: the round-2 figure, no stop decision)")
     args = ap.parse_args()
+    if args.probe_only:
+        import subprocess
+        sys.exit(subprocess.call([sys.executable, os.path.join(ROOT, "tools", "first_contact.py"), "--gpus", str(max(args.gpus, 2))]))
     c4 = [int(x) for x in args.configs4.split(":")]
     if args.strong and (args.grid, args.frames, args.model) == (256, 50, "SH1"):      # --strong and nothing chosen explicitly: BASELINE configs[4] is `value`
         args.grid, args.frames, args.model = c4[0], c4[1], "SH2"

@@ -196,7 +196,15 @@ int psgsdf_get_tuning(psgsdf_ctx* c, char* json, size_t cap) {
              (int)c->pcg_prefetch, (int)c->pcg_fuse_asm, (int)c->pcg_fuse_apply, (int)c->pcg_xcd_local, (int)c->fm_solve, (int)c->fm_solve_led, (int)c->img_compact, c->xcd_map,
              (int)c->xr_enable, (int)c->xf_enable, (int)c->xs_enable, (int)c->xh_enable, c->xr_mem_kind, (int)lround(log2((double)c->xwait_spins)), c->cu_mask_lo, c->cu_mask_hi,
              (int)c->mbox_check, c->pcg_ablate, c->fault_solve, c->fault_halo);
-    o += buf; o += "}}";
+    o += buf; o += "}";
+    if (c->n_ranks > 1) {      // the hand-off probe as THIS rank saw it, per memory kind tried (comm.hip xr_probe): a first multi-GPU run reads its pairs here
+        snprintf(buf, sizeof(buf), ", \"xr_probe\": {\"rank\": %d, \"n_ranks\": %d, \"kind_chosen\": %d, \"stale_mappings\": %lld, \"fine_grained\": {\"tried\": %lld, \"stale_records_from_lower\": %lld, \"expired_waits_lower\": %lld, \"expired_waits_upper\": %lld}, "
+                 "\"uncached\": {\"tried\": %lld, \"stale_records_from_lower\": %lld, \"expired_waits_lower\": %lld, \"expired_waits_upper\": %lld}}",
+                 c->rank, c->n_ranks, c->xr_mem_kind, c->xr_stale_maps, c->xr_probe_local[1][3], c->xr_probe_local[1][0], c->xr_probe_local[1][1], c->xr_probe_local[1][2],
+                 c->xr_probe_local[2][3], c->xr_probe_local[2][0], c->xr_probe_local[2][1], c->xr_probe_local[2][2]);
+        o += buf;
+    }
+    o += "}";
     if (json && cap) { const size_t n = std::min(cap - 1, o.size()); memcpy(json, o.data(), n); json[n] = 0; }
     return (int)o.size();
 }

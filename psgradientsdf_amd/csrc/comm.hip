@@ -366,6 +366,7 @@ int xr_probe(psgsdf_ctx* c) {
             double o[4] = {0, 0, 0, 0};
             if (hipMemcpyAsync(o, out, sizeof(o), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "cross-rank probe: kernel");
             res[0] = o[0]; res[1] = o[1] + o[2]; res[2] = 1.0;
+            c->xr_probe_local[kind][0] = (long long)o[0]; c->xr_probe_local[kind][1] = (long long)o[1]; c->xr_probe_local[kind][2] = (long long)o[2]; c->xr_probe_local[kind][3] = 1;      // this rank's own view: stale records it read from its lower neighbour, waits that expired towards the lower / upper neighbour
             if (!rc) rc = host_allreduce(c, res, "cross-rank probe");
             c->xr_probe_stale += (long long)res[0]; c->xr_probe_timeouts += (long long)res[1];
         }

@@ -118,6 +118,7 @@ struct psgsdf_ctx {
     double* xr = nullptr;
     int xr_mem_kind = -1;                // memory kind of xr / rec_mem chosen by xr_probe: 1 fine-grained records + uncached region, 2 both uncached, 0 none passed (cross-rank solve off); -1 not probed yet
     long long xr_probe_stale = 0, xr_probe_timeouts = 0;   // what the probe saw (all ranks, all kinds tried)
+    long long xr_probe_local[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [memory kind 1 / 2][stale records read from the lower neighbour, expired waits towards the lower, towards the upper neighbour, tried]: this rank's own view (psgsdf_get_tuning)
     bool xr_mapped = false;              // peers may hold IPC mappings of xr / rec_mem: they have to be closed everywhere before either is freed (xr_quiesce)
     unsigned long long xr_openers = 0;   // bit r: rank r opened this rank's region at the last set-up (agreed there); xr_quiesce waits for exactly those
     long long xr_serial = 0, xr_closed_off = 0;   // number of the last set-up (the same on every rank) and where the R "closed" slots of a region sit

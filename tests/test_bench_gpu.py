@@ -109,3 +109,24 @@ def test_strong_scaling_mode_two_ranks_share_the_gpu(built):
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     rows = d["config"]["band_rows_per_rank"]
     assert len(rows) == 2 and min(rows) > 0 and max(rows) <= 1.35 * min(rows) and d["config"]["collectives_per_step"] >= 0
+
+
+def test_first_contact_probe(built):
+    """`python bench.py --probe-only --gpus N` (tools/first_contact.py): communicator, one collective, the hand-off forms per memory kind
+    between every neighbour pair, two iterations with every in-kernel exchange against one context -- one JSON line, every phase under a wall-clock
+    bound.  Here: four ranks sharing GPU 0 (each on a quarter of the CUs) through the gloo test transport."""
+    env = dict(os.environ, PSGSDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PSGSDF_CU_MASK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--probe-only", "--gpus", "4"], capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    d = _one_json(r.stdout)
+    assert r.returncode == 0 and d["ok"] and d["timed_out_phase"] is None, d
+    assert d["ranks"] == 4 and set(d["phases"]) == {"rccl_init", "allreduce", "hand_off", "exchanges"}
+    assert d["hand_off_memory_kinds_that_pass"] == ["fine", "uncached"]
+    for x in d["phases"]["hand_off"]["per_rank"]:
+        for kind in ("fine", "uncached"):
+            k = x["kinds"][kind]
+            assert k["passed_on_all_ranks"] and k["cross_rank_ready"] == 1 and k["stale_mappings"] == 0 and k["all_ranks_stale_records"] == 0 and k["all_ranks_expired_waits"] == 0
+            assert k["this_rank"]["tried"] == 1 and k["this_rank"]["stale_records_from_lower"] == 0
+    for x in d["phases"]["exchanges"]["per_rank"]:
+        assert x["ok"] and x["e_total_rel_diff"] <= 1e-5 and x["cross_rank_solves"] == 2 and x["persist_fallbacks"] == 0 and x["halo_exchanges_by_push_kernels"] > 0
