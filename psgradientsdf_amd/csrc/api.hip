@@ -273,16 +273,19 @@ int psgsdf_rebalance_slabs(psgsdf_ctx* c) {
     std::vector<double> cuts((size_t)4 * R, 0.0);
     cuts[4 * c->rank] = oz0; cuts[4 * c->rank + 1] = oz1; cuts[4 * c->rank + 2] = nz0; cuts[4 * c->rank + 3] = nz1;
     { int rc = host_allreduce(c, cuts, "rebalance_slabs"); if (rc) return rc; }
-    // the new local grid and its arrays
+    // the new local grid and its arrays.  The new arrays are allocated BEFORE the context lets go of the old ones, and every error path frees what it
+    // allocated and leaves the context as it was (a failed allocation used to leak both sets and leave have_volume = true over empty arrays)
     DenseView od = c->dense; uint64_t* ovis = c->vis_seq;
-    c->dense = DenseView{}; c->vis_seq = nullptr;
-    { int rc = set_local_grid(c, nz0, nz1); if (rc) return rc; }
-    const int nzlo = c->zlo, nzhi = c->zhi;
-    const long long n = c->grid.nvox;
+    const int nzlo = std::max(0, nz0 - 1), nzhi = std::min(nz, nz1 + 1);
+    const long long n = (long long)(nzhi - nzlo) * (long long)plane;
     DenseView nd{};
-    int rc = alloc_dense(c, nd, n, 0, true); if (rc) return rc;
     uint64_t* nvis = nullptr;
-    HIPCHK(c, hipMalloc(&nvis, sizeof(uint64_t) * n * wpv));
+    auto free_new = [&] { hipFree(nd.dist); for (int a = 0; a < 3; ++a) { hipFree(nd.g[a]); hipFree(nd.rho[a]); } hipFree(nd.weight); hipFree(nd.vis); hipFree(nd.row_of); hipFree(nvis); (void)hipGetLastError(); };
+    int rc = alloc_dense(c, nd, n, 0, true);
+    if (!rc && hipMalloc(&nvis, sizeof(uint64_t) * n * wpv) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "rebalance_slabs: out of memory");
+    if (rc) { free_new(); return rc; }
+    { int rc2 = set_local_grid(c, nz0, nz1); if (rc2) { free_new(); set_local_grid(c, oz0, oz1); return rc2; } }
+    c->dense = DenseView{}; c->vis_seq = nullptr;
     float* oarr[8] = {od.dist, od.g[0], od.g[1], od.g[2], od.rho[0], od.rho[1], od.rho[2], od.weight};
     float* narr[8] = {nd.dist, nd.g[0], nd.g[1], nd.g[2], nd.rho[0], nd.rho[1], nd.rho[2], nd.weight};
     std::vector<psgsdf_comm_xfer> sends, recvs;
@@ -295,8 +298,8 @@ int psgsdf_rebalance_slabs(psgsdf_ctx* c) {
             const size_t so = (size_t)(s0 - ozlo) * plane, cntv = (size_t)(s1 - s0) * plane;
             if (peer == c->rank) {
                 const size_t dn = (size_t)(s0 - nzlo) * plane;
-                for (int q = 0; q < 8; ++q) HIPCHK(c, hipMemcpyAsync(narr[q] + dn, oarr[q] + so, sizeof(float) * cntv, hipMemcpyDeviceToDevice, c->stream));
-                HIPCHK(c, hipMemcpyAsync(nvis + dn * wpv, ovis + so * wpv, sizeof(uint64_t) * cntv * wpv, hipMemcpyDeviceToDevice, c->stream));
+                for (int q = 0; q < 8; ++q) if (hipMemcpyAsync(narr[q] + dn, oarr[q] + so, sizeof(float) * cntv, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "rebalance_slabs: plane copy");
+                if (hipMemcpyAsync(nvis + dn * wpv, ovis + so * wpv, sizeof(uint64_t) * cntv * wpv, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "rebalance_slabs: plane copy");
             } else {
                 for (int q = 0; q < 8; ++q) sends.push_back({oarr[q] + so, sizeof(float) * cntv, peer});
                 sends.push_back({ovis + so * wpv, sizeof(uint64_t) * cntv * wpv, peer});
@@ -312,12 +315,13 @@ int psgsdf_rebalance_slabs(psgsdf_ctx* c) {
             }
         }
     }
-    rc = comm_xfer(c, sends, recvs);
+    if (!rc) rc = comm_xfer(c, sends, recvs);      // (every rank enters the exchange unless its own local copies failed)
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "rebalance_slabs: exchange");
     for (int q = 0; q < 8; ++q) hipFree(oarr[q]);
     hipFree(od.vis); hipFree(od.row_of); hipFree(ovis); hipFree(c->block_sums); c->block_sums = nullptr;
     c->dense = nd; c->vis_seq = nvis;
     c->inited = false;
+    if (rc) c->have_volume = false;      // (a failed exchange leaves planes missing: the volume must be uploaded / fused again)
     return rc;
 }
 

@@ -253,7 +253,8 @@ typedef float v4f_probe_t __attribute__((ext_vector_type(4)));
 constexpr int kProbeRecs = 2048, kProbeRounds = 48, kProbeFlagDoubles = 64;
 // Two roles, one workgroup each.  OWNER (towards the lower neighbour): pull the payload into this device's caches, wait for the neighbour's
 // round flag (system-scope relaxed loads), ONE system-scope acquire fence, read the payload with plain loads and count records that do not
-// carry the round, answer.  PEER (towards the upper neighbour): write-through 16-byte stores into its payload, drain, flag, wait for the answer.
+// carry the round, answer.  PEER (towards the upper neighbour): write-through stores into its payload -- 16-byte records in even rounds (the classic
+// solve), 8-byte words in odd rounds (the pipelined solve, the frame rows, the scalar folds) --, drain, flag, wait for the answer.
 __global__ void __launch_bounds__(256) k_xr_probe(double* myF, const float4* myP, double* loF, double* hiF, float4* hiP, int has_lo, int has_hi, double* out) {
     __shared__ int s_to; __shared__ unsigned long long s_stale;
     if (threadIdx.x == 0) { s_to = 0; s_stale = 0; }
@@ -261,7 +262,7 @@ __global__ void __launch_bounds__(256) k_xr_probe(double* myF, const float4* myP
     if (blockIdx.x == 0 && has_lo) {
         unsigned long long stale = 0; float sink = 0.f;
         for (int r = 1; r <= kProbeRounds; ++r) {
-            for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) sink += myP[i].x;
+            for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) sink += myP[i].x + (float)((const double*)myP)[2 * i + 1];      // (stale copies of both forms in this device's caches)
             __syncthreads();
             if (threadIdx.x == 0) {
                 int spins = 0;
@@ -270,7 +271,8 @@ __global__ void __launch_bounds__(256) k_xr_probe(double* myF, const float4* myP
             }
             __syncthreads();
             if (s_to) break;
-            for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { const float4 v = myP[i]; if (v.x != (float)r || v.w != (float)(r + i)) stale++; }
+            if (r & 1) { const double* pd = (const double*)myP; for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { if (pd[2 * i] != (double)r || pd[2 * i + 1] != (double)(r + i)) stale++; } }      // odd rounds: the pipelined solve's form (8-byte records, plain 8-byte loads)
+            else for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { const float4 v = myP[i]; if (v.x != (float)r || v.w != (float)(r + i)) stale++; }
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_store(loF + 8, (double)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -280,7 +282,10 @@ __global__ void __launch_bounds__(256) k_xr_probe(double* myF, const float4* myP
     }
     if (blockIdx.x == 1 && has_hi) {
         for (int r = 1; r <= kProbeRounds; ++r) {
-            for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) {
+            // even rounds: k_cgf_solve's hand-off (16-byte sc0 sc1 records); odd rounds: k_cgp_solve's, the frame rows' and the scalar folds' (8-byte
+            // sc0 sc1 words: device_common.h store8_system / pcg.hip store8_sys) -- the default solve is the pipelined one
+            if (r & 1) for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { store8_system((double*)hiP + 2 * i, (double)r); store8_system((double*)hiP + 2 * i + 1, (double)(r + i)); }
+            else for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) {
                 const v4f_probe_t d = {(float)r, 0.f, 0.f, (float)(r + i)};
                 asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(hiP + i), "v"(d) : "memory");
             }

@@ -10,8 +10,13 @@
 //   band.hip       : k_select_vis, k_band_flags, k_scan_*, k_band_fill, k_band_nb, k_band_scatter, k_upsample, k_derive, k_obs_*, k_sum_parts
 //   sweeps.hip     : k_init_albedo, k_energy, k_sweep_albedo (voxel-major, set-bit iteration); k_sweep_light, k_sweep_pose
 //                    (frame-major, wave + LDS reduction); k_solve_light, k_solve_pose (LDL^T per frame)
-//   dist.hip       : k_sweep_dist, k_assemble          pcg.hip: k_cgf_init, k_cgf_pass (fused Jacobi-PCG), k_apply_dist
-//   albedo_reg.hip : k_areg_*                          frontend.hip: k_integrate, k_normals_h/v, k_track
+//   dist.hip       : k_sweep_dist, k_assemble (per-pass path only)
+//   pcg.hip        : k_cgp_solve (the whole distance step as ONE persistent kernel: assembly into LDS, pipelined Jacobi-PCG in double, update; the
+//                    default), k_cgf_solve (the same with the classic recurrences), k_cgf_init / k_cgf_pass / k_cgf_sum (one kernel per pass:
+//                    bands that do not fit the LDS, multi-rank contexts without mappings, the fall-back), k_apply_dist
+//   albedo_reg.hip : k_areg_*                          frontend.hip: k_integrate, k_normals_h/v, k_track, k_try_pack_f32, k_pack_rgb8
+//   extract.hip    : k_box_*, k_mc_count / k_mc_emit (marching cubes), k_pc_flags / k_pc_fill (point clouds), k_sdf_crop, k_cscan_*
+//   comm.hip       : k_halo_push / k_halo_pull, k_xr_probe, k_xr_nonces, k_xr_closed (multi-rank exchanges through IPC-mapped memory)
 #pragma once
 #include "engine.h"
 #include <float.h>

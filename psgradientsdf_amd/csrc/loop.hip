@@ -102,7 +102,10 @@ int pcg_solve(psgsdf_ctx* c, SweepArgs& a, int* iters_out, int* success_out, dou
             // The persistent kernel needs all its workgroups co-resident (no cooperative launch) and gave up waiting for some of them: something
             // else holds CUs of this device (another process, a CU mask).  Nothing has been applied (its epilogue only acts on status 1 and it
             // leaves both gates closed, so the tail enqueued behind it did nothing): redo this solve with the per-pass kernels, which make
-            // no residency assumption and give the same bits, and keep this context on them until the next band is built.
+            // no residency assumption, and keep this context on them until the next band is built.  NOT the same bits: the per-pass kernels run
+            // Eigen's classic recurrences in float, the persistent kernel the pipelined ones in double (deviation 3) -- the two agree to
+            // rounding (tests/test_knobs_gpu.py, tests/test_edge_gpu.py::test_persistent_solve_falls_back...: 2e-6 in the energies, 5e-5 voxel), so a
+            // run that fell back is reproducible only given the same fall-back; psgsdf_debug_sync_stats out[2] / the bench line's `degraded` say so.
             // Multi-rank: the decision is the same on every rank without asking -- a rank that gives up in pass j never publishes the sums of
             // pass j, so no rank can obtain them and finish; a rank CAN only reach its last pass when every rank has published everything that
             // pass needs (records before sums), and the last pass itself waits for nothing.  The abort flag only shortens the others' waits.

@@ -190,7 +190,8 @@ void launch_apply_albedo(const SweepArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------
 // frame-major sweeps: grid = (row chunks, F); per-thread accumulation over several voxels of ONE
-// frame, then wavefront shuffle reduction -> LDS -> one double atomic per value per workgroup
+// frame, then wavefront DPP reduction -> LDS -> the workgroup's partial row (plain write-through stores, NO floating-point
+// atomics); the frame's last workgroup to arrive sums the partial rows in launch order (frame_rows_publish below)
 // ------------------------------------------------------------------------------------------
 // Observations per thread: a launch parameter.  A workgroup's life is `rows` sequential observations per lane, and these kernels
 // are VALU-bound per SIMD, so the grid should fill the resident workgroup slots of the chip evenly in ONE generation; a fixed 16
