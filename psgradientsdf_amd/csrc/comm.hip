@@ -251,6 +251,8 @@ int xr_alloc(psgsdf_ctx* c, void** p, size_t bytes, bool polled) {
 namespace {
 typedef float v4f_probe_t __attribute__((ext_vector_type(4)));
 constexpr int kProbeRecs = 2048, kProbeRounds = 48, kProbeFlagDoubles = 64;
+// (the instruction of device_common.h store8_system / pcg.hip store8_sys, spelled out: this file does not include the kernels' header)
+__device__ __forceinline__ void probe_store8(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
 // Two roles, one workgroup each.  OWNER (towards the lower neighbour): pull the payload into this device's caches, wait for the neighbour's
 // round flag (system-scope relaxed loads), ONE system-scope acquire fence, read the payload with plain loads and count records that do not
 // carry the round, answer.  PEER (towards the upper neighbour): write-through stores into its payload -- 16-byte records in even rounds (the classic
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(256) k_xr_probe(double* myF, const float4* myP
         for (int r = 1; r <= kProbeRounds; ++r) {
             // even rounds: k_cgf_solve's hand-off (16-byte sc0 sc1 records); odd rounds: k_cgp_solve's, the frame rows' and the scalar folds' (8-byte
             // sc0 sc1 words: device_common.h store8_system / pcg.hip store8_sys) -- the default solve is the pipelined one
-            if (r & 1) for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { store8_system((double*)hiP + 2 * i, (double)r); store8_system((double*)hiP + 2 * i + 1, (double)(r + i)); }
+            if (r & 1) for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { probe_store8((double*)hiP + 2 * i, (double)r); probe_store8((double*)hiP + 2 * i + 1, (double)(r + i)); }
             else for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) {
                 const v4f_probe_t d = {(float)r, 0.f, 0.f, (float)(r + i)};
                 asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(hiP + i), "v"(d) : "memory");
