@@ -254,7 +254,7 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
     eng.watch_kernel("")
     sync_stats = eng.debug_sync_stats()
     solve_model = None
-    if headline and dom == "pcg_solve" and not slab:
+    if headline and dom == "pcg_solve" and not slab and os.environ.get("PSGSDF_BENCH_NO_SOLVE_MODEL") != "1":      # (off under the kernel trace of tools/profile_round.sh: the forced-pass launches would sit in the solve's statistics)
         # what the dominant kernel's time is made of, measured live: the same launch forced to 16 and to 48 passes (stop rule off) -> time per pass
         # and the fixed part (assembly of the system from the sweep's voxel blocks, first records, distance update, launch ramp)
         try:

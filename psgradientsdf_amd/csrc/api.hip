@@ -387,12 +387,24 @@ static int set_keyframes_impl(psgsdf_ctx* c, int n_frames, const int32_t* frame_
         c->img_compacted = false;
         if (c->img_compact && npix < ((size_t)1 << 30) && (size_t)n_frames * height < ((size_t)1 << 24)) {
             const float scale = 1.0f / 255.0f;
-            HIPCHK(c, hipMalloc(&c->img8, sizeof(unsigned) * npix));
-            HIPCHK(c, hipMemsetAsync(c->d_total, 0, sizeof(int), c->stream));
-            launch_try_pack_f32(c->img, c->img8, npix, scale, c->d_total, c->stream);
+            // a sample first (every 61st pixel, nothing written: data that is not 8-bit at all is recognised in microseconds), the full pass only behind a clean sample
+            int* d_flags = nullptr; std::vector<int> h_flags(kTryPackFlags);
+            HIPCHK(c, hipMalloc(&d_flags, sizeof(int) * kTryPackFlags));
+            auto any_miss = [&](unsigned* out, size_t stride, int* bad) -> int {
+                if (hipMemsetAsync(d_flags, 0, sizeof(int) * kTryPackFlags, c->stream) != hipSuccess) return fail(c, PSGSDF_ERR_DEVICE, "set_keyframes: 8-bit check");
+                launch_try_pack_f32(c->img, out, npix, stride, scale, d_flags, c->stream);
+                if (hipMemcpyAsync(h_flags.data(), d_flags, sizeof(int) * kTryPackFlags, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return fail(c, PSGSDF_ERR_DEVICE, "set_keyframes: 8-bit check");
+                *bad = 0; for (int v : h_flags) *bad |= v;
+                return 0;
+            };
             int bad = 1;
-            HIPCHK(c, hipMemcpyAsync(&bad, c->d_total, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            int prc = any_miss(nullptr, 61, &bad);
+            if (!prc && !bad) {
+                if (hipMalloc(&c->img8, sizeof(unsigned) * npix) != hipSuccess) prc = fail(c, PSGSDF_ERR_DEVICE, "set_keyframes: out of memory");
+                else prc = any_miss(c->img8, 1, &bad);
+            }
+            hipFree(d_flags);
+            if (prc) return prc;
             if (bad) { hipFree(c->img8); c->img8 = nullptr; }
             else { hipFree(c->img); c->img = nullptr; c->img_scale = scale; c->img_compacted = true; }
         }

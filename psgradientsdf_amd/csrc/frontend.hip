@@ -168,13 +168,16 @@ __global__ void __launch_bounds__(kBlock) k_pack_rgb8(const uint8_t* __restrict_
 // float keyframes that ARE 8-bit data -- every channel equal to RN((float)b * scale) for a byte b, which is what the reference's loader produces from a
 // PNG (ImageLoader.h:181 convertTo(CV_32FC3, 1.0f / 255.0f)) -- can be kept as RGBA8 words: the sampler's (float)b * scale gives back the same floats.
 // *fail becomes non-zero if any channel is not such a value (the words are then not used).
-// One flag for the whole image stack, and no same-address atomics on it (round 4 did one atomicOr per wavefront that saw a non-8-bit channel: 240 k
-// serialised atomics, 2.7 ms for 50 x 640 x 480 float keyframes -- DESIGN.md 4 "No same-address atomics"): a wavefront that finds one stores a plain 1
-// only while the flag still reads 0, and every wavefront looks at the flag before each pixel it takes and leaves as soon as it is set -- nothing it
-// would pack will be used.
-__global__ void __launch_bounds__(kBlock) k_try_pack_f32(const float* __restrict__ rgb, unsigned* __restrict__ rgba, size_t npix, float scale, float inv_scale, int* __restrict__ fail) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
-        if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+// One flag for the whole image stack, and no same-address traffic on it: round 4 did one atomicOr per wavefront that saw a non-8-bit channel (240 k
+// serialised atomics: 2.7 ms for 50 x 640 x 480 float keyframes -- DESIGN.md 4 "No same-address atomics"); polling the flag once per pixel instead (round
+// 5's first version) hammered its memory channel just the same (143-154 us on rendered floats, more than the 50 us a full pass takes).  Now in two steps:
+// a SAMPLE of the stack (every `stride`-th pixel, nothing written) decides for data that is not 8-bit at all -- rendered or filtered images fail at the
+// first non-background pixel: ~9 us; (one flag word per WORKGROUP: 3 900 wavefronts storing the same 1 to ONE word still took 140 us) --, and only a sample without a miss is followed by the full pass, which streams the stack once (184 MB in, 61 MB
+// out at 50 x 640 x 480: 50 us = 4.9 TB/s) and never reads the flag; a wavefront that still finds a miss stores a plain 1 and leaves.
+__global__ void __launch_bounds__(kBlock) k_try_pack_f32(const float* __restrict__ rgb, unsigned* __restrict__ rgba, size_t npix, size_t stride, float scale, float inv_scale, int* __restrict__ fail) {
+    const size_t n = (npix + stride - 1) / stride;
+    for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = q * stride;
         unsigned w = 0; bool bad = false;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -184,16 +187,18 @@ __global__ void __launch_bounds__(kBlock) k_try_pack_f32(const float* __restrict
             bad = bad || !ok;
             w |= (ok ? (unsigned)bf : 0u) << (8 * ch);
         }
-        rgba[i] = w;
-        if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {      // (a benign race: every writer writes the same 1)
-            if (bad && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (rgba) rgba[i] = w;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {      // one store per wavefront that found a miss, into ITS WORKGROUP'S flag (kTryPackFlags distinct words: the host ORs them), then it leaves
+            if (bad && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(bad))) fail[blockIdx.x] = 1;
             return;
         }
     }
 }
-void launch_try_pack_f32(const float* rgb, unsigned* rgba, size_t npix, float scale, int* fail, hipStream_t s) {
-    // grid-stride over a few workgroups per CU: 8-bit data streams through once (184 MB in, 61 MB out at 50 x 640 x 480), anything else ends within the first pixels
-    if (npix) hipLaunchKernelGGL(k_try_pack_f32, dim3((unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, 256 * 8)), dim3(kBlock), 0, s, rgb, rgba, npix, scale, 1.0f / scale, fail);
+// step 1: the sample (rgba = nullptr: nothing is written); step 2 (only if the sample had no miss): the full pass
+void launch_try_pack_f32(const float* rgb, unsigned* rgba, size_t npix, size_t stride, float scale, int* fail, hipStream_t s) {
+    if (!npix) return;
+    const size_t n = (npix + stride - 1) / stride;
+    hipLaunchKernelGGL(k_try_pack_f32, dim3((unsigned)std::min<size_t>((n + kBlock - 1) / kBlock, (size_t)kTryPackFlags)), dim3(kBlock), 0, s, rgb, rgba, npix, stride, scale, 1.0f / scale, fail);
 }
 void launch_pack_rgb8(const uint8_t* rgb, unsigned* rgba, size_t npix, hipStream_t s) {
     if (npix) hipLaunchKernelGGL(k_pack_rgb8, dim3((unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, 65535)), dim3(kBlock), 0, s, rgb, rgba, npix);
