@@ -317,28 +317,42 @@ __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, i
     if (!s_last) return;
     if (threadIdx.x == 0) __hip_atomic_store(a.acc.fdone + a.F, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.xf) {
-        // multi-rank tail: every frame of THIS slab is out.  Element (f, l) of the global rows: wait for the R flags of frame f (bounded), add the
-        // R slabs' values in rank order -- the same bits on every rank -- and put the row where the solves read it; then one lane per frame solves.
+        // multi-rank tail: every frame of THIS slab is out.  (a) wait for the R flags of every frame (bounded), (b) element (f, l) of the global rows:
+        // the R slabs' values added in rank order -- the same bits on every rank -- and put where the solves read them, (c) one lane per frame solves.
         const XfTable& t = *a.xf;
         const int Rk = t.n_ranks, buf = (int)(a.xf_epoch & 1);
         const double tag = (double)a.xf_epoch;
         double* const mine = t.region[t.rank];
-        for (int i = threadIdx.x; i < a.F * NV; i += blockDim.x) {
-            const int ff = i / NV, l = i - ff * NV;
+        // (a) one thread per frame waits for the frame's R flags -- F x R polls in all, not F x NV x R; a frame whose wait expires is marked late
+        __shared__ unsigned char s_late[kMaxFramesLds];
+        for (int ff = threadIdx.x; ff < a.F; ff += blockDim.x) {
             bool late = false; int late_rank = -1;
             for (int r = 0; r < Rk && !late; ++r) {
                 const double* fp = mine + t.flg + ((long long)buf * Rk + r) * t.F + ff;
                 int spins = 0;
                 while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > t.spin_max) { late = true; late_rank = r; break; } }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-            double tot = 0.0;
-            for (int r = 0; r < Rk; ++r) tot += __hip_atomic_load(mine + t.pay + (((long long)buf * Rk + r) * t.F + ff) * kFrameRow + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            s_late[ff] = late ? 1 : 0;
             if (late) {      // (a rank that never delivers: the host sees the NaN energy and reports PSGSDF_ERR_DEVICE -- and what was missing: engine.hip deliver_first)
-                tot = __builtin_nan("");
                 __hip_atomic_store(mine + kXrLate, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(mine + kXrLate + 3, (double)(late_rank * 1000 + ff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        __syncthreads();
+        // (b) every flag has been seen: element (f, l) = the R slabs' values in rank order, R independent loads in flight per element
+        for (int i = threadIdx.x; i < a.F * NV; i += blockDim.x) {
+            const int ff = i / NV, l = i - ff * NV;
+            const double* p0 = mine + t.pay + ((long long)buf * Rk * t.F + ff) * kFrameRow + l;
+            double tot = 0.0;
+            for (int r0 = 0; r0 < Rk; r0 += 8) {      // eight ranks' values in flight at a time (registers, not scratch: this code sits in the sweeps' kernels)
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = r0 + j < Rk ? __hip_atomic_load(p0 + (long long)(r0 + j) * t.F * kFrameRow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tot += v[j];
+            }
+            if (s_late[ff]) tot = __builtin_nan("");
             __hip_atomic_store(a.acc.frame + (size_t)ff * kFrameRow + l, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
