@@ -67,7 +67,7 @@ def test_n_ranks_share_the_gpu(built, world):
         assert all(c["ok"] for c in checks)
         assert degraded == (mg["persist_fallbacks"] > 0)
     small, full = d["multi_gpu"]["self_check"]
-    assert small["rel_diff"] <= 1e-5 and full["rel_diff"] <= 1e-4 and "the measured one" in full["scene"]
+    assert small["rel_diff"] <= 1e-5 and full["rel_diff"] <= 1e-5 and "the measured one" in full["scene"]
     assert d["extra"]["weak"]["scaling"] == "weak" and d["extra"]["weak"]["value"] > 0 and f"{8 * world} keyframes" in d["extra"]["weak"]["workload"]
     assert d["extra"]["configs4_strong"]["scaling"] == "strong" and "2 visibility words" in d["extra"]["configs4_strong"]["workload"]
     assert d["spread"]["reps"] == 2 and d["spread"]["min"] <= d["value"] <= d["spread"]["max"]
