@@ -248,6 +248,64 @@ __device__ __forceinline__ void frame_solve_pose(const SweepArgs& a, FrameP* fra
     }
 }
 
+// What the LAST workgroup of a frame-major launch does once every frame's final row is in a.acc.frame: (multi-rank: the per-frame solves, one lane per
+// frame --) the LED light vector over all frames, and the energy / n_obs sums over the frames into the mailbox.  Shared by the sweeps' own epilogue
+// (single rank: the frames were solved by their own last workgroups) and by k_frame_gather (multi-rank).
+template <int NV, int KIND, int MODEL>
+__device__ __forceinline__ void frame_tail(const SweepArgs& a, double* lds, bool solve_all) {
+    if (solve_all) {
+        for (int ff = threadIdx.x; ff < a.F; ff += blockDim.x) {
+            const double* row = a.acc.frame + (size_t)ff * kFrameRow;
+            if (KIND == 0) { if (!ModelTraits<MODEL>::LED) frame_solve_light_sh<ModelTraits<MODEL>::NB == 3 ? 4 : ModelTraits<MODEL>::NB>(a.fm_frames, ff, row, a.fm_undo); }
+            else frame_solve_pose(a, a.fm_frames, ff, row);
+        }
+        __syncthreads();
+    }
+    if (KIND == 0 && ModelTraits<MODEL>::LED) {
+        // LED: ONE light vector over all frames (LedOptimizer.cpp:128-160): this workgroup is the last of the whole sweep, every frame's final row is
+        // in place and no workgroup reads a frame record any more -- k_solve_light's arithmetic (sums over the frames in frame order, three
+        // scalar equations, every frame's copy updated), thread 0 solving, all threads updating
+        constexpr int NHL = 3;
+        __shared__ float s_dl[3];
+        if (a.fm_undo) {
+            for (int i = threadIdx.x; i < a.F * 9; i += blockDim.x) a.fm_undo[i] = a.fm_frames[i / 9].l[i % 9];
+            if (threadIdx.x < 3) a.fm_undo[a.F * 9 + threadIdx.x] = a.fm_led_light[threadIdx.x];
+        }
+        __shared__ double srow[6 * kMaxFramesLds];      // the six columns staged by all threads at once (summed straight from memory: 2 x F dependent loads per thread)
+        for (int i = threadIdx.x; i < 6 * a.F; i += blockDim.x) { const int ff = i / 6, c6 = i % 6; srow[c6 * kMaxFramesLds + ff] = __hip_atomic_load(a.acc.frame + (size_t)ff * kFrameRow + (c6 < 3 ? c6 : NHL + c6 - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int ch = threadIdx.x;
+            double hs = 0, bs = 0;
+            for (int ff = 0; ff < a.F; ++ff) { hs += srow[ch * kMaxFramesLds + ff]; bs += srow[(3 + ch) * kMaxFramesLds + ff]; }
+            float h = (float)hs; const float bb = (float)bs;
+            if (a.damping != 0.0f) h += a.damping * h;
+            double Hd[1] = {(double)h}, bd[1] = {(double)bb}, xd[1];
+            solve_spd<1>(Hd, bd, xd);
+            s_dl[ch] = (float)xd[0];
+        }
+        __syncthreads();
+        for (int ff = threadIdx.x; ff < a.F; ff += blockDim.x) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { const float nl = a.fm_frames[ff].l[ch] - s_dl[ch]; a.fm_frames[ff].l[ch] = nl; if (ff == 0) a.fm_led_light[ch] = nl; }
+        }
+    }
+    if (a.fm_e_out) {      // energy / n_obs over the frames, in frame_rows_finish's order (one 256-thread workgroup, threads striding the frames)
+        constexpr int col_e = NV - 2;
+        double e = 0, n = 0;
+        for (int ff = threadIdx.x; ff < a.F; ff += blockDim.x) {
+            e += __hip_atomic_load(a.acc.frame + (size_t)ff * kFrameRow + col_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n += __hip_atomic_load(a.acc.frame + (size_t)ff * kFrameRow + col_e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        e = wave_sum(e); n = wave_sum(n);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) { lds[2 * w] = e; lds[2 * w + 1] = n; }
+        __syncthreads();
+        if (threadIdx.x == 0) { double te = 0, tn = 0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { te += lds[2 * i]; tn += lds[2 * i + 1]; } mbox_put(a.fm_e_out, 2, 0, te, a.fm_e_key); mbox_put(a.fm_e_out, 2, 1, tn, a.fm_e_key); mbox_commit(a.fm_e_key); }
+    }
+}
+
 // Epilogue of the frame-major sweeps: every workgroup stores ITS partial row of frame f (plain stores, no floating-point atomics) and
 // takes a ticket on the frame's arrival counter; the LAST workgroup of the frame to arrive sums the frame's partial rows in launch order
 // into the final row -- reproducible from run to run, and done while the other frames' workgroups are still sweeping.
@@ -304,8 +362,9 @@ __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, i
         else a.acc.frame[(size_t)f * kFrameRow + threadIdx.x] = s;
     }
     if (!solve) return;
+    if (a.xf) return;      // multi-rank: this frame's slab row is out; k_frame_gather (launched behind the sweep) forms the global rows and solves
     __syncthreads();
-    if (threadIdx.x == 0 && !a.xf) {
+    if (threadIdx.x == 0) {
         if (KIND == 0) { if (!ModelTraits<MODEL>::LED) frame_solve_light_sh<ModelTraits<MODEL>::NB == 3 ? 4 : ModelTraits<MODEL>::NB>(a.fm_frames, f, lds, a.fm_undo); }
         else frame_solve_pose(a, a.fm_frames, f, lds);
     }
@@ -316,96 +375,79 @@ __device__ __forceinline__ void frame_rows_publish(const SweepArgs& a, int cx, i
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x == 0) __hip_atomic_store(a.acc.fdone + a.F, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.xf) {
-        // multi-rank tail: every frame of THIS slab is out.  (a) wait for the R flags of every frame (bounded), (b) element (f, l) of the global rows:
-        // the R slabs' values added in rank order -- the same bits on every rank -- and put where the solves read them, (c) one lane per frame solves.
-        const XfTable& t = *a.xf;
-        const int Rk = t.n_ranks, buf = (int)(a.xf_epoch & 1);
-        const double tag = (double)a.xf_epoch;
-        double* const mine = t.region[t.rank];
-        // (a) one thread per frame waits for the frame's R flags -- F x R polls in all, not F x NV x R; a frame whose wait expires is marked late
-        __shared__ unsigned char s_late[kMaxFramesLds];
-        for (int ff = threadIdx.x; ff < a.F; ff += blockDim.x) {
-            bool late = false; int late_rank = -1;
-            for (int r = 0; r < Rk && !late; ++r) {
-                const double* fp = mine + t.flg + ((long long)buf * Rk + r) * t.F + ff;
-                int spins = 0;
-                while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > t.spin_max) { late = true; late_rank = r; break; } }
-            }
-            s_late[ff] = late ? 1 : 0;
-            if (late) {      // (a rank that never delivers: the host sees the NaN energy and reports PSGSDF_ERR_DEVICE -- and what was missing: engine.hip deliver_first)
-                __hip_atomic_store(mine + kXrLate, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(mine + kXrLate + 3, (double)(late_rank * 1000 + ff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        __syncthreads();
-        // (b) every flag has been seen: element (f, l) = the R slabs' values in rank order, R independent loads in flight per element
-        for (int i = threadIdx.x; i < a.F * NV; i += blockDim.x) {
-            const int ff = i / NV, l = i - ff * NV;
-            const double* p0 = mine + t.pay + ((long long)buf * Rk * t.F + ff) * kFrameRow + l;
-            double tot = 0.0;
-            for (int r0 = 0; r0 < Rk; r0 += 8) {      // eight ranks' values in flight at a time (registers, not scratch: this code sits in the sweeps' kernels)
-                double v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = r0 + j < Rk ? __hip_atomic_load(p0 + (long long)(r0 + j) * t.F * kFrameRow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) tot += v[j];
-            }
-            if (s_late[ff]) tot = __builtin_nan("");
-            __hip_atomic_store(a.acc.frame + (size_t)ff * kFrameRow + l, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int ff = threadIdx.x; ff < a.F; ff += blockDim.x) {
-            const double* row = a.acc.frame + (size_t)ff * kFrameRow;
-            if (KIND == 0) { if (!ModelTraits<MODEL>::LED) frame_solve_light_sh<ModelTraits<MODEL>::NB == 3 ? 4 : ModelTraits<MODEL>::NB>(a.fm_frames, ff, row, a.fm_undo); }
-            else frame_solve_pose(a, a.fm_frames, ff, row);
-        }
-        __syncthreads();
-    }
-    if (KIND == 0 && ModelTraits<MODEL>::LED) {
-        // LED: ONE light vector over all frames (LedOptimizer.cpp:128-160): this workgroup is the last of the whole sweep, every frame's final row is
-        // in place and no workgroup reads a frame record any more -- k_solve_light's arithmetic (sums over the frames in frame order, three
-        // scalar equations, every frame's copy updated), thread 0 solving, all threads updating
-        constexpr int NHL = 3;
-        __shared__ float s_dl[3];
-        if (a.fm_undo) {
-            for (int i = threadIdx.x; i < a.F * 9; i += blockDim.x) a.fm_undo[i] = a.fm_frames[i / 9].l[i % 9];
-            if (threadIdx.x < 3) a.fm_undo[a.F * 9 + threadIdx.x] = a.fm_led_light[threadIdx.x];
-        }
-        __shared__ double srow[6 * kMaxFramesLds];      // the six columns staged by all threads at once (summed straight from memory: 2 x F dependent loads per thread)
-        for (int i = threadIdx.x; i < 6 * a.F; i += blockDim.x) { const int ff = i / 6, c6 = i % 6; srow[c6 * kMaxFramesLds + ff] = __hip_atomic_load(a.acc.frame + (size_t)ff * kFrameRow + (c6 < 3 ? c6 : NHL + c6 - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            const int ch = threadIdx.x;
-            double hs = 0, bs = 0;
-            for (int ff = 0; ff < a.F; ++ff) { hs += srow[ch * kMaxFramesLds + ff]; bs += srow[(3 + ch) * kMaxFramesLds + ff]; }
-            float h = (float)hs; const float bb = (float)bs;
-            if (a.damping != 0.0f) h += a.damping * h;
-            double Hd[1] = {(double)h}, bd[1] = {(double)bb}, xd[1];
-            solve_spd<1>(Hd, bd, xd);
-            s_dl[ch] = (float)xd[0];
-        }
-        __syncthreads();
-        for (int ff = threadIdx.x; ff < a.F; ff += blockDim.x) {
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) { const float nl = a.fm_frames[ff].l[ch] - s_dl[ch]; a.fm_frames[ff].l[ch] = nl; if (ff == 0) a.fm_led_light[ch] = nl; }
+    frame_tail<NV, KIND, MODEL>(a, lds, false);
+}
+
+// Multi-rank: the slabs' rows of a frame meet here, not inside the sweep.  The sweep's workgroups publish their slab's row of every frame into all
+// ranks' regions and are done (frame_rows_publish); this kernel, launched behind the sweep on the same stream, has one workgroup per kGatherFrames
+// frames: (a) wait -- bounded -- for the R flags of its frames, (b) element (f, l) of the global rows = the R slabs' values added in rank order (the
+// same bits on every rank), written where the solves read them; the last workgroup to finish solves every frame (one lane each), the LED light vector
+// and the energy sums (frame_tail).  Waiting happens in <= F / kGatherFrames workgroups of a kernel that starts when this rank's sweep has published
+// everything the other ranks could be waiting for: no rank's progress ever depends on a waiting workgroup of another rank (round 4's in-sweep waits
+// dead-locked at world size 8, profiles/r05_notes.md section 1; round 5's first fix did all of this in the sweep's very last workgroup: F x NV / 256
+// serial gather rounds -- 45 us at 400 keyframes).
+constexpr int kGatherFrames = 16;
+template <int NV, int KIND, int MODEL>
+__global__ void __launch_bounds__(kBlock) k_frame_gather(SweepArgs a) {
+    __shared__ double lds[(kBlock / 64) * NV > 2 * (kBlock / 64) ? (kBlock / 64) * NV : 2 * (kBlock / 64)];
+    __shared__ unsigned char s_late[kGatherFrames];
+    __shared__ int s_last;
+    const XfTable& t = *a.xf;
+    const int Rk = t.n_ranks, buf = (int)(a.xf_epoch & 1);
+    const double tag = (double)a.xf_epoch;
+    double* const mine = t.region[t.rank];
+    const int f0 = blockIdx.x * kGatherFrames, nf = min(kGatherFrames, a.F - f0);
+    if (threadIdx.x < kGatherFrames) s_late[threadIdx.x] = 0;
+    __syncthreads();
+    // (a) one thread per (frame, rank) flag
+    for (int q = threadIdx.x; q < nf * Rk; q += blockDim.x) {
+        const int ff = f0 + q / Rk, r = q - (q / Rk) * Rk;
+        const double* fp = mine + t.flg + ((long long)buf * Rk + r) * t.F + ff;
+        int spins = 0; bool late = false;
+        while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > t.spin_max) { late = true; break; } }
+        if (late) {      // (a rank that never delivers: the host sees the NaN energy and reports PSGSDF_ERR_DEVICE -- and what was missing: engine.hip deliver_first)
+            s_late[ff - f0] = 1;
+            __hip_atomic_store(mine + kXrLate, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(mine + kXrLate + 3, (double)(r * 1000 + ff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (a.fm_e_out) {      // energy / n_obs over the frames, in frame_rows_finish's order (one 256-thread workgroup, threads striding the frames)
-        constexpr int col_e = NV - 2;
-        double e = 0, n = 0;
-        for (int ff = threadIdx.x; ff < a.F; ff += blockDim.x) {
-            e += __hip_atomic_load(a.acc.frame + (size_t)ff * kFrameRow + col_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            n += __hip_atomic_load(a.acc.frame + (size_t)ff * kFrameRow + col_e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
+    // (b) the global rows of this workgroup's frames
+    for (int i = threadIdx.x; i < nf * NV; i += blockDim.x) {
+        const int fl = i / NV, l = i - fl * NV, ff = f0 + fl;
+        const double* p0 = mine + t.pay + ((long long)buf * Rk * t.F + ff) * kFrameRow + l;
+        double tot = 0.0;
+        for (int r0 = 0; r0 < Rk; r0 += 8) {      // eight ranks' values in flight at a time
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = r0 + j < Rk ? __hip_atomic_load(p0 + (long long)(r0 + j) * t.F * kFrameRow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tot += v[j];
         }
-        e = wave_sum(e); n = wave_sum(n);
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        __syncthreads();
-        if (lane == 0) { lds[2 * w] = e; lds[2 * w + 1] = n; }
-        __syncthreads();
-        if (threadIdx.x == 0) { double te = 0, tn = 0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { te += lds[2 * i]; tn += lds[2 * i + 1]; } mbox_put(a.fm_e_out, 2, 0, te, a.fm_e_key); mbox_put(a.fm_e_out, 2, 1, tn, a.fm_e_key); mbox_commit(a.fm_e_key); }
+        if (s_late[fl]) tot = __builtin_nan("");
+        __hip_atomic_store(a.acc.frame + (size_t)ff * kFrameRow + l, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(a.acc.fdone + a.F, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(a.acc.fdone + a.F, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    frame_tail<NV, KIND, MODEL>(a, lds, true);
+}
+template <int KIND>
+static void launch_frame_gather(const SweepArgs& a, hipStream_t s) {
+    const dim3 g((a.F + kGatherFrames - 1) / kGatherFrames), bl(kBlock);
+    constexpr int NVP = 21 + 6 + 2;
+    if (KIND == 1) {
+        if (a.model == 0) hipLaunchKernelGGL((k_frame_gather<NVP, 1, 0>), g, bl, 0, s, a);
+        else if (a.model == 1) hipLaunchKernelGGL((k_frame_gather<NVP, 1, 1>), g, bl, 0, s, a);
+        else hipLaunchKernelGGL((k_frame_gather<NVP, 1, 2>), g, bl, 0, s, a);
+    } else {      // light rows: NH + NB + 2 (SH1: 10 + 4 + 2, SH2: 45 + 9 + 2, LED: 3 + 3 + 2)
+        if (a.model == 0) hipLaunchKernelGGL((k_frame_gather<16, 0, 0>), g, bl, 0, s, a);
+        else if (a.model == 1) hipLaunchKernelGGL((k_frame_gather<56, 0, 1>), g, bl, 0, s, a);
+        else hipLaunchKernelGGL((k_frame_gather<8, 0, 2>), g, bl, 0, s, a);
     }
 }
 
@@ -491,6 +533,7 @@ int launch_sweep_light(const SweepArgs& a, hipStream_t s) {
     const int chunk = kBlock * rows;
     dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
     PSG_LAUNCH_SWEEP(k_sweep_light, a, true, g, bl, 0, s, a, rows);
+    if (a.xf && a.fm_solve) launch_frame_gather<0>(a, s);      // multi-rank: the slabs' rows meet, and the frames are solved, in a kernel of their own behind the sweep
     return (int)g.x;
 }
 
@@ -589,6 +632,7 @@ int launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
     const int chunk = kBlock * rows;
     dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
     PSG_LAUNCH_SWEEP(k_sweep_pose, a, true, g, bl, 0, s, a, rows);
+    if (a.xf && a.fm_solve) launch_frame_gather<1>(a, s);
     return (int)g.x;
 }
 
