@@ -297,10 +297,12 @@ __global__ void __launch_bounds__(kBlock) k_sum_parts(const double* __restrict__
     __shared__ double red[kBlock / 64];
     double t[8];
     for (int s = 0; s < slots.n; ++s) { t[s] = block_total(part + (size_t)slots.id[s] * PB, nblk, red); __syncthreads(); }
-    if (threadIdx.x == 0) {
-        if (xf) fold_exchange(xf, xf_epoch, slots.n, t);      // multi-rank: the sums over all slabs (device_common.h)
-        for (int s = 0; s < slots.n; ++s) mbox_put(out, slots.n, s, t[s], key);
-        mbox_commit(key);
+    if (threadIdx.x < 64) {
+        if (xf) fold_exchange(xf, xf_epoch, slots.n, t);      // multi-rank: the sums over all slabs (device_common.h; the whole first wavefront takes part)
+        if (threadIdx.x == 0) {
+            for (int s = 0; s < slots.n; ++s) mbox_put(out, slots.n, s, t[s], key);
+            mbox_commit(key);
+        }
     }
 }
 void launch_sum_parts(const double* part, int PB, int nblk, const SlotList& slots, double* out, unsigned long long key, hipStream_t s, const XfTable* xf, long long xf_epoch) {

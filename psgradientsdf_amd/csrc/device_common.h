@@ -250,30 +250,37 @@ __device__ __forceinline__ void mbox_put(double* out, int n, int i, double v, un
 __device__ __forceinline__ void mbox_commit(unsigned long long key) { if (key) __threadfence_system(); }
 // 8-byte write-through store at system scope: the word reaches memory (another device's view) without a later write-back
 __device__ __forceinline__ void store8_system(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
-// Multi-rank fold (ONE thread): this slab's n <= 8 sums go into slot [parity][rank] of EVERY rank's mailbox region (payload, drained, then a flag
-// carrying the fold's number), the R ranks' sums come back out of the own region and are added in rank order -- the same bits on every rank.
-// A rank that never delivers (bounded wait) turns the sums into NaN; the host reports it.
+// Multi-rank fold (ONE WAVEFRONT, all 64 lanes call; lane 0 holds the slab's n <= 8 sums): they go into slot [parity][rank] of EVERY rank's mailbox
+// region (payload, drained, then a flag carrying the fold's number); lane r waits for rank r's flag -- R polls side by side instead of one after the
+// other: a fold sits on the iteration's critical path several times per iteration and a poll of an uncached word costs ~0.7 us -- and loads rank r's
+// sums; they are added in rank order, the same bits on every rank and in every lane.  A rank that never delivers (bounded wait) turns the sums into
+// NaN and leaves its mark in the region's "late" word; the host reports it.
 __device__ __forceinline__ void fold_exchange(const XfTable* xf, long long epoch, int n, double* t) {
     const XfTable& x = *xf;
-    const int Rk = x.n_ranks, buf = (int)(epoch & 1);
+    const int Rk = x.n_ranks, buf = (int)(epoch & 1), lane = (int)(threadIdx.x & 63);
     const double tag = (double)epoch;
     const long long slot = (long long)buf * Rk + x.rank;
-    for (int r = 0; r < Rk; ++r) for (int s = 0; s < n; ++s) store8_system(x.region[r] + x.spay + slot * 8 + s, t[s]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int r = 0; r < Rk; ++r) __hip_atomic_store(x.region[r] + x.sflg + slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     double* const mine = x.region[x.rank];
-    bool late = false;
-    for (int r = 0; r < Rk && !late; ++r) {
-        int spins = 0;
-        while (__hip_atomic_load(mine + x.sflg + (long long)buf * Rk + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > x.spin_max) { late = true; break; } }
+    for (int s = 0; s < n; ++s) t[s] = __shfl(t[s], 0, 64);
+    if (lane == 0) {
+        for (int r = 0; r < Rk; ++r) for (int s = 0; s < n; ++s) store8_system(x.region[r] + x.spay + slot * 8 + s, t[s]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int r = 0; r < Rk; ++r) __hip_atomic_store(x.region[r] + x.sflg + slot, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    bool late = false;
+    if (lane < Rk) {
+        int spins = 0;
+        while (__hip_atomic_load(mine + x.sflg + (long long)buf * Rk + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != tag) { __builtin_amdgcn_s_sleep(2); if (++spins > x.spin_max) { late = true; break; } }
+    }
+    const bool any_late = __builtin_amdgcn_ballot_w64(late) != 0ull;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     for (int s = 0; s < n; ++s) {
+        const double v = lane < Rk ? __hip_atomic_load(mine + x.spay + ((long long)buf * Rk + lane) * 8 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
         double tot = 0.0;
-        for (int r = 0; r < Rk; ++r) tot += __hip_atomic_load(mine + x.spay + ((long long)buf * Rk + r) * 8 + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        t[s] = late ? __builtin_nan("") : tot;
+        for (int r = 0; r < Rk; ++r) tot += __shfl(v, r, 64);
+        t[s] = any_late ? __builtin_nan("") : tot;
     }
-    if (late) __hip_atomic_store(mine + kXrLate + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (out of band: the host tells a lost peer from a NaN state, engine.hip deliver_first)
+    if (any_late && lane == 0) __hip_atomic_store(mine + kXrLate + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (out of band: the host tells a lost peer from a NaN state, engine.hip deliver_first)
 }
 // a.fold: sum the partial slots the PREVIOUS kernel left behind (first workgroup only; all its threads must call).
 // The calling kernel must not write the folded slots itself (engine.hip: take_fold checks).
@@ -281,10 +288,12 @@ __device__ __forceinline__ void fold_pending(const SweepArgs& a, double* red /*[
     if (a.fold.n == 0 || blockIdx.x != 0 || blockIdx.y != 0) return;
     double t[4];
     for (int s = 0; s < a.fold.n; ++s) t[s] = block_total(PART(a, a.fold.id[s]), a.fold.nblk, red);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {      // (the exchange between the ranks takes the whole first wavefront)
         if (a.fold.xf) fold_exchange(a.fold.xf, a.fold.xf_epoch, a.fold.n, t);
-        for (int s = 0; s < a.fold.n; ++s) mbox_put(a.fold.out, a.fold.n, s, t[s], a.fold.key);
-        mbox_commit(a.fold.key);
+        if (threadIdx.x == 0) {
+            for (int s = 0; s < a.fold.n; ++s) mbox_put(a.fold.out, a.fold.n, s, t[s], a.fold.key);
+            mbox_commit(a.fold.key);
+        }
     }
     __syncthreads();
 }

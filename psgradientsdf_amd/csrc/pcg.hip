@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
     if (ASM && a.fold.n != 0 && blockIdx.x == 0) {
         // no k_assemble in front of this kernel to fold the sums the distance sweep left pending (device_common.h fold_pending): done here,
         // by the first 256 threads in that function's order (the same bits as in any 256-thread kernel)
-        double ftot[4];
+        double ftot[4] = {0.0, 0.0, 0.0, 0.0};
         for (int sl = 0; sl < a.fold.n; ++sl) {
             const double* part = PART(a, a.fold.id[sl]);
             double v = 0;
@@ -473,10 +473,12 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgf_solve(SweepArgs a, dou
             __syncthreads();
             if (tid == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; ftot[sl] = t; }
         }
-        if (tid == 0) {
+        if (tid < 64) {      // (the exchange between the ranks takes the whole first wavefront; lane 0 holds the slab's sums)
             if (a.fold.xf) fold_exchange(a.fold.xf, a.fold.xf_epoch, a.fold.n, ftot);      // multi-rank: the sums over all slabs
-            for (int sl = 0; sl < a.fold.n; ++sl) mbox_put(a.fold.out, a.fold.n, sl, ftot[sl], a.fold.key);
-            mbox_commit(a.fold.key);
+            if (tid == 0) {
+                for (int sl = 0; sl < a.fold.n; ++sl) mbox_put(a.fold.out, a.fold.n, sl, ftot[sl], a.fold.key);
+                mbox_commit(a.fold.key);
+            }
         }
         __syncthreads();
     }
@@ -862,7 +864,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
     unsigned cp[R][(kNQ - 1) / 2]; int row[R]; bool live[R];
     double x[R], r[R], w[R], z[R], sv[R], pv[R]; float inv[R];      // every vector of the recurrences in double: see "precision" above
     if (a.fold.n != 0 && blockIdx.x == 0) {      // the sums the distance sweep left pending (device_common.h fold_pending), in that function's order
-        double ftot[4];
+        double ftot[4] = {0.0, 0.0, 0.0, 0.0};
         for (int sl = 0; sl < a.fold.n; ++sl) {
             const double* part = PART(a, a.fold.id[sl]);
             double v = 0;
@@ -873,10 +875,12 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
             __syncthreads();
             if (tid == 0) { double t = 0; for (int i = 0; i < kBlock / 64; ++i) t += red[i]; ftot[sl] = t; }
         }
-        if (tid == 0) {
+        if (tid < 64) {      // (the exchange between the ranks takes the whole first wavefront; lane 0 holds the slab's sums)
             if (a.fold.xf) fold_exchange(a.fold.xf, a.fold.xf_epoch, a.fold.n, ftot);      // multi-rank: the sums over all slabs
-            for (int sl = 0; sl < a.fold.n; ++sl) mbox_put(a.fold.out, a.fold.n, sl, ftot[sl], a.fold.key);
-            mbox_commit(a.fold.key);
+            if (tid == 0) {
+                for (int sl = 0; sl < a.fold.n; ++sl) mbox_put(a.fold.out, a.fold.n, sl, ftot[sl], a.fold.key);
+                mbox_commit(a.fold.key);
+            }
         }
         __syncthreads();
     }
