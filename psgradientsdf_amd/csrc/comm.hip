@@ -11,6 +11,7 @@
 // stencil-direction bits; before a 2x refinement, of albedo and gradient).
 #include "engine_internal.h"
 
+#include <atomic>
 #include <chrono>
 #include <dlfcn.h>
 #include <unistd.h>
@@ -475,8 +476,8 @@ int xr_setup(psgsdf_ctx* c, const std::vector<double>& info) {
     // peers read it back THROUGH THEIR MAPPING before they rely on it.  (Round 5: with eight processes creating and destroying contexts in turn,
     // a rank was seen to sweep into a region nobody polled -- every peer timed out waiting for ITS flags while it saw all of theirs.  A mapping
     // that does not show the owner's nonce is not the owner's memory.)
-    static unsigned nonce_counter = 0;
-    const double nonce = (double)(getpid() % 1000000) * 4096.0 + (double)(++nonce_counter % 4096u) + 0.5;
+    static std::atomic<unsigned> nonce_counter{0};      // (contexts of one process may live on different host threads)
+    const double nonce = (double)(getpid() % 1000000) * 4096.0 + (double)((nonce_counter.fetch_add(1) + 1u) % 4096u) + 0.5;
     if (c->xr) {
         if (hipMemsetAsync(c->xr, 0, sizeof(double) * c->xr_doubles, c->stream) != hipSuccess
             || hipMemcpyAsync(c->xr + kXrNonce, &nonce, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess
