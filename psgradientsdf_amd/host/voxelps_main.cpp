@@ -110,7 +110,25 @@ static int selftest_sample(int n, int max_num) {
     return 0;
 }
 
+// the threaded writers print floats with snprintf("%g"), the reference with `ostream << float`: the same characters for EVERY float?  `--selftest-fmt N` formats N
+// pseudo-random bit patterns (all exponents, denormals, +-0, inf, nan) and a ladder of round-number cases both ways and counts the differences
+static int selftest_fmt(long n) {
+    unsigned long long x = 0x9e3779b97f4a7c15ull; long bad = 0, done = 0;
+    auto check = [&](float v) {
+        TextOut t; t.f(v);
+        std::ostringstream o; o << v;
+        if (o.str() != t.s) { if (bad < 5) std::cout << "MISMATCH " << o.str() << " vs " << t.s << std::endl; ++bad; }
+        ++done;
+    };
+    for (long i = 0; i < n; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; uint32_t u = (uint32_t)(x >> 16); float v; memcpy(&v, &u, 4); check(v); }
+    for (int e = -45; e <= 38; ++e) for (float m : {1.0f, 9.999995f, 9.9999995f, 1.234565f, 1.2345649f, 0.5f, 2.5f}) { check(m * std::pow(10.0f, (float)e)); check(-m * std::pow(10.0f, (float)e)); }
+    for (int i = 0; i <= 255; ++i) check((float)i * (1.0f / 255.0f));
+    std::cout << done << " " << bad << std::endl;
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char* argv[]) {
+    if (argc >= 3 && std::string(argv[1]) == "--selftest-fmt") return selftest_fmt(atol(argv[2]));
     if (argc >= 3 && std::string(argv[1]) == "--selftest-lapm") return selftest_lapm(argv[2]);
     if (argc >= 4 && std::string(argv[1]) == "--selftest-sample") return selftest_sample(atoi(argv[2]), atoi(argv[3]));
     if (argc >= 3 && std::string(argv[1]) == "--selftest-png") return selftest_png(argv[2]);

@@ -240,3 +240,13 @@ def test_keyframe_sampling_against_numpy(built, n, max_num):
     assert [int(r[3]) for r in rows] == want
     assert all(int(r[0]) == 3 * int(r[3]) + 1 and int(r[1]) == int(r[3]) and int(r[2]) == -int(r[3]) for r in rows)
     assert len(rows) == (max_num if n > max_num else n) and int(rows[-1][3]) == n - 1
+
+
+def test_threaded_writers_print_floats_like_the_reference(built):
+    """The round-5 writers format with snprintf("%g") into per-thread buffers; the reference (and round 4's writers) with `ostream << float`, one std::endl
+    per line.  `voxelPS --selftest-fmt N`: two million pseudo-random float bit patterns (every exponent, denormals, infinities, NaNs), a ladder of
+    values at the rounding edges of six significant digits and the 256 colour levels come out character for character the same both ways."""
+    r = subprocess.run([EXE, "--selftest-fmt", "2000000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-500:]
+    done, bad = (int(x) for x in r.stdout.strip().split("\n")[-1].split())
+    assert bad == 0 and done > 2000000
