@@ -512,7 +512,44 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     device = local_rank if world > 1 else 0
 
-    check = self_check(dist, rank, world, device, share, *(("SH2", 70) if args.model == "SH2" else ("SH1", 8))) if world > 1 else None
+    check, fallback = None, None
+    if world > 1:
+        # A first lease on a multi-GPU node must measure, not debug: the 64^3 self-check runs every in-kernel exchange between the real devices.  If it
+        # raises on any rank (a bounded wait expired: the engine names the exchange) or disagrees with the single context, ALL ranks fall back to the
+        # communicator paths (PSGSDF_XR=0: one RCCL all-reduce per PCG pass, rows / sums / halos over RCCL) and the line says so: `degraded`, `fallback`.
+        # A watchdog ends a rank that is stuck in a collective behind a failed peer (stack dump, non-zero exit) instead of hanging the lease.
+        import faulthandler
+        if not os.environ.get("PSGSDF_FAULT_DUMP"):
+            faulthandler.dump_traceback_later(int(os.environ.get("PSGSDF_BENCH_WATCHDOG_S", "1500")), exit=True)
+        if os.environ.get("PSGSDF_BENCH_FAULT"):      # test hook "rank:VAR=value": an environment variable for ONE rank (tests/test_bench_gpu.py: fault injection, development library)
+            r_, kv = os.environ["PSGSDF_BENCH_FAULT"].split(":", 1)
+            if int(r_) == rank:
+                os.environ.update(dict([kv.split("=", 1)]))
+        sc_args = ("SH2", 70) if args.model == "SH2" else ("SH1", 8)
+
+        def guarded():
+            err, chk = None, None
+            try:
+                chk = self_check(dist, rank, world, device, share, *sc_args)
+            except capi.PsgsdfError as ex:
+                err = str(ex)[-300:]
+            votes = [None] * world
+            dist.all_gather_object(votes, (bool(err is None and chk and chk["ok"]), err))
+            return chk, votes
+        check, votes = guarded()
+        if not all(v[0] for v in votes):
+            reason = next((f"rank {i}: {v[1]}" for i, v in enumerate(votes) if v[1]), "the N-rank result differs from the single context's")
+            if rank == 0:
+                print(f"bench.py: the self-check with the in-kernel exchanges failed ({reason}); falling back to the communicator paths (PSGSDF_XR=0)", file=sys.stderr)
+            os.environ["PSGSDF_XR"] = "0"
+            for k in ("PSGSDF_FAULT_HALO", "PSGSDF_FAULT_SOLVE"):
+                os.environ.pop(k, None)
+            fallback = {"reason": reason, "exchanges": "RCCL collectives on every rank (PSGSDF_XR=0): one all-reduce per PCG pass, per-frame rows, scalar sums and halo rows over the communicator"}
+            check, votes = guarded()
+            if not all(v[0] for v in votes):
+                if rank == 0:
+                    print("bench.py: the self-check fails on the communicator paths too: " + "; ".join(f"rank {i}: {v[1]}" for i, v in enumerate(votes) if v[1]), file=sys.stderr)
+                sys.exit(4)
     m = measure(args, args.model, torch, dist, rank, world, device, slab, share, headline=True)
     if world > 1 and args.strong and os.environ.get("PSGSDF_BENCH_NO_FULL_CHECK") != "1":
         check = [check, full_size_check(m["make_context"], m, args, args.model, torch, dist, rank, world, device)]
@@ -540,6 +577,8 @@ def main():
     if world > 1:
         # degraded: the line is not the design's N-GPU figure -- the cross-rank persistent solve is off or fell back, or the N-rank result is wrong
         out["multi_gpu"], out["degraded"] = multi_gpu_block(m, check, world, share)
+        if fallback:
+            out["multi_gpu"]["fallback"] = fallback; out["degraded"] = True
 
     if rank == 0:
         # ---- roofline of the dominant kernel, timed live with HIP events inside the timed region

@@ -130,3 +130,23 @@ def test_first_contact_probe(built):
             assert k["this_rank"]["tried"] == 1 and k["this_rank"]["stale_records_from_lower"] == 0
     for x in d["phases"]["exchanges"]["per_rank"]:
         assert x["ok"] and x["e_total_rel_diff"] <= 1e-5 and x["cross_rank_solves"] == 2 and x["persist_fallbacks"] == 0 and x["halo_exchanges_by_push_kernels"] > 0
+
+
+def test_failed_in_kernel_exchange_falls_back_to_the_communicator(built):
+    """A first multi-GPU lease must measure, not debug: if the pre-timing self-check fails with the in-kernel exchanges on (here: rank 1's second halo push is
+    dropped -- fault injection, development library -- and rank 0's bounded wait expires), every rank falls back to the communicator paths (PSGSDF_XR=0),
+    the self-check is repeated, the measurement goes ahead and the line says `degraded` with the reason."""
+    env = dict(os.environ, PSGSDF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo", PSGSDF_USE_DEV_LIB="1", PSGSDF_XWAIT_LOG2="16",
+               PSGSDF_BENCH_FAULT="1:PSGSDF_FAULT_HALO=2", PSGSDF_BENCH_WATCHDOG_S="400", PSGSDF_DESTROY_TIMEOUT_S="3")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PSGSDF_CU_MASK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--reps", "1", "--grid", "64", "--frames", "8", "--no-extra"],
+                       capture_output=True, text=True, timeout=450, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json(r.stdout)
+    assert d["degraded"] is True and d["n_gpus"] == 2 and d["value"] > 0
+    fb = d["multi_gpu"]["fallback"]
+    assert "PSGSDF_XR=0" in fb["exchanges"] and ("gave up" in fb["reason"] or "NaN came back" in fb["reason"]), fb
+    assert d["multi_gpu"]["cross_rank_ready"] == 0 and d["multi_gpu"]["collectives_per_step"] > 10      # the per-pass collectives are back
+    assert all(c["ok"] for c in d["multi_gpu"]["self_check"])
+    assert "falling back to the communicator paths" in r.stderr
