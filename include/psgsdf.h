@@ -252,7 +252,11 @@ int psgsdf_upload_light(psgsdf_ctx* ctx, const float* light);
 
 /* What the reference writes every third iteration (PsOptimizer.cpp:419-423) is computed from the dense state: a mesh by marching cubes and a point
  * cloud of the band.  These calls do that on the device and hand back compact arrays in engine-owned pinned host memory, valid until the next
- * extraction call on the context; the host only formats text.  Single-rank contexts.
+ * extraction call on the context; the host only formats text.
+ * Multi-rank contexts (round 5): collective calls; every rank gets ITS share -- the cells whose lower z-plane it owns, its own band rows / voxels /
+ * planes of the crop box (which is the whole volume's: lo, dim) -- in the single context's order: the shares concatenated in rank order are the single
+ * context's arrays.  extract_sdf returns the planes k of the box with z0 <= lo[2] + k < z1 (psgsdf_mg_info); a share may be empty (NULL, 0).
+ * psgsdf_comm_allreduce_host gives a host the counts before it (host/ps_optimizer.hpp: every rank writes its lines into its place in the one file).
  *
  * psgsdf_extract_mesh: Optimizer::extract_mesh (OptimizerAux.cpp:278-363) = crop box of |d| <= sqrt(3) vs, tsdf = -dist, 8-bit colours, then
  *   MarchingCubes::computeIsoSurface / computeTriangles (third/mesh/MarchingCubes.cpp:314-637): cells in (z, y, x) order, faces in the classic
@@ -282,7 +286,7 @@ int psgsdf_extract_sdf(psgsdf_ctx* ctx, int32_t lo[3], int32_t dim[3], const flo
  * psgsdf_download_volume writes the z-planes the rank OWNS into the caller's whole-volume arrays (the slabs tile the volume);
  * psgsdf_download_band returns the rank's own band voxels (global linear indices).  The exchanges -- all-reduce of the per-frame light /
  * pose rows, of the 7 sums of a PCG pass and of the folded scalars; halo rows of the per-voxel blocks, the PCG records and the distances
- * with the two z-neighbours -- are enqueued by the engine itself on its HIP stream.  Frame fusion, normals and the tracker are single-rank.
+ * with the two z-neighbours -- are enqueued by the engine itself on its HIP stream.
  *
  *   rank 0:  psgsdf_comm_unique_id(id);  (hand the 128 bytes to the other ranks: file, socket, MPI_Bcast, torch.distributed ...)
  *   all   :  psgsdf_create(.., device, &ctx);  psgsdf_comm_init(ctx, id, rank, n_ranks);  then the usual call sequence.
@@ -315,6 +319,13 @@ typedef struct psgsdf_comm_ops {
                     const psgsdf_comm_xfer* recvs, int n_recvs, void* hip_stream);              /* peers: rank-1 / rank+1 (any rank in psgsdf_rebalance_slabs); matched in list order per peer */
 } psgsdf_comm_ops;
 int psgsdf_comm_init_ext(psgsdf_ctx* ctx, const psgsdf_comm_ops* ops, int rank, int n_ranks);
+/* A built-in transport of that kind for the ranks of ONE node: peer_fd[r] = a connected stream socket (socketpair / TCP) to rank r, entry `rank`
+ * ignored; the launcher owns the sockets.  Host-staged and blocking: for ranks that share a device (RCCL refuses that -- the one-GPU rehearsals of
+ * `voxelPS --gpus N`) or a node without a working RCCL.  A peer that stops answering fails the call after PSGSDF_SOCKET_TIMEOUT_S (120) seconds. */
+int psgsdf_comm_init_sockets(psgsdf_ctx* ctx, const int* peer_fd, int rank, int n_ranks);
+/* In-place sum over the ranks of n doubles in HOST memory through the context's communicator (collective; nothing to do on one rank): what a multi-rank
+ * host needs to place its share of an output. */
+int psgsdf_comm_allreduce_host(psgsdf_ctx* ctx, double* buf, int n);
 
 /* A volume fused slab-parallel (psgsdf_volume_init / psgsdf_integrate_frame on a multi-rank context: every rank fuses every frame into the z-planes it
  * holds, VolumetricGradSdf.cpp:78-134 touches each voxel independently; the slabs are cut by HEIGHT because the band does not exist yet) is re-cut

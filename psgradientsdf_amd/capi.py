@@ -336,9 +336,11 @@ class Api:
         lo = (C.c_int32 * 3)(); dim = (C.c_int32 * 3)(); v = C.POINTER(C.c_float)()
         self._check(self._fn("extract_sdf")(self.ctx, lo, dim, C.byref(v)), "extract_sdf")
         d = list(dim)
-        if d[0] == 0:
-            return list(lo), d, np.zeros((0, 0, 0), np.float32)
-        return list(lo), d, np.ctypeslib.as_array(v, shape=(d[2], d[1], d[0])).copy()
+        mi = self.mg_info()      # a slab of a multi-rank run gets the planes of the (global) box it owns
+        own = max(0, min(lo[2] + d[2], mi["z1"]) - max(lo[2], mi["z0"])) if mi["n_ranks"] > 1 else d[2]
+        if d[0] == 0 or own == 0:
+            return list(lo), d, np.zeros((0, max(d[1], 0), max(d[0], 0)), np.float32)
+        return list(lo), d, np.ctypeslib.as_array(v, shape=(own, d[1], d[0])).copy()
 
     def download_band(self, n=None):
         """one rank: the whole band.  A slab of a multi-rank run: pass n = row1 - row0 of mg_info (its own band voxels)"""
@@ -375,6 +377,17 @@ class Api:
         """ops: a CommOps struct (caller-supplied transport); the caller keeps it (and its callbacks) alive"""
         self._comm_ops = ops
         self._check(self._fn("comm_init_ext")(self.ctx, C.byref(ops), C.c_int(rank), C.c_int(n_ranks)), "comm_init_ext")
+
+    def comm_init_sockets(self, peer_fds, rank, n_ranks):
+        """the built-in node-local transport: peer_fds[r] = fileno of a connected stream socket to rank r (the caller keeps the sockets open)"""
+        fds = (C.c_int * n_ranks)(*[int(f) for f in peer_fds])
+        self._check(self._fn("comm_init_sockets")(self.ctx, fds, C.c_int(rank), C.c_int(n_ranks)), "comm_init_sockets")
+
+    def comm_allreduce_host(self, values):
+        """sum over the ranks of a host vector of doubles (collective)"""
+        a = np.ascontiguousarray(values, np.float64).copy()
+        self._check(self._fn("comm_allreduce_host")(self.ctx, a.ctypes.data_as(C.c_void_p), C.c_int(a.size)), "comm_allreduce_host")
+        return a
 
     def comm_stats(self):
         n = C.c_int64()

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <algorithm>
 #include <functional>
+#include <memory>
 #include <map>
 #include <string>
 #include <vector>
@@ -120,6 +121,7 @@ struct psgsdf_ctx {
     long long xr_probe_stale = 0, xr_probe_timeouts = 0;   // what the probe saw (all ranks, all kinds tried)
     long long xr_probe_local[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};   // [memory kind 1 / 2][stale records read from the lower neighbour, expired waits towards the lower, towards the upper neighbour, tried]: this rank's own view (psgsdf_get_tuning)
     bool xr_mapped = false;              // peers may hold IPC mappings of xr / rec_mem: they have to be closed everywhere before either is freed (xr_quiesce)
+    std::shared_ptr<void> comm_keep;     // what a built-in caller-side transport (psgsdf_comm_init_sockets) needs for the life of the context
     unsigned long long xr_openers = 0;   // bit r: rank r opened this rank's region at the last set-up (agreed there); xr_quiesce waits for exactly those
     long long xr_serial = 0, xr_closed_off = 0;   // number of the last set-up (the same on every rank) and where the R "closed" slots of a region sit
     void* xo_host[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; size_t xo_bytes[5] = {0, 0, 0, 0, 0};   // pinned host results of the extraction calls (extract.hip): mesh xyz / rgb, point cloud xyz+n / rgb, sdf block; valid until the next extraction

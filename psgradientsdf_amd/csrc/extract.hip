@@ -8,6 +8,11 @@
 //   psgsdf_extract_sdf         the cropped -dist block of Optimizer::saveSDF / VolumetricGradSdf::saveSDF (OptimizerAux.cpp:513-577)
 // The arithmetic is the HOST writers' (psgradientsdf_amd/host/marching_cubes.hpp, ps_optimizer.hpp), operation for operation, with FMA contraction
 // off: the files written from these arrays are byte-identical to the ones the host-side pass writes (tests/test_extract_gpu.py).
+// Multi-rank contexts (z-slabs): the calls are collective and every rank returns ITS share -- the cells whose lower z-plane it owns, its own band rows /
+// voxels / planes of the (global) crop box -- in the single context's order, so that the shares concatenated in rank order ARE the single context's
+// arrays (tests/test_extract_gpu.py gathers the slabs' volume into one context and compares).  Two exchanges: the crop box (one all-reduce of 6 R
+// numbers) and, for the mesh, the albedo of the upper neighbour's first plane (a cell reaches one plane up; the engine itself only keeps the halo
+// planes' DISTANCES current).
 #include "engine_internal.h"
 
 namespace psg {
@@ -22,12 +27,12 @@ __constant__ int kCornerD[8][3] = {{1, 1, 0}, {1, 0, 0}, {0, 0, 0}, {0, 1, 0}, {
 __constant__ int kEdgeD[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
 
 // ---- crop box: min / max voxel index over |d| <= sqrt(3) vs (crop_box, ps_optimizer.hpp; the comparison is the host's: double)
-__global__ void __launch_bounds__(kBlock) k_box_part(const float* __restrict__ dist, int nx, int ny, long long nvox, double lim, int* __restrict__ part) {
+__global__ void __launch_bounds__(kBlock) k_box_part(const float* __restrict__ dist, int nx, int ny, long long nvox, int k0, double lim, int* __restrict__ part) {
     int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-(1 << 30), -(1 << 30), -(1 << 30)};
     const long long nxy = (long long)nx * ny;
     for (long long lin = blockIdx.x * (long long)blockDim.x + threadIdx.x; lin < nvox; lin += (long long)gridDim.x * blockDim.x) {
         if ((double)fabsf(dist[lin]) > lim) continue;
-        const int k = (int)(lin / nxy), rest = (int)(lin - (long long)k * nxy), j = rest / nx, i = rest - j * nx;
+        const int kl = (int)(lin / nxy), rest = (int)(lin - (long long)kl * nxy), j = rest / nx, i = rest - j * nx, k = kl + k0;      // (k0: global z of the first plane looked at)
         lo[0] = min(lo[0], i); hi[0] = max(hi[0], i); lo[1] = min(lo[1], j); hi[1] = max(hi[1], j); lo[2] = min(lo[2], k); hi[2] = max(hi[2], k);
     }
     __shared__ int s[6][kBlock / 64];
@@ -114,11 +119,13 @@ __global__ void __launch_bounds__(kBlock) k_cscan_add(int* __restrict__ v, long 
 struct McGrid {
     const float* dist; const float* weight; const float* rho[3];
     int nx, ny;                 // the dense grid's row / plane strides
-    int lo[3], d[3];            // crop box: first voxel and extent
+    int lo[3], d[3];            // crop box: first voxel and extent (global)
+    int zlo;                    // global z of the context's local plane 0 (0 on one rank)
+    int zc0;                    // first cell plane of this launch (a slab: the cells whose lower plane it owns)
     float voxel[3], origin[3];  // MarchingCubes ctor: size / dim, and the origin offset that is subtracted (write_mesh: -vs * lo)
     long long total;            // voxels of the cropped grid (the colour look-ups run one / two past it: B10)
 };
-__device__ __forceinline__ long long dense_lin(const McGrid& g, int i, int j, int k) { return (long long)(k + g.lo[2]) * g.nx * g.ny + (long long)(j + g.lo[1]) * g.nx + (i + g.lo[0]); }
+__device__ __forceinline__ long long dense_lin(const McGrid& g, int i, int j, int k) { return (long long)(k + g.lo[2] - g.zlo) * g.nx * g.ny + (long long)(j + g.lo[1]) * g.nx + (i + g.lo[0]); }
 // colour byte of channel ch at CROPPED linear index cl (write_mesh: (unsigned char)int(255 * rgb); at(): 0 past the last voxel)
 __device__ __forceinline__ unsigned char colour_at(const McGrid& g, int ch, long long cl) {
     if (cl >= g.total) return 0;
@@ -194,7 +201,7 @@ __global__ void __launch_bounds__(kBlock) k_mc_count(McGrid g, long long ncell, 
     const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (c >= ncell) return;
     const int cx = g.d[0] - 2, cy = g.d[1] - 2;
-    const int z = (int)(c / ((long long)cx * cy)), rest = (int)(c - (long long)z * cx * cy), y = rest / cx, x = rest - y * cx;
+    const int zl = (int)(c / ((long long)cx * cy)), rest = (int)(c - (long long)zl * cx * cy), y = rest / cx, x = rest - y * cx, z = zl + g.zc0;
     cnt[c] = mc_cell<false>(g, x, y, z, nullptr, nullptr);
 }
 __global__ void __launch_bounds__(kBlock) k_mc_emit(McGrid g, long long ncell, const int* __restrict__ offs, int total, float* __restrict__ xyz, unsigned char* __restrict__ rgb) {
@@ -203,26 +210,26 @@ __global__ void __launch_bounds__(kBlock) k_mc_emit(McGrid g, long long ncell, c
     const int mine = (c + 1 < ncell ? offs[c + 1] : total) - offs[c];
     if (mine <= 0) return;
     const int cx = g.d[0] - 2, cy = g.d[1] - 2;
-    const int z = (int)(c / ((long long)cx * cy)), rest = (int)(c - (long long)z * cx * cy), y = rest / cx, x = rest - y * cx;
+    const int zl = (int)(c / ((long long)cx * cy)), rest = (int)(c - (long long)zl * cx * cy), y = rest / cx, x = rest - y * cx, z = zl + g.zc0;
     mc_cell<true>(g, x, y, z, xyz + (size_t)offs[c] * 9, rgb + (size_t)offs[c] * 9);
 }
 
 // ---- point clouds
 // which = 0: the band voxels (ascending) with |d| < sqrt(3) vs;  which = 1: every voxel with weight > 0 and |d| < sqrt(3) vs
-__global__ void __launch_bounds__(kBlock) k_pc_flags(const float* __restrict__ dist, const float* __restrict__ weight, const int* __restrict__ band_lin, long long n, double lim, int* __restrict__ flag) {
+__global__ void __launch_bounds__(kBlock) k_pc_flags(const float* __restrict__ dist, const float* __restrict__ weight, const int* __restrict__ band_lin, long long lin0, long long n, double lim, int* __restrict__ flag) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const long long lin = band_lin ? band_lin[i] : i;
+    const long long lin = band_lin ? band_lin[i] : i + lin0;      // (lin0: the first voxel of the planes the context owns)
     flag[i] = ((double)fabsf(dist[lin]) < lim && (band_lin || weight[lin] > 0)) ? 1 : 0;
 }
-__global__ void __launch_bounds__(kBlock) k_pc_fill(DenseView d, int nx, int ny, float vs, const int* __restrict__ band_lin, long long n, double lim, const int* __restrict__ offs,
+__global__ void __launch_bounds__(kBlock) k_pc_fill(DenseView d, int nx, int ny, int zlo, float vs, const int* __restrict__ band_lin, long long lin0, long long n, double lim, const int* __restrict__ offs,
                                                     float* __restrict__ pn, int* __restrict__ col) {
     const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (q >= n) return;
-    const long long lin = band_lin ? band_lin[q] : q;
+    const long long lin = band_lin ? band_lin[q] : q + lin0;
     if (!((double)fabsf(d.dist[lin]) < lim && (band_lin || d.weight[lin] > 0))) return;
     const long long nxy = (long long)nx * ny;
-    const int k = (int)(lin / nxy), rest = (int)(lin - (long long)k * nxy), j = rest / nx, i = rest - j * nx;
+    const int kl = (int)(lin / nxy), rest = (int)(lin - (long long)kl * nxy), j = rest / nx, i = rest - j * nx, k = kl + zlo;
     float g[3] = {d.g[0][lin], d.g[1][lin], d.g[2][lin]};
     const float z = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
     if (z > 0) { const float s = sqrtf(z); g[0] /= s; g[1] /= s; g[2] /= s; }
@@ -267,25 +274,34 @@ int host_out(psgsdf_ctx* c, int slot, size_t bytes, void** p) {
 }
 // the crop box of |d| <= sqrt(3) vs; any = false if no voxel qualifies
 int crop_box_dev(psgsdf_ctx* c, int lo[3], int hi[3], bool* any) {
-    const long long n = c->grid.nvox;
-    const int nblk = (int)std::min<long long>((n + kBlock - 1) / kBlock, 2048);
+    // (a slab looks at the planes it OWNS: [z0, z1) of the volume = local planes [z0 - zlo, z1 - zlo))
+    const long long plane = (long long)c->grid.dim[0] * c->grid.dim[1], n = plane * (c->z1 - c->z0);
+    const float* dist0 = c->dense.dist + plane * (c->z0 - c->zlo);
+    const int nblk = (int)std::max<long long>(1, std::min<long long>((n + kBlock - 1) / kBlock, 2048));
     int* part = nullptr;
     HIPCHK(c, hipMalloc(&part, sizeof(int) * (6 * (size_t)nblk + 6)));
     const double lim = sqrt(3.0) * (double)c->grid.vs;      // std::sqrt(3) * vs: double (ps_optimizer.hpp crop_box)
-    hipLaunchKernelGGL(psg::k_box_part, dim3(nblk), dim3(kBlock), 0, c->stream, c->dense.dist, c->grid.dim[0], c->grid.dim[1], n, lim, part);
+    hipLaunchKernelGGL(psg::k_box_part, dim3(nblk), dim3(kBlock), 0, c->stream, dist0, c->grid.dim[0], c->grid.dim[1], n, c->z0, lim, part);
     hipLaunchKernelGGL(psg::k_box_final, dim3(1), dim3(kBlock), 0, c->stream, part, nblk, part + 6 * (size_t)nblk);
     int box[6];
     hipError_t e = hipMemcpyAsync(box, part + 6 * (size_t)nblk, sizeof(box), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(part);
     if (e != hipSuccess) return fail(c, PSGSDF_ERR_DEVICE, "crop box: %s", hipGetErrorString(e));
+    if (c->n_ranks > 1) {      // min / max over the slabs: every rank's six numbers in its own slots of one sum
+        std::vector<double> all((size_t)6 * c->n_ranks, 0.0);
+        for (int a = 0; a < 6; ++a) all[(size_t)6 * c->rank + a] = (double)box[a];
+        if (int rc = host_allreduce(c, all, "crop box")) return rc;
+        for (int r = 0; r < c->n_ranks; ++r)
+            for (int a = 0; a < 6; ++a) { const int v = (int)all[(size_t)6 * r + a]; box[a] = r == 0 ? v : (a < 3 ? std::min(box[a], v) : std::max(box[a], v)); }
+    }
     for (int a = 0; a < 3; ++a) { lo[a] = box[a]; hi[a] = box[3 + a]; }
     *any = hi[0] >= lo[0];
     return 0;
 }
 int extract_ready(psgsdf_ctx* c, const char* what) {
     if (!c || !c->have_volume) return fail(c, PSGSDF_ERR_STATE, "%s: no volume", what);
-    if (c->n_ranks > 1) return fail(c, PSGSDF_ERR_UNSUPPORTED, "%s: single-rank contexts only (a slab holds a part of the surface; gather with psgsdf_download_volume)", what);
+    if (c->n_ranks > 1 && !c->comm) return fail(c, PSGSDF_ERR_COMM, "%s: rank %d of %d has no communicator", what, c->rank, c->n_ranks);
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->deferred.empty() || c->pending_fold.n) { int rc = flush(c); if (rc) return rc; }
     if (c->inited) launch_band_scatter(c->dense, c->band, c->stream);      // the band's state back into the dense arrays (as psgsdf_download_volume does)
@@ -304,7 +320,7 @@ int psgsdf_extract_mesh(psgsdf_ctx* c, const float** xyz, const uint8_t** rgb, i
     if (!any) return PSGSDF_OK;
     psg::McGrid g{};
     g.dist = c->dense.dist; g.weight = c->dense.weight; for (int a = 0; a < 3; ++a) g.rho[a] = c->dense.rho[a];
-    g.nx = c->grid.dim[0]; g.ny = c->grid.dim[1];
+    g.nx = c->grid.dim[0]; g.ny = c->grid.dim[1]; g.zlo = c->zlo;
     const float vs = c->grid.vs;
     for (int a = 0; a < 3; ++a) {
         g.lo[a] = lo[a]; g.d[a] = hi[a] - lo[a] + 1;
@@ -314,7 +330,20 @@ int psgsdf_extract_mesh(psgsdf_ctx* c, const float** xyz, const uint8_t** rgb, i
     }
     g.total = (long long)g.d[0] * g.d[1] * g.d[2];
     if (g.d[0] < 3 || g.d[1] < 3 || g.d[2] < 3) return PSGSDF_OK;      // (no cell: the loops of computeIsoSurface run to dim - 2)
-    const long long ncell = (long long)(g.d[0] - 2) * (g.d[1] - 2) * (g.d[2] - 2);
+    // the cells of this context: lower plane lo2 + zc in [z0, z1) (their upper plane is the halo plane of a slab with a neighbour above)
+    g.zc0 = std::max(0, c->z0 - lo[2]);
+    const int zc1 = std::min(g.d[2] - 2, c->z1 - lo[2]);
+    if (c->n_ranks > 1) {      // the albedo of plane z1 from the rank above (the cells' upper corners and their colours)
+        const size_t plane = (size_t)g.nx * g.ny;
+        std::vector<psgsdf_comm_xfer> sends, recvs;
+        for (int a = 0; a < 3; ++a) {
+            if (c->rank > 0) sends.push_back({(void*)(c->dense.rho[a] + plane * (size_t)(c->z0 - c->zlo)), sizeof(float) * plane, c->rank - 1});
+            if (c->rank + 1 < c->n_ranks) recvs.push_back({(void*)(c->dense.rho[a] + plane * (size_t)(c->z1 - c->zlo)), sizeof(float) * plane, c->rank + 1});
+        }
+        if (int rc = comm_xfer(c, sends, recvs)) return rc;
+    }
+    const long long ncell = (long long)(g.d[0] - 2) * (g.d[1] - 2) * std::max(0, zc1 - g.zc0);
+    if (ncell == 0) return PSGSDF_OK;
     if (ncell >= (1ll << 31)) return fail(c, PSGSDF_ERR_UNSUPPORTED, "extract_mesh: %lld cells", ncell);
     const int nb = (int)((ncell + psg::kTile - 1) / psg::kTile);
     int* cnt = nullptr; int* sums = nullptr;
@@ -346,16 +375,18 @@ int psgsdf_extract_pointcloud(psgsdf_ctx* c, int which, const float** xyz_nxyz, 
     { int rc = extract_ready(c, "extract_pointcloud"); if (rc) return rc; }
     if (which == 0 && !c->inited) return fail(c, PSGSDF_ERR_STATE, "extract_pointcloud(band): psgsdf_init first");
     *xyz_nxyz = nullptr; *rgb = nullptr; *n_points = 0;
-    const long long n = which == 0 ? (long long)c->band.S : c->grid.nvox;
+    // a slab: its own band rows [row0, row1) / the voxels of the planes it owns
+    const long long plane = (long long)c->grid.dim[0] * c->grid.dim[1], lin0 = plane * (c->z0 - c->zlo);
+    const long long n = which == 0 ? (long long)(c->row1 - c->row0) : plane * (c->z1 - c->z0);
     if (n <= 0) return PSGSDF_OK;
-    const int* band_lin = which == 0 ? c->band.lin : nullptr;
+    const int* band_lin = which == 0 ? c->band.lin + c->row0 : nullptr;
     const double lim = sqrt(3.0) * (double)c->grid.vs;
     const int nb = (int)((n + psg::kTile - 1) / psg::kTile);
     int* flag = nullptr; int* sums = nullptr;
     HIPCHK(c, hipMalloc(&flag, sizeof(int) * (size_t)n));
     if (hipMalloc(&sums, sizeof(int) * (size_t)(nb + 1)) != hipSuccess) { hipFree(flag); return fail(c, PSGSDF_ERR_DEVICE, "extract_pointcloud: out of memory"); }
     const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(psg::k_pc_flags, dim3(grid), dim3(kBlock), 0, c->stream, c->dense.dist, c->dense.weight, band_lin, n, lim, flag);
+    hipLaunchKernelGGL(psg::k_pc_flags, dim3(grid), dim3(kBlock), 0, c->stream, c->dense.dist, c->dense.weight, band_lin, lin0, n, lim, flag);
     int total = 0;
     int rc = scan_counts(c, flag, n, sums, &total);
     float* d_pn = nullptr; int* d_col = nullptr;
@@ -365,7 +396,7 @@ int psgsdf_extract_pointcloud(psgsdf_ctx* c, int which, const float** xyz_nxyz, 
         if (!rc) rc = host_out(c, 2, sizeof(float) * 6 * (size_t)total, &hp);
         if (!rc) rc = host_out(c, 3, sizeof(int) * 3 * (size_t)total, &hc);
         if (!rc) {
-            hipLaunchKernelGGL(psg::k_pc_fill, dim3(grid), dim3(kBlock), 0, c->stream, c->dense, c->grid.dim[0], c->grid.dim[1], c->grid.vs, band_lin, n, lim, (const int*)flag, d_pn, d_col);
+            hipLaunchKernelGGL(psg::k_pc_fill, dim3(grid), dim3(kBlock), 0, c->stream, c->dense, c->grid.dim[0], c->grid.dim[1], c->zlo, c->grid.vs, band_lin, lin0, n, lim, (const int*)flag, d_pn, d_col);
             if (hipMemcpyAsync(hp, d_pn, sizeof(float) * 6 * (size_t)total, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipMemcpyAsync(hc, d_col, sizeof(int) * 3 * (size_t)total, hipMemcpyDeviceToHost, c->stream) != hipSuccess
                 || hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "extract_pointcloud: download");
         }
@@ -383,18 +414,22 @@ int psgsdf_extract_sdf(psgsdf_ctx* c, int32_t lo[3], int32_t dim[3], const float
     { int rc = crop_box_dev(c, l, h, &any); if (rc) return rc; }
     if (!any) return PSGSDF_OK;
     const int d0 = h[0] - l[0] + 1, d1 = h[1] - l[1] + 1, d2 = h[2] - l[2] + 1;
-    const long long n = (long long)d0 * d1 * d2;
+    for (int a = 0; a < 3; ++a) lo[a] = l[a];
+    dim[0] = d0; dim[1] = d1; dim[2] = d2;
+    // a slab: the planes of the box it owns, [ka, kb)
+    const int ka = std::max(l[2], c->z0), kb = std::min(h[2] + 1, c->z1);
+    const long long n = (long long)d0 * d1 * std::max(0, kb - ka);
+    if (n == 0) return PSGSDF_OK;
     float* dv = nullptr; void* hv = nullptr;
     HIPCHK(c, hipMalloc(&dv, sizeof(float) * (size_t)n));
     int rc = host_out(c, 4, sizeof(float) * (size_t)n, &hv);
     if (!rc) {
-        hipLaunchKernelGGL(psg::k_sdf_crop, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->dense.dist, c->grid.dim[0], c->grid.dim[1], l[0], l[1], l[2], d0, d1, n, dv);
+        hipLaunchKernelGGL(psg::k_sdf_crop, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->dense.dist, c->grid.dim[0], c->grid.dim[1], l[0], l[1], ka - c->zlo, d0, d1, n, dv);
         if (hipMemcpyAsync(hv, dv, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, PSGSDF_ERR_DEVICE, "extract_sdf: download");
     }
     hipFree(dv);
     if (rc) return rc;
-    for (int a = 0; a < 3; ++a) lo[a] = l[a];
-    dim[0] = d0; dim[1] = d1; dim[2] = d2; *neg_dist = (const float*)hv;
+    *neg_dist = (const float*)hv;
     return PSGSDF_OK;
 }
 

@@ -52,6 +52,8 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
             sys.exit(3)
         print("COMM_OK", flush=True)
         sys.exit(0)
+    elif transport == "sockets":      # the engine's built-in node-local transport over the socket pairs the test made (psgsdf_comm_init_sockets)
+        eng.comm_init_sockets([int(x) for x in os.environ["SLAB_FDS"].split(",")], rank, world)
     else:
         import torch.distributed as dist
         from _gloo_transport import GlooTransport
@@ -87,13 +89,18 @@ def main(rank, world, port, model, out, n_iters, N, transport, mode):
         recs += eng.iterate(capi.ALL, 1)
     info = eng.mg_info()
     v = eng.download_volume()          # whole-volume arrays, NaN outside the z-planes this rank owns
+    xs = {}
+    if os.environ.get("SLAB_EXTRACT"):      # this rank's share of the writers' geometry (collective calls) + a host-side sum over the ranks
+        mx, mc = eng.extract_mesh(); p0, c0 = eng.extract_pointcloud(0); p1, c1 = eng.extract_pointcloud(1); lo, dim, blk = eng.extract_sdf()
+        cnt = np.zeros(world); cnt[rank] = len(mx)
+        xs = dict(x_mesh_xyz=mx, x_mesh_rgb=mc, x_pc0=p0, x_pc0_rgb=c0, x_pc1=p1, x_pc1_rgb=c1, x_sdf_lo=lo, x_sdf_dim=dim, x_sdf=blk, x_counts=eng.comm_allreduce_host(cnt), x_weight=v["weight"])
     np.savez(out + f".rank{rank}.npz", dist=v["dist"], rgb=v["rgb"], grad=v["grad"], poses=eng.download_poses(), light=eng.download_light(),
              e_total=[r["e_total"] for r in recs], cg=[r["cg_iters"] for r in recs], e0=e0, band=eng.download_band(info["row1"] - info["row0"]),
              info=[info["row0"], info["row1"], info["halo"], info["S"], info["need_lo"], info["need_hi"], info["z0"], info["z1"], info["rows"]],
              track=track if track is not None else np.zeros(0), fused_weight=fused["weight"] if mode.startswith("fuse") else np.zeros(0), fused_dist=fused["dist"] if mode.startswith("fuse") else np.zeros(0),
              fused_vis=fused_vis if mode.startswith("fuse") else np.zeros(0), cut_before=[cut_before["z0"], cut_before["z1"]] if mode.startswith("fuse") and world > 1 else [0, 0],
              halo_pushes=eng.debug_sync_stats()["halo_pushes"], conv=conv, spec=[eng.debug_sync_stats()[k] for k in ("speculative_starts", "speculative_undos")], upsampled=[int(r["upsampled"]) for r in recs],
-             ncoll=eng.comm_stats(), dim=list(eng.info().dim), n_band=eng.info().n_band, xr=[eng.debug_sync_stats()[k] for k in ("cross_rank_ready", "cross_rank_solves", "persist_fallbacks", "cross_rank_mem_kind", "probe_stale", "probe_timeouts")])
+             **xs, ncoll=eng.comm_stats(), dim=list(eng.info().dim), n_band=eng.info().n_band, xr=[eng.debug_sync_stats()[k] for k in ("cross_rank_ready", "cross_rank_solves", "persist_fallbacks", "cross_rank_mem_kind", "probe_stale", "probe_timeouts")])
     eng.close()
     if tr is not None:
         dist.barrier(); dist.destroy_process_group()

@@ -21,11 +21,28 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def socket_mesh(world):
+    """one connected stream-socket pair per pair of ranks: mesh[r][q] = rank r's end of its connection to rank q (psgsdf_comm_init_sockets)"""
+    mesh = [[-1] * world for _ in range(world)]
+    for r in range(world):
+        for q in range(r + 1, world):
+            a, b = socket.socketpair(socket.AF_UNIX, socket.SOCK_STREAM)
+            mesh[r][q], mesh[q][r] = a.detach(), b.detach()
+    return mesh
+
+
 def run_ranks(tmp_path, model, world, transport, mode, N, n_iters, extra_env=None, timeout=150):
     port = free_port(); out = str(tmp_path / "slab")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SLAB_WORKER_TIMEOUT=str(timeout - 40), **(extra_env or {}))
+    mesh = socket_mesh(world) if transport == "sockets" else None
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_slab_worker_gpu.py"), str(r), str(world), str(port), model, out, str(n_iters), str(N), transport, mode],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(env, SLAB_FDS=",".join(str(f) for f in mesh[r])) if mesh else env,
+                              pass_fds=[f for f in mesh[r] if f >= 0] if mesh else ()) for r in range(world)]
+    if mesh:
+        for row in mesh:
+            for f in row:
+                if f >= 0:
+                    os.close(f)
     try:
         for p in procs:
             o, _ = p.communicate(timeout=timeout)
