@@ -23,6 +23,8 @@
 #include <mutex>
 #include <thread>
 #include <cstdint>
+#include <fcntl.h>
+#include <unistd.h>
 #include <fstream>
 #include <iostream>
 #include <memory>
@@ -91,41 +93,62 @@ struct TextOut {
     void i(long long v) { char t[24]; const int n = snprintf(t, sizeof t, "%lld", v); s.append(t, (size_t)n); }
     void c(char ch) { s.push_back(ch); }
 };
-// n lines, line(out, i) appends line i; formatted on up to 16 threads, written in order
+// n lines, line(out, i) appends line i; formatted on up to 16 threads, in order
 template <class Fn>
-inline bool write_lines(FILE* f, size_t n, size_t approx_line_bytes, Fn line) {
+inline std::vector<TextOut> format_lines(size_t n, size_t approx_line_bytes, Fn line) {
     unsigned T = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     if (n < 50000) T = 1;
     std::vector<TextOut> parts(T);
     auto work = [&](unsigned t) { const size_t a = n * t / T, b = n * (t + 1) / T; parts[t].s.reserve((b - a) * approx_line_bytes); for (size_t q = a; q < b; ++q) line(parts[t], q); };
     if (T == 1) work(0);
     else { std::vector<std::thread> th; for (unsigned t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
-    for (auto& p : parts) if (!p.s.empty() && fwrite(p.s.data(), 1, p.s.size(), f) != p.s.size()) return false;
+    return parts;
+}
+template <class Fn>
+inline bool write_lines(FILE* f, size_t n, size_t approx_line_bytes, Fn line) {
+    for (auto& p : format_lines(n, approx_line_bytes, line)) if (!p.s.empty() && fwrite(p.s.data(), 1, p.s.size(), f) != p.s.size()) return false;
     return true;
+}
+inline void mesh_vertex_line(TextOut& o, const float* xyz, const uint8_t* rgb, size_t i) { o.f(xyz[3 * i]); o.c(' '); o.f(xyz[3 * i + 1]); o.c(' '); o.f(xyz[3 * i + 2]); o.c(' '); o.i(rgb[3 * i]); o.c(' '); o.i(rgb[3 * i + 1]); o.c(' '); o.i(rgb[3 * i + 2]); o.c('\n'); }
+inline void mesh_face_line(TextOut& o, size_t q) { o.c('3'); o.c(' '); o.i((long long)(3 * q)); o.c(' '); o.i((long long)(3 * q + 1)); o.c(' '); o.i((long long)(3 * q + 2)); o.c('\n'); }
+inline void pointcloud_line(TextOut& o, const float* pn, const int32_t* col, size_t i) { for (int k = 0; k < 6; ++k) { o.f(pn[6 * i + k]); o.c(' '); } o.i(col[3 * i]); o.c(' '); o.i(col[3 * i + 1]); o.c(' '); o.i(col[3 * i + 2]); o.c('\n'); }
+inline std::string mesh_header(size_t nv) {
+    char h[400]; const int n = snprintf(h, sizeof h, "ply\nformat ascii 1.0\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
+               "element face %d\nproperty list uchar int vertex_indices\nend_header\n", nv, (int)(nv / 3));
+    return std::string(h, (size_t)n);
+}
+inline std::string pointcloud_header(size_t n) {
+    char h[400]; const int k = snprintf(h, sizeof h, "ply\nformat ascii 1.0\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+               "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n", n);
+    return std::string(h, (size_t)k);
+}
+inline std::string sdf_header(const int lo[3], const int dim[3], float vs) {
+    TextOut h; h.i(dim[0]); h.c(' '); h.i(dim[1]); h.c(' '); h.i(dim[2]); h.c('\n'); h.f(lo[0] * vs); h.c(' '); h.f(lo[1] * vs); h.c(' '); h.f(lo[2] * vs); h.c('\n'); h.f(vs); h.c('\n');
+    return h.s;
 }
 // MarchingCubes::savePly (third/mesh/MarchingCubes.cpp:659-699) from non-indexed vertices: 3 per face
 inline bool write_mesh_ply(const std::string& file, const float* xyz, const uint8_t* rgb, size_t nv) {
     if (nv == 0) return false;
     FILE* f = fopen(file.c_str(), "wb"); if (!f) return false;
-    fprintf(f, "ply\nformat ascii 1.0\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
-               "element face %d\nproperty list uchar int vertex_indices\nend_header\n", nv, (int)(nv / 3));
-    bool ok = write_lines(f, nv, 40, [&](TextOut& o, size_t i) { o.f(xyz[3 * i]); o.c(' '); o.f(xyz[3 * i + 1]); o.c(' '); o.f(xyz[3 * i + 2]); o.c(' '); o.i(rgb[3 * i]); o.c(' '); o.i(rgb[3 * i + 1]); o.c(' '); o.i(rgb[3 * i + 2]); o.c('\n'); });
-    ok = ok && write_lines(f, nv / 3, 24, [&](TextOut& o, size_t q) { o.c('3'); o.c(' '); o.i((long long)(3 * q)); o.c(' '); o.i((long long)(3 * q + 1)); o.c(' '); o.i((long long)(3 * q + 2)); o.c('\n'); });
+    const std::string h = mesh_header(nv);
+    bool ok = fwrite(h.data(), 1, h.size(), f) == h.size();
+    ok = ok && write_lines(f, nv, 40, [&](TextOut& o, size_t i) { mesh_vertex_line(o, xyz, rgb, i); });
+    ok = ok && write_lines(f, nv / 3, 24, [&](TextOut& o, size_t q) { mesh_face_line(o, q); });
     return fclose(f) == 0 && ok;
 }
 // save_pointcloud / extract_pc (OptimizerAux.cpp:456-511, VolumetricGradSdf.cpp:320-376): x y z nx ny nz r g b
 inline bool write_pointcloud_ply(const std::string& file, const float* pn, const int32_t* col, size_t n) {
     FILE* f = fopen(file.c_str(), "wb"); if (!f) return false;
-    fprintf(f, "ply\nformat ascii 1.0\nelement vertex %zu\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
-               "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n", n);
-    const bool ok = write_lines(f, n, 80, [&](TextOut& o, size_t i) { for (int k = 0; k < 6; ++k) { o.f(pn[6 * i + k]); o.c(' '); } o.i(col[3 * i]); o.c(' '); o.i(col[3 * i + 1]); o.c(' '); o.i(col[3 * i + 2]); o.c('\n'); });
+    const std::string h = pointcloud_header(n);
+    bool ok = fwrite(h.data(), 1, h.size(), f) == h.size();
+    ok = ok && write_lines(f, n, 80, [&](TextOut& o, size_t i) { pointcloud_line(o, pn, col, i); });
     return fclose(f) == 0 && ok;
 }
 // saveSDF (OptimizerAux.cpp:513-577): dims, the box's first voxel in metres, the voxel size, then -dist, x fastest
 inline bool write_sdf_block(const std::string& file, const int lo[3], const int dim[3], float vs, const float* v) {
     FILE* f = fopen(file.c_str(), "wb"); if (!f) return false;
-    TextOut h; h.i(dim[0]); h.c(' '); h.i(dim[1]); h.c(' '); h.i(dim[2]); h.c('\n'); h.f(lo[0] * vs); h.c(' '); h.f(lo[1] * vs); h.c(' '); h.f(lo[2] * vs); h.c('\n'); h.f(vs); h.c('\n');
-    bool ok = fwrite(h.s.data(), 1, h.s.size(), f) == h.s.size();
+    const std::string h = sdf_header(lo, dim, vs);
+    bool ok = fwrite(h.data(), 1, h.size(), f) == h.size();
     ok = ok && write_lines(f, (size_t)dim[0] * dim[1] * dim[2], 12, [&](TextOut& o, size_t i) { o.f(v[i]); o.c('\n'); });
     return fclose(f) == 0 && ok;
 }
@@ -152,6 +175,41 @@ public:
     void drain() { PSG_STAGE("wait for the background writer"); std::unique_lock<std::mutex> l(m_); idle_.wait(l, [&] { return q_.empty() && !busy_; }); }
     ~DumpQueue() { { std::lock_guard<std::mutex> l(m_); stop_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
 };
+
+// ---- one run on N devices (`voxelPS --gpus N`: one process per GPU, the volume cut into z-slabs; no reference counterpart) ---------------------------
+// main() fills this in before anything else.  Every rank runs the same program on the same inputs (decodes the frames, selects the keyframes); the
+// engine calls are collective.  Rank 0 narrates and writes the small text files; the big ones are written by ALL ranks: each formats the lines of
+// its share (psgsdf_extract_* on a multi-rank context) and writes them into their place in the one file -- the places come from an exclusive scan of
+// the byte counts over the ranks (psgsdf_comm_allreduce_host).  The files are the single-process files line for line, up to what the slabs'
+// rank-order sums do to the last digit of a value.
+struct RankInfo { int rank = 0, n = 1, device = 0; bool sockets = false; std::vector<int> fds; std::vector<uint8_t> id; };
+inline RankInfo& rank_info() { static RankInfo r; return r; }
+inline bool multi_rank() { return rank_info().n > 1; }
+inline bool lead_rank() { return rank_info().rank == 0; }
+// k numbers of every rank -> the sums over the ranks in front of this one, and over all
+inline bool scan_over_ranks(psgsdf_ctx* ctx, const std::vector<double>& mine, std::vector<double>& before, std::vector<double>& total) {
+    const RankInfo& ri = rank_info(); const size_t k = mine.size();
+    std::vector<double> all(k * (size_t)ri.n, 0.0);
+    for (size_t i = 0; i < k; ++i) all[k * (size_t)ri.rank + i] = mine[i];
+    if (psgsdf_comm_allreduce_host(ctx, all.data(), (int)all.size())) return false;
+    before.assign(k, 0.0); total.assign(k, 0.0);
+    for (int r = 0; r < ri.n; ++r) for (size_t i = 0; i < k; ++i) { if (r < ri.rank) before[i] += all[k * (size_t)r + i]; total[i] += all[k * (size_t)r + i]; }
+    return true;
+}
+inline size_t bytes_of(const std::vector<TextOut>& parts) { size_t b = 0; for (auto& p : parts) b += p.s.size(); return b; }
+struct FilePiece { long long offset; std::shared_ptr<std::vector<TextOut>> parts; };
+// this rank's pieces of a file all ranks write: rank 0 also owns the header and the file's final length
+inline void write_shared_file(const std::string& file, const std::string& header, long long total_bytes, std::vector<FilePiece> pieces) {
+    DumpQueue::get().push([=] {
+        const int fd = open(file.c_str(), O_CREAT | O_WRONLY, 0644);
+        if (fd < 0) { std::cerr << "couldn't open " << file << std::endl; return; }
+        auto put = [&](const char* p, size_t n, long long at) { while (n) { const ssize_t k = pwrite(fd, p, n, (off_t)at); if (k <= 0) { std::cerr << "couldn't write " << file << std::endl; return false; } p += k; n -= (size_t)k; at += k; } return true; };
+        bool ok = true;
+        if (lead_rank()) ok = put(header.data(), header.size(), 0) && ftruncate(fd, (off_t)total_bytes) == 0;
+        for (auto& pc : pieces) { long long at = pc.offset; for (auto& t : *pc.parts) { if (ok && !t.s.empty()) ok = put(t.s.data(), t.s.size(), at); at += (long long)t.s.size(); } }
+        close(fd);
+    });
+}
 
 struct DepthImage;
 // writers shared by VolumetricGradSdf (init_* files) and Optimizer (refined files): cropped box of |d| <= sqrt(3) vs,
@@ -215,7 +273,12 @@ struct VolumetricGradSdf {
         for (int a = 0; a < 3; ++a) { grid_dim_[a] = dim[a]; shift_[a] = shift[a]; }
         voxel_size_ = voxel_size; T_ = T;
         psgsdf_grid_desc g{}; for (int a = 0; a < 3; ++a) { g.dim[a] = dim[a]; g.shift[a] = shift[a]; } g.voxel_size = voxel_size; g.truncation = T;
-        if (psgsdf_create(&g, K.v, &s, 0, &ctx)) { ctx = nullptr; return false; }
+        const RankInfo& ri = rank_info();
+        if (psgsdf_create(&g, K.v, &s, ri.device, &ctx)) { ctx = nullptr; return false; }
+        if (ri.n > 1) {      // one process per GPU: RCCL over xGMI, or the node-local socket transport (ranks that share a device; no RCCL)
+            const int rc = ri.sockets ? psgsdf_comm_init_sockets(ctx, ri.fds.data(), ri.rank, ri.n) : psgsdf_comm_init(ctx, ri.id.data(), ri.rank, ri.n);
+            if (rc) { std::cerr << "rank " << ri.rank << ": no communicator: " << last_error() << std::endl; return false; }
+        }
         std::cout << "Number of voxels: " << num_voxels() << std::endl;
         return psgsdf_volume_init(ctx, max_frames) == 0;
     }
@@ -251,7 +314,20 @@ struct VolumetricGradSdf {
     // the device-side extraction (include/psgsdf.h psgsdf_extract_*): compact arrays come back, a copy of them goes to the background writer
     static bool device_mesh(psgsdf_ctx* ctx, const std::string& file) {
         const float* xyz = nullptr; const uint8_t* rgb = nullptr; int64_t nv = 0;
-        if (psgsdf_extract_mesh(ctx, &xyz, &rgb, &nv) || nv == 0) return false;
+        if (psgsdf_extract_mesh(ctx, &xyz, &rgb, &nv)) return false;
+        if (multi_rank()) {
+            std::vector<double> before, total;
+            if (!scan_over_ranks(ctx, {(double)nv}, before, total) || total[0] == 0) return false;
+            auto V = std::make_shared<std::vector<TextOut>>(format_lines((size_t)nv, 40, [&](TextOut& o, size_t i) { mesh_vertex_line(o, xyz, rgb, i); }));
+            const size_t face0 = (size_t)before[0] / 3;      // (faces are numbered through the whole file)
+            auto F = std::make_shared<std::vector<TextOut>>(format_lines((size_t)nv / 3, 24, [&](TextOut& o, size_t q) { mesh_face_line(o, face0 + q); }));
+            const std::string h = mesh_header((size_t)total[0]);
+            std::vector<double> bb, bt;
+            if (!scan_over_ranks(ctx, {(double)bytes_of(*V), (double)bytes_of(*F)}, bb, bt)) return false;
+            write_shared_file(file, h, (long long)(h.size() + bt[0] + bt[1]), {{(long long)(h.size() + bb[0]), V}, {(long long)(h.size() + bt[0] + bb[1]), F}});
+            return true;
+        }
+        if (nv == 0) return false;
         auto vx = std::make_shared<std::vector<float>>(xyz, xyz + 3 * nv); auto vc = std::make_shared<std::vector<uint8_t>>(rgb, rgb + 3 * nv);
         DumpQueue::get().push([=] { if (!write_mesh_ply(file, vx->data(), vc->data(), (size_t)nv)) std::cout << "couldn't save mesh " << file << std::endl; });
         return true;
@@ -259,13 +335,34 @@ struct VolumetricGradSdf {
     static bool device_pointcloud(psgsdf_ctx* ctx, int which, const std::string& file) {
         const float* pn = nullptr; const int32_t* col = nullptr; int64_t n = 0;
         if (psgsdf_extract_pointcloud(ctx, which, &pn, &col, &n)) return false;
+        if (multi_rank()) {
+            auto L = std::make_shared<std::vector<TextOut>>(format_lines((size_t)n, 80, [&](TextOut& o, size_t i) { pointcloud_line(o, pn, col, i); }));
+            std::vector<double> before, total;
+            if (!scan_over_ranks(ctx, {(double)n, (double)bytes_of(*L)}, before, total)) return false;
+            const std::string h = pointcloud_header((size_t)total[0]);
+            write_shared_file(file, h, (long long)(h.size() + total[1]), {{(long long)(h.size() + before[1]), L}});
+            return true;
+        }
         auto vp = std::make_shared<std::vector<float>>(pn, pn + 6 * n); auto vc = std::make_shared<std::vector<int32_t>>(col, col + 3 * n);
         DumpQueue::get().push([=] { if (!write_pointcloud_ply(file, vp->data(), vc->data(), (size_t)n)) std::cout << " can't save point cloud!" << std::endl; });
         return true;
     }
     static bool device_sdf(psgsdf_ctx* ctx, const std::string& file, float vs) {
         int32_t lo[3], dim[3]; const float* v = nullptr;
-        if (psgsdf_extract_sdf(ctx, lo, dim, &v) || !v) return false;
+        if (psgsdf_extract_sdf(ctx, lo, dim, &v)) return false;
+        if (multi_rank()) {
+            if (dim[0] == 0) return false;
+            int32_t mi[12]; if (psgsdf_mg_info(ctx, mi)) return false;
+            const size_t cnt = (size_t)dim[0] * dim[1] * (size_t)std::max(0, std::min(lo[2] + dim[2], mi[11]) - std::max(lo[2], mi[10]));      // the planes of the box this rank owns
+            auto L = std::make_shared<std::vector<TextOut>>(format_lines(cnt, 12, [&](TextOut& o, size_t i) { o.f(v[i]); o.c('\n'); }));
+            std::vector<double> before, total;
+            if (!scan_over_ranks(ctx, {(double)bytes_of(*L)}, before, total)) return false;
+            const int l3[3] = {lo[0], lo[1], lo[2]}, d3[3] = {dim[0], dim[1], dim[2]};
+            const std::string h = sdf_header(l3, d3, vs);
+            write_shared_file(file, h, (long long)(h.size() + total[0]), {{(long long)(h.size() + before[0]), L}});
+            return true;
+        }
+        if (!v) return false;
         auto vv = std::make_shared<std::vector<float>>(v, v + (size_t)dim[0] * dim[1] * dim[2]);
         const std::array<int, 3> l{lo[0], lo[1], lo[2]}, d{dim[0], dim[1], dim[2]};
         DumpQueue::get().push([=] { write_sdf_block(file, l.data(), d.data(), vs, vv->data()); });
@@ -405,6 +502,7 @@ public:
         if (num_frames_ == 0) return;
         if (tSDF_->ctx) {   // device-resident volume: the fused state is already there
             ctx_ = tSDF_->ctx; borrowed_ = true;
+            if (multi_rank()) { const int rb = psgsdf_rebalance_slabs(ctx_); if (rb) { fail("psgsdf_rebalance_slabs", rb); return; } }      // fused in slabs of equal height, optimised in slabs of equal band count
             const int W = images_[0]->cols, H = images_[0]->rows;
             std::vector<float> img((size_t)num_frames_ * W * H * 3), P(num_frames_ * 16);
             for (size_t f = 0; f < num_frames_; ++f) {
@@ -447,9 +545,9 @@ public:
     virtual bool alternatingOptimize(bool light, bool albedo, bool distance, bool pose) {
         PSG_STAGE("alternatingOptimize: total (incl. its dumps)");
         if (!ctx_) return false;
-        doc_.open((save_path_ + "optimizer_doc.txt").c_str());
+        if (lead_rank()) doc_.open((save_path_ + "optimizer_doc.txt").c_str());
         std::cout << "albation study settings: \n" << "light: " << light << "\n" << "albedo: " << albedo << "\n" << "distance: " << distance << "\n" << "pose: " << pose << std::endl;
-        doc_ << "albation study settings: \t" << "light: " << light << "\t" << "albedo: " << albedo << "\t" << "distance: " << distance << "\t" << "pose: " << pose
+        if (doc_.is_open()) doc_ << "albation study settings: \t" << "light: " << light << "\t" << "albedo: " << albedo << "\t" << "distance: " << distance << "\t" << "pose: " << pose
              << "\n" << "num of key frame: " << num_frames_ << " \n total voxels: " << num_voxels_ << "\n";
         int flags = (albedo ? PSGSDF_ALBEDO : 0) | (light ? PSGSDF_LIGHT : 0) | (distance ? PSGSDF_DIST : 0) | (pose ? PSGSDF_POSE : 0);
         std::vector<psgsdf_iter_stats> recs(settings_->max_it + 1);
@@ -463,7 +561,7 @@ public:
             const int iter = n_done - 1;
             narrate(n_done, &recs[n_done - 1]);   // (the observer is not invoked for the terminating iteration.  Narration only: the reference returns at PsOptimizer.cpp:368-384, before ++iter and the iter % 3 dumps of :419-423 -- no after_iter_<k> files for it)
             std::cout << "===> [" << iter << "]: " << (result ? "converged!" : "diverged!") << std::endl;
-            doc_ << "===> [" << iter << "]: " << (result ? "converged! \n" : "diverged!\n");
+            if (doc_.is_open()) doc_ << "===> [" << iter << "]: " << (result ? "converged! \n" : "diverged!\n");
             save_pointcloud("final_refined");                      // PsOptimizer.cpp:372-373,379-380
             extract_mesh("final_refined");
             if (settings_->model == LED) saveSDF("refined_sdf.sdf");   // LedOptimizer.cpp:422,430
@@ -472,8 +570,9 @@ public:
         psgsdf_info info{}; psgsdf_get_info(ctx_, &info);
         settings_->reg_weight_n = info.reg_weight_n; settings_->reg_weight_l = info.reg_weight_l;
         sync_back();
-        doc_.close();
+        if (doc_.is_open()) doc_.close();
         DumpQueue::get().drain();      // the reference has written its files when alternatingOptimize returns
+        if (multi_rank()) { double one = 1; psgsdf_comm_allreduce_host(ctx_, &one, 1); }      // ... on every rank
         return result != 0;
     }
 
@@ -484,9 +583,10 @@ public:
         size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
         for (int a = 0; a < 3; ++a) tSDF_->grid_dim_[a] = info.dim[a];
         tSDF_->voxel_size_ = info.voxel_size; voxel_size_ = info.voxel_size;
+        if (multi_rank()) n = 0;      // (a rank holds a slab: no whole-volume host copy; nothing in voxelPS reads one after the optimisation)
         tSDF_->dist.resize(n); tSDF_->grad.resize(3 * n); tSDF_->weight.resize(n); tSDF_->rgb.resize(3 * n);
         tSDF_->vis.resize(n * info.vis_words); tSDF_->vis_words = info.vis_words;
-        int rc = psgsdf_download_volume(ctx_, tSDF_->dist.data(), tSDF_->grad.data(), tSDF_->weight.data(), tSDF_->rgb.data(), tSDF_->vis.data());
+        int rc = multi_rank() ? 0 : psgsdf_download_volume(ctx_, tSDF_->dist.data(), tSDF_->grad.data(), tSDF_->weight.data(), tSDF_->rgb.data(), tSDF_->vis.data());
         if (rc) return fail("psgsdf_download_volume", rc);
         std::vector<float> P(num_frames_ * 16);
         rc = psgsdf_download_poses(ctx_, P.data());
@@ -500,6 +600,7 @@ public:
         PSG_STAGE("dump: poses");
         std::vector<float> P(num_frames_ * 16);
         if (psgsdf_download_poses(ctx_, P.data())) return false;
+        if (!lead_rank()) return true;
         std::ofstream posefile((save_path_ + filename + ".txt").c_str());
         if (!posefile.is_open()) { std::cout << "couldn't save optimized poses! " << std::endl; return false; }
         for (size_t i = 0; i < num_frames_; ++i) {

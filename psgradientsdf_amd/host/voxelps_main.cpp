@@ -4,6 +4,9 @@
 // Extra optional keys: "grid dim" (default 128, main_ps.cpp:123), "max keyframes" (default 40, :312).
 #include "image_loader.hpp"
 #include "mini_json.hpp"
+#include <signal.h>
+#include <sys/socket.h>
+#include <sys/wait.h>
 
 using namespace psgsdf_host;
 
@@ -127,6 +130,60 @@ static int selftest_fmt(long n) {
     return bad ? 1 : 0;
 }
 
+// `voxelPS --config_file <cfg> --gpus N [--transport rccl|sockets]`: this process only starts the N ranks (itself, once per GPU) and waits for them.
+// rccl (default): rank r runs on device r, the ranks meet in ncclCommInitRank over the id made here.  sockets: the engine's node-local transport over one
+// socket pair per pair of ranks (psgsdf_comm_init_sockets) -- a node without a working RCCL, or ranks that share a device: VOXELPS_SHARE_GPU=1 puts
+// all of them on device 0, VOXELPS_CU_MASKS="0:128,128:256" confines rank r to the r-th CU range (the one-GPU rehearsal, tests/test_voxelps_ranks_gpu.py).
+// A rank that fails ends the run: the others are terminated (exactly the processes started here) and its exit code is returned.
+static int launch_ranks(int n, bool sockets, int argc, char* argv[]) {
+    if (n < 2 || n > 32) { std::cerr << "--gpus " << n << ": 2 .. 32 ranks" << std::endl; return 1; }
+    std::vector<std::vector<int>> mesh(n, std::vector<int>(n, -1));
+    std::string id_hex;
+    if (sockets) {
+        for (int r = 0; r < n; ++r) for (int q = r + 1; q < n; ++q) { int sv[2]; if (socketpair(AF_UNIX, SOCK_STREAM, 0, sv)) { perror("socketpair"); return 1; } mesh[r][q] = sv[0]; mesh[q][r] = sv[1]; }
+    } else {
+        uint8_t id[128];
+        if (psgsdf_comm_unique_id(id)) { std::cerr << "no RCCL on this node (psgsdf_comm_unique_id failed): --transport sockets runs without it" << std::endl; return 1; }
+        static const char* hx = "0123456789abcdef";
+        for (int i = 0; i < 128; ++i) { id_hex.push_back(hx[id[i] >> 4]); id_hex.push_back(hx[id[i] & 15]); }
+    }
+    std::vector<std::string> masks;
+    if (const char* e = getenv("VOXELPS_CU_MASKS")) { std::string m = e; size_t a = 0; while (a <= m.size()) { size_t b = m.find(',', a); if (b == std::string::npos) b = m.size(); masks.push_back(m.substr(a, b - a)); a = b + 1; } }
+    std::vector<pid_t> pids;
+    for (int r = 0; r < n; ++r) {
+        const pid_t pid = fork();
+        if (pid < 0) { perror("fork"); for (pid_t p : pids) kill(p, SIGTERM); return 1; }
+        if (pid == 0) {
+            for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) if (a != r && mesh[a][b] >= 0) close(mesh[a][b]);      // the other ranks' ends
+            if ((int)masks.size() == n) setenv("PSGSDF_CU_MASK", masks[r].c_str(), 1);
+            setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+            std::vector<std::string> av(argv, argv + argc);
+            av.push_back("--rank"); av.push_back(std::to_string(r)); av.push_back("--nranks"); av.push_back(std::to_string(n));
+            if (sockets) { std::string f; for (int q = 0; q < n; ++q) f += (q ? "," : "") + std::to_string(mesh[r][q]); av.push_back("--fds"); av.push_back(f); }
+            else { av.push_back("--comm-id"); av.push_back(id_hex); }
+            std::vector<char*> cv; for (auto& a : av) cv.push_back(const_cast<char*>(a.c_str())); cv.push_back(nullptr);
+            execv("/proc/self/exe", cv.data());
+            perror("execv"); _exit(127);
+        }
+        pids.push_back(pid);
+    }
+    for (auto& row : mesh) for (int f : row) if (f >= 0) close(f);
+    int rc = 0, left = n;
+    while (left > 0) {
+        int st = 0; const pid_t p = waitpid(-1, &st, 0);
+        if (p < 0) break;
+        auto it = std::find(pids.begin(), pids.end(), p); if (it == pids.end()) continue;
+        --left; *it = -1;
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+        if (code != 0 && rc == 0) {
+            rc = code;
+            std::cerr << "rank " << (it - pids.begin()) << " ended with " << code << ": stopping the other ranks" << std::endl;
+            for (pid_t q : pids) if (q > 0) kill(q, SIGTERM);
+        }
+    }
+    return rc;
+}
+
 int main(int argc, char* argv[]) {
     if (argc >= 3 && std::string(argv[1]) == "--selftest-fmt") return selftest_fmt(atol(argv[2]));
     if (argc >= 3 && std::string(argv[1]) == "--selftest-lapm") return selftest_lapm(argv[2]);
@@ -136,10 +193,28 @@ int main(int argc, char* argv[]) {
     if (argc >= 2 && std::string(argv[1]) == "--selftest-mc-table") return selftest_mc_table(false);
     if (argc >= 2 && std::string(argv[1]) == "--selftest-mc-generated") return selftest_mc_table(true);
     if (argc >= 4 && std::string(argv[1]) == "--selftest-mc-ply") return selftest_mc_ply(atoi(argv[2]), argv[3]);
+    int want_ranks = 1; std::string transport = "rccl";
     std::string configfile, timing_file;      // --timing <file.json>: wall-clock per stage (no reference counterpart; the reference's outputs are unchanged)
     for (int i = 1; i < argc; ++i) { std::string a = argv[i]; if (a == "--config_file" && i + 1 < argc) configfile = argv[++i]; else if (a.rfind("--config_file=", 0) == 0) configfile = a.substr(14);
         else if (a == "--timing" && i + 1 < argc) timing_file = argv[++i];
-        else if (a == "--host-writers") host_writers() = true; }      // round 4's dump path (dense download, host marching cubes, iostream) and frame path (serial decode, normals through the host): the cross-check of the device / threaded one
+        else if (a == "--host-writers") host_writers() = true;
+        else if (a == "--gpus" && i + 1 < argc) want_ranks = atoi(argv[++i]);
+        else if (a == "--transport" && i + 1 < argc) transport = argv[++i];
+        else if (a == "--rank" && i + 1 < argc) rank_info().rank = atoi(argv[++i]);
+        else if (a == "--nranks" && i + 1 < argc) rank_info().n = atoi(argv[++i]);
+        else if (a == "--fds" && i + 1 < argc) { std::string f = argv[++i]; size_t p0 = 0; while (p0 <= f.size()) { size_t p1 = f.find(',', p0); if (p1 == std::string::npos) p1 = f.size(); rank_info().fds.push_back(atoi(f.substr(p0, p1 - p0).c_str())); p0 = p1 + 1; } }
+        else if (a == "--comm-id" && i + 1 < argc) { std::string h = argv[++i]; for (size_t q = 0; q + 1 < h.size(); q += 2) rank_info().id.push_back((uint8_t)strtol(h.substr(q, 2).c_str(), nullptr, 16)); } }      // round 4's dump path (dense download, host marching cubes, iostream) and frame path (serial decode, normals through the host): the cross-check of the device / threaded one
+    if (transport != "rccl" && transport != "sockets") { std::cerr << "--transport: rccl or sockets" << std::endl; return 1; }
+    if ((want_ranks > 1 || multi_rank()) && host_writers()) { std::cerr << "--host-writers is the single-process cross-check" << std::endl; return 1; }
+    if (want_ranks > 1 && !multi_rank()) return launch_ranks(want_ranks, transport == "sockets", argc, argv);
+    static std::ofstream null_out;
+    if (multi_rank()) {
+        RankInfo& ri = rank_info();
+        ri.sockets = transport == "sockets";
+        ri.device = getenv("VOXELPS_SHARE_GPU") && atoi(getenv("VOXELPS_SHARE_GPU")) ? 0 : ri.rank;
+        if (ri.rank < 0 || ri.rank >= ri.n || (ri.sockets ? (int)ri.fds.size() != ri.n : ri.id.size() != 128)) { std::cerr << "--rank / --nranks / --fds / --comm-id are set by `voxelPS --gpus N`" << std::endl; return 1; }
+        if (!lead_rank()) { null_out.open("/dev/null"); std::cout.rdbuf(null_out.rdbuf()); }      // rank 0 narrates
+    }
     const auto t_main0 = std::chrono::steady_clock::now();
     std::cout << "load the config file from: " << configfile << std::endl;
     JsonObject config;
@@ -183,7 +258,7 @@ int main(int argc, char* argv[]) {
     if (config.contains("converge threshold")) opt_set_->conv_threshold = (float)config.num("converge threshold");
     if (config.contains("upsample")) opt_set_->upsample = config.boolean("upsample");
     if (config.contains("lambda")) { opt_set_->lambda = (float)config.num("lambda"); opt_set_->lambda_sq = opt_set_->lambda * opt_set_->lambda; }
-    { std::ofstream save_conf(output + "saved_config.json"); if (!save_conf.is_open()) std::cout << "could not save config file." << std::endl; config.dump(save_conf); }
+    if (lead_rank()) { std::ofstream save_conf(output + "saved_config.json"); if (!save_conf.is_open()) std::cout << "could not save config file." << std::endl; config.dump(save_conf); }
     bool light = false, albedo = false, distance = false, pose = false;
     if (config.contains("--light")) light = config.boolean("--light");
     if (config.contains("--albedo")) albedo = config.boolean("--albedo");
@@ -203,7 +278,7 @@ int main(int argc, char* argv[]) {
     int grid_dim[3] = {grid, grid, grid};
     VolumetricGradSdf* tSDF = new VolumetricGradSdf();
     RigidPointOptimizer* pOpt = nullptr; Optimizer* vOpt = nullptr;
-    std::ofstream pose_out(output + "tracking_poses.txt");
+    std::ofstream pose_out; if (lead_rank()) pose_out.open(output + "tracking_poses.txt");
     std::vector<Mat4f> poses; std::vector<int> keyframes{0}; std::vector<std::string> key_stamps; std::vector<std::shared_ptr<ImageRGB>> key_images;
     const Mat4f I4 = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     std::vector<Mat4f> key_poses{I4};   // key_poses[0] is Identity even with GT poses (main_ps.cpp:139, B1)
@@ -276,7 +351,7 @@ int main(int argc, char* argv[]) {
     vOpt->alternatingOptimize(light, albedo, distance, pose);
     DumpQueue::get().drain();
     delete vOpt; delete pOpt; delete tSDF; delete loader; delete opt_set_;
-    if (!timing_file.empty()) {
+    if (!timing_file.empty() && lead_rank()) {
         char extra[256];
         snprintf(extra, sizeof(extra), ", \"total_s\": %.6f, \"frames\": %zu, \"keyframes\": %zu", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main0).count(),
                  (size_t)(last == (size_t)-1 ? 0 : last - first + 1), keyframes.size());

@@ -1,0 +1,99 @@
+"""`voxelPS --config_file <cfg> --gpus N`: the drop-in executable on N ranks (one process per GPU, z-slabs; psgradientsdf_amd/host/voxelps_main.cpp
+launch_ranks).  On the one-GPU box the ranks share the device (VOXELPS_SHARE_GPU=1, each on its own CU range) and meet through the engine's node-local
+socket transport; everything else is the multi-GPU program: slab-parallel fusion, the re-cut by band count, the in-kernel exchanges of the
+optimisation, and the output files written by ALL ranks -- each formats the lines of its share of a mesh / point cloud / sdf block and writes them
+into their place in the one file.
+
+Against the single-process run on the same config: the same files; everything in front of the optimisation (init_mesh.ply, init_pointcloud.ply,
+init_sdf.sdf, tracking_poses.txt: the fusion touches every voxel independently) byte for byte; behind it line for line, numbers within what the slabs'
+rank-order sums do to the sixth printed digit."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "psgradientsdf_amd", "host", "voxelPS")
+GOLD = os.path.join(ROOT, "tests", "golden", "sokrates_small")
+
+
+def config(out, **kw):
+    cfg = {"input": GOLD + "/", "output": out, "pose filename": "pose.txt", "datatype": "multiview", "first": 0, "last": 7, "voxel size": 0.004,
+           "truncation factor": 5, "zmin": 0.5, "zmax": 3.5, "sharpness threshold": 0.0, "model type": "SH1", "loss function": "cauchy",
+           "reg albedo": 0.0, "reg norm": 10.0, "reg laplacian": 0.0, "max iter": 7, "damping": 1.0, "converge threshold": 1e-9, "lambda": 0.2,
+           "upsample": False, "--light": True, "--albedo": True, "--distance": True, "--pose": True, "grid dim": 128}
+    cfg.update(kw)
+    json.dump(cfg, open(out + "config.json", "w"))
+    return out + "config.json"
+
+
+def body_numbers(path):
+    """(header lines, all numbers behind the header as one float64 array, number of body lines)"""
+    raw = open(path, "rb").read()
+    if path.endswith(".ply"):
+        cut = raw.index(b"end_header\n") + len(b"end_header\n")
+    else:
+        cut = 0
+    body = raw[cut:]
+    return raw[:cut], np.array(body.split(), dtype=np.float64), body.count(b"\n")
+
+
+@pytest.mark.parametrize("ranks,kw", [(2, {}), (4, {"upsample": True, "damping": 10.0, "grid dim": 64}), (3, {"model type": "LED", "reg norm": 0.1, "reg laplacian": 5.0, "damping": 3.0, "grid dim": 96})])
+def test_voxelps_on_n_ranks_writes_the_single_process_files(built, margins, tmp_path, ranks, kw):
+    import torch
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    outs = {}
+    for name, extra, env in (("one", [], {}), ("ranks", ["--gpus", str(ranks), "--transport", "sockets"],
+                                              {"VOXELPS_SHARE_GPU": "1", "VOXELPS_CU_MASKS": ",".join(f"{r * ncu // ranks}:{(r + 1) * ncu // ranks}" for r in range(ranks))})):
+        out = str(tmp_path / name) + "/"; os.makedirs(out)
+        r = subprocess.run([EXE, "--config_file", config(out, **kw)] + extra, capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[name] = out
+    skip = ("config.json", "saved_config.json")
+    names = sorted(f for f in os.listdir(outs["one"]) if f not in skip)
+    assert sorted(f for f in os.listdir(outs["ranks"]) if f not in skip) == names
+    assert {"init_mesh.ply", "init_pointcloud.ply", "init_sdf.sdf", "after_iter_3_mesh.ply", "after_iter_3_pointcloud.ply", "after_iter_6_mesh.ply", "optimizer_doc.txt", "tracking_poses.txt"} <= set(names)
+    if kw.get("upsample"):
+        assert any(n.startswith("upsample_after_") and n.endswith("_mesh.ply") for n in names)
+    worst, same = {}, {}
+    for n in names:
+        a, b = open(outs["one"] + n, "rb").read(), open(outs["ranks"] + n, "rb").read()
+        if n.startswith("init_") or n == "tracking_poses.txt":
+            assert a == b, n                                               # the fusion: bit for bit whatever the cut
+            continue
+        if n.endswith(".txt") and not n.startswith("after_poses"):
+            la, lb = a.decode().splitlines(), b.decode().splitlines()      # the narration: the same lines; energies to five digits
+            assert len(la) == len(lb), n
+            for x, y in zip(la, lb):
+                tx, ty = x.split(), y.split()
+                assert len(tx) == len(ty), (n, x, y)
+                for p, q in zip(tx, ty):
+                    try:
+                        fp, fq = float(p), float(q)
+                    except ValueError:
+                        assert p == q, (n, x, y)
+                        continue
+                    assert abs(fp - fq) <= 2e-5 * max(1.0, abs(fq)), (n, x, y)
+            continue
+        ha, na, la_ = body_numbers(outs["one"] + n); hb, nb, lb_ = body_numbers(outs["ranks"] + n)
+        assert ha == hb and la_ == lb_ and na.shape == nb.shape, (n, la_, lb_)      # the same header (counts!) and as many lines
+        d = np.abs(na - nb)
+        worst[n] = float(d.max())
+        # positions and -dist are metres printed to six digits (1e-6 at 0.1-0.9 m = 2.5e-4 voxel), unit normals (finite differences of the distances:
+        # 1e-8 m of rank-order rounding over a 4 mm voxel, grown over six iterations on textured images -- profiles/r05_notes.md section 2), colours 0..255
+        big = np.abs(nb) >= 2.0
+        assert (d[big] <= 1.0).all() and (d[~big] <= 1e-4).all(), (n, d[~big].max(), d[big].max() if big.any() else 0)
+        same[n] = float((d == 0).mean())
+        assert same[n] > 0.9, (n, same[n])                                 # and almost every number is the same characters
+    margins(ranks=ranks, max_abs_difference_of_a_printed_number=worst, fraction_of_numbers_with_identical_characters=same, tolerance="1e-4 (positions / -dist in metres, unit normals), 1 (8-bit colours), indices exact; > 90 % of the numbers identical")
+
+
+def test_a_rank_that_cannot_start_ends_the_run(built, tmp_path):
+    """--gpus 2 over RCCL on a one-GPU box: rank 1 has no device.  The launcher must report it and stop rank 0 (which sits in ncclCommInitRank), not hang."""
+    out = str(tmp_path / "x") + "/"; os.makedirs(out)
+    r = subprocess.run([EXE, "--config_file", config(out), "--gpus", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "stopping the other ranks" in r.stderr, r.stderr[-1500:]
