@@ -250,3 +250,21 @@ def test_threaded_writers_print_floats_like_the_reference(built):
     assert r.returncode == 0, r.stdout[-500:]
     done, bad = (int(x) for x in r.stdout.strip().split("\n")[-1].split())
     assert bad == 0 and done > 2000000
+
+
+def test_voxelps_gpus_n_without_a_device_fails_loudly_and_ends_every_rank(built, tmp_path):
+    """`voxelPS --gpus N` on a box without a GPU: the ranks cannot create their device volumes -- the launcher reports the first one that ends, stops
+    the others and returns its code (no CPU fallback, no rank left behind).  The working case runs on the GPU: tests/test_voxelps_ranks_gpu.py."""
+    import json
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: tests/test_voxelps_ranks_gpu.py covers the launcher")
+    gold = os.path.join(ROOT, "tests", "golden", "sokrates_small")
+    out = str(tmp_path) + "/"
+    json.dump({"input": gold + "/", "output": out, "pose filename": "pose.txt", "datatype": "multiview", "first": 0, "last": 3, "voxel size": 0.004, "grid dim": 32, "model type": "SH1"}, open(out + "config.json", "w"))
+    for transport in ("sockets", "rccl"):
+        r = subprocess.run([os.path.join(ROOT, "psgradientsdf_amd", "host", "voxelPS"), "--config_file", out + "config.json", "--gpus", "3", "--transport", transport], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0
+        assert "stopping the other ranks" in r.stderr or "no RCCL on this node" in r.stderr, r.stderr[-800:]
+    r = subprocess.run([os.path.join(ROOT, "psgradientsdf_amd", "host", "voxelPS"), "--config_file", out + "config.json", "--gpus", "2", "--host-writers"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "single-process cross-check" in r.stderr
