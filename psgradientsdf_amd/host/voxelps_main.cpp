@@ -5,6 +5,7 @@
 #include "image_loader.hpp"
 #include "mini_json.hpp"
 #include <signal.h>
+#include <sys/prctl.h>
 #include <sys/socket.h>
 #include <sys/wait.h>
 
@@ -154,6 +155,7 @@ static int launch_ranks(int n, bool sockets, int argc, char* argv[]) {
         const pid_t pid = fork();
         if (pid < 0) { perror("fork"); for (pid_t p : pids) kill(p, SIGTERM); return 1; }
         if (pid == 0) {
+            prctl(PR_SET_PDEATHSIG, SIGTERM);      // a launcher that is killed takes its ranks with it
             for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) if (a != r && mesh[a][b] >= 0) close(mesh[a][b]);      // the other ranks' ends
             if ((int)masks.size() == n) setenv("PSGSDF_CU_MASK", masks[r].c_str(), 1);
             setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
