@@ -41,10 +41,9 @@ def body_numbers(path):
     return raw[:cut], np.array(body.split(), dtype=np.float64), body.count(b"\n")
 
 
-@pytest.mark.parametrize("ranks,kw", [(2, {}), (4, {"upsample": True, "damping": 10.0, "grid dim": 64}), (3, {"model type": "LED", "reg norm": 0.1, "reg laplacian": 5.0, "damping": 3.0, "grid dim": 96})])
+@pytest.mark.parametrize("ranks,kw", [(2, {}), (2, {"model type": "SH2", "grid dim": 96}), (4, {"upsample": True, "damping": 10.0, "grid dim": 64}), (3, {"model type": "LED", "reg norm": 0.1, "reg laplacian": 5.0, "damping": 3.0, "grid dim": 96})])
 def test_voxelps_on_n_ranks_writes_the_single_process_files(built, margins, tmp_path, ranks, kw):
-    import torch
-    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    ncu = 256      # MI355X
     outs = {}
     for name, extra, env in (("one", [], {}), ("ranks", ["--gpus", str(ranks), "--transport", "sockets"],
                                               {"VOXELPS_SHARE_GPU": "1", "VOXELPS_CU_MASKS": ",".join(f"{r * ncu // ranks}:{(r + 1) * ncu // ranks}" for r in range(ranks))})):
@@ -85,10 +84,12 @@ def test_voxelps_on_n_ranks_writes_the_single_process_files(built, margins, tmp_
         # positions and -dist are metres printed to six digits (1e-6 at 0.1-0.9 m = 2.5e-4 voxel), unit normals (finite differences of the distances:
         # 1e-8 m of rank-order rounding over a 4 mm voxel, grown over six iterations on textured images -- profiles/r05_notes.md section 2), colours 0..255
         big = np.abs(nb) >= 2.0
-        assert (d[big] <= 1.0).all() and (d[~big] <= 1e-4).all(), (n, d[~big].max(), d[big].max() if big.any() else 0)
+        # (SH2: 9 coefficients per frame with cond ~ 2e4, the single context itself is 4e-5 voxel from an 8-slab run after TWO iterations: tests/test_slab_gpu.py)
+        tol = 2e-3 if kw.get("model type") == "SH2" else 1e-4
+        assert (d[big] <= 1.0).all() and (d[~big] <= tol).all(), (n, d[~big].max(), d[big].max() if big.any() else 0)
         same[n] = float((d == 0).mean())
         assert same[n] > 0.9, (n, same[n])                                 # and almost every number is the same characters
-    margins(ranks=ranks, max_abs_difference_of_a_printed_number=worst, fraction_of_numbers_with_identical_characters=same, tolerance="1e-4 (positions / -dist in metres, unit normals), 1 (8-bit colours), indices exact; > 90 % of the numbers identical")
+    margins(ranks=ranks, max_abs_difference_of_a_printed_number=worst, fraction_of_numbers_with_identical_characters=same, tolerance="1e-4 (SH2: 2e-3) (positions / -dist in metres, unit normals), 1 (8-bit colours), indices exact; > 90 % of the numbers identical")
 
 
 def test_a_rank_that_cannot_start_ends_the_run(built, tmp_path):
