@@ -343,6 +343,9 @@ int psgsdf_mg_info(psgsdf_ctx* ctx, int32_t out[12]);
 int psgsdf_comm_stats(psgsdf_ctx* ctx, int64_t* n_collectives);
 
 /* ---- measurement / test hooks (not part of the reference seam) -------------------------- */
+/* the FALS estimator's per-resolution cache (NormalEstimator::cache, NormalEstimator.h:52-125) as the device computed it: 9 planes of width * height floats
+ * (ray / (1 + x0^2 + y0^2): 3, the inverse of the box-filtered 3x3 matrix: 6) */
+int psgsdf_debug_normals_cache(psgsdf_ctx* ctx, int width, int height, float* cache9);
 
 /* last measured kernel durations in ms keyed by name; names[i] are static strings.
  * Returns the number of entries written (<= cap). */

@@ -378,6 +378,12 @@ class Api:
         self._comm_ops = ops
         self._check(self._fn("comm_init_ext")(self.ctx, C.byref(ops), C.c_int(rank), C.c_int(n_ranks)), "comm_init_ext")
 
+    def debug_normals_cache(self, width, height):
+        """the FALS estimator's per-resolution cache as the device computed it: [9, height, width] float32"""
+        out = np.empty((9, height, width), np.float32)
+        self._check(self._fn("debug_normals_cache")(self.ctx, C.c_int(width), C.c_int(height), out.ctypes.data_as(C.c_void_p)), "debug_normals_cache")
+        return out
+
     def comm_init_sockets(self, peer_fds, rank, n_ranks):
         """the built-in node-local transport: peer_fds[r] = fileno of a connected stream socket to rank r (the caller keeps the sockets open)"""
         fds = (C.c_int * n_ranks)(*[int(f) for f in peer_fds])

@@ -6,6 +6,21 @@ using namespace psge;
 // ============================================================================================
 // C ABI
 // ============================================================================================
+namespace psge {
+int host_stage(psgsdf_ctx* c, size_t bytes, void** p) {
+    if (c->pin_bytes < bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // (nothing may still be reading the old buffer)
+        if (c->pin_stage) hipHostFree(c->pin_stage);
+        c->pin_stage = nullptr; c->pin_bytes = 0;
+        const size_t want = bytes + bytes / 4;
+        HIPCHK(c, hipHostMalloc(&c->pin_stage, want, hipHostMallocDefault));
+        c->pin_bytes = want;
+    }
+    *p = c->pin_stage;
+    return 0;
+}
+}  // namespace psge
+
 extern "C" {
 
 #ifdef PSGSDF_DEV
@@ -119,6 +134,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
     hipFree(c->band_mem); if (!c->leak_exported) hipFree(c->rec_mem); hipFree(c->obs_mem); hipFree(c->stage);
     hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->frame_part); hipFree(c->frame_done); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->pcg_gran); hipFree(c->d_total);
     for (void* p : c->xo_host) if (p) hipHostFree(p);
+    if (c->pin_stage) hipHostFree(c->pin_stage);
     if (c->host_buf) hipHostFree(c->host_buf);
     if (c->mbox) hipHostFree(c->mbox);
     if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1);
@@ -346,10 +362,16 @@ int psgsdf_integrate_frame(psgsdf_ctx* c, const float* rgb, const float* depth, 
         c->stage_px = npx;
     }
     float* d_rgb = c->stage; float* d_depth = c->stage + 3 * npx; float* d_nrm = c->stage + 4 * npx;
-    HIPCHK(c, hipMemcpyAsync(d_rgb, rgb, sizeof(float) * 3 * npx, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_depth, depth, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
-    if (normals_xyz) HIPCHK(c, hipMemcpyAsync(d_nrm, normals_xyz, sizeof(float) * 3 * npx, hipMemcpyHostToDevice, c->stream));
-    else {      // normals_xyz == NULL: NormalEstimator::compute on the depth map that is on the device already (what VolumetricGradSdf::update does, VolumetricGradSdf.cpp:59-61) -- no 3-plane round trip through the host
+    // The caller's arrays go through engine-owned PINNED memory: a DMA straight from pageable memory makes the runtime pin the caller's pages for every call --
+    // 5-11 ms per 380 x 570 frame when the frames come out of fresh allocations (voxelPS's prefetching decoder), against 0.3 ms for the copy into the staging
+    // buffer (profiles/r05_notes.md section 8).  One transfer: rgb | depth | normals are contiguous on both sides.
+    const size_t nfl = npx * (normals_xyz ? 7 : 4);
+    void* hs = nullptr;
+    { int src = host_stage(c, sizeof(float) * nfl, &hs); if (src) return src; }
+    memcpy(hs, rgb, sizeof(float) * 3 * npx); memcpy((float*)hs + 3 * npx, depth, sizeof(float) * npx);
+    if (normals_xyz) memcpy((float*)hs + 4 * npx, normals_xyz, sizeof(float) * 3 * npx);
+    HIPCHK(c, hipMemcpyAsync(d_rgb, hs, sizeof(float) * nfl, hipMemcpyHostToDevice, c->stream));
+    if (!normals_xyz) {      // normals_xyz == NULL: NormalEstimator::compute on the depth map that is on the device already (what VolumetricGradSdf::update does, VolumetricGradSdf.cpp:59-61) -- no 3-plane round trip through the host
         int nrc = frontend_normals_dev(c, d_depth, width, height, d_nrm); if (nrc) return nrc;
     }
     Cam cam = c->cam; cam.W = width; cam.H = height;

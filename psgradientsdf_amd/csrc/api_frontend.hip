@@ -5,38 +5,20 @@ using namespace psge;
 
 // ---- front end: FALS normals and depth tracker -------------------------------------------
 namespace {
-inline int reflect101_h(int i, int n) { if (n == 1) return 0; while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * n - 2 - i; } return i; }
-void box_filter_h(const std::vector<double>& src, std::vector<double>& dst, int W, int H, int r) {
-    std::vector<double> tmp((size_t)W * H);
-    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) { double s = 0; for (int k = -r; k <= r; ++k) s += src[(size_t)y * W + reflect101_h(x + k, W)]; tmp[(size_t)y * W + x] = s; }
-    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) { double s = 0; for (int k = -r; k <= r; ++k) s += tmp[(size_t)reflect101_h(y + k, H) * W + x]; dst[(size_t)y * W + x] = s; }
-}
-// NormalEstimator::cache (NormalEstimator.h:52-125), once per image size: double on the host, 9 float planes on the device
+// NormalEstimator::cache (NormalEstimator.h:52-125), once per image size: 9 float planes on the device
 int normals_cache(psgsdf_ctx* c, int W, int H) {
     if (c->ncache && c->ncache_w == W && c->ncache_h == H) return 0;
     const size_t n = (size_t)W * H;
     hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); c->ncache = nullptr; c->ntmp = nullptr; c->nout = nullptr; c->ndepth = nullptr;
-    std::vector<double> a[6], M[6]; for (int i = 0; i < 6; ++i) { a[i].resize(n); M[i].resize(n); }
-    std::vector<float> out(9 * n);
-    const double fx_inv = 1. / (double)c->cam.fx, fy_inv = 1. / (double)c->cam.fy, cx = (double)c->cam.cx, cy = (double)c->cam.cy;
-    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
-        size_t p = (size_t)y * W + x;
-        double x0 = fx_inv * ((double)x - cx), y0 = fy_inv * ((double)y - cy), nsi = 1. / (1. + x0 * x0 + y0 * y0);
-        a[0][p] = x0 * x0 * nsi; a[1][p] = x0 * y0 * nsi; a[2][p] = x0 * nsi; a[3][p] = y0 * y0 * nsi; a[4][p] = y0 * nsi; a[5][p] = nsi;
-        out[p] = (float)(x0 * nsi); out[n + p] = (float)(y0 * nsi); out[2 * n + p] = (float)nsi;
-    }
-    for (int i = 0; i < 6; ++i) box_filter_h(a[i], M[i], W, H, 5);
-    for (size_t p = 0; p < n; ++p) {
-        double M11 = M[0][p], M12 = M[1][p], M13 = M[2][p], M22 = M[3][p], M23 = M[4][p], M33 = M[5][p];
-        double det = M11 * (M22 * M33) + 2 * M12 * (M23 * M13) - (M13 * (M13 * M22) + M12 * (M12 * M33) + M23 * (M23 * M11));
-        double di = 1. / det;
-        out[3 * n + p] = (float)(di * (M22 * M33 - M23 * M23)); out[4 * n + p] = (float)(di * (M13 * M23 - M12 * M33));
-        out[5 * n + p] = (float)(di * (M12 * M23 - M13 * M22)); out[6 * n + p] = (float)(di * (M11 * M33 - M13 * M13));
-        out[7 * n + p] = (float)(di * (M12 * M13 - M11 * M23)); out[8 * n + p] = (float)(di * (M11 * M22 - M12 * M12));
-    }
+    // on the device (round 5; frontend.hip k_ncache_*): the same doubles in the same order as the host loop this replaces
     HIPCHK(c, hipMalloc(&c->ncache, sizeof(float) * 9 * n)); HIPCHK(c, hipMalloc(&c->ntmp, sizeof(double) * 3 * n));
     HIPCHK(c, hipMalloc(&c->nout, sizeof(float) * 3 * n)); HIPCHK(c, hipMalloc(&c->ndepth, sizeof(float) * n));
-    HIPCHK(c, hipMemcpy(c->ncache, out.data(), sizeof(float) * 9 * n, hipMemcpyHostToDevice));
+    double* work = nullptr;
+    HIPCHK(c, hipMalloc(&work, sizeof(double) * 12 * n));
+    timed(c, "normals_cache", [&] { launch_normals_cache(W, H, 5, 1. / (double)c->cam.fx, 1. / (double)c->cam.fy, (double)c->cam.cx, (double)c->cam.cy, work, c->ncache, c->stream); });
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(work);
+    if (e != hipSuccess) return fail(c, PSGSDF_ERR_DEVICE, "normals cache: %s", hipGetErrorString(e));
     c->ncache_w = W; c->ncache_h = H;
     return 0;
 }
@@ -51,12 +33,21 @@ int frontend_normals_dev(psgsdf_ctx* c, const float* d_depth, int width, int hei
 }
 }  // namespace psge
 
+extern "C" int psgsdf_debug_normals_cache(psgsdf_ctx* c, int width, int height, float* cache9) {
+    if (!c || !cache9 || width < 2 || height < 2) return fail(c, PSGSDF_ERR_ARG, "debug_normals_cache: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = normals_cache(c, width, height); if (rc) return rc;
+    HIPCHK(c, hipMemcpy(cache9, c->ncache, sizeof(float) * 9 * (size_t)width * height, hipMemcpyDeviceToHost));
+    return PSGSDF_OK;
+}
+
 extern "C" int psgsdf_estimate_normals(psgsdf_ctx* c, const float* depth, int width, int height, float* normals_xyz) {
     if (!c || !depth || !normals_xyz || width < 2 || height < 2) return fail(c, PSGSDF_ERR_ARG, "estimate_normals: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = normals_cache(c, width, height); if (rc) return rc;
     const size_t n = (size_t)width * height;
-    HIPCHK(c, hipMemcpyAsync(c->ndepth, depth, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    { void* hs = nullptr; int src = host_stage(c, sizeof(float) * n, &hs); if (src) return src; memcpy(hs, depth, sizeof(float) * n);
+      HIPCHK(c, hipMemcpyAsync(c->ndepth, hs, sizeof(float) * n, hipMemcpyHostToDevice, c->stream)); }
     timed(c, "normals", [&] { launch_normals(c->ndepth, c->ncache, width, height, 5, c->ntmp, c->nout, c->stream); });
     HIPCHK(c, hipMemcpyAsync(normals_xyz, c->nout, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -73,7 +64,8 @@ extern "C" int psgsdf_track(psgsdf_ctx* c, const float* depth, int width, int he
     int rc = normals_cache(c, width, height); if (rc) return rc;   // (allocates the depth staging buffer)
     const int nblk = 256;
     if (!c->track_part) { HIPCHK(c, hipMalloc(&c->track_part, sizeof(double) * nblk * 29)); HIPCHK(c, hipHostMalloc(&c->track_host, sizeof(double) * nblk * 29)); }
-    HIPCHK(c, hipMemcpyAsync(c->ndepth, depth, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    { void* hs = nullptr; int src = host_stage(c, sizeof(float) * n, &hs); if (src) return src; memcpy(hs, depth, sizeof(float) * n);
+      HIPCHK(c, hipMemcpyAsync(c->ndepth, hs, sizeof(float) * n, hipMemcpyHostToDevice, c->stream)); }
     Cam cam = c->cam; cam.W = width; cam.H = height;
     if (converged) *converged = 0;
     int k = 0;

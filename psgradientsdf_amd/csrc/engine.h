@@ -202,6 +202,7 @@ constexpr unsigned kXrEpochMask = 0x3fffu;      // (the host clears every region
 
 // ---- launchers implemented in the kernel files (all asynchronous on `s`) ----------------------
 constexpr int kTryPackFlags = 2048;   // workgroups of k_try_pack_f32 = words of its flag array (one per workgroup: no same-address stores)
+void launch_normals_cache(int W, int H, int r, double fx_inv, double fy_inv, double cx, double cy, double* work /*12 planes of W*H doubles*/, float* out /*9 float planes*/, hipStream_t s);   // NormalEstimator::cache on the device
 void launch_try_pack_f32(const float* rgb, unsigned* rgba, size_t npix, size_t stride, float scale, int* fail /*[kTryPackFlags], zeroed*/, hipStream_t s);   // float RGB that is exactly (float)byte * scale -> RGBA8 words; *fail != 0 otherwise
 void launch_pack_rgb8(const uint8_t* rgb, unsigned* rgba, size_t npix, hipStream_t s);   // [npix][3] bytes -> one RGBA8 word per pixel
 void launch_select_vis(const uint64_t* vis_seq, int wpv_seq, uint64_t* vis_key, int KW, const int* frame_idx, int F, long long nvox, hipStream_t s);

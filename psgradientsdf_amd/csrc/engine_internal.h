@@ -63,6 +63,7 @@ struct psgsdf_ctx {
     void* rec_mem = nullptr;             // the two PCG record planes (Band::rec): an allocation of their own, fine-grained on a multi-rank context (the neighbours' solve kernels write its halo rows while this rank's kernel reads them)
     void* obs_mem = nullptr;
     float* stage = nullptr; size_t stage_px = 0;   // device staging of one RGB-D frame (integrate_frame)
+    void* pin_stage = nullptr; size_t pin_bytes = 0;   // pinned host staging of the caller's frame (host_stage): the DMA never has to pin the caller's pages
     // front end: FALS cache (9 float planes), box-filter scratch, tracker partials
     float* ncache = nullptr; double* ntmp = nullptr; float* nout = nullptr; float* ndepth = nullptr; int ncache_w = 0, ncache_h = 0;
     double* track_part = nullptr; double* track_host = nullptr;
@@ -244,6 +245,7 @@ int xr_alloc(psgsdf_ctx* c, void** p, size_t bytes, bool polled);     // comm.hi
 int mg_commit(psgsdf_ctx* c);                                          // engine.hip: all-reduce + deliver the staged scalar read-backs
 int set_local_grid(psgsdf_ctx* c, int z0, int z1);                     // engine.hip: this context owns global planes [z0, z1) (+ halo planes)
 
+int host_stage(psgsdf_ctx* c, size_t bytes, void** p);   // api.hip: engine-owned pinned host memory of at least `bytes` (grows; valid until the next call)
 int frontend_normals_dev(psgsdf_ctx* c, const float* d_depth, int width, int height, float* d_normals);   // api_frontend.hip: FALS normals, device to device
 // ---- engine.hip
 SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg);

@@ -100,6 +100,56 @@ void launch_normals(const float* depth, const float* cache, int W, int H, int r,
     hipLaunchKernelGGL(k_normals_h, dim3(grid), dim3(kBlock), 0, s, depth, cache, W, H, r, tmp);
     hipLaunchKernelGGL(k_normals_v, dim3(grid), dim3(kBlock), 0, s, (const double*)tmp, cache, W, H, r, out);
 }
+// NormalEstimator::cache (NormalEstimator.h:52-125), once per image size: per pixel the ray (x0, y0, 1) / (1 + x0^2 + y0^2), the (2r+1)^2 box sums of the six
+// products M and the inverse of the 3x3 matrix they form -- in double, operation for operation and in the summation order of the host code this replaces
+// (round 4: 0.15-0.5 s of one core at 1139 x 1709, more than the fusion of four such frames); tests/test_frontend.py pins it to a numpy restatement bit for bit.
+// work: 12 planes of n doubles (a | tmp); out: the 9 float planes of the cache
+__global__ void __launch_bounds__(kBlock) k_ncache_rays(int W, int H, double fx_inv, double fy_inv, double cx, double cy, double* __restrict__ a, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const size_t n = (size_t)W * H;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+        const double x0 = fx_inv * ((double)x - cx), y0 = fy_inv * ((double)y - cy), nsi = 1. / (1. + x0 * x0 + y0 * y0);
+        a[p] = x0 * x0 * nsi; a[n + p] = x0 * y0 * nsi; a[2 * n + p] = x0 * nsi; a[3 * n + p] = y0 * y0 * nsi; a[4 * n + p] = y0 * nsi; a[5 * n + p] = nsi;
+        out[p] = (float)(x0 * nsi); out[n + p] = (float)(y0 * nsi); out[2 * n + p] = (float)nsi;
+    }
+}
+template <bool VERTICAL>
+__global__ void __launch_bounds__(kBlock) k_ncache_box(const double* __restrict__ src, double* __restrict__ dst, int W, int H, int r) {
+#pragma clang fp contract(off)
+    const size_t n = (size_t)W * H;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(p / W), x = (int)(p - (size_t)y * W);
+        double s[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = -r; k <= r; ++k) {
+            const size_t q = VERTICAL ? (size_t)reflect101(y + k, H) * W + x : (size_t)y * W + reflect101(x + k, W);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) s[i] += src[i * n + q];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dst[i * n + p] = s[i];
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_ncache_inverse(const double* __restrict__ M, size_t n, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+        const double M11 = M[p], M12 = M[n + p], M13 = M[2 * n + p], M22 = M[3 * n + p], M23 = M[4 * n + p], M33 = M[5 * n + p];
+        const double det = M11 * (M22 * M33) + 2 * M12 * (M23 * M13) - (M13 * (M13 * M22) + M12 * (M12 * M33) + M23 * (M23 * M11));
+        const double di = 1. / det;
+        out[3 * n + p] = (float)(di * (M22 * M33 - M23 * M23)); out[4 * n + p] = (float)(di * (M13 * M23 - M12 * M33));
+        out[5 * n + p] = (float)(di * (M12 * M23 - M13 * M22)); out[6 * n + p] = (float)(di * (M11 * M33 - M13 * M13));
+        out[7 * n + p] = (float)(di * (M12 * M13 - M11 * M23)); out[8 * n + p] = (float)(di * (M11 * M22 - M12 * M12));
+    }
+}
+void launch_normals_cache(int W, int H, int r, double fx_inv, double fy_inv, double cx, double cy, double* work, float* out, hipStream_t s) {
+    const size_t n = (size_t)W * H;
+    const int grid = (int)min((n + kBlock - 1) / kBlock, (size_t)4096);
+    double* a = work; double* t = work + 6 * n;
+    hipLaunchKernelGGL(k_ncache_rays, dim3(grid), dim3(kBlock), 0, s, W, H, fx_inv, fy_inv, cx, cy, a, out);
+    hipLaunchKernelGGL(k_ncache_box<false>, dim3(grid), dim3(kBlock), 0, s, (const double*)a, t, W, H, r);
+    hipLaunchKernelGGL(k_ncache_box<true>, dim3(grid), dim3(kBlock), 0, s, (const double*)t, a, W, H, r);
+    hipLaunchKernelGGL(k_ncache_inverse, dim3(grid), dim3(kBlock), 0, s, (const double*)a, n, out);
+}
 // one Gauss-Newton pass of the tracker: H (21) | g (6) | E | count per workgroup -> partial rows part[blockIdx][29]
 // gdimz, zown0, zown1: z-slabs -- the volume's plane count and the planes THIS context owns; a pixel is counted by the rank that owns the plane of its
 // nearest voxel (the ranks' sums are all-reduced by the host), the bounds test is the whole volume's

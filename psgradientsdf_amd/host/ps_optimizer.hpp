@@ -87,10 +87,60 @@ struct OptimizerSettings {                           // OptimizerSettings.h:24-5
 // its files are tens of MB of that.  Same characters here, from snprintf into per-thread buffers (the lines of a file are formatted in parallel
 // chunks and written in order), on a background thread, so that the optimisation goes on while a dump is being formatted.
 inline bool& host_writers() { static bool v = false; return v; }      // voxelPS --host-writers: round 4's path (dense download, host marching cubes, iostream): the cross-check
+// printf's "%g" (six significant digits, trailing zeros stripped, scientific below 1e-4 and from 1e6) without printf: a dump is 3-5 million numbers and
+// snprintf takes ~150 ns for each.  The float is exact in a double; scaled by an EXACT power of ten (10^0 .. 10^22) the product is off by at most one
+// rounding (1.1e-16 relative, < 2e-10 at six digits), so the six digits are decided unless the value sits within 1e-6 of a rounding tie -- those, the
+// non-finite values and the exponents outside the exact powers' reach go to snprintf.  `voxelPS --selftest-fmt N` compares with `ostream << float`.
+inline int format_g6(float v, char* out) {
+    static const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    char* o = out;
+    if (v == 0.0f) { if (std::signbit(v)) *o++ = '-'; *o++ = '0'; return (int)(o - out); }
+    if (!std::isfinite(v)) return -1;
+    const double a = std::fabs((double)v);
+    int e2; std::frexp(a, &e2);
+    int X = (int)std::floor((e2 - 1) * 0.30102999566398120);      // floor(log10(a)) or one less
+    double x;
+    for (int tries = 0;; ++tries) {
+        const int sh = 5 - X;                                       // a * 10^sh in [1e5, 1e6)
+        if (sh < -22 || sh > 22 || tries > 3) return -1;
+        x = sh >= 0 ? a * p10[sh] : a / p10[-sh];
+        if (x < 1e5) { --X; continue; }
+        if (x >= 1e6) { ++X; continue; }
+        break;
+    }
+    const double fl = std::floor(x), fr = x - fl;
+    if (std::fabs(fr - 0.5) < 1e-6) return -1;                    // too close to a tie for this arithmetic to call
+    long D = (long)fl + (fr > 0.5 ? 1 : 0);
+    if (D >= 1000000) { D = 100000; ++X; }
+    char d[6]; for (int k = 5; k >= 0; --k) { d[k] = (char)('0' + D % 10); D /= 10; }
+    int nd = 6; while (nd > 1 && d[nd - 1] == '0') --nd;
+    if (std::signbit(v)) *o++ = '-';
+    if (X < -4 || X >= 6) {
+        *o++ = d[0];
+        if (nd > 1) { *o++ = '.'; for (int k = 1; k < nd; ++k) *o++ = d[k]; }
+        *o++ = 'e'; *o++ = X < 0 ? '-' : '+';
+        const int ax = X < 0 ? -X : X;
+        if (ax >= 100) *o++ = (char)('0' + ax / 100);
+        *o++ = (char)('0' + (ax / 10) % 10); *o++ = (char)('0' + ax % 10);
+    } else if (X >= 0) {
+        for (int k = 0; k <= X; ++k) *o++ = k < nd ? d[k] : '0';
+        if (nd > X + 1) { *o++ = '.'; for (int k = X + 1; k < nd; ++k) *o++ = d[k]; }
+    } else {
+        *o++ = '0'; *o++ = '.';
+        for (int k = 0; k < -X - 1; ++k) *o++ = '0';
+        for (int k = 0; k < nd; ++k) *o++ = d[k];
+    }
+    return (int)(o - out);
+}
 struct TextOut {
     std::string s;
-    void f(float v) { char t[40]; const int n = snprintf(t, sizeof t, "%g", (double)v); s.append(t, (size_t)n); }
-    void i(long long v) { char t[24]; const int n = snprintf(t, sizeof t, "%lld", v); s.append(t, (size_t)n); }
+    void f(float v) { char t[40]; int n = format_g6(v, t); if (n < 0) n = snprintf(t, sizeof t, "%g", (double)v); s.append(t, (size_t)n); }
+    void i(long long v) {
+        char t[24]; int n = 24; unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        do { t[--n] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) t[--n] = '-';
+        s.append(t + n, (size_t)(24 - n));
+    }
     void c(char ch) { s.push_back(ch); }
 };
 // n lines, line(out, i) appends line i; formatted on up to 16 threads, in order

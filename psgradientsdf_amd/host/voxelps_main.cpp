@@ -124,7 +124,13 @@ static int selftest_fmt(long n) {
         if (o.str() != t.s) { if (bad < 5) std::cout << "MISMATCH " << o.str() << " vs " << t.s << std::endl; ++bad; }
         ++done;
     };
-    for (long i = 0; i < n; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; uint32_t u = (uint32_t)(x >> 16); float v; memcpy(&v, &u, 4); check(v); }
+    auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (long i = 0; i < n; ++i) { uint32_t u = (uint32_t)(rnd() >> 16); float v; memcpy(&v, &u, 4); check(v); }
+    // the ranges the dumps live in (the fast path of format_g6): uniform in (-2, 2), log-uniform over 1e-7 .. 1e7, and decimals of seven digits ending in 5
+    // -- the floats nearest to a rounding tie of the sixth digit
+    for (long i = 0; i < n; ++i) check((float)((double)(rnd() >> 11) * (4.0 / 9007199254740992.0) - 2.0));
+    for (long i = 0; i < n; ++i) { const double u = (double)(rnd() >> 11) / 9007199254740992.0; check((float)std::pow(10.0, 14.0 * u - 7.0)); }
+    for (long i = 0; i < n; ++i) { const long k = (long)(rnd() % 900000) + 100000; const int e = (int)(rnd() % 16) - 9; const double t = ((double)k * 10.0 + 5.0) * std::pow(10.0, (double)e - 6.0); check((float)t); check(std::nextafter((float)t, 0.0f)); check(std::nextafter((float)t, 1e30f)); }
     for (int e = -45; e <= 38; ++e) for (float m : {1.0f, 9.999995f, 9.9999995f, 1.234565f, 1.2345649f, 0.5f, 2.5f}) { check(m * std::pow(10.0f, (float)e)); check(-m * std::pow(10.0f, (float)e)); }
     for (int i = 0; i <= 255; ++i) check((float)i * (1.0f / 255.0f));
     std::cout << done << " " << bad << std::endl;

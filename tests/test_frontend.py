@@ -69,3 +69,44 @@ def test_engine_normals_and_tracker_match_oracle(built):
     Pe, ie, ce = eng.track(sc.depth[0], P0, num_iterations=3); Po, io, co = orc.track(sc.depth[0], P0, num_iterations=3)
     assert ce == co and ie == io
     assert np.abs(Pe - Po).max() <= 2e-5, np.abs(Pe - Po).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H", [(160, 120), (380, 570), (1139, 1709), (7, 5)])
+def test_normals_cache_on_the_device_is_the_host_formula_bit_for_bit(built, W, H):
+    """NormalEstimator::cache (NormalEstimator.h:52-125) runs on the device since round 5 (it was 0.15-0.5 s of one host core at the demo's native
+    1139 x 1709).  Restated here in numpy float64 -- the same products, the (2r+1)^2 box sums as eleven adds per direction in the order k = -r .. r with
+    OpenCV's BORDER_REFLECT_101, the cofactor inverse -- it must agree in every bit of the nine float planes; (7, 5): an image smaller than the window."""
+    sc = synth.make_scene(N=16, F=2, W=64, H=48, model="SH1")
+    K = np.array([[525.3 * W / 640, 0, 0.5 * W - 0.37], [0, 524.1 * H / 480, 0.5 * H + 0.21], [0, 0, 1]], np.float32)
+    eng = capi.load_engine(sc, K.reshape(-1), capi.default_settings(capi.SH1), 0)
+    got = eng.debug_normals_cache(W, H)
+    eng.close()
+    f64 = np.float64
+    fx_inv, fy_inv, cx, cy = f64(1.0) / f64(K[0, 0]), f64(1.0) / f64(K[1, 1]), f64(K[0, 2]), f64(K[1, 2])
+    x0 = (fx_inv * (np.arange(W, dtype=f64) - cx))[None, :] * np.ones((H, 1)); y0 = (fy_inv * (np.arange(H, dtype=f64) - cy))[:, None] * np.ones((1, W))
+    nsi = 1.0 / (1.0 + x0 * x0 + y0 * y0)
+    a = [x0 * x0 * nsi, x0 * y0 * nsi, x0 * nsi, y0 * y0 * nsi, y0 * nsi, nsi]
+
+    def reflect(i, n):
+        i = np.asarray(i).copy()
+        if n == 1:
+            return np.zeros_like(i)
+        while ((i < 0) | (i >= n)).any():
+            i = np.where(i < 0, -i, i); i = np.where(i >= n, 2 * n - 2 - i, i)
+        return i
+
+    def box(v, r=5):
+        t = np.zeros_like(v)
+        for k in range(-r, r + 1):
+            t = t + v[:, reflect(np.arange(W) + k, W)]
+        o = np.zeros_like(v)
+        for k in range(-r, r + 1):
+            o = o + t[reflect(np.arange(H) + k, H), :]
+        return o
+    M11, M12, M13, M22, M23, M33 = (box(v) for v in a)
+    det = M11 * (M22 * M33) + 2 * M12 * (M23 * M13) - (M13 * (M13 * M22) + M12 * (M12 * M33) + M23 * (M23 * M11))
+    di = 1.0 / det
+    want = np.stack([x0 * nsi, y0 * nsi, nsi, di * (M22 * M33 - M23 * M23), di * (M13 * M23 - M12 * M33), di * (M12 * M23 - M13 * M22),
+                     di * (M11 * M33 - M13 * M13), di * (M12 * M13 - M11 * M23), di * (M11 * M22 - M12 * M12)]).astype(np.float32)
+    assert np.array_equal(got, want), np.abs(got.astype(f64) - want).max()

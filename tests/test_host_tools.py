@@ -243,13 +243,15 @@ def test_keyframe_sampling_against_numpy(built, n, max_num):
 
 
 def test_threaded_writers_print_floats_like_the_reference(built):
-    """The round-5 writers format with snprintf("%g") into per-thread buffers; the reference (and round 4's writers) with `ostream << float`, one std::endl
-    per line.  `voxelPS --selftest-fmt N`: two million pseudo-random float bit patterns (every exponent, denormals, infinities, NaNs), a ladder of
-    values at the rounding edges of six significant digits and the 256 colour levels come out character for character the same both ways."""
-    r = subprocess.run([EXE, "--selftest-fmt", "2000000"], capture_output=True, text=True, timeout=300)
+    """The round-5 writers format floats with their own "%g" (host/ps_optimizer.hpp format_g6: exact power-of-ten scaling in double, snprintf for the values
+    within 1e-6 of a rounding tie and outside the exact powers' reach) into per-thread buffers; the reference (and round 4's writers) with `ostream << float`,
+    one std::endl per line.  `voxelPS --selftest-fmt N`: N pseudo-random float bit patterns (every exponent, denormals, infinities, NaNs), N uniform values in
+    (-2, 2), N log-uniform over 1e-7 .. 1e7, 3 N floats at and next to seven-digit decimals ending in 5 (the nearest a float gets to a tie of the sixth
+    digit), a ladder of values at the rounding edges and the 256 colour levels come out character for character the same both ways."""
+    r = subprocess.run([EXE, "--selftest-fmt", "1000000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-500:]
     done, bad = (int(x) for x in r.stdout.strip().split("\n")[-1].split())
-    assert bad == 0 and done > 2000000
+    assert bad == 0 and done > 6000000
 
 
 def test_voxelps_gpus_n_without_a_device_fails_loudly_and_ends_every_rank(built, tmp_path):
