@@ -144,6 +144,9 @@ int psgsdf_upload_volume(psgsdf_ctx* ctx, const float* dist, const float* grad_x
  * integration counter of keyframe f (selects the visibility bit, Optimizer.cpp:30-47). */
 int psgsdf_set_keyframes(psgsdf_ctx* ctx, int n_frames, const int32_t* frame_idx,
                          const float* rgb_images, int width, int height, const float* poses);
+/* The same with one pointer per image (n_frames pointers to width * height * 3 floats each): the reference keeps its keyframes as a std::vector<cv::Mat>,
+ * one allocation per image (Optimizer.h:137-140) -- no gather into one array on the host. */
+int psgsdf_set_keyframes_frames(psgsdf_ctx* ctx, int n_frames, const int32_t* frame_idx, const float* const* rgb_images, int width, int height, const float* poses);
 
 /* The same with the keyframes as the reference's loader receives them: 8-bit interleaved RGB [F][H][W][3] plus the factor
  * of its conversion (ImageLoader.h:167-181: cv::imread, then convertTo(CV_32FC3, 1.0f / 255.0f)).  The engine samples

@@ -185,6 +185,14 @@ class Api:
         a = [_fp(frame_idx, np.int32), _fp(images), _fp(poses)]
         self._check(self._fn("set_keyframes")(self.ctx, C.c_int(F), a[0][1], a[1][1], C.c_int(W), C.c_int(H), a[2][1]), "set_keyframes")
 
+    def set_keyframes_frames(self, frame_idx, image_list, poses):
+        """one array [H][W][3] per keyframe (psgsdf_set_keyframes_frames: the host keeps one allocation per image)"""
+        imgs = [np.ascontiguousarray(im, np.float32) for im in image_list]
+        H, W, _ = imgs[0].shape
+        ptrs = (C.c_void_p * len(imgs))(*[im.ctypes.data for im in imgs])
+        a = [_fp(frame_idx, np.int32), _fp(poses)]
+        self._check(self._fn("set_keyframes_frames")(self.ctx, C.c_int(len(imgs)), a[0][1], ptrs, C.c_int(W), C.c_int(H), a[1][1]), "set_keyframes_frames")
+
     def set_keyframes_u8(self, frame_idx, images_u8, scale, poses):
         """8-bit RGB keyframes [F][H][W][3] + the loader's conversion factor (colour = byte * scale)"""
         F, H, W = images_u8.shape[:3]

@@ -385,8 +385,9 @@ int psgsdf_integrate_frame(psgsdf_ctx* c, const float* rgb, const float* depth, 
 
 // everything of set_keyframes but the pixels; exactly one of rgb_f32 / rgb_u8 is given
 static int set_keyframes_impl(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_f32, const uint8_t* rgb_u8, float scale,
-                              int width, int height, const float* poses) {
-    if (!c || n_frames <= 0 || !frame_idx || (!rgb_f32 && !rgb_u8) || !poses || width <= 1 || height <= 1) return fail(c, PSGSDF_ERR_ARG, "set_keyframes: bad argument");
+                              int width, int height, const float* poses, const float* const* rgb_f32_frames = nullptr) {
+    if (!c || n_frames <= 0 || !frame_idx || (!rgb_f32 && !rgb_u8 && !rgb_f32_frames) || !poses || width <= 1 || height <= 1) return fail(c, PSGSDF_ERR_ARG, "set_keyframes: bad argument");
+    if (rgb_f32_frames) for (int f = 0; f < n_frames; ++f) if (!rgb_f32_frames[f]) return fail(c, PSGSDF_ERR_ARG, "set_keyframes: image %d is NULL", f);
     if (n_frames > kMaxFramesLds) return fail(c, PSGSDF_ERR_UNSUPPORTED, "at most %d keyframes", kMaxFramesLds);
     if (rgb_u8 && ((size_t)n_frames * width * height >= ((size_t)1 << 30) || (size_t)n_frames * height >= ((size_t)1 << 24))) return fail(c, PSGSDF_ERR_UNSUPPORTED, "8-bit keyframes: at most 2^30 pixels and 2^24 image rows");
     HIPCHK(c, hipSetDevice(c->device));
@@ -401,9 +402,11 @@ static int set_keyframes_impl(psgsdf_ctx* c, int n_frames, const int32_t* frame_
     HIPCHK(c, hipMalloc(&c->acc_frame, sizeof(double) * c->acc_frame_n));
     HIPCHK(c, hipMemsetAsync(c->acc_frame, 0, sizeof(double) * c->acc_frame_n, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->frame_idx, frame_idx, sizeof(int) * n_frames, hipMemcpyHostToDevice, c->stream));
-    if (rgb_f32) {
+    if (rgb_f32 || rgb_f32_frames) {
         HIPCHK(c, hipMalloc(&c->img, sizeof(float) * npix * 3));
-        HIPCHK(c, hipMemcpyAsync(c->img, rgb_f32, sizeof(float) * npix * 3, hipMemcpyHostToDevice, c->stream));
+        const size_t per = (size_t)width * height * 3;
+        if (rgb_f32) HIPCHK(c, hipMemcpyAsync(c->img, rgb_f32, sizeof(float) * npix * 3, hipMemcpyHostToDevice, c->stream));
+        else for (int f = 0; f < n_frames; ++f) HIPCHK(c, hipMemcpyAsync(c->img + per * f, rgb_f32_frames[f], sizeof(float) * per, hipMemcpyHostToDevice, c->stream));      // one image per allocation (the reference's std::vector<cv::Mat>): no gather on the host
         // Keyframes that came out of 8-bit files (the reference's loader: imread + convertTo(CV_32FC3, 1.0f / 255.0f)) are kept as RGBA8 words: the
         // samplers give back the SAME floats (device_common.h unpack_rgb8), with two tap loads per observation instead of four and a third of the bytes.
         c->img_compacted = false;
@@ -452,6 +455,9 @@ static int set_keyframes_impl(psgsdf_ctx* c, int n_frames, const int32_t* frame_
 }
 int psgsdf_set_keyframes(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, const float* rgb_images, int width, int height, const float* poses) {
     return set_keyframes_impl(c, n_frames, frame_idx, rgb_images, nullptr, 0.f, width, height, poses);
+}
+int psgsdf_set_keyframes_frames(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, const float* const* rgb_images, int width, int height, const float* poses) {
+    return set_keyframes_impl(c, n_frames, frame_idx, nullptr, nullptr, 0.f, width, height, poses, rgb_images);
 }
 int psgsdf_set_keyframes_u8(psgsdf_ctx* c, int n_frames, const int32_t* frame_idx, const uint8_t* rgb_images, float scale, int width, int height, const float* poses) {
     return set_keyframes_impl(c, n_frames, frame_idx, nullptr, rgb_images, scale, width, height, poses);

@@ -554,12 +554,13 @@ public:
             ctx_ = tSDF_->ctx; borrowed_ = true;
             if (multi_rank()) { const int rb = psgsdf_rebalance_slabs(ctx_); if (rb) { fail("psgsdf_rebalance_slabs", rb); return; } }      // fused in slabs of equal height, optimised in slabs of equal band count
             const int W = images_[0]->cols, H = images_[0]->rows;
-            std::vector<float> img((size_t)num_frames_ * W * H * 3), P(num_frames_ * 16);
+            std::vector<float> P(num_frames_ * 16); std::vector<const float*> img(num_frames_);
             for (size_t f = 0; f < num_frames_; ++f) {
-                std::copy(images_[f]->data.begin(), images_[f]->data.end(), img.begin() + f * (size_t)W * H * 3);
+                if (images_[f]->cols != W || images_[f]->rows != H) { std::cerr << "keyframe " << f << " has another size" << std::endl; return; }
+                img[f] = images_[f]->data.data();      // (one allocation per image, like the reference's std::vector<cv::Mat>: no gather)
                 std::copy(poses_[f].begin(), poses_[f].end(), P.begin() + f * 16);
             }
-            int rc = psgsdf_set_keyframes(ctx_, (int)num_frames_, frame_idx_.data(), img.data(), W, H, P.data());
+            int rc = psgsdf_set_keyframes_frames(ctx_, (int)num_frames_, frame_idx_.data(), img.data(), W, H, P.data());
             if (rc) { fail("psgsdf_set_keyframes", rc); return; }
             rc = psgsdf_init(ctx_);
             if (rc) fail("psgsdf_init", rc);

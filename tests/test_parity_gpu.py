@@ -278,3 +278,10 @@ def test_8bit_keyframes(built, margins, name, mid):
     m = sdf_margin(ve["dist"], vo["dist"], band, vs)
     margins(sdf=m, tolerance={"q999_vs": 1e-4, "max_vs": 1e-4})
     assert m["q999_vs"] <= 1e-4 and m["max_vs"] <= 1e-4, m
+    # one allocation per keyframe (psgsdf_set_keyframes_frames: the reference's std::vector<cv::Mat>): the very same run as the one-array entry point
+    engp = capi.load_engine(sc, sc.K, st, 0)
+    engp.upload_volume(sc.dist, sc.grad, sc.weight, sc.rgb, sc.vis, sc.vis_words)
+    engp.set_keyframes_frames(sc.frame_idx, [sc.images[f].copy() for f in range(sc.F)], sc.poses); engp.init()
+    engp.init_albedo(); engp.normalize_weights()
+    rp = engp.iterate(capi.ALL, 2)
+    assert [r["e_total"] for r in rp] == [r["e_total"] for r in rc_] and engp.debug_sync_stats()["keyframes_compacted"] == 1
