@@ -86,7 +86,10 @@ struct OptimizerSettings {                           // OptimizerSettings.h:24-5
 // The reference prints every number through `ostream << float`, i.e. printf's %g with six significant digits, one std::endl (= a flush) per line;
 // its files are tens of MB of that.  Same characters here, from snprintf into per-thread buffers (the lines of a file are formatted in parallel
 // chunks and written in order), on a background thread, so that the optimisation goes on while a dump is being formatted.
-inline bool& host_writers() { static bool v = false; return v; }      // voxelPS --host-writers: round 4's path (dense download, host marching cubes, iostream): the cross-check
+inline bool& host_writers() { static bool v = false; return v; }
+// voxelPS reads nothing of the refined volume after alternatingOptimize (main_ps.cpp:330-343 ends there): the executable skips the whole-volume download
+// that mirrors the reference's in-place mutation of tSDF_ (a host that goes on using tSDF_ keeps it: the default)
+inline bool& skip_sync_back() { static bool v = false; return v; }      // voxelPS --host-writers: round 4's path (dense download, host marching cubes, iostream): the cross-check
 // printf's "%g" (six significant digits, trailing zeros stripped, scientific below 1e-4 and from 1e6) without printf: a dump is 3-5 million numbers and
 // snprintf takes ~150 ns for each.  The float is exact in a double; scaled by an EXACT power of ten (10^0 .. 10^22) the product is off by at most one
 // rounding (1.1e-16 relative, < 2e-10 at six digits), so the six digits are decided unless the value sits within 1e-6 of a rounding tie -- those, the
@@ -634,10 +637,11 @@ public:
         size_t n = (size_t)info.dim[0] * info.dim[1] * info.dim[2];
         for (int a = 0; a < 3; ++a) tSDF_->grid_dim_[a] = info.dim[a];
         tSDF_->voxel_size_ = info.voxel_size; voxel_size_ = info.voxel_size;
-        if (multi_rank()) n = 0;      // (a rank holds a slab: no whole-volume host copy; nothing in voxelPS reads one after the optimisation)
+        const bool no_volume = multi_rank() || skip_sync_back();      // (a rank holds a slab: no whole-volume host copy; nothing in voxelPS reads one after the optimisation)
+        if (no_volume) n = 0;
         tSDF_->dist.resize(n); tSDF_->grad.resize(3 * n); tSDF_->weight.resize(n); tSDF_->rgb.resize(3 * n);
         tSDF_->vis.resize(n * info.vis_words); tSDF_->vis_words = info.vis_words;
-        int rc = multi_rank() ? 0 : psgsdf_download_volume(ctx_, tSDF_->dist.data(), tSDF_->grad.data(), tSDF_->weight.data(), tSDF_->rgb.data(), tSDF_->vis.data());
+        int rc = no_volume ? 0 : psgsdf_download_volume(ctx_, tSDF_->dist.data(), tSDF_->grad.data(), tSDF_->weight.data(), tSDF_->rgb.data(), tSDF_->vis.data());
         if (rc) return fail("psgsdf_download_volume", rc);
         std::vector<float> P(num_frames_ * 16);
         rc = psgsdf_download_poses(ctx_, P.data());

@@ -354,6 +354,7 @@ int main(int argc, char* argv[]) {
     std::cout << " selected key frame: " << std::endl; for (int k : keyframes) std::cout << k << " "; std::cout << std::endl;
     if ((int)keyframes.size() > max_key) sampleKeyFrame(keyframes, key_stamps, key_images, key_poses, max_key);
     std::cout << " selected key frame after sampling: " << std::endl; for (int k : keyframes) std::cout << k << " "; std::cout << std::endl;
+    skip_sync_back() = !host_writers();
     vOpt->setImages(key_images); vOpt->setKeyframes(keyframes); vOpt->setKeytimestamps(key_stamps); vOpt->setPoses(key_poses);
     vOpt->init();
     vOpt->alternatingOptimize(light, albedo, distance, pose);
