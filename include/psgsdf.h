@@ -348,6 +348,9 @@ int psgsdf_comm_stats(psgsdf_ctx* ctx, int64_t* n_collectives);
 /* ---- measurement / test hooks (not part of the reference seam) -------------------------- */
 /* the FALS estimator's per-resolution cache (NormalEstimator::cache, NormalEstimator.h:52-125) as the device computed it: 9 planes of width * height floats
  * (ray / (1 + x0^2 + y0^2): 3, the inverse of the box-filtered 3x3 matrix: 6) */
+/* timing probe (profiles/r05_notes.md section 5): out[4] = ms of { distance sweep alone, distance solve alone, the two back to back, the solve started on a
+ * second stream together with the sweep } -- the upper bound of what starting the solve under the sweep's tail could hide */
+int psgsdf_debug_overlap_probe(psgsdf_ctx* ctx, int reps, double* out);
 int psgsdf_debug_normals_cache(psgsdf_ctx* ctx, int width, int height, float* cache9);
 
 /* last measured kernel durations in ms keyed by name; names[i] are static strings.

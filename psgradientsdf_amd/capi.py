@@ -386,6 +386,12 @@ class Api:
         self._comm_ops = ops
         self._check(self._fn("comm_init_ext")(self.ctx, C.byref(ops), C.c_int(rank), C.c_int(n_ranks)), "comm_init_ext")
 
+    def debug_overlap_probe(self, reps=10):
+        """ms of {distance sweep alone, solve alone, back to back, solve started beside the sweep on a second stream}"""
+        out = (C.c_double * 4)()
+        self._check(self._fn("debug_overlap_probe")(self.ctx, C.c_int(reps), out), "debug_overlap_probe")
+        return list(out)
+
     def debug_normals_cache(self, width, height):
         """the FALS estimator's per-resolution cache as the device computed it: [9, height, width] float32"""
         out = np.empty((9, height, width), np.float32)

@@ -108,6 +108,54 @@ int psgsdf_debug_time_pcg_solve(psgsdf_ctx* c, int passes, int reps, double* ms_
     return PSGSDF_OK;
 }
 
+// VERDICT r04 item 4b, measured instead of argued: how much of the distance solve could an early start hide under the distance sweep?  Timing only.
+//   out[0] the distance sweep alone, out[1] the solve alone (its own assembly prologue, natural stop, no update applied), out[2] the two back to back on
+//   one stream (what the loop does), out[3] the solve started on a SECOND stream at the same moment as a repeat of the sweep -- it assembles from the
+//   blocks of the identical sweep before, so it never waits for the one running beside it: every workgroup of the solve that finds a free CU is resident
+//   from the first microsecond.  out[2] - out[3] is the most any overlap scheme (per-block "done" flags included) could win.  Milliseconds, means over reps.
+int psgsdf_debug_overlap_probe(psgsdf_ctx* c, int reps, double* out) {
+    if (!c || !c->inited || !out || reps < 1) return fail(c, PSGSDF_ERR_STATE, "init first");
+    if (c->n_ranks > 1) return fail(c, PSGSDF_ERR_UNSUPPORTED, "overlap probe: one rank");
+    HIPCHK(c, hipSetDevice(c->device));
+    int G = 0, rows = 0;
+    if (!cgf_solve_shape(c, &G, &rows) || !c->pcg_fuse_asm) return fail(c, PSGSDF_ERR_UNSUPPORTED, "the persistent solve with its fused assembly does not apply to this context");
+    { int rc = flush(c); if (rc) return rc; }
+    SweepArgs a = make_args(c, c->reg_l != 0.f);
+    a.pcg_fuse_init = 1; a.pcg_init_blocks = band_blocks(c); a.pcg_gran = c->pcg_gran; a.pcg_gran_n = 2 * kSolveGranPlanes * kSolveMaxBlocksHost; a.pcg_asm = 1;
+    SweepArgs quiet = a; quiet.pcg_gran = nullptr; quiet.pcg_gran_n = 0;      // (a sweep that does NOT clear the solve's tags: the one that runs beside a solve)
+    hipStream_t s2; HIPCHK(c, hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    hipEvent_t e[4]; for (auto& x : e) HIPCHK(c, hipEventCreate(&x));
+    double acc[4] = {0, 0, 0, 0};
+    int rc = PSGSDF_OK;
+    auto ms = [&](hipEvent_t x, hipEvent_t y) { float t = 0; hipEventElapsedTime(&t, x, y); return (double)t; };
+    auto solve = [&](hipStream_t s) { launch_cgf_solve(a, c->pcg_sc, c->pcg_gran, G, rows, 1 << 30, c->mbox_dev, 0ull, 0, s); };
+    for (int r = 0; r < reps + 1 && !rc; ++r) {
+        // [0] + [1]: each alone
+        hipEventRecord(e[0], c->stream); launch_sweep_dist(a, c->stream); hipEventRecord(e[1], c->stream);
+        hipStreamSynchronize(c->stream);
+        hipEventRecord(e[2], c->stream); solve(c->stream); hipEventRecord(e[3], c->stream);
+        hipStreamSynchronize(c->stream);
+        if (c->mbox[3] != 1.0) { rc = fail(c, PSGSDF_ERR_DEVICE, "overlap probe: solve status %g", c->mbox[3]); break; }
+        if (r) { acc[0] += ms(e[0], e[1]); acc[1] += ms(e[2], e[3]); }
+        // [2]: back to back
+        hipEventRecord(e[0], c->stream); launch_sweep_dist(a, c->stream); solve(c->stream); hipEventRecord(e[1], c->stream);
+        hipStreamSynchronize(c->stream);
+        if (r) acc[2] += ms(e[0], e[1]);
+        // [3]: side by side (the tags were cleared by the sweep of [2]; its solve consumed them, so clear them again first)
+        launch_sweep_dist(a, c->stream);
+        hipEventRecord(e[0], c->stream); hipStreamWaitEvent(s2, e[0], 0);
+        launch_sweep_dist(quiet, c->stream); hipEventRecord(e[1], c->stream);
+        solve(s2); hipEventRecord(e[2], s2);
+        hipStreamSynchronize(c->stream); hipStreamSynchronize(s2);
+        if (c->mbox[3] != 1.0) { rc = fail(c, PSGSDF_ERR_DEVICE, "overlap probe (side by side): solve status %g", c->mbox[3]); break; }
+        if (r) acc[3] += std::max(ms(e[0], e[1]), ms(e[0], e[2]));
+    }
+    for (auto& x : e) hipEventDestroy(x);
+    hipStreamDestroy(s2);
+    for (int i = 0; i < 4; ++i) out[i] = acc[i] / reps;
+    return rc;
+}
+
 // how many rows of the assembled distance system carry any of the 6 "rare" ELL columns, and how many 64-row groups
 // (wavefronts of a one-row-per-thread launch) contain such a row
 int psgsdf_debug_rare_rows(psgsdf_ctx* c, int64_t* rows, int64_t* waves) {

@@ -24,7 +24,7 @@ def test_oracle_mirrors_the_abi(built):
     lib = oracle.lib()
     # (the oracle's multi-rank mirror is driven through its own phase API by tests/_slab_runner.py: no communicator entry points)
     skip = {"psgsdf_comm_unique_id", "psgsdf_comm_init_ext", "psgsdf_comm_init_sockets", "psgsdf_comm_allreduce_host", "psgsdf_comm_stats", "psgsdf_kernel_times", "psgsdf_reset_kernel_times",
-            "psgsdf_set_profiling", "psgsdf_watch_kernel", "psgsdf_debug_time_pcg_pass", "psgsdf_debug_time_pcg_solve", "psgsdf_debug_rare_rows", "psgsdf_debug_sync_stats", "psgsdf_debug_normals_cache", "psgsdf_set_keyframes_frames",
+            "psgsdf_set_profiling", "psgsdf_watch_kernel", "psgsdf_debug_time_pcg_pass", "psgsdf_debug_time_pcg_solve", "psgsdf_debug_rare_rows", "psgsdf_debug_sync_stats", "psgsdf_debug_normals_cache", "psgsdf_debug_overlap_probe", "psgsdf_set_keyframes_frames",
             "psgsdf_slab_plane_count", "psgsdf_plan_slab", "psgsdf_upload_volume_slab", "psgsdf_rebalance_slabs", "psgsdf_set_record_observer", "psgsdf_set_on_iter_period", "psgsdf_get_tuning",
             "psgsdf_extract_mesh", "psgsdf_extract_pointcloud", "psgsdf_extract_sdf"}      # (the writers' geometry on the device: the oracle's counterpart is the host-side pass of psgradientsdf_amd/host)
     for n in g._declared_symbols():
