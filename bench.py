@@ -630,12 +630,12 @@ def main():
             fixed_floor_us = 76.0 * S / (HBM_PEAK_GBS * 1e3) + 2.0       # the fused assembly + update stream 76 B per band voxel once; + the launch ramp
             floor_us = fixed_floor_us + passes * hand_off_us
             out["roofline"].update({
-                "bound_observed": "device-wide hand-off latency (one tag wait + gather round + publish per PCG pass across 256 workgroups; the matrix is LDS-resident, HBM traffic is 0.13 x the algorithmic bytes)",
+                "bound_observed": "device-wide hand-off latency (per PCG pass: the neighbours' values back from beyond the L2 -- self-validating since round 5: no tag wait, acquire or drain in front of them -- two gather batches, the all-gather of the sums, across 256 workgroups; the matrix is LDS-resident, HBM traffic is 0.13 x the algorithmic bytes)",
                 "passes": passes, "us_per_pass": sm["us_per_pass"] if sm else None, "fixed_us": sm["fixed_us"] if sm else None,
                 "floor_model": {"formula": "fixed_floor + passes x hand_off", "hand_off_us": hand_off_us, "fixed_floor_us": fixed_floor_us, "floor_us": floor_us,
                                 "measured_us": 1e3 * avg_ms, "frac_of_floor": floor_us / (1e3 * avg_ms) if avg_ms == avg_ms else None,
                                 "measured_decomposition_us": ({"fixed (assembly, first records, update, launch)": sm["fixed_us"], "passes": passes * sm["us_per_pass"]} if sm else None),
-                                "note": "a pass costs 2.6 hand-offs' worth: the tag wait of the slowest neighbour, 18 gathers per row in two batches, the publish (profiles/r04_notes.md section 4: five variants measured against it)"}})
+                                "note": "a pass costs 2.3 hand-offs' worth (round 4: 2.7): the exchanged values carry their own tags, so the chain is store -> gather (re-issued until the tag is the pass's) -> sums; 18 gathers per row in two batches (profiles/r04_notes.md section 4, r05_notes.md sections 9-10)"}})
         # whole-iteration algorithmic bytes (SURVEY.md §8d formula) for reference
         U = min(48 * n_obs, 12 * args.width * args.height * args.frames)
         B_iter = 4 * (S * 60 + U) + 120 * S + 124 * cg_iters * S   # SURVEY §8d per-pass figure kept (the fused pass moves 144 B/row)

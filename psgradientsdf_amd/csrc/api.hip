@@ -34,7 +34,7 @@ const char* psgsdf_version(void) { return "psgsdf-hip gfx950 r5"; }
 // WRONG on purpose and are compiled out of libpsgsdf.so.
 static const char* const kKnobs[] = {
     "PSGSDF_PCG_POLL", "PSGSDF_SPECULATE", "PSGSDF_FOLD_IN_NEXT", "PSGSDF_FUSE_ALBEDO", "PSGSDF_FUSE_PCG_INIT", "PSGSDF_PCG_PERSIST", "PSGSDF_PCG_XCD_LOCAL",
-    "PSGSDF_PCG_FUSE_ASM", "PSGSDF_PCG_FUSE_APPLY", "PSGSDF_PCG_PIPELINE", "PSGSDF_PCG_PREFETCH", "PSGSDF_PCG_COL16", "PSGSDF_PCG_ROWS", "PSGSDF_PCG_BLOCKS",
+    "PSGSDF_PCG_FUSE_ASM", "PSGSDF_PCG_FUSE_APPLY", "PSGSDF_PCG_PIPELINE", "PSGSDF_PCG_TAGM", "PSGSDF_PCG_PREFETCH", "PSGSDF_PCG_COL16", "PSGSDF_PCG_ROWS", "PSGSDF_PCG_BLOCKS",
     "PSGSDF_FM_SOLVE", "PSGSDF_FM_ROWS", "PSGSDF_IMG_COMPACT", "PSGSDF_XCD_MAP", "PSGSDF_XCD_STRIPE",
     "PSGSDF_XR", "PSGSDF_XF", "PSGSDF_XS", "PSGSDF_XH", "PSGSDF_XR_MEM", "PSGSDF_XWAIT_LOG2", "PSGSDF_SPECULATE_MR", "PSGSDF_CU_MASK",
     "PSGSDF_WAIT_TIMEOUT_S", "PSGSDF_DESTROY_TIMEOUT_S", "PSGSDF_SOLVE_DUMP"};
@@ -58,6 +58,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_PCG_XCD_LOCAL")) c->pcg_xcd_local = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_FUSE_ASM")) c->pcg_fuse_asm = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_PIPELINE")) c->pcg_pipeline = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_PCG_TAGM")) c->pcg_tagm = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_PREFETCH")) c->pcg_prefetch = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FM_SOLVE")) { c->fm_solve = atoi(e) != 0; c->fm_solve_led = atoi(e) == 1; }
     if (const char* e = getenv("PSGSDF_XF")) c->xf_enable = atoi(e) != 0;

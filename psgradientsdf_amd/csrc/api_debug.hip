@@ -90,6 +90,7 @@ int psgsdf_debug_time_pcg_solve(psgsdf_ctx* c, int passes, int reps, double* ms_
         launch_sweep_dist(a, c->stream);
         launch_assemble(a, c->stream);
         HIPCHK(c, hipEventRecord(e0, c->stream));
+        a.pcg_epoch = ++c->pcg_solve_serial;
         launch_cgf_solve(a, c->pcg_sc, c->pcg_gran, G, rows, 1 << 30, c->mbox_dev, 0ull, passes, c->stream);
         HIPCHK(c, hipEventRecord(e1, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -128,7 +129,7 @@ int psgsdf_debug_overlap_probe(psgsdf_ctx* c, int reps, double* out) {
     double acc[4] = {0, 0, 0, 0};
     int rc = PSGSDF_OK;
     auto ms = [&](hipEvent_t x, hipEvent_t y) { float t = 0; hipEventElapsedTime(&t, x, y); return (double)t; };
-    auto solve = [&](hipStream_t s) { launch_cgf_solve(a, c->pcg_sc, c->pcg_gran, G, rows, 1 << 30, c->mbox_dev, 0ull, 0, s); };
+    auto solve = [&](hipStream_t s) { a.pcg_epoch = ++c->pcg_solve_serial; launch_cgf_solve(a, c->pcg_sc, c->pcg_gran, G, rows, 1 << 30, c->mbox_dev, 0ull, 0, s); };
     for (int r = 0; r < reps + 1 && !rc; ++r) {
         // [0] + [1]: each alone
         hipEventRecord(e[0], c->stream); launch_sweep_dist(a, c->stream); hipEventRecord(e[1], c->stream);
@@ -237,10 +238,10 @@ int psgsdf_get_tuning(psgsdf_ctx* c, char* json, size_t cap) {
     for (auto& kv : c->tuning_ignored) { o += (first ? "\"" : ", \"") + kv.first + "\": \"" + esc(kv.second) + "\""; first = false; }
     o += "}, \"effective\": {";
     char buf[1024];
-    snprintf(buf, sizeof(buf), "\"pcg_poll\": %d, \"speculate\": %d, \"speculate_mr\": %d, \"fold_in_next\": %d, \"fuse_albedo\": %d, \"fuse_pcg_init\": %d, \"pcg_persist\": %d, \"pcg_pipeline\": %d, "
+    snprintf(buf, sizeof(buf), "\"pcg_poll\": %d, \"speculate\": %d, \"speculate_mr\": %d, \"fold_in_next\": %d, \"fuse_albedo\": %d, \"fuse_pcg_init\": %d, \"pcg_persist\": %d, \"pcg_pipeline\": %d, \"pcg_tagm\": %d, "
              "\"pcg_prefetch\": %d, \"pcg_fuse_asm\": %d, \"pcg_fuse_apply\": %d, \"pcg_xcd_local\": %d, \"fm_solve\": %d, \"fm_solve_led\": %d, \"img_compact\": %d, \"xcd_map\": %d, "
              "\"xr\": %d, \"xf\": %d, \"xs\": %d, \"xh\": %d, \"xr_mem_kind\": %d, \"xwait_log2\": %d, \"cu_mask\": [%d, %d], \"mbox_check\": %d, \"pcg_ablate\": %d, \"fault_solve\": %d, \"fault_halo\": %lld",
-             (int)c->pcg_poll, (int)c->speculate, (int)c->speculate_mr, (int)c->fold_in_next, (int)c->fuse_albedo, (int)c->fuse_pcg_init, (int)c->pcg_persist, (int)c->pcg_pipeline,
+             (int)c->pcg_poll, (int)c->speculate, (int)c->speculate_mr, (int)c->fold_in_next, (int)c->fuse_albedo, (int)c->fuse_pcg_init, (int)c->pcg_persist, (int)c->pcg_pipeline, (int)(c->pcg_tagm && c->n_ranks <= 1),
              (int)c->pcg_prefetch, (int)c->pcg_fuse_asm, (int)c->pcg_fuse_apply, (int)c->pcg_xcd_local, (int)c->fm_solve, (int)c->fm_solve_led, (int)c->img_compact, c->xcd_map,
              (int)c->xr_enable, (int)c->xf_enable, (int)c->xs_enable, (int)c->xh_enable, c->xr_mem_kind, (int)lround(log2((double)c->xwait_spins)), c->cu_mask_lo, c->cu_mask_hi,
              (int)c->mbox_check, c->pcg_ablate, c->fault_solve, c->fault_halo);

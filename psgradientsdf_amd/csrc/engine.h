@@ -142,6 +142,7 @@ struct SweepArgs {
     AlbedoReg ar;             // ar.anb == nullptr unless "reg albedo" != 0
     double* pcg_part; double* pcg_fs;   // fused PCG state (pcg.hip)
     int pcg_asm;              // persistent solve assembles the distance system itself (no k_assemble launch in front of it)
+    unsigned pcg_epoch;       // serial number of this context's distance solve (k_cgp_solve<.., TM>: the tag of its exchanged values; the launch sites count it)
     int pcg_pipe;             // ... and runs the pipelined recurrences (pcg.hip k_cgp_solve: the sums of a pass travel while the next pass gathers)
     int pcg_xcd_local;        // ... and keeps the records of workgroups whose neighbours all run on their own XCD in that XCD's L2 (plain stores)
     int pcg_apply;            // ... and applies the distance update itself (no k_apply_dist behind it): 1 = when finished, 2 = only on Success

@@ -84,6 +84,7 @@ int pcg_solve(psgsdf_ctx* c, SweepArgs& a, int* iters_out, int* success_out, dou
                 int rc = comm_allreduce(c, c->mg_ext, 1); if (rc) return rc;      // (a rank's kernel writes into another's region only behind this: every memset is ordered before its owner's contribution)
             }
         }
+        as.pcg_epoch = ++c->pcg_solve_serial;
         timed(c, "pcg_solve", [&] { launch_cgf_solve(as, c->pcg_sc, c->pcg_gran, G, rows, cap, c->mbox_dev + off, key, inject, c->stream, xr); });
         if (tail && !c->profiling) { tail(c->pcg_sc + (gate_on_converged ? 2 : 1)); if (tail_ran) *tail_ran = true; }
         // the four status words are taken only together with their check word (engine.h FoldReq)

@@ -825,7 +825,12 @@ constexpr int kCgpDepth = PSG_CGP_DEPTH;      // gather batches (of 9 doubles) i
 __device__ __forceinline__ void store8_sc1(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void store8_sys(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory"); }
 
-template <int R, bool MR>
+// TM (round 5, single rank, PSGSDF_PCG_TAGM): SELF-VALIDATING m.  Every exchanged value carries (solve epoch << 2 | pass tag) in its four lowest mantissa bits
+// (2^-48 of a double that multiplies float coefficients), is stored write-through and gathered with agent-scope loads that are re-issued until the tag is
+// the pass's: no neighbour-tag wait, no acquire, no drain of the stores in front of the sums -- the hand-off of a pass is ONE trip through memory.
+__device__ __forceinline__ double m_tag(double v, unsigned tag) { return __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(v) & ~15ull) | tag)); }
+__device__ __forceinline__ unsigned m_tag_of(double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) & 15ull); }
+template <int R, bool MR, bool TM = false>
 __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, double* fs, double* gran, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, XrArgs xr) {
     __shared__ double red[8 * kSolveThreads / 64];
     __shared__ int s_abort;
@@ -861,6 +866,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
         if (MR) for (int r = 0; r < xr.n_ranks; ++r) __hip_atomic_store(xr.region[r] + kXrAbort, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
     float* hs = (float*)psg_dyn_smem;
+    const unsigned mepoch = TM ? (1u + a.pcg_epoch % 3u) << 2 : 0u;      // 1 .. 3, never the epoch of the solve before; 0 = memory no solve has written yet (the planes are zeroed when the band is built)
     unsigned cp[R][(kNQ - 1) / 2]; int row[R]; bool live[R];
     double x[R], r[R], w[R], z[R], sv[R], pv[R]; float inv[R];      // every vector of the recurrences in double: see "precision" above
     if (a.fold.n != 0 && blockIdx.x == 0) {      // the sums the distance sweep left pending (device_common.h fold_pending), in that function's order
@@ -902,7 +908,11 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
         inv[u] = dg != 0.f ? 1.0f / dg : 1.0f;
         r[u] = live[u] ? (double)(float)rhs : 0.0;      // (b is the float vector the reference solves for)
         x[u] = 0.0; z[u] = 0.0; sv[u] = 0.0; pv[u] = 0.0; w[u] = 0.0;
-        if (live[u]) { const double u0 = (double)inv[u] * r[u]; store8_sc1(recd[1] + row[u], u0); push_record(1, row[u] - a.row0, u0); }
+        if (live[u]) {
+            const double u0 = (double)inv[u] * r[u];
+            if (TM) __hip_atomic_store(recd[1] + row[u], m_tag(u0, mepoch | 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else { store8_sc1(recd[1] + row[u], u0); push_record(1, row[u] - a.row0, u0); }
+        }
 #pragma unroll
         for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) cp[u][wd] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rC, row[u] * 4, wd * plane, 0);
     }
@@ -928,7 +938,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
         // their m_k had drained; k = -1: the prologue's flag)
         if (tid == 0) { s_abort = 0; if (k < 0) s_foreign = 0; }
         __syncthreads();
-        if (tid <= nhi - nlo && !((a.pcg_xcd_local >> 3) & 2)) {
+        if (!TM && tid <= nhi - nlo && !((a.pcg_xcd_local >> 3) & 2)) {
             int spins = 0;
             const double* wp = k >= 0 ? gp + nlo + tid : gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + nlo + tid;
             double seen = 0.0;
@@ -950,11 +960,13 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                 }
             }
         }
-        __syncthreads();
-        if (s_abort) { if (tid == 0) raise_abort(); status = 2; break; }
-        if (tid == 0) { if (MR) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-        if (k < 0) xcd_local = (a.pcg_xcd_local & 1) && !s_foreign;
-        __syncthreads();
+        if (!TM) {
+            __syncthreads();
+            if (s_abort) { if (tid == 0) raise_abort(); status = 2; break; }
+            if (tid == 0) { if (MR) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+            if (k < 0) xcd_local = (a.pcg_xcd_local & 1) && !s_foreign;
+            __syncthreads();
+        }
         SOLVE_STAMP(1);
         if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 1536 + lb] = (double)wall_clock64();      // ... neighbours' tags of pass 9 seen
         // ---- B: n = A m (k = -1: w_0 = A u_0): 18 four-byte gathers per row in two batches of 9, software-pipelined across the rows of the thread
@@ -969,7 +981,8 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                 const int jj = j0 + j; const int pk = (int)cp[u][jj >> 1];
                 constexpr unsigned kInPlane = (1u << 0) | (1u << 1) | (1u << 2) | (1u << 3) | (1u << 6) | (1u << 7) | (1u << 12) | (1u << 13);      // columns without a z offset (q_offset: q = jj + 1)
                 if ((abl & 4) && ((kInPlane >> jj) & 1u)) { ob[t % kCgpDepth][j] = 0.0; continue; }      // ablation 4: the in-plane columns are not gathered at all
-                ob[t % kCgpDepth][j] = rin[row[u] + ((abl & 1) ? 0 : ((jj & 1) ? (pk >> 16) : ((pk << 16) >> 16)))];
+                const double* src = rin + (row[u] + ((abl & 1) ? 0 : ((jj & 1) ? (pk >> 16) : ((pk << 16) >> 16))));
+                ob[t % kCgpDepth][j] = TM ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
             }
         };
         // The sums of pass k were published when m_k was: by the time the last gather batch is on its way they have normally arrived, but FETCHING
@@ -993,6 +1006,22 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
             const int u = t >> 1, j0 = (t & 1) * 9;
             const float* hrow = hs + (size_t)u * kNQ * kSolveThreads + tid;
             if (!(t & 1)) { const double mine = (double)inv[u] * (k >= 0 ? w[u] : r[u]); acc = (double)hrow[0] * mine; }      // (the row's own m: what it published)
+            if (TM) {      // a value that is not this pass's yet: ask again (the producer is at most one hand-off behind)
+                const unsigned wantm = mepoch | want;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    if (m_tag_of(ob[t % kCgpDepth][j]) == wantm) continue;
+                    const int jj = j0 + j; const int pk = (int)cp[u][jj >> 1];
+                    const double* src = rin + (row[u] + ((jj & 1) ? (pk >> 16) : ((pk << 16) >> 16)));
+                    int spins = 0; double vv;
+                    do {
+                        __builtin_amdgcn_s_sleep(1);
+                        vv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (++spins > kLocalSpins || ((spins & 255) == 0 && __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0)) { s_abort = 1; break; }
+                    } while (m_tag_of(vv) != wantm);
+                    ob[t % kCgpDepth][j] = vv;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 9; ++j) acc += (double)hrow[(j0 + j + 1) * kSolveThreads] * ob[t % kCgpDepth][j];
             asm volatile("" : "+v"(acc));
@@ -1096,17 +1125,21 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                 double* dst = recd[(k + 1) & 1] + row[u];
                 // readers on this XCD hit the line in its L2 if it is DIRTY there (a plain store: the per-pass acquire only drops clean lines); readers
                 // on another XCD need it in memory (write-through store).  A workgroup with neighbours on both sides does both.
-                if (!xcd_local) store8_sc1(dst, mnext);
-                *dst = mnext;
-                push_record((k + 1) & 1, row[u] - a.row0, mnext);
+                if (TM) __hip_atomic_store(dst, m_tag(mnext, mepoch | ((unsigned)(k + 2) & 3u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else {
+                    if (!xcd_local) store8_sc1(dst, mnext);
+                    *dst = mnext;
+                    push_record((k + 1) & 1, row[u] - a.row0, mnext);
+                }
             }
         }
         SOLVE_STAMP(4);
         // ---- E: publish: m has to be out (drained) before the tagged sums
         double t0, t1; wave_sum8(s, t0, t1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!TM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
         __syncthreads();
+        if (TM && s_abort) { if (tid == 0) raise_abort(); status = 2; break; }      // (a gather of this pass gave up)
         SOLVE_STAMP(5);
         if (tid < kCgpSums) {
             double tot = 0;
@@ -1170,19 +1203,19 @@ template <int R, bool ASM, bool MR> static int cgf_solve_prepare() {      // > 6
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cgf_solve<R, ASM, MR>, kSolveThreads, cgf_solve_lds(R)) == hipSuccess) per_cu = n;
     return per_cu;
 }
-template <int R, bool MR> static int cgp_solve_prepare() {
+template <int R, bool MR, bool TM = false> static int cgp_solve_prepare() {
     static int per_cu = -1;
     if (per_cu >= 0) return per_cu;
     per_cu = 0;
-    if (hipFuncSetAttribute((const void*)k_cgp_solve<R, MR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cgp_solve_lds(R)) != hipSuccess) return per_cu;
+    if (hipFuncSetAttribute((const void*)k_cgp_solve<R, MR, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cgp_solve_lds(R)) != hipSuccess) return per_cu;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cgp_solve<R, MR>, kSolveThreads, cgp_solve_lds(R)) == hipSuccess) per_cu = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_cgp_solve<R, MR, TM>, kSolveThreads, cgp_solve_lds(R)) == hipSuccess) per_cu = n;
     return per_cu;
 }
 template <int R> static int cgf_solve_prepare_both() {
     const int classic = std::min(std::min(cgf_solve_prepare<R, false, false>(), cgf_solve_prepare<R, true, false>()), cgf_solve_prepare<R, true, true>());
     if (R > kCgpMaxRows) return classic;
-    return std::min(classic, std::min(cgp_solve_prepare<R, false>(), cgp_solve_prepare<R, true>()));
+    return std::min(classic, std::min(std::min(cgp_solve_prepare<R, false>(), cgp_solve_prepare<R, false, true>()), cgp_solve_prepare<R, true>()));
 }
 int cgf_solve_max_blocks(int rows) {
     return rows == 1 ? cgf_solve_prepare_both<1>() : rows == 2 ? cgf_solve_prepare_both<2>() : rows == 3 ? cgf_solve_prepare_both<3>() : cgf_solve_prepare_both<4>();
@@ -1192,6 +1225,7 @@ static void launch_cgf_solve_r(const SweepArgs& a, double* fs, double* gran, int
     XrArgs none{};
     if (a.pcg_asm && a.pcg_pipe && R <= kCgpMaxRows) {      // the pipelined recurrences (always with the fused assembly)
         if (xr && xr->n_ranks > 1) hipLaunchKernelGGL((k_cgp_solve<R, true>), dim3(G), dim3(kSolveThreads), cgp_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, *xr);
+        else if (a.pcg_pipe == 2) { hipLaunchKernelGGL((k_cgp_solve<R, false, true>), dim3(G), dim3(kSolveThreads), cgp_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, none); }      // self-validating m (PSGSDF_PCG_TAGM)
         else hipLaunchKernelGGL((k_cgp_solve<R, false>), dim3(G), dim3(kSolveThreads), cgp_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, none);
         return;
     }

@@ -29,6 +29,7 @@ VARIANTS = {
     "poll0": {"PSGSDF_PCG_POLL": "0"},
     "persist0": {"PSGSDF_PCG_PERSIST": "0"},     # per-pass kernels: the CLASSIC recurrences (family "classic": bit-identical among themselves, rounding-level apart from the pipelined default)
     "pipeline0": {"PSGSDF_PCG_PIPELINE": "0"},   # persistent kernel with the classic recurrences (same family as persist0)
+    "tagm0": {"PSGSDF_PCG_TAGM": "0"},           # pipelined solve without the self-validating exchanged values (round 4's hand-off: tags, acquire, drain) -- family "untagged": 2^-48 of the exchanged values apart
     "prefetch0": {"PSGSDF_PCG_PREFETCH": "0"},   # pipelined solve: sums requested after the last gather batch
     "fmsolve0": {"PSGSDF_FM_SOLVE": "0"},        # light / pose solves as kernels of their own
     "fmsolve2": {"PSGSDF_FM_SOLVE": "2"},        # ... only the LED light vector
@@ -40,7 +41,7 @@ VARIANTS = {
     "nocheck": {"PSGSDF_MBOX_CHECK": "0", "PSGSDF_USE_DEV_LIB": "1"},      # read-backs taken on the marker's say-so (round 2): expected to deviate now and then
 }
 KNOB_NAMES = sorted({k for v in VARIANTS.values() for k in v})
-FAMILY = {"persist0": "classic", "pipeline0": "classic"}      # which distance-solve recurrences a variant runs (default: pipelined)
+FAMILY = {"persist0": "classic", "pipeline0": "classic", "tagm0": "untagged"}      # which distance-solve recurrences a variant runs (default: pipelined)
 
 
 def _hash(a):
