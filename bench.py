@@ -622,7 +622,7 @@ def main():
                            "traffic_source": traffic_src}
         if dom == "pcg_solve":
             # SURVEY 8d prices this kernel against HBM (`bound`, `frac` above: the contract's figure), but HBM is not what bounds it: the matrix lives in LDS
-            # and the counters see 0.13 x the algorithmic bytes.  A pass is a chain of device-wide hand-offs (tag wait -> gathers of the neighbours' values
+            # and the counters see 0.13-0.24 x the algorithmic bytes.  A pass is a chain of device-wide hand-offs (tag wait -> gathers of the neighbours' values
             # -> publish); the floor below is that chain at its shortest, the decomposition next to it is measured in this run.
             sm = m.get("solve_model")
             passes = cg_iters + 2.0                                      # cg_iters + 1 passes, + the prologue's gather round w_0 = A u_0
@@ -630,7 +630,7 @@ def main():
             fixed_floor_us = 76.0 * S / (HBM_PEAK_GBS * 1e3) + 2.0       # the fused assembly + update stream 76 B per band voxel once; + the launch ramp
             floor_us = fixed_floor_us + passes * hand_off_us
             out["roofline"].update({
-                "bound_observed": "device-wide hand-off latency (per PCG pass: the neighbours' values back from beyond the L2 -- self-validating since round 5: no tag wait, acquire or drain in front of them -- two gather batches, the all-gather of the sums, across 256 workgroups; the matrix is LDS-resident, HBM traffic is 0.13 x the algorithmic bytes)",
+                "bound_observed": "device-wide hand-off latency (per PCG pass: the neighbours' values back from beyond the L2 -- self-validating since round 5: no tag wait, acquire or drain in front of them -- two gather batches, the all-gather of the sums, across 256 workgroups; the matrix is LDS-resident, HBM-side traffic is %s x the algorithmic bytes)" % (("%.2f" % out["roofline"]["traffic_over_algorithmic"]) if out["roofline"].get("traffic_over_algorithmic") else "a fraction of"),
                 "passes": passes, "us_per_pass": sm["us_per_pass"] if sm else None, "fixed_us": sm["fixed_us"] if sm else None,
                 "floor_model": {"formula": "fixed_floor + passes x hand_off", "hand_off_us": hand_off_us, "fixed_floor_us": fixed_floor_us, "floor_us": floor_us,
                                 "measured_us": 1e3 * avg_ms, "frac_of_floor": floor_us / (1e3 * avg_ms) if avg_ms == avg_ms else None,
