@@ -398,7 +398,7 @@ int psgsdf_debug_sync_stats(psgsdf_ctx* ctx, int64_t out[8]);
  * between equivalent execution strategies -- results agree to rounding, most bit for bit (tests/test_knobs_gpu.py) -- and none is needed in
  * normal operation.  psgsdf_get_tuning reports what was set and what it resolved to.
  *   PSGSDF_PCG_POLL, PSGSDF_SPECULATE, PSGSDF_SPECULATE_MR, PSGSDF_FOLD_IN_NEXT, PSGSDF_FUSE_ALBEDO, PSGSDF_FUSE_PCG_INIT        (0 / 1) host-side scheduling
- *   PSGSDF_PCG_PERSIST, PSGSDF_PCG_PIPELINE, PSGSDF_PCG_TAGM (0: the pipelined solve's exchanged values without their own tags -- round 4's hand-off), PSGSDF_PCG_PREFETCH, PSGSDF_PCG_FUSE_ASM, PSGSDF_PCG_FUSE_APPLY, PSGSDF_PCG_XCD_LOCAL,
+ *   PSGSDF_PCG_PERSIST, PSGSDF_PCG_PIPELINE, PSGSDF_PCG_TAGM (0: the pipelined solve's exchanged values without their own tags -- round 4's hand-off; 1: self-validating on one rank only; default 2: between ranks too), PSGSDF_PCG_PREFETCH, PSGSDF_PCG_FUSE_ASM, PSGSDF_PCG_FUSE_APPLY, PSGSDF_PCG_XCD_LOCAL,
  *   PSGSDF_PCG_COL16*, PSGSDF_PCG_ROWS*, PSGSDF_PCG_BLOCKS*                                                                        distance solve
  *   PSGSDF_FM_SOLVE, PSGSDF_FM_ROWS*, PSGSDF_IMG_COMPACT, PSGSDF_XCD_MAP, PSGSDF_XCD_STRIPE                                        sweeps
  *   PSGSDF_XR, PSGSDF_XF, PSGSDF_XS, PSGSDF_XH (0: that exchange through the communicator instead of IPC-mapped memory), PSGSDF_XR_MEM* (fine | uncached |

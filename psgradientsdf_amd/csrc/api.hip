@@ -58,7 +58,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_PCG_XCD_LOCAL")) c->pcg_xcd_local = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_FUSE_ASM")) c->pcg_fuse_asm = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_PIPELINE")) c->pcg_pipeline = atoi(e) != 0;
-    if (const char* e = getenv("PSGSDF_PCG_TAGM")) c->pcg_tagm = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_PCG_TAGM")) { c->pcg_tagm = atoi(e) != 0; c->pcg_tagm_mr = atoi(e) >= 2; }
     if (const char* e = getenv("PSGSDF_PCG_PREFETCH")) c->pcg_prefetch = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FM_SOLVE")) { c->fm_solve = atoi(e) != 0; c->fm_solve_led = atoi(e) == 1; }
     if (const char* e = getenv("PSGSDF_XF")) c->xf_enable = atoi(e) != 0;

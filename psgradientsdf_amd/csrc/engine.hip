@@ -43,7 +43,7 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.fold.n = 0; a.gate = nullptr; a.fuse_apply = 0;
     a.xcd_map = c->xcd_map; a.xf = nullptr; a.xf_epoch = 0; a.fm_led_light = nullptr; a.vm_order = c->vm_order;
     a.fm_solve = 0; a.fm_frames = nullptr; a.fm_undo = nullptr; a.fm_e_out = nullptr; a.fm_e_key = 0;
-    a.pcg_part = c->pcg_part; a.pcg_fs = c->pcg_sc; a.pcg_fuse_init = 0; a.pcg_init_blocks = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.pcg_asm = 0; a.pcg_epoch = 0; a.pcg_pipe = c->pcg_pipeline ? (c->pcg_tagm && c->n_ranks <= 1 ? 2 : 1) : 0; a.pcg_apply = 0; a.pcg_xcd_local = (c->pcg_xcd_local ? 1 : 0) | (c->pcg_prefetch ? 2 : 0) | (c->pcg_ablate << 3);
+    a.pcg_part = c->pcg_part; a.pcg_fs = c->pcg_sc; a.pcg_fuse_init = 0; a.pcg_init_blocks = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.pcg_asm = 0; a.pcg_epoch = 0; a.pcg_pipe = c->pcg_pipeline ? (c->pcg_tagm ? (c->n_ranks <= 1 ? 2 : (c->pcg_tagm_mr ? 3 : 1)) : 1) : 0; a.pcg_apply = 0; a.pcg_xcd_local = (c->pcg_xcd_local ? 1 : 0) | (c->pcg_prefetch ? 2 : 0) | (c->pcg_ablate << 3);
     a.ar = c->ar; a.ar.weight = c->reg_r;
     a.model = c->set.model; a.quirks = c->set.ref_quirks;
     a.reg_n = c->reg_n; a.reg_l = c->reg_l;

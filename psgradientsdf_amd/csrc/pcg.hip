@@ -910,7 +910,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
         x[u] = 0.0; z[u] = 0.0; sv[u] = 0.0; pv[u] = 0.0; w[u] = 0.0;
         if (live[u]) {
             const double u0 = (double)inv[u] * r[u];
-            if (TM) __hip_atomic_store(recd[1] + row[u], m_tag(u0, mepoch | 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (TM) { const double ut = m_tag(u0, mepoch | 0u); __hip_atomic_store(recd[1] + row[u], ut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); push_record(1, row[u] - a.row0, ut); }
             else { store8_sc1(recd[1] + row[u], u0); push_record(1, row[u] - a.row0, u0); }
         }
 #pragma unroll
@@ -918,7 +918,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) { __hip_atomic_store(gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + lb, (double)(1 + my_xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR) peer_tag(2, xr_tag(1.0, etag0 | 1u)); }
+    if (tid == 0) { __hip_atomic_store(gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + lb, (double)(1 + my_xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (MR && !TM) peer_tag(2, xr_tag(1.0, etag0 | 1u)); }
     float rhsNorm2 = 0.f, thr = 0.f, rr_cur = 0.f;
     double gamma_old = 0.0, alpha = 0.0;
     int k = -1, status = 1;                   // k = -1: the extra round w_0 = A u_0
@@ -948,7 +948,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
             }
             if (k < 0 && (int)seen != 1 + my_xcc) s_foreign = 1;
         }
-        if (MR) {
+        if (MR && !TM) {
             const int side = tid >= 128 ? 1 : 0, j = tid - (side ? 128 : 64);
             if (tid >= 64 && tid < 192 && j < (side ? xr.wait_hi : xr.wait_lo) && (side ? need_hi : need_lo)) {
                 int spins = 0;
@@ -1016,8 +1016,8 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                     int spins = 0; double vv;
                     do {
                         __builtin_amdgcn_s_sleep(1);
-                        vv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (++spins > kLocalSpins || ((spins & 255) == 0 && __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0)) { s_abort = 1; break; }
+                        vv = MR ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (a halo row is written by the neighbour RANK)
+                        if (++spins > kLocalSpins || ((spins & 255) == 0 && (__hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || (MR && __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0)))) { s_abort = 1; break; }
                     } while (m_tag_of(vv) != wantm);
                     ob[t % kCgpDepth][j] = vv;
                 }
@@ -1125,7 +1125,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                 double* dst = recd[(k + 1) & 1] + row[u];
                 // readers on this XCD hit the line in its L2 if it is DIRTY there (a plain store: the per-pass acquire only drops clean lines); readers
                 // on another XCD need it in memory (write-through store).  A workgroup with neighbours on both sides does both.
-                if (TM) __hip_atomic_store(dst, m_tag(mnext, mepoch | ((unsigned)(k + 2) & 3u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (TM) { const double mt = m_tag(mnext, mepoch | ((unsigned)(k + 2) & 3u)); __hip_atomic_store(dst, mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); push_record((k + 1) & 1, row[u] - a.row0, mt); }
                 else {
                     if (!xcd_local) store8_sc1(dst, mnext);
                     *dst = mnext;
@@ -1147,7 +1147,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
             double* gq = gran + (size_t)((k + 1) & 1) * kSolveGranPlanes * kSolveMaxBlocks + (size_t)tid * kSolveMaxBlocks + lb;
             __hip_atomic_store(gq, gran_tag(tot, (unsigned)(k + 2) & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (MR && tid == 64) peer_tag((k + 1) & 1, xr_tag(1.0, etag0 | ((unsigned)(k + 2) & 3u)));
+        if (MR && !TM && tid == 64) peer_tag((k + 1) & 1, xr_tag(1.0, etag0 | ((unsigned)(k + 2) & 3u)));
         __syncthreads();
         SOLVE_STAMP(6);
         if (force_passes > 0 && k == 8 && tid == 0) fs[16 + lb] = (double)wall_clock64();      // ... published at the end of pass 8 (m_9 and the sums of pass 9)
@@ -1215,7 +1215,7 @@ template <int R, bool MR, bool TM = false> static int cgp_solve_prepare() {
 template <int R> static int cgf_solve_prepare_both() {
     const int classic = std::min(std::min(cgf_solve_prepare<R, false, false>(), cgf_solve_prepare<R, true, false>()), cgf_solve_prepare<R, true, true>());
     if (R > kCgpMaxRows) return classic;
-    return std::min(classic, std::min(std::min(cgp_solve_prepare<R, false>(), cgp_solve_prepare<R, false, true>()), cgp_solve_prepare<R, true>()));
+    return std::min(classic, std::min(std::min(cgp_solve_prepare<R, false>(), cgp_solve_prepare<R, false, true>()), std::min(cgp_solve_prepare<R, true>(), cgp_solve_prepare<R, true, true>())));
 }
 int cgf_solve_max_blocks(int rows) {
     return rows == 1 ? cgf_solve_prepare_both<1>() : rows == 2 ? cgf_solve_prepare_both<2>() : rows == 3 ? cgf_solve_prepare_both<3>() : cgf_solve_prepare_both<4>();
@@ -1224,8 +1224,9 @@ template <int R>
 static void launch_cgf_solve_r(const SweepArgs& a, double* fs, double* gran, int G, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, hipStream_t s, const XrArgs* xr) {
     XrArgs none{};
     if (a.pcg_asm && a.pcg_pipe && R <= kCgpMaxRows) {      // the pipelined recurrences (always with the fused assembly)
-        if (xr && xr->n_ranks > 1) hipLaunchKernelGGL((k_cgp_solve<R, true>), dim3(G), dim3(kSolveThreads), cgp_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, *xr);
-        else if (a.pcg_pipe == 2) { hipLaunchKernelGGL((k_cgp_solve<R, false, true>), dim3(G), dim3(kSolveThreads), cgp_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, none); }      // self-validating m (PSGSDF_PCG_TAGM)
+        if (xr && xr->n_ranks > 1 && a.pcg_pipe == 3) hipLaunchKernelGGL((k_cgp_solve<R, true, true>), dim3(G), dim3(kSolveThreads), cgp_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, *xr);      // ... across ranks too (PSGSDF_PCG_TAGM=2)
+        else if (xr && xr->n_ranks > 1) hipLaunchKernelGGL((k_cgp_solve<R, true>), dim3(G), dim3(kSolveThreads), cgp_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, *xr);
+        else if (a.pcg_pipe >= 2) { hipLaunchKernelGGL((k_cgp_solve<R, false, true>), dim3(G), dim3(kSolveThreads), cgp_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, none); }      // self-validating m (PSGSDF_PCG_TAGM)
         else hipLaunchKernelGGL((k_cgp_solve<R, false>), dim3(G), dim3(kSolveThreads), cgp_solve_lds(R), s, a, fs, gran, rows_per_wg, kmax, mb, mb_key, force_passes, none);
         return;
     }
