@@ -71,6 +71,11 @@ def test_distance_step_fusions_are_bitwise_neutral(built, model):
     for env in ({"PSGSDF_PCG_FUSE_APPLY": "0"}, {"PSGSDF_PCG_XCD_LOCAL": "0"}, {"PSGSDF_PCG_PREFETCH": "0"}):
         got = run(model, env, full=True)
         assert got == ref, (env, got, ref)
+    # round 5: the exchanged values carry their own tags in four mantissa bits (2^-48) instead of being ordered behind flags -- same pass counts, the rest to rounding
+    untagged = run(model, {"PSGSDF_PCG_TAGM": "0"}, full=True)
+    assert untagged["cg"] == ref["cg"] and untagged["n2"] == ref["n2"], (untagged["cg"], ref["cg"])
+    assert all(abs(a - b) <= 1e-7 * abs(b) for a, b in zip(untagged["e"] + untagged["e2"], ref["e"] + ref["e2"])), (untagged["e"], ref["e"])
+    assert abs(untagged["dsum"] - ref["dsum"]) <= 1e-7 * ref["dsum"] and abs(untagged["psum"] - ref["psum"]) <= 1e-7 * ref["psum"]
     classic = run(model, {"PSGSDF_PCG_PIPELINE": "0"}, full=True)
     for env in ({"PSGSDF_PCG_FUSE_ASM": "0"}, {"PSGSDF_PCG_PERSIST": "0"}, {"PSGSDF_PCG_PIPELINE": "0", "PSGSDF_PCG_XCD_LOCAL": "0"}):
         got = run(model, env, full=True)
