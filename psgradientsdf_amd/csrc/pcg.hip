@@ -1012,6 +1012,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                 for (int j = 0; j < 9; ++j) {
                     if (m_tag_of(ob[t % kCgpDepth][j]) == wantm) continue;
                     const int jj = j0 + j; const int pk = (int)cp[u][jj >> 1];
+                    if ((abl & 4) && ((0x30cfu >> jj) & 1u)) continue;      // (timing ablation 4: this column was not gathered)
                     const double* src = rin + (row[u] + ((jj & 1) ? (pk >> 16) : ((pk << 16) >> 16)));
                     int spins = 0; double vv;
                     do {
