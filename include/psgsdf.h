@@ -251,6 +251,23 @@ int psgsdf_download_poses(psgsdf_ctx* ctx, float* poses);
 int psgsdf_download_light(psgsdf_ctx* ctx, float* light);
 int psgsdf_upload_light(psgsdf_ctx* ctx, const float* light);
 
+/* ---- the solver of the light and pose blocks ---------------------------------------------- */
+
+/* optimizeLightAll / optimizePosesAll (PsOptimizer.cpp:175-203,207-234, LedOptimizer.cpp:134-160,245-275) hand the block-diagonal normal equations of
+ * ALL frames to ONE Eigen::ConjugateGradient<SparseMatrix<float>> (Jacobi preconditioner, tolerance eps_f32, <= 2n passes); the LED pose update is
+ * applied only when info() == Success.
+ *   mode 0 (default): every frame's block solved directly, LDL^T in double, inside the sweep that summed it (no launch) -- the
+ *           exact step of each block; it differs from the reference's by what a float CG leaves undetermined, cond(block) x eps_f32 of the step
+ *           (SH1 / LED / pose: 1e-7 relative; SH2's 9 x 9 light blocks, cond ~2e4: 1e-3);
+ *   mode 1: the reference's solver itself (csrc/frame_solve.hip: one workgroup, the same float recurrences, stop rule and info() semantics as Eigen's
+ *           conjugate_gradient) in a kernel of its own behind the sweep: +5-25 % per iteration.
+ * Also PSGSDF_FRAME_SOLVE=eigen|ldlt when the context is created.  Mode 1 holds at most 2048 unknowns (227 keyframes with SH2). */
+int psgsdf_set_frame_solver(psgsdf_ctx* ctx, int mode);
+/* What the last mode-1 solve of `block` (PSGSDF_LIGHT / PSGSDF_POSE) reported: Eigen's iterations(), error(), info() == Success, and whether the
+ * update was applied (the LED pose gate).  Synchronises the context's stream.  Any pointer may be NULL.  psgsdf_step fills the same numbers into
+ * its psgsdf_step_stats. */
+int psgsdf_get_frame_solver_stats(psgsdf_ctx* ctx, int block, int32_t* iterations, double* error, int32_t* converged, int32_t* applied);
+
 /* ---- the writers' geometry, extracted on the device ---------------------- */
 
 /* What the reference writes every third iteration (PsOptimizer.cpp:419-423) is computed from the dense state: a mesh by marching cubes and a point
@@ -346,12 +363,17 @@ int psgsdf_mg_info(psgsdf_ctx* ctx, int32_t out[12]);
 int psgsdf_comm_stats(psgsdf_ctx* ctx, int64_t* n_collectives);
 
 /* ---- measurement / test hooks (not part of the reference seam) -------------------------- */
-/* the FALS estimator's per-resolution cache (NormalEstimator::cache, NormalEstimator.h:52-125) as the device computed it: 9 planes of width * height floats
- * (ray / (1 + x0^2 + y0^2): 3, the inverse of the box-filtered 3x3 matrix: 6) */
 /* timing probe (profiles/r05_notes.md section 5): out[4] = ms of { distance sweep alone, distance solve alone, the two back to back, the solve started on a
  * second stream together with the sweep } -- the upper bound of what starting the solve under the sweep's tail could hide */
 int psgsdf_debug_overlap_probe(psgsdf_ctx* ctx, int reps, double* out);
+/* the FALS estimator's per-resolution cache (NormalEstimator::cache, NormalEstimator.h:52-125) as the device computed it: 9 planes of width * height floats
+ * (ray / (1 + x0^2 + y0^2): 3, the inverse of the box-filtered 3x3 matrix: 6) */
 int psgsdf_debug_normals_cache(psgsdf_ctx* ctx, int width, int height, float* cache9);
+/* the mode-1 frame solver alone (known-answer tests): Eigen's conjugate_gradient with the Jacobi preconditioner on a caller-supplied block-diagonal
+ * system of n_blocks blocks of n x n floats (row-major, used as given; n in {3, 4, 6, 9}, n_blocks * n <= 2048), right-hand side b, at most max_it
+ * passes (<= 0: Eigen's default 2 * n_blocks * n).  x: n_blocks * n floats out. */
+int psgsdf_debug_frame_cg(psgsdf_ctx* ctx, int n_blocks, int n, const float* H, const float* b, float* x, int max_it,
+                          int32_t* iterations, double* error, int32_t* converged);
 
 /* last measured kernel durations in ms keyed by name; names[i] are static strings.
  * Returns the number of entries written (<= cap). */
@@ -400,6 +422,7 @@ int psgsdf_debug_sync_stats(psgsdf_ctx* ctx, int64_t out[8]);
  *   PSGSDF_PCG_POLL, PSGSDF_SPECULATE, PSGSDF_SPECULATE_MR, PSGSDF_FOLD_IN_NEXT, PSGSDF_FUSE_ALBEDO, PSGSDF_FUSE_PCG_INIT        (0 / 1) host-side scheduling
  *   PSGSDF_PCG_PERSIST, PSGSDF_PCG_PIPELINE, PSGSDF_PCG_TAGM (0: the pipelined solve's exchanged values without their own tags -- round 4's hand-off; 1: self-validating on one rank only; default 2: between ranks too), PSGSDF_PCG_PREFETCH, PSGSDF_PCG_FUSE_ASM, PSGSDF_PCG_FUSE_APPLY, PSGSDF_PCG_XCD_LOCAL,
  *   PSGSDF_PCG_COL16*, PSGSDF_PCG_ROWS*, PSGSDF_PCG_BLOCKS*                                                                        distance solve
+ *   PSGSDF_FRAME_SOLVE (ldlt | eigen: psgsdf_set_frame_solver; the ONE knob that changes results beyond rounding),
  *   PSGSDF_FM_SOLVE, PSGSDF_FM_ROWS*, PSGSDF_IMG_COMPACT, PSGSDF_XCD_MAP, PSGSDF_XCD_STRIPE                                        sweeps
  *   PSGSDF_XR, PSGSDF_XF, PSGSDF_XS, PSGSDF_XH (0: that exchange through the communicator instead of IPC-mapped memory), PSGSDF_XR_MEM* (fine | uncached |
  *   coarse), PSGSDF_XWAIT_LOG2 (log2 of the polls an in-kernel wait for another rank may take), PSGSDF_CU_MASK (lo:hi)              multi-rank

@@ -87,6 +87,7 @@ typedef struct orc_ctx {
     float *cg_x, *cg_r, *cg_t, *cg_p, *cg_inv; double* cg_sc;
     void* mg_sys; /* dist_sys* of the current solve */
     int solver_mode; /* 0 = direct per-block solves, 1 = Eigen-style global Jacobi-PCG */
+    int fs_iters[2], fs_ok[2], fs_applied[2]; double fs_err[2]; /* the last light [0] / pose [1] solve: Eigen's iterations(), info() == Success, update applied, error() */
     int faithful;    /* 1 = band membership as the reference does it: std::find over surface_points_ (Optimizer.cpp:470), O(S) per look-up */
     long long n_find; /* look-ups made through band_find (both modes) */
     int threads;
@@ -755,6 +756,7 @@ static int light_finish(orc_ctx* c, double* H, double* b, double e_in, long long
     cg_result cr = solve_blockdiag(c, nb, n, Hf, bf, x);
     if (led) for (int ch = 0; ch < 3; ++ch) c->light[ch] -= x[ch]; /* LedOptimizer.cpp:159 */
     else for (int f = 0; f < c->F; ++f) for (int i = 0; i < n; ++i) c->light[(size_t)f * MAXB + i] -= x[f * n + i]; /* PsOptimizer.cpp:199-201 */
+    c->fs_iters[0] = cr.iters; c->fs_ok[0] = cr.success; c->fs_applied[0] = 1; c->fs_err[0] = cr.error;
     if (st) { st->block = PSGSDF_LIGHT; st->cg_iters = cr.iters; st->cg_converged = cr.success; st->applied = 1; st->e_in = e_in; st->cg_error = cr.error; st->n_accepted = nb; st->n_obs = nobs; }
     free(H); free(b); free(Hf); free(bf); free(x);
     return 0;
@@ -855,6 +857,7 @@ static int pose_finish(orc_ctx* c, double* H, double* b, double e_in, long long 
             for (int k = 0; k < 3; ++k) P[i * 4 + k] = (R[i * 3 + 0] * E3[0 * 3 + k] + R[i * 3 + 1] * E3[1 * 3 + k]) + R[i * 3 + 2] * E3[2 * 3 + k];
         }
     }
+    c->fs_iters[1] = cr.iters; c->fs_ok[1] = cr.success; c->fs_applied[1] = apply; c->fs_err[1] = cr.error;
     if (st) { st->block = PSGSDF_POSE; st->cg_iters = cr.iters; st->cg_converged = cr.success; st->applied = apply; st->e_in = e_in; st->cg_error = cr.error; st->n_accepted = apply ? nb : 0; st->n_obs = nobs; }
     free(H); free(b); free(Hf); free(bf); free(x);
     return 0;
@@ -1430,6 +1433,25 @@ void orc_destroy(orc_ctx* c) {
 const char* orc_last_error(const orc_ctx* c) { return c ? c->err : "null context"; }
 const char* orc_version(void) { return "psgsdf-oracle cpu (test infrastructure)"; }
 int orc_set_solver_mode(orc_ctx* c, int mode) { c->solver_mode = mode; return 0; }
+/* the engine's name for the same switch (include/psgsdf.h psgsdf_set_frame_solver): 1 = the reference's global Eigen CG over all frames' blocks */
+int orc_set_frame_solver(orc_ctx* c, int mode) { if (mode != 0 && mode != 1) return PSGSDF_ERR_ARG; c->solver_mode = mode; return 0; }
+int orc_get_frame_solver_stats(orc_ctx* c, int block, int32_t* iterations, double* error, int32_t* converged, int32_t* applied) {
+    if (!c || (block != PSGSDF_LIGHT && block != PSGSDF_POSE)) return PSGSDF_ERR_ARG;
+    const int k = block == PSGSDF_POSE;
+    if (iterations) *iterations = c->fs_iters[k]; if (error) *error = c->fs_err[k]; if (converged) *converged = c->fs_ok[k]; if (applied) *applied = c->fs_applied[k];
+    return 0;
+}
+/* eigen_cg on a block-diagonal system of nb blocks of n x n floats (the engine's psgsdf_debug_frame_cg) */
+int orc_debug_frame_cg(orc_ctx* c, int nb, int n, const float* H, const float* b, float* x, int max_it, int* iters, double* err, int* ok) {
+    (void)c;
+    blockdiag B = {nb, n, H};
+    float* diag = (float*)malloc(sizeof(float) * nb * n);
+    for (int k = 0; k < nb; ++k) for (int i = 0; i < n; ++i) diag[k * n + i] = H[(size_t)k * n * n + i * n + i];
+    cg_result r = eigen_cg(nb * n, blockdiag_mv, &B, diag, b, x, max_it);
+    free(diag);
+    if (iters) *iters = r.iters; if (err) *err = r.error; if (ok) *ok = r.success;
+    return 0;
+}
 /* 1: every band-membership test is the reference's std::find over the band list (SURVEY 8d(i) "faithful mode"; same results, O(S) per test) */
 int orc_set_faithful(orc_ctx* c, int on) { c->faithful = on; return 0; }
 int orc_set_threads(orc_ctx* c, int n) { c->threads = n > 0 ? n : 1; return 0; }

@@ -497,6 +497,25 @@ class Api:
         self._check(self._fn("debug_frame_system")(self.ctx, C.c_int(block), H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)), "debug_frame_system")
         return H, b
 
+    def set_frame_solver(self, mode):
+        """0 = every frame's light / pose block solved directly (LDL^T in double; the engine's default), 1 = the reference's solver: ONE Eigen-style float
+        Jacobi-PCG over the block-diagonal system of all frames (include/psgsdf.h psgsdf_set_frame_solver; the oracle: orc_set_frame_solver = its solver_mode)"""
+        self._check(self._fn("set_frame_solver")(self.ctx, C.c_int(mode)), "set_frame_solver")
+
+    def frame_solver_stats(self, block):
+        it = C.c_int32(); err = C.c_double(); ok = C.c_int32(); ap = C.c_int32()
+        self._check(self._fn("get_frame_solver_stats")(self.ctx, C.c_int(block), C.byref(it), C.byref(err), C.byref(ok), C.byref(ap)), "get_frame_solver_stats")
+        return {"cg_iters": it.value, "cg_error": err.value, "cg_converged": ok.value, "applied": ap.value}
+
+    def debug_frame_cg(self, H, b, max_it=0):
+        """the mode-1 frame solver alone on the block-diagonal system H [nb][n][n], b [nb][n] -> (x [nb][n], iterations, error, converged)"""
+        H = np.ascontiguousarray(H, np.float32); b = np.ascontiguousarray(b, np.float32)
+        nb, n = b.shape
+        x = np.empty((nb, n), np.float32); it = C.c_int32(); err = C.c_double(); ok = C.c_int32()
+        self._check(self._fn("debug_frame_cg")(self.ctx, C.c_int(nb), C.c_int(n), H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p),
+                                               C.c_int(max_it), C.byref(it), C.byref(err), C.byref(ok)), "debug_frame_cg")
+        return x, it.value, err.value, bool(ok.value)
+
     def debug_albedo_system(self):
         S = self.info().n_band
         H = np.empty((S, 3), np.float32); b = np.empty((S, 3), np.float32)

@@ -35,7 +35,7 @@ const char* psgsdf_version(void) { return "psgsdf-hip gfx950 r5"; }
 static const char* const kKnobs[] = {
     "PSGSDF_PCG_POLL", "PSGSDF_SPECULATE", "PSGSDF_FOLD_IN_NEXT", "PSGSDF_FUSE_ALBEDO", "PSGSDF_FUSE_PCG_INIT", "PSGSDF_PCG_PERSIST", "PSGSDF_PCG_XCD_LOCAL",
     "PSGSDF_PCG_FUSE_ASM", "PSGSDF_PCG_FUSE_APPLY", "PSGSDF_PCG_PIPELINE", "PSGSDF_PCG_TAGM", "PSGSDF_PCG_PREFETCH", "PSGSDF_PCG_COL16", "PSGSDF_PCG_ROWS", "PSGSDF_PCG_BLOCKS",
-    "PSGSDF_FM_SOLVE", "PSGSDF_FM_ROWS", "PSGSDF_IMG_COMPACT", "PSGSDF_XCD_MAP", "PSGSDF_XCD_STRIPE",
+    "PSGSDF_FM_SOLVE", "PSGSDF_FRAME_SOLVE", "PSGSDF_FM_ROWS", "PSGSDF_IMG_COMPACT", "PSGSDF_XCD_MAP", "PSGSDF_XCD_STRIPE",
     "PSGSDF_XR", "PSGSDF_XF", "PSGSDF_XS", "PSGSDF_XH", "PSGSDF_XR_MEM", "PSGSDF_XWAIT_LOG2", "PSGSDF_SPECULATE_MR", "PSGSDF_CU_MASK",
     "PSGSDF_WAIT_TIMEOUT_S", "PSGSDF_DESTROY_TIMEOUT_S", "PSGSDF_SOLVE_DUMP"};
 static const char* const kDevKnobs[] = {"PSGSDF_PCG_ABLATE", "PSGSDF_FAULT_SOLVE", "PSGSDF_FAULT_HALO", "PSGSDF_MBOX_CHECK"};
@@ -61,6 +61,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_PCG_TAGM")) { c->pcg_tagm = atoi(e) != 0; c->pcg_tagm_mr = atoi(e) >= 2; }
     if (const char* e = getenv("PSGSDF_PCG_PREFETCH")) c->pcg_prefetch = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FM_SOLVE")) { c->fm_solve = atoi(e) != 0; c->fm_solve_led = atoi(e) == 1; }
+    if (const char* e = getenv("PSGSDF_FRAME_SOLVE")) c->frame_solve = (!strcmp(e, "eigen") || !strcmp(e, "1")) ? 1 : 0;
     if (const char* e = getenv("PSGSDF_XF")) c->xf_enable = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XS")) c->xs_enable = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_XH")) c->xh_enable = atoi(e) != 0;
@@ -112,6 +113,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
         && hipMalloc(&c->d_need, 2 * sizeof(int)) == hipSuccess
         && hipMalloc(&c->d_total, sizeof(int)) == hipSuccess
         && hipMalloc(&c->led_light, sizeof(float) * 3) == hipSuccess
+        && hipMalloc(&c->fs_stats, sizeof(double) * 8) == hipSuccess && hipMemset(c->fs_stats, 0, sizeof(double) * 8) == hipSuccess
         && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
     if (!ok) { delete c; return PSGSDF_ERR_DEVICE; }
     *out = c;
@@ -131,7 +133,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
         fprintf(stderr, "psgsdf: rank %d: a peer did not close its mappings of this rank's exchange memory within %.0f s (failed or still running?): that memory is leaked, not freed\n", c->rank, qt);
     }
     free_dense(c);
-    hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->frames_undo); hipFree(c->led_light);
+    hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->frames_undo); hipFree(c->led_light); hipFree(c->fs_stats);
     hipFree(c->band_mem); if (!c->leak_exported) hipFree(c->rec_mem); hipFree(c->obs_mem); hipFree(c->stage);
     hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->frame_part); hipFree(c->frame_done); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->pcg_gran); hipFree(c->d_total);
     for (void* p : c->xo_host) if (p) hipHostFree(p);

@@ -173,6 +173,46 @@ int psgsdf_debug_rare_rows(psgsdf_ctx* c, int64_t* rows, int64_t* waves) {
     return PSGSDF_OK;
 }
 
+int psgsdf_set_frame_solver(psgsdf_ctx* c, int mode) {
+    if (!c) return PSGSDF_ERR_ARG;
+    if (mode != 0 && mode != 1) return fail(c, PSGSDF_ERR_ARG, "frame solver mode %d (0 = LDL^T per frame, 1 = the reference's global float Jacobi-PCG)", mode);
+    c->frame_solve = mode;
+    return PSGSDF_OK;
+}
+int psgsdf_get_frame_solver_stats(psgsdf_ctx* c, int block, int32_t* iterations, double* error, int32_t* converged, int32_t* applied) {
+    if (!c) return PSGSDF_ERR_ARG;
+    if (block != PSGSDF_LIGHT && block != PSGSDF_POSE) return fail(c, PSGSDF_ERR_ARG, "block must be LIGHT or POSE");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int kind = block == PSGSDF_POSE ? 1 : 0;
+    psgsdf_step_stats st; memset(&st, 0, sizeof(st));
+    if (int rc = read_frame_solver_stats(c, kind, &st)) return rc;
+    if (iterations) *iterations = st.cg_iters;
+    if (error) *error = st.cg_error;
+    if (converged) *converged = st.cg_converged;
+    if (applied) *applied = st.applied;
+    return PSGSDF_OK;
+}
+int psgsdf_debug_frame_cg(psgsdf_ctx* c, int nb, int n, const float* H, const float* b, float* x, int max_it, int32_t* iterations, double* error, int32_t* converged) {
+    if (!c || !H || !b || !x || nb <= 0) return fail(c, PSGSDF_ERR_ARG, "null argument");
+    if ((n != 3 && n != 4 && n != 6 && n != 9) || (long long)nb * n > 2048) return fail(c, PSGSDF_ERR_UNSUPPORTED, "block size %d x %d blocks", n, nb);
+    HIPCHK(c, hipSetDevice(c->device));
+    float *dH = nullptr, *db = nullptr, *dx = nullptr; double* ds = nullptr;
+    const size_t nH = (size_t)nb * n * n, nv = (size_t)nb * n;
+    int rc = PSGSDF_OK;
+    if (hipMalloc(&dH, sizeof(float) * nH) != hipSuccess || hipMalloc(&db, sizeof(float) * nv) != hipSuccess || hipMalloc(&dx, sizeof(float) * nv) != hipSuccess || hipMalloc(&ds, sizeof(double) * 4) != hipSuccess)
+        rc = fail(c, PSGSDF_ERR_DEVICE, "out of device memory");
+    double st[4] = {0, 0, 0, 0};
+    if (!rc && (hipMemcpy(dH, H, sizeof(float) * nH, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(db, b, sizeof(float) * nv, hipMemcpyHostToDevice) != hipSuccess)) rc = fail(c, PSGSDF_ERR_DEVICE, "upload failed");
+    if (!rc && launch_frames_eigen_raw(nb, n, dH, db, dx, ds, max_it, c->stream)) rc = fail(c, PSGSDF_ERR_UNSUPPORTED, "shape");
+    if (!rc && (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(x, dx, sizeof(float) * nv, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(st, ds, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(c, PSGSDF_ERR_DEVICE, "%s", hipGetErrorString(hipGetLastError()));
+    hipFree(dH); hipFree(db); hipFree(dx); hipFree(ds);
+    if (rc) return rc;
+    if (iterations) *iterations = (int32_t)st[0];
+    if (error) *error = st[1];
+    if (converged) *converged = (int32_t)st[2];
+    return PSGSDF_OK;
+}
 int psgsdf_debug_frame_system(psgsdf_ctx* c, int block, double* H, double* b) {
     if (!c || !c->inited || !H || !b) return fail(c, PSGSDF_ERR_STATE, "init first");
     HIPCHK(c, hipSetDevice(c->device));
@@ -239,10 +279,10 @@ int psgsdf_get_tuning(psgsdf_ctx* c, char* json, size_t cap) {
     o += "}, \"effective\": {";
     char buf[1024];
     snprintf(buf, sizeof(buf), "\"pcg_poll\": %d, \"speculate\": %d, \"speculate_mr\": %d, \"fold_in_next\": %d, \"fuse_albedo\": %d, \"fuse_pcg_init\": %d, \"pcg_persist\": %d, \"pcg_pipeline\": %d, \"pcg_tagm\": %d, "
-             "\"pcg_prefetch\": %d, \"pcg_fuse_asm\": %d, \"pcg_fuse_apply\": %d, \"pcg_xcd_local\": %d, \"fm_solve\": %d, \"fm_solve_led\": %d, \"img_compact\": %d, \"xcd_map\": %d, "
+             "\"pcg_prefetch\": %d, \"pcg_fuse_asm\": %d, \"pcg_fuse_apply\": %d, \"pcg_xcd_local\": %d, \"fm_solve\": %d, \"fm_solve_led\": %d, \"frame_solve\": \"%s\", \"img_compact\": %d, \"xcd_map\": %d, "
              "\"xr\": %d, \"xf\": %d, \"xs\": %d, \"xh\": %d, \"xr_mem_kind\": %d, \"xwait_log2\": %d, \"cu_mask\": [%d, %d], \"mbox_check\": %d, \"pcg_ablate\": %d, \"fault_solve\": %d, \"fault_halo\": %lld",
-             (int)c->pcg_poll, (int)c->speculate, (int)c->speculate_mr, (int)c->fold_in_next, (int)c->fuse_albedo, (int)c->fuse_pcg_init, (int)c->pcg_persist, (int)c->pcg_pipeline, (int)(c->pcg_tagm && c->n_ranks <= 1),
-             (int)c->pcg_prefetch, (int)c->pcg_fuse_asm, (int)c->pcg_fuse_apply, (int)c->pcg_xcd_local, (int)c->fm_solve, (int)c->fm_solve_led, (int)c->img_compact, c->xcd_map,
+             (int)c->pcg_poll, (int)c->speculate, (int)c->speculate_mr, (int)c->fold_in_next, (int)c->fuse_albedo, (int)c->fuse_pcg_init, (int)c->pcg_persist, (int)c->pcg_pipeline, (c->pcg_pipeline && c->pcg_tagm) ? (c->n_ranks > 1 ? (c->pcg_tagm_mr ? 2 : 0) : 1) : 0,
+             (int)c->pcg_prefetch, (int)c->pcg_fuse_asm, (int)c->pcg_fuse_apply, (int)c->pcg_xcd_local, (int)c->fm_solve, (int)c->fm_solve_led, c->frame_solve == 1 ? "eigen" : "ldlt", (int)c->img_compact, c->xcd_map,
              (int)c->xr_enable, (int)c->xf_enable, (int)c->xs_enable, (int)c->xh_enable, c->xr_mem_kind, (int)lround(log2((double)c->xwait_spins)), c->cu_mask_lo, c->cu_mask_hi,
              (int)c->mbox_check, c->pcg_ablate, c->fault_solve, c->fault_halo);
     o += buf; o += "}";

@@ -662,4 +662,36 @@ __device__ __forceinline__ int sym4(int a, int b) {   // index into the 10 upper
     return a * 4 - (a * (a - 1)) / 2 + (b - a);
 }
 
+// Sophus SO3::exp(w).matrix() (quaternion exponential + Eigen toRotationMatrix): OptimizerAux.cpp:103,193
+__device__ inline void so3_exp(const float* w, float* R) {
+    float theta_sq = dot3(w, w);
+    float imag, real;
+    if (theta_sq < 1e-10f) {
+        float theta_po4 = theta_sq * theta_sq;
+        imag = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_po4;
+        real = 1.0f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_po4;
+    } else {
+        float theta = sqrtf(theta_sq), half = 0.5f * theta;
+        imag = sinf(half) / theta; real = cosf(half);
+    }
+    float qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
+    float tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+// updatePose (OptimizerAux.cpp:190-205): t <- t - xi[0:3], R <- R exp(-xi[3:6]), on frame f's record
+__device__ inline void pose_update(FrameP* frames, int f, const float* xi) {
+    float R[9], t[3];
+    for (int i = 0; i < 9; ++i) R[i] = frames[f].R[i];
+    for (int i = 0; i < 3; ++i) t[i] = frames[f].t[i];
+    float mw[3] = {-xi[3], -xi[4], -xi[5]}, E3[9];
+    so3_exp(mw, E3);
+    for (int i = 0; i < 3; ++i) {
+        frames[f].t[i] = t[i] - xi[i];
+        for (int k = 0; k < 3; ++k) frames[f].R[i * 3 + k] = (R[i * 3 + 0] * E3[0 * 3 + k] + R[i * 3 + 1] * E3[1 * 3 + k]) + R[i * 3 + 2] * E3[2 * 3 + k];
+    }
+}
+
 }  // namespace psg

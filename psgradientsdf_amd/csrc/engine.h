@@ -237,6 +237,12 @@ int launch_sweep_pose(const SweepArgs& a, hipStream_t s);
 void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key, float* undo, hipStream_t s);
 void launch_restore_light(int F, FrameP* frames, float* led_light, const float* undo, hipStream_t s);   // undo of a speculative light update (undo: [F][9] + [3] floats)   // also sums the energy columns -> e_out (nullable; e_key: FoldReq)
 void launch_solve_pose(const SweepArgs& a, FrameP* frames, double* e_out, unsigned long long e_key, hipStream_t s);
+// the reference's own solver for the light / pose blocks (frame_solve.hip: ONE Eigen-style Jacobi-PCG over the block-diagonal system of all frames; PSGSDF_FRAME_SOLVE=eigen).
+// stats (nullable, device): {iterations, ||r|| / ||b||, info() == Success, update applied}
+bool frames_eigen_fits(int model, int F);
+void launch_frames_eigen_light(const SweepArgs& a, FrameP* frames, float* led_light, double* e_out, unsigned long long e_key, float* undo, double* stats, hipStream_t s);
+void launch_frames_eigen_pose(const SweepArgs& a, FrameP* frames, double* e_out, unsigned long long e_key, double* stats, hipStream_t s);
+int launch_frames_eigen_raw(int nb, int n, const float* H, const float* b, float* x, double* stats, int max_it, hipStream_t s);   // nb blocks of n x n floats, n in {3, 4, 6, 9}; -1: unsupported shape
 void launch_sweep_dist(const SweepArgs& a, hipStream_t s);
 void launch_assemble(const SweepArgs& a, hipStream_t s);
 void launch_cgf_init(const SweepArgs& a, double* fs, double* part, int G, hipStream_t s);

@@ -176,6 +176,9 @@ struct psgsdf_ctx {
     bool fm_solve = true;                // PSGSDF_FM_SOLVE=0: k_solve_light / k_solve_pose as kernels of their own behind the frame-major sweeps
     bool fm_solve_led = true;            // ... also the LED light vector (by the sweep's very last workgroup); PSGSDF_FM_SOLVE=2 keeps k_solve_light for it
     bool fm_solved = false;              // the sweep just launched solves its frames itself (step_begin -> step_finish)
+    int frame_solve = 0;                 // PSGSDF_FRAME_SOLVE / psgsdf_set_frame_solver: 0 = LDL^T per frame in double (default), 1 = the reference's solver: ONE Eigen-style float Jacobi-PCG over the block-diagonal system of all frames (frame_solve.hip)
+    double* fs_stats = nullptr;          // device [2][4]: {iterations, ||r||/||b||, Success, applied} of the last eigen light / pose solve
+    double fs_last[2][4] = {{0, 0, 1, 1}, {0, 0, 1, 1}};   // host copy, refreshed by the synchronous steps (psgsdf_step, psgsdf_get_frame_solver_stats)
     bool albedo_applied = false;         // the last albedo sweep already applied its update (step_begin -> step_finish)
     unsigned* img8 = nullptr; float img_scale = 0.f;   // keyframes uploaded as 8-bit RGB (psgsdf_set_keyframes_u8): RGBA8 words, c->img stays null
     double* frame_e_slot = nullptr; unsigned long long frame_e_key = 0;   // mailbox slot (and its key) the next per-frame solve writes its sweep's energy sums to
@@ -291,6 +294,7 @@ int albedo_reg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* ok_
 int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, std::function<void(double, double)> deferred_consumer = nullptr, bool may_apply = true);
 int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, bool defer_reg_sums = false);
 int do_step(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st);
+int read_frame_solver_stats(psgsdf_ctx* c, int kind, psgsdf_step_stats* st);   // kind 0 light, 1 pose; synchronises the stream
 int run_loop(psgsdf_ctx* c, int flags, LoopState& L, int max_iters, bool full, psgsdf_iter_stats* stats, int stats_cap, int* n_done, int* result,
              psgsdf_iter_cb on_iter, void* user);
 int do_upsample(psgsdf_ctx* c);

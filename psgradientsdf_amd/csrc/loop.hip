@@ -296,7 +296,7 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
             // cross-rank persistent solve is set up), so the same epilogue serves -- no RCCL all-reduce of the rows, no solve launch.  A one-rank
             // communicator has nothing to exchange.  (An empty slab still has to deliver its -- zero -- rows: it keeps the all-reduce path, on every rank.)
             const bool xf = c->n_ranks > 1 && c->xf_enable && c->xr_ready && c->xf_table && !c->any_empty_slab;
-            const bool fuse = deferred_consumer && c->fm_solve && (!slab_mode(c) || c->n_ranks == 1 || xf) && !c->profiling && (block == PSGSDF_POSE || !led || c->fm_solve_led) && c->row1 > c->row0 && c->band.obs_max > 0;
+            const bool fuse = deferred_consumer && c->fm_solve && c->frame_solve == 0 && (!slab_mode(c) || c->n_ranks == 1 || xf) && !c->profiling && (block == PSGSDF_POSE || !led || c->fm_solve_led) && c->row1 > c->row0 && c->band.obs_max > 0;
             double* fm_slot = nullptr; unsigned long long fm_key = 0;
             if (fuse) {      // (the mailbox slot first: reserving may flush, and a flush must not find the pending fold already handed to `a`)
                 if ((rc = reserve_frame_energy_deferred(c, xf ? std::function<void(double, double)>([c, deferred_consumer](double e, double n) { if (std::isnan(e)) c->xf_timeout = true; deferred_consumer(e, n); }) : deferred_consumer, &fm_slot, &fm_key))) return rc;
@@ -332,6 +332,13 @@ int step_begin(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* s
     st->n_obs = (int64_t)nobs;
     return 0;
 }
+// the eigen frame solve's {iterations, error, Success, applied} (synchronous: psgsdf_step and the debug paths only -- the alternation loop never waits for them)
+int read_frame_solver_stats(psgsdf_ctx* c, int kind, psgsdf_step_stats* st) {
+    HIPCHK(c, hipMemcpyAsync(c->fs_last[kind], c->fs_stats + 4 * kind, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (st) { st->cg_iters = (int)c->fs_last[kind][0]; st->cg_error = c->fs_last[kind][1]; st->cg_converged = (int)c->fs_last[kind][2]; st->applied = (int)c->fs_last[kind][3]; }
+    return 0;
+}
 int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* st, bool defer_reg_sums) {
     SweepArgs a = make_args(c, laplacian_reg);
     const bool led = c->set.model == PSGSDF_LED;
@@ -360,16 +367,26 @@ int step_finish(psgsdf_ctx* c, int block, int laplacian_reg, psgsdf_step_stats* 
         case PSGSDF_LIGHT:
             // (a speculative light update keeps the coefficients it overwrites: the solve kernel copies them to frames_undo first)
             if (c->fm_solved) c->fm_solved = false;      // (the sweep's last workgroups solved their frames: step_begin)
+            else if (c->frame_solve == 1) {             // the reference's global float Jacobi-PCG over all frames' blocks (frame_solve.hip)
+                if (!frames_eigen_fits(c->set.model, c->F)) return fail(c, PSGSDF_ERR_UNSUPPORTED, "PSGSDF_FRAME_SOLVE=eigen holds at most 2048 unknowns in its one workgroup (%d keyframes)", c->F);
+                timed(c, "solve_light_eigen", [&] { launch_frames_eigen_light(a, c->frames, c->led_light, c->frame_e_slot, c->frame_e_key, c->spec_undo ? (float*)c->frames_undo : nullptr, c->fs_stats, c->stream); });
+            }
             else timed(c, "solve_light", [&] { launch_solve_light(a, c->frames, c->led_light, c->frame_e_slot, c->frame_e_key, c->spec_undo ? (float*)c->frames_undo : nullptr, c->stream); });
             if (c->spec_undo) c->spec_light_saved = true;
             c->frame_e_slot = nullptr; c->frame_e_key = 0;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = led ? 1 : c->F;
+            if (c->frame_solve == 1 && c->want_counts) { if ((rc = read_frame_solver_stats(c, 0, st))) return rc; }
             break;
         case PSGSDF_POSE:
             if (c->fm_solved) c->fm_solved = false;
+            else if (c->frame_solve == 1) {
+                if (!frames_eigen_fits(c->set.model, c->F)) return fail(c, PSGSDF_ERR_UNSUPPORTED, "PSGSDF_FRAME_SOLVE=eigen holds at most 2048 unknowns in its one workgroup (%d keyframes)", c->F);
+                timed(c, "solve_pose_eigen", [&] { launch_frames_eigen_pose(a, c->frames, c->frame_e_slot, c->frame_e_key, c->fs_stats + 4, c->stream); });
+            }
             else timed(c, "solve_pose", [&] { launch_solve_pose(a, c->frames, c->frame_e_slot, c->frame_e_key, c->stream); });
             c->frame_e_slot = nullptr; c->frame_e_key = 0;
             st->cg_converged = 1; st->applied = 1; st->n_accepted = c->F;
+            if (c->frame_solve == 1 && c->want_counts) { if ((rc = read_frame_solver_stats(c, 1, st))) return rc; st->n_accepted = st->applied ? c->F : 0; }
             break;
         case PSGSDF_DIST: {
             take_fold(c, a, 0u);

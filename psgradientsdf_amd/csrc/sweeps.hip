@@ -207,7 +207,6 @@ static int fm_rows(const SweepArgs& a, int slots_per_cu) {
 
 // small dense solves and SO3::exp (defined below)
 template <int N> __device__ void solve_spd(const double* Hin, const double* bin, double* x);
-__device__ void so3_exp(const float* w, float* R);
 
 // One frame's light step (optimizeLightAll, PsOptimizer.cpp:175-203: no damping; SH models: NB x NB per frame) from its final row `acc`, and one
 // frame's pose step (optimizePosesAll PsOptimizer.cpp:207-234 + updatePose OptimizerAux.cpp:190-205).  Shared by the one-workgroup solve kernels
@@ -237,15 +236,7 @@ __device__ __forceinline__ void frame_solve_pose(const SweepArgs& a, FrameP* fra
     solve_spd<6>(Hd, bd, xd);
     float xi[6];
     for (int i = 0; i < 6; ++i) xi[i] = (float)xd[i];
-    float R[9], t[3];
-    for (int i = 0; i < 9; ++i) R[i] = frames[f].R[i];
-    for (int i = 0; i < 3; ++i) t[i] = frames[f].t[i];
-    float mw[3] = {-xi[3], -xi[4], -xi[5]}, E3[9];
-    so3_exp(mw, E3);
-    for (int i = 0; i < 3; ++i) {
-        frames[f].t[i] = t[i] - xi[i];
-        for (int k = 0; k < 3; ++k) frames[f].R[i * 3 + k] = (R[i * 3 + 0] * E3[0 * 3 + k] + R[i * 3 + 1] * E3[1 * 3 + k]) + R[i * 3 + 2] * E3[2 * 3 + k];
-    }
+    pose_update(frames, f, xi);
 }
 
 // What the LAST workgroup of a frame-major launch does once every frame's final row is in a.acc.frame: (multi-rank: the per-frame solves, one lane per
@@ -736,25 +727,6 @@ void launch_solve_light(const SweepArgs& a, FrameP* frames, float* led_light, do
     else hipLaunchKernelGGL((k_solve_light<2>), g, bl, 0, s, a, frames, led_light, e_out, e_key, undo);
 }
 
-// Sophus SO3::exp(w).matrix() (quaternion exponential + Eigen toRotationMatrix)
-__device__ void so3_exp(const float* w, float* R) {
-    float theta_sq = dot3(w, w);
-    float imag, real;
-    if (theta_sq < 1e-10f) {
-        float theta_po4 = theta_sq * theta_sq;
-        imag = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_po4;
-        real = 1.0f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_po4;
-    } else {
-        float theta = sqrtf(theta_sq), half = 0.5f * theta;
-        imag = sinf(half) / theta; real = cosf(half);
-    }
-    float qw = real, qx = imag * w[0], qy = imag * w[1], qz = imag * w[2];
-    float tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
-    float twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
-    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
-    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
-    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
-}
 // optimizePosesAll PsOptimizer.cpp:207-234 + updatePose OptimizerAux.cpp:190-205
 __global__ void __launch_bounds__(kBlock) k_solve_pose(SweepArgs a, FrameP* frames, double* e_out, unsigned long long e_key) {
     __shared__ double red[2 * kBlock / 64];

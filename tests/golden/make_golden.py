@@ -4,6 +4,9 @@
 The reference ships no golden vectors and cannot be run here, so these fixtures pin the ORACLE against
 accidental edits and give the GPU tests a committed expected output; they are data (inputs are regenerated from the seed
 by psgradientsdf_amd/synth.py, outputs are stored).  Run from the repo root:  python tests/golden/make_golden.py
+
+Round 6: generated with the oracle's solver_mode 1 -- the light and pose blocks solved as the reference solves them, ONE Eigen-style float Jacobi-PCG over
+all frames' blocks (PsOptimizer.cpp:175-234, LedOptimizer.cpp:134-275) -- instead of the per-block direct solves of the earlier fixtures.
 """
 import os
 import sys
@@ -22,7 +25,7 @@ def run(model):
     kw = CASES[model]
     sc = synth.make_scene(model=model, **kw)
     st = capi.default_settings(sc.model_id, reg_weight_l=1.0)
-    o = oracle.Oracle(sc, sc.K, st)
+    o = oracle.Oracle(sc, sc.K, st, solver_mode=1)
     o.load_scene(sc)
     o.init_albedo()
     e_tot0 = o.normalize_weights()
@@ -30,7 +33,7 @@ def run(model):
     recs = o.iterate(capi.ALL, 2)
     band = o.download_band()
     v = o.download_volume()
-    return sc, dict(band=band, energy0=np.array(e0), e_total0=e_tot0, e_total=np.array([r["e_total"] for r in recs]),
+    return sc, dict(solver_mode=np.array(1), band=band, energy0=np.array(e0), e_total0=e_tot0, e_total=np.array([r["e_total"] for r in recs]),
                     e_after=np.array([r["e_after"] for r in recs]), cg_iters=np.array([r["cg_iters"] for r in recs]),
                     dist=v["dist"][band], rgb=v["rgb"][:, band], grad=v["grad"][:, band], poses=o.download_poses(), light=o.download_light(),
                     scene_checksum=np.array([float(np.abs(sc.dist).sum()), float(sc.images.sum()), float(sc.poses.sum())]))

@@ -31,6 +31,32 @@ def sdf_errors(eng, orc, vs, margins=None, **more):
     return m["rel"], m["q999_vs"], m["max_vs"]
 
 
+# Round 6: the ORACLE of every configuration below solves the light and pose blocks as the reference does -- one global float
+# Jacobi-PCG over all frames' blocks (solver_mode 1; PsOptimizer.cpp:175-234, LedOptimizer.cpp:134-275).  `eng` runs the same solver
+# (psgsdf_set_frame_solver(1), csrc/frame_solve.hip): the primary comparison, under the tolerances these tests always had.  `eng_d` is the engine AS
+# SHIPPED (each block solved directly in double): what that substitution costs against the reference's solver is measured on the same run and recorded
+# as `shipped_engine_vs_reference_solver` (norm-wise and 99.9 % quantile held to the north star's 1e-4; the every-voxel maximum is recorded).
+def new_engines(g, K, st):
+    eng = capi.load_engine(g, K, st, 0); eng.set_frame_solver(1)
+    eng_d = capi.load_engine(g, K, st, 0)
+    assert eng.get_tuning()["effective"]["frame_solve"] == "eigen" and eng_d.get_tuning()["effective"]["frame_solve"] == "ldlt"
+    return eng, eng_d
+
+
+def shipped_engine(eng_d, orc, vs, ro, margins, e_tol=1e-4, light_tol=2e-4, pose_tol=2e-5):
+    """one iteration of the engine as shipped (direct block solves) against the oracle's record `ro` (reference's solver)"""
+    rd = eng_d.iterate(capi.ALL, 1)[0]
+    band = eng_d.download_band()
+    m = sdf_margin(eng_d.download_volume()["dist"], orc.download_volume()["dist"], band, vs)
+    lo = orc.download_light()
+    got = {"sdf": m, "e_total_rel": abs(rd["e_total"] - ro["e_total"]) / abs(ro["e_total"]), "pose": float(np.abs(eng_d.download_poses() - orc.download_poses()).max()),
+           "light_rel": float(np.abs(eng_d.download_light() - lo).max() / np.abs(lo).max()), "tolerance": {"rel": 1e-4, "q999_vs": 1e-4, "e_total_rel": e_tol, "light_rel": light_tol, "pose": pose_tol}}
+    margins(shipped_engine_vs_reference_solver=got)
+    assert m["rel"] <= 1e-4 and m["q999_vs"] <= 1e-4, m
+    assert got["e_total_rel"] <= e_tol and got["light_rel"] <= light_tol and got["pose"] <= pose_tol, got
+    assert abs(rd["cg_iters"] - ro["cg_iters"]) <= 1
+
+
 # ---------------------------------------------------------------------------------------------------- configs[0]
 def load_sokrates():
     """the multiview layout of the reference's demo data (MultiviewLoader.h:35-58): colorNNNNNN.png / depthNNNNNN.png (uint16 mm),
@@ -82,8 +108,8 @@ def test_config0_sokrates_frames_0_20(built, margins):
     vs = 0.004
     g = capi.GridDesc(); g.dim[:] = [128, 128, 128]; g.voxel_size = vs; g.shift[:] = [float(x) for x in centroid(K, depth[0], poses[0])]; g.truncation = 5 * vs
     st = capi.default_settings(capi.SH1)                                   # config_skorates.json: cauchy 0.2, damping 1, reg norm 10
-    eng = capi.load_engine(g, K.reshape(-1), st, 0); orc = oracle.Oracle(g, K.reshape(-1), st, threads=THREADS)
-    for api in (eng, orc):
+    (eng, eng_d), orc = new_engines(g, K.reshape(-1), st), oracle.Oracle(g, K.reshape(-1), st, threads=THREADS, solver_mode=1)
+    for api in (eng, eng_d, orc):
         api.volume_init(len(poses))
         for f in range(len(poses)):
             n = api.estimate_normals(depth[f])
@@ -100,16 +126,18 @@ def test_config0_sokrates_frames_0_20(built, margins):
         assert np.abs(a - b).max() <= 5e-5 * max(1.0, np.abs(b).max()), k
     key_poses = np.stack(poses).reshape(-1, 16).copy(); key_poses[0] = np.eye(4, dtype=np.float32).reshape(16)     # B1, main_ps.cpp:139
     imgs = np.stack(color)
-    for api in (eng, orc):
+    for api in (eng, eng_d, orc):
         api.set_keyframes(np.arange(len(poses), dtype=np.int32), imgs, key_poses)
         api.init(); api.init_albedo()
     be, bo = eng.download_band(), orc.download_band()
     assert 3e4 < len(bo) < 2e5
     if not np.array_equal(be, bo):     # the gate voxels above: the two volumes differ there, so run the optimiser comparison on ONE volume
-        eng.upload_volume(vo["dist"], vo["grad"], vo["weight"], vo["rgb"], orc.download_vis_seq(1), 1)
-        eng.set_keyframes(np.arange(len(poses), dtype=np.int32), imgs, key_poses); eng.init(); eng.init_albedo()
+        for e in (eng, eng_d):
+            e.upload_volume(vo["dist"], vo["grad"], vo["weight"], vo["rgb"], orc.download_vis_seq(1), 1)
+            e.set_keyframes(np.arange(len(poses), dtype=np.int32), imgs, key_poses); e.init(); e.init_albedo()
         assert np.array_equal(eng.download_band(), bo)
     e0e, e0o = eng.normalize_weights(), orc.normalize_weights()
+    eng_d.normalize_weights()
     assert abs(e0e - e0o) <= 2e-5 * abs(e0o)
     re_, ro = eng.iterate(capi.ALL, 1)[0], orc.iterate(capi.ALL, 1)[0]
     assert abs(re_["e_total"] - ro["e_total"]) <= 1e-4 * abs(ro["e_total"]) and abs(re_["cg_iters"] - ro["cg_iters"]) <= 1
@@ -119,6 +147,7 @@ def test_config0_sokrates_frames_0_20(built, margins):
     assert rel <= 1e-4 and q999 <= 1e-4, (rel, q999, dmax)
     assert got["pose"] <= 2e-5
     assert got["light_rel"] <= 2e-4
+    shipped_engine(eng_d, orc, vs, ro, margins)
 
 
 def test_config0_native_resolution(built, margins):
@@ -141,8 +170,8 @@ def test_config0_native_resolution(built, margins):
     vs = 0.004
     g = capi.GridDesc(); g.dim[:] = [128, 128, 128]; g.voxel_size = vs; g.shift[:] = [float(x) for x in centroid(K, depth[0], poses[0])]; g.truncation = 5 * vs
     st = capi.default_settings(capi.SH1)
-    eng = capi.load_engine(g, K.reshape(-1), st, 0); orc = oracle.Oracle(g, K.reshape(-1), st, threads=THREADS)
-    for api in (eng, orc):
+    (eng, eng_d), orc = new_engines(g, K.reshape(-1), st), oracle.Oracle(g, K.reshape(-1), st, threads=THREADS, solver_mode=1)
+    for api in (eng, eng_d, orc):
         api.volume_init(len(poses))
         for f in range(len(poses)):
             api.integrate_frame(color[f], depth[f], api.estimate_normals(depth[f]), poses[f], f, z_min=0.5, z_max=3.5)
@@ -155,13 +184,15 @@ def test_config0_native_resolution(built, margins):
     assert max(fused.values()) <= 5e-5, fused
     key_poses = np.stack(poses).reshape(-1, 16).copy(); key_poses[0] = np.eye(4, dtype=np.float32).reshape(16)     # B1
     imgs = np.stack(color)
-    for api in (eng, orc):
+    for api in (eng, eng_d, orc):
         api.set_keyframes(np.arange(len(poses), dtype=np.int32), imgs, key_poses); api.init(); api.init_albedo()
     if not np.array_equal(eng.download_band(), orc.download_band()):     # (voxels on the fusion's normal gate: compare the optimiser on ONE volume)
-        eng.upload_volume(vo["dist"], vo["grad"], vo["weight"], vo["rgb"], orc.download_vis_seq(1), 1)
-        eng.set_keyframes(np.arange(len(poses), dtype=np.int32), imgs, key_poses); eng.init(); eng.init_albedo()
+        for e in (eng, eng_d):
+            e.upload_volume(vo["dist"], vo["grad"], vo["weight"], vo["rgb"], orc.download_vis_seq(1), 1)
+            e.set_keyframes(np.arange(len(poses), dtype=np.int32), imgs, key_poses); e.init(); e.init_albedo()
     assert np.array_equal(eng.download_band(), orc.download_band()) and eng.info().n_band > 2e4
     e0e, e0o = eng.normalize_weights(), orc.normalize_weights()
+    eng_d.normalize_weights()
     assert abs(e0e - e0o) <= 2e-5 * abs(e0o)
     re_, ro = eng.iterate(capi.ALL, 1)[0], orc.iterate(capi.ALL, 1)[0]
     got = {"e_total_rel": abs(re_["e_total"] - ro["e_total"]) / abs(ro["e_total"]), "pose": float(np.abs(eng.download_poses() - orc.download_poses()).max()),
@@ -170,6 +201,7 @@ def test_config0_native_resolution(built, margins):
     assert got["e_total_rel"] <= 1e-4 and abs(re_["cg_iters"] - ro["cg_iters"]) <= 1
     assert rel <= 1e-4 and q999 <= 1e-4, (rel, q999, dmax)
     assert got["pose"] <= 2e-5 and got["light_rel"] <= 2e-4
+    shipped_engine(eng_d, orc, vs, ro, margins)
 
 
 # ---------------------------------------------------------------------------------------------------- configs[2]
@@ -183,8 +215,8 @@ def test_config2_stream_with_tracking_256(built, margins):
     F = 50
     sc = synth.make_scene(N=256, F=F, W=640, H=480, model="SH1", bump=6.0, arc=30.0, zigzag=False)   # smooth path: 0.6 deg = 4 voxels per frame
     st = capi.default_settings(capi.SH1)
-    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=THREADS)
-    for api in (eng, orc):
+    (eng, eng_d), orc = new_engines(sc, sc.K, st), oracle.Oracle(sc, sc.K, st, threads=THREADS, solver_mode=1)
+    for api in (eng, eng_d, orc):
         api.volume_init(F)
     pose = sc.poses_gt[0].reshape(4, 4).copy()
     tracked = [pose.reshape(16).copy()]
@@ -199,7 +231,7 @@ def test_config2_stream_with_tracking_256(built, margins):
             worst_t = max(worst_t, float(np.abs(Pe - Po).max()))
             pose, _, _ = orc.track(sc.depth[f], Po, num_iterations=5)      # a few more passes drive the stream; both sides fuse at THIS pose
             tracked.append(pose.reshape(16).copy())
-        for api in (eng, orc):
+        for api in (eng, eng_d, orc):
             api.integrate_frame(sc.images[f], sc.depth[f], no, pose, f, z_min=0.05, z_max=10.0)
     assert worst_n <= 5e-5 and worst_t <= 5e-5, (worst_n, worst_t)
     drift = np.abs(np.stack(tracked)[:, [3, 7, 11]] - sc.poses_gt[:, [3, 7, 11]]).max()
@@ -209,7 +241,7 @@ def test_config2_stream_with_tracking_256(built, margins):
     for k in ("dist", "grad", "rgb"):
         assert np.abs(ve[k] - vo[k]).max() <= 2e-6 * max(1.0, np.abs(vo[k]).max()), k
     key_poses = np.stack(tracked)
-    for api in (eng, orc):
+    for api in (eng, eng_d, orc):
         api.set_keyframes(np.arange(F, dtype=np.int32), sc.images, key_poses)
         api.init(); api.init_albedo(); api.normalize_weights()
     assert np.array_equal(eng.download_band(), orc.download_band()) and eng.info().n_band > 5e4      # (a 30 degree sweep sees a quarter of the object)
@@ -220,6 +252,7 @@ def test_config2_stream_with_tracking_256(built, margins):
     rel, q999, dmax = sdf_errors(eng, orc, float(sc.voxel_size), margins, achieved=got, tolerance={"rel": 1e-4, "q999_vs": 1e-4, "e_total_rel": 1e-4, "pose": 2e-5, "normals": 5e-5, "tracker_pose": 5e-5})
     assert rel <= 1e-4 and q999 <= 1e-4, (rel, q999, dmax)
     assert got["pose"] <= 2e-5
+    shipped_engine(eng_d, orc, float(sc.voxel_size), ro, margins)
 
 
 # ---------------------------------------------------------------------------------------------------- configs[3]
@@ -230,8 +263,8 @@ def test_config3_led_256x50(built, margins):
     sc = synth.make_scene(N=256, F=50, W=640, H=480, model="LED")
     st = capi.default_settings(capi.LED)
     st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0
-    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=THREADS)
-    for api in (eng, orc):
+    (eng, eng_d), orc = new_engines(sc, sc.K, st), oracle.Oracle(sc, sc.K, st, threads=THREADS, solver_mode=1)
+    for api in (eng, eng_d, orc):
         api.load_scene(sc); api.init_albedo(); api.normalize_weights()
     assert eng.info().n_band == orc.info().n_band > 2.5e5
     assert abs(eng.info().reg_weight_l - orc.info().reg_weight_l) <= 1e-5 * orc.info().reg_weight_l
@@ -246,6 +279,7 @@ def test_config3_led_256x50(built, margins):
     assert got["rgb"] <= 1e-4
     assert got["pose"] <= 1e-5
     assert got["light_rel"] <= 1e-4
+    shipped_engine(eng_d, orc, float(sc.voxel_size), ro, margins, light_tol=1e-4, pose_tol=1e-5)
 
 
 # ---------------------------------------------------------------------------------------------------- configs[4]
@@ -256,8 +290,8 @@ def test_config4_sh2_512x100(built, margins):
     sc = synth.make_scene(N=512, F=100, W=640, H=480, model="SH2")
     assert sc.vis_words == 2
     st = capi.default_settings(capi.SH2)
-    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=THREADS)
-    for api in (eng, orc):
+    (eng, eng_d), orc = new_engines(sc, sc.K, st), oracle.Oracle(sc, sc.K, st, threads=THREADS, solver_mode=1)
+    for api in (eng, eng_d, orc):
         api.load_scene(sc); api.init_albedo(); api.normalize_weights()
     S = eng.info().n_band
     assert S == orc.info().n_band and 0.8e6 < S < 2e6
@@ -273,10 +307,16 @@ def test_config4_sh2_512x100(built, margins):
     for a, b in ((de, do), (re_, ro), (ye, yo)):
         assert np.abs(a[idx] - b[idx]).max() <= 2e-5 * np.abs(b).max()
     ie, io = eng.iterate(capi.ALL, 1)[0], orc.iterate(capi.ALL, 1)[0]
-    # SH2: the 9x9 light blocks are kept in float32 by the reference and have cond ~2e4 (tests/test_parity_gpu.py: LIGHT_RTOL)
+    # SH2: the 9x9 light blocks are kept in float32 by the reference and have cond ~2e4 (tests/test_parity_gpu.py: LIGHT_RTOL, LIGHT_RTOL_EIGEN)
     assert abs(ie["e_total"] - io["e_total"]) <= 5e-4 * abs(io["e_total"]) and abs(ie["cg_iters"] - io["cg_iters"]) <= 1
+    fs = {b: eng.frame_solver_stats(b) for b in (capi.LIGHT, capi.POSE)}      # Eigen's iterations() / info() of the 900- and 600-unknown solves
+    assert fs[capi.LIGHT]["cg_converged"] == 1 and fs[capi.POSE]["cg_converged"] == 1, fs
     got = {"e_total_rel": abs(ie["e_total"] - io["e_total"]) / abs(io["e_total"]), "pose": float(np.abs(eng.download_poses() - orc.download_poses()).max()),
-           "light_rel": float(np.abs(eng.download_light() - orc.download_light()).max() / np.abs(orc.download_light()).max())}
-    rel, q999, dmax = sdf_errors(eng, orc, float(sc.voxel_size), margins, achieved=got, tolerance={"rel": 1e-4, "q999_vs": 1e-4, "e_total_rel": 5e-4, "pose": 2e-5})
+           "light_rel": float(np.abs(eng.download_light() - orc.download_light()).max() / np.abs(orc.download_light()).max()),
+           "frame_cg_iters": {"light": fs[capi.LIGHT]["cg_iters"], "pose": fs[capi.POSE]["cg_iters"]}}
+    rel, q999, dmax = sdf_errors(eng, orc, float(sc.voxel_size), margins, achieved=got, tolerance={"rel": 1e-4, "q999_vs": 1e-4, "e_total_rel": 5e-4, "pose": 2e-5, "light_rel": 1e-3})
     assert rel <= 1e-4 and q999 <= 1e-4, (rel, q999, dmax)
-    assert got["pose"] <= 2e-5
+    assert got["pose"] <= 2e-5 and got["light_rel"] <= 1e-3
+    # the engine as shipped: SH2's light step differs from the reference solver's by what a float CG leaves undetermined on cond-2e4 blocks (1e-3 of the
+    # step: tests/test_frame_solver_gpu.py::test_default_solver_against_the_references)
+    shipped_engine(eng_d, orc, float(sc.voxel_size), io, margins, e_tol=5e-4, light_tol=5e-3)

@@ -1,5 +1,7 @@
 """Committed golden vectors (tests/golden/make_golden.py): the oracle must keep reproducing them (CPU), and the HIP
-engine must reproduce them through the C ABI (GPU)."""
+engine must reproduce them through the C ABI (GPU).  Since round 6 the vectors are the oracle's with the REFERENCE's solver of the light / pose
+blocks (solver_mode 1: one global float Jacobi-PCG); the engine is held to them with that solver (psgsdf_set_frame_solver(1): the primary comparison)
+and as shipped (direct block solves), the latter with SH2's tolerance stated as what the substitution costs."""
 import os
 
 import numpy as np
@@ -20,6 +22,7 @@ def _run(api):
 
 def _check(model, api, sc, tol_d, tol_e):
     g = np.load(os.path.join(GOLD, f"oracle_small_{model}.npz"))
+    assert int(g["solver_mode"]) == 1
     chk = np.array([float(np.abs(sc.dist).sum()), float(sc.images.sum()), float(sc.poses.sum())])
     assert np.allclose(chk, g["scene_checksum"], rtol=1e-6), "the synthetic scene generator changed: regenerate the fixtures"
     e_tot0, recs = _run(api)
@@ -39,13 +42,18 @@ def _check(model, api, sc, tol_d, tol_e):
 def test_oracle_reproduces_golden(built, model):
     from oracle import oracle
     sc = synth.make_scene(model=model, **CASE)
-    o = oracle.Oracle(sc, sc.K, capi.default_settings(sc.model_id, reg_weight_l=1.0)); o.load_scene(sc)
+    o = oracle.Oracle(sc, sc.K, capi.default_settings(sc.model_id, reg_weight_l=1.0), solver_mode=1); o.load_scene(sc)
     _check(model, o, sc, 1e-6, 1e-6)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["eigen", "ldlt"])
 @pytest.mark.parametrize("model", ["SH1", "SH2", "LED"])
-def test_engine_reproduces_golden(built, model):
+def test_engine_reproduces_golden(built, model, solver):
     sc = synth.make_scene(model=model, **CASE)
-    e = capi.load_engine(sc, sc.K, capi.default_settings(sc.model_id, reg_weight_l=1.0), 0); e.load_scene(sc)
+    e = capi.load_engine(sc, sc.K, capi.default_settings(sc.model_id, reg_weight_l=1.0), 0)
+    e.set_frame_solver(1 if solver == "eigen" else 0)
+    e.load_scene(sc)
+    # SH2 (either solver): the 9 x 9 light blocks' condition number (~2e4) times the 1e-8 between the two sides' float normal equations; four keyframes:
+    # the reference's light CG ends on NoConvergence after its 2n = 72 passes (tests/test_parity_gpu.py LIGHT_RTOL_EIGEN has the measurement)
     _check(model, e, sc, 1e-3 if model == "SH2" else 1e-4, 2e-3 if model == "SH2" else 2e-4)

@@ -23,12 +23,32 @@ LIGHT_RTOL = {"SH1": 1e-4, "SH2": 1e-3, "LED": 1e-4}      # (achieved on the dri
 OPT_MAX_VS = 1e-4
 
 
-def make_pair(model_name, model_id, N=48, F=6, **kw):
+# The solver of the light / pose blocks.  "eigen": engine and oracle BOTH run the reference's algorithm -- one global float
+# Jacobi-PCG over all frames' blocks (PsOptimizer.cpp:175-234, LedOptimizer.cpp:134-275; csrc/frame_solve.hip, oracle solver_mode 1): the PRIMARY
+# comparison.  "ldlt": the engine's default (each block solved directly in double) against the oracle's direct solves: the same deviation on both sides.
+# What the DEFAULT engine deviates from the reference's solver is measured in tests/test_frame_solver_gpu.py::test_default_solver_against_the_references.
+SOLVERS = ["eigen", "ldlt"]
+# Light tolerance per (solver, model).  Measured (profiles/r06_parity_margins.json): running the reference's solver on BOTH sides does not tighten SH2 -- its 9 x 9
+# light blocks have cond ~2e4, so the 1e-8 relative difference between the engine's and the oracle's float normal equations alone moves the step by
+# cond x 1e-8 ~ 2e-4 whatever solves them, and with six keyframes the reference's CG does not even reach eps within its 2n passes (info() = NoConvergence on
+# both sides, update applied regardless: PsOptimizer.cpp:199-201), which leaves the step to the rounding of the last passes.  With 50 keyframes it converges
+# (251 passes on both sides) and the two agree to 1.5e-4 (tests/test_frame_solver_gpu.py::test_full_keyframe_count).
+LIGHT_RTOL_EIGEN = {"SH1": 1e-4, "SH2": 1e-3, "LED": 1e-4}
+
+
+def light_rtol(solver, name):
+    return LIGHT_RTOL_EIGEN[name] if solver == "eigen" else LIGHT_RTOL[name]
+
+
+def make_pair(model_name, model_id, N=48, F=6, solver="ldlt", **kw):
     from oracle import oracle
     sc = synth.make_scene(N=N, F=F, W=160, H=120, model=model_name)
     st = capi.default_settings(model_id, **kw)
     eng = capi.load_engine(sc, sc.K, st, 0)
-    orc = oracle.Oracle(sc, sc.K, st)
+    orc = oracle.Oracle(sc, sc.K, st, solver_mode=1 if solver == "eigen" else 0)
+    if solver == "eigen":
+        eng.set_frame_solver(1)
+        assert eng.get_tuning()["effective"]["frame_solve"] == "eigen"
     for api in (eng, orc):
         api.load_scene(sc)
     return sc, eng, orc
@@ -70,9 +90,10 @@ def test_normal_equations(built, margins, name, mid):
     assert all(v < 2e-5 for v in got.values()), got
 
 
+@pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("name,mid", MODELS)
-def test_substeps(built, margins, name, mid):
-    sc, eng, orc = make_pair(name, mid)
+def test_substeps(built, margins, name, mid, solver):
+    sc, eng, orc = make_pair(name, mid, solver=solver)
     worst = {"dist_vs": 0.0, "rgb": 0.0, "grad": 0.0, "pose": 0.0, "light_rel": 0.0, "e_in_rel": 0.0}
     for api in (eng, orc):
         api.init_albedo(); api.normalize_weights()
@@ -87,22 +108,30 @@ def test_substeps(built, margins, name, mid):
         assert abs(se["e_in"] - so["e_in"]) <= (2e-4 if name == "SH2" else 2e-5) * abs(so["e_in"]), (blk, se, so)   # SH2: after the ill-conditioned light step
         if blk == capi.DIST:
             assert abs(se["cg_iters"] - so["cg_iters"]) <= 1 and se["cg_converged"] == so["cg_converged"]
+        if solver == "eigen" and blk in (capi.LIGHT, capi.POSE):      # Eigen's iterations() / info() of the global solve, and the LED pose gate
+            assert abs(se["cg_iters"] - so["cg_iters"]) <= (8 if name == "SH2" and blk == capi.LIGHT else 1), (blk, se, so)
+            # (SH2 with six keyframes: the reference's light solve uses up its 2n = 108 passes a few 1e-6 above eps -- NoConvergence, on both sides -- and
+            # applies the update regardless, PsOptimizer.cpp:199-201)
+            assert se["cg_converged"] == so["cg_converged"] and se["applied"] == so["applied"] == 1, (blk, se, so)
+            assert so["cg_converged"] == 1 or (name == "SH2" and blk == capi.LIGHT), (blk, so)
+            worst.setdefault("frame_cg_iters", {})[blk] = (se["cg_iters"], so["cg_iters"])
         ve, vo = eng.download_volume(), orc.download_volume()
         got = {"dist_vs": float(np.abs(ve["dist"][band] - vo["dist"][band]).max() / vs), "rgb": float(np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max()),
                "grad": float(np.abs(ve["grad"][:, band] - vo["grad"][:, band]).max()), "pose": float(np.abs(eng.download_poses() - orc.download_poses()).max()),
                "light_rel": relmax(eng.download_light(), orc.download_light()), "e_in_rel": float(abs(se["e_in"] - so["e_in"]) / abs(so["e_in"]))}
-        worst = {k: max(worst[k], got[k]) for k in worst}
+        worst.update({k: max(worst[k], got[k]) for k in got})
         assert got["dist_vs"] <= 1e-4, blk
         assert got["rgb"] <= 1e-4, blk
         assert got["grad"] <= 2e-4, blk
         assert got["pose"] <= 1e-5, blk
-        assert got["light_rel"] <= LIGHT_RTOL[name], blk
-    margins(achieved=worst, tolerance={"dist_vs": 1e-4, "rgb": 1e-4, "grad": 2e-4, "pose": 1e-5, "light_rel": LIGHT_RTOL[name], "e_in_rel": 2e-4 if name == "SH2" else 2e-5})
+        assert got["light_rel"] <= light_rtol(solver, name), blk
+    margins(achieved=worst, tolerance={"dist_vs": 1e-4, "rgb": 1e-4, "grad": 2e-4, "pose": 1e-5, "light_rel": light_rtol(solver, name), "e_in_rel": 2e-4 if name == "SH2" else 2e-5})
 
 
+@pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("name,mid", MODELS)
-def test_iterations(built, margins, name, mid):
-    sc, eng, orc = make_pair(name, mid)
+def test_iterations(built, margins, name, mid, solver):
+    sc, eng, orc = make_pair(name, mid, solver=solver)
     for api in (eng, orc):
         api.init_albedo(); api.normalize_weights()
     re_, ro = eng.iterate(capi.ALL, 3), orc.iterate(capi.ALL, 3)
@@ -113,8 +142,10 @@ def test_iterations(built, margins, name, mid):
         assert abs(a["e_total"] - b["e_total"]) <= 2e-4 * abs(b["e_total"])
     ve, vo = eng.download_volume(), orc.download_volume()
     m = sdf_margin(ve["dist"], vo["dist"], band, vs)
-    margins(sdf=m, e_total_rel=max(abs(a["e_total"] - b["e_total"]) / abs(b["e_total"]) for a, b in zip(re_, ro)), tolerance={"q999_vs": 1e-4, "max_vs": 1e-4, "e_total_rel": 2e-4})
+    lrel = relmax(eng.download_light(), orc.download_light()); rgb = float(np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max())
+    margins(sdf=m, light_rel=lrel, rgb=rgb, e_total_rel=max(abs(a["e_total"] - b["e_total"]) / abs(b["e_total"]) for a, b in zip(re_, ro)), tolerance={"q999_vs": 1e-4, "max_vs": 1e-4, "e_total_rel": 2e-4})
     assert m["q999_vs"] <= 1e-4 and m["max_vs"] <= 1e-4, m      # three iterations: EVERY band voxel inside the north star's tolerance
+    assert lrel <= 3 * light_rtol(solver, name), lrel
 
 
 def test_upsample_and_optimize(built):
@@ -128,8 +159,9 @@ def test_upsample_and_optimize(built):
         assert abs(a["e_total"] - b["e_total"]) <= 1e-3 * abs(b["e_total"]), (a, b)
 
 
+@pytest.mark.parametrize("solver", SOLVERS)
 @pytest.mark.parametrize("name,mid", MODELS)
-def test_optimize_matches_oracle(built, margins, name, mid):
+def test_optimize_matches_oracle(built, margins, name, mid, solver):
     """psgsdf_optimize -- the loop voxelPS calls -- against the oracle's restatement of alternatingOptimize (PsOptimizer.cpp:239-428: albedo ->
     light -> distance -> pose; LedOptimizer.cpp:279-478: light -> albedo -> distance -> pose) for all three shading models: initAlbedo and weight
     normalisation inside the call, the per-iteration records with the energy after EVERY block, the converged / diverged flags that end the loop,
@@ -138,14 +170,14 @@ def test_optimize_matches_oracle(built, margins, name, mid):
     kw = dict(upsample=1, max_it=18, conv_threshold=0.0, damping=10.0)      # (damping 10: the loop survives its divergence test up to the refinement on these scenes)
     if mid == capi.LED:
         kw.update(reg_weight_n=0.1, reg_weight_l=5.0)                       # config_basket_LED.json's regularisers
-    sc, eng, orc = make_pair(name, mid, N=24, F=5, **kw)
+    sc, eng, orc = make_pair(name, mid, N=24, F=5, solver=solver, **kw)
     (re_, ce), (ro, co) = eng.optimize(capi.ALL), orc.optimize(capi.ALL)
     assert len(re_) == len(ro) >= 6 and ce == co
     assert [(r["converged"], r["diverged"], r["upsampled"]) for r in re_] == [(r["converged"], r["diverged"], r["upsampled"]) for r in ro]
     assert sum(r["upsampled"] for r in re_) == 1 and re_[5]["upsampled"] == 1
     for a, b in zip(re_, ro):
         assert abs(a["e_total"] - b["e_total"]) <= 1e-4 * abs(b["e_total"]), (a["e_total"], b["e_total"])
-        assert np.allclose(a["e_after"], b["e_after"], rtol=2e-4), (a["e_after"], b["e_after"])
+        assert np.allclose(a["e_after"], b["e_after"], rtol=1e-3 if (name, solver) == ("SH2", "eigen") else 2e-4), (a["e_after"], b["e_after"])      # (SH2 / eigen, five keyframes: a light solve that ends on NoConvergence, see LIGHT_RTOL_EIGEN)
         assert a["cg_iters"] == b["cg_iters"]
         assert abs(a["reg_weight_l"] - b["reg_weight_l"]) <= 1e-4 * abs(b["reg_weight_l"]) and abs(a["reg_weight_n"] - b["reg_weight_n"]) <= 1e-5 * abs(b["reg_weight_n"])
     assert tuple(eng.info().dim) == tuple(orc.info().dim) == (48, 48, 48)
@@ -157,11 +189,11 @@ def test_optimize_matches_oracle(built, margins, name, mid):
     le, lo = eng.download_light(), orc.download_light()
     got = {"rgb": float(np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max()), "pose": float(np.abs(eng.download_poses() - orc.download_poses()).max()),
            "light_rel": float(np.abs(le - lo).max() / np.abs(lo).max()), "e_total_rel": max(abs(a["e_total"] - b["e_total"]) / abs(b["e_total"]) for a, b in zip(re_, ro))}
-    margins(sdf=m, achieved=got, iterations=len(re_), tolerance={"q999_vs": 1e-4, "max_vs": OPT_MAX_VS, "rgb": 2e-3 if name == "SH2" else 2e-4, "pose": 1e-5, "light_rel": 5 * LIGHT_RTOL[name], "e_total_rel": 1e-4})
+    margins(sdf=m, achieved=got, iterations=len(re_), tolerance={"q999_vs": 1e-4, "max_vs": OPT_MAX_VS, "rgb": 2e-3 if name == "SH2" else 2e-4, "pose": 1e-5, "light_rel": 5 * light_rtol(solver, name), "e_total_rel": 1e-4})
     assert m["q999_vs"] <= 1e-4 and m["max_vs"] <= OPT_MAX_VS, m      # north star: <= 1e-4 relative SDF error
     assert got["rgb"] <= (2e-3 if name == "SH2" else 2e-4)
     assert got["pose"] <= 1e-5
-    assert got["light_rel"] <= 5 * LIGHT_RTOL[name]
+    assert got["light_rel"] <= 5 * light_rtol(solver, name)
 
 
 SCHEDULE_CASES = [("SH1", capi.SH1, 12, dict(damping=10.0, reg_weight_n=10.0)), ("SH2", capi.SH2, 16, dict(damping=1.0, reg_weight_n=0.1)),
