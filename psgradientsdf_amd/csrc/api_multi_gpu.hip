@@ -5,6 +5,8 @@
 #include <sys/socket.h>
 #include <sys/time.h>
 #include <cerrno>
+#include <atomic>
+#include <algorithm>
 #include <thread>
 
 using namespace psge;
@@ -38,7 +40,10 @@ int sock_allreduce(void* user, double* dev, int n, void* stream) {
     }
     return hipMemcpy(dev, h.data(), sizeof(double) * n, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
 }
-// the sends leave on a thread of their own while this one receives: no ordering between the peers' calls can dead-lock on a full socket buffer
+// The sends leave on threads of their own -- ONE PER PEER -- while this one receives in list order.  (One sender thread for all peers, round 5, could be
+// blocked on a full socket buffer towards a peer that was itself reading somebody else first: with three or more ranks and payloads beyond the socket
+// buffers -- psgsdf_rebalance_slabs allows any peer -- such waits can close a cycle, ended only by the send timeout.  With a thread per peer a send to P
+// waits for P alone, and P's reads are fed by senders that wait for nobody else: no cycle.  ADVICE r05.)
 int sock_sendrecv(void* user, const psgsdf_comm_xfer* sends, int ns, const psgsdf_comm_xfer* recvs, int nr, void* stream) {
     SockComm* s = (SockComm*)user;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return 1;
@@ -48,15 +53,18 @@ int sock_sendrecv(void* user, const psgsdf_comm_xfer* sends, int ns, const psgsd
         out[i].resize(sends[i].bytes);
         if (sends[i].bytes && hipMemcpy(out[i].data(), sends[i].ptr_dev, sends[i].bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
     }
-    bool sent = true;
-    std::thread tx([&] { for (int i = 0; i < ns; ++i) if (!wr_all(s->fd[sends[i].peer], out[i].data(), out[i].size())) { sent = false; return; } });
+    std::atomic<bool> sent{true};
+    std::vector<int> peers;
+    for (int i = 0; i < ns; ++i) if (std::find(peers.begin(), peers.end(), sends[i].peer) == peers.end()) peers.push_back(sends[i].peer);
+    std::vector<std::thread> txs;
+    for (int peer : peers) txs.emplace_back([&, peer] { for (int i = 0; i < ns; ++i) if (sends[i].peer == peer && !wr_all(s->fd[peer], out[i].data(), out[i].size())) { sent = false; return; } });      // (list order per peer)
     bool got = true;
     for (int i = 0; i < nr && got; ++i) {
         if (recvs[i].peer < 0 || recvs[i].peer >= s->n || recvs[i].peer == s->rank) { got = false; break; }
         in[i].resize(recvs[i].bytes);
         got = rd_all(s->fd[recvs[i].peer], in[i].data(), in[i].size());
     }
-    tx.join();
+    for (auto& t : txs) t.join();
     if (!sent || !got) return 1;
     for (int i = 0; i < nr; ++i) if (recvs[i].bytes && hipMemcpy(recvs[i].ptr_dev, in[i].data(), recvs[i].bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
     return 0;
@@ -89,7 +97,8 @@ int psgsdf_comm_init_sockets(psgsdf_ctx* c, const int* peer_fd, int rank, int n_
         if (sc->fd[r] < 0) return fail(c, PSGSDF_ERR_ARG, "comm_init_sockets: no socket for rank %d", r);
         double t = 120.0; if (const char* e = getenv("PSGSDF_SOCKET_TIMEOUT_S")) t = atof(e);      // a peer that died must end the run, not hang it
         struct timeval tv; tv.tv_sec = (long)t; tv.tv_usec = (long)((t - (double)tv.tv_sec) * 1e6);
-        setsockopt(sc->fd[r], SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv); setsockopt(sc->fd[r], SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+        if (setsockopt(sc->fd[r], SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv) != 0 || setsockopt(sc->fd[r], SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv) != 0)
+            return fail(c, PSGSDF_ERR_COMM, "comm_init_sockets: the socket to rank %d takes no timeout (%s): a lost peer would hang this rank", r, strerror(errno));
     }
     psgsdf_comm_ops ops{sc.get(), &sock_allreduce, &sock_sendrecv};
     c->comm_keep = sc;

@@ -267,6 +267,19 @@ __global__ void __launch_bounds__(256) k_xr_probe(double* myF, const float4* myP
         for (int r = 1; r <= kProbeRounds; ++r) {
             for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) sink += myP[i].x + (float)((const double*)myP)[2 * i + 1];      // (stale copies of both forms in this device's caches)
             __syncthreads();
+            if ((r & 3) == 3) {
+                // every fourth round: the pipelined solve's SELF-VALIDATING hand-off (pcg.hip k_cgp_solve<.., MR, TM>) -- no flag wait, no fence:
+                // every word is polled with system-scope relaxed loads until it carries the round's 2-bit tag, as a halo row's m is.  The previous round of
+                // this kind (r - 4) left words with the SAME tag in the same place, and this device holds cached copies of them (the loop above): a word
+                // that validates by its tag but is not this round's is exactly the silent failure a two-valued tag would allow -- counted as stale.
+                for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) {
+                    const double* src = (const double*)myP + 2 * i;
+                    int spins = 0; long long w;
+                    do { w = (long long)__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); if (((w >> 12) & 3) == 3) break; __builtin_amdgcn_s_sleep(1); } while (++spins <= (1 << 21));
+                    if (spins > (1 << 21)) s_to = 1;
+                    else if (w != (((long long)(r >> 2) << 14) | (3ll << 12) | (long long)i)) stale++;
+                }
+            }
             if (threadIdx.x == 0) {
                 int spins = 0;
                 while (__hip_atomic_load(myF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (double)r) { __builtin_amdgcn_s_sleep(1); if (++spins > (1 << 21)) { s_to = 1; break; } }
@@ -274,7 +287,8 @@ __global__ void __launch_bounds__(256) k_xr_probe(double* myF, const float4* myP
             }
             __syncthreads();
             if (s_to) break;
-            if (r & 1) { const double* pd = (const double*)myP; for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { if (pd[2 * i] != (double)r || pd[2 * i + 1] != (double)(r + i)) stale++; } }      // odd rounds: the pipelined solve's form (8-byte records, plain 8-byte loads)
+            if ((r & 3) == 3) { }
+            else if (r & 1) { const double* pd = (const double*)myP; for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { if (pd[2 * i] != (double)r || pd[2 * i + 1] != (double)(r + i)) stale++; } }      // odd rounds: the pipelined solve's form (8-byte records, plain 8-byte loads)
             else for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { const float4 v = myP[i]; if (v.x != (float)r || v.w != (float)(r + i)) stale++; }
             __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_store(loF + 8, (double)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -287,7 +301,8 @@ __global__ void __launch_bounds__(256) k_xr_probe(double* myF, const float4* myP
         for (int r = 1; r <= kProbeRounds; ++r) {
             // even rounds: k_cgf_solve's hand-off (16-byte sc0 sc1 records); odd rounds: k_cgp_solve's, the frame rows' and the scalar folds' (8-byte
             // sc0 sc1 words: device_common.h store8_system / pcg.hip store8_sys) -- the default solve is the pipelined one
-            if (r & 1) for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { probe_store8((double*)hiP + 2 * i, (double)r); probe_store8((double*)hiP + 2 * i + 1, (double)(r + i)); }
+            if ((r & 3) == 3) for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) probe_store8((double*)hiP + 2 * i, (double)(((long long)(r >> 2) << 14) | (3ll << 12) | (long long)i));      // tagged words: (round / 4) << 14 | tag 3 << 12 | index
+            else if (r & 1) for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) { probe_store8((double*)hiP + 2 * i, (double)r); probe_store8((double*)hiP + 2 * i + 1, (double)(r + i)); }
             else for (int i = threadIdx.x; i < kProbeRecs; i += blockDim.x) {
                 const v4f_probe_t d = {(float)r, 0.f, 0.f, (float)(r + i)};
                 asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(hiP + i), "v"(d) : "memory");

@@ -79,8 +79,8 @@ struct psgsdf_ctx {
     double* pcg_gran = nullptr;          // persistent solve: [2][kSolveGranPlanes][kSolveMaxBlocksHost] tagged per-workgroup sums
     bool pcg_fuse_asm = true;            // PSGSDF_PCG_FUSE_ASM=0: k_assemble in front of the persistent solve (round-2a)
     unsigned pcg_solve_serial = 0;       // distance solves launched on this context (SweepArgs::pcg_epoch)
-    bool pcg_tagm_mr = true;             // ... also between the ranks of a multi-rank context (PSGSDF_PCG_TAGM=1: one rank only)
-    bool pcg_tagm = true;                // PSGSDF_PCG_TAGM: the pipelined solve with self-validating exchanged values (pcg.hip k_cgp_solve<.., TM>; single rank)
+    bool pcg_tagm_mr = true;             // ... also between the ranks of a multi-rank context (the default, PSGSDF_PCG_TAGM=2: halo rows gathered at system scope from the first attempt on); PSGSDF_PCG_TAGM=1: on one rank only
+    bool pcg_tagm = true;                // PSGSDF_PCG_TAGM (default 2): the pipelined solve with self-validating exchanged values (pcg.hip k_cgp_solve<.., TM>); 0 = round 4's ordered hand-off; whether it also runs BETWEEN ranks: pcg_tagm_mr
     int pcg_ablate = 0;                  // PSGSDF_PCG_ABLATE: timing ablations of the pipelined solve (wrong results; tools only)
     bool pcg_prefetch = true;            // PSGSDF_PCG_PREFETCH=0: pipelined solve: the sums of a pass are only fetched after its gathers (not behind the last gather batch)
     bool pcg_pipeline = true;            // PSGSDF_PCG_PIPELINE=0: the persistent solve with round 2's recurrences (k_cgf_solve: a pass waits for its own reduction)

@@ -981,8 +981,13 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                 const int jj = j0 + j; const int pk = (int)cp[u][jj >> 1];
                 constexpr unsigned kInPlane = (1u << 0) | (1u << 1) | (1u << 2) | (1u << 3) | (1u << 6) | (1u << 7) | (1u << 12) | (1u << 13);      // columns without a z offset (q_offset: q = jj + 1)
                 if ((abl & 4) && ((kInPlane >> jj) & 1u)) { ob[t % kCgpDepth][j] = 0.0; continue; }      // ablation 4: the in-plane columns are not gathered at all
-                const double* src = rin + (row[u] + ((abl & 1) ? 0 : ((jj & 1) ? (pk >> 16) : ((pk << 16) >> 16))));
-                ob[t % kCgpDepth][j] = TM ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+                const int srow = row[u] + ((abl & 1) ? 0 : ((jj & 1) ? (pk >> 16) : ((pk << 16) >> 16)));
+                const double* src = rin + srow;
+                //  a HALO row's value is written by the neighbour RANK: gathered at system scope from the first attempt on -- the tag alone cannot tell
+                // this pass's value from the one of four passes ago (a buffer's tags alternate between two values), so the load itself must not be served from a
+                // copy this device cached then.  Own rows: agent scope, as on one rank.
+                if (TM && MR && (srow < a.row0 || srow >= a.row1)) ob[t % kCgpDepth][j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else ob[t % kCgpDepth][j] = TM ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
             }
         };
         // The sums of pass k were published when m_k was: by the time the last gather batch is on its way they have normally arrived, but FETCHING

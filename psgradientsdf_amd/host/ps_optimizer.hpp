@@ -21,6 +21,7 @@
 #include <deque>
 #include <functional>
 #include <mutex>
+#include <atomic>
 #include <thread>
 #include <cstdint>
 #include <fcntl.h>
@@ -217,8 +218,11 @@ class DumpQueue {
             idle_.notify_all();
         }
     }
+    std::atomic<int> failures_{0};
 public:
     static DumpQueue& get() { static DumpQueue q; return q; }
+    void report_failure() { failures_.fetch_add(1); }      // a job could not open / write its file: surfaced by failures() after drain() (voxelPS exits non-zero)
+    int failures() const { return failures_.load(); }
     void push(std::function<void()> job) {
         if (host_writers()) { job(); return; }
         std::lock_guard<std::mutex> l(m_);
@@ -240,27 +244,32 @@ inline RankInfo& rank_info() { static RankInfo r; return r; }
 inline bool multi_rank() { return rank_info().n > 1; }
 inline bool lead_rank() { return rank_info().rank == 0; }
 // k numbers of every rank -> the sums over the ranks in front of this one, and over all
-inline bool scan_over_ranks(psgsdf_ctx* ctx, const std::vector<double>& mine, std::vector<double>& before, std::vector<double>& total) {
-    const RankInfo& ri = rank_info(); const size_t k = mine.size();
-    std::vector<double> all(k * (size_t)ri.n, 0.0);
-    for (size_t i = 0; i < k; ++i) all[k * (size_t)ri.rank + i] = mine[i];
+// `local_ok` = false: this rank failed in front of the collective.  It STILL enters it (a rank that returned early left the others blocked in the
+// all-reduce: ADVICE r05) and its flag travels as one more summed element, so that every rank returns false together.
+inline bool scan_over_ranks(psgsdf_ctx* ctx, const std::vector<double>& mine, std::vector<double>& before, std::vector<double>& total, bool local_ok = true) {
+    const RankInfo& ri = rank_info(); const size_t k = mine.size(), k1 = k + 1;
+    std::vector<double> all(k1 * (size_t)ri.n, 0.0);
+    for (size_t i = 0; i < k; ++i) all[k1 * (size_t)ri.rank + i] = local_ok ? mine[i] : 0.0;
+    all[k1 * (size_t)ri.rank + k] = local_ok ? 0.0 : 1.0;
     if (psgsdf_comm_allreduce_host(ctx, all.data(), (int)all.size())) return false;
     before.assign(k, 0.0); total.assign(k, 0.0);
-    for (int r = 0; r < ri.n; ++r) for (size_t i = 0; i < k; ++i) { if (r < ri.rank) before[i] += all[k * (size_t)r + i]; total[i] += all[k * (size_t)r + i]; }
-    return true;
+    double failed = 0.0;
+    for (int r = 0; r < ri.n; ++r) { for (size_t i = 0; i < k; ++i) { if (r < ri.rank) before[i] += all[k1 * (size_t)r + i]; total[i] += all[k1 * (size_t)r + i]; } failed += all[k1 * (size_t)r + k]; }
+    return failed == 0.0;
 }
 inline size_t bytes_of(const std::vector<TextOut>& parts) { size_t b = 0; for (auto& p : parts) b += p.s.size(); return b; }
 struct FilePiece { long long offset; std::shared_ptr<std::vector<TextOut>> parts; };
 // this rank's pieces of a file all ranks write: rank 0 also owns the header and the file's final length
 inline void write_shared_file(const std::string& file, const std::string& header, long long total_bytes, std::vector<FilePiece> pieces) {
     DumpQueue::get().push([=] {
-        const int fd = open(file.c_str(), O_CREAT | O_WRONLY, 0644);
-        if (fd < 0) { std::cerr << "couldn't open " << file << std::endl; return; }
+        const int fd = open(file.c_str(), O_CREAT | O_WRONLY, 0644);      // (no O_TRUNC: the other ranks write their pieces into the same file at the same time; the lead rank sets the final length)
+        if (fd < 0) { std::cerr << "couldn't open " << file << std::endl; DumpQueue::get().report_failure(); return; }
         auto put = [&](const char* p, size_t n, long long at) { while (n) { const ssize_t k = pwrite(fd, p, n, (off_t)at); if (k <= 0) { std::cerr << "couldn't write " << file << std::endl; return false; } p += k; n -= (size_t)k; at += k; } return true; };
         bool ok = true;
         if (lead_rank()) ok = put(header.data(), header.size(), 0) && ftruncate(fd, (off_t)total_bytes) == 0;
         for (auto& pc : pieces) { long long at = pc.offset; for (auto& t : *pc.parts) { if (ok && !t.s.empty()) ok = put(t.s.data(), t.s.size(), at); at += (long long)t.s.size(); } }
-        close(fd);
+        if (close(fd) != 0) ok = false;
+        if (!ok) DumpQueue::get().report_failure();      // (this rank's piece is missing from a file the other ranks completed: the run reports it, voxelps_main.cpp)
     });
 }
 
@@ -367,10 +376,11 @@ struct VolumetricGradSdf {
     // the device-side extraction (include/psgsdf.h psgsdf_extract_*): compact arrays come back, a copy of them goes to the background writer
     static bool device_mesh(psgsdf_ctx* ctx, const std::string& file) {
         const float* xyz = nullptr; const uint8_t* rgb = nullptr; int64_t nv = 0;
-        if (psgsdf_extract_mesh(ctx, &xyz, &rgb, &nv)) return false;
+        const bool ok = psgsdf_extract_mesh(ctx, &xyz, &rgb, &nv) == 0;
+        if (!ok) nv = 0;
         if (multi_rank()) {
             std::vector<double> before, total;
-            if (!scan_over_ranks(ctx, {(double)nv}, before, total) || total[0] == 0) return false;
+            if (!scan_over_ranks(ctx, {(double)nv}, before, total, ok) || total[0] == 0) return false;
             auto V = std::make_shared<std::vector<TextOut>>(format_lines((size_t)nv, 40, [&](TextOut& o, size_t i) { mesh_vertex_line(o, xyz, rgb, i); }));
             const size_t face0 = (size_t)before[0] / 3;      // (faces are numbered through the whole file)
             auto F = std::make_shared<std::vector<TextOut>>(format_lines((size_t)nv / 3, 24, [&](TextOut& o, size_t q) { mesh_face_line(o, face0 + q); }));
@@ -380,42 +390,46 @@ struct VolumetricGradSdf {
             write_shared_file(file, h, (long long)(h.size() + bt[0] + bt[1]), {{(long long)(h.size() + bb[0]), V}, {(long long)(h.size() + bt[0] + bb[1]), F}});
             return true;
         }
-        if (nv == 0) return false;
+        if (!ok || nv == 0) return false;
         auto vx = std::make_shared<std::vector<float>>(xyz, xyz + 3 * nv); auto vc = std::make_shared<std::vector<uint8_t>>(rgb, rgb + 3 * nv);
         DumpQueue::get().push([=] { if (!write_mesh_ply(file, vx->data(), vc->data(), (size_t)nv)) std::cout << "couldn't save mesh " << file << std::endl; });
         return true;
     }
     static bool device_pointcloud(psgsdf_ctx* ctx, int which, const std::string& file) {
         const float* pn = nullptr; const int32_t* col = nullptr; int64_t n = 0;
-        if (psgsdf_extract_pointcloud(ctx, which, &pn, &col, &n)) return false;
+        const bool ok = psgsdf_extract_pointcloud(ctx, which, &pn, &col, &n) == 0;
+        if (!ok) n = 0;
         if (multi_rank()) {
             auto L = std::make_shared<std::vector<TextOut>>(format_lines((size_t)n, 80, [&](TextOut& o, size_t i) { pointcloud_line(o, pn, col, i); }));
             std::vector<double> before, total;
-            if (!scan_over_ranks(ctx, {(double)n, (double)bytes_of(*L)}, before, total)) return false;
+            if (!scan_over_ranks(ctx, {(double)n, (double)bytes_of(*L)}, before, total, ok)) return false;
             const std::string h = pointcloud_header((size_t)total[0]);
             write_shared_file(file, h, (long long)(h.size() + total[1]), {{(long long)(h.size() + before[1]), L}});
             return true;
         }
+        if (!ok) return false;
         auto vp = std::make_shared<std::vector<float>>(pn, pn + 6 * n); auto vc = std::make_shared<std::vector<int32_t>>(col, col + 3 * n);
         DumpQueue::get().push([=] { if (!write_pointcloud_ply(file, vp->data(), vc->data(), (size_t)n)) std::cout << " can't save point cloud!" << std::endl; });
         return true;
     }
     static bool device_sdf(psgsdf_ctx* ctx, const std::string& file, float vs) {
         int32_t lo[3], dim[3]; const float* v = nullptr;
-        if (psgsdf_extract_sdf(ctx, lo, dim, &v)) return false;
+        bool ok = psgsdf_extract_sdf(ctx, lo, dim, &v) == 0;
         if (multi_rank()) {
-            if (dim[0] == 0) return false;
-            int32_t mi[12]; if (psgsdf_mg_info(ctx, mi)) return false;
+            int32_t mi[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok && psgsdf_mg_info(ctx, mi)) ok = false;
+            if (!ok) dim[0] = dim[1] = dim[2] = lo[0] = lo[1] = lo[2] = 0;
             const size_t cnt = (size_t)dim[0] * dim[1] * (size_t)std::max(0, std::min(lo[2] + dim[2], mi[11]) - std::max(lo[2], mi[10]));      // the planes of the box this rank owns
             auto L = std::make_shared<std::vector<TextOut>>(format_lines(cnt, 12, [&](TextOut& o, size_t i) { o.f(v[i]); o.c('\n'); }));
             std::vector<double> before, total;
-            if (!scan_over_ranks(ctx, {(double)bytes_of(*L)}, before, total)) return false;
+            if (!scan_over_ranks(ctx, {(double)bytes_of(*L)}, before, total, ok)) return false;
+            if (dim[0] == 0) return false;      // (the crop box is the whole volume's: empty on every rank alike)
             const int l3[3] = {lo[0], lo[1], lo[2]}, d3[3] = {dim[0], dim[1], dim[2]};
             const std::string h = sdf_header(l3, d3, vs);
             write_shared_file(file, h, (long long)(h.size() + total[0]), {{(long long)(h.size() + before[0]), L}});
             return true;
         }
-        if (!v) return false;
+        if (!ok || !v) return false;
         auto vv = std::make_shared<std::vector<float>>(v, v + (size_t)dim[0] * dim[1] * dim[2]);
         const std::array<int, 3> l{lo[0], lo[1], lo[2]}, d{dim[0], dim[1], dim[2]};
         DumpQueue::get().push([=] { write_sdf_block(file, l.data(), d.data(), vs, vv->data()); });

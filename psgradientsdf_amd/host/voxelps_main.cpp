@@ -359,6 +359,8 @@ int main(int argc, char* argv[]) {
     vOpt->init();
     vOpt->alternatingOptimize(light, albedo, distance, pose);
     DumpQueue::get().drain();
+    const int write_failures = DumpQueue::get().failures();      // (a rank whose piece of a shared output file could not be written: the file has a hole where it belongs)
+    if (write_failures) std::cerr << "rank " << rank_info().rank << ": " << write_failures << " output file piece(s) could not be written" << std::endl;
     delete vOpt; delete pOpt; delete tSDF; delete loader; delete opt_set_;
     if (!timing_file.empty() && lead_rank()) {
         char extra[256];
@@ -366,5 +368,5 @@ int main(int argc, char* argv[]) {
                  (size_t)(last == (size_t)-1 ? 0 : last - first + 1), keyframes.size());
         StageClock::get().write_json(timing_file, extra);
     }
-    return 0;
+    return write_failures ? 1 : 0;
 }

@@ -18,7 +18,9 @@ sys.path.insert(0, ROOT)
 from psgradientsdf_amd import capi, synth  # noqa: E402
 from oracle import oracle  # noqa: E402
 
-CASES = {"SH1": dict(N=24, F=4, W=96, H=72), "SH2": dict(N=24, F=4, W=96, H=72), "LED": dict(N=24, F=4, W=96, H=72)}
+# SH2 with twelve keyframes: with fewer than ~ten the reference's global light solve (9 unknowns per keyframe, cond ~2e4) uses up its 2n passes at a residual of
+# 1e-4 .. 1e-6, reports NoConvergence and applies a step that depends on the last bit of its inputs -- a legitimate course of the reference, and a useless fixture
+CASES = {"SH1": dict(N=24, F=4, W=96, H=72), "SH2": dict(N=24, F=12, W=96, H=72), "LED": dict(N=24, F=4, W=96, H=72)}
 
 
 def run(model):

@@ -10,7 +10,7 @@ import pytest
 from psgradientsdf_amd import capi, synth
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASE = dict(N=24, F=4, W=96, H=72)
+CASES = {"SH1": dict(N=24, F=4, W=96, H=72), "SH2": dict(N=24, F=12, W=96, H=72), "LED": dict(N=24, F=4, W=96, H=72)}      # (tests/golden/make_golden.py: why SH2 has twelve keyframes)
 
 
 def _run(api):
@@ -41,7 +41,7 @@ def _check(model, api, sc, tol_d, tol_e):
 @pytest.mark.parametrize("model", ["SH1", "SH2", "LED"])
 def test_oracle_reproduces_golden(built, model):
     from oracle import oracle
-    sc = synth.make_scene(model=model, **CASE)
+    sc = synth.make_scene(model=model, **CASES[model])
     o = oracle.Oracle(sc, sc.K, capi.default_settings(sc.model_id, reg_weight_l=1.0), solver_mode=1); o.load_scene(sc)
     _check(model, o, sc, 1e-6, 1e-6)
 
@@ -50,10 +50,10 @@ def test_oracle_reproduces_golden(built, model):
 @pytest.mark.parametrize("solver", ["eigen", "ldlt"])
 @pytest.mark.parametrize("model", ["SH1", "SH2", "LED"])
 def test_engine_reproduces_golden(built, model, solver):
-    sc = synth.make_scene(model=model, **CASE)
+    sc = synth.make_scene(model=model, **CASES[model])
     e = capi.load_engine(sc, sc.K, capi.default_settings(sc.model_id, reg_weight_l=1.0), 0)
     e.set_frame_solver(1 if solver == "eigen" else 0)
     e.load_scene(sc)
-    # SH2 (either solver): the 9 x 9 light blocks' condition number (~2e4) times the 1e-8 between the two sides' float normal equations; four keyframes:
-    # the reference's light CG ends on NoConvergence after its 2n = 72 passes (tests/test_parity_gpu.py LIGHT_RTOL_EIGEN has the measurement)
+    # SH2 (either solver): the 9 x 9 light blocks' condition number (~2e4) times the 1e-8 between the two sides' float normal equations
+    # (tests/test_parity_gpu.py LIGHT_RTOL_EIGEN has the measurement)
     _check(model, e, sc, 1e-3 if model == "SH2" else 1e-4, 2e-3 if model == "SH2" else 2e-4)

@@ -170,14 +170,14 @@ def test_optimize_matches_oracle(built, margins, name, mid, solver):
     kw = dict(upsample=1, max_it=18, conv_threshold=0.0, damping=10.0)      # (damping 10: the loop survives its divergence test up to the refinement on these scenes)
     if mid == capi.LED:
         kw.update(reg_weight_n=0.1, reg_weight_l=5.0)                       # config_basket_LED.json's regularisers
-    sc, eng, orc = make_pair(name, mid, N=24, F=5, solver=solver, **kw)
+    sc, eng, orc = make_pair(name, mid, N=24, F=12 if name == "SH2" else 5, solver=solver, **kw)      # (SH2: enough keyframes for the reference's own light solve to converge, tests/golden/make_golden.py)
     (re_, ce), (ro, co) = eng.optimize(capi.ALL), orc.optimize(capi.ALL)
     assert len(re_) == len(ro) >= 6 and ce == co
     assert [(r["converged"], r["diverged"], r["upsampled"]) for r in re_] == [(r["converged"], r["diverged"], r["upsampled"]) for r in ro]
     assert sum(r["upsampled"] for r in re_) == 1 and re_[5]["upsampled"] == 1
     for a, b in zip(re_, ro):
         assert abs(a["e_total"] - b["e_total"]) <= 1e-4 * abs(b["e_total"]), (a["e_total"], b["e_total"])
-        assert np.allclose(a["e_after"], b["e_after"], rtol=1e-3 if (name, solver) == ("SH2", "eigen") else 2e-4), (a["e_after"], b["e_after"])      # (SH2 / eigen, five keyframes: a light solve that ends on NoConvergence, see LIGHT_RTOL_EIGEN)
+        assert np.allclose(a["e_after"], b["e_after"], rtol=2e-4), (a["e_after"], b["e_after"])
         assert a["cg_iters"] == b["cg_iters"]
         assert abs(a["reg_weight_l"] - b["reg_weight_l"]) <= 1e-4 * abs(b["reg_weight_l"]) and abs(a["reg_weight_n"] - b["reg_weight_n"]) <= 1e-5 * abs(b["reg_weight_n"])
     assert tuple(eng.info().dim) == tuple(orc.info().dim) == (48, 48, 48)
