@@ -24,9 +24,31 @@
 // Floating-point contraction: ON for the Jacobian / normal-equation algebra (FMA: fewer instructions, one rounding
 // less), OFF inside the functions whose results feed discrete decisions or must match the CPU reference build bit for
 // bit (baseline x86-64, no FMA): normalisation, the surface point, the projection (floor / in-image test), FD gradient.
+// PSG_STRICT (development builds only: `make strict STRICT=<mask>` -> libpsgsdf_strict<mask>.so; the product library is built with 0): every deviation of the
+// device arithmetic from the reference's can be switched off, bit by bit, to measure what it contributes to the
+// drift of a whole optimisation (tools/deviations.py, profiles/r06_notes.md):
+//   1  no FMA contraction anywhere in the per-observation algebra (the oracle -- and the reference's baseline x86-64 build -- has none)
+//   2  the robust weights / losses with IEEE divisions and logf, `r / lambda` as Optimizer.cpp:140-186 writes it (not r * (1 / lambda), v_rcp_f32, v_log_f32)
+//   4  bilinear weights partly in double as Auxilary.h:47 evaluates them, 1 / z through double (OptimizerAux.cpp:219)
+//   8  sums over a voxel's / a thread's observations in double (the oracle's accumulators) instead of float
+//  16  the Jacobian chains in the reference's order of evaluation: image_grad x pi_grad first, then R^T, then the direction (PsOptimizerJa.cpp:78-100,
+//      160-289; LedOptimizerJa.cpp:117-218), the SH2 / LED shading terms per channel and stencil slot -- not contracted from the right
+// (The solver of the light / pose blocks and the recurrences of the distance solve are run-time switches: PSGSDF_FRAME_SOLVE, PSGSDF_PCG_PIPELINE / _PERSIST.)
+#ifndef PSG_STRICT
+#define PSG_STRICT 0
+#endif
+#if PSG_STRICT & 1
+#pragma clang fp contract(off)
+#else
 #pragma clang fp contract(fast)
+#endif
 
 namespace psg {
+#if PSG_STRICT & 8
+typedef double obs_acc_t;      // accumulator of a sum over observations
+#else
+typedef float obs_acc_t;
+#endif
 
 // ------------------------------------------------------------------------------------------
 // small device helpers
@@ -83,6 +105,15 @@ template <int MODEL> struct ModelTraits { static constexpr int NB = MODEL == 1 ?
 // decided at run time -- six wavefront-uniform switches per observation cost the sweeps 3-4 us each
 template <int LOSS = -1>
 __device__ __forceinline__ float robust_weight(const Robust& rb, float r) {
+#if PSG_STRICT & 2
+    switch (LOSS >= 0 ? LOSS : rb.loss) {      // Optimizer.cpp:140-161 as written
+        case 1: { float x = r / rb.lambda; return 1.0f / (1.0f + x * x); }
+        case 3: { float x = r / rb.lambda; float w = (1.0f - x * x); w = w * w; return (r * r < rb.lambda_sq) ? w : 0.0f; }
+        case 2: { float w = rb.lambda * fabsf(1.0f / r); return (r * r < rb.lambda_sq) ? 1.0f : w; }
+        case 4: return (r * r < rb.lambda_sq) ? 1.0f : 0.0f;
+        default: return 1.0f;
+    }
+#endif
     switch (LOSS >= 0 ? LOSS : rb.loss) {
         case 1: { float x = r * rb.inv_lambda; return __builtin_amdgcn_rcpf(1.0f + x * x); }   // v_rcp_f32: 1 ulp
         case 3: { float x = r * rb.inv_lambda; float w = (1.0f - x * x); w = w * w; return (r * r < rb.lambda_sq) ? w : 0.0f; }
@@ -93,6 +124,15 @@ __device__ __forceinline__ float robust_weight(const Robust& rb, float r) {
 }
 template <int LOSS = -1>
 __device__ __forceinline__ float robust_loss(const Robust& rb, float r) {
+#if PSG_STRICT & 2
+    switch (LOSS >= 0 ? LOSS : rb.loss) {      // Optimizer.cpp:164-186 as written
+        case 1: { float x = r / rb.lambda; return logf(1.0f + x * x); }
+        case 3: { float x = r / rb.lambda; float u = 1.0f - x * x; float v = 1.0f - u * u * u; return (r * r < rb.lambda_sq) ? v : 1.0f; }
+        case 2: return (r * r < rb.lambda_sq) ? 0.5f * (r * r) : rb.lambda * (fabsf(r) - 0.5f * rb.lambda * 1.0f);
+        case 4: { float x = fminf(fmaxf(r, -rb.lambda), rb.lambda); return x * x; }
+        default: return r * r;
+    }
+#endif
     switch (LOSS >= 0 ? LOSS : rb.loss) {
         case 1: { float x = r * rb.inv_lambda; return __builtin_amdgcn_logf(1.0f + x * x) * 0.693147180559945f; }   // v_log_f32 (argument >= 1: no denormal scaling) x ln 2: 2 instructions instead of logf's 13, <= 2 ulp
         case 3: { float x = r * rb.inv_lambda; float u = 1.0f - x * x; float v = 1.0f - u * u * u; return (r * r < rb.lambda_sq) ? v : 1.0f; }
@@ -159,8 +199,8 @@ __device__ __forceinline__ void wave_sum8_store(double t0, double t1, double* re
     if (lane < 4) { const int base = 4 * (lane & 1) + (lane & 2); red[base * NW + w] = t0; red[(base + 1) * NW + w] = t1; }
 }
 // NV wavefront sums of float accumulators, in double, eight at a time -> row[0..NV) (written by lanes 0..3)
-template <int NV>
-__device__ __forceinline__ void wave_sums_to(const float* acc, double* row) {
+template <int NV, class T>
+__device__ __forceinline__ void wave_sums_to(const T* acc, double* row) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int g = 0; g < (NV + 7) / 8; ++g) {
@@ -342,7 +382,11 @@ __device__ __forceinline__ Proj project(const float* xs, const FrameP& fp, const
     for (int i = 0; i < 3; ++i) o.p[i] = (fp.R[0 * 3 + i] * tmp[0] + fp.R[1 * 3 + i] * tmp[1]) + fp.R[2 * 3 + i] * tmp[2];
     // reference: (float)(1. / point[2]) evaluated in double (OptimizerAux.cpp:219); the correctly rounded float
     // reciprocal differs from that only in double-rounding corner cases (~1e-8 of all inputs)
+#if PSG_STRICT & 4
+    const float z_inv = (float)(1.0 / (double)o.p[2]);      // OptimizerAux.cpp:219
+#else
     const float z_inv = 1.0f / o.p[2];
+#endif
     o.z_inv = z_inv;
     o.m = cam.fx * o.p[0] * z_inv + cam.cx;
     o.n = cam.fy * o.p[1] * z_inv + cam.cy;
@@ -359,11 +403,27 @@ __device__ __forceinline__ const float* pix(const float* img, const Cam& cam, in
 // Auxilary.h:41-61 interpolateImage + Auxilary.h:64-123 computeImageGradient from one set of taps.
 // Output convention (col=m_col / row=n_row are the projected pixel coordinates): I = bilinear colour, gu = d/d(col), gv = d/d(row).
 template <bool GRAD>
-__device__ __forceinline__ void interp_taps(const float* a00, const float* a01, const float* a10, const float* a11, float fm, float fn, float gm, float gn, float* I, float* gu, float* gv) {   // (fm, fn): fractions of the colour's coordinates, (gm, gn): of the gradient's
+__device__ __forceinline__ void interp_taps(const float* a00, const float* a01, const float* a10, const float* a11, float fm, float fn, float gm, float gn, float* I, float* gu, float* gv,
+                                            float m = 0.f, float n = 0.f, int x = 0, int y = 0) {   // (fm, fn): fractions of the colour's coordinates (row, column), (gm, gn): of the gradient's; (m, n, x, y): the coordinates themselves (PSG_STRICT & 4)
+#if PSG_STRICT & 4
+    {   // Auxilary.h:41-61 as C++ evaluates it: `y + 1. - n` is double, `(m - x)` float -> three of the four weights are double products, rounded to float per tap
+#pragma clang fp contract(off)
+        const double w1 = ((double)y + 1.0 - (double)n) * (double)(m - (float)x);
+        const double w2 = ((double)y + 1.0 - (double)n) * ((double)x + 1.0 - (double)m);
+        const float w3 = (n - (float)y) * (m - (float)x);
+        const double w4 = (double)(n - (float)y) * ((double)x + 1.0 - (double)m);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float t1 = (float)((double)a10[ch] * w1), t2 = (float)((double)a00[ch] * w2), t3 = a11[ch] * w3, t4 = (float)((double)a01[ch] * w4);
+            I[ch] = ((t1 + t2) + t3) + t4;
+        }
+    }
+#else
     // reference: weights partly in double (Auxilary.h:47); float weights agree to ~1e-7 relative
     const float w1 = (1.0f - fn) * fm, w2 = (1.0f - fn) * (1.0f - fm), w3 = fn * fm, w4 = fn * (1.0f - fm);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) I[ch] = ((a10[ch] * w1 + a00[ch] * w2) + a11[ch] * w3) + a01[ch] * w4;
+#endif
     if (GRAD) {
         const float w01 = gm, w11 = gn, w00 = 1.0f - gm, w10 = 1.0f - gn;
 #pragma unroll
@@ -423,7 +483,7 @@ __device__ __forceinline__ void sample_cell(const float* base, int frame, bool i
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { a00[ch] = p00[ch]; a01[ch] = p00[3 + ch]; a10[ch] = p10[ch]; a11[ch] = p10[3 + ch]; }
         }
-        interp_taps<GRAD>(a00, a01, a10, a11, m - (float)x, n - (float)y, nj_row - (float)x, mj_col - (float)y, I, gu, gv);
+        interp_taps<GRAD>(a00, a01, a10, a11, m - (float)x, n - (float)y, nj_row - (float)x, mj_col - (float)y, I, gu, gv, m, n, x, y);
     } else {
         const float* img = base + (size_t)frame * cam.H * cam.W * 3;   // (64-bit multiply-adds issue at quarter rate: keep them on this rare path)
         auto tex = [&](int row, int col, float* o) { const float* q = pix(img, cam, row, col); o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; };
@@ -462,7 +522,7 @@ __device__ __forceinline__ void sample_u8_cell(const unsigned* base, float scale
         const unsigned t00 = p0[0], t01 = p0[1], t10 = p1[0], t11 = p1[1];
         float a00[3], a01[3], a10[3], a11[3];
         unpack_rgb8(t00, scale, a00); unpack_rgb8(t01, scale, a01); unpack_rgb8(t10, scale, a10); unpack_rgb8(t11, scale, a11);
-        interp_taps<GRAD>(a00, a01, a10, a11, m - (float)x, n - (float)y, nj_row - (float)x, mj_col - (float)y, I, gu, gv);
+        interp_taps<GRAD>(a00, a01, a10, a11, m - (float)x, n - (float)y, nj_row - (float)x, mj_col - (float)y, I, gu, gv, m, n, x, y);
     } else {
         const unsigned* img = base + (size_t)frame * cam.H * cam.W;
         auto tex = [&](int row, int col, float* o) {

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
     const int bid = vm_bid(a, 2, true);
     int j = a.row0 + bid * blockDim.x + threadIdx.x;
     double E = 0, nobs = 0, sI[3] = {0, 0, 0}, sR[3] = {0, 0, 0};
-    float Ef = 0.f;
+    obs_acc_t Ef = 0;
     if (j < a.row1) {
         Vox v; load_vox(b, j, v);
         float shfd[kMaxBasis];
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(kBlock) k_energy(SweepArgs a) {
                 float l = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) l += robust_loss<LOSS>(a.rob, I[ch] - ren[ch]);
-                Ef += l; nobs += 1.0;
+                Ef += (obs_acc_t)l; nobs += 1.0;
             }
         }
     }
@@ -104,8 +104,8 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
         Vox v; load_vox(b, j, v);
         float shfd[kMaxBasis], shg[kMaxBasis];
         if (!ModelTraits<MODEL>::LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
-        float Hd[3] = {0, 0, 0}, bd[3] = {0, 0, 0};
-        float Ef = 0.f; int nobs_i = 0;
+        obs_acc_t Hd[3] = {0, 0, 0}, bd[3] = {0, 0, 0};
+        obs_acc_t Ef = 0; int nobs_i = 0;
         FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
             const FrameP& fp = frame_at(sf, f);
             Proj pr = project(v.xs, fp, a.cam);
@@ -119,10 +119,10 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
             for (int ch = 0; ch < 3; ++ch) {
                 float r = I[ch] - ren[ch]; float w = robust_weight<LOSS>(a.rob, r);
                 float jw = J[ch] * w;
-                Hd[ch] += jw * J[ch]; bd[ch] += jw * r;
+                Hd[ch] += (obs_acc_t)(jw * J[ch]); bd[ch] += (obs_acc_t)(jw * r);
                 l += robust_loss<LOSS>(a.rob, r);
             }
-            Ef += l; nobs_i += 1;
+            Ef += (obs_acc_t)l; nobs_i += 1;
         }
         E = (double)Ef; nobs = (double)nobs_i;
         if (a.fuse_apply) {   // the system is diagonal and the voxel's albedo is read by this thread only: k_apply_albedo's arithmetic, here
@@ -134,15 +134,15 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
             }
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                float h = Hd[ch];
+                float h = (float)Hd[ch];
                 if (a.damping != 0.0f) h += a.damping * h;
-                const float delta = (h != 0.f) ? bd[ch] / h : 0.f;
+                const float delta = (h != 0.f) ? (float)bd[ch] / h : 0.f;
                 const float nv = v.rho[ch] - delta;
                 if (nv > 0.0f && nv < 1.0f) { set_rho(b, j, ch, nv); cnt += 1.0; }
             }
         } else {
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) { b.aH[(size_t)ch * b.Spad + j] = Hd[ch]; b.ab[(size_t)ch * b.Spad + j] = bd[ch]; }
+            for (int ch = 0; ch < 3; ++ch) { b.aH[(size_t)ch * b.Spad + j] = (float)Hd[ch]; b.ab[(size_t)ch * b.Spad + j] = (float)bd[ch]; }
         }
     }
     block_part_store(E, PART(a, SC_ENERGY), red, bid);
@@ -461,9 +461,9 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
     ImgSrc img = a.im;                       // this frame's image as frame 0 of its own stack (offsets always fit 32 bits)
     if (img.u8) img.u8 += (size_t)f * a.cam.H * a.cam.W; else img.f32 += (size_t)f * a.cam.H * a.cam.W * 3;
     img.idx32 = true;
-    float acc[NV];
+    obs_acc_t acc[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+    for (int k = 0; k < NV; ++k) acc[k] = 0;
     const int beg = b.obs_ptr[f], end = b.obs_ptr[f + 1];
     // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
     // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
@@ -494,23 +494,39 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
             l += robust_loss<LOSS>(a.rob, r);
             if (LED) {
                 float J = refl * v.rho[ch]; float jw = J * w;
-                acc[ch] += jw * J; acc[NH + ch] += jw * r;
+                acc[ch] += (obs_acc_t)(jw * J); acc[NH + ch] += (obs_acc_t)(jw * r);
             } else {   // J_c = -rho_c SH(g): the three channels share the direction SH(g), so their normal equations are ONE outer product
+#if PSG_STRICT & 16
+                float Jc[kMaxBasis];      // the reference's order: one row per channel, J = -rho_c SH(g), H += (J w) J^T (PsOptimizerJa.cpp:132-143,323-371; oracle light_system)
+#pragma unroll
+                for (int i = 0; i < NB; ++i) Jc[i] = -v.rho[ch] * shg[i];
+                int q = 0;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const float jw = Jc[i] * w;
+#pragma unroll
+                    for (int k = i; k < NB; ++k) acc[q++] += (obs_acc_t)(jw * Jc[k]);
+                    acc[NH + i] += (obs_acc_t)(jw * r);
+                }
+#else
                 w2 += w * (v.rho[ch] * v.rho[ch]);
                 r1 -= w * (v.rho[ch] * r);
+#endif
             }
         }
+#if !(PSG_STRICT & 16)
         if (!LED) {    // H += (sum_c w_c rho_c^2) SH SH^T ; b += (-sum_c w_c rho_c r_c) SH   (lightJacobian, PsOptimizerJa.cpp:132-143,323-371)
             int q = 0;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const float sw = shg[i] * w2;
 #pragma unroll
-                for (int k = i; k < NB; ++k) acc[q++] += sw * shg[k];
-                acc[NH + i] += shg[i] * r1;
+                for (int k = i; k < NB; ++k) acc[q++] += (obs_acc_t)(sw * shg[k]);
+                acc[NH + i] += (obs_acc_t)(shg[i] * r1);
             }
         }
-        acc[NH + NB] += l; acc[NH + NB + 1] += 1.0f;
+#endif
+        acc[NH + NB] += (obs_acc_t)l; acc[NH + NB + 1] += 1;
     }
     // row layout: [NH H entries | NB rhs | energy | n_obs]
     const int w = threadIdx.x >> 6;
@@ -545,9 +561,9 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
     ImgSrc img = a.im;                       // this frame's image as frame 0 of its own stack (offsets always fit 32 bits)
     if (img.u8) img.u8 += (size_t)f * a.cam.H * a.cam.W; else img.f32 += (size_t)f * a.cam.H * a.cam.W * 3;
     img.idx32 = true;
-    float acc[NV];
+    obs_acc_t acc[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+    for (int k = 0; k < NV; ++k) acc[k] = 0;
     const int beg = b.obs_ptr[f], end = b.obs_ptr[f + 1];
     // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
     // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
@@ -573,11 +589,36 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
         // J_c = image_grad_c pi_grad [-R^T | skew(p)] (PsOptimizerJa.cpp:78-100), contracted from the right (device_common.h pi_rows):
         // J_c = gu_c [-U | a skew(p)] + gv_c [-V | b skew(p)] with the channel-independent rows written out (structural zeros dropped)
         const PiRows pi = pi_rows(a.cam, pr);
-        float U[3], V[3]; pi_rows_world(pi, fp.R, U, V);
         const float* p = pr.p;
+        float J[18];
+#if PSG_STRICT & 16
+        {   // the reference's order (PsOptimizerJa.cpp:78-100 / LedOptimizerJa.cpp:48-78; oracle pose_jacobian): G = image_grad pi_grad with its structural zeros, -G R^T, G skew(p)
+            float G[9];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) { G[ch * 3 + 0] = gu[ch] * pi.p00 + gv[ch] * 0.0f; G[ch * 3 + 1] = gu[ch] * 0.0f + gv[ch] * pi.p11; G[ch * 3 + 2] = gu[ch] * pi.p02 + gv[ch] * pi.p12; }
+            const float sk[9] = {0, -p[2], p[1], p[2], 0, -p[0], -p[1], p[0], 0};
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float sg = (G[ch * 3 + 0] * fp.R[k * 3 + 0] + G[ch * 3 + 1] * fp.R[k * 3 + 1]) + G[ch * 3 + 2] * fp.R[k * 3 + 2];
+                    J[ch * 6 + k] = -sg;
+                    J[ch * 6 + 3 + k] = (G[ch * 3 + 0] * sk[0 * 3 + k] + G[ch * 3 + 1] * sk[1 * 3 + k]) + G[ch * 3 + 2] * sk[2 * 3 + k];
+                }
+            if (LED) {
+                const float pn = norm3(p); const double pd = (double)pn; const float l3 = (float)(pd * pd * pd);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float sl = -(v.rho[ch] * fp.l[ch] / l3);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) J[ch * 6 + k] += sl * v.gn[k];
+                }
+            }
+        }
+#else
+        float U[3], V[3]; pi_rows_world(pi, fp.R, U, V);
         const float AS[3] = {-(pi.p02 * p[1]), pi.p02 * p[0] - pi.p00 * p[2], pi.p00 * p[1]};
         const float BS[3] = {pi.p11 * p[2] - pi.p12 * p[1], pi.p12 * p[0], -(pi.p11 * p[0])};
-        float J[18];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
@@ -595,6 +636,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
                 for (int k = 0; k < 3; ++k) J[ch * 6 + k] += s * v.gn[k];
             }
         }
+#endif
         float l = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -606,11 +648,11 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
             for (int i = 0; i < 6; ++i) {
                 float jw = J[ch * 6 + i] * w;
 #pragma unroll
-                for (int k = i; k < 6; ++k) acc[q++] += jw * J[ch * 6 + k];
-                acc[21 + i] += jw * r;
+                for (int k = i; k < 6; ++k) acc[q++] += (obs_acc_t)(jw * J[ch * 6 + k]);
+                acc[21 + i] += (obs_acc_t)(jw * r);
             }
         }
-        acc[27] += l; acc[28] += 1.0f;
+        acc[27] += (obs_acc_t)l; acc[28] += 1;
     }
     const int w = threadIdx.x >> 6;
     wave_sums_to<NV>(acc, lds + w * NV);   // row layout: [21 H | 6 rhs | energy | n_obs]
