@@ -42,6 +42,54 @@ from psgradientsdf_amd import capi, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+PMC_NAMES = {"k_cgf_solve": "pcg_solve", "k_cgp_solve": "pcg_solve", "k_cgf_pass": "pcg_pass", "k_cgf_init": "pcg_init", "k_sweep_dist": "sweep_dist", "k_sweep_pose": "sweep_pose",
+             "k_sweep_light": "sweep_light", "k_sweep_albedo": "sweep_albedo", "k_energy": "energy", "k_assemble": "assemble", "k_derive": "derive",
+             "k_frames_eigen": "solve_frames_eigen"}
+
+
+def live_traffic(args):
+    """HBM-side bytes per launch of the bench kernels, measured IN THIS RUN: two short child runs of this very command under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only -- no tracing domain next to them), 4 iterations each, corrected as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes (both counters in KiB; gfx950 tallies a 128-byte fetch as 64: FETCH_SIZE x 2).  None where rocprofv3
+    is missing, the run is itself being profiled, or PSGSDF_BENCH_LIVE_PMC=0 -- the line then falls back to the archived summary under its own label."""
+    import csv, re, shutil, subprocess, tempfile
+    from collections import defaultdict
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if (not exe or os.environ.get("PSGSDF_BENCH_LIVE_PMC") == "0" or os.environ.get("PSGSDF_BENCH_CHILD") == "1"
+            or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_LIBRARY_CTOR") or os.environ.get("ROCP_TOOL_LIBRARIES")):
+        return None
+    t0 = time.perf_counter()
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="psgsdf_pmc_", dir="/tmp")
+    env = dict(os.environ, PSGSDF_BENCH_CHILD="1", PSGSDF_BENCH_NO_SOLVE_MODEL="1", TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "1", "--reps", "1",
+                   "--no-cpu-baseline", "--no-breakdown", "--no-extra", "--grid", str(args.grid), "--frames", str(args.frames), "--width", str(args.width), "--height", str(args.height), "--model", args.model]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=float(os.environ.get("PSGSDF_BENCH_PMC_TIMEOUT_S", "240")))
+            path = next((os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")), None)
+            if r.returncode != 0 or not path:
+                return {"error": f"rocprofv3 --pmc {counter}: rc {r.returncode}, {r.stderr.decode(errors='replace')[-200:]}"}
+            acc = defaultdict(list)
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    mm = re.search(r"psg::(k_[a-z0-9_]+)", row.get("Kernel_Name", ""))
+                    if row.get("Counter_Name") == counter and mm and mm.group(1) in PMC_NAMES:
+                        acc[PMC_NAMES[mm.group(1)]].append(float(row["Counter_Value"]))
+            res[counter] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items() if v}
+    except Exception as ex:      # (a side measurement: never takes the line down)
+        return {"error": repr(ex)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    kernels = {}
+    for k in sorted(set(res.get("FETCH_SIZE", {})) | set(res.get("WRITE_SIZE", {}))):
+        f, nf = res["FETCH_SIZE"].get(k, (0.0, 0)); w, _ = res["WRITE_SIZE"].get(k, (0.0, 0))
+        kernels[k] = {"hbm_bytes_per_launch": (2.0 * f + w) * 1024.0, "launches": nf, "fetch_size_kib_raw": f, "write_size_kib_raw": w}
+    return {"kernels": kernels, "seconds": round(time.perf_counter() - t0, 1),
+            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two passes, counters only) around 4 iterations of this command, spawned by this run; FETCH_SIZE x2 (gfx950), KiB -> bytes; Infinity-Cache hits are counted"}
+
+
 def algorithmic_bytes(kernel, S, n_obs, W, H, F, laplacian=False, pcg_passes=1.0):
     """Algorithmic HBM bytes of ONE launch: per band voxel B_v = 60 B of state
     (dist 4, grad 12, rgb 12, vis 8, 3 stencil-neighbour dists 12, 3 row lookups 12; +12 with the Laplacian),
@@ -236,6 +284,10 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
         eng.set_profiling(False)
         kernels = {k: {"ms_per_iter": v[0] / nprof, "launches_per_iter": v[1] / nprof} for k, v in kt.items()}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_iter"] if algorithmic_bytes(k, 1, 1, 1, 1, 1) else -1)
+    kernels_per_rank = None
+    if dist is not None and headline and not args.no_breakdown:      # every rank's own breakdown: a measured N-GPU curve can be attributed kernel by kernel
+        kernels_per_rank = [None] * world
+        dist.all_gather_object(kernels_per_rank, {k: round(1e3 * v["ms_per_iter"], 1) for k, v in kernels.items()})
     watch = dom + ("/16" if dom == "pcg_pass" else "/4")   # HIP events around every 16th (4th) launch (each pair breaks the back-to-back dispatch: ~6 us of stream time)
     use_watch = headline and os.environ.get("PSGSDF_NO_WATCH") != "1"
     timing_iterate = args.loop == "iterate"
@@ -321,7 +373,7 @@ def measure(args, model, torch, dist, rank, world, device, slab, share, headline
                iterate_ms_per_step=1e3 * t_iter / args.steps, optimize_ms_per_step=(1e3 * t_opt / args.steps) if t_opt else None,
                kernels=kernels, dom=dom, watched=watched, t_gen=t_gen, st=st, sc=sc, sync_stats=sync_stats,
                collectives_per_step=(coll1 - coll0) / max(args.steps, 1), use_u8=use_u8, own_rows=own_rows,
-               scene_kw=scene_kw, solve_model=solve_model, tuning=tuning, make_context=lambda: context(st))
+               scene_kw=scene_kw, solve_model=solve_model, tuning=tuning, make_context=lambda: context(st), kernels_per_rank=kernels_per_rank)
     return res
 
 
@@ -361,6 +413,15 @@ def multi_gpu_block(m, check, world, share):
            "band_rows_per_rank": m["own_rows"],
            "exchange": "inside the kernels through IPC-mapped peer memory (distance solve, per-frame rows, scalar folds, halo rows); collectives_per_step counts what still went through the communicator",
            "self_check": check}
+    if m.get("kernels_per_rank"):
+        # per rank, microseconds per iteration from the synchronous-event pass (each launch bracketed by events and a host wait: ~4 us above rocprofv3's
+        # durations per launch; it ranks and attributes, it does not add up to ms_per_step).  The distance solve's launch / (passes + 1 prologue round) bounds
+        # the cross-rank pass from above (it still contains the assembly and the update: ~30 us on one GPU at the headline band).
+        blk["per_rank_kernels_us_per_iteration_sync_pass"] = m["kernels_per_rank"]
+        passes = m["cg_iters"] + 2.0
+        blk["cross_rank_solve"] = {"passes_per_solve": passes, "us_per_launch_per_rank": [k.get("pcg_solve", k.get("pcg_pass")) for k in m["kernels_per_rank"]],
+                                   "us_per_pass_upper_bound_per_rank": [round((k.get("pcg_solve") or 0.0) / passes, 2) if k.get("pcg_solve") else None for k in m["kernels_per_rank"]],
+                                   "one_gpu_reference": "7.0 us per pass + 30 us fixed on one MI355X at the 256^3 band (roofline.us_per_pass / fixed_us of the N = 1 line); DESIGN.md section 7.5 has the predicted curve"}
     checks_ok = all(c["ok"] for c in (check if isinstance(check, list) else [check]) if c)
     return blk, bool(not ss["cross_rank_ready"] or ss["persist_fallbacks"] > 0 or not checks_ok)
 
@@ -602,12 +663,18 @@ def main():
         except OSError:
             src_hash = None
         stale = lambda j: None if not (j and j.get("source_hash") and src_hash) else bool(j["source_hash"] != src_hash)
-        if os.path.exists(pmc) and (args.grid, args.frames, args.model, world) == (256, 50, "SH1", 1):   # the counters were collected on this configuration
+        live = live_traffic(args) if (world == 1 and not slab and not args.no_breakdown) else None
+        if live and live.get("kernels", {}).get(dom):
+            pj = dict(live["kernels"])
+            traffic = pj[dom]["hbm_bytes_per_launch"]
+            traffic_src = f"live: {live['how']} ({live['seconds']} s, {pj[dom]['launches']} launches of {dom})"
+            out["pmc_live"] = live
+        elif os.path.exists(pmc) and (args.grid, args.frames, args.model, world) == (256, 50, "SH1", 1):   # the counters were collected on this configuration
             try:
                 pj = json.load(open(pmc))
                 traffic = (pj.get(dom) or {}).get("hbm_bytes_per_launch")
                 traffic_src = (f"static: profiles/pmc_summary.json @{pj.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x2 (gfx950), KiB -> bytes); "
-                               f"not re-measured in this run; engine sources changed since it was collected: {stale(pj)}")
+                               f"not re-measured in this run ({(live or {}).get('error') or 'rocprofv3 not available / live pass switched off'}); engine sources changed since it was collected: {stale(pj)}")
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -648,7 +715,7 @@ def main():
             per_iter = ("pcg_solve", "sweep_dist", "sweep_pose", "sweep_light", "sweep_albedo", "derive")
             cb = sum((pj.get(k) or {}).get("hbm_bytes_per_launch", 0.0) for k in per_iter)
             out["iteration"].update({"counter_bytes": cb, "counter_frac_of_hbm_peak": cb * (m["value"] / world) / 1e9 / HBM_PEAK_GBS,
-                                     "counter_source": f"static: profiles/pmc_summary.json @{pj.get('commit', '?')}, kernels {', '.join(per_iter)}; sources changed since: {stale(pj)}"})
+                                     "counter_source": (f"live (pmc_live), kernels {', '.join(per_iter)}" if "pmc_live" in out else f"static: profiles/pmc_summary.json @{pj.get('commit', '?')}, kernels {', '.join(per_iter)}; sources changed since: {stale(pj)}")})
         if kernels:
             # A SYNCHRONOUS-event pass over psgsdf_iterate (every launch bracketed by an event pair and a host wait: ~4 us of overhead per launch, and
             # `energy`, which the product loop folds into the next sweep, runs as a kernel of its own here): it ranks the kernels, it does not add
@@ -664,6 +731,9 @@ def main():
             # per-kernel roofline fractions from the same synchronous-event pass (events add ~4 us per launch: fractions err low)
             out["kernel_roofline_frac"] = {k: round(algorithmic_bytes(k, S, n_obs, args.width, args.height, args.frames, lap, pcg_passes=cg_iters + 1.0) / (v["ms_per_iter"] / max(v["launches_per_iter"], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
                                            for k, v in kernels.items() if algorithmic_bytes(k, 1, 1, 1, 1, 1) and v["ms_per_iter"] > 0}
+        out["config"]["frame_solver"] = m["tuning"]["effective"].get("frame_solve", "ldlt") + (
+            " (light / pose blocks: every frame's block solved directly, LDL^T in double, inside the sweep; the reference's own solver -- ONE global float Jacobi-PCG, PSGSDF_FRAME_SOLVE=eigen -- is measured under extra.reference_frame_solver)"
+            if m["tuning"]["effective"].get("frame_solve", "ldlt") == "ldlt" else " (the reference's solver of the light / pose blocks: one global float Jacobi-PCG over all frames, csrc/frame_solve.hip)")
         out["sync_stats"] = m["sync_stats"]      # scalar read-backs validated / found late / persistent-solve fallbacks in this run (include/psgsdf.h)
         out["tuning"] = {"build": m["tuning"]["build"], "env": m["tuning"]["env"], "ignored_dev_only": m["tuning"]["ignored_dev_only"]}      # psgsdf_get_tuning: every PSGSDF_* knob that was in force
         out["setup_s"] = {"scene_generation": round(m["t_gen"], 1)}
@@ -727,6 +797,25 @@ def main():
         extra["SH1_png_like_float_keyframes"] = {"value": e["value"], "unit": "it/s", "ms_per_step": e["ms_per_step"],
                                                  "note": "keyframes quantised to 8 bits, passed through psgsdf_set_keyframes (float); held as RGBA8 words (PSGSDF_IMG_COMPACT)"}
         del e
+        # ---- the same three workloads with the REFERENCE's solver of the light / pose blocks (PSGSDF_FRAME_SOLVE=eigen: one global float Jacobi-PCG over all
+        # frames' blocks in a kernel of its own behind the sweep, csrc/frame_solve.hip) -- what exact solver fidelity costs
+        if os.environ.get("PSGSDF_FRAME_SOLVE") is None:
+            import copy
+            fs = {}
+            a3 = copy.copy(args); a3.reps = min(args.reps, 3)
+            os.environ["PSGSDF_FRAME_SOLVE"] = "eigen"
+            try:
+                for mod in ("SH1", "LED", "SH2"):
+                    e = measure(a3, mod, torch, dist, rank, world, device, slab, share, headline=False)
+                    assert e["tuning"]["effective"].get("frame_solve") == "eigen"
+                    base = out["value"] if mod == "SH1" else extra[mod]["value"]
+                    fs[mod] = {"value": e["value"], "unit": "it/s", "ms_per_step": e["ms_per_step"], "vs_default_solver": e["value"] / base}
+                    del e
+            finally:
+                del os.environ["PSGSDF_FRAME_SOLVE"]
+            fs["note"] = ("Eigen's iteration counts on these scenes: light 42 (SH1) / 250-370 (SH2) / 0 (LED: a diagonal 3 x 3), pose 14; one workgroup, 3 barriers per pass. "
+                          "The default (direct block solves inside the sweeps) stays: the reference's solver costs more than 3 % on every model; parity against it is measured either way (tests/test_frame_solver_gpu.py, profiles/r06_parity_margins.json)")
+            extra["reference_frame_solver"] = fs
         # ---- the drop-in end to end: `voxelPS --config_file` with config_skorates.json's settings on the reference's demo frames
         # (tests/golden/sokrates_21), wall-clock of the whole process and its stages; "round4_path" = the same binary with --host-writers (dense
         # downloads, host marching cubes, iostream text, serial PNG decode): the files are byte for byte the same (tests/test_extract_gpu.py)

@@ -10,44 +10,53 @@ from psgradientsdf_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 
-def pair(sc, st):
+def pair(sc, st, solver="eigen"):
+    """engine and oracle on one scene; solver = "eigen": both solve the light / pose blocks as the reference does (one global float Jacobi-PCG:
+    psgsdf_set_frame_solver(1) / the oracle's solver_mode 1), "ldlt": the engine as shipped against the oracle's direct solves"""
     from oracle import oracle
-    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=4)
+    eng = capi.load_engine(sc, sc.K, st, 0); orc = oracle.Oracle(sc, sc.K, st, threads=4, solver_mode=1 if solver == "eigen" else 0)
+    if solver == "eigen":
+        eng.set_frame_solver(1)
     for api in (eng, orc):
         api.load_scene(sc)
     return eng, orc
 
 
-def compare(eng, orc, sc, iters=2, tol=2e-4, flags=capi.ALL):
+def compare(eng, orc, sc, iters=2, tol=2e-4, flags=capi.ALL, margins=None, max_vs=1e-4):
+    """round 6: EVERY band voxel within the north star's 1e-4 voxel (round 5 asserted q999 <= 2e-4 and max <= 1e-2), what was achieved on record"""
+    from conftest import sdf_margin
     for api in (eng, orc):
         api.init_albedo(); api.normalize_weights()
     re_, ro = eng.iterate(flags, iters), orc.iterate(flags, iters)
     band = eng.download_band()
     assert np.array_equal(band, orc.download_band())
+    e_rel = max(abs(a["e_total"] - b["e_total"]) / (abs(b["e_total"]) + 1e-300) for a, b in zip(re_, ro))
     for a, b in zip(re_, ro):
         assert abs(a["e_total"] - b["e_total"]) <= tol * abs(b["e_total"]) + 1e-12, (a["e_total"], b["e_total"])
     if len(band):
         ve, vo = eng.download_volume(), orc.download_volume()
-        d = np.abs(ve["dist"][band] - vo["dist"][band]) / float(sc.voxel_size)
-        assert np.quantile(d, 0.999) <= 2e-4 and d.max() <= 1e-2
+        m = sdf_margin(ve["dist"], vo["dist"], band, float(sc.voxel_size))
+        if margins:
+            margins(sdf=m, e_total_rel=float(e_rel), rgb=float(np.abs(ve["rgb"][:, band] - vo["rgb"][:, band]).max()), tolerance={"max_vs": max_vs, "e_total_rel": tol})
+        assert m["q999_vs"] <= 1e-4 and m["max_vs"] <= max_vs, m
     return re_
 
 
-def test_two_visibility_words(built):
+def test_two_visibility_words(built, margins):
     sc = synth.make_scene(N=32, F=70, W=96, H=72, model="SH1")
     assert sc.vis_words == 2
     eng, orc = pair(sc, capi.default_settings(capi.SH1))
     assert eng.info().n_band == orc.info().n_band > 500
-    compare(eng, orc, sc)
+    compare(eng, orc, sc, margins=margins)
 
 
-def test_single_keyframe(built):
+def test_single_keyframe(built, margins):
     sc = synth.make_scene(N=32, F=1, W=128, H=96, model="SH1")
     eng, orc = pair(sc, capi.default_settings(capi.SH1))
-    compare(eng, orc, sc, iters=1)
+    compare(eng, orc, sc, iters=1, margins=margins)
 
 
-def test_keyframe_subset_of_the_sequence(built):
+def test_keyframe_subset_of_the_sequence(built, margins):
     """visibility is recorded per SEQUENCE frame; the optimiser uses a subset as keyframes (Optimizer.cpp:30-47 select_vis)"""
     sc = synth.make_scene(N=32, F=9, W=128, H=96, model="SH1")
     keep = np.array([1, 4, 7], np.int32)
@@ -57,10 +66,10 @@ def test_keyframe_subset_of_the_sequence(built):
         sub.light_gt = sc.light_gt[keep]
     eng, orc = pair(sub, capi.default_settings(capi.SH1))
     assert eng.info().n_frames == 3
-    compare(eng, orc, sub)
+    compare(eng, orc, sub, margins=margins)
 
 
-def test_tiny_and_empty_band(built):
+def test_tiny_and_empty_band(built, margins):
     sc = synth.make_scene(N=24, F=3, W=96, H=72, model="SH1")
     # tiny: keep the visibility of a handful of voxels only
     tiny = copy.copy(sc); tiny.vis = sc.vis.copy()
@@ -72,7 +81,7 @@ def test_tiny_and_empty_band(built):
     assert eng.info().n_band == orc.info().n_band == len(keep)
     # five isolated voxels cannot determine 4 light + 6 pose unknowns per frame (those blocks are singular to rounding): compare the
     # per-voxel blocks tightly, and only require the full iteration to run
-    compare(eng, orc, tiny, iters=1, tol=5e-4, flags=capi.ALBEDO | capi.DIST)
+    compare(eng, orc, tiny, iters=1, tol=5e-4, flags=capi.ALBEDO | capi.DIST, margins=margins)
     r = eng.iterate(capi.ALL, 1)
     assert len(r) == 1 and np.isfinite(r[0]["e_total"])
     # empty: nothing was ever seen
@@ -84,23 +93,30 @@ def test_tiny_and_empty_band(built):
     assert len(recs) == 1 and recs[0]["cg_iters"] == 0
 
 
-@pytest.mark.parametrize("loss", [0, 2, 3, 4])
-def test_other_robust_losses_led(built, loss):
-    sc = synth.make_scene(N=32, F=5, W=128, H=96, model="LED")
-    st = capi.default_settings(capi.LED, loss=loss)
+LOSSES = {0: "L2", 2: "Huber", 3: "Tukey", 4: "truncated L2"}      # (1 = Cauchy: every shipped config, every other test)
+
+
+@pytest.mark.parametrize("name,mid", [("SH1", capi.SH1), ("SH2", capi.SH2), ("LED", capi.LED)])
+@pytest.mark.parametrize("loss", sorted(LOSSES))
+def test_other_robust_losses(built, margins, loss, name, mid):
+    """computeWeight / computeLoss (Optimizer.cpp:140-186) for L2, Huber, Tukey and truncated L2 on ALL three shading models (round 5: LED only): the
+    run-time-loss instances of every sweep (the compiled-in one is Cauchy), two iterations, every band voxel.  Twelve keyframes: enough for the reference's
+    SH2 light solve to converge (tests/golden/make_golden.py)."""
+    sc = synth.make_scene(N=32, F=12, W=128, H=96, model=name)
+    st = capi.default_settings(mid, loss=loss)
     eng, orc = pair(sc, st)
-    compare(eng, orc, sc, iters=1, tol=5e-4)
+    compare(eng, orc, sc, iters=2, tol=2e-4, margins=margins)
 
 
-@pytest.mark.parametrize("name,mid", [("SH1", capi.SH1), ("LED", capi.LED)])
-def test_without_reference_quirks(built, name, mid):
-    """ref_quirks = 0: the LED neighbour-column sign (B6) and the 'skip the update unless CG reports Success' gate (B8) are off"""
-    sc = synth.make_scene(N=32, F=5, W=128, H=96, model=name)
+@pytest.mark.parametrize("name,mid", [("SH1", capi.SH1), ("SH2", capi.SH2), ("LED", capi.LED)])
+def test_without_reference_quirks(built, margins, name, mid):
+    """ref_quirks = 0: the LED neighbour-column sign (B6) and the 'skip the update unless CG reports Success' gates (B8; LED poses) are off"""
+    sc = synth.make_scene(N=32, F=12 if mid == capi.SH2 else 5, W=128, H=96, model=name)
     st = capi.default_settings(mid, ref_quirks=0)
     if mid == capi.LED:
         st.reg_weight_n, st.reg_weight_l, st.damping = 0.1, 5.0, 3.0      # config_basket_LED.json
     eng, orc = pair(sc, st)
-    compare(eng, orc, sc, iters=2, tol=5e-4)
+    compare(eng, orc, sc, iters=2, tol=2e-4, margins=margins)
 
 
 def test_laplacian_and_upsample_schedule(built):

@@ -2,6 +2,7 @@
 # One profiling pass for profiles/: kernel trace + stats of the default bench command, then FETCH_SIZE / WRITE_SIZE PMC passes.
 # usage (on the GPU box): tools/profile_round.sh <tag>     -> gpurun_out/prof_<tag>/
 set -u
+export PSGSDF_BENCH_LIVE_PMC=0      # (the passes below ARE the counter passes: bench.py must not spawn its own under a profiler)
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag; mkdir -p $out
@@ -14,6 +15,6 @@ done
 f=$(find $out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find $out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools/pmc_summary.py "$f" "$w" > $out/pmc_summary.json
 cp $out/pmc_summary.json profiles/pmc_summary.json; cp $out/kernel_stats_summary.json profiles/kernel_stats_summary.json      # (the line below quotes them; copy them into profiles/ at home too)
-python bench.py > $out/bench.json 2> $out/bench.err
+env -u PSGSDF_BENCH_LIVE_PMC python bench.py > $out/bench.json 2> $out/bench.err
 find $out/trace -name "*.db" -delete; rm -rf $out/pmc_*/    # keep the summaries only (the databases are tens of MB)
 head -20 $out/kernel_stats.md; cat $out/pmc_summary.json | head -30; cut -c 1-300 $out/bench.json
