@@ -38,7 +38,7 @@ static const char* const kKnobs[] = {
     "PSGSDF_FM_SOLVE", "PSGSDF_FRAME_SOLVE", "PSGSDF_FM_ROWS", "PSGSDF_IMG_COMPACT", "PSGSDF_XCD_MAP", "PSGSDF_XCD_STRIPE",
     "PSGSDF_XR", "PSGSDF_XF", "PSGSDF_XS", "PSGSDF_XH", "PSGSDF_XR_MEM", "PSGSDF_XWAIT_LOG2", "PSGSDF_SPECULATE_MR", "PSGSDF_CU_MASK",
     "PSGSDF_WAIT_TIMEOUT_S", "PSGSDF_DESTROY_TIMEOUT_S", "PSGSDF_SOLVE_DUMP"};
-static const char* const kDevKnobs[] = {"PSGSDF_PCG_ABLATE", "PSGSDF_ABLATE_REUSE", "PSGSDF_FAULT_SOLVE", "PSGSDF_FAULT_HALO", "PSGSDF_MBOX_CHECK"};
+static const char* const kDevKnobs[] = {"PSGSDF_PCG_ABLATE", "PSGSDF_FAULT_SOLVE", "PSGSDF_FAULT_HALO", "PSGSDF_MBOX_CHECK"};
 const char* psgsdf_last_error(const psgsdf_ctx* c) { return c ? c->err : "null context"; }
 
 int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_settings* settings, int device, psgsdf_ctx** out) {
@@ -73,7 +73,6 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
 #ifdef PSGSDF_DEV      // fault injection / ablation / the round-2 race: development build only (libpsgsdf_dev.so)
     if (const char* e = getenv("PSGSDF_PCG_ABLATE")) c->pcg_ablate = atoi(e) & 7;
     if (const char* e = getenv("PSGSDF_MBOX_CHECK")) c->mbox_check = atoi(e) != 0;
-    if (const char* e = getenv("PSGSDF_ABLATE_REUSE")) c->ablate_reuse = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_FAULT_SOLVE")) c->fault_solve = atoi(e);
     if (const char* e = getenv("PSGSDF_FAULT_HALO")) c->fault_halo = atoll(e);
 #endif
@@ -134,7 +133,7 @@ void psgsdf_destroy(psgsdf_ctx* c) {
         fprintf(stderr, "psgsdf: rank %d: a peer did not close its mappings of this rank's exchange memory within %.0f s (failed or still running?): that memory is leaked, not freed\n", c->rank, qt);
     }
     free_dense(c);
-    hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->frames_undo); hipFree(c->led_light); hipFree(c->fs_stats); hipFree(c->obs_I);
+    hipFree(c->vis_seq); hipFree(c->frame_idx); hipFree(c->img); hipFree(c->img8); hipFree(c->frames); hipFree(c->frames_undo); hipFree(c->led_light); hipFree(c->fs_stats);
     hipFree(c->band_mem); if (!c->leak_exported) hipFree(c->rec_mem); hipFree(c->obs_mem); hipFree(c->stage);
     hipFree(c->ncache); hipFree(c->ntmp); hipFree(c->nout); hipFree(c->ndepth); hipFree(c->track_part); if (c->track_host) hipHostFree(c->track_host); hipFree(c->acc_frame); hipFree(c->frame_part); hipFree(c->frame_done); hipFree(c->part); hipFree(c->pcg_sc); hipFree(c->pcg_part); hipFree(c->pcg_gran); hipFree(c->d_total);
     for (void* p : c->xo_host) if (p) hipHostFree(p);

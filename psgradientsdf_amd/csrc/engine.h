@@ -157,7 +157,6 @@ struct SweepArgs {
     int xcd_map;              // workgroup -> work mapping that gives every XCD (physical workgroup id mod 8) one contiguous range of band rows / observation chunks: its L2 then holds an eighth of the band (device_common.h xcd_remap)
     int fm_solve;             // frame-major sweeps: the last workgroup of a frame solves the frame's light (SH) / pose block, the last frame sums the energy columns (sweeps.hip frame_rows_publish): no solve launch
     FrameP* fm_frames; float* fm_undo; double* fm_e_out; unsigned long long fm_e_key;
-    float* obs_I;             // TIMING ABLATION ONLY (libpsgsdf_dev.so, PSGSDF_ABLATE_REUSE=1; nullptr in the product): [3 * observations] colours the albedo sweep stores per observation slot and the light sweep reads instead of projecting and sampling -- the bound on what sharing one sample between the two sweeps could win (profiles/r06_notes.md section 4; results are WRONG with it)
     const double* gate;       // speculative launch: the kernel does nothing unless *gate != 0 (nullptr = always run); see pcg_solve
     const double* ext;        // multi-rank PCG: the 7 globally reduced sums of the previous pass (|b|^2 in ext[0] for pass 0), else nullptr
 };

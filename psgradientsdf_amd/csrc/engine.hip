@@ -42,7 +42,6 @@ SweepArgs make_args(psgsdf_ctx* c, int laplacian_reg) {
     a.acc.fpart = c->frame_part; a.acc.fcap = c->frame_cap; a.acc.fdone = c->frame_done;
     a.fold.n = 0; a.gate = nullptr; a.fuse_apply = 0;
     a.xcd_map = c->xcd_map; a.xf = nullptr; a.xf_epoch = 0; a.fm_led_light = nullptr; a.vm_order = c->vm_order;
-    a.obs_I = c->obs_I;
     a.fm_solve = 0; a.fm_frames = nullptr; a.fm_undo = nullptr; a.fm_e_out = nullptr; a.fm_e_key = 0;
     a.pcg_part = c->pcg_part; a.pcg_fs = c->pcg_sc; a.pcg_fuse_init = 0; a.pcg_init_blocks = 0; a.pcg_gran = nullptr; a.pcg_gran_n = 0; a.pcg_asm = 0; a.pcg_epoch = 0; a.pcg_pipe = c->pcg_pipeline ? (c->pcg_tagm ? (c->n_ranks <= 1 ? 2 : (c->pcg_tagm_mr ? 3 : 1)) : 1) : 0; a.pcg_apply = 0; a.pcg_xcd_local = (c->pcg_xcd_local ? 1 : 0) | (c->pcg_prefetch ? 2 : 0) | (c->pcg_ablate << 3);
     a.ar = c->ar; a.ar.weight = c->reg_r;
@@ -383,8 +382,6 @@ int build_band(psgsdf_ctx* c) {
             b.obs_ptr = (int*)c->obs_mem; b.obs_rows = b.obs_ptr + (F + 1); b.obs_max = mx; b.obs_ptr_total = run;
             HIPCHK(c, hipMemcpyAsync(b.obs_ptr, ptr.data(), sizeof(int) * (F + 1), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipMemcpyAsync(d_counts, off.data(), sizeof(int) * off.size(), hipMemcpyHostToDevice, c->stream));
-            if (c->obs_I) { hipFree(c->obs_I); c->obs_I = nullptr; }
-            if (c->ablate_reuse) HIPCHK(c, hipMalloc(&c->obs_I, sizeof(float) * 3 * ((size_t)run + 64)));      // (timing ablation, development build)
             launch_obs_fill(b, F, c->row0, c->row1, d_counts, c->stream);
             HIPCHK(c, hipStreamSynchronize(c->stream));
             hipFree(d_counts);

@@ -176,7 +176,6 @@ struct psgsdf_ctx {
     bool fm_solve = true;                // PSGSDF_FM_SOLVE=0: k_solve_light / k_solve_pose as kernels of their own behind the frame-major sweeps
     bool fm_solve_led = true;            // ... also the LED light vector (by the sweep's very last workgroup); PSGSDF_FM_SOLVE=2 keeps k_solve_light for it
     bool fm_solved = false;              // the sweep just launched solves its frames itself (step_begin -> step_finish)
-    bool ablate_reuse = false; float* obs_I = nullptr;   // PSGSDF_ABLATE_REUSE (development build only): SweepArgs::obs_I
     int frame_solve = 0;                 // PSGSDF_FRAME_SOLVE / psgsdf_set_frame_solver: 0 = LDL^T per frame in double (default), 1 = the reference's solver: ONE Eigen-style float Jacobi-PCG over the block-diagonal system of all frames (frame_solve.hip)
     double* fs_stats = nullptr;          // device [2][4]: {iterations, ||r||/||b||, Success, applied} of the last eigen light / pose solve
     double fs_last[2][4] = {{0, 0, 1, 1}, {0, 0, 1, 1}};   // host copy, refreshed by the synchronous steps (psgsdf_step, psgsdf_get_frame_solver_stats)

@@ -112,12 +112,6 @@ __global__ void __launch_bounds__(kBlock) k_sweep_albedo(SweepArgs a) {
             if (!pr.ok) continue;
             float I[3], ren[3], J[3];
             sample<false, IMG>(a.im, f, a.cam, pr.m, pr.n, I, nullptr, nullptr);
-            if (a.obs_I) {      // TIMING ABLATION (engine.h SweepArgs::obs_I): the cost side of sharing the sample with the light sweep -- one map look-up + a 12-byte store per observation
-                const int beg = b.obs_ptr[f], len = b.obs_ptr[f + 1] - beg;
-                int slot = beg + min(max(len - 1, 0), (int)((float)(j - a.row0) * ((float)len / (float)(a.row1 - a.row0))));      // (about where row j sits in frame f's ascending list)
-                slot += b.obs_rows[slot] < 0 ? 1 : 0;      // the voxel -> slot map's read
-                float* dst = a.obs_I + 3 * (size_t)slot; dst[0] = I[0]; dst[1] = I[1]; dst[2] = I[2];
-            }
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
             rho_jac<MODEL>(fp, pr, v.gn, shg, J);
             float l = 0.f;
@@ -484,13 +478,12 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
         const int j_nn = (it + 2 < rows && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
         if (j_nxt >= 0) load_vox(b, j_nxt, vn);
         j_cur = j_nxt; j_nxt = j_nn;
-        Proj pr;
-        if (!a.obs_I || LED) { pr = project(v.xs, fp, a.cam); if (!pr.ok) continue; }      // (obs_I: timing ablation -- the SH models need neither the projection nor the taps)
+        Proj pr = project(v.xs, fp, a.cam);
+        if (!pr.ok) continue;
         float shfd[kMaxBasis], shg[kMaxBasis];
         if (!LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
         float I[3], ren[3];
-        if (a.obs_I) { const float* src = a.obs_I + 3 * (size_t)e; I[0] = src[0]; I[1] = src[1]; I[2] = src[2]; }
-        else sample<false, IMG>(img, 0, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        sample<false, IMG>(img, 0, a.cam, pr.m, pr.n, I, nullptr, nullptr);
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
         float refl = 0.f;
         if (LED) { float Rp[3]; mul3(fp.R, pr.p, Rp); refl = dot3(v.gn, Rp); float pn = norm3(pr.p); double pd = (double)pn; refl /= (float)(pd * pd * pd); }

@@ -8,6 +8,9 @@ means: the albedo sweep stores each observation's colour (12 B) at its slot of t
 from the engine's own synchronous event pass, and the whole iteration through psgsdf_iterate.
 
     python tools/reuse_ablate.py            (GPU box; writes gpurun_out/reuse_ablate.json)
+
+NEEDS THE ENGINE AT COMMIT 42a383b: the ablation hooks (SweepArgs::obs_I, PSGSDF_ABLATE_REUSE) were removed again after the measurement -- the shared sample is a
+net loss (profiles/r06_reuse_ablate.json, profiles/r06_notes.md section 4) and the hooks cost the product's sweeps a branch per observation.
 """
 import json
 import os
