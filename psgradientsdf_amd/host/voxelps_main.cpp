@@ -206,7 +206,7 @@ int main(int argc, char* argv[]) {
     for (int i = 1; i < argc; ++i) { std::string a = argv[i]; if (a == "--config_file" && i + 1 < argc) configfile = argv[++i]; else if (a.rfind("--config_file=", 0) == 0) configfile = a.substr(14);
         else if (a == "--timing" && i + 1 < argc) timing_file = argv[++i];
         else if (a == "--host-writers") host_writers() = true;
-        else if (a == "--frame-solver" && i + 1 < argc) setenv("PSGSDF_FRAME_SOLVE", argv[++i], 1);      // eigen = the reference's own solver of the light / pose blocks (include/psgsdf.h psgsdf_set_frame_solver); default ldlt.  The ranks of --gpus N inherit the environment.
+        else if (a == "--frame-solver" && i + 1 < argc) { setenv("PSGSDF_FRAME_SOLVE", argv[++i], 1); std::cout << "frame solver: " << argv[i] << std::endl; }      // eigen = the reference's own solver of the light / pose blocks (include/psgsdf.h psgsdf_set_frame_solver); default ldlt.  The ranks of --gpus N inherit the environment.
         else if (a == "--gpus" && i + 1 < argc) want_ranks = atoi(argv[++i]);
         else if (a == "--transport" && i + 1 < argc) transport = argv[++i];
         else if (a == "--rank" && i + 1 < argc) rank_info().rank = atoi(argv[++i]);

@@ -115,3 +115,9 @@ def test_everything_compiles_from_scratch_in_a_clean_copy(tmp_path):
         assert os.access(tmp_path / "psgradientsdf_amd/host" / exe, os.X_OK), exe
     olib = ctypes.CDLL(str(next((tmp_path / "oracle").glob("*.so"))))
     assert hasattr(olib, "orc_iterate")
+    # the strict-arithmetic development variant (device_common.h PSG_STRICT, tools/deviations.py) must keep compiling too: every deviation switched off
+    t0 = time.time()
+    subprocess.run(["make", "-s", "-j16", "-C", str(tmp_path / "psgradientsdf_amd/csrc"), "strict", "STRICT=31"], check=True, timeout=1500)
+    print(f"strict variant: {time.time() - t0:.0f} s")
+    slib = ctypes.CDLL(str(tmp_path / "psgradientsdf_amd/csrc/libpsgsdf_strict31.so"))
+    assert hasattr(slib, "psgsdf_set_frame_solver") and b"dev" in ctypes.cast(slib.psgsdf_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()
