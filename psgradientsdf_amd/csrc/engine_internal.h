@@ -172,7 +172,7 @@ struct psgsdf_ctx {
     bool img_compacted = false;          // the float keyframes of this context are held as RGBA8 words
     bool speculate_mr = true;            // PSGSDF_SPECULATE_MR=0: no speculative start of the next iteration on multi-rank contexts (round 3's loop)
     int* vm_order = nullptr;             // distance sweep: physical workgroup -> logical block, heaviest first (build_band)
-    int xcd_map = 35;                    // PSGSDF_XCD_MAP: logical workgroup ids -- bit 0 frame-major sweeps XCD-contiguous, bit 1 k_sweep_albedo / k_energy / k_derive XCD-contiguous, bit 2 k_sweep_dist XCD-contiguous (off: 68 -> 76 us), bit 5 (32) k_sweep_dist heaviest block first (70 -> 62 us), bit 6 (64) albedo / energy heaviest first (no gain); PSGSDF_XCD_STRIPE=T: stripes of T ids instead of eighths
+    int xcd_map = 163;                   // PSGSDF_XCD_MAP: logical workgroup ids -- bit 0 frame-major sweeps XCD-contiguous, bit 1 k_sweep_albedo / k_energy / k_derive XCD-contiguous, bit 2 k_sweep_dist XCD-contiguous (off: 68 -> 76 us), bit 5 (32) k_sweep_dist heaviest block first (70 -> 62 us), bit 6 (64) albedo / energy heaviest first (no gain), bit 7 (128) the per-pass distance solve k_cgf_pass XCD-contiguous (round 6); PSGSDF_XCD_STRIPE=T: stripes of T ids instead of eighths
     bool fm_solve = true;                // PSGSDF_FM_SOLVE=0: k_solve_light / k_solve_pose as kernels of their own behind the frame-major sweeps
     bool fm_solve_led = true;            // ... also the LED light vector (by the sweep's very last workgroup); PSGSDF_FM_SOLVE=2 keeps k_solve_light for it
     bool fm_solved = false;              // the sweep just launched solves its frames itself (step_begin -> step_finish)

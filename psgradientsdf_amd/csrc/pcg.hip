@@ -80,7 +80,7 @@ __device__ __forceinline__ void block_total_n(double* const* src, int n, double*
     block_total_finish<N>(pl, red, out);
 }
 template <int N>
-__device__ __forceinline__ void block_part_store_n(const double* vin, double* const* dst, double* red /*[8 * kBlock/64]*/) {
+__device__ __forceinline__ void block_part_store_n(const double* vin, double* const* dst, double* red /*[8 * kBlock/64]*/, int slot) {
     static_assert(N > 2 && N <= 8, "reduce-scatter of up to eight sums");
     double v[8];
 #pragma unroll
@@ -93,7 +93,7 @@ __device__ __forceinline__ void block_part_store_n(const double* vin, double* co
     if (threadIdx.x < N) {
         double s = 0;
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[threadIdx.x * (kBlock / 64) + i];
-        dst[threadIdx.x][blockIdx.x] = s;
+        dst[threadIdx.x][slot] = s;
     }
 }
 
@@ -220,7 +220,12 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
     const float4* __restrict__ rin = b.rec[(k + 1) & 1];
     float4* __restrict__ rout = b.rec[k & 1];
     const int stride = gridDim.x * blockDim.x;
-    int i0 = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware: workgroups are dealt to the 8 XCDs round-robin; the LOGICAL id gives every XCD a contiguous range of row blocks per trip, so the records a row
+    // gathers (its z neighbours sit one plane of band rows away: ~10 row blocks at 512^3) are fetched into ONE L2 instead of several (round 6: the per-pass
+    // kernel's counter traffic was 1.5 x algorithmic at the 512^3 band, the surplus = the record planes fetched by three XCDs each).  Rows AND partial-sum
+    // slots follow the logical id, so the sums -- added in slot order -- do not depend on the mapping.
+    const int lb = (a.xcd_map & 128) ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;      // (PSGSDF_XCD_MAP bit 7)
+    int i0 = a.row0 + lb * blockDim.x + threadIdx.x;
     CgfRow w[kCgfRows]; CgfPending<kCgfRows> pend; CgfStream<kCgfRows> sl;
     const double stopped = fs[1];
     cgf_stream_issue<kCgfRows, C16>(b, i0, stride, a.row1, w, sl);
@@ -237,7 +242,7 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
         else { double* src[1] = {fpart(part, -1, 6)}; block_total_n<1>(src, gridDim.x, red, &bb); }
         cgf_rows_finish<kCgfRows>(w, pend);
         rhsNorm2 = (float)bb; rr_cur = rhsNorm2;
-        if (blockIdx.x == 0 && threadIdx.x == 0) { fs[0] = bb; mb[0] = bb; __threadfence_system(); }   // mb may be host-mapped: the host watches it
+        if (lb == 0 && threadIdx.x == 0) { fs[0] = bb; mb[0] = bb; __threadfence_system(); }   // mb may be host-mapped: the host watches it
     } else {
         double* src[kCgfSums]; double t[kCgfSums];
 #pragma unroll
@@ -259,12 +264,12 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
         const float rz_cur = (float)(t[5] - 2.0 * al * t[1] + al * al * t[2]);
         rr_cur = (float)(t[6] - 2.0 * al * t[3] + al * al * t[4]);
         beta = rz_cur / rz_old;                            // beta = absNew / absOld
-        if (blockIdx.x == 0 && threadIdx.x == 0) { mb[0] = (double)rr_cur; __threadfence_system(); }
+        if (lb == 0 && threadIdx.x == 0) { mb[0] = (double)rr_cur; __threadfence_system(); }
     }
     CGF_STAMP(2);
     const bool rhs_zero = rhsNorm2 == 0.f;
     const bool stop = !(ab & 16) && (rhs_zero || k == kmax || (k > 0 && rr_cur < pcg_threshold(rhsNorm2)));
-    if (stop && blockIdx.x == 0 && threadIdx.x == 0) { fs[1] = (double)(k + 1); fs[2] = (rhs_zero || sqrt((double)rr_cur / (double)rhsNorm2) <= (double)FLT_EPSILON) ? 1.0 : 0.0; }   // fs[2]: Eigen's info() == Success, the host's rule (loop.hip: pcg_solve)
+    if (stop && lb == 0 && threadIdx.x == 0) { fs[1] = (double)(k + 1); fs[2] = (rhs_zero || sqrt((double)rr_cur / (double)rhsNorm2) <= (double)FLT_EPSILON) ? 1.0 : 0.0; }   // fs[2]: Eigen's info() == Success, the host's rule (loop.hip: pcg_solve)
     double s[kCgfSums];
 #pragma unroll
     for (int q = 0; q < kCgfSums; ++q) s[q] = 0;
@@ -300,7 +305,7 @@ __global__ void __launch_bounds__(kBlock, kMinWaves) k_cgf_pass(SweepArgs a, dou
     double* dst[kCgfSums];
 #pragma unroll
     for (int q = 0; q < kCgfSums; ++q) dst[q] = fpart(part, k, q);
-    block_part_store_n<kCgfSums>(s, dst, red);
+    block_part_store_n<kCgfSums>(s, dst, red, lb);
     CGF_STAMP(4);
 #undef CGF_STAMP
 }

@@ -77,7 +77,8 @@ def test_distance_step_fusions_are_bitwise_neutral(built, model):
     assert all(abs(a - b) <= 1e-7 * abs(b) for a, b in zip(untagged["e"] + untagged["e2"], ref["e"] + ref["e2"])), (untagged["e"], ref["e"])
     assert abs(untagged["dsum"] - ref["dsum"]) <= 1e-7 * ref["dsum"] and abs(untagged["psum"] - ref["psum"]) <= 1e-7 * ref["psum"]
     classic = run(model, {"PSGSDF_PCG_PIPELINE": "0"}, full=True)
-    for env in ({"PSGSDF_PCG_FUSE_ASM": "0"}, {"PSGSDF_PCG_PERSIST": "0"}, {"PSGSDF_PCG_PIPELINE": "0", "PSGSDF_PCG_XCD_LOCAL": "0"}):
+    for env in ({"PSGSDF_PCG_FUSE_ASM": "0"}, {"PSGSDF_PCG_PERSIST": "0"}, {"PSGSDF_PCG_PIPELINE": "0", "PSGSDF_PCG_XCD_LOCAL": "0"},
+                {"PSGSDF_PCG_PERSIST": "0", "PSGSDF_XCD_MAP": "35"}):      # (round 6: the per-pass kernel's XCD-contiguous row blocks, bit 7 of the map, switched off)
         got = run(model, env, full=True)
         assert got == classic, (env, got, classic)
     assert all(abs(a - b) <= 1 for a, b in zip(classic["cg"], ref["cg"])) and classic["n2"] == ref["n2"]
