@@ -557,6 +557,64 @@ __device__ __forceinline__ void sample(const ImgSrc& s, int frame, const Cam& ca
     sample<false, IMG>(s, frame, cam, m_col, n_row, m_col, n_row, I, gu, gv);
 }
 
+// The same sample in two halves (frame-major sweeps, round 6): taps_issue computes the cell and REQUESTS the four taps, taps_colour / taps_colour_grad
+// weigh them.  A sweep issues observation i + 1 before it finishes observation i, so a thread has two observations' taps in flight and an iteration no
+// longer starts with a wait for its own loads (k_sweep_light ran at 53 % VALU-busy with five wavefronts per SIMD: one exposed tap latency per
+// observation).  Same loads, same arithmetic: the bits of sample().  Frame 0 of the launch's own image stack (frame-major kernels point the source at
+// their frame); IMG 0 = float RGB with 32-bit offsets, 1 = RGBA8 words.
+// Two rules keep the compiler from waiting for the loads where they are issued: (1) they are UNCONDITIONAL -- a lane whose observation is outside the
+// image requests cell (0, 0) and ignores it (loads inside a divergent branch are waited for at the end of the branch, where the loaded registers are
+// merged); (2) the finishing half contains NO load at all -- with one behind a rare branch, every use of the taps behind that branch waits for vmcnt(0),
+// i.e. for the taps just requested for the next observation as well.  Hence the image's last row / column (nearest sample, Auxilary.h:55-57) is served
+// from the four taps of the cell clamped into the image -- the nearest sample IS one of them -- and what needs taps outside the cell (the one-sided
+// differences of the border, a gradient whose own projection fell into the neighbouring cell: ~1e-4 of the observations) is reported back to the caller.
+template <int IMG> struct Taps {
+    float a00[3], a01[3], a10[3], a11[3];      // IMG 0: the taps of cell (xc, yc)
+    unsigned w[4];                             // IMG 1: the four packed words
+    bool cell;                                 // the bilinear cell of the observation is inside the image
+    bool bx, by;                               // border: the nearest sample is tap (bx, by) of the clamped cell
+};
+template <int IMG>
+__device__ __forceinline__ void taps_issue(const ImgSrc& s, const Cam& cam, bool ok, float m_col, float n_row, Taps<IMG>& t) {
+    static_assert(IMG == 0 || IMG == 1, "image format known at compile time");
+    const int x = (int)floorf(n_row), y = (int)floorf(m_col);
+    t.cell = ok && (x + 1) < cam.H && (y + 1) < cam.W;
+    const int xc = ok ? max(min(x, cam.H - 2), 0) : 0, yc = ok ? max(min(y, cam.W - 2), 0) : 0;      // (ok: 0 <= x < H, 0 <= y < W; images have at least two rows and columns: api.hip)
+    t.bx = x != xc; t.by = y != yc;
+    if (IMG == 0) {
+        const unsigned e = mad24((unsigned)xc, 3u * (unsigned)cam.W, 3u * (unsigned)yc);
+        const float* p00 = (const float*)((const char*)s.f32 + (size_t)(e << 2));
+        const float* p10 = (const float*)((const char*)s.f32 + (size_t)((e + 3u * (unsigned)cam.W) << 2));
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { t.a00[ch] = p00[ch]; t.a01[ch] = p00[3 + ch]; t.a10[ch] = p10[ch]; t.a11[ch] = p10[3 + ch]; }
+    } else {
+        const unsigned e = mad24((unsigned)xc, (unsigned)cam.W, (unsigned)yc);
+        const unsigned* p0 = (const unsigned*)((const char*)s.u8 + (size_t)(e << 2));
+        const unsigned* p1 = (const unsigned*)((const char*)s.u8 + (size_t)((e + (unsigned)cam.W) << 2));
+        t.w[0] = p0[0]; t.w[1] = p0[1]; t.w[2] = p1[0]; t.w[3] = p1[1];
+    }
+}
+// colour at (m_col, n_row) [+ image gradient at (mj_col, nj_row), project_jac].  GRAD: returns false -- nothing written -- when the gradient needs taps
+// outside the cell; the caller evaluates such an observation with sample<true>().
+template <int IMG, bool GRAD>
+__device__ __forceinline__ bool taps_colour(const ImgSrc& s, const Cam& cam, const Taps<IMG>& t, float m_col, float n_row, float mj_col, float nj_row, float* I, float* gu, float* gv) {
+    const float m = n_row, n = m_col;
+    const float xf = floorf(m), yf = floorf(n);
+    if (GRAD && (!t.cell || floorf(nj_row) != xf || floorf(mj_col) != yf)) return false;
+    float c00[3], c01[3], c10[3], c11[3];      // (values, not pointers into either source: a select between pointers sends the taps through scratch memory)
+    if (IMG == 1) { unpack_rgb8(t.w[0], s.scale, c00); unpack_rgb8(t.w[1], s.scale, c01); unpack_rgb8(t.w[2], s.scale, c10); unpack_rgb8(t.w[3], s.scale, c11); }
+    else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { c00[ch] = t.a00[ch]; c01[ch] = t.a01[ch]; c10[ch] = t.a10[ch]; c11[ch] = t.a11[ch]; }
+    }
+    if (GRAD || t.cell) interp_taps<GRAD>(c00, c01, c10, c11, m - xf, n - yf, nj_row - xf, mj_col - yf, I, gu, gv);
+    else {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { const float lo = t.by ? c01[ch] : c00[ch], hi = t.by ? c11[ch] : c10[ch]; I[ch] = t.bx ? hi : lo; }      // sample_border: I = the pixel (x, y) itself
+    }
+    return true;
+}
+
 // rendered intensity: PsOptimizerJa.cpp:30-40 (SH) / LedOptimizerJa.cpp:15-29 (LED).
 // nfd = normalized FD gradient, shfd = SH(nfd) (SH models only)
 template <int MODEL>
@@ -608,6 +666,47 @@ __device__ __forceinline__ void load_vox(const Band& b, int j, Vox& v) {
     v.xs[0] = p0.x; v.xs[1] = p0.y; v.xs[2] = p0.z; v.rho[0] = p0.w;
     v.gn[0] = p1.x; v.gn[1] = p1.y; v.gn[2] = p1.z; v.rho[1] = p1.w;
     v.nfd[0] = p2.x; v.nfd[1] = p2.y; v.nfd[2] = p2.z; v.rho[2] = p2.w;
+}
+
+// The observations e0, e0 + kBlock, ... (< end, at most `rows` <= 64) of one thread of a frame-major sweep as a software pipeline, three stages deep
+// (round 6): row index three observations ahead, voxel state two ahead, and observation k + 1 PROJECTED and its four taps REQUESTED (taps_issue) before
+// `body` weighs and accumulates observation k -- an iteration used to begin with a wait for its own taps, and at 4-5 wavefronts per SIMD that latency
+// was not covered (k_sweep_light: 53 % VALU-busy).  Every load is unconditional: index k is clamped to the thread's last observation (a repeat that is
+// requested and never weighed).  Unrolled by two with the in-flight state in two fixed register sets (P0 / P1, vX / vY): a rotating copy at the loop's
+// end would wait for the loads just issued.  `body` must not load (taps_colour's rule 2); an observation it cannot finish (returns false) is redone by
+// `slow(v, pr)` behind the loop -- in the order of the observations, but after the thread's others: the sums of such a thread differ from the two-stage
+// loop's in the order of their float additions (deterministically); every other thread's are the same bits.
+template <int IMG> struct ObsPend { Vox v; Proj pr; Taps<IMG> ts; };
+template <int IMG, class F, class G>
+__device__ __forceinline__ void fm_for_each_obs(const Band& b, const FrameP& fp, const Cam& cam, const ImgSrc& img, int e0, int end, int rows, F&& body, G&& slow) {
+    const int n = e0 < end ? min(rows, (end - e0 + kBlock - 1) / kBlock) : 0;
+    if (n <= 0) return;
+    const int eL = e0 + (n - 1) * kBlock;
+    auto row_of_obs = [&](int k) { return b.obs_rows[min(e0 + k * kBlock, eL)]; };
+    auto stage_a = [&](const Vox& v, ObsPend<IMG>& P) {
+        P.v = v; P.pr = project(v.xs, fp, cam);
+        taps_issue<IMG>(img, cam, P.pr.ok, P.pr.m, P.pr.n, P.ts);
+    };
+    Vox vX, vY; ObsPend<IMG> P0, P1;
+    { Vox v0; load_vox(b, row_of_obs(0), v0); load_vox(b, row_of_obs(1), vX); stage_a(v0, P0); }
+    int jY = row_of_obs(2);
+    unsigned long long redo = 0ull;
+    for (int k = 0; k < n; k += 2) {
+        // [P0 = observation k in flight, vX = state of k + 1, jY = row of k + 2]
+        const int jX = row_of_obs(k + 3);
+        load_vox(b, jY, vY);
+        stage_a(vX, P1);
+        if (P0.pr.ok && !body(P0)) redo |= 1ull << k;
+        // [P1 = observation k + 1 in flight, vY = state of k + 2, jX = row of k + 3]
+        jY = row_of_obs(k + 4);
+        load_vox(b, jX, vX);
+        stage_a(vY, P0);
+        if (k + 1 < n && P1.pr.ok && !body(P1)) redo |= 2ull << k;
+    }
+    for (; redo; redo &= redo - 1) {
+        Vox v; load_vox(b, row_of_obs(__builtin_ctzll(redo)), v);
+        slow(v, project(v.xs, fp, cam));
+    }
 }
 
 // ELL column offsets of one assembled distance row: self, 6 axis neighbours, 12 axis pairs

@@ -3,6 +3,13 @@
 // Shared device helpers: device_common.h; the launchers are declared in engine.h.
 #include "device_common.h"
 
+#ifndef PSG_FM_PIPE
+#define PSG_FM_PIPE 3      // (development: bit 0 = k_sweep_light, bit 1 = k_sweep_pose run the three-stage observation pipeline of device_common.h fm_for_each_obs)
+#endif
+#ifndef PSG_POSE_WAVES
+#define PSG_POSE_WAVES 1
+#endif
+
 namespace psg {
 
 // Optimizer.cpp:50-81 initAlbedo
@@ -197,7 +204,7 @@ void launch_apply_albedo(const SweepArgs& a, hipStream_t s) {
 // are VALU-bound per SIMD, so the grid should fill the resident workgroup slots of the chip evenly in ONE generation; a fixed 16
 // left 13 % of the pose sweep's workgroups for a second, nearly empty generation (fm_rows below).
 static int fm_rows(const SweepArgs& a, int slots_per_cu) {
-    if (const char* e = getenv("PSGSDF_FM_ROWS")) { int v = atoi(e); if (v >= 4 && v <= 256) return v; }   // tuning knob (>= 4: the partial-row buffer is sized for that)
+    if (const char* e = getenv("PSGSDF_FM_ROWS")) { int v = atoi(e); if (v >= 4 && v <= 64) return v; }   // tuning knob (>= 4: the partial-row buffer is sized for that; <= 64: fm_for_each_obs keeps one bit per observation of a thread)
     const long long total = a.b.obs_ptr_total > 0 ? a.b.obs_ptr_total : (long long)a.b.obs_max * a.F;
     const long long slots = 256LL * slots_per_cu;                       // resident workgroups on the chip
     // every frame wastes half a chunk on average: aim at ~92 % of the slots
@@ -465,25 +472,11 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0;
     const int beg = b.obs_ptr[f], end = b.obs_ptr[f + 1];
-    // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
-    // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
-    // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
-    int e = beg + cx * (kBlock * rows) + threadIdx.x;
-    int j_cur = e < end ? b.obs_rows[e] : -1;
-    int j_nxt = (rows > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
-    Vox vn;
-    if (j_cur >= 0) load_vox(b, j_cur, vn);
-    for (int it = 0; it < rows && j_cur >= 0; ++it, e += kBlock) {
-        const Vox v = vn;
-        const int j_nn = (it + 2 < rows && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
-        if (j_nxt >= 0) load_vox(b, j_nxt, vn);
-        j_cur = j_nxt; j_nxt = j_nn;
-        Proj pr = project(v.xs, fp, a.cam);
-        if (!pr.ok) continue;
+    // one observation's contribution once its colour I is known (shared by the two loop forms below)
+    auto accumulate = [&](const Vox& v, const Proj& pr, const float* I) {
         float shfd[kMaxBasis], shg[kMaxBasis];
         if (!LED) { SH<NB == 3 ? 4 : NB>(v.nfd, shfd); SH<NB == 3 ? 4 : NB>(v.gn, shg); }
-        float I[3], ren[3];
-        sample<false, IMG>(img, 0, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        float ren[3];
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
         float refl = 0.f;
         if (LED) { float Rp[3]; mul3(fp.R, pr.p, Rp); refl = dot3(v.gn, Rp); float pn = norm3(pr.p); double pd = (double)pn; refl /= (float)(pd * pd * pd); }
@@ -527,6 +520,36 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
         }
 #endif
         acc[NH + NB] += (obs_acc_t)l; acc[NH + NB + 1] += 1;
+    };
+    const int e0 = beg + cx * (kBlock * rows) + threadIdx.x;
+    if constexpr (IMG >= 0 && !(PSG_STRICT & 4) && (PSG_FM_PIPE & 1)) {
+        // three-stage software pipeline over the thread's observations (device_common.h fm_for_each_obs; rows <= 64: fm_rows)
+        fm_for_each_obs<IMG>(b, fp, a.cam, img, e0, end, rows, [&](const ObsPend<IMG>& P) {
+            float I[3];
+            taps_colour<IMG, false>(img, a.cam, P.ts, P.pr.m, P.pr.n, P.pr.m, P.pr.n, I, nullptr, nullptr);
+            accumulate(P.v, P.pr, I);
+            return true;
+        }, [&](const Vox&, const Proj&) {});
+    } else {
+    // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
+    // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
+    // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
+    int e = e0;
+    int j_cur = e < end ? b.obs_rows[e] : -1;
+    int j_nxt = (rows > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
+    Vox vn;
+    if (j_cur >= 0) load_vox(b, j_cur, vn);
+    for (int it = 0; it < rows && j_cur >= 0; ++it, e += kBlock) {
+        const Vox v = vn;
+        const int j_nn = (it + 2 < rows && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
+        if (j_nxt >= 0) load_vox(b, j_nxt, vn);
+        j_cur = j_nxt; j_nxt = j_nn;
+        Proj pr = project(v.xs, fp, a.cam);
+        if (!pr.ok) continue;
+        float I[3];
+        sample<false, IMG>(img, 0, a.cam, pr.m, pr.n, I, nullptr, nullptr);
+        accumulate(v, pr, I);
+    }
     }
     // row layout: [NH H entries | NB rhs | energy | n_obs]
     const int w = threadIdx.x >> 6;
@@ -536,7 +559,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_light(SweepArgs a, int rows) {
 }
 int launch_sweep_light(const SweepArgs& a, hipStream_t s) {
     if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return 0;
-    const int rows = fm_rows(a, a.model == 1 ? 3 : 5);           // resident workgroups per CU at this kernel's register count
+    const int rows = fm_rows(a, a.model == 1 ? 3 : ((PSG_FM_PIPE & 1) ? 4 : 5));           // resident workgroups per CU at this kernel's register count (pipelined: 108-120 VGPRs, SH2 161-168)
     const int chunk = kBlock * rows;
     dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
     PSG_LAUNCH_SWEEP(k_sweep_light, a, true, g, bl, 0, s, a, rows);
@@ -546,7 +569,7 @@ int launch_sweep_light(const SweepArgs& a, hipStream_t s) {
 
 // pose normal equations: poseJacobian PsOptimizerJa.cpp:61-115,427-475 / LedOptimizerJa.cpp:32-81,351-399
 template <int MODEL, int LOSS, int IMG>
-__global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
+__global__ void __launch_bounds__(kBlock, PSG_POSE_WAVES) k_sweep_pose(SweepArgs a, int rows) {
     { __shared__ double fred[kBlock / 64]; fold_pending(a, fred); }
     constexpr int NB = ModelTraits<MODEL>::NB;
     constexpr bool LED = ModelTraits<MODEL>::LED;
@@ -565,26 +588,11 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0;
     const int beg = b.obs_ptr[f], end = b.obs_ptr[f + 1];
-    // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
-    // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
-    // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
-    int e = beg + cx * (kBlock * rows) + threadIdx.x;
-    int j_cur = e < end ? b.obs_rows[e] : -1;
-    int j_nxt = (rows > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
-    Vox vn;
-    if (j_cur >= 0) load_vox(b, j_cur, vn);
-    for (int it = 0; it < rows && j_cur >= 0; ++it, e += kBlock) {
-        const Vox v = vn;
-        const int j_nn = (it + 2 < rows && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
-        if (j_nxt >= 0) load_vox(b, j_nxt, vn);
-        j_cur = j_nxt; j_nxt = j_nn;
-        Proj pr = project(v.xs, fp, a.cam);
-        if (!pr.ok) continue;
+    // one observation's contribution once its colour I and image gradient (gu, gv) are known (shared by the two loop forms below)
+    auto accumulate = [&](const Vox& v, const Proj& pr, const ProjJ& pj, const float* I, const float* gu, const float* gv) {
         float shfd[kMaxBasis];
         if (!LED) SH<NB == 3 ? 4 : NB>(v.nfd, shfd);
-        float I[3], gu[3], gv[3], ren[3];
-        const ProjJ pj = project_jac(pr, a.cam);      // poseJacobian projects again, with its own in-image test (PsOptimizerJa.cpp:70-76)
-        sample<true, IMG>(img, 0, a.cam, pr.m, pr.n, pj.mj, pj.nj, I, gu, gv);
+        float ren[3];
         rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
         // J_c = image_grad_c pi_grad [-R^T | skew(p)] (PsOptimizerJa.cpp:78-100), contracted from the right (device_common.h pi_rows):
         // J_c = gu_c [-U | a skew(p)] + gv_c [-V | b skew(p)] with the channel-independent rows written out (structural zeros dropped)
@@ -647,7 +655,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
                 acc[21 + i] += (obs_acc_t)(ra * A6[i]); acc[21 + i] += (obs_acc_t)(rb * B6[i]);
             }
             acc[27] += (obs_acc_t)l; acc[28] += 1;
-            continue;
+            return;
         }
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
@@ -683,6 +691,44 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
             }
         }
         acc[27] += (obs_acc_t)l; acc[28] += 1;
+    };
+    const int e0 = beg + cx * (kBlock * rows) + threadIdx.x;
+    if constexpr (IMG >= 0 && !(PSG_STRICT & 4) && (PSG_FM_PIPE & 2)) {
+        // three-stage software pipeline over the thread's observations (device_common.h fm_for_each_obs; rows <= 64: fm_rows); an observation whose
+        // gradient needs taps outside its cell (image border, the Jacobian's projection in the neighbouring cell) is evaluated behind the loop
+        fm_for_each_obs<IMG>(b, fp, a.cam, img, e0, end, rows, [&](const ObsPend<IMG>& P) {
+            const ProjJ pj = project_jac(P.pr, a.cam);      // poseJacobian projects again, with its own in-image test (PsOptimizerJa.cpp:70-76)
+            float I[3], gu[3], gv[3];
+            if (!taps_colour<IMG, true>(img, a.cam, P.ts, P.pr.m, P.pr.n, pj.mj, pj.nj, I, gu, gv)) return false;
+            accumulate(P.v, P.pr, pj, I, gu, gv);
+            return true;
+        }, [&](const Vox& v, const Proj& pr) {
+            const ProjJ pj = project_jac(pr, a.cam);
+            float I[3], gu[3], gv[3];
+            sample<true, IMG>(img, 0, a.cam, pr.m, pr.n, pj.mj, pj.nj, I, gu, gv);
+            accumulate(v, pr, pj, I, gu, gv);
+        });
+    } else {
+    // Software pipeline over the thread's observations: the row index is fetched two observations ahead and the voxel state one
+    // ahead, so that an iteration waits for its image taps only (un-pipelined, index -> state -> taps were three dependent round
+    // trips per observation and the sweep was latency-bound at 4-6 waves per SIMD).
+    int e = e0;
+    int j_cur = e < end ? b.obs_rows[e] : -1;
+    int j_nxt = (rows > 1 && e + kBlock < end) ? b.obs_rows[e + kBlock] : -1;
+    Vox vn;
+    if (j_cur >= 0) load_vox(b, j_cur, vn);
+    for (int it = 0; it < rows && j_cur >= 0; ++it, e += kBlock) {
+        const Vox v = vn;
+        const int j_nn = (it + 2 < rows && e + 2 * kBlock < end) ? b.obs_rows[e + 2 * kBlock] : -1;
+        if (j_nxt >= 0) load_vox(b, j_nxt, vn);
+        j_cur = j_nxt; j_nxt = j_nn;
+        Proj pr = project(v.xs, fp, a.cam);
+        if (!pr.ok) continue;
+        float I[3], gu[3], gv[3];
+        const ProjJ pj = project_jac(pr, a.cam);      // poseJacobian projects again, with its own in-image test (PsOptimizerJa.cpp:70-76)
+        sample<true, IMG>(img, 0, a.cam, pr.m, pr.n, pj.mj, pj.nj, I, gu, gv);
+        accumulate(v, pr, pj, I, gu, gv);
+    }
     }
     const int w = threadIdx.x >> 6;
     wave_sums_to<NV>(acc, lds + w * NV);   // row layout: [21 H | 6 rhs | energy | n_obs]
@@ -691,7 +737,7 @@ __global__ void __launch_bounds__(kBlock) k_sweep_pose(SweepArgs a, int rows) {
 }
 int launch_sweep_pose(const SweepArgs& a, hipStream_t s) {
     if (a.b.S <= 0 || a.F <= 0 || a.b.obs_max <= 0) return 0;
-    const int rows = fm_rows(a, 4);
+    const int rows = fm_rows(a, ((PSG_FM_PIPE & 2) && PSG_POSE_WAVES < 4) ? 3 : 4);      // (pipelined: 131-145 VGPRs)
     const int chunk = kBlock * rows;
     dim3 g((a.b.obs_max + chunk - 1) / chunk, a.F), bl(kBlock);
     PSG_LAUNCH_SWEEP(k_sweep_pose, a, true, g, bl, 0, s, a, rows);

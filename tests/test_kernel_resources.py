@@ -1,6 +1,6 @@
 """Register budgets the performance of the hot kernels rests on, checked at build time (hipcc's kernel-resource-usage remarks, no GPU needed):
 the persistent distance step must not spill (the compiler once hoisted all 54 gather addresses out of the pass loop and spilled them --
-profiles/r02_notes.md section 9), and the per-observation sweeps must stay at 4 wavefronts per SIMD (<= 128 VGPRs)."""
+profiles/r02_notes.md section 9), and the per-observation sweeps must stay at their measured occupancy (voxel-major: 4-8 wavefronts per SIMD; frame-major, pipelined: 3-4) without scratch."""
 import os
 import re
 import shutil
@@ -54,8 +54,10 @@ def test_sweeps_keep_four_waves_per_simd(tmp_path):
     sw = resources("sweeps.hip", tmp_path)
     for k, v in sw.items():
         if "k_sweep_pose" in k and "ELi1ELi0E" in k:
-            assert v["vgpr"] <= 128 and v["scratch"] == 0, (k, v)
+            # round 6: the three-stage observation pipeline (two observations' taps in flight per thread) at 3 waves per SIMD measured FASTER than the
+            # two-stage loop at 4 (61.5 -> 57.4 us); forced into 128 registers it spills and loses (66-67 us): profiles/r06_notes.md section 6
+            assert v["vgpr"] <= 168 and v["waves"] >= 3 and v["scratch"] == 0, (k, v)
         if ("k_sweep_albedo" in k or "k_energy" in k) and "ELi1ELi0E" in k:
             assert v["vgpr"] <= 64 and v["scratch"] == 0, (k, v)       # 8 waves per SIMD
         if "k_sweep_light" in k and "ILi0ELi1ELi0E" in k:
-            assert v["vgpr"] <= 96 and v["scratch"] == 0, (k, v)       # SH1: 5 waves per SIMD
+            assert v["vgpr"] <= 128 and v["waves"] >= 4 and v["scratch"] == 0, (k, v)       # SH1, pipelined: 4 waves per SIMD (the two-stage loop: 88 registers, 5 waves -- and the same time)
