@@ -839,6 +839,17 @@ template <int R, bool MR, bool TM = false>
 __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, double* fs, double* gran, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, XrArgs xr) {
     __shared__ double red[8 * kSolveThreads / 64];
     __shared__ int s_abort;
+    // kFast (single rank, self-validating values: the production kernel): TWO workgroup barriers per pass instead of five (round 6: 7.05 -> 6.5 us per
+    // pass).  What is left is one barrier per cross-wavefront sum: in front of stage C's reads of `red` and in front of stage E's reads of `red2`.  The sums
+    // of C and E meet in buffers of their own, E's alternating by pass parity -- so neither the barrier between C's reads and E's writes nor the one behind
+    // E's reads is needed: whoever writes a buffer again is two barriers further on than its last reader.  The 'a wait gave up' flag rotates through three
+    // words (pass mod 3): thread 0 clears the word of pass k + 2 behind stage E's barrier of pass k -- its last readers passed that barrier with it, its next
+    // raisers are two barriers away -- so the barrier that only published the cleared flag at the top of a pass goes too.  Every read of a pass's word lies
+    // behind a barrier of that pass and every raise in front of it: all threads of the workgroup take the same decision.
+    constexpr bool kFast = TM && !MR;
+    __shared__ double red2[kFast ? 2 * 8 * kSolveThreads / 64 : 1];
+    __shared__ int s_ab3[3];
+#define CGP_ABORT (*(kFast ? &s_ab3[(k + 3) % 3] : &s_abort))
     __shared__ int s_foreign;
     const Band& b = a.b;
     const int G = gridDim.x, tid = threadIdx.x;
@@ -941,15 +952,17 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
             for (int wd = 0; wd < (kNQ - 1) / 2; ++wd) asm volatile("" : "+v"(cp[u][wd]));
         // ---- A: the values this workgroup gathers are those of its neighbours in band order: their tag (the first sum of pass k, stored after
         // their m_k had drained; k = -1: the prologue's flag)
-        if (tid == 0) { s_abort = 0; if (k < 0) s_foreign = 0; }
-        __syncthreads();
+        if (!kFast || k < 0) {
+            if (tid == 0) { s_abort = 0; s_ab3[0] = 0; s_ab3[1] = 0; s_ab3[2] = 0; if (k < 0) s_foreign = 0; }
+            __syncthreads();
+        }
         if (!TM && tid <= nhi - nlo && !((a.pcg_xcd_local >> 3) & 2)) {
             int spins = 0;
             const double* wp = k >= 0 ? gp + nlo + tid : gran + (size_t)(kSolveGranPlanes + 7) * kSolveMaxBlocks + nlo + tid;
             double seen = 0.0;
             while (k >= 0 ? gran_tag_of(seen = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != want : (seen = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0.0) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > kLocalSpins || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
+                if (++spins > kLocalSpins || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { CGP_ABORT = 1; break; }
             }
             if (k < 0 && (int)seen != 1 + my_xcc) s_foreign = 1;
         }
@@ -961,13 +974,13 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                 const unsigned wantx = etag0 | (k >= 0 ? want : 1u);
                 while (xr_tag_of(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != wantx) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 24) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
+                    if (++spins > (1 << 24) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { CGP_ABORT = 1; break; }
                 }
             }
         }
         if (!TM) {
             __syncthreads();
-            if (s_abort) { if (tid == 0) raise_abort(); status = 2; break; }
+            if (CGP_ABORT) { if (tid == 0) raise_abort(); status = 2; break; }
             if (tid == 0) { if (MR) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
             if (k < 0) xcd_local = (a.pcg_xcd_local & 1) && !s_foreign;
             __syncthreads();
@@ -1028,7 +1041,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                     do {
                         __builtin_amdgcn_s_sleep(1);
                         vv = MR ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (a halo row is written by the neighbour RANK)
-                        if (++spins > kLocalSpins || ((spins & 255) == 0 && (__hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || (MR && __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0)))) { s_abort = 1; break; }
+                        if (++spins > kLocalSpins || ((spins & 255) == 0 && (__hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || (MR && __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0)))) { CGP_ABORT = 1; break; }
                     } while (m_tag_of(vv) != wantm);
                     ob[t % kCgpDepth][j] = vv;
                 }
@@ -1053,7 +1066,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                 bool ok = prefetched && gran_tag_of(v[0]) == want && gran_tag_of(v[1]) == want && gran_tag_of(v[2]) == want;
                 while (!ok) {
                     if (spins) __builtin_amdgcn_s_sleep(1);
-                    if (++spins > kLocalSpins || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { s_abort = 1; break; }
+                    if (++spins > kLocalSpins || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0) { CGP_ABORT = 1; break; }
                     ok = true;
 #pragma unroll
                     for (int q = 0; q < kCgpSums; ++q) { v[q] = __hip_atomic_load(base + (size_t)q * kSolveMaxBlocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = ok && gran_tag_of(v[q]) == want; }
@@ -1063,11 +1076,11 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
             double t0, t1; wave_sum8(v, t0, t1);
             wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
             __syncthreads();
-            if (s_abort) { if (tid == 0) raise_abort(); status = 2; break; }
+            if (CGP_ABORT) { if (tid == 0) raise_abort(); status = 2; break; }
             double t[kCgpSums];
 #pragma unroll
             for (int q = 0; q < kCgpSums; ++q) { double s_ = 0; for (int i = 0; i < kSolveThreads / 64; ++i) s_ += red[q * (kSolveThreads / 64) + i]; t[q] = s_; }
-            __syncthreads();
+            if (!kFast) __syncthreads();      // (kFast: stage E has a buffer of its own)
             if (MR) {
                 // ---- C2: this RANK's sums -> every rank's region (workgroup 0), then the R rank granules of the own region in rank order
                 const int pb = k & 1;
@@ -1086,14 +1099,14 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                         for (int q = 0; q < kCgpSums; ++q) { rv[q] = __hip_atomic_load(xr_me + kXrRankGran + (pb * 8 + q) * kXrMaxRanks + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ok = ok && xr_tag_of(rv[q]) == (etag0 | want); }
                         if (!ok) {
                             __builtin_amdgcn_s_sleep(1);
-                            if (++spins > (1 << 24) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { s_abort = 1; break; }
+                            if (++spins > (1 << 24) || __hip_atomic_load(fs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0.0 || __hip_atomic_load(xr_me + kXrAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0.0) { CGP_ABORT = 1; break; }
                         }
                     }
                 }
                 double r0, r1; wave_sum8(rv, r0, r1);
                 wave_sum8_store<kSolveThreads / 64>(r0, r1, red, tid >> 6);
                 __syncthreads();
-                if (s_abort) { if (tid == 0) raise_abort(); status = 2; break; }
+                if (CGP_ABORT) { if (tid == 0) raise_abort(); status = 2; break; }
 #pragma unroll
                 for (int q = 0; q < kCgpSums; ++q) t[q] = red[q * (kSolveThreads / 64)];      // (all <= 32 rank granules sit in wavefront 0)
                 __syncthreads();
@@ -1148,23 +1161,26 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
         // ---- E: publish: m has to be out (drained) before the tagged sums
         double t0, t1; wave_sum8(s, t0, t1);
         if (!TM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
+        double* const redE = kFast ? red2 + ((k + 1) & 1) * (8 * kSolveThreads / 64) : red;
+        wave_sum8_store<kSolveThreads / 64>(t0, t1, redE, tid >> 6);
         __syncthreads();
-        if (TM && s_abort) { if (tid == 0) raise_abort(); status = 2; break; }      // (a gather of this pass gave up)
+        if (TM && CGP_ABORT) { if (tid == 0) raise_abort(); status = 2; break; }      // (a gather of this pass gave up)
+        if (kFast && tid == 0) s_ab3[(k + 5) % 3] = 0;      // the flag of pass k + 2: its readers (pass k - 1) are past this barrier, its raisers two barriers away
         SOLVE_STAMP(5);
         if (tid < kCgpSums) {
             double tot = 0;
-            for (int i = 0; i < kSolveThreads / 64; ++i) tot += red[tid * (kSolveThreads / 64) + i];
+            for (int i = 0; i < kSolveThreads / 64; ++i) tot += redE[tid * (kSolveThreads / 64) + i];
             double* gq = gran + (size_t)((k + 1) & 1) * kSolveGranPlanes * kSolveMaxBlocks + (size_t)tid * kSolveMaxBlocks + lb;
             __hip_atomic_store(gq, gran_tag(tot, (unsigned)(k + 2) & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (MR && !TM && tid == 64) peer_tag((k + 1) & 1, xr_tag(1.0, etag0 | ((unsigned)(k + 2) & 3u)));
-        __syncthreads();
+        if (!kFast) __syncthreads();
         SOLVE_STAMP(6);
         if (force_passes > 0 && k == 8 && tid == 0) fs[16 + lb] = (double)wall_clock64();      // ... published at the end of pass 8 (m_9 and the sums of pass 9)
         if (force_passes > 0 && k == 9 && tid == 0) fs[16 + 1280 + lb] = (double)wall_clock64();  // ... and at the end of pass 9
     }
 #undef SOLVE_STAMP
+#undef CGP_ABORT
     // ---- leave: x of the own rows; the distance update; the outcome for the host and for the gated kernels behind this one
     float xf[R];
 #pragma unroll
