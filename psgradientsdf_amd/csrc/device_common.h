@@ -192,6 +192,29 @@ __device__ __forceinline__ void wave_sum8(const double (&v)[8], double& t0, doub
     }
     t0 = t[0]; t1 = t[1];
 }
+// Four wavefront sums at once: the same reduce-scatter with half the values -- and, value for value, the SAME additions in the same order as wave_sum8
+// computes for its values 0..3 (pairs lane^1, lane^2, then row_ror 4 / 8 and the two cross-row shuffles): the same bits for 31 instead of 66 instructions.
+// Afterwards every lane holds the total of value  2 (lane & 1) + ((lane >> 1) & 1).
+__device__ __forceinline__ double wave_sum4(const double (&v)[4]) {
+    const int lane = threadIdx.x & 63;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    double u[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const double keep = b0 ? v[2 + j] : v[j], give = b0 ? v[j] : v[2 + j]; u[j] = keep + dpp_get<0xB1>(give); }   // quad_perm [1,0,3,2]
+    const double keep = b1 ? u[1] : u[0], give = b1 ? u[0] : u[1];
+    double t = keep + dpp_get<0x4E>(give);                                                                                                     // quad_perm [2,3,0,1]
+    t += dpp_get<0x124>(t);      // row_ror:4
+    t += dpp_get<0x128>(t);      // row_ror:8
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    return t;
+}
+// lanes 0..3 of wavefront w file the four totals under red[value * NW + w] (the layout of wave_sum8_store)
+template <int NW>
+__device__ __forceinline__ void wave_sum4_store(double t, double* red, int w) {
+    const int lane = threadIdx.x & 63;
+    if (lane < 4) red[(2 * (lane & 1) + ((lane >> 1) & 1)) * NW + w] = t;
+}
 // lanes 0..3 of wavefront w file the eight totals under red[value * NW + w]
 template <int NW>
 __device__ __forceinline__ void wave_sum8_store(double t0, double t1, double* red, int w) {

@@ -1073,8 +1073,7 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                 }
             };
             if (tid < G) poll3(gp + tid, (a.pcg_xcd_local & 2) != 0);
-            double t0, t1; wave_sum8(v, t0, t1);
-            wave_sum8_store<kSolveThreads / 64>(t0, t1, red, tid >> 6);
+            { const double v4[4] = {v[0], v[1], v[2], 0.0}; wave_sum4_store<kSolveThreads / 64>(wave_sum4(v4), red, tid >> 6); }      // (three sums: the four-value reduce-scatter, the same bits as wave_sum8's)
             __syncthreads();
             if (CGP_ABORT) { if (tid == 0) raise_abort(); status = 2; break; }
             double t[kCgpSums];
@@ -1159,10 +1158,11 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
         }
         SOLVE_STAMP(4);
         // ---- E: publish: m has to be out (drained) before the tagged sums
-        double t0, t1; wave_sum8(s, t0, t1);
+        const double s4[4] = {s[0], s[1], s[2], 0.0};
+        const double tE = wave_sum4(s4);
         if (!TM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         double* const redE = kFast ? red2 + ((k + 1) & 1) * (8 * kSolveThreads / 64) : red;
-        wave_sum8_store<kSolveThreads / 64>(t0, t1, redE, tid >> 6);
+        wave_sum4_store<kSolveThreads / 64>(tE, redE, tid >> 6);
         __syncthreads();
         if (TM && CGP_ABORT) { if (tid == 0) raise_abort(); status = 2; break; }      // (a gather of this pass gave up)
         if (kFast && tid == 0) s_ab3[(k + 5) % 3] = 0;      // the flag of pass k + 2: its readers (pass k - 1) are past this barrier, its raisers two barriers away

@@ -1,0 +1,18 @@
+import os, sys, json
+sys.path.insert(0, os.getcwd())
+from psgradientsdf_amd import capi, synth
+sc = synth.make_scene(N=256, F=50, W=640, H=480, model="SH1")
+st = capi.default_settings(sc.model_id)
+out = {}
+for lib in sys.argv[1:]:
+    os.environ["PSGSDF_ENGINE_LIB"] = os.path.abspath(lib)
+    import importlib; importlib.reload(capi)
+    eng = capi.load_engine(sc, sc.K, st, 0); eng.load_scene(sc); eng.init_albedo(); eng.normalize_weights()
+    r = {}
+    for rep in range(3):
+        for p in (16, 48):
+            ms, shape, _ = eng.debug_time_pcg_solve(passes=p, reps=10)
+            r.setdefault(p, []).append(ms)
+    out[lib] = {"per_pass_us": [round(1e3 * (b - a) / 32, 3) for a, b in zip(r[16], r[48])], "ms16": [round(x, 4) for x in r[16]]}
+    eng.close()
+print(json.dumps(out))
