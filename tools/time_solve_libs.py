@@ -1,3 +1,6 @@
+"""Time per pass of the persistent distance solve for several BUILDS of the engine (forced 16 / 48 passes, psgsdf_debug_time_pcg_solve), alternating:
+    python tools/time_solve_libs.py libA.so libB.so ...      -> one JSON line {lib: {per_pass_us: [...], ms16: [...]}}
+Used for the timing ablations of profiles/r06_notes.md section 5.7 (a build whose sums are wrong still times correctly: the passes are forced)."""
 import os, sys, json
 sys.path.insert(0, os.getcwd())
 from psgradientsdf_amd import capi, synth
