@@ -53,6 +53,7 @@ typedef float obs_acc_t;
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
+typedef float f2_t __attribute__((ext_vector_type(2)));      // two floats in an aligned register pair: a * b + c on them is ONE v_pk_fma_f32 (the scalar factor of a product is broadcast)
 __device__ __forceinline__ float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 __device__ __forceinline__ float norm3(const float* a) { return sqrtf(dot3(a, a)); }
 // Eigen normalized(): z>0 ? v/sqrt(z) : v

@@ -3,6 +3,10 @@
 // Shared device helpers: device_common.h; the launchers are declared in engine.h.
 #include "device_common.h"
 
+#ifndef PSG_DIST_PK
+#define PSG_DIST_PK 1      // (development: 0 = the scalar form of the SH models' Jacobian rows and block accumulation in k_sweep_dist)
+#endif
+
 namespace psg {
 
 // ------------------------------------------------------------------------------------------
@@ -66,6 +70,16 @@ __global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      //
         for (int i = 0; i < 10; ++i) B[i] = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) g[i] = 0;
+        // SH models, packed form (round 6): the four stencil slots travel as two pairs -- the rows' three basis vectors (S, T, Z below), the Jacobian rows and the
+        // block's accumulators are 2-vectors, so the multiply-adds issue as v_pk_fma_f32 (two slots per instruction, the scalar factor broadcast).  The same
+        // products and sums as the scalar form, entry for entry.
+        constexpr bool kPk = !LED && PSG_DIST_PK && !(PSG_STRICT & 24);
+        f2_t dxp[3][2], dnp[3][2];      // [component][slot pair]: {slot 2h, slot 2h + 1}
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { dxp[k][h] = f2_t{dx[2 * h][k], dx[2 * h + 1][k]}; dnp[k][h] = f2_t{dn[2 * h][k], dn[2 * h + 1][k]}; }
+        f2_t B01 = {0.f, 0.f}, B23 = {0.f, 0.f}, B1x = {0.f, 0.f}, B2x = {0.f, 0.f}, g01 = {0.f, 0.f}, g23 = {0.f, 0.f}; float B11 = 0.f, B33 = 0.f;      // B(0,0..1), B(0,2..3), B(1,2..3), B(2,2..3); B(1,1), B(3,3)
         FOR_EACH_VISIBLE_FRAME(b, j, a.F, f) {
             const FrameP& fp = frame_at(sf, f);
             Proj pr = project(v.xs, fp, a.cam);
@@ -122,6 +136,40 @@ __global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      //
                 }
             }
 #else
+            bool done_pk = false;
+            if constexpr (kPk) {
+                done_pk = true;
+                float U[3], V[3]; pi_rows_world(pi_rows(a.cam, pr), fp.R, U, V);
+                float lc[3] = {fp.l[1], fp.l[2], fp.l[3]};      // l . dSH/dn (SH2: regrouped as in the scalar form below)
+                if (NB == 9) {
+                    const float* nh = v.nfd;
+                    lc[0] = (fp.l[1] + fp.l[4] * nh[1]) + (fp.l[5] * nh[2] + 2 * nh[0] * (fp.l[7] + fp.l[8]));
+                    lc[1] = (fp.l[2] + fp.l[4] * nh[0]) + (fp.l[6] * nh[2] - 2 * nh[1] * fp.l[7]);
+                    lc[2] = (fp.l[3] + fp.l[5] * nh[0]) + (fp.l[6] * nh[1] - 2 * nh[2] * fp.l[8]);
+                }
+                f2_t S2[2], T2[2], Z2[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    S2[h] = (U[0] * dxp[0][h] + U[1] * dxp[1][h]) + U[2] * dxp[2][h];
+                    T2[h] = (V[0] * dxp[0][h] + V[1] * dxp[1][h]) + V[2] * dxp[2][h];
+                    Z2[h] = (lc[0] * dnp[0][h] + lc[1] * dnp[1][h]) + lc[2] * dnp[2][h];
+                }
+                float l = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    f2_t J0 = gu[ch] * S2[0] + gv[ch] * T2[0], J1 = gu[ch] * S2[1] + gv[ch] * T2[1];
+                    J0 = J0 - v.rho[ch] * Z2[0]; J1 = J1 - v.rho[ch] * Z2[1];
+                    const float r = I[ch] - ren[ch]; float w = robust_weight<LOSS>(a.rob, r);
+                    l += robust_loss<LOSS>(a.rob, r);
+                    w = pj.ok ? w : 0.f;                      // the residual counts for the energy, but the row has no Jacobian
+                    const f2_t jw0 = J0 * w, jw1 = J1 * w;
+                    B01 += jw0.x * J0; B23 += jw0.x * J1; B1x += jw0.y * J1; B2x += jw1.x * J1;
+                    B11 += jw0.y * J0.y; B33 += jw1.y * J1.y;
+                    g01 += jw0 * r; g23 += jw1 * r;
+                }
+                Ef += (obs_acc_t)l; nobs_i += 1;
+            }
+            if (!done_pk) {
             float U[3], V[3]; pi_rows_world(pi_rows(a.cam, pr), fp.R, U, V);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                         // dI_q = image_grad pi_grad R^T dx_q, contracted from the right (device_common.h)
@@ -185,8 +233,13 @@ __global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      //
                 }
             }
             Ef += (obs_acc_t)l; nobs_i += 1;
+            }
         }
         E = (double)Ef; nobs = (double)nobs_i;
+        if (kPk) {      // (B / g were zero: exact copies)
+            B[0] += (obs_acc_t)B01.x; B[1] += (obs_acc_t)B01.y; B[2] += (obs_acc_t)B23.x; B[3] += (obs_acc_t)B23.y; B[4] += (obs_acc_t)B11; B[5] += (obs_acc_t)B1x.x; B[6] += (obs_acc_t)B1x.y;
+            B[7] += (obs_acc_t)B2x.x; B[8] += (obs_acc_t)B2x.y; B[9] += (obs_acc_t)B33; g[0] += (obs_acc_t)g01.x; g[1] += (obs_acc_t)g01.y; g[2] += (obs_acc_t)g23.x; g[3] += (obs_acc_t)g23.y;
+        }
         if (a.normal_reg) {   // Eikonal row, Optimizer.cpp:196-218 + residual :509
             float n_d[3] = {-vs_inv * dir[0], -vs_inv * dir[1], -vs_inv * dir[2]};
             float Jr[4];
