@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      //
         // SH models, packed form (round 6): the four stencil slots travel as two pairs -- the rows' three basis vectors (S, T, Z below), the Jacobian rows and the
         // block's accumulators are 2-vectors, so the multiply-adds issue as v_pk_fma_f32 (two slots per instruction, the scalar factor broadcast).  The same
         // products and sums as the scalar form, entry for entry.
-        constexpr bool kPk = !LED && PSG_DIST_PK && !(PSG_STRICT & 24);
+        constexpr bool kPk = PSG_DIST_PK && !(PSG_STRICT & 24);
         f2_t dxp[3][2], dnp[3][2];      // [component][slot pair]: {slot 2h, slot 2h + 1}
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      //
                 done_pk = true;
                 float U[3], V[3]; pi_rows_world(pi_rows(a.cam, pr), fp.R, U, V);
                 float lc[3] = {fp.l[1], fp.l[2], fp.l[3]};      // l . dSH/dn (SH2: regrouped as in the scalar form below)
-                if (NB == 9) {
+                if (!LED && NB == 9) {
                     const float* nh = v.nfd;
                     lc[0] = (fp.l[1] + fp.l[4] * nh[1]) + (fp.l[5] * nh[2] + 2 * nh[0] * (fp.l[7] + fp.l[8]));
                     lc[1] = (fp.l[2] + fp.l[4] * nh[0]) + (fp.l[6] * nh[2] - 2 * nh[1] * fp.l[7]);
@@ -152,13 +152,30 @@ __global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      //
                 for (int h = 0; h < 2; ++h) {
                     S2[h] = (U[0] * dxp[0][h] + U[1] * dxp[1][h]) + U[2] * dxp[2][h];
                     T2[h] = (V[0] * dxp[0][h] + V[1] * dxp[1][h]) + V[2] * dxp[2][h];
-                    Z2[h] = (lc[0] * dnp[0][h] + lc[1] * dnp[1][h]) + lc[2] * dnp[2][h];
+                    if (!LED) Z2[h] = (lc[0] * dnp[0][h] + lc[1] * dnp[1][h]) + lc[2] * dnp[2][h];
+                }
+                if (LED) {      // the fall-off term dm_q of the scalar form below (LedOptimizerJa.cpp:157-186), two slots at a time; Z = -dm so that J_c = gu_c S + gv_c T - (rho_c l_c) Z
+                    float Rp[3]; mul3(fp.R, pr.p, Rp);
+                    const float pn = norm3(pr.p); const double pd = (double)pn;
+                    const float radius = (float)(pd * pd * pd), p5 = (float)(pd * pd * pd * pd * pd);
+                    const float nRp = dot3(v.nfd, Rp);
+                    const float y5 = 1.0f / p5, y3 = 1.0f / radius;
+                    auto div2 = [](f2_t a2, float b, float y) { const f2_t q0 = a2 * y; return __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, f2_t{b, b}, a2), f2_t{y, y}, q0); };      // div_by on a pair: the same bits
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f2_t d1 = (dnp[0][h] * Rp[0] + dnp[1][h] * Rp[1]) + dnp[2][h] * Rp[2];
+                        const f2_t d2 = (v.nfd[0] * dxp[0][h] + v.nfd[1] * dxp[1][h]) + v.nfd[2] * dxp[2][h];
+                        const f2_t d3 = (Rp[0] * dxp[0][h] + Rp[1] * dxp[1][h]) + Rp[2] * dxp[2][h];
+                        const f2_t dm2 = div2(-3 * d3, p5, y5);
+                        Z2[h] = -(div2(d1 + d2, radius, y3) + dm2 * nRp);
+                    }
                 }
                 float l = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     f2_t J0 = gu[ch] * S2[0] + gv[ch] * T2[0], J1 = gu[ch] * S2[1] + gv[ch] * T2[1];
-                    J0 = J0 - v.rho[ch] * Z2[0]; J1 = J1 - v.rho[ch] * Z2[1];
+                    const float zc = LED ? v.rho[ch] * fp.l[ch] : v.rho[ch];
+                    J0 = J0 - zc * Z2[0]; J1 = J1 - zc * Z2[1];
                     const float r = I[ch] - ren[ch]; float w = robust_weight<LOSS>(a.rob, r);
                     l += robust_loss<LOSS>(a.rob, r);
                     w = pj.ok ? w : 0.f;                      // the residual counts for the energy, but the row has no Jacobian
