@@ -88,54 +88,6 @@ __global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      //
             const ProjJ pj = project_jac(pr, a.cam);      // distJacobian projects again, with its own in-image test (PsOptimizerJa.cpp:180-190)
             sample<true, IMG>(a.im, f, a.cam, pr.m, pr.n, pj.mj, pj.nj, I, gu, gv);
             rendered<MODEL>(fp, pr, v.nfd, shfd, v.rho, ren);
-            float J[4][3];
-#if PSG_STRICT & 16
-            {   // the reference's order (PsOptimizerJa.cpp:78-100,212-289 / LedOptimizerJa.cpp:117-218; oracle dist_jacobian): G = image_grad(3x2) pi_grad(2x3) with its structural
-                // zeros, then G R^T, then (G R^T) dx_q; the shading terms per channel and stencil slot
-                const PiRows pi = pi_rows(a.cam, pr);
-                float G[9], GRt[9];
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) { G[ch * 3 + 0] = gu[ch] * pi.p00 + gv[ch] * 0.0f; G[ch * 3 + 1] = gu[ch] * 0.0f + gv[ch] * pi.p11; G[ch * 3 + 2] = gu[ch] * pi.p02 + gv[ch] * pi.p12; }
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) GRt[ch * 3 + k] = (G[ch * 3 + 0] * fp.R[k * 3 + 0] + G[ch * 3 + 1] * fp.R[k * 3 + 1]) + G[ch * 3 + 2] * fp.R[k * 3 + 2];
-                float dI[4][3];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) mul3(GRt, dx[q], dI[q]);
-                if (!LED && NB != 9) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) { const float dr[3] = {v.rho[ch] * fp.l[1], v.rho[ch] * fp.l[2], v.rho[ch] * fp.l[3]}; J[q][ch] = dI[q][ch] - dot3(dr, dn[q]); }
-                } else if (!LED) {
-                    const float* nh = v.nfd;
-                    const float D[3][9] = {{0, 1, 0, 0, nh[1], nh[2], 0, 2 * nh[0], 2 * nh[0]}, {0, 0, 1, 0, nh[0], 0, nh[2], -2 * nh[1], 0}, {0, 0, 0, 1, 0, nh[0], nh[1], 0, -2 * nh[2]}};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float dsh[9];
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) dsh[i] = (D[0][i] * dn[q][0] + D[1][i] * dn[q][1]) + D[2][i] * dn[q][2];
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) { float sacc = 0; for (int i = 0; i < 9; ++i) sacc += (v.rho[ch] * fp.l[i]) * dsh[i]; J[q][ch] = dI[q][ch] - sacc; }
-                    }
-                } else {
-                    float Rp[3]; mul3(fp.R, pr.p, Rp);
-                    const float pn = norm3(pr.p); const double pd = (double)pn;
-                    const float radius = (float)(pd * pd * pd), p5 = (float)(pd * pd * pd * pd * pd);
-                    const float nRp = dot3(v.nfd, Rp);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float dm = dot3(dn[q], Rp) + dot3(v.nfd, dx[q]);
-                        float tmp3[3]; mulT3(fp.R, dx[q], tmp3);
-                        const float dm2 = -3 * dot3(pr.p, tmp3) / p5;
-                        dm = dm / radius + dm2 * nRp;
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) J[q][ch] = dI[q][ch] + (v.rho[ch] * fp.l[ch]) * dm;
-                    }
-                }
-            }
-#else
             bool done_pk = false;
             if constexpr (kPk) {
                 done_pk = true;
@@ -187,6 +139,54 @@ __global__ void __launch_bounds__(kBlock, 4) k_sweep_dist(SweepArgs a) {      //
                 Ef += (obs_acc_t)l; nobs_i += 1;
             }
             if (!done_pk) {
+            float J[4][3];
+#if PSG_STRICT & 16
+            {   // the reference's order (PsOptimizerJa.cpp:78-100,212-289 / LedOptimizerJa.cpp:117-218; oracle dist_jacobian): G = image_grad(3x2) pi_grad(2x3) with its structural
+                // zeros, then G R^T, then (G R^T) dx_q; the shading terms per channel and stencil slot
+                const PiRows pi = pi_rows(a.cam, pr);
+                float G[9], GRt[9];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) { G[ch * 3 + 0] = gu[ch] * pi.p00 + gv[ch] * 0.0f; G[ch * 3 + 1] = gu[ch] * 0.0f + gv[ch] * pi.p11; G[ch * 3 + 2] = gu[ch] * pi.p02 + gv[ch] * pi.p12; }
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) GRt[ch * 3 + k] = (G[ch * 3 + 0] * fp.R[k * 3 + 0] + G[ch * 3 + 1] * fp.R[k * 3 + 1]) + G[ch * 3 + 2] * fp.R[k * 3 + 2];
+                float dI[4][3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mul3(GRt, dx[q], dI[q]);
+                if (!LED && NB != 9) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) { const float dr[3] = {v.rho[ch] * fp.l[1], v.rho[ch] * fp.l[2], v.rho[ch] * fp.l[3]}; J[q][ch] = dI[q][ch] - dot3(dr, dn[q]); }
+                } else if (!LED) {
+                    const float* nh = v.nfd;
+                    const float D[3][9] = {{0, 1, 0, 0, nh[1], nh[2], 0, 2 * nh[0], 2 * nh[0]}, {0, 0, 1, 0, nh[0], 0, nh[2], -2 * nh[1], 0}, {0, 0, 0, 1, 0, nh[0], nh[1], 0, -2 * nh[2]}};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float dsh[9];
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) dsh[i] = (D[0][i] * dn[q][0] + D[1][i] * dn[q][1]) + D[2][i] * dn[q][2];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) { float sacc = 0; for (int i = 0; i < 9; ++i) sacc += (v.rho[ch] * fp.l[i]) * dsh[i]; J[q][ch] = dI[q][ch] - sacc; }
+                    }
+                } else {
+                    float Rp[3]; mul3(fp.R, pr.p, Rp);
+                    const float pn = norm3(pr.p); const double pd = (double)pn;
+                    const float radius = (float)(pd * pd * pd), p5 = (float)(pd * pd * pd * pd * pd);
+                    const float nRp = dot3(v.nfd, Rp);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float dm = dot3(dn[q], Rp) + dot3(v.nfd, dx[q]);
+                        float tmp3[3]; mulT3(fp.R, dx[q], tmp3);
+                        const float dm2 = -3 * dot3(pr.p, tmp3) / p5;
+                        dm = dm / radius + dm2 * nRp;
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) J[q][ch] = dI[q][ch] + (v.rho[ch] * fp.l[ch]) * dm;
+                    }
+                }
+            }
+#else
             float U[3], V[3]; pi_rows_world(pi_rows(a.cam, pr), fp.R, U, V);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                         // dI_q = image_grad pi_grad R^T dx_q, contracted from the right (device_common.h)
