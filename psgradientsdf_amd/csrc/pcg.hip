@@ -839,15 +839,16 @@ template <int R, bool MR, bool TM = false>
 __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, double* fs, double* gran, int rows_per_wg, int kmax, double* mb, unsigned long long mb_key, int force_passes, XrArgs xr) {
     __shared__ double red[8 * kSolveThreads / 64];
     __shared__ int s_abort;
-    // kFast (single rank, self-validating values: the production kernel): TWO workgroup barriers per pass instead of five (round 6: 7.05 -> 6.5 us per
+    // kFast (self-validating values: the production kernels): TWO workgroup barriers per pass instead of five (round 6: 7.05 -> 6.5 us per
     // pass).  What is left is one barrier per cross-wavefront sum: in front of stage C's reads of `red` and in front of stage E's reads of `red2`.  The sums
     // of C and E meet in buffers of their own, E's alternating by pass parity -- so neither the barrier between C's reads and E's writes nor the one behind
     // E's reads is needed: whoever writes a buffer again is two barriers further on than its last reader.  The 'a wait gave up' flag rotates through three
     // words (pass mod 3): thread 0 clears the word of pass k + 2 behind stage E's barrier of pass k -- its last readers passed that barrier with it, its next
     // raisers are two barriers away -- so the barrier that only published the cleared flag at the top of a pass goes too.  Every read of a pass's word lies
     // behind a barrier of that pass and every raise in front of it: all threads of the workgroup take the same decision.
-    constexpr bool kFast = TM && !MR;
+    constexpr bool kFast = TM;      // (multi-rank too: its stage C2 -- the ranks' sums -- gets a third buffer and keeps the one barrier in front of its reads: three per pass instead of seven)
     __shared__ double red2[kFast ? 2 * 8 * kSolveThreads / 64 : 1];
+    __shared__ double red3[(kFast && MR) ? 8 * kSolveThreads / 64 : 1];
     __shared__ int s_ab3[3];
 #define CGP_ABORT (*(kFast ? &s_ab3[(k + 3) % 3] : &s_abort))
     __shared__ int s_foreign;
@@ -1102,13 +1103,14 @@ __global__ void __launch_bounds__(kSolveThreads, 2) k_cgp_solve(SweepArgs a, dou
                         }
                     }
                 }
+                double* const redR = kFast ? red3 : red;
                 double r0, r1; wave_sum8(rv, r0, r1);
-                wave_sum8_store<kSolveThreads / 64>(r0, r1, red, tid >> 6);
+                wave_sum8_store<kSolveThreads / 64>(r0, r1, redR, tid >> 6);
                 __syncthreads();
                 if (CGP_ABORT) { if (tid == 0) raise_abort(); status = 2; break; }
 #pragma unroll
-                for (int q = 0; q < kCgpSums; ++q) t[q] = red[q * (kSolveThreads / 64)];      // (all <= 32 rank granules sit in wavefront 0)
-                __syncthreads();
+                for (int q = 0; q < kCgpSums; ++q) t[q] = redR[q * (kSolveThreads / 64)];      // (all <= 32 rank granules sit in wavefront 0)
+                if (!kFast) __syncthreads();
             }
             if (k == 0) { rhsNorm2 = (float)t[2]; thr = pcg_threshold(rhsNorm2); if (lb == 0 && tid == 0) fs[0] = t[2]; }
             rr_cur = (float)t[2];
