@@ -49,6 +49,17 @@ def test_host_side_knobs_are_bitwise_neutral(built, model):
         assert got == ref, (env, got, ref)
 
 
+def test_per_pass_solve_launch_shapes(built):
+    """The per-pass distance solve (bands beyond the persistent kernel's cap, fall-backs) over several trips of a small grid, on XCD-contiguous logical
+    workgroup ids (round 6, PSGSDF_XCD_MAP bit 7) and on physical ones: every shape covers every row once -- only the order of the partial sums differs."""
+    ref = run("SH1", {"PSGSDF_PCG_PERSIST": "0"})
+    for env in ({"PSGSDF_PCG_BLOCKS": "7"}, {"PSGSDF_PCG_BLOCKS": "24"}, {"PSGSDF_PCG_BLOCKS": "24", "PSGSDF_XCD_MAP": "35"}, {"PSGSDF_PCG_BLOCKS": "61"}):
+        got = run("SH1", dict(env, PSGSDF_PCG_PERSIST="0"))
+        assert all(abs(a - b) <= 1 for a, b in zip(got["cg"], ref["cg"])), (env, got["cg"], ref["cg"])
+        assert all(abs(a - b) <= 2e-5 * abs(b) for a, b in zip(got["e"], ref["e"])), (env, got["e"], ref["e"])
+        assert abs(got["dsum"] - ref["dsum"]) <= 1e-5 * ref["dsum"]
+
+
 def test_pcg_launch_shape_only_changes_rounding(built):
     ref = run("SH1", {})
     for env in ({"PSGSDF_PCG_ROWS": "2", "PSGSDF_PCG_BLOCKS": "7"}, {"PSGSDF_PCG_ROWS": "1", "PSGSDF_PCG_BLOCKS": "5"}, {"PSGSDF_PCG_ROWS": "2", "PSGSDF_PCG_BLOCKS": "512"},
