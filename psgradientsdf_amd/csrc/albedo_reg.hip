@@ -222,6 +222,93 @@ __global__ void __launch_bounds__(kBlock) k_areg_cg_dir(SweepArgs a, float beta)
 void launch_areg_cg_dir(const SweepArgs& a, float beta, hipStream_t s) {
     if (a.row1 > a.row0) hipLaunchKernelGGL(k_areg_cg_dir, dim3((a.row1 - a.row0 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a, beta);
 }
+// ---- device-driven CG (round 6; single rank).  The four kernels of an iteration as above, but alpha, beta and the stop test are derived on the device:
+// every workgroup sums the previous kernel's per-workgroup partials in block_total's fixed order (the order of the host's read-backs: the same bits as the
+// host-driven loop) and the chain r.z_old -> r.z_new travels through ar.cgs[3 + parity].  Once |r|^2 < threshold the flag ar.cgs[0] turns the rest of an
+// enqueued chunk of iterations into no-ops; the host looks at ar.cgs once per chunk (loop.hip albedo_reg_solve).
+__global__ void __launch_bounds__(kBlock) k_areg_jx_d(SweepArgs a) {
+    if (a.ar.cgs[0] != 0.0) return;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.row1) return;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) a.ar.t[(size_t)ch * a.b.Spad + j] = areg_jrow(a, a.ar.p, j, ch);
+}
+__global__ void __launch_bounds__(kBlock) k_areg_jt_d(SweepArgs a) {
+    __shared__ double red[kBlock / 64];
+    const Band& b = a.b; const AlbedoReg& ar = a.ar;
+    if (ar.cgs[0] != 0.0) return;
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    double pq = 0;
+    if (j < a.row1) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const size_t u = (size_t)ch * b.Spad + j;
+            float v = b.aH[u] * ar.p[u] + ar.weight * areg_jtcol<false>(a, ar.t, j, ch);
+            if (a.damping != 0.0f) v += (a.damping * ar.diag0[u]) * ar.p[u];
+            ar.q[u] = v; pq += (double)ar.p[u] * (double)v;
+        }
+    }
+    block_part_store(pq, PART(a, SC_AUX0), red);
+}
+__global__ void __launch_bounds__(kBlock) k_areg_update_d(SweepArgs a, int i, int nblk) {
+    __shared__ double red[kBlock / 64];
+    const Band& b = a.b; const AlbedoReg& ar = a.ar;
+    if (ar.cgs[0] != 0.0) return;
+    const double pq = block_total(PART(a, SC_AUX0), nblk, red);
+    const float alpha = (float)ar.cgs[3 + (i & 1)] / (float)pq;      // alpha = absNew / p.dot(tmp)
+    __syncthreads();      // (red is reused below)
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    double rr = 0, rz = 0;
+    if (j < a.row1) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const size_t u = (size_t)ch * b.Spad + j;
+            ar.x[u] += alpha * ar.p[u];
+            const float r = ar.r[u] - alpha * ar.q[u];
+            ar.r[u] = r;
+            const float dg = ar.diag[u];
+            const float z = (dg != 0.f ? 1.0f / dg : 1.0f) * r;
+            rr += (double)r * (double)r; rz += (double)r * (double)z;
+        }
+    }
+    block_part_store(rr, PART(a, SC_AUX1), red);
+    block_part_store(rz, PART(a, SC_AUX2), red);
+}
+__global__ void __launch_bounds__(kBlock) k_areg_dir_d(SweepArgs a, int i, int nblk, float thr) {
+    __shared__ double red[kBlock / 64];
+    __shared__ double s_stop;
+    const Band& b = a.b; const AlbedoReg& ar = a.ar;
+    if (threadIdx.x == 0) s_stop = ar.cgs[0];      // (workgroup 0 of THIS kernel may raise the flag: every thread of a workgroup must see the same value)
+    __syncthreads();
+    if (s_stop != 0.0) return;
+    const double rr = block_total(PART(a, SC_AUX1), nblk, red);
+    __syncthreads();
+    const double rz = block_total(PART(a, SC_AUX2), nblk, red);
+    const float res2 = (float)rr;
+    if (res2 < thr) {      // Eigen leaves the loop before ++i
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ar.cgs[1] = (double)i; ar.cgs[2] = rr; __threadfence(); ar.cgs[0] = 1.0; }
+        return;
+    }
+    const float beta = (float)rz / (float)ar.cgs[3 + (i & 1)];      // absNew / absOld
+    int j = a.row0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < a.row1) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const size_t u = (size_t)ch * b.Spad + j;
+            const float dg = ar.diag[u];
+            ar.p[u] = (dg != 0.f ? 1.0f / dg : 1.0f) * ar.r[u] + beta * ar.p[u];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ar.cgs[3 + ((i + 1) & 1)] = rz; ar.cgs[1] = (double)(i + 1); ar.cgs[2] = rr; }
+}
+void launch_areg_cg_iteration(const SweepArgs& a, int i, int nblk, float thr, hipStream_t s) {
+    if (a.row1 <= a.row0) return;
+    const dim3 g((a.row1 - a.row0 + kBlock - 1) / kBlock), bl(kBlock);
+    hipLaunchKernelGGL(k_areg_jx_d, g, bl, 0, s, a);
+    hipLaunchKernelGGL(k_areg_jt_d, g, bl, 0, s, a);
+    hipLaunchKernelGGL(k_areg_update_d, g, bl, 0, s, a, i, nblk);
+    hipLaunchKernelGGL(k_areg_dir_d, g, bl, 0, s, a, i, nblk, thr);
+}
 // updateAlbedo (OptimizerAux.cpp:120-150) with a solved step instead of b / H
 __global__ void __launch_bounds__(kBlock) k_apply_albedo_delta(SweepArgs a, const float* __restrict__ delta) {
     __shared__ double red[kBlock / 64];

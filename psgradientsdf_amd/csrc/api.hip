@@ -56,6 +56,7 @@ int psgsdf_create(const psgsdf_grid_desc* grid, const float K[9], const psgsdf_s
     if (const char* e = getenv("PSGSDF_FUSE_PCG_INIT")) c->fuse_pcg_init = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_PERSIST")) c->pcg_persist = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_XCD_LOCAL")) c->pcg_xcd_local = atoi(e) != 0;
+    if (const char* e = getenv("PSGSDF_AREG_DEVICE")) c->areg_device = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_FUSE_ASM")) c->pcg_fuse_asm = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_PIPELINE")) c->pcg_pipeline = atoi(e) != 0;
     if (const char* e = getenv("PSGSDF_PCG_TAGM")) { c->pcg_tagm = atoi(e) != 0; c->pcg_tagm_mr = atoi(e) >= 2; }

@@ -103,6 +103,7 @@ struct AlbedoReg {
     float* J;        // [12][Spad] (slot, channel): d ||grad rho_c|| / d rho_c(slot), slot 0 = the voxel, 1..3 = x/y/z neighbour
     float* res;      // [3][Spad] ||grad rho_c||
     float* rhs; float* diag; float* diag0; float* x; float* r; float* p; float* q; float* t;   // CG over the 3S unknowns, [3][Spad] each (diag0 = undamped diagonal)
+    double* cgs;     // device-driven CG (single rank, loop.hip albedo_reg_solve): [0] 1 = converged, [1] iterations done, [2] |r|^2, [3 + parity] r.z of the last update
     float weight;
 };
 
@@ -261,6 +262,9 @@ void launch_areg_system(const SweepArgs& a, hipStream_t s);                     
 void launch_areg_jx(const SweepArgs& a, const float* p, float* t, hipStream_t s);               // t = Jr p
 void launch_areg_jt(const SweepArgs& a, const float* p, const float* t, float* q, hipStream_t s);   // q = (H_d + damping diag) p + weight Jr^T t; p.q -> SC_AUX0
 void launch_areg_cg_init(const SweepArgs& a, hipStream_t s);                     // x = 0, r = rhs, p = r/diag; |b|^2 -> SC_AUX0, r.z -> SC_AUX1
+// device-driven form (round 6): iteration i of Eigen's CG as four launches whose scalars (alpha, beta, the stop test) every workgroup derives from the
+// previous kernel's per-workgroup partials and ar.cgs -- no read-back inside a chunk of iterations; a converged solve turns the rest of the chunk into no-ops
+void launch_areg_cg_iteration(const SweepArgs& a, int i, int nblk, float thr, hipStream_t s);
 void launch_areg_cg_update(const SweepArgs& a, float alpha, hipStream_t s);      // x += alpha p, r -= alpha q; |r|^2 -> SC_AUX0, r.z -> SC_AUX1
 void launch_areg_cg_dir(const SweepArgs& a, float beta, hipStream_t s);          // p = r/diag + beta p
 void launch_apply_albedo_delta(const SweepArgs& a, const float* delta, hipStream_t s);

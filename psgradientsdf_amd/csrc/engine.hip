@@ -350,14 +350,14 @@ int build_band(psgsdf_ctx* c) {
     }
     if (c->areg_mem) { hipFree(c->areg_mem); c->areg_mem = nullptr; c->ar = AlbedoReg{}; }
     if (c->reg_r != 0.f) {   // "reg albedo": stencil tables + matrix-free CG vectors over the 3S unknowns
-        const size_t planes = 3 + 1 + 9 + 12 + 3 + 8 * 3;
+        const size_t planes = 3 + 1 + 9 + 12 + 3 + 8 * 3 + 1;      // (+ 1: the device-driven CG's scalars)
         HIPCHK(c, hipMalloc(&c->areg_mem, planes * 4 * (size_t)Spad));
         HIPCHK(c, hipMemsetAsync(c->areg_mem, 0, planes * 4 * (size_t)Spad, c->stream));
         char* q = (char*)c->areg_mem;
         auto tk = [&](size_t n) { void* r = q; q += n * 4 * (size_t)Spad; return r; };
         AlbedoReg& ar = c->ar;
         ar.anb = (int*)tk(3); ar.back = (int*)tk(1); ar.anrho = (float*)tk(9); ar.J = (float*)tk(12); ar.res = (float*)tk(3);
-        ar.rhs = (float*)tk(3); ar.diag = (float*)tk(3); ar.diag0 = (float*)tk(3); ar.x = (float*)tk(3); ar.r = (float*)tk(3); ar.p = (float*)tk(3); ar.q = (float*)tk(3); ar.t = (float*)tk(3);
+        ar.rhs = (float*)tk(3); ar.diag = (float*)tk(3); ar.diag0 = (float*)tk(3); ar.x = (float*)tk(3); ar.r = (float*)tk(3); ar.p = (float*)tk(3); ar.q = (float*)tk(3); ar.t = (float*)tk(3); ar.cgs = (double*)tk(1);
         SweepArgs at{}; at.b = b; at.ar = ar;
         launch_areg_tables(c->dense, c->grid, at, c->stream);
         // which side a halo row's stencil takes depends on the plane beyond the halo: its owner knows

@@ -147,6 +147,7 @@ struct psgsdf_ctx {
     long long n_collectives = 0;
     float reg_r = 0.f;                   // "reg albedo" (never normalised, PsOptimizer.cpp:279)
     void* areg_mem = nullptr; AlbedoReg ar{};   // planes of the albedo regulariser, allocated with the band when reg_r != 0
+    bool areg_device = true; int areg_last_iters = 0;      // PSGSDF_AREG_DEVICE=0: the regularised albedo solve driven by the host (two read-backs per CG iteration: what multi-rank contexts run)
     double er_sum = 0;                   // sum over the band of sum_c ||grad rho_c|| at the last evaluation
     FoldReq pending_fold{};              // scalar fold waiting for the next kernel (read_parts_deferred / take_fold)
     bool fuse_pcg_init = true;           // PSGSDF_FUSE_PCG_INIT=0: separate k_cgf_init launch

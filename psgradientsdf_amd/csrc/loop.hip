@@ -232,7 +232,28 @@ int albedo_reg_solve(psgsdf_ctx* c, const SweepArgs& a, int* iters_out, int* ok_
     float res2 = rhsN, absNew = (float)s[1];
     const int maxIters = c->set.cg_max_it > 0 ? c->set.cg_max_it : (int)std::min<long long>(6 * c->S_global, INT_MAX);
     int i = 0;
-    if (res2 >= thr) {
+    if (res2 >= thr && c->areg_device && !slab_mode(c)) {
+        // ---- device-driven (round 6, single rank): chunks of iterations enqueued back to back, alpha / beta / the stop test derived on the device from the
+        // kernels' own partial sums (albedo_reg.hip); ONE look at the five scalars per chunk instead of two read-backs per iteration.  The first chunk is
+        // sized from the previous solve (the count is stable between Gauss-Newton iterations); a converged solve makes the rest of its chunk no-ops.
+        const double init[5] = {0.0, 0.0, (double)rhsN, s[1], 0.0};
+        HIPCHK(c, hipMemcpyAsync(ar.cgs, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // (`init` lives on this stack frame)
+        const int nblk = band_blocks(c);
+        int chunk = std::min(64, std::max(4, c->areg_last_iters + 2));
+        double got[5] = {0, 0, 0, 0, 0};
+        while (i < maxIters) {
+            const int n = std::min(chunk, maxIters - i);
+            for (int q = 0; q < n; ++q) launch_areg_cg_iteration(a, i + q, nblk, thr, c->stream);
+            HIPCHK(c, hipMemcpyAsync(got, ar.cgs, sizeof(got), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            res2 = (float)got[2];
+            if (got[0] != 0.0) { i = (int)got[1]; break; }
+            i += n; chunk = 4;
+        }
+        if (!(res2 == res2)) return fail(c, PSGSDF_ERR_DEVICE, "the regularised albedo solve produced NaN");
+        c->areg_last_iters = i;
+    } else if (res2 >= thr) {
         while (i < maxIters) {
             if ((rc = comm_halo(c, ar.p, 3, 1))) return rc;
             launch_areg_jx(a, ar.p, ar.t, c->stream);

@@ -18,7 +18,8 @@ sys.path.insert(0, %r)
 import numpy as np
 from psgradientsdf_amd import capi, synth
 sc = synth.make_scene(N=64, F=8, W=160, H=120, model=sys.argv[1])
-st = capi.default_settings(sc.model_id)
+import os
+st = capi.default_settings(sc.model_id, reg_weight_rho=float(os.environ.get('PSGSDF_TEST_REG_RHO', '0')))
 eng = capi.load_engine(sc, sc.K, st, 0); eng.load_scene(sc); eng.init_albedo(); eng.normalize_weights()
 recs = eng.iterate(capi.ALL, 3)
 recs2, conv = eng.optimize(capi.ALL) if len(sys.argv) > 2 else ([], False)
@@ -47,6 +48,18 @@ def test_host_side_knobs_are_bitwise_neutral(built, model):
                 {"PSGSDF_FM_SOLVE": "0"}, {"PSGSDF_FM_SOLVE": "0", "PSGSDF_SPECULATE": "0"}):      # FM_SOLVE=0: the per-frame light / pose solves as kernels of their own instead of in the sweeps' last workgroups
         got = run(model, env, full=True)
         assert got == ref, (env, got, ref)
+
+
+@pytest.mark.parametrize("model", ["SH1", "LED"])
+def test_regularised_albedo_solve_device_driven_equals_host_driven(built, model):
+    """`reg albedo` != 0: the CG over the 3S albedo unknowns driven by the device (round 6: chunks of iterations, alpha / beta / the stop test from the kernels'
+    own partial sums) against the host-driven loop (two read-backs per iteration; what multi-rank contexts run): the same sums in the same order, the same
+    float recurrences -- every energy, iteration count and the optimised state to the bit, through psgsdf_optimize too."""
+    ref = run(model, {"PSGSDF_TEST_REG_RHO": "0.02", "PSGSDF_AREG_DEVICE": "0"}, full=True)
+    got = run(model, {"PSGSDF_TEST_REG_RHO": "0.02"}, full=True)
+    assert got == ref, (got, ref)
+    plain = run(model, {}, full=True)
+    assert plain["e"] != ref["e"]      # (the term is on)
 
 
 def test_per_pass_solve_launch_shapes(built):
