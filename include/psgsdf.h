@@ -424,6 +424,7 @@ int psgsdf_debug_sync_stats(psgsdf_ctx* ctx, int64_t out[8]);
  *   PSGSDF_PCG_COL16*, PSGSDF_PCG_ROWS*, PSGSDF_PCG_BLOCKS*                                                                        distance solve
  *   PSGSDF_FRAME_SOLVE (ldlt | eigen: psgsdf_set_frame_solver; the ONE knob that changes results beyond rounding),
  *   PSGSDF_FM_SOLVE, PSGSDF_FM_ROWS*, PSGSDF_IMG_COMPACT, PSGSDF_XCD_MAP, PSGSDF_XCD_STRIPE                                        sweeps
+ *   PSGSDF_AREG_DEVICE (0: the `reg albedo` CG driven by the host, two read-backs per iteration)                                   regularised albedo solve
  *   PSGSDF_XR, PSGSDF_XF, PSGSDF_XS, PSGSDF_XH (0: that exchange through the communicator instead of IPC-mapped memory), PSGSDF_XR_MEM* (fine | uncached |
  *   coarse), PSGSDF_XWAIT_LOG2 (log2 of the polls an in-kernel wait for another rank may take), PSGSDF_CU_MASK (lo:hi)              multi-rank
  *   PSGSDF_WAIT_TIMEOUT_S*, PSGSDF_DESTROY_TIMEOUT_S*, PSGSDF_SOLVE_DUMP*                                                           host waits / diagnostics
